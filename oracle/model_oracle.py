@@ -1,0 +1,298 @@
+"""ORACLE - TEST INFRASTRUCTURE ONLY.  Not part of the product path.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module.  The product (``rdpn6d_amd``) never routes through it.
+
+Plain PyTorch-CPU fp32 restatement of the reference's RGB-D forward / loss path, with the same
+``state_dict`` key names so that one seeded weight set drives the reference, this oracle and the
+HIP path.  Each piece cites the reference code it follows (paths relative to /root/reference):
+
+  backbone   core/gdrn_modeling/models/resnet_backbone.py:264-340 (+ md_pointnet :23-54,
+             torchvision 0.17.1 BasicBlock: conv3x3(s)-BN-ReLU-conv3x3-BN (+downsample) add ReLU)
+  head       core/gdrn_modeling/models/cdpn_rot_head_region.py:83-146 (layers), :185-198 (split)
+  glue       core/gdrn_modeling/models/GDRN.py:196-233, models/model_utils.py:24-42
+  ConvPnPNet core/gdrn_modeling/models/conv_pnp_net.py:41-163
+  rot6d      core/utils/rot_reps.py:9-49
+  pose       core/gdrn_modeling/models/pose_from_pred_centroid_z.py:52-141 (test), :144-227 (train)
+             core/utils/utils.py:39-94 (numpy allo->ego), :208-236 (torch allo->ego)
+             transforms3d 0.4.2 axangles.axangle2mat (restated: third-party, not in /root/reference)
+  losses     core/gdrn_modeling/models/GDRN.py:373-633, losses/pm_loss.py:82-173
+
+Parity is PINNED: tools/oracle/gen_model_golden.py imports the real reference (with stub third-party
+packages) in the build container, runs it on the seeded inputs/weights of rdpn6d_amd/synth.py and
+commits its outputs to tests/golden/model_c1.npz; tests/test_model_oracle.py checks this file
+against those vectors.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------------------- trunk
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, cin, cout, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(cout)
+        self.downsample = downsample
+
+    def forward(self, x):
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        idt = x if self.downsample is None else self.downsample(x)
+        return self.relu(y + idt)
+
+
+class PointFusion(nn.Module):
+    """md_pointnet (resnet_backbone.py:23-54): point-wise MLP over (trunk feature, depth xyz)."""
+
+    def __init__(self, cin=512, ch=(64, 128, 256, 512)):
+        super().__init__()
+        self.xyz_emb = nn.Conv2d(cin, ch[0], 1)
+        self.xb = nn.BatchNorm2d(ch[0])
+        self.conv1 = nn.Conv2d(ch[0] + 3, ch[1], 1)
+        self.conv2 = nn.Conv2d(ch[1], ch[2], 1)
+        self.conv3 = nn.Conv2d(ch[2], ch[3], 1)
+        self.b1 = nn.BatchNorm2d(ch[1])
+        self.b2 = nn.BatchNorm2d(ch[2])
+        self.b3 = nn.BatchNorm2d(ch[3])
+
+    def forward(self, feat, xyz):
+        emb = F.relu(self.xb(self.xyz_emb(feat)))
+        l1 = F.relu(self.b1(self.conv1(torch.cat([xyz, emb], 1))))
+        l2 = F.relu(self.b2(self.conv2(l1)))
+        l3 = self.b3(self.conv3(l2))  # BN, no ReLU (:49)
+        g = l3.amax(dim=(2, 3), keepdim=True).expand_as(l3)  # global max, broadcast (:51-52)
+        return torch.cat([l3, g], 1)
+
+
+class Backbone(nn.Module):
+    LAYERS = {18: (2, 2, 2, 2), 34: (3, 4, 6, 3)}
+
+    def __init__(self, num_layers=34):
+        super().__init__()
+        self.spatial_net = PointFusion(512, (64, 128, 256, 512))
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        cin = 64
+        for li, (planes, nblk) in enumerate(zip((64, 128, 256, 512), self.LAYERS[num_layers])):
+            stride = 1 if li == 0 else 2
+            blocks = []
+            for bi in range(nblk):
+                ds = None
+                if bi == 0 and (stride != 1 or cin != planes):
+                    ds = nn.Sequential(nn.Conv2d(cin, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
+                blocks.append(BasicBlock(cin, planes, stride if bi == 0 else 1, ds))
+                cin = planes
+            setattr(self, f"layer{li + 1}", nn.Sequential(*blocks))
+
+    def forward(self, x):
+        xyz = x[:, 3:]
+        rgb = x[:, :3]
+        r8 = x.shape[-1] // 8
+        xyz = F.interpolate(xyz, (r8, r8), mode="nearest")  # == xyz[:, :, ::8, ::8]
+        y = self.maxpool(self.relu(self.bn1(self.conv1(rgb))))
+        y = self.layer4(self.layer3(self.layer2(self.layer1(y))))
+        y = F.interpolate(y, scale_factor=4, mode="bilinear", align_corners=True)  # UpsamplingBilinear2d
+        return self.spatial_net(y, xyz)
+
+
+# --------------------------------------------------------------------------------------- heads
+class RotHead(nn.Module):
+    def __init__(self, num_regions=32, num_filters=256, num_layers=3, in_channels=1024):
+        super().__init__()
+        f = [nn.ConvTranspose2d(in_channels, num_filters, 3, 2, 1, output_padding=1, bias=False),
+             nn.BatchNorm2d(num_filters), nn.ReLU(inplace=True)]
+        for _ in range(2 * num_layers):
+            f += [nn.Conv2d(num_filters, num_filters, 3, 1, 1, bias=False), nn.BatchNorm2d(num_filters),
+                  nn.ReLU(inplace=True)]
+        f.append(nn.Conv2d(num_filters, 1 + 3 + num_regions + 1, 1, bias=True))
+        self.features = nn.ModuleList(f)
+
+    def forward(self, x):
+        for l in self.features:
+            x = l(x)
+        return x[:, :1], x[:, 1:2], x[:, 2:3], x[:, 3:4], x[:, 4:]  # mask, coor_x, coor_y, coor_z, region
+
+
+class ConvPnP(nn.Module):
+    def __init__(self, n_in=43, featdim=128, rot_dim=6, out_res=64):
+        super().__init__()
+        f = []
+        for i in range(3):
+            f += [nn.Conv2d(n_in if i == 0 else featdim, featdim, 3, 2, 1, bias=False), nn.GroupNorm(32, featdim),
+                  nn.ReLU(inplace=True)]
+        self.features = nn.ModuleList(f)
+        self.fc1 = nn.Linear(featdim * (out_res // 8) ** 2, 1024)
+        self.fc2 = nn.Linear(1024, 256)
+        self.fc_r = nn.Linear(256, rot_dim)
+        self.fc_t = nn.Linear(256, 3)
+        self.act = nn.LeakyReLU(0.1, inplace=True)
+
+    def forward(self, coor_feat, region, mask_attention=None):
+        x = torch.cat([coor_feat, region], 1)
+        if mask_attention is not None:
+            x = x * mask_attention
+        for l in self.features:
+            x = l(x)
+        x = x.flatten(1)
+        x = self.act(self.fc2(self.act(self.fc1(x))))
+        return self.fc_r(x), self.fc_t(x)
+
+
+# --------------------------------------------------------------------------------------- pose
+def rot6d_to_mat(p):
+    x = F.normalize(p[:, 0:3], p=2, dim=1)
+    z = F.normalize(torch.cross(x, p[:, 3:6], dim=1), p=2, dim=1)
+    y = torch.cross(z, x, dim=1)
+    return torch.stack([x, y, z], dim=2)
+
+
+def axangle2mat(axis, angle):
+    """transforms3d.axangles.axangle2mat restated (Rodrigues, normalises the axis)."""
+    x, y, z = axis
+    n = math.sqrt(x * x + y * y + z * z)
+    x, y, z = x / n, y / n, z / n
+    c, s = math.cos(angle), math.sin(angle)
+    C = 1 - c
+    xs, ys, zs = x * s, y * s, z * s
+    xC, yC, zC = x * C, y * C, z * C
+    xyC, yzC, zxC = x * yC, y * zC, z * xC
+    return np.array([[x * xC + c, xyC - zs, zxC + ys], [xyC + zs, y * yC + c, yzC - xs], [zxC - ys, yzC + xs, z * zC + c]])
+
+
+def allo_to_ego_numpy(rot_allo, trans):
+    """core/utils/utils.py:39-94 for src=dst='mat': fp32 inputs, fp64 axis-angle, fp32 result."""
+    rot_allo = np.asarray(rot_allo, dtype=np.float32)
+    trans = np.asarray(trans, dtype=np.float32)
+    cam_ray = np.asarray((0, 0, 1.0))
+    obj_ray = trans.copy() / np.linalg.norm(trans)
+    angle = math.acos(cam_ray.dot(obj_ray))
+    if angle > 0:
+        rot = axangle2mat(np.cross(cam_ray, obj_ray), angle)
+        return np.dot(rot, rot_allo).astype(np.float32)
+    return rot_allo.copy()
+
+
+def site_translation(pred_t, roi_cams, roi_centers, roi_whs, resize_ratios):
+    cx = pred_t[:, 0:1] * roi_whs[:, 0:1] + roi_centers[:, 0:1]
+    cy = pred_t[:, 1:2] * roi_whs[:, 1:2] + roi_centers[:, 1:2]
+    z = pred_t[:, 2:3] * resize_ratios.view(-1, 1)
+    return torch.cat(
+        [z * (cx - roi_cams[:, 0:1, 2]) / roi_cams[:, 0:1, 0], z * (cy - roi_cams[:, 1:2, 2]) / roi_cams[:, 1:2, 1], z], 1
+    )
+
+
+def quat2mat(q):
+    """core/utils/pose_utils.py:323-355 with its default eps=0 (as called from utils.py:232)."""
+    qn = q / q.norm(p=2, dim=1, keepdim=True)
+    w, x, y, z = qn[:, 0], qn[:, 1], qn[:, 2], qn[:, 3]
+    B = q.shape[0]
+    X, Y, Z = x * 2.0, y * 2.0, z * 2.0
+    wX, wY, wZ = w * X, w * Y, w * Z
+    xX, xY, xZ = x * X, x * Y, x * Z
+    yY, yZ, zZ = y * Y, y * Z, z * Z
+    return torch.stack(
+        [1.0 - (yY + zZ), xY - wZ, xZ + wY, xY + wZ, 1.0 - (xX + zZ), yZ - wX, xZ - wY, yZ + wX, 1.0 - (xX + yY)], dim=1
+    ).reshape(B, 3, 3)
+
+
+def allo_to_ego_torch(trans, rot_allo, eps=1e-4):
+    cam_ray = torch.tensor([0, 0, 1.0], dtype=trans.dtype)
+    obj_ray = trans / (trans.norm(dim=1, keepdim=True) + eps)
+    angle = obj_ray[:, 2:3].acos()
+    axis = torch.cross(cam_ray.expand_as(obj_ray), obj_ray, dim=1)
+    axis = axis / (axis.norm(dim=1, keepdim=True) + eps)
+    q = torch.cat([torch.cos(angle / 2), axis * torch.sin(angle / 2)], 1)
+    return torch.matmul(quat2mat(q), rot_allo)
+
+
+# --------------------------------------------------------------------------------------- model
+class GDRNOracle(nn.Module):
+    def __init__(self, num_regions=32, mask_attention="none", out_res=64, num_layers=34):
+        super().__init__()
+        self.backbone = Backbone(num_layers)
+        self.rot_head_net = RotHead(num_regions)
+        self.pnp_net = ConvPnP(11 + num_regions, out_res=out_res)
+        self.mask_attention = mask_attention
+        self.out_res = out_res
+
+    def dense(self, x):
+        return self.rot_head_net(self.backbone(x))
+
+    def glue(self, mask, cx, cy, cz, region, roi_coord_2d, fps):
+        B = mask.shape[0]
+        r = self.out_res
+        coor_feat = torch.cat([cx, cy, cz, roi_coord_2d], 1)
+        prob = F.softmax(region[:, 1:], dim=1)
+        amax = prob.reshape(B, prob.shape[1], -1).argmax(dim=1)  # (B, HW), arg-max ON the softmax output
+        anchors = torch.gather(fps, 1, amax.unsqueeze(2).expand(-1, -1, 3))  # (B,HW,3)
+        anchors = anchors.reshape(B, r, r, 3).permute(0, 3, 1, 2)
+        coor_feat = torch.cat([coor_feat, anchors], 1)
+        att = None
+        if self.mask_attention != "none":
+            mx = mask.reshape(B, -1).max(dim=1)[0].view(B, 1, 1, 1)
+            mn = mask.reshape(B, -1).min(dim=1)[0].view(B, 1, 1, 1)
+            att = (mask - mn) / (mx - mn)
+        return coor_feat, prob, att, amax.reshape(B, r, r)
+
+    def forward(self, x, roi_coord_2d, fps, roi_cams, roi_centers, roi_whs, resize_ratios, train_pose=False):
+        mask, cx, cy, cz, region = self.dense(x)
+        coor_feat, prob, att, amax = self.glue(mask, cx, cy, cz, region, roi_coord_2d, fps)
+        rot6d, pred_t = self.pnp_net(coor_feat, prob, att)
+        rot_allo = rot6d_to_mat(rot6d)
+        trans = site_translation(pred_t, roi_cams, roi_centers, roi_whs, resize_ratios)
+        if train_pose:
+            rot = allo_to_ego_torch(trans, rot_allo, eps=1e-4)
+        else:
+            ra, tn = rot_allo.detach().numpy(), trans.detach().numpy()
+            rot = torch.from_numpy(np.stack([allo_to_ego_numpy(ra[i], tn[i]) for i in range(ra.shape[0])]))
+        return {"rot": rot, "trans": trans, "mask": mask, "coor_x": cx, "coor_y": cy, "coor_z": cz, "region": region,
+                "pred_rot6d": rot6d, "pred_t_": pred_t, "region_argmax": amax}
+
+
+# --------------------------------------------------------------------------------------- losses
+def gdrn_losses(out, gt, roi_extents):
+    """Active losses of the shipped configs (GDRN.py:411-424,452-454,470-483,529-531,552-554;
+    pm_loss.py:102-114 with PM_R_ONLY, PM_NORM_BY_EXTENT, L1, no symmetry)."""
+    mv = gt["roi_mask_visib"]
+    denom = mv.sum().float().clamp(min=1.0)
+    L = {}
+    for i, k in enumerate(("coor_x", "coor_y", "coor_z")):
+        L[f"loss_{k}"] = F.l1_loss(out[k] * mv[:, None], gt["roi_xyz"][:, i:i + 1] * mv[:, None], reduction="sum") / denom
+    L["loss_mask"] = F.l1_loss(out["mask"][:, 0], gt["roi_mask_trunc"], reduction="mean")
+    L["loss_region"] = F.cross_entropy(out["region"] * mv[:, None], gt["roi_region"].long() * mv.long(),
+                                       reduction="sum") / denom
+    L["loss_region_my"] = F.l1_loss(mv, out["region"][:, 0], reduction="mean")
+    pts = gt["roi_points"]
+    w = 1.0 / roi_extents.max(1, keepdim=True)[0]
+    pe = torch.bmm(pts, out["rot"].transpose(1, 2))
+    pg = torch.bmm(pts, gt["ego_rot"].transpose(1, 2))
+    L["loss_PM_R"] = 3 * F.l1_loss(w[:, :, None] * pe, w[:, :, None] * pg, reduction="mean")
+    L["loss_centroid"] = F.l1_loss(out["pred_t_"][:, :2], gt["roi_trans_ratio"][:, :2], reduction="mean")
+    L["loss_z"] = F.l1_loss(out["pred_t_"][:, 2], gt["roi_trans_ratio"][:, 2], reduction="mean")
+    return L
+
+
+def calibrate_bn(model, x):
+    """One train-mode pass of backbone+head with momentum=None so running stats == batch stats."""
+    bns = [m for m in model.modules() if isinstance(m, nn.BatchNorm2d)]
+    for m in bns:
+        m.reset_running_stats()
+        m.momentum = None
+    model.train()
+    with torch.no_grad():
+        model.dense(x)
+    model.eval()
+    for m in bns:
+        m.momentum = 0.1

@@ -1,0 +1,83 @@
+"""The torch-CPU restatement (oracle/model_oracle.py) against golden vectors captured from the
+REAL reference (tools/oracle/gen_model_golden.py).  Tolerances: the reference itself differs by
+2-3e-5 on maps between 1 and 8 threads, so 1e-4 abs is the floor we assert."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import model_oracle
+from rdpn6d_amd import synth
+
+
+@pytest.fixture(scope="module")
+def setup(golden_dir):
+    gold = np.load(os.path.join(golden_dir, "model_c1.npz"))
+    bn = np.load(os.path.join(golden_dir, "bn_stats_c1.npz"))
+    inp = synth.make_inputs(4, seed=0)
+    assert synth.sha256_of([inp[k] for k in sorted(inp)]) == str(gold["sha256_inputs"])
+    m = model_oracle.GDRNOracle(32, "none")
+    sd = synth.make_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=1234)
+    sd.update({k: bn[k] for k in bn.files})
+    assert synth.sha256_of([sd[k] for k in sorted(sd) if not k.endswith("num_batches_tracked")]) == str(gold["sha256_weights"])
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    m.eval()
+    return m, {k: torch.from_numpy(v) for k, v in inp.items()}, gold
+
+
+def _fwd(m, t, att):
+    m.mask_attention = att
+    with torch.no_grad():
+        return m(t["roi_img"], t["roi_coord_2d"], t["fps"], t["roi_cam"], t["roi_center"], t["roi_wh"], t["resize_ratio"])
+
+
+def test_state_dict_has_reference_keys(setup):
+    m = setup[0]
+    keys = list(m.state_dict().keys())
+    assert len(keys) == 305  # SURVEY.md §8b [probe]
+    assert keys[0] == "backbone.spatial_net.xyz_emb.weight"
+    assert "rot_head_net.features.21.bias" in keys and "pnp_net.fc_t.bias" in keys
+    assert sum(p.numel() for p in m.parameters()) == 36403630 or abs(sum(p.numel() for p in m.parameters()) / 1e6 - 36.40363) < 1e-4
+
+
+def test_eval_maps_and_pose(setup):
+    m, t, gold = setup
+    o = _fwd(m, t, "none")
+    for k in ("mask", "coor_x", "coor_y", "coor_z", "region"):
+        assert np.abs(o[k].numpy() - gold["eval_" + k]).max() < 1e-4, k
+    assert (o["region_argmax"].numpy() == gold["eval_region_argmax"]).mean() > 0.9995
+    for att in ("none", "mul"):
+        o = _fwd(m, t, att)
+        R, T = gold[f"eval_{att}_rot"], gold[f"eval_{att}_trans"]
+        assert np.linalg.norm(o["rot"].numpy() - R) / np.linalg.norm(R) < 1e-4
+        assert np.linalg.norm(o["trans"].numpy() - T) / np.linalg.norm(T) < 1e-4
+
+
+def test_backbone_feature(setup):
+    m, t, gold = setup
+    with torch.no_grad():
+        f = m.backbone(t["roi_img"])
+    assert np.abs(f[0, :8].numpy() - gold["backbone_feat_sample0_ch0_8"]).max() < 1e-4
+    assert np.allclose(f.double().sum(dim=(2, 3)).numpy(), gold["backbone_feat_sum"], rtol=1e-5, atol=1e-2)
+
+
+def test_train_losses(setup):
+    m, t, gold = setup
+    gt = synth.make_train_gt(4, {k: v.numpy() for k, v in t.items()})
+    assert synth.sha256_of([gt[k] for k in sorted(gt)]) == str(gold["train_sha256_gt"])
+    tg = {k: torch.from_numpy(v) for k, v in gt.items()}
+    m.mask_attention = "none"
+    m.train()
+    o = m(t["roi_img"], t["roi_coord_2d"], t["fps"], t["roi_cam"], t["roi_center"], t["roi_wh"], t["resize_ratio"],
+          train_pose=True)
+    L = model_oracle.gdrn_losses(o, tg, t["roi_extent"])
+    for k, v in L.items():
+        assert abs(v.item() - float(gold["train_" + k])) < 1e-4 * max(1.0, abs(float(gold["train_" + k]))), k
+    sum(L.values()).backward()
+    named = dict(m.named_parameters())
+    for k in gold.files:
+        if k.startswith("train_gradnorm_"):
+            g = named[k[len("train_gradnorm_"):]].grad.double().norm().item()
+            assert abs(g - float(gold[k])) < 1e-3 * float(gold[k]), k
+    m.eval()
