@@ -1,0 +1,140 @@
+/*
+ * rdpn6d.h - C ABI of librdpn6d_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * RDPN6D hot path.  Plain pointers and sizes only; no torch / C++ types cross this boundary.
+ *
+ * Conventions
+ *   - every `d_*` / activation / weight pointer is a DEVICE pointer (HBM), fp32 unless noted;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); calls are asynchronous;
+ *   - functions returning int return 0 on success, a negative RDPN6D_E* code otherwise and
+ *     leave a message retrievable with rdpn6d_last_error();
+ *   - internal activation layout is NHWC ("pixels x channels", channel counts padded to a
+ *     multiple of 16 with zeros); tensors that cross the reference's Python API are NCHW.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the
+ * reference repository root).
+ */
+#ifndef RDPN6D_H
+#define RDPN6D_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RDPN6D_OK 0
+#define RDPN6D_EINVAL -1  /* bad argument                      */
+#define RDPN6D_EHIP -2    /* HIP runtime error / no GPU        */
+#define RDPN6D_ENOMEM -3
+
+const char* rdpn6d_last_error(void);
+int rdpn6d_version(void);
+/* number of visible HIP devices (0 on a CPU-only box); never throws */
+int rdpn6d_device_count(void);
+
+/* ------------------------------------------------------------------ farthest point sampling
+ * Replaces core/csrc/fps/src/ext.h:1-14 (same two symbols, same signature, HOST pointers,
+ * synchronous).  pts [pn,3] f32 C-contiguous, idxs [sn] i32.  The plain variant draws its start
+ * index like the reference does (srand(time(0)); rand()%pn, farthest_point_sampling.cpp:93-94).
+ * On failure (no GPU) they write -1 into idxs and print to stderr: there is no CPU fallback. */
+void farthest_point_sampling(float* pts, int* idxs, int pn, int sn);
+void farthest_point_sampling_init_center(float* pts, int* idxs, int pn, int sn);
+/* Extra entry points (status code; pinned start; batched device-resident form).
+ * start < 0 : bbox-centre initialisation (== farthest_point_sampling_init_center)
+ * start >= 0: random-start variant with the start index pinned to start % pn            */
+int rdpn6d_fps_host(const float* pts, int* idxs, int pn, int sn, int start);
+/* nobj clouds concatenated in d_pts; cloud o = points [d_offsets[o], d_offsets[o+1]);
+ * d_idxs [nobj, sn]; d_mindist = scratch of d_offsets[nobj] floats.                      */
+int rdpn6d_fps_device(const float* d_pts, const int* d_offsets, int nobj, int max_pn, int sn, int start,
+                      int* d_idxs, float* d_mindist, void* stream);
+
+/* ------------------------------------------------------------------ implicit-GEMM convolution
+ * One kernel family serves every conv / transposed-conv phase / FC layer of
+ * core/gdrn_modeling/models/{resnet_backbone.py:264-340, cdpn_rot_head_region.py:83-138,
+ * conv_pnp_net.py:75-95} (cuDNN / cuBLAS calls in the reference).
+ *   y[pix_out(b,oy,ox), co + n] = act( scale[n] * sum_{t,c} x[b, oy*stride+dy[t], ox*stride+dx[t], ci + c]
+ *                                                         * w[n, t, c] + shift[n] (+ res[...]) )
+ * fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32 (exact fp32).                      */
+typedef struct {
+    const float* x;      /* input, NHWC [B,H,W,in_cs]                                      */
+    const float* w;      /* packed weights [Npad][ntaps][Cin]                             */
+    const float* scale;  /* [Npad] per-output-channel multiplier (folded BN) or NULL = 1   */
+    const float* shift;  /* [Npad] per-output-channel offset (folded BN / bias) or NULL = 0 */
+    const float* res;    /* optional residual, NHWC [B,OH,OW,res_cs], or NULL              */
+    float* y;            /* output, NHWC [B,OH,OW,out_cs]                                  */
+    int B, H, W;         /* input batch / spatial                                          */
+    int Cin;             /* reduction channels (multiple of 16)                            */
+    int in_cs, in_co;    /* input channel stride / first channel (multiples of 4)          */
+    int Ho, Wo;          /* iteration space (outputs per phase)                            */
+    int stride;          /* input step per output step                                     */
+    int ntaps;           /* 1..9                                                           */
+    int dy[9], dx[9];    /* input offset of tap t (pad already folded in; may be negative) */
+    int N, Npad;         /* real / padded output channels                                  */
+    int OH, OW;          /* full output spatial size                                       */
+    int osy, osx, ooy, oox; /* output pixel = (oy*osy+ooy, ox*osx+oox)                    */
+    int out_cs, out_co;  /* output channel stride / first channel                          */
+    int res_cs, res_co;
+    int act;             /* 0 none, 1 ReLU, 2 LeakyReLU(slope)                             */
+    float slope;
+} rdpn6d_conv_desc;
+int rdpn6d_conv2d_f32(const rdpn6d_conv_desc* d, void* stream);
+
+/* ------------------------------------------------------------------ stem & point-wise kernels
+ * conv1 7x7/2 + BN + ReLU on channels 0..2 of the NCHW 6-channel crop (resnet_backbone.py:272,
+ * :304,:321-323).  x NCHW [B,xc,R,R]; w [64][7][7][3]; y NHWC [B,R/2,R/2,64].             */
+int rdpn6d_stem_conv7x7_f32(const float* x, int B, int xc, int R, const float* w, const float* scale,
+                            const float* shift, float* y, void* stream);
+/* MaxPool2d(3,2,1) (resnet_backbone.py:275), NHWC, C multiple of 4 */
+int rdpn6d_maxpool3x3s2_f32(const float* x, int B, int H, int W, int C, float* y, void* stream);
+/* UpsamplingBilinear2d(scale_factor=4) == align_corners=True (resnet_backbone.py:280,:332) */
+int rdpn6d_upsample_bilinear_f32(const float* x, int B, int H, int W, int C, int factor, float* y, void* stream);
+/* F.interpolate(xyz,(R/8,R/8),'nearest') == x[:,3:6,::8,::8] (resnet_backbone.py:304-306),
+ * written into channels [out_co, out_co+3) of an NHWC buffer                              */
+int rdpn6d_xyz_subsample_f32(const float* x, int B, int xc, int R, int step, float* y, int out_cs, int out_co,
+                             void* stream);
+/* adaptive_max_pool2d->(1,1) + broadcast + concat (resnet_backbone.py:51-54): reads channels
+ * [0,C) of buf NHWC [B,HW,cs], writes max over HW into channels [C,2C)                    */
+int rdpn6d_global_max_concat_f32(float* buf, int B, int HW, int C, int cs, void* stream);
+/* GroupNorm(G, C) + ReLU (conv_pnp_net.py:80-82), NHWC in place; eps 1e-5                 */
+int rdpn6d_groupnorm_relu_f32(float* x, int B, int HW, int C, int G, const float* gamma, const float* beta,
+                              void* stream);
+
+/* ------------------------------------------------------------------ dense-map glue
+ * GDRN.forward:196-233 + get_mask_prob (model_utils.py:24-42) + ConvPnPNet input assembly
+ * (conv_pnp_net.py:129-137) in one pass over the head output.
+ *   head NHWC [B,HW,head_cs] with channels [mask | x y z | region bg+K];
+ *   coord2d NCHW [B,5,HW]; fps [B,K,3]
+ *   out_nchw [B,4+K+1,HW]  (the reference's mask/coor_x/coor_y/coor_z/region views)
+ *   pnp_in NHWC [B,HW,pnp_cs] = [x y z | coord2d(5) | anchor(3) | softmax(K) | 0-pad] (* mask attention)
+ *   argmax_out [B,HW] int32 (region index 0..K-1), may be NULL
+ * mask_attention: 0 none, 1 mul (min-max normalised mask, no epsilon as in the reference).  */
+int rdpn6d_dense_glue_f32(const float* head, int head_cs, const float* coord2d, const float* fps, int B, int HW,
+                          int K, int mask_attention, float* minmax_scratch, float* out_nchw, float* pnp_in,
+                          int pnp_cs, int* argmax_out, void* stream);
+
+/* ------------------------------------------------------------------ pose decode
+ * ortho6d_to_mat_batch (core/utils/rot_reps.py:34-49) + pose_from_predictions_test
+ * (models/pose_from_pred_centroid_z.py:52-141) + allocentric_to_egocentric
+ * (core/utils/utils.py:39-94, fp64 axis-angle like the numpy original).
+ *   rt [B,rt_stride] = [rot6d(6) | centroid dx dy | z_rel]; out rot [B,9], trans [B,3]
+ * train_variant != 0 selects pose_from_predictions_train / allo_to_ego_mat_torch (eps 1e-4). */
+int rdpn6d_pose_decode_f32(const float* rt, int rt_stride, const float* roi_cams, const float* roi_centers,
+                           const float* roi_whs, const float* resize_ratios, int B, int is_allo, int train_variant,
+                           float* rot, float* trans, void* stream);
+
+/* ------------------------------------------------------------------ per-crop RANSAC + Kabsch
+ * New capability named by the north star (no reference implementation; replaces the role of
+ * cv2.solvePnPRansac at lib/pysixd/misc.py:170-179 for the RGB-D residual formulation):
+ * correspondences (anchor[region_i], P_i - delta_i) per foreground pixel, one hypothesis per
+ * wavefront, inlier counts on an LDS scoreboard, adaptive stop, Kabsch refit on the inliers.
+ *   out_nchw [B,4+K+1,HW] dense maps; coord2d [B,5,HW] (ch 0..2 = depth xyz / resize_ratio)
+ *   pose_out [B,12] = R row-major | t;   n_inliers [B];   inlier_mask [B,HW] uint8 (may be NULL)
+ * A crop with fewer than 3 usable correspondences gets the sentinel pose -100 (as the reference
+ * does for n<4, gdrn_evaluator.py:391-392). */
+int rdpn6d_ransac_kabsch_f32(const float* out_nchw, const float* coord2d, const float* fps, const float* extents,
+                             const float* resize_ratios, const int* region_argmax, int B, int HW, int K,
+                             float mask_thr, float inlier_thr, int iters, float confidence, unsigned seed,
+                             float* pose_out, int* n_inliers, unsigned char* inlier_mask, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

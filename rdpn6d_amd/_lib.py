@@ -1,0 +1,79 @@
+"""ctypes binding of librdpn6d_hip.so (the C ABI declared in include/rdpn6d.h).
+
+There is deliberately NO fallback: if the library is missing, or a call fails, a RuntimeError is
+raised.  Nothing in this package computes the hot path on the CPU.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librdpn6d_hip.so")
+
+c_float_p = ctypes.c_void_p
+c_int_p = ctypes.c_void_p
+_vp, _i, _f, _u = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_uint
+
+
+class ConvDesc(ctypes.Structure):
+    """Mirror of rdpn6d_conv_desc (include/rdpn6d.h)."""
+
+    _fields_ = [
+        ("x", _vp), ("w", _vp), ("scale", _vp), ("shift", _vp), ("res", _vp), ("y", _vp),
+        ("B", _i), ("H", _i), ("W", _i), ("Cin", _i), ("in_cs", _i), ("in_co", _i), ("Ho", _i), ("Wo", _i),
+        ("stride", _i), ("ntaps", _i), ("dy", _i * 9), ("dx", _i * 9), ("N", _i), ("Npad", _i), ("OH", _i), ("OW", _i),
+        ("osy", _i), ("osx", _i), ("ooy", _i), ("oox", _i), ("out_cs", _i), ("out_co", _i), ("res_cs", _i),
+        ("res_co", _i), ("act", _i), ("slope", _f),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/rdpn6d.h declares
+SIGNATURES = {
+    "rdpn6d_last_error": (ctypes.c_char_p, []),
+    "rdpn6d_version": (_i, []),
+    "rdpn6d_device_count": (_i, []),
+    "farthest_point_sampling": (None, [_vp, _vp, _i, _i]),
+    "farthest_point_sampling_init_center": (None, [_vp, _vp, _i, _i]),
+    "rdpn6d_fps_host": (_i, [_vp, _vp, _i, _i, _i]),
+    "rdpn6d_fps_device": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "rdpn6d_conv2d_f32": (_i, [ctypes.POINTER(ConvDesc), _vp]),
+    "rdpn6d_stem_conv7x7_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "rdpn6d_maxpool3x3s2_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "rdpn6d_upsample_bilinear_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "rdpn6d_xyz_subsample_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
+    "rdpn6d_global_max_concat_f32": (_i, [_vp, _i, _i, _i, _i, _vp]),
+    "rdpn6d_groupnorm_relu_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "rdpn6d_dense_glue_f32": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "rdpn6d_pose_decode_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "rdpn6d_ransac_kabsch_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _f, _u, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build the HIP extension first (python -m rdpn6d_amd.build). "
+                "rdpn6d_amd has no CPU fallback."
+            )
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        try:
+            fn = lib.rdpn6d_conv_force_tile
+            fn.restype, fn.argtypes = None, [_i, _i]
+        except AttributeError:
+            pass
+        _lib = lib
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().rdpn6d_last_error()
+        raise RuntimeError(f"rdpn6d HIP call failed ({what}, rc={rc}): {msg.decode() if msg else '?'}")

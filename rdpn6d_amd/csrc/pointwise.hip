@@ -1,0 +1,537 @@
+// Bandwidth-bound kernels of the RDPN6D forward path (everything that is not a GEMM).
+// All activations are NHWC fp32; loads/stores are 16 bytes per lane wherever the layout allows.
+#include "common.h"
+#include <float.h>
+
+// ------------------------------------------------------------------------------------------------
+// Stem: conv 7x7 stride 2 pad 3 on channels 0..2 of the NCHW crop + folded BN + ReLU -> NHWC 64.
+// (resnet_backbone.py:272,:321-323).  K = 147 is too ragged/small for the MFMA path and the layer
+// is 0.7 % of the FLOPs: a direct LDS-tiled VALU kernel.  Workgroup = 16x16 output pixels; the
+// 37x37x3 input patch and the 147x64 weights sit in LDS; each thread owns one pixel x 64 channels
+// (weights are wave-uniform LDS broadcasts, 16 B per read).
+__global__ __launch_bounds__(256) void stem_conv7x7_kernel(const float* __restrict__ x, int xc, int R,
+                                                           const float* __restrict__ w,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, float* __restrict__ y)
+{
+    constexpr int T = 16, P = 2 * T + 5;  // 37
+    __shared__ float s_in[3][P][P + 1];
+    __shared__ __attribute__((aligned(16))) float s_w[147 * 64];  // [tap(ky,kx,c)][64]
+    const int Ro = R / 2;
+    const int b = blockIdx.z, ty0 = blockIdx.y * T, tx0 = blockIdx.x * T;
+    const int tid = threadIdx.x;
+    // weights: global layout [64][7][7][3] -> LDS [147][64]
+    for (int i = tid; i < 147 * 64; i += 256) {
+        const int n = i / 147, k = i - n * 147;
+        s_w[k * 64 + n] = w[i];
+    }
+    const int iy0 = ty0 * 2 - 3, ix0 = tx0 * 2 - 3;
+    for (int i = tid; i < 3 * P * P; i += 256) {
+        const int c = i / (P * P), rem = i - c * P * P, py = rem / P, px = rem - py * P;
+        const int iy = iy0 + py, ix = ix0 + px;
+        float v = 0.f;
+        if ((unsigned)iy < (unsigned)R && (unsigned)ix < (unsigned)R)
+            v = x[(((long long)b * xc + c) * R + iy) * R + ix];
+        s_in[c][py][px] = v;
+    }
+    __syncthreads();
+    const int ly = tid / T, lx = tid - ly * T;
+    const int oy = ty0 + ly, ox = tx0 + lx;
+    float acc[64];
+#pragma unroll
+    for (int n = 0; n < 64; ++n) acc[n] = 0.f;
+    for (int ky = 0; ky < 7; ++ky)
+        for (int kx = 0; kx < 7; ++kx)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float v = s_in[c][ly * 2 + ky][lx * 2 + kx];
+                const f32x4* wp = reinterpret_cast<const f32x4*>(&s_w[((ky * 7 + kx) * 3 + c) * 64]);
+#pragma unroll
+                for (int n4 = 0; n4 < 16; ++n4) {
+                    const f32x4 wv = wp[n4];
+                    acc[n4 * 4 + 0] = fmaf(v, wv[0], acc[n4 * 4 + 0]);
+                    acc[n4 * 4 + 1] = fmaf(v, wv[1], acc[n4 * 4 + 1]);
+                    acc[n4 * 4 + 2] = fmaf(v, wv[2], acc[n4 * 4 + 2]);
+                    acc[n4 * 4 + 3] = fmaf(v, wv[3], acc[n4 * 4 + 3]);
+                }
+            }
+    if (oy < Ro && ox < Ro) {
+        f32x4* yp = reinterpret_cast<f32x4*>(y + (((long long)b * Ro + oy) * Ro + ox) * 64);
+#pragma unroll
+        for (int n4 = 0; n4 < 16; ++n4) {
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = n4 * 4 + e;
+                const float v = acc[n] * scale[n] + shift[n];
+                o[e] = v > 0.f ? v : 0.f;
+            }
+            yp[n4] = o;
+        }
+    }
+}
+
+extern "C" int rdpn6d_stem_conv7x7_f32(const float* x, int B, int xc, int R, const float* w, const float* scale,
+                                       const float* shift, float* y, void* stream)
+{
+    RD_REQUIRE(x && w && scale && shift && y, "null pointer");
+    RD_REQUIRE(B > 0 && xc >= 3 && R > 0 && R % 2 == 0, "shape");
+    const int Ro = R / 2;
+    dim3 grid(rd_cdiv(Ro, 16), rd_cdiv(Ro, 16), B);
+    hipLaunchKernelGGL(stem_conv7x7_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, xc, R, w, scale, shift, y);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// MaxPool2d(kernel 3, stride 2, pad 1): one thread per (output pixel, 4 channels).
+__global__ void maxpool3x3s2_kernel(const float* __restrict__ x, int B, int H, int W, int C, float* __restrict__ y)
+{
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1, C4 = C / 4;
+    const long long total = (long long)B * Ho * Wo * C4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        long long p = i / C4;
+        const int ox = (int)(p % Wo);
+        p /= Wo;
+        const int oy = (int)(p % Ho);
+        const int b = (int)(p / Ho);
+        f32x4 m = {-FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * 2 - 1 + ky;
+            if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * 2 - 1 + kx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((long long)b * H + iy) * W + ix) * C + c4 * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+            }
+        }
+        *reinterpret_cast<f32x4*>(y + (((long long)b * Ho + oy) * Wo + ox) * C + c4 * 4) = m;
+    }
+}
+
+extern "C" int rdpn6d_maxpool3x3s2_f32(const float* x, int B, int H, int W, int C, float* y, void* stream)
+{
+    RD_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "shape");
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long long total = (long long)B * Ho * Wo * (C / 4);
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, B, H, W, C, y);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bilinear upsampling, align_corners=True (nn.UpsamplingBilinear2d).
+__global__ void upsample_bilinear_kernel(const float* __restrict__ x, int B, int H, int W, int C, int f,
+                                         float* __restrict__ y)
+{
+    const int Ho = H * f, Wo = W * f, C4 = C / 4;
+    const float sy = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
+    const float sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    const long long total = (long long)B * Ho * Wo * C4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        long long p = i / C4;
+        const int ox = (int)(p % Wo);
+        p /= Wo;
+        const int oy = (int)(p % Ho);
+        const int b = (int)(p / Ho);
+        const float fy = sy * oy, fx = sx * ox;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < H - 1), x1 = x0 + (x0 < W - 1);
+        const float ly = fy - y0, lx = fx - x0, hy = 1.f - ly, hx = 1.f - lx;
+        const float* base = x + (long long)b * H * W * C + c4 * 4;
+        const f32x4 v00 = *reinterpret_cast<const f32x4*>(base + ((long long)y0 * W + x0) * C);
+        const f32x4 v01 = *reinterpret_cast<const f32x4*>(base + ((long long)y0 * W + x1) * C);
+        const f32x4 v10 = *reinterpret_cast<const f32x4*>(base + ((long long)y1 * W + x0) * C);
+        const f32x4 v11 = *reinterpret_cast<const f32x4*>(base + ((long long)y1 * W + x1) * C);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = hy * (hx * v00[e] + lx * v01[e]) + ly * (hx * v10[e] + lx * v11[e]);
+        *reinterpret_cast<f32x4*>(y + (((long long)b * Ho + oy) * Wo + ox) * C + c4 * 4) = o;
+    }
+}
+
+extern "C" int rdpn6d_upsample_bilinear_f32(const float* x, int B, int H, int W, int C, int factor, float* y,
+                                            void* stream)
+{
+    RD_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && factor >= 1, "shape");
+    const long long total = (long long)B * H * factor * W * factor * (C / 4);
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(upsample_bilinear_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, B, H, W, C,
+                       factor, y);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Nearest-neighbour subsample of the depth-xyz channels (3..5) of the NCHW crop into an NHWC slice.
+__global__ void xyz_subsample_kernel(const float* __restrict__ x, int B, int xc, int R, int step, float* __restrict__ y,
+                                     int out_cs, int out_co)
+{
+    const int Ro = R / step;
+    const long long total = (long long)B * Ro * Ro;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % Ro);
+        const int oy = (int)((i / Ro) % Ro);
+        const int b = (int)(i / ((long long)Ro * Ro));
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            y[i * out_cs + out_co + c] = x[(((long long)b * xc + 3 + c) * R + oy * step) * R + ox * step];
+    }
+}
+
+extern "C" int rdpn6d_xyz_subsample_f32(const float* x, int B, int xc, int R, int step, float* y, int out_cs,
+                                        int out_co, void* stream)
+{
+    RD_REQUIRE(x && y && B > 0 && xc >= 6 && R > 0 && step > 0 && R % step == 0, "shape");
+    RD_REQUIRE(out_co + 3 <= out_cs, "output slice");
+    const long long total = (long long)B * (R / step) * (R / step);
+    hipLaunchKernelGGL(xyz_subsample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       x, B, xc, R, step, y, out_cs, out_co);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Global max over the HW pixels of channels [0,C) and broadcast into channels [C,2C) of the same
+// NHWC buffer (md_pointnet's adaptive_max_pool2d + adaptive_avg_pool2d-broadcast + cat).
+// grid = (C/64, B); block = 256 = 4 pixel lanes x 64 channels (256-byte coalesced rows).
+__global__ __launch_bounds__(256) void global_max_concat_kernel(float* __restrict__ buf, int HW, int C, int cs)
+{
+    __shared__ float s_m[4][64];
+    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+    float* base = buf + (long long)b * HW * cs;
+    float m = -FLT_MAX;
+    for (int p = pl; p < HW; p += 4) {
+        const float v = base[(long long)p * cs + c];
+        m = v > m ? v : m;
+    }
+    s_m[pl][threadIdx.x & 63] = m;
+    __syncthreads();
+    const int cl = threadIdx.x & 63;
+    m = fmaxf(fmaxf(s_m[0][cl], s_m[1][cl]), fmaxf(s_m[2][cl], s_m[3][cl]));
+    for (int p = pl; p < HW; p += 4) base[(long long)p * cs + C + c] = m;
+}
+
+extern "C" int rdpn6d_global_max_concat_f32(float* buf, int B, int HW, int C, int cs, void* stream)
+{
+    RD_REQUIRE(buf && B > 0 && HW > 0 && C > 0 && C % 64 == 0 && 2 * C <= cs, "shape");
+    hipLaunchKernelGGL(global_max_concat_kernel, dim3(C / 64, B), dim3(256), 0, (hipStream_t)stream, buf, HW, C, cs);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm(G groups of C/G = 4 channels) + ReLU, in place, one workgroup per sample.
+// Two passes (mean, then centred variance) with wave-shuffle + LDS reductions.
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void groupnorm4_relu_kernel(float* __restrict__ x, int HW, int C,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta)
+{
+    // thread t: group g = t % G (G = C/4 <= 64), pixel lane pl = t / G
+    const int G = C / 4;
+    const int PL = 256 / G;
+    __shared__ float s_part[256];
+    __shared__ float s_mean[64], s_rstd[64];
+    const int g = threadIdx.x % G, pl = threadIdx.x / G;
+    float* base = x + (long long)blockIdx.x * HW * C + g * 4;
+    float s = 0.f;
+    for (int p = pl; p < HW; p += PL) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(base + (long long)p * C);
+        s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    s_part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < G) {
+        float t = 0.f;
+        for (int i = 0; i < PL; ++i) t += s_part[i * G + threadIdx.x];
+        s_mean[threadIdx.x] = t / (float)(HW * 4);
+    }
+    __syncthreads();
+    const float mean = s_mean[g];
+    float q = 0.f;
+    for (int p = pl; p < HW; p += PL) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(base + (long long)p * C);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float dlt = v[e] - mean;
+            q += dlt * dlt;
+        }
+    }
+    __syncthreads();
+    s_part[threadIdx.x] = q;
+    __syncthreads();
+    if (threadIdx.x < G) {
+        float t = 0.f;
+        for (int i = 0; i < PL; ++i) t += s_part[i * G + threadIdx.x];
+        s_rstd[threadIdx.x] = 1.0f / sqrtf(t / (float)(HW * 4) + 1e-5f);
+    }
+    __syncthreads();
+    const float rstd = s_rstd[g];
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + g * 4);
+    const f32x4 be = *reinterpret_cast<const f32x4*>(beta + g * 4);
+    for (int p = pl; p < HW; p += PL) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(base + (long long)p * C);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float o = (v[e] - mean) * rstd * ga[e] + be[e];
+            v[e] = o > 0.f ? o : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(base + (long long)p * C) = v;
+    }
+}
+
+extern "C" int rdpn6d_groupnorm_relu_f32(float* x, int B, int HW, int C, int G, const float* gamma, const float* beta,
+                                         void* stream)
+{
+    RD_REQUIRE(x && gamma && beta && B > 0 && HW > 0, "null/shape");
+    RD_REQUIRE(C == 4 * G && G <= 64 && 256 % G == 0, "only C/G == 4 with G | 256 is implemented (GroupNorm(32,128))");
+    hipLaunchKernelGGL(groupnorm4_relu_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, HW, C, gamma, beta);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dense-map glue.  Pass 1 (only for mask attention): per-sample min / max of the mask channel.
+__global__ __launch_bounds__(256) void mask_minmax_kernel(const float* __restrict__ head, int head_cs, int HW,
+                                                          float* __restrict__ minmax)
+{
+    __shared__ float s_mn[4], s_mx[4];
+    const float* base = head + (long long)blockIdx.x * HW * head_cs;
+    float mn = FLT_MAX, mx = -FLT_MAX;
+    for (int p = threadIdx.x; p < HW; p += 256) {
+        const float v = base[(long long)p * head_cs];
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = fminf(mn, __shfl_xor(mn, o));
+        mx = fmaxf(mx, __shfl_xor(mx, o));
+    }
+    if ((threadIdx.x & 63) == 0) { s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        minmax[blockIdx.x * 2 + 0] = fminf(fminf(s_mn[0], s_mn[1]), fminf(s_mn[2], s_mn[3]));
+        minmax[blockIdx.x * 2 + 1] = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
+    }
+}
+
+// Pass 2: one thread per pixel.  Reads the head's NHWC row, writes (a) the NCHW maps the reference
+// API returns and (b) the ConvPnPNet input row [xyz | coord2d | anchor | softmax(region[1:]) | pad].
+// The arg-max is taken ON the softmax output with first-max tie-break, exactly like
+// GDRN.py:206-209 (two different logits can round to the same probability).
+template <int KMAX>
+__global__ __launch_bounds__(256) void dense_glue_kernel(const float* __restrict__ head, int head_cs,
+                                                         const float* __restrict__ coord2d,
+                                                         const float* __restrict__ fps, int B, int HW, int K,
+                                                         int mask_attention, const float* __restrict__ minmax,
+                                                         float* __restrict__ out_nchw, float* __restrict__ pnp_in,
+                                                         int pnp_cs, int* __restrict__ argmax_out)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)B * HW) return;
+    const int b = (int)(i / HW), p = (int)(i - (long long)b * HW);
+    const float* h = head + i * head_cs;
+    const int C = 4 + K + 1;
+    float v[4 + KMAX + 1];
+    // head row -> registers (16-byte loads), and out to the NCHW API tensor (coalesced over pixels)
+#pragma unroll
+    for (int c4 = 0; c4 < (4 + KMAX + 1 + 3) / 4; ++c4) {
+        if (c4 * 4 < C) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(h + c4 * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c4 * 4 + e < 4 + KMAX + 1) v[c4 * 4 + e] = t[e];
+        }
+    }
+    float* o = out_nchw + (long long)b * C * HW + p;
+#pragma unroll
+    for (int c = 0; c < 4 + KMAX + 1; ++c)
+        if (c < C) o[(long long)c * HW] = v[c];
+    // softmax over region[1..K]
+    float mx = -FLT_MAX;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+        if (k < K) mx = fmaxf(mx, v[5 + k]);
+    float sum = 0.f;
+    float e[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+        if (k < K) {
+            e[k] = expf(v[5 + k] - mx);
+            sum += e[k];
+        }
+    int am = 0;
+    float best = -1.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+        if (k < K) {
+            e[k] = e[k] / sum;
+            if (e[k] > best) { best = e[k]; am = k; }
+        }
+    if (argmax_out) argmax_out[i] = am;
+    float att = 1.f;
+    if (mask_attention) {
+        const float mn = minmax[b * 2], mxm = minmax[b * 2 + 1];
+        att = (v[0] - mn) / (mxm - mn);  // no epsilon, as model_utils.py:34
+    }
+    float* q = pnp_in + i * pnp_cs;
+    const float* cd = coord2d + (long long)b * 5 * HW + p;
+    const float* an = fps + ((long long)b * K + am) * 3;
+    float row[11];
+    row[0] = v[1]; row[1] = v[2]; row[2] = v[3];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) row[3 + c] = cd[(long long)c * HW];
+    row[8] = an[0]; row[9] = an[1]; row[10] = an[2];
+    // 11 + K channels, then zero pad up to pnp_cs (all register indices are compile-time constants)
+#pragma unroll
+    for (int c4 = 0; c4 < (11 + KMAX + 3) / 4 + 1; ++c4) {
+        if (c4 * 4 < pnp_cs) {
+            f32x4 t;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ch = c4 * 4 + u;
+                float val = 0.f;
+                if (ch < 11) val = row[ch < 11 ? ch : 0];
+                else if (ch - 11 < KMAX) val = (ch - 11 < K) ? e[ch - 11 < KMAX ? ch - 11 : 0] : 0.f;
+                t[u] = val * att;
+            }
+            *reinterpret_cast<f32x4*>(q + c4 * 4) = t;
+        }
+    }
+    for (int c = ((11 + KMAX + 3) / 4 + 1) * 4; c < pnp_cs; c += 4) *reinterpret_cast<f32x4*>(q + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+extern "C" int rdpn6d_dense_glue_f32(const float* head, int head_cs, const float* coord2d, const float* fps, int B,
+                                     int HW, int K, int mask_attention, float* minmax_scratch, float* out_nchw,
+                                     float* pnp_in, int pnp_cs, int* argmax_out, void* stream)
+{
+    RD_REQUIRE(head && coord2d && fps && out_nchw && pnp_in, "null pointer");
+    RD_REQUIRE(B > 0 && HW > 0 && K >= 2 && K <= 64, "K in 2..64");
+    RD_REQUIRE(head_cs % 4 == 0 && head_cs >= 5 + K && pnp_cs % 4 == 0 && pnp_cs >= 11 + K, "channel strides");
+    RD_REQUIRE(!mask_attention || minmax_scratch, "mask attention needs a [B,2] scratch");
+    hipStream_t s = (hipStream_t)stream;
+    if (mask_attention) {
+        hipLaunchKernelGGL(mask_minmax_kernel, dim3(B), dim3(256), 0, s, head, head_cs, HW, minmax_scratch);
+        RD_LAUNCH_CHECK();
+    }
+    const unsigned blocks = (unsigned)(((long long)B * HW + 255) / 256);
+    if (K <= 32)
+        hipLaunchKernelGGL(dense_glue_kernel<32>, dim3(blocks), dim3(256), 0, s, head, head_cs, coord2d, fps, B, HW, K,
+                           mask_attention, minmax_scratch, out_nchw, pnp_in, pnp_cs, argmax_out);
+    else
+        hipLaunchKernelGGL(dense_glue_kernel<64>, dim3(blocks), dim3(256), 0, s, head, head_cs, coord2d, fps, B, HW, K,
+                           mask_attention, minmax_scratch, out_nchw, pnp_in, pnp_cs, argmax_out);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pose decode: rot6d -> R_allo, SITE translation, allocentric -> egocentric.  One thread per crop.
+__global__ void pose_decode_kernel(const float* __restrict__ rt, int rt_stride, const float* __restrict__ cams,
+                                   const float* __restrict__ centers, const float* __restrict__ whs,
+                                   const float* __restrict__ ratios, int B, int is_allo, int train_variant,
+                                   float* __restrict__ rot, float* __restrict__ trans)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float* p = rt + (long long)b * rt_stride;
+    // ortho6d_to_mat_batch: x = norm(a1); z = norm(x x a2); y = z x x; columns [x y z]
+    float x[3] = {p[0], p[1], p[2]}, a2[3] = {p[3], p[4], p[5]};
+    float n = sqrtf(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    n = fmaxf(n, 1e-12f);
+    x[0] /= n; x[1] /= n; x[2] /= n;
+    float z[3] = {x[1] * a2[2] - x[2] * a2[1], x[2] * a2[0] - x[0] * a2[2], x[0] * a2[1] - x[1] * a2[0]};
+    n = sqrtf(z[0] * z[0] + z[1] * z[1] + z[2] * z[2]);
+    n = fmaxf(n, 1e-12f);
+    z[0] /= n; z[1] /= n; z[2] /= n;
+    const float y[3] = {z[1] * x[2] - z[2] * x[1], z[2] * x[0] - z[0] * x[2], z[0] * x[1] - z[1] * x[0]};
+    float Ra[9] = {x[0], y[0], z[0], x[1], y[1], z[1], x[2], y[2], z[2]};
+    // SITE: c = delta * wh + centre ; z = z_rel * resize_ratio ; back-project
+    const float* K = cams + b * 9;
+    const float cx = p[6] * whs[b * 2 + 0] + centers[b * 2 + 0];
+    const float cy = p[7] * whs[b * 2 + 1] + centers[b * 2 + 1];
+    const float tz = p[8] * ratios[b];
+    const float t[3] = {tz * (cx - K[2]) / K[0], tz * (cy - K[5]) / K[4], tz};
+    trans[b * 3 + 0] = t[0]; trans[b * 3 + 1] = t[1]; trans[b * 3 + 2] = t[2];
+    float* R = rot + b * 9;
+    if (!is_allo) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) R[i] = Ra[i];
+        return;
+    }
+    if (!train_variant) {
+        // numpy path (utils.py:39-94): fp32 ray, fp64 axis-angle, fp64 product, fp32 result
+        const float tn = sqrtf(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
+        const float ray[3] = {t[0] / tn, t[1] / tn, t[2] / tn};
+        const double angle = acos((double)ray[2]);
+        if (angle > 0.0) {
+            double ax = -(double)ray[1], ay = (double)ray[0], az = 0.0;  // cross((0,0,1), ray)
+            const double an = sqrt(ax * ax + ay * ay + az * az);
+            ax /= an; ay /= an; az /= an;
+            const double c = cos(angle), s = sin(angle), C = 1.0 - c;
+            const double xs = ax * s, ys = ay * s, zs = az * s, xC = ax * C, yC = ay * C, zC = az * C;
+            const double xyC = ax * yC, yzC = ay * zC, zxC = az * xC;
+            const double M[9] = {ax * xC + c, xyC - zs, zxC + ys, xyC + zs, ay * yC + c, yzC - xs,
+                                 zxC - ys, yzC + xs, az * zC + c};
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    R[i * 3 + j] = (float)(M[i * 3 + 0] * (double)Ra[0 * 3 + j] + M[i * 3 + 1] * (double)Ra[1 * 3 + j] +
+                                           M[i * 3 + 2] * (double)Ra[2 * 3 + j]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) R[i] = Ra[i];
+        }
+    } else {
+        // torch path (utils.py:208-236): fp32 quaternion, eps = 1e-4 in both norms
+        const float eps = 1e-4f;
+        const float tn = sqrtf(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]) + eps;
+        const float ray[3] = {t[0] / tn, t[1] / tn, t[2] / tn};
+        const float angle = acosf(ray[2]);
+        float ax = -ray[1], ay = ray[0], az = 0.f;
+        const float an = sqrtf(ax * ax + ay * ay + az * az) + eps;
+        ax /= an; ay /= an; az /= an;
+        const float sh = sinf(angle * 0.5f);
+        float qw = cosf(angle * 0.5f), qx = ax * sh, qy = ay * sh, qz = az * sh;
+        const float qn = sqrtf(qw * qw + qx * qx + qy * qy + qz * qz);
+        qw /= qn; qx /= qn; qy /= qn; qz /= qn;
+        const float X = qx * 2.f, Y = qy * 2.f, Z = qz * 2.f;
+        const float wX = qw * X, wY = qw * Y, wZ = qw * Z, xX = qx * X, xY = qx * Y, xZ = qx * Z, yY = qy * Y,
+                    yZ = qy * Z, zZ = qz * Z;
+        const float M[9] = {1.f - (yY + zZ), xY - wZ, xZ + wY, xY + wZ, 1.f - (xX + zZ), yZ - wX,
+                            xZ - wY, yZ + wX, 1.f - (xX + yY)};
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                R[i * 3 + j] = M[i * 3 + 0] * Ra[0 * 3 + j] + M[i * 3 + 1] * Ra[1 * 3 + j] + M[i * 3 + 2] * Ra[2 * 3 + j];
+    }
+}
+
+extern "C" int rdpn6d_pose_decode_f32(const float* rt, int rt_stride, const float* roi_cams, const float* roi_centers,
+                                      const float* roi_whs, const float* resize_ratios, int B, int is_allo,
+                                      int train_variant, float* rot, float* trans, void* stream)
+{
+    RD_REQUIRE(rt && roi_cams && roi_centers && roi_whs && resize_ratios && rot && trans, "null pointer");
+    RD_REQUIRE(B > 0 && rt_stride >= 9, "shape");
+    hipLaunchKernelGGL(pose_decode_kernel, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, rt, rt_stride,
+                       roi_cams, roi_centers, roi_whs, resize_ratios, B, is_allo, train_variant, rot, trans);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}

@@ -1,0 +1,560 @@
+"""Host-side mirror of the reference's model interface, running on the HIP kernels.
+
+Mirrors (paths relative to the reference repository root):
+  * ``core/gdrn_modeling/models/GDRN.py:662-855``  ``build_model_optimizer(cfg) -> (model, optimizer)``
+  * ``core/gdrn_modeling/models/GDRN.py:107-134``  ``GDRN.forward(x, ..., do_loss=False, fps=None)``
+    (same keyword names, same ``out_dict`` keys ``rot, trans, mask, coor_x, coor_y, coor_z, region``)
+  * the 305 ``state_dict`` keys (``backbone.*``, ``rot_head_net.features.N.*``, ``pnp_net.*``), so the
+    reference's checkpoints load with ``load_state_dict(..., strict=True)``.
+
+The ``nn.Module`` tree below only HOLDS parameters (none of the holder classes has a forward that
+computes anything): every FLOP of ``GDRN.forward`` is issued through the C ABI of
+``librdpn6d_hip.so`` on the current torch stream.  PyTorch supplies device memory and streams.
+There is no CPU / eager fallback: without the extension or without a GPU the forward raises.
+
+Generalisation over the reference's hard-coded geometry: ``nIn = 11 + NUM_REGIONS``,
+xyz resize = ``INPUT_RES/8``, out = ``INPUT_RES/4``, ``fc1`` in = ``128*(OUT_RES/8)**2``.
+"""
+import ctypes
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .config import ConfigDict
+
+RESNET_SPEC = {18: (2, 2, 2, 2), 34: (3, 4, 6, 3)}  # BasicBlock trunks (resnet_backbone.py:15-21)
+
+
+# ----------------------------------------------------------------------------- parameter holders
+class _Holder(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter holder: compute happens in the HIP engine, not in nn.Module.forward")
+
+
+class ConvP(_Holder):
+    def __init__(self, cin, cout, k, stride=1, pad=0, bias=False, transposed=False):
+        super().__init__()
+        shape = (cin, cout, k, k) if transposed else (cout, cin, k, k)
+        self.weight = nn.Parameter(torch.empty(shape))
+        self.bias = nn.Parameter(torch.empty(cout)) if bias else None
+        self.k, self.stride, self.pad, self.transposed = k, stride, pad, transposed
+        nn.init.normal_(self.weight, std=0.001)  # mmcv normal_init(std=0.001), bias 0
+        if bias:
+            nn.init.zeros_(self.bias)
+
+
+class LinearP(_Holder):
+    def __init__(self, cin, cout, std=0.001):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin))
+        self.bias = nn.Parameter(torch.zeros(cout))
+        nn.init.normal_(self.weight, std=std)
+
+
+class BNP(_Holder):
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self.eps = 1e-5
+
+
+class GNP(_Holder):
+    def __init__(self, groups, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.groups, self.eps = groups, 1e-5
+
+
+class Slot(_Holder):
+    """Parameter-free placeholder keeping ModuleList indices equal to the reference's (ReLU slots)."""
+
+
+class BlockP(_Holder):
+    def __init__(self, cin, cout, stride, downsample):
+        super().__init__()
+        self.conv1 = ConvP(cin, cout, 3, stride, 1)
+        self.bn1 = BNP(cout)
+        self.conv2 = ConvP(cout, cout, 3, 1, 1)
+        self.bn2 = BNP(cout)
+        if downsample:
+            self.downsample = nn.Sequential(ConvP(cin, cout, 1, stride, 0), BNP(cout))
+        else:
+            self.downsample = None
+
+
+class PointFusionP(_Holder):
+    def __init__(self, cin=512, ch=(64, 128, 256, 512)):
+        super().__init__()
+        self.xyz_emb = ConvP(cin, ch[0], 1, bias=True)
+        self.xb = BNP(ch[0])
+        self.conv1 = ConvP(ch[0] + 3, ch[1], 1, bias=True)
+        self.conv2 = ConvP(ch[1], ch[2], 1, bias=True)
+        self.conv3 = ConvP(ch[2], ch[3], 1, bias=True)
+        self.b1, self.b2, self.b3 = BNP(ch[1]), BNP(ch[2]), BNP(ch[3])
+
+
+class BackboneP(_Holder):
+    def __init__(self, num_layers=34):
+        super().__init__()
+        if num_layers not in RESNET_SPEC:
+            raise ValueError(f"only BasicBlock trunks {sorted(RESNET_SPEC)} are implemented, got {num_layers}")
+        self.spatial_net = PointFusionP(512, (64, 128, 256, 512))
+        self.conv1 = ConvP(3, 64, 7, 2, 3)
+        self.bn1 = BNP(64)
+        cin = 64
+        for li, (planes, nblk) in enumerate(zip((64, 128, 256, 512), RESNET_SPEC[num_layers])):
+            stride = 1 if li == 0 else 2
+            blocks = []
+            for bi in range(nblk):
+                s = stride if bi == 0 else 1
+                blocks.append(BlockP(cin, planes, s, bi == 0 and (s != 1 or cin != planes)))
+                cin = planes
+            setattr(self, f"layer{li + 1}", nn.Sequential(*blocks))
+
+
+class RotHeadP(_Holder):
+    def __init__(self, num_regions, num_filters=256, num_layers=3, in_channels=1024):
+        super().__init__()
+        f = [ConvP(in_channels, num_filters, 3, 2, 1, transposed=True), BNP(num_filters), Slot()]
+        for _ in range(2 * num_layers):
+            f += [ConvP(num_filters, num_filters, 3, 1, 1), BNP(num_filters), Slot()]
+        f.append(ConvP(num_filters, 1 + 3 + num_regions + 1, 1, bias=True))
+        self.features = nn.ModuleList(f)
+
+
+class ConvPnPP(_Holder):
+    def __init__(self, n_in, featdim=128, rot_dim=6, out_res=64):
+        super().__init__()
+        f = []
+        for i in range(3):
+            f += [ConvP(n_in if i == 0 else featdim, featdim, 3, 2, 1), GNP(32, featdim), Slot()]
+        self.features = nn.ModuleList(f)
+        self.fc1 = LinearP(featdim * (out_res // 8) ** 2, 1024)
+        self.fc2 = LinearP(1024, 256)
+        self.fc_r = LinearP(256, rot_dim, std=0.01)
+        self.fc_t = LinearP(256, 3, std=0.01)
+
+
+# ----------------------------------------------------------------------------- packing helpers
+def _pad_to(n, m):
+    return (n + m - 1) // m * m
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def pack_conv_weight(w, cin_pad=None, perm=None):
+    """(Cout,Cin,kh,kw) -> [Npad][taps][Cin_pad] fp32 contiguous (zeros in the padding)."""
+    cout, cin, kh, kw = w.shape
+    if perm is not None:
+        w = w[:, perm]
+    cin_pad = cin_pad or _pad_to(cin, 16)
+    npad = _pad_to(cout, 64)
+    out = torch.zeros(npad, kh * kw, cin_pad, dtype=torch.float32, device=w.device)
+    out[:cout, :, :cin] = w.permute(0, 2, 3, 1).reshape(cout, kh * kw, cin)
+    return out.contiguous()
+
+
+def fold_bn(bn, conv_bias=None, npad=None):
+    """scale = gamma/sqrt(var+eps), shift = beta + (bias - mean)*scale, computed in fp64."""
+    g, b = bn.weight.detach().double(), bn.bias.detach().double()
+    m, v = bn.running_mean.double(), bn.running_var.double()
+    scale = g / torch.sqrt(v + bn.eps)
+    shift = b - m * scale
+    if conv_bias is not None:
+        shift = shift + conv_bias.detach().double() * scale
+    return _pad_vec(scale.float(), npad, 1.0), _pad_vec(shift.float(), npad, 0.0)
+
+
+def _pad_vec(v, npad, fill):
+    npad = npad or _pad_to(v.numel(), 64)
+    out = torch.full((npad,), fill, dtype=torch.float32, device=v.device)
+    out[: v.numel()] = v
+    return out
+
+
+class _Launch:
+    """One pre-built C-ABI call (function + argument tuple); the stream is appended at run time."""
+
+    __slots__ = ("fn", "args", "name", "keep")
+
+    def __init__(self, name, fn, args, keep=()):
+        self.name, self.fn, self.args, self.keep = name, fn, args, keep
+
+
+class InferencePlan:
+    """Packed weights, NHWC activation buffers and the launch list for one (batch, device)."""
+
+    def __init__(self, model, B, device):
+        self.lib = _lib.load()
+        self.B, self.device = B, device
+        self.launches = []
+        self.bufs = {}
+        self.keep = []  # packed weights etc. kept alive
+        cfg = model.cfg
+        self.R = int(cfg.MODEL.CDPN.BACKBONE.INPUT_RES)
+        self.K = int(cfg.MODEL.CDPN.ROT_HEAD.NUM_REGIONS)
+        self.mask_attention = cfg.MODEL.CDPN.PNP_NET.MASK_ATTENTION
+        if self.mask_attention not in ("none", "mul"):
+            raise ValueError(f"MASK_ATTENTION={self.mask_attention!r} is not implemented (none | mul)")
+        self._build(model)
+
+    # ---- buffers
+    def buf(self, name, *shape, dtype=torch.float32, zero=False):
+        if name not in self.bufs:
+            fn = torch.zeros if zero else torch.empty
+            self.bufs[name] = fn(*shape, dtype=dtype, device=self.device)
+        return self.bufs[name]
+
+    # ---- launch builders
+    def conv(self, name, x, xshape, w, scale, shift, y, yshape, *, cin, in_cs, in_co=0, k=1, stride=1, pad=0, N,
+             out_cs, out_co=0, res=None, res_cs=0, res_co=0, act=0, slope=0.0, taps=None, phase=None):
+        """xshape = (H, W) of the input, yshape = (OH, OW) of the full output."""
+        d = _lib.ConvDesc()
+        d.x, d.w, d.scale, d.shift, d.res, d.y = _ptr(x), _ptr(w), _ptr(scale), _ptr(shift), _ptr(res), _ptr(y)
+        d.B, d.H, d.W = self.B, xshape[0], xshape[1]
+        d.Cin, d.in_cs, d.in_co = cin, in_cs, in_co
+        if taps is None:
+            taps = [(ky - pad, kx - pad) for ky in range(k) for kx in range(k)]
+        d.ntaps = len(taps)
+        for t, (dy, dx) in enumerate(taps):
+            d.dy[t], d.dx[t] = dy, dx
+        d.stride = stride
+        d.N, d.Npad = N, w.shape[0]
+        d.OH, d.OW = yshape
+        if phase is None:
+            d.Ho, d.Wo, d.osy, d.osx, d.ooy, d.oox = yshape[0], yshape[1], 1, 1, 0, 0
+        else:
+            d.Ho, d.Wo, d.osy, d.osx, d.ooy, d.oox = phase
+        d.out_cs, d.out_co, d.res_cs, d.res_co = out_cs, out_co, res_cs, res_co
+        d.act, d.slope = act, slope
+        assert w.shape[1] == d.ntaps and w.shape[2] == cin, (name, tuple(w.shape), d.ntaps, cin)
+        self.keep += [w, scale, shift]
+        self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_f32, (ctypes.byref(d),), keep=(d,)))
+
+    def call(self, name, fn, *args):
+        self.launches.append(_Launch(name, fn, args))
+
+    # ---- the network
+    def _build(self, model):
+        B, R, K, lib = self.B, self.R, self.K, self.lib
+        bb, head, pnp = model.backbone, model.rot_head_net, model.pnp_net
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.x_in = None  # bound per call
+        R2, R4, R8, R16, R32 = R // 2, R // 4, R // 8, R // 16, R // 32
+
+        # --- stem + maxpool
+        w = bb.conv1.weight.detach().float().permute(0, 2, 3, 1).contiguous()  # [64][7][7][3]
+        sc, sh = fold_bn(bb.bn1)
+        s0 = self.buf("stem", B, R2, R2, 64)
+        self.keep += [w, sc, sh]
+        self.stem_args = (B, 6, R, _ptr(w), _ptr(sc), _ptr(sh), _ptr(s0))
+        p0 = self.buf("pool", B, R4, R4, 64)
+        self.call("maxpool", lib.rdpn6d_maxpool3x3s2_f32, _ptr(s0), B, R2, R2, 64, _ptr(p0))
+
+        # --- residual trunk
+        cur, cur_hw, cur_c = p0, R4, 64
+        for li in range(4):
+            layer = getattr(bb, f"layer{li + 1}")
+            for bi, blk in enumerate(layer):
+                cout = blk.conv1.weight.shape[0]
+                s = blk.conv1.stride
+                ohw = cur_hw // s
+                t = self.buf(f"l{li}_t{bi % 2}", B, ohw, ohw, cout)
+                o = self.buf(f"l{li}_o{bi % 2}", B, ohw, ohw, cout)
+                w1 = pack_conv_weight(blk.conv1.weight.detach().float())
+                sc1, sh1 = fold_bn(blk.bn1, npad=w1.shape[0])
+                self.conv(f"layer{li + 1}.{bi}.conv1", cur, (cur_hw, cur_hw), w1, sc1, sh1, t, (ohw, ohw), cin=cur_c,
+                          in_cs=cur_c, k=3, stride=s, pad=1, N=cout, out_cs=cout, act=1)
+                res = cur
+                if blk.downsample is not None:
+                    dsb = self.buf(f"l{li}_ds", B, ohw, ohw, cout)
+                    wd = pack_conv_weight(blk.downsample[0].weight.detach().float())
+                    scd, shd = fold_bn(blk.downsample[1], npad=wd.shape[0])
+                    self.conv(f"layer{li + 1}.{bi}.downsample", cur, (cur_hw, cur_hw), wd, scd, shd, dsb, (ohw, ohw),
+                              cin=cur_c, in_cs=cur_c, k=1, stride=s, pad=0, N=cout, out_cs=cout, act=0)
+                    res = dsb
+                w2 = pack_conv_weight(blk.conv2.weight.detach().float())
+                sc2, sh2 = fold_bn(blk.bn2, npad=w2.shape[0])
+                self.conv(f"layer{li + 1}.{bi}.conv2", t, (ohw, ohw), w2, sc2, sh2, o, (ohw, ohw), cin=cout, in_cs=cout,
+                          k=3, stride=1, pad=1, N=cout, out_cs=cout, res=res, res_cs=cout, act=1)
+                cur, cur_hw, cur_c = o, ohw, cout
+
+        # --- x4 bilinear up-sampling + point-wise fusion with the depth xyz
+        up = self.buf("up", B, R8, R8, 512)
+        self.call("upsample", lib.rdpn6d_upsample_bilinear_f32, _ptr(cur), B, cur_hw, cur_hw, 512, R8 // cur_hw, _ptr(up))
+        sn = bb.spatial_net
+        pin = self.buf("pn_in", B, R8, R8, 80, zero=True)  # [emb(64) | xyz(3) | 0-pad(13)]
+        self.xyz_args = (B, 6, R, 8, _ptr(pin), 80, 64)
+        we = pack_conv_weight(sn.xyz_emb.weight.detach().float())
+        sce, she = fold_bn(sn.xb, sn.xyz_emb.bias, npad=we.shape[0])
+        self.conv("spatial_net.xyz_emb", up, (R8, R8), we, sce, she, pin, (R8, R8), cin=512, in_cs=512, N=64, out_cs=80,
+                  act=1)
+        perm = list(range(3, 67)) + [0, 1, 2]  # reference order [xyz | emb] -> buffer order [emb | xyz]
+        wc1 = pack_conv_weight(sn.conv1.weight.detach().float(), cin_pad=80, perm=perm)
+        s1, h1 = fold_bn(sn.b1, sn.conv1.bias, npad=wc1.shape[0])
+        l1 = self.buf("pn_l1", B, R8, R8, 128)
+        self.conv("spatial_net.conv1", pin, (R8, R8), wc1, s1, h1, l1, (R8, R8), cin=80, in_cs=80, N=128, out_cs=128, act=1)
+        wc2 = pack_conv_weight(sn.conv2.weight.detach().float())
+        s2, h2 = fold_bn(sn.b2, sn.conv2.bias, npad=wc2.shape[0])
+        l2 = self.buf("pn_l2", B, R8, R8, 256)
+        self.conv("spatial_net.conv2", l1, (R8, R8), wc2, s2, h2, l2, (R8, R8), cin=128, in_cs=128, N=256, out_cs=256, act=1)
+        wc3 = pack_conv_weight(sn.conv3.weight.detach().float())
+        s3, h3 = fold_bn(sn.b3, sn.conv3.bias, npad=wc3.shape[0])
+        feat = self.buf("feat", B, R8, R8, 1024)
+        self.conv("spatial_net.conv3", l2, (R8, R8), wc3, s3, h3, feat, (R8, R8), cin=256, in_cs=256, N=512, out_cs=1024,
+                  act=0)
+        self.call("global_max_concat", lib.rdpn6d_global_max_concat_f32, _ptr(feat), B, R8 * R8, 512, 1024)
+
+        # --- dense head: ConvTranspose(3, s2, p1, op1) as 4 sub-pixel phase convolutions
+        F = head.features[0].weight.shape[1]
+        hA = self.buf("head_a", B, R4, R4, F)
+        hB = self.buf("head_b", B, R4, R4, F)
+        wt = head.features[0].weight.detach().float()  # (Cin, Cout, 3, 3)
+        sct, sht = fold_bn(head.features[1], npad=_pad_to(F, 64))
+        for py in (0, 1):
+            for px in (0, 1):
+                ys = [(1, 0)] if py == 0 else [(0, 1), (2, 0)]  # (kernel index, input offset)
+                xs = [(1, 0)] if px == 0 else [(0, 1), (2, 0)]
+                taps, slabs = [], []
+                for ky, dy in ys:
+                    for kx, dx in xs:
+                        taps.append((dy, dx))
+                        slabs.append(wt[:, :, ky, kx].t())  # (Cout, Cin)
+                wp = torch.zeros(_pad_to(F, 64), len(taps), 1024, **f32)
+                wp[:F] = torch.stack(slabs, dim=1)
+                self.conv(f"rot_head.convT.phase{py}{px}", feat, (R8, R8), wp.contiguous(), sct, sht, hA, (R4, R4),
+                          cin=1024, in_cs=1024, N=F, out_cs=F, act=1, taps=taps, phase=(R8, R8, 2, 2, py, px))
+        a, b = hA, hB
+        nfeat = len(head.features)
+        for i in range(3, nfeat - 1, 3):
+            wh = pack_conv_weight(head.features[i].weight.detach().float())
+            sch, shh = fold_bn(head.features[i + 1], npad=wh.shape[0])
+            self.conv(f"rot_head.features.{i}", a, (R4, R4), wh, sch, shh, b, (R4, R4), cin=F, in_cs=F, k=3, stride=1,
+                      pad=1, N=F, out_cs=F, act=1)
+            a, b = b, a
+        last = head.features[nfeat - 1]
+        nout = last.weight.shape[0]
+        assert nout == 5 + K
+        self.head_cs = _pad_to(nout, 4)
+        wl = pack_conv_weight(last.weight.detach().float())
+        bl = _pad_vec(last.bias.detach().float(), wl.shape[0], 0.0)
+        ho = self.buf("head_out", B, R4 * R4, self.head_cs, zero=True)
+        self.conv("rot_head.out", a, (R4, R4), wl, None, bl, ho, (R4, R4), cin=F, in_cs=F, N=nout, out_cs=self.head_cs)
+
+        # --- glue -> NCHW API maps + ConvPnPNet input
+        HW = R4 * R4
+        self.pnp_cs = _pad_to(11 + K, 16)
+        self.out_nchw = self.buf("out_nchw", B, nout, R4, R4)
+        pnp_in = self.buf("pnp_in", B, HW, self.pnp_cs)
+        self.argmax = self.buf("argmax", B, HW, dtype=torch.int32)
+        minmax = self.buf("minmax", B, 2)
+        self.glue_args = lambda coord2d, fps: (_ptr(ho), self.head_cs, _ptr(coord2d), _ptr(fps), B, HW, K,
+                                               1 if self.mask_attention == "mul" else 0, _ptr(minmax),
+                                               _ptr(self.out_nchw), _ptr(pnp_in), self.pnp_cs, _ptr(self.argmax))
+        self.post = []  # launches after the glue
+        main, self.launches = self.launches, self.post
+
+        # --- ConvPnPNet
+        x, hw, cin = pnp_in, R4, self.pnp_cs
+        for i in range(0, 9, 3):
+            conv, gn = pnp.features[i], pnp.features[i + 1]
+            fd = conv.weight.shape[0]
+            wpn = pack_conv_weight(conv.weight.detach().float(), cin_pad=cin)
+            y = self.buf(f"pnp_c{i}", B, hw // 2, hw // 2, fd)
+            self.conv(f"pnp_net.features.{i}", x, (hw, hw), wpn, None, None, y, (hw // 2, hw // 2), cin=cin, in_cs=cin,
+                      k=3, stride=2, pad=1, N=fd, out_cs=fd)
+            g, bta = gn.weight.detach().float().contiguous(), gn.bias.detach().float().contiguous()
+            self.keep += [g, bta]
+            self.call(f"pnp_net.features.{i + 1}", lib.rdpn6d_groupnorm_relu_f32, _ptr(y), B, (hw // 2) ** 2, fd, gn.groups,
+                      _ptr(g), _ptr(bta))
+            x, hw, cin = y, hw // 2, fd
+        # FC stack as 1x1 "convolutions" over B pixels; fc1's K is permuted NCHW-flatten -> NHWC-flatten
+        kin = cin * hw * hw
+        w1 = pnp.fc1.weight.detach().float().view(-1, cin, hw, hw).permute(0, 2, 3, 1).reshape(-1, kin)
+        w1p = torch.zeros(_pad_to(w1.shape[0], 64), 1, kin, **f32)
+        w1p[: w1.shape[0], 0] = w1
+        f1 = self.buf("fc1", B, w1.shape[0])
+        self._fc("pnp_net.fc1", x, kin, w1p, pnp.fc1.bias, f1, w1.shape[0], act=2)
+        w2 = pnp.fc2.weight.detach().float()
+        w2p = torch.zeros(_pad_to(w2.shape[0], 64), 1, w2.shape[1], **f32)
+        w2p[: w2.shape[0], 0] = w2
+        f2 = self.buf("fc2", B, w2.shape[0])
+        self._fc("pnp_net.fc2", f1, w2.shape[1], w2p, pnp.fc2.bias, f2, w2.shape[0], act=2)
+        wrt = torch.cat([pnp.fc_r.weight.detach().float(), pnp.fc_t.weight.detach().float()], 0)  # (6+3, 256)
+        brt = torch.cat([pnp.fc_r.bias.detach().float(), pnp.fc_t.bias.detach().float()], 0)
+        if wrt.shape[0] != 9:
+            raise ValueError("only ROT_TYPE *_rot6d (rot_dim 6) is implemented")
+        wrtp = torch.zeros(64, 1, wrt.shape[1], **f32)
+        wrtp[:9, 0] = wrt
+        self.rt = self.buf("rt", B, 16, zero=True)
+        self._fc("pnp_net.fc_r|fc_t", f2, wrt.shape[1], wrtp, brt, self.rt, 9, act=0, out_cs=16)
+        self.rot = self.buf("rot", B, 3, 3)
+        self.trans = self.buf("trans", B, 3)
+        self.launches = main
+
+    def _fc(self, name, x, kin, wp, bias, y, nout, act, out_cs=None):
+        b = _pad_vec(bias.detach().float(), wp.shape[0], 0.0)
+        self.conv(name, x, (1, 1), wp, None, b, y, (1, 1), cin=kin, in_cs=kin, N=nout, out_cs=out_cs or nout, act=act,
+                  slope=0.1)
+
+    # ---- run
+    def run(self, x, roi_coord_2d, fps, roi_cams, roi_centers, roi_whs, resize_ratios, is_allo=True, train_pose=False):
+        lib = self.lib
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        B = self.B
+        _lib.check(lib.rdpn6d_stem_conv7x7_f32(_ptr(x), self.stem_args[0], x.shape[1], *self.stem_args[2:], st), "stem")
+        _lib.check(lib.rdpn6d_xyz_subsample_f32(_ptr(x), self.xyz_args[0], x.shape[1], *self.xyz_args[2:], st), "xyz")
+        for L in self.launches:
+            _lib.check(L.fn(*L.args, st), L.name)
+        _lib.check(lib.rdpn6d_dense_glue_f32(*self.glue_args(roi_coord_2d, fps), st), "dense_glue")
+        for L in self.post:
+            _lib.check(L.fn(*L.args, st), L.name)
+        _lib.check(lib.rdpn6d_pose_decode_f32(_ptr(self.rt), 16, _ptr(roi_cams), _ptr(roi_centers), _ptr(roi_whs),
+                                              _ptr(resize_ratios), B, 1 if is_allo else 0, 1 if train_pose else 0,
+                                              _ptr(self.rot), _ptr(self.trans), st), "pose_decode")
+
+
+# ----------------------------------------------------------------------------- the model
+def get_xyz_mask_region_out_dim(cfg):
+    """GDRN.py:636-659 for the loss types the RGB-D configs use."""
+    r = cfg.MODEL.CDPN.ROT_HEAD
+    if r.XYZ_LOSS_TYPE not in ("MSE", "L1", "L2", "SmoothL1"):
+        raise NotImplementedError(f"unknown / unsupported xyz loss type: {r.XYZ_LOSS_TYPE}")
+    if r.MASK_LOSS_TYPE not in ("L1", "BCE"):
+        raise NotImplementedError(f"unknown / unsupported mask loss type: {r.MASK_LOSS_TYPE}")
+    region_out_dim = r.NUM_REGIONS + 1
+    assert region_out_dim > 2, region_out_dim
+    return 3, 1, region_out_dim
+
+
+class GDRN(nn.Module):
+    def __init__(self, cfg, backbone, rot_head_net, trans_head_net=None, pnp_net=None):
+        super().__init__()
+        assert cfg.MODEL.CDPN.NAME == "GDRN", cfg.MODEL.CDPN.NAME
+        self.backbone = backbone
+        self.rot_head_net = rot_head_net
+        self.pnp_net = pnp_net
+        self.trans_head_net = trans_head_net
+        self.cfg = cfg
+        self._plans = {}
+
+    # weights changed -> packed copies are stale
+    def invalidate_plans(self):
+        self._plans.clear()
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self.invalidate_plans()
+        return r
+
+    def _apply(self, fn, *a, **k):
+        self._plans = {}
+        return super()._apply(fn, *a, **k)
+
+    def plan(self, B, device):
+        key = (B, str(device))
+        if key not in self._plans:
+            self._plans[key] = InferencePlan(self, B, device)
+        return self._plans[key]
+
+    def forward(self, x, gt_xyz=None, gt_xyz_bin=None, gt_mask_trunc=None, gt_mask_visib=None, gt_mask_obj=None,
+                gt_region=None, gt_allo_quat=None, gt_ego_quat=None, gt_allo_rot6d=None, gt_ego_rot6d=None,
+                gt_ego_rot=None, gt_points=None, sym_infos=None, gt_trans=None, gt_trans_ratio=None, roi_classes=None,
+                roi_coord_2d=None, roi_cams=None, roi_centers=None, roi_whs=None, roi_extents=None, resize_ratios=None,
+                do_loss=False, fps=None):
+        if do_loss:
+            raise NotImplementedError("training path (losses + backward kernels) is not wired into this build yet")
+        if not x.is_cuda:
+            raise RuntimeError("rdpn6d_amd.GDRN runs on the MI355X HIP kernels only; got a CPU tensor (no CPU fallback)")
+        pcfg = self.cfg.MODEL.CDPN.PNP_NET
+        assert roi_coord_2d is not None and fps is not None and roi_cams is not None
+        B = x.shape[0]
+        if roi_cams.dim() == 2:
+            roi_cams = roi_cams.unsqueeze(0).expand(B, 3, 3)
+
+        def f32c(t):
+            return t.detach().to(device=x.device, dtype=torch.float32).contiguous()
+
+        x, roi_coord_2d, fps = f32c(x), f32c(roi_coord_2d), f32c(fps)
+        if fps.dim() == 2:
+            fps = fps.unsqueeze(0).expand(B, -1, -1).contiguous()
+        roi_cams, roi_centers, roi_whs, resize_ratios = f32c(roi_cams), f32c(roi_centers), f32c(roi_whs), f32c(resize_ratios)
+        plan = self.plan(B, x.device)
+        if tuple(x.shape[1:]) != (6, plan.R, plan.R):
+            raise ValueError(f"expected x of shape (B,6,{plan.R},{plan.R}), got {tuple(x.shape)}")
+        if pcfg.TRANS_TYPE != "centroid_z" or pcfg.Z_TYPE != "REL":
+            raise ValueError("only TRANS_TYPE='centroid_z' with Z_TYPE='REL' is implemented")
+        plan.run(x, roi_coord_2d, fps, roi_cams, roi_centers, roi_whs, resize_ratios, is_allo="allo" in pcfg.ROT_TYPE)
+        o = plan.out_nchw
+        K = plan.K
+        return {
+            "rot": plan.rot.clone(), "trans": plan.trans.clone(),
+            "mask": o[:, 0:1], "coor_x": o[:, 1:2], "coor_y": o[:, 2:3], "coor_z": o[:, 3:4], "region": o[:, 4:5 + K],
+            "consistent_map": None,
+        }
+
+
+def build_model_optimizer(cfg):
+    """Factory with the reference's signature and side effects (GDRN.py:662-855)."""
+    m = cfg.MODEL.CDPN
+    backbone_cfg, r_head_cfg, t_head_cfg, pnp_net_cfg = m.BACKBONE, m.ROT_HEAD, m.TRANS_HEAD, m.PNP_NET
+    if "resnet" not in backbone_cfg.ARCH:
+        raise ValueError(f"unknown backbone arch {backbone_cfg.ARCH}")
+    params_lr_list = []
+    backbone = BackboneP(backbone_cfg.NUM_LAYERS)
+    r_out_dim, mask_out_dim, region_out_dim = get_xyz_mask_region_out_dim(cfg)
+    rot_head = RotHeadP(r_head_cfg.NUM_REGIONS, r_head_cfg.NUM_FILTERS, r_head_cfg.NUM_LAYERS)
+    if t_head_cfg.ENABLED:
+        raise NotImplementedError("TRANS_HEAD is disabled in every RGB-D config and is not implemented")
+    assert not pnp_net_cfg.R_ONLY, "if pnp_net is R_ONLY, trans_head must be enabled!"
+    n_in = r_out_dim + (5 + 3 if pnp_net_cfg.WITH_2D_COORD else 3) + (r_head_cfg.NUM_REGIONS if pnp_net_cfg.REGION_ATTENTION else 0)
+    if not (pnp_net_cfg.WITH_2D_COORD and pnp_net_cfg.REGION_ATTENTION):
+        raise NotImplementedError("the RGB-D path needs WITH_2D_COORD and REGION_ATTENTION (as all shipped configs)")
+    if pnp_net_cfg.ROT_TYPE in ("allo_rot6d", "ego_rot6d"):
+        rot_dim = 6
+    elif pnp_net_cfg.ROT_TYPE in ("allo_quat", "ego_quat", "allo_log_quat", "ego_log_quat", "allo_lie_vec", "ego_lie_vec"):
+        raise NotImplementedError(f"ROT_TYPE {pnp_net_cfg.ROT_TYPE}: only the rot6d types are implemented")
+    else:
+        raise ValueError(f"Unknown ROT_TYPE: {pnp_net_cfg.ROT_TYPE}")
+    pnp_head_cfg = pnp_net_cfg.PNP_HEAD_CFG
+    pnp_head_type = pnp_head_cfg.pop("type")  # in place, like the reference (:778-779)
+    if pnp_head_type != "ConvPnPNet":
+        raise ValueError(f"Unknown pnp head type: {pnp_head_type}")
+    pnp_net = ConvPnPP(n_in, featdim=128, rot_dim=rot_dim, out_res=backbone_cfg.OUTPUT_RES)
+    for net, frozen, mult in ((backbone, backbone_cfg.FREEZE, 1.0), (rot_head, r_head_cfg.FREEZE, 1.0),
+                              (pnp_net, pnp_net_cfg.FREEZE, pnp_net_cfg.LR_MULT)):
+        if frozen:
+            for p in net.parameters():
+                p.requires_grad = False
+        else:
+            params_lr_list.append({"params": [p for p in net.parameters() if p.requires_grad],
+                                   "lr": float(cfg.SOLVER.BASE_LR) * mult})
+    model = GDRN(cfg, backbone, rot_head, trans_head_net=None, pnp_net=pnp_net)
+    optimizer = build_optimizer_with_params(cfg, params_lr_list)
+    model.to(torch.device(cfg.MODEL.DEVICE))
+    return model, optimizer
+
+
+def build_optimizer_with_params(cfg, params):
+    """core/utils/solver_utils.py:47-57: OPTIMIZER_CFG dict(type=..., lr=..., ...)."""
+    if not params:
+        return None
+    ocfg = dict(cfg.SOLVER.OPTIMIZER_CFG)
+    typ = ocfg.pop("type")
+    ocfg.pop("_delete_", None)
+    if typ == "Ranger":
+        from .ranger import Ranger
+
+        return Ranger(params, **ocfg)
+    if hasattr(torch.optim, typ):
+        return getattr(torch.optim, typ)(params, **ocfg)
+    raise ValueError(f"unknown optimizer type {typ}")

@@ -1,0 +1,118 @@
+"""Functional wrappers over the C ABI (torch tensors in, torch tensors out; HIP kernels do the work).
+
+Used by the tests and by callers that want one operator rather than the whole GDRN plan.
+Every function raises if its tensors are not on the GPU: there is no CPU path.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .gdrn import _pad_to, _pad_vec, _ptr, pack_conv_weight
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("rdpn6d_amd.ops: tensors must live on the GPU (no CPU fallback)")
+
+
+def conv2d_nhwc(x, weight, scale=None, shift=None, stride=1, pad=0, residual=None, act=0, slope=0.0, out=None,
+                out_co=0, in_co=0, cin=None):
+    """x NHWC [B,H,W,Cs] fp32 (Cs multiple of 4), weight OIHW (torch layout).  Returns NHWC [B,Ho,Wo,N]
+    (or writes channels [out_co, out_co+N) of ``out``)."""
+    _need_gpu(x, weight, scale, shift, residual, out)
+    lib = _lib.load()
+    B, H, W, cs = x.shape
+    N, wcin, k, _ = weight.shape
+    cin_real = cin or wcin
+    cin_pad = _pad_to(cin_real, 16)
+    assert in_co + cin_pad <= cs, "input slice must cover the 16-padded reduction width"
+    wp = pack_conv_weight(weight.float(), cin_pad=cin_pad)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    if out is None:
+        out = torch.empty(B, Ho, Wo, N, dtype=torch.float32, device=x.device)
+    sc = _pad_vec(scale.float(), wp.shape[0], 1.0) if scale is not None else None
+    sh = _pad_vec(shift.float(), wp.shape[0], 0.0) if shift is not None else None
+    d = _lib.ConvDesc()
+    d.x, d.w, d.scale, d.shift, d.res, d.y = _ptr(x), _ptr(wp), _ptr(sc), _ptr(sh), _ptr(residual), _ptr(out)
+    d.B, d.H, d.W, d.Cin, d.in_cs, d.in_co = B, H, W, cin_pad, cs, in_co
+    d.Ho, d.Wo, d.stride = Ho, Wo, stride
+    taps = [(ky - pad, kx - pad) for ky in range(k) for kx in range(k)]
+    d.ntaps = len(taps)
+    for t, (dy, dx) in enumerate(taps):
+        d.dy[t], d.dx[t] = dy, dx
+    d.N, d.Npad, d.OH, d.OW = N, wp.shape[0], Ho, Wo
+    d.osy = d.osx = 1
+    d.ooy = d.oox = 0
+    d.out_cs, d.out_co = out.shape[-1], out_co
+    if residual is not None:
+        d.res_cs, d.res_co = residual.shape[-1], 0
+    d.act, d.slope = act, slope
+    _lib.check(lib.rdpn6d_conv2d_f32(ctypes.byref(d), _stream()), "conv2d")
+    return out
+
+
+def stem_conv7x7(x_nchw, weight, scale, shift):
+    _need_gpu(x_nchw, weight, scale, shift)
+    B, xc, R, _ = x_nchw.shape
+    w = weight.float().permute(0, 2, 3, 1).contiguous()
+    y = torch.empty(B, R // 2, R // 2, 64, dtype=torch.float32, device=x_nchw.device)
+    _lib.check(_lib.load().rdpn6d_stem_conv7x7_f32(_ptr(x_nchw), B, xc, R, _ptr(w), _ptr(scale), _ptr(shift), _ptr(y),
+                                                   _stream()), "stem")
+    return y
+
+
+def maxpool3x3s2(x):
+    _need_gpu(x)
+    B, H, W, C = x.shape
+    y = torch.empty(B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().rdpn6d_maxpool3x3s2_f32(_ptr(x), B, H, W, C, _ptr(y), _stream()), "maxpool")
+    return y
+
+
+def upsample_bilinear(x, factor):
+    _need_gpu(x)
+    B, H, W, C = x.shape
+    y = torch.empty(B, H * factor, W * factor, C, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().rdpn6d_upsample_bilinear_f32(_ptr(x), B, H, W, C, factor, _ptr(y), _stream()), "upsample")
+    return y
+
+
+def global_max_concat_(buf, C):
+    _need_gpu(buf)
+    B, H, W, cs = buf.shape
+    _lib.check(_lib.load().rdpn6d_global_max_concat_f32(_ptr(buf), B, H * W, C, cs, _stream()), "global_max_concat")
+    return buf
+
+
+def groupnorm_relu_(x, groups, gamma, beta):
+    _need_gpu(x, gamma, beta)
+    B, H, W, C = x.shape
+    _lib.check(_lib.load().rdpn6d_groupnorm_relu_f32(_ptr(x), B, H * W, C, groups, _ptr(gamma), _ptr(beta), _stream()), "gn")
+    return x
+
+
+def farthest_point_sampling(pts, sn, init_center=False, start=None):
+    """Host-array face of the fps ABI (mirrors core/csrc/fps/fps_utils.py:6-21): returns pts[idxs] (sn,3) f32.
+    ``start`` pins the random variant's start index (extra to the reference)."""
+    pts = np.ascontiguousarray(pts, np.float32)
+    pn, three = pts.shape
+    assert three == 3
+    idxs = np.zeros([sn], np.int32)
+    lib = _lib.load()
+    P = ctypes.c_void_p
+    if init_center:
+        _lib.check(lib.rdpn6d_fps_host(pts.ctypes.data_as(P), idxs.ctypes.data_as(P), pn, sn, -1), "fps")
+    elif start is not None:
+        _lib.check(lib.rdpn6d_fps_host(pts.ctypes.data_as(P), idxs.ctypes.data_as(P), pn, sn, int(start)), "fps")
+    else:
+        lib.farthest_point_sampling(pts.ctypes.data_as(P), idxs.ctypes.data_as(P), pn, sn)
+        if (idxs < 0).any():
+            raise RuntimeError("farthest_point_sampling failed: " + lib.rdpn6d_last_error().decode())
+    return pts[idxs], idxs

@@ -1,0 +1,263 @@
+"""GPU parity tests (run on the MI355X box: ``pytest -m gpu``).  Every kernel is called through the
+C ABI of librdpn6d_hip.so and compared with a plain PyTorch-CPU fp32 reference of the same op
+(floating-point kernels) or with the C oracle / golden vectors (fps: bit-exact indices)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from rdpn6d_amd import _lib
+
+    lib = _lib.load()
+    assert lib.rdpn6d_device_count() >= 1
+    return torch.device("cuda:0")
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def _close(a, b, tol, what):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item()
+    assert err <= tol * max(ref, 1.0), f"{what}: max abs err {err:.3e} (ref max {ref:.3e})"
+
+
+CONV_CASES = [
+    # B, H, Cin, Cout, k, stride, pad, res, act
+    (2, 16, 16, 64, 3, 1, 1, False, 1),
+    (2, 16, 64, 64, 3, 1, 1, True, 1),
+    (3, 16, 64, 128, 3, 2, 1, False, 1),
+    (3, 16, 64, 128, 1, 2, 0, False, 0),
+    (2, 8, 256, 256, 3, 1, 1, True, 1),
+    (1, 64, 256, 256, 3, 1, 1, False, 1),   # large M: 128x128 tiles
+    (2, 32, 256, 37, 1, 1, 0, False, 0),    # ragged N
+    (2, 64, 48, 128, 3, 2, 1, False, 0),
+    (5, 1, 512, 1024, 1, 1, 0, False, 2),   # FC-like, leaky
+    (2, 7, 32, 64, 3, 1, 1, False, 1),      # odd spatial, M not multiple of the tile
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_igemm(dev, case):
+    from rdpn6d_amd import ops
+
+    B, H, Cin, Cout, k, stride, pad, use_res, act = case
+    g = torch.Generator().manual_seed(hash(case) % (2**31))
+    x = torch.randn(B, Cin, H, H, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    scale = torch.rand(Cout, generator=g) + 0.5
+    shift = torch.randn(Cout, generator=g) * 0.1
+    ref = F.conv2d(x, w, None, stride, pad) * scale[None, :, None, None] + shift[None, :, None, None]
+    res = None
+    if use_res:
+        res = torch.randn(ref.shape, generator=g)
+        ref = ref + res
+    if act == 1:
+        ref = F.relu(ref)
+    elif act == 2:
+        ref = F.leaky_relu(ref, 0.1)
+    y = ops.conv2d_nhwc(nhwc(x).to(dev), w.to(dev), scale.to(dev), shift.to(dev), stride, pad,
+                        residual=nhwc(res).to(dev) if use_res else None, act=act, slope=0.1)
+    torch.cuda.synchronize()
+    _close(nchw(y), ref, 2e-5, f"conv {case}")
+
+
+def test_conv_channel_slices(dev):
+    """input read from a channel slice, output written into a slice of a wider buffer (free concat)."""
+    from rdpn6d_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    xfull = torch.randn(2, 10, 10, 48, generator=g)
+    w = torch.randn(20, 16, 1, 1, generator=g)
+    out = torch.full((2, 10, 10, 40), 7.0)
+    o = ops.conv2d_nhwc(xfull.to(dev), w.to(dev), in_co=16, out=out.to(dev), out_co=8)
+    torch.cuda.synchronize()
+    ref = F.conv2d(nchw(xfull[..., 16:32]), w)
+    _close(nchw(o[..., 8:28]), ref, 2e-5, "slice conv")
+    assert (o[..., :8] == 7).all() and (o[..., 28:] == 7).all()
+
+
+def test_force_tiles(dev):
+    """every tile configuration gives the same answer."""
+    from rdpn6d_amd import _lib, ops
+
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 64, 12, 12, generator=g)
+    w = torch.randn(128, 64, 3, 3, generator=g) / 24
+    ref = F.conv2d(x, w, None, 1, 1)
+    try:
+        for bm, bn in ((128, 128), (128, 64), (64, 128), (64, 64)):
+            lib.rdpn6d_conv_force_tile(bm, bn)
+            y = ops.conv2d_nhwc(nhwc(x).to(dev), w.to(dev), stride=1, pad=1)
+            torch.cuda.synchronize()
+            _close(nchw(y), ref, 2e-5, f"tile {bm}x{bn}")
+    finally:
+        lib.rdpn6d_conv_force_tile(0, 0)
+
+
+def test_stem(dev):
+    from rdpn6d_amd import ops
+
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 6, 64, 64, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) / 12
+    sc, sh = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    ref = F.relu(F.conv2d(x[:, :3], w, None, 2, 3) * sc[None, :, None, None] + sh[None, :, None, None])
+    y = ops.stem_conv7x7(x.to(dev), w.to(dev), sc.to(dev), sh.to(dev))
+    torch.cuda.synchronize()
+    _close(nchw(y), ref, 2e-5, "stem")
+
+
+def test_maxpool_upsample_gmax_gn(dev):
+    from rdpn6d_amd import ops
+
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 64, 18, 18, generator=g)
+    _close(nchw(ops.maxpool3x3s2(nhwc(x).to(dev))), F.max_pool2d(x, 3, 2, 1), 0, "maxpool")
+    x = torch.randn(2, 32, 8, 8, generator=g)
+    _close(nchw(ops.upsample_bilinear(nhwc(x).to(dev), 4)), F.interpolate(x, scale_factor=4, mode="bilinear", align_corners=True),
+           2e-6, "upsample")
+    x = torch.randn(3, 64, 6, 5, generator=g)
+    buf = torch.zeros(3, 6, 5, 128)
+    buf[..., :64] = nhwc(x)
+    o = ops.global_max_concat_(buf.to(dev), 64).cpu()
+    assert torch.equal(o[..., 64:], x.amax(dim=(2, 3))[:, None, None, :].expand(3, 6, 5, 64))
+    assert torch.equal(o[..., :64], nhwc(x))
+    x = torch.randn(3, 128, 8, 8, generator=g) * 2 + 0.3
+    ga, be = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g) * 0.1
+    ref = F.relu(F.group_norm(x, 32, ga, be, 1e-5))
+    y = ops.groupnorm_relu_(nhwc(x).to(dev), 32, ga.to(dev), be.to(dev))
+    _close(nchw(y), ref, 1e-5, "groupnorm")
+
+
+def test_fps_bit_exact(dev, oracle_lib, golden_dir):
+    from rdpn6d_amd import ops
+    from tests.fps_cases import fps_cases, make_cloud
+
+    gold = np.load(os.path.join(golden_dir, "fps_golden.npz"))
+    for name, kind, n, sn, seed, mode in fps_cases():
+        pts = make_cloud(kind, n, seed)
+        if mode == "center":
+            _, idx = ops.farthest_point_sampling(pts, sn, init_center=True)
+        else:
+            _, idx = ops.farthest_point_sampling(pts, sn, start=int(mode))
+        assert np.array_equal(idx, gold[name]), f"{name}: {idx[:8]} vs {gold[name][:8]}"
+
+
+def test_fps_reference_symbols(dev, oracle_lib):
+    """the two reference-named void symbols (ext.h) with host pointers."""
+    from rdpn6d_amd import _lib
+    from tests.fps_cases import make_cloud
+
+    lib = _lib.load()
+    P = ctypes.c_void_p
+    pts = make_cloud("gauss", 3000, 21)
+    idx = np.zeros(16, dtype=np.int32)
+    lib.farthest_point_sampling_init_center(pts.ctypes.data_as(P), idx.ctypes.data_as(P), 3000, 16)
+    want = np.zeros(16, dtype=np.int32)
+    oracle_lib.oracle_fps_init_center(pts.ctypes.data_as(P), want.ctypes.data_as(P), 3000, 16)
+    assert np.array_equal(idx, want)
+    lib.farthest_point_sampling(pts.ctypes.data_as(P), idx.ctypes.data_as(P), 3000, 16)  # random start
+    oracle_lib.oracle_fps_from_start(pts.ctypes.data_as(P), want.ctypes.data_as(P), 3000, 16, int(idx[0]))
+    assert np.array_equal(idx, want)
+
+
+# ----------------------------------------------------------------------------- whole path vs golden
+@pytest.fixture(scope="module")
+def golden_setup(dev, golden_dir):
+    from rdpn6d_amd import synth
+    from rdpn6d_amd.config import gdrn_base_cfg
+    from rdpn6d_amd.gdrn import build_model_optimizer
+
+    gold = np.load(os.path.join(golden_dir, "model_c1.npz"))
+    bn = np.load(os.path.join(golden_dir, "bn_stats_c1.npz"))
+    inp = synth.make_inputs(4, seed=0)
+    assert synth.sha256_of([inp[k] for k in sorted(inp)]) == str(gold["sha256_inputs"])
+    models = {}
+    for att in ("none", "mul"):
+        cfg = gdrn_base_cfg(mask_attention=att, device="cuda")
+        model, _ = build_model_optimizer(cfg)
+        sd = synth.make_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=1234)
+        sd.update({k: bn[k] for k in bn.files})
+        assert synth.sha256_of([sd[k] for k in sorted(sd) if not k.endswith("num_batches_tracked")]) == str(gold["sha256_weights"])
+        model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+        model.eval()
+        models[att] = model
+    t = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
+    return models, t, gold
+
+
+def _run(model, t):
+    with torch.no_grad():
+        o = model(t["roi_img"], roi_classes=t["roi_cls"], roi_coord_2d=t["roi_coord_2d"], roi_cams=t["roi_cam"],
+                  roi_centers=t["roi_center"], roi_whs=t["roi_wh"], roi_extents=t["roi_extent"],
+                  resize_ratios=t["resize_ratio"], do_loss=False, fps=t["fps"])
+    torch.cuda.synchronize()
+    return o
+
+
+def test_model_maps_vs_reference_golden(golden_setup):
+    """tier (i): dense maps vs the reference's own outputs, fp32 path, <= 1e-4 max-abs."""
+    models, t, gold = golden_setup
+    o = _run(models["none"], t)
+    for k in ("mask", "coor_x", "coor_y", "coor_z", "region"):
+        err = np.abs(o[k].cpu().numpy() - gold["eval_" + k]).max()
+        print(f"{k}: max abs err vs reference {err:.3e}")
+        assert err < 1e-4, (k, err)
+    am = models["none"].plan(4, t["roi_img"].device).argmax.cpu().numpy().reshape(4, 64, 64)
+    agree = (am == gold["eval_region_argmax"]).mean()
+    print("region arg-max agreement", agree)
+    assert agree > 0.9995
+
+
+@pytest.mark.parametrize("att", ["none", "mul"])
+def test_model_pose_vs_reference_golden(golden_setup, att):
+    """tier (iii): end-to-end pose, relative error <= 1e-4 (batch Frobenius) vs the reference."""
+    models, t, gold = golden_setup
+    o = _run(models[att], t)
+    R, T = gold[f"eval_{att}_rot"], gold[f"eval_{att}_trans"]
+    r, tr = o["rot"].cpu().numpy(), o["trans"].cpu().numpy()
+    er = np.linalg.norm(r - R) / np.linalg.norm(R)
+    et = np.linalg.norm(tr - T) / np.linalg.norm(T)
+    worst_r = max(np.linalg.norm(r[i] - R[i]) / np.linalg.norm(R[i]) for i in range(4))
+    worst_t = max(np.linalg.norm(tr[i] - T[i]) / np.linalg.norm(T[i]) for i in range(4))
+    print(f"[{att}] pose rel err: R {er:.3e} (worst {worst_r:.3e})  t {et:.3e} (worst {worst_t:.3e})")
+    assert er < 1e-4 and et < 1e-4
+    assert np.allclose(np.linalg.det(r), 1.0, atol=1e-5)
+
+
+def test_model_vs_oracle_other_batch(golden_setup, dev):
+    """a batch the golden file does not hold (B=3, other seed): HIP path vs the torch-CPU oracle."""
+    from oracle import model_oracle
+    from rdpn6d_amd import synth
+
+    models, _, _ = golden_setup
+    model = models["mul"]
+    orc = model_oracle.GDRNOracle(32, "mul")
+    orc.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()}, strict=True)
+    orc.eval()
+    inp = synth.make_inputs(3, seed=7)
+    tc = {k: torch.from_numpy(v) for k, v in inp.items()}
+    with torch.no_grad():
+        oo = orc(tc["roi_img"], tc["roi_coord_2d"], tc["fps"], tc["roi_cam"], tc["roi_center"], tc["roi_wh"], tc["resize_ratio"])
+    o = _run(model, {k: v.to(dev) for k, v in tc.items()})
+    for k in ("mask", "coor_x", "region"):
+        _close(o[k], oo[k], 1e-4, k)
+    assert np.linalg.norm(o["rot"].cpu().numpy() - oo["rot"].numpy()) / np.linalg.norm(oo["rot"].numpy()) < 1e-4
+    assert np.linalg.norm(o["trans"].cpu().numpy() - oo["trans"].numpy()) / np.linalg.norm(oo["trans"].numpy()) < 1e-4

@@ -1,0 +1,114 @@
+"""Host logic: config loader semantics, model factory surface, state_dict contract, weight packing."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from rdpn6d_amd.config import Config, gdrn_base_cfg
+from rdpn6d_amd.gdrn import build_model_optimizer, fold_bn, pack_conv_weight, BNP
+
+
+def test_config_base_merge_and_delete(tmp_path):
+    (tmp_path / "base.py").write_text("A = dict(x=1, y=dict(p=1, q=2))\nS = dict(OPT=dict(type='RMSprop', lr=1, momentum=0))\n")
+    (tmp_path / "child.py").write_text(
+        "_base_ = './base.py'\nA = dict(y=dict(q=3), z=5)\nS = dict(OPT=dict(_delete_=True, type='Ranger', lr=1e-4))\n")
+    cfg = Config.fromfile(str(tmp_path / "child.py"))
+    assert cfg.A.x == 1 and cfg.A.y.p == 1 and cfg.A.y.q == 3 and cfg.A.z == 5
+    assert dict(cfg.S.OPT) == {"type": "Ranger", "lr": 1e-4}
+    cfg.merge_from_dict(["A.y.q=7", "A.name=abc", "NEW.K=[1,2]"])
+    assert cfg.A.y.q == 7 and cfg.A.name == "abc" and cfg.NEW.K == [1, 2]
+    assert cfg.A.get("nope", 4) == 4
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/configs"), reason="reference configs only exist in the build container")
+def test_loads_reference_config_files_unchanged():
+    cfg = Config.fromfile("/root/reference/configs/gdrn/lm/a6_cPnP_lm13.py")
+    assert cfg.MODEL.CDPN.ROT_HEAD.NUM_REGIONS == 32 and cfg.MODEL.CDPN.PNP_NET.ROT_TYPE == "allo_rot6d"
+    assert cfg.MODEL.CDPN.BACKBONE.NUM_LAYERS == 34 and cfg.SOLVER.OPTIMIZER_CFG.type == "Ranger"
+    assert "momentum" not in cfg.SOLVER.OPTIMIZER_CFG  # _delete_=True honoured
+    assert cfg.INPUT.FORMAT == "BGR" and cfg.TEST.USE_PNP is False
+    ours = gdrn_base_cfg()
+    for sec in ("BACKBONE", "ROT_HEAD", "PNP_NET"):
+        for k, v in ours.MODEL.CDPN[sec].items():
+            if k == "PRETRAINED":
+                continue
+            assert cfg.MODEL.CDPN[sec][k] == v, (sec, k)
+
+
+def test_factory_surface():
+    cfg = gdrn_base_cfg(device="cpu")
+    model, opt = build_model_optimizer(cfg)
+    assert "type" not in cfg.MODEL.CDPN.PNP_NET.PNP_HEAD_CFG  # popped in place like the reference
+    assert len(model.state_dict()) == 305
+    assert sum(p.numel() for p in model.parameters()) == 36403630
+    sd = model.state_dict()
+    assert tuple(sd["rot_head_net.features.0.weight"].shape) == (1024, 256, 3, 3)
+    assert tuple(sd["rot_head_net.features.21.weight"].shape) == (37, 256, 1, 1)
+    assert tuple(sd["pnp_net.features.0.weight"].shape) == (128, 43, 3, 3)
+    assert tuple(sd["pnp_net.fc1.weight"].shape) == (1024, 8192)
+    assert len(opt.param_groups) == 3
+    bad = gdrn_base_cfg(device="cpu")
+    bad.MODEL.CDPN.PNP_NET.ROT_TYPE = "nonsense"
+    with pytest.raises(ValueError):
+        build_model_optimizer(bad)
+    bad = gdrn_base_cfg(device="cpu")
+    bad.MODEL.CDPN.PNP_NET.PNP_HEAD_CFG.type = "Other"
+    with pytest.raises(ValueError):
+        build_model_optimizer(bad)
+    # K = 64 (the reference cannot build this: nIn is hard-coded to 43)
+    model64, _ = build_model_optimizer(gdrn_base_cfg(num_regions=64, device="cpu"))
+    assert tuple(model64.state_dict()["pnp_net.features.0.weight"].shape) == (128, 75, 3, 3)
+    with pytest.raises(NotImplementedError):
+        model(torch.zeros(1, 6, 256, 256), do_loss=True)
+
+
+def test_weight_packing_and_bn_fold():
+    w = torch.arange(2 * 3 * 3 * 3, dtype=torch.float32).reshape(2, 3, 3, 3)
+    p = pack_conv_weight(w)
+    assert tuple(p.shape) == (64, 9, 16)
+    assert p[1, 4, 2] == w[1, 2, 1, 1] and p[0, 0, 1] == w[0, 1, 0, 0]
+    assert p[2:].abs().sum() == 0 and p[:, :, 3:].abs().sum() == 0
+    bn = BNP(4)
+    with torch.no_grad():
+        bn.weight.copy_(torch.tensor([1.0, 2.0, 0.5, 1.5]))
+        bn.bias.copy_(torch.tensor([0.1, -0.2, 0.3, 0.0]))
+        bn.running_mean.copy_(torch.tensor([0.5, -1.0, 2.0, 0.0]))
+        bn.running_var.copy_(torch.tensor([1.0, 4.0, 0.25, 9.0]))
+    sc, sh = fold_bn(bn, conv_bias=torch.tensor([1.0, 1.0, 1.0, 1.0]))
+    x = torch.randn(5, 4)
+    ref = torch.nn.functional.batch_norm(x + 1.0, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, 1e-5)
+    assert torch.allclose(x * sc[:4] + sh[:4], ref, atol=1e-6)
+    assert sc.numel() == 64 and (sc[4:] == 1).all() and (sh[4:] == 0).all()
+
+
+def test_ranger_matches_reference_rule():
+    """one tensor, a few steps, against a literal per-tensor restatement of the update rule."""
+    import math
+    from rdpn6d_amd.ranger import Ranger
+
+    torch.manual_seed(0)
+    p = torch.nn.Parameter(torch.randn(4, 3, 3, 3))
+    q = p.detach().clone()
+    opt = Ranger([p], lr=1e-2)
+    m, v, slow = torch.zeros_like(q), torch.zeros_like(q), q.clone()
+    b1, b2, eps, lr = 0.95, 0.999, 1e-5, 1e-2
+    for step in range(1, 14):
+        g = torch.randn_like(q)
+        p.grad = g.clone()
+        opt.step()
+        g = g - g.mean(dim=(1, 2, 3), keepdim=True)
+        v = v * b2 + (1 - b2) * g * g
+        m = m * b1 + (1 - b1) * g
+        b2t = b2 ** step
+        nmax = 2 / (1 - b2) - 1
+        nsma = nmax - 2 * step * b2t / (1 - b2t)
+        if nsma > 5:
+            ss = math.sqrt((1 - b2t) * (nsma - 4) / (nmax - 4) * (nsma - 2) / nsma * nmax / (nmax - 2)) / (1 - b1 ** step)
+            q = q - ss * lr * m / (v.sqrt() + eps)
+        else:
+            q = q - lr / (1 - b1 ** step) * m
+        if step % 6 == 0:
+            slow = slow + 0.5 * (q - slow)
+            q = slow.clone()
+        assert torch.allclose(p.detach(), q, atol=1e-6), step
