@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Throughput of the RDPN6D hot path on MI355X: RGB-D crops/s, forward + pose solve, 256x256.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one device-resident synthetic batch of 64 crops
+(BASELINE.json configs[1]: LM 13-object inference, batch 64, 256x256): stem -> ResNet-34 trunk ->
+point-wise depth fusion -> dense mask/residual/region head -> glue -> ConvPnPNet -> pose decode
+(+ the per-crop RANSAC/Kabsch solve when built).  Inference shards with no collective: each rank
+runs its own batch ("weak" scaling); value = all ranks' crops / max-over-ranks time.
+
+Prints ONE JSON line (rank 0) with the driver's contract plus
+  "roofline"     - the dominant kernel (conv_igemm_f32_kernel<128,128>) timed live with events on the
+                   launch stream: algorithmic FLOPs of its launches / their total duration vs the fp32
+                   MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md);
+  "cpu_baseline" - the torch-CPU oracle (a port of the reference path, pinned to it by golden vectors)
+                   timed on this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def build_model(device, mask_attention="none"):
+    from rdpn6d_amd import synth
+    from rdpn6d_amd.config import gdrn_base_cfg
+    from rdpn6d_amd.gdrn import build_model_optimizer
+
+    cfg = gdrn_base_cfg(mask_attention=mask_attention, device=str(device))
+    model, _ = build_model_optimizer(cfg)
+    sd = synth.make_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=1234)
+    bn = np.load(os.path.join(ROOT, "tests", "golden", "bn_stats_c1.npz"))
+    sd.update({k: bn[k] for k in bn.files})
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    model.eval()
+    return model, sd
+
+
+def step(model, t):
+    return model(t["roi_img"], roi_classes=t["roi_cls"], roi_coord_2d=t["roi_coord_2d"], roi_cams=t["roi_cam"],
+                 roi_centers=t["roi_center"], roi_whs=t["roi_wh"], roi_extents=t["roi_extent"],
+                 resize_ratios=t["resize_ratio"], do_loss=False, fps=t["fps"])
+
+
+def conv_flops(d):
+    return 2.0 * d.B * d.Ho * d.Wo * d.N * d.ntaps * d.Cin
+
+
+def roofline(model, t, B, device, reps=3):
+    """Event-time every launch of the dominant conv kernel instance inside a real forward."""
+    from rdpn6d_amd import _lib
+
+    plan = model.plan(B, device)
+    lib = plan.lib
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    sel = []
+    for L in plan.launches + plan.post:
+        if L.keep:
+            d = L.keep[0]
+            bm, bn = ctypes.c_int(), ctypes.c_int()
+            lib.rdpn6d_conv_tile_for(ctypes.byref(d), ctypes.byref(bm), ctypes.byref(bn))
+            if (bm.value, bn.value) == (128, 128):
+                sel.append(L)
+    flops = sum(conv_flops(L.keep[0]) for L in sel)
+    total_ms, n = 0.0, 0
+    step(model, t)
+    for _ in range(reps):
+        # replay the plan with events around the selected launches (same stream the kernels run on)
+        x = t["roi_img"]
+        _lib.check(lib.rdpn6d_stem_conv7x7_f32(ctypes.c_void_p(x.data_ptr()), plan.stem_args[0], x.shape[1], *plan.stem_args[2:], st))
+        _lib.check(lib.rdpn6d_xyz_subsample_f32(ctypes.c_void_p(x.data_ptr()), plan.xyz_args[0], x.shape[1], *plan.xyz_args[2:], st))
+        evs = []
+        for L in plan.launches:
+            if L in sel:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                _lib.check(L.fn(*L.args, st), L.name)
+                e1.record()
+                evs.append((e0, e1))
+            else:
+                _lib.check(L.fn(*L.args, st), L.name)
+        torch.cuda.synchronize()
+        total_ms += sum(a.elapsed_time(b) for a, b in evs)
+        n += len(evs)
+    avg_ms = total_ms / max(n, 1)
+    achieved = flops / len(sel) / (avg_ms * 1e-3) / 1e12 if sel else 0.0
+    return {
+        "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+        "kernel": "conv_igemm_f32_kernel<128,128>", "launches_per_step": len(sel),
+        "avg_launch_ms": round(avg_ms, 4), "algorithmic_gflop_per_launch": round(flops / max(len(sel), 1) / 1e9, 2),
+        "share_of_step_flops": round(flops / (44.10e9 * B), 3),
+    }
+
+
+def cpu_baseline(sd, budget_s=20.0):
+    """torch-CPU oracle (port of the reference path) on a bounded sample: B=4 batches for ~budget_s."""
+    from oracle import model_oracle
+    from rdpn6d_amd import synth
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    m = model_oracle.GDRNOracle(32, "none")
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    m.eval()
+    inp = {k: torch.from_numpy(v) for k, v in synth.make_inputs(4, seed=0).items()}
+    args = (inp["roi_img"], inp["roi_coord_2d"], inp["fps"], inp["roi_cam"], inp["roi_center"], inp["roi_wh"], inp["resize_ratio"])
+    with torch.no_grad():
+        m(*args)
+        t0, it = time.perf_counter(), 0
+        while True:
+            m(*args)
+            it += 1
+            dt = time.perf_counter() - t0
+            if dt > budget_s or it >= 200:
+                break
+    return {"value": round(4 * it / dt, 2), "unit": "crops/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{it} forward passes of a B=4 batch (256x256, fp32, torch-CPU oracle incl. pose decode), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="crops per GPU per step (BASELINE configs[1]: 64)")
+    ap.add_argument("--mask-attention", default="none", choices=["none", "mul"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from rdpn6d_amd import synth
+
+    model, sd = build_model(device, args.mask_attention)
+    B = args.batch
+    t = {k: torch.from_numpy(v).to(device) for k, v in synth.make_inputs(B, seed=100 + rank).items()}
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step(model, t)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(model, t)
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        barrier()
+    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    roof, cpu = None, None
+    if rank == 0:
+        with torch.no_grad():
+            roof = roofline(model, t, B, device)
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(sd)
+    if dist is not None:
+        dist.barrier()
+    if rank == 0:
+        value = world * B * args.steps / elapsed
+        line = {
+            "metric": "RGB-D crops/sec (fwd+PnP) at 256x256", "value": round(value, 1), "unit": "crops/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "LM 13-object inference, batch=64 per GPU, 256x256 RGB-D crops, K=32 regions, "
+                                   "ResNet-34 trunk + dense head + ConvPnPNet + pose decode, fps+PnP on-device",
+                       "batch_per_gpu": B, "global_batch": B * world, "mask_attention": args.mask_attention,
+                       "parallelism": f"replicated weights, {world} independent shard(s), no collective"},
+            "achieved_tflops_whole_step": round(44.10e9 * value / 1e12, 2),
+            "roofline": roof,
+        }
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

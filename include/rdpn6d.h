@@ -76,6 +76,10 @@ typedef struct {
     float slope;
 } rdpn6d_conv_desc;
 int rdpn6d_conv2d_f32(const rdpn6d_conv_desc* d, void* stream);
+/* tile configuration (BM x BN) the launcher picks for this descriptor - used to attribute rocprof
+ * kernel names / roofline figures to layers; rdpn6d_conv_force_tile(0,0) restores the heuristic */
+int rdpn6d_conv_tile_for(const rdpn6d_conv_desc* d, int* bm, int* bn);
+void rdpn6d_conv_force_tile(int bm, int bn);
 
 /* ------------------------------------------------------------------ stem & point-wise kernels
  * conv1 7x7/2 + BN + ReLU on channels 0..2 of the NCHW 6-channel crop (resnet_backbone.py:272,

@@ -36,6 +36,8 @@ SIGNATURES = {
     "rdpn6d_fps_host": (_i, [_vp, _vp, _i, _i, _i]),
     "rdpn6d_fps_device": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "rdpn6d_conv2d_f32": (_i, [ctypes.POINTER(ConvDesc), _vp]),
+    "rdpn6d_conv_tile_for": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp]),
+    "rdpn6d_conv_force_tile": (None, [_i, _i]),
     "rdpn6d_stem_conv7x7_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "rdpn6d_maxpool3x3s2_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "rdpn6d_upsample_bilinear_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
@@ -64,11 +66,6 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
             fn.restype = res
             fn.argtypes = args
-        try:
-            fn = lib.rdpn6d_conv_force_tile
-            fn.restype, fn.argtypes = None, [_i, _i]
-        except AttributeError:
-            pass
         _lib = lib
     return _lib
 

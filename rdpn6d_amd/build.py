@@ -8,6 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librdpn6d_hip.so")
 SOURCES = ["api.cpp", "conv_igemm.hip", "pointwise.hip", "fps.hip", "ransac.hip"]
+NO_CONTRACT = {"fps.hip", "ransac.hip"}  # bit-exact integer outputs depend on un-fused fp32 arithmetic
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -29,7 +30,8 @@ def build(force=False, verbose=True):
     for src in SOURCES:
         obj = os.path.join(HERE, "build", src + ".o")
         objs.append(obj)
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        extra = ["-ffp-contract=off"] if src in NO_CONTRACT else []
+        cmd = [hipcc] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", obj]
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     for src, p in procs:
         out, _ = p.communicate()

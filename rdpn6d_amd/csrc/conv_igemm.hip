@@ -193,6 +193,27 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs a)
 static int g_force_bm = 0, g_force_bn = 0;
 extern "C" void rdpn6d_conv_force_tile(int bm, int bn) { g_force_bm = bm; g_force_bn = bn; }
 
+static void conv_pick_tile(const rdpn6d_conv_desc* d, long long M, int* pbm, int* pbn)
+{
+    int bn = (d->Npad % 128 == 0) ? 128 : 64;
+    int bm = 128;
+    // small problems: prefer more, smaller tiles so that all 256 CUs get work
+    if ((long long)rd_cdiv(M, 128) * (d->Npad / bn) < 512) bm = 64;
+    if (bm == 64 && bn == 128 && (long long)rd_cdiv(M, 64) * (d->Npad / 128) < 512) bn = 64;
+    if (g_force_bm) bm = g_force_bm;
+    if (g_force_bn && d->Npad % g_force_bn == 0) bn = g_force_bn;
+    *pbm = bm;
+    *pbn = bn;
+}
+
+// which tile configuration rdpn6d_conv2d_f32 will use for this descriptor (for profiling / roofline)
+extern "C" int rdpn6d_conv_tile_for(const rdpn6d_conv_desc* d, int* bm, int* bn)
+{
+    RD_REQUIRE(d && bm && bn, "null pointer");
+    conv_pick_tile(d, (long long)d->B * d->Ho * d->Wo, bm, bn);
+    return RDPN6D_OK;
+}
+
 extern "C" int rdpn6d_conv2d_f32(const rdpn6d_conv_desc* d, void* stream)
 {
     RD_REQUIRE(d && d->x && d->w && d->y, "null pointer");
@@ -214,13 +235,8 @@ extern "C" int rdpn6d_conv2d_f32(const rdpn6d_conv_desc* d, void* stream)
     a.nk = d->ntaps * a.cchunks;
     a.Ktot = d->ntaps * d->Cin;
     a.linear_out = (d->osy == 1 && d->osx == 1 && d->ooy == 0 && d->oox == 0 && d->OH == d->Ho && d->OW == d->Wo);
-    int bn = (d->Npad % 128 == 0) ? 128 : 64;
-    int bm = 128;
-    // small problems: prefer more, smaller tiles so that all 256 CUs get work
-    if ((long long)rd_cdiv(a.M, 128) * (d->Npad / bn) < 512) bm = 64;
-    if (bm == 64 && bn == 128 && (long long)rd_cdiv(a.M, 64) * (d->Npad / 128) < 512) bn = 64;
-    if (g_force_bm) bm = g_force_bm;
-    if (g_force_bn && d->Npad % g_force_bn == 0) bn = g_force_bn;
+    int bm, bn;
+    conv_pick_tile(d, a.M, &bm, &bn);
     a.mtiles = rd_cdiv(a.M, bm);
     a.ntiles = d->Npad / bn;
     dim3 grid((unsigned)(a.mtiles * a.ntiles)), block(256);

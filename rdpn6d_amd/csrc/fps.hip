@@ -19,6 +19,11 @@
 #include <stdlib.h>
 #include <time.h>
 
+// HIP's __fmul_rn/__fadd_rn are plain operators, so the compiler's default fp-contract=fast would
+// still fuse them into FMAs: contraction is switched off for this whole translation unit (and the
+// build passes -ffp-contract=off for this file as well).
+#pragma clang fp contract(off)
+
 #define FPS_THREADS 1024
 
 __device__ __forceinline__ float fps_sqdist(float px, float py, float pz, float cx, float cy, float cz)
