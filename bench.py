@@ -8,7 +8,7 @@
 One step = one pass of the hot path over one device-resident synthetic batch of 64 crops
 (BASELINE.json configs[1]: LM 13-object inference, batch 64, 256x256): stem -> ResNet-34 trunk ->
 point-wise depth fusion -> dense mask/residual/region head -> glue -> ConvPnPNet -> pose decode
-(+ the per-crop RANSAC/Kabsch solve when built).  Inference shards with no collective: each rank
++ the per-crop RANSAC/Kabsch pose solve.  Inference shards with no collective: each rank
 runs its own batch ("weak" scaling); value = all ranks' crops / max-over-ranks time.
 
 Prints ONE JSON line (rank 0) with the driver's contract plus
@@ -40,6 +40,7 @@ def build_model(device, mask_attention="none"):
     from rdpn6d_amd.gdrn import build_model_optimizer
 
     cfg = gdrn_base_cfg(mask_attention=mask_attention, device=str(device))
+    cfg.TEST.USE_PNP = True  # the step includes the per-crop RANSAC/Kabsch solve ("fwd+PnP")
     model, _ = build_model_optimizer(cfg)
     sd = synth.make_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=1234)
     bn = np.load(os.path.join(ROOT, "tests", "golden", "bn_stats_c1.npz"))
@@ -107,28 +108,40 @@ def roofline(model, t, B, device, reps=3):
 
 
 def cpu_baseline(sd, budget_s=20.0):
-    """torch-CPU oracle (port of the reference path) on a bounded sample: B=4 batches for ~budget_s."""
+    """torch-CPU oracle (port of the reference path) on a bounded sample of the same workload.
+
+    oneDNN's small convolutions scale badly past a few dozen threads, so the thread count is chosen by
+    a short sweep (the best one is what gets reported as ``cores``) before the timed ~budget_s run."""
     from oracle import model_oracle
     from rdpn6d_amd import synth
 
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     m = model_oracle.GDRNOracle(32, "none")
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
     m.eval()
     inp = {k: torch.from_numpy(v) for k, v in synth.make_inputs(4, seed=0).items()}
     args = (inp["roi_img"], inp["roi_coord_2d"], inp["fps"], inp["roi_cam"], inp["roi_center"], inp["roi_wh"], inp["resize_ratio"])
+    best_nt, best = 1, float("inf")
     with torch.no_grad():
-        m(*args)
+        for nt in sorted({min(n, ncpu) for n in (8, 16, 32, 64)}):
+            torch.set_num_threads(nt)
+            m(*args)
+            t0 = time.perf_counter()
+            m(*args)
+            dt = time.perf_counter() - t0
+            if dt < best:
+                best_nt, best = nt, dt
+        torch.set_num_threads(best_nt)
         t0, it = time.perf_counter(), 0
         while True:
             m(*args)
             it += 1
             dt = time.perf_counter() - t0
-            if dt > budget_s or it >= 200:
+            if dt > budget_s or it >= 400:
                 break
-    return {"value": round(4 * it / dt, 2), "unit": "crops/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{it} forward passes of a B=4 batch (256x256, fp32, torch-CPU oracle incl. pose decode), {dt:.1f} s"}
+    return {"value": round(4 * it / dt, 2), "unit": "crops/s", "cores": best_nt, "kind": "port",
+            "sample": f"{it} forward passes of a B=4 batch (256x256, fp32, torch-CPU oracle incl. glue + pose decode) in "
+                      f"{dt:.1f} s with {best_nt} threads (best of an 8/16/32/64 sweep; host has {ncpu} logical CPUs)"}
 
 
 def main():
@@ -197,7 +210,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "LM 13-object inference, batch=64 per GPU, 256x256 RGB-D crops, K=32 regions, "
-                                   "ResNet-34 trunk + dense head + ConvPnPNet + pose decode, fps+PnP on-device",
+                                   "ResNet-34 trunk + dense head + ConvPnPNet + pose decode + per-crop RANSAC/Kabsch (100 hyp.), all on-device",
                        "batch_per_gpu": B, "global_batch": B * world, "mask_attention": args.mask_attention,
                        "parallelism": f"replicated weights, {world} independent shard(s), no collective"},
             "achieved_tflops_whole_step": round(44.10e9 * value / 1e12, 2),

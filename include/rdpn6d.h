@@ -137,6 +137,11 @@ int rdpn6d_ransac_kabsch_f32(const float* out_nchw, const float* coord2d, const 
                              const float* resize_ratios, const int* region_argmax, int B, int HW, int K,
                              float mask_thr, float inlier_thr, int iters, float confidence, unsigned seed,
                              float* pose_out, int* n_inliers, unsigned char* inlier_mask, void* stream);
+/* same, additionally reporting the index of the winning hypothesis per crop (-1 = none) */
+int rdpn6d_ransac_kabsch_ex(const float* out_nchw, const float* coord2d, const float* fps, const float* extents,
+                            const float* resize_ratios, const int* region_argmax, int B, int HW, int K,
+                            float mask_thr, float inlier_thr, int iters, float confidence, unsigned seed,
+                            float* pose_out, int* n_inliers, unsigned char* inlier_mask, int* best_hyp, void* stream);
 
 #ifdef __cplusplus
 }

@@ -399,6 +399,11 @@ class InferencePlan:
         self._fc("pnp_net.fc_r|fc_t", f2, wrt.shape[1], wrtp, brt, self.rt, 9, act=0, out_cs=16)
         self.rot = self.buf("rot", B, 3, 3)
         self.trans = self.buf("trans", B, 3)
+        # outputs of the optional RANSAC / Kabsch solve (cfg.TEST.USE_PNP)
+        self.pnp_pose = self.buf("pnp_pose", B, 12)
+        self.pnp_ninl = self.buf("pnp_ninl", B, dtype=torch.int32)
+        self.pnp_mask = self.buf("pnp_mask", B, HW, dtype=torch.uint8)
+        self.pnp_best = self.buf("pnp_best", B, dtype=torch.int32)
         self.launches = main
 
     def _fc(self, name, x, kin, wp, bias, y, nout, act, out_cs=None):
@@ -421,6 +426,16 @@ class InferencePlan:
         _lib.check(lib.rdpn6d_pose_decode_f32(_ptr(self.rt), 16, _ptr(roi_cams), _ptr(roi_centers), _ptr(roi_whs),
                                               _ptr(resize_ratios), B, 1 if is_allo else 0, 1 if train_pose else 0,
                                               _ptr(self.rot), _ptr(self.trans), st), "pose_decode")
+
+    def run_ransac(self, roi_coord_2d, fps, roi_extents, resize_ratios, mask_thr=0.5, inlier_thr=0.01, iters=100,
+                   confidence=0.99, seed=0):
+        """per-crop RANSAC + Kabsch on the maps the last run() left in out_nchw / argmax"""
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        HW = self.out_nchw.shape[2] * self.out_nchw.shape[3]
+        _lib.check(self.lib.rdpn6d_ransac_kabsch_ex(
+            _ptr(self.out_nchw), _ptr(roi_coord_2d), _ptr(fps), _ptr(roi_extents), _ptr(resize_ratios), _ptr(self.argmax),
+            self.B, HW, self.K, mask_thr, inlier_thr, iters, confidence, seed, _ptr(self.pnp_pose), _ptr(self.pnp_ninl),
+            _ptr(self.pnp_mask), _ptr(self.pnp_best), st), "ransac_kabsch")
 
 
 # ----------------------------------------------------------------------------- the model
@@ -496,11 +511,25 @@ class GDRN(nn.Module):
         plan.run(x, roi_coord_2d, fps, roi_cams, roi_centers, roi_whs, resize_ratios, is_allo="allo" in pcfg.ROT_TYPE)
         o = plan.out_nchw
         K = plan.K
-        return {
+        out = {
             "rot": plan.rot.clone(), "trans": plan.trans.clone(),
             "mask": o[:, 0:1], "coor_x": o[:, 1:2], "coor_y": o[:, 2:3], "coor_z": o[:, 3:4], "region": o[:, 4:5 + K],
             "consistent_map": None,
         }
+        tcfg = self.cfg.get("TEST", {})
+        if tcfg.get("USE_PNP", False):
+            # the reference leaves "TODO: move the pnp/ransac inside forward" (GDRN.py:294); here it is inside:
+            # per-crop RANSAC + Kabsch on the residual correspondences, result next to the learned pose
+            if tcfg.get("PNP_TYPE", "ransac_pnp") != "ransac_pnp":
+                raise NotImplementedError(f"TEST.PNP_TYPE={tcfg.PNP_TYPE!r}: only 'ransac_pnp' is implemented")
+            assert roi_extents is not None, "USE_PNP needs roi_extents"
+            plan.run_ransac(roi_coord_2d, fps, f32c(roi_extents), resize_ratios,
+                            mask_thr=float(self.cfg.MODEL.CDPN.ROT_HEAD.MASK_THR_TEST),
+                            inlier_thr=float(tcfg.get("PNP_INLIER_THR", 0.01)), iters=int(tcfg.get("PNP_ITERS", 100)),
+                            confidence=float(tcfg.get("PNP_CONFIDENCE", 0.99)), seed=int(tcfg.get("PNP_SEED", 0)))
+            out.update({"pnp_pose": plan.pnp_pose.clone(),
+                        "pnp_num_inliers": plan.pnp_ninl.clone(), "pnp_inlier_mask": plan.pnp_mask.clone()})
+        return out
 
 
 def build_model_optimizer(cfg):

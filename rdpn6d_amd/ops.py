@@ -116,3 +116,25 @@ def farthest_point_sampling(pts, sn, init_center=False, start=None):
         if (idxs < 0).any():
             raise RuntimeError("farthest_point_sampling failed: " + lib.rdpn6d_last_error().decode())
     return pts[idxs], idxs
+
+
+def ransac_kabsch(out_nchw, coord2d, fps, extents, resize_ratios, region_argmax, mask_thr=0.5, inlier_thr=0.01,
+                  iters=100, confidence=0.99, seed=0):
+    """Per-crop RANSAC + Kabsch on the dense maps (device tensors).  Returns pose [B,12] (R row-major | t),
+    n_inliers [B] int32, inlier_mask [B,HW] uint8, best_hyp [B] int32.  Role of process_pnp_ransac
+    (gdrn_evaluator.py:316-435) for the RGB-D residual formulation; sentinel pose -100 when < 3 points."""
+    _need_gpu(out_nchw, coord2d, fps, extents, resize_ratios, region_argmax)
+    B, C = out_nchw.shape[0], out_nchw.shape[1]
+    HW = out_nchw[0, 0].numel()
+    K = C - 5
+    dev = out_nchw.device
+    pose = torch.empty(B, 12, dtype=torch.float32, device=dev)
+    nin = torch.empty(B, dtype=torch.int32, device=dev)
+    mask = torch.empty(B, HW, dtype=torch.uint8, device=dev)
+    best = torch.empty(B, dtype=torch.int32, device=dev)
+    args = [t.contiguous() for t in (out_nchw, coord2d, fps, extents, resize_ratios, region_argmax)]
+    assert args[5].dtype == torch.int32
+    _lib.check(_lib.load().rdpn6d_ransac_kabsch_ex(*[_ptr(t) for t in args], B, HW, K, mask_thr, inlier_thr, iters,
+                                                   confidence, seed, _ptr(pose), _ptr(nin), _ptr(mask), _ptr(best),
+                                                   _stream()), "ransac_kabsch")
+    return pose, nin, mask, best

@@ -343,3 +343,72 @@ def test_model_vs_oracle_other_batch(golden_setup, dev):
         assert fl_hip <= 8
         tol_r, tol_t = (2.0 * max(sr, 1e-4), 2.0 * max(st_, 1e-4)) if fl_hip == 0 and fl_ref == 0 else (1e-2, 1e-2)
         assert er <= tol_r and et <= tol_t, i
+
+
+# ----------------------------------------------------------------------------- RANSAC / Kabsch
+@pytest.mark.parametrize("outliers,K,side", [(0.0, 32, 64), (0.3, 32, 64), (0.6, 32, 64), (0.4, 64, 64), (0.3, 8, 80)])
+def test_ransac_bit_exact_vs_oracle_and_ground_truth(dev, oracle_lib, outliers, K, side):
+    """inlier masks, counts and the winning hypothesis are bit-exact vs the C oracle under a fixed seed;
+    the refit pose agrees to 1e-5; both recover the known pose."""
+    from rdpn6d_amd import ops
+    from tests.ransac_cases import make_case, pose_errors
+    from tests.test_ransac_oracle import run_oracle
+
+    c = make_case(B=5, K=K, side=side, outliers=outliers, seed=17 + K + side)
+    for seed in (1, 99):
+        pose_o, nin_o, msk_o, best_o = run_oracle(oracle_lib, c, seed=seed)
+        g = {k: torch.from_numpy(c[k]).to(dev) for k in ("out_nchw", "coord2d", "fps", "extents", "ratios", "argmax")}
+        pose, nin, msk, best = ops.ransac_kabsch(g["out_nchw"], g["coord2d"], g["fps"], g["extents"], g["ratios"], g["argmax"],
+                                                 seed=seed)
+        torch.cuda.synchronize()
+        assert np.array_equal(best.cpu().numpy(), best_o), (best.cpu().numpy(), best_o)
+        assert np.array_equal(nin.cpu().numpy(), nin_o)
+        assert np.array_equal(msk.cpu().numpy(), msk_o)
+        assert np.abs(pose.cpu().numpy() - pose_o).max() < 1e-5
+        for b in range(c["B"]):
+            re, te = pose_errors(pose[b].cpu().numpy(), c["R"][b], c["t"][b])
+            assert re < 0.5 and te < 0.002, (b, re, te)
+
+
+def test_ransac_sentinel_and_edge_cases(dev, oracle_lib):
+    from rdpn6d_amd import ops
+    from tests.ransac_cases import make_case
+    from tests.test_ransac_oracle import run_oracle
+
+    c = make_case(B=3, seed=3)
+    c["out_nchw"][:2, 0] = 0.0
+    c["out_nchw"][:2, 0, 0], c["out_nchw"][:2, 0, 1] = -1.0, 1.0
+    c["out_nchw"][1, 0, 5] = 0.9           # crop 0: no point, crop 1: one point, crop 2: normal
+    c["out_nchw"][2, 0, :] = np.where(np.arange(4096) % 7 == 0, c["out_nchw"][2, 0, :], 0.0)
+    c["out_nchw"][2, 0, 0], c["out_nchw"][2, 0, 1] = -0.2, 1.2
+    po, ni, mo, bo = run_oracle(oracle_lib, c)
+    g = {k: torch.from_numpy(c[k]).to(dev) for k in ("out_nchw", "coord2d", "fps", "extents", "ratios", "argmax")}
+    pose, nin, msk, best = ops.ransac_kabsch(g["out_nchw"], g["coord2d"], g["fps"], g["extents"], g["ratios"], g["argmax"], seed=7)
+    torch.cuda.synchronize()
+    assert (pose[:2].cpu().numpy() == -100).all() and (nin[:2].cpu().numpy() == 0).all()
+    assert np.array_equal(best.cpu().numpy(), bo) and np.array_equal(msk.cpu().numpy(), mo)
+    assert np.abs(pose.cpu().numpy() - po).max() < 1e-5
+
+
+def test_model_use_pnp_matches_oracle_on_model_maps(golden_setup, dev, oracle_lib):
+    """TEST.USE_PNP=True: the RANSAC/Kabsch launched inside GDRN.forward on the model's own maps equals
+    the C oracle run on those same maps (bit-exact masks / counts), and returns the extra out_dict keys."""
+    from tests.test_ransac_oracle import run_oracle
+
+    models, t, _ = golden_setup
+    model = models["none"]
+    model.cfg.TEST.USE_PNP = True
+    model.cfg.TEST.PNP_INLIER_THR = 0.05
+    try:
+        o = _run(model, t)
+    finally:
+        model.cfg.TEST.USE_PNP = False
+    plan = model.plan(4, dev)
+    c = dict(out_nchw=plan.out_nchw.cpu().numpy().reshape(4, 37, 4096), coord2d=t["roi_coord_2d"].cpu().numpy().reshape(4, 5, 4096),
+             fps=t["fps"].cpu().numpy(), extents=t["roi_extent"].cpu().numpy(), ratios=t["resize_ratio"].cpu().numpy(),
+             argmax=plan.argmax.cpu().numpy(), B=4, HW=4096, K=32)
+    po, ni, mo, bo = run_oracle(oracle_lib, c, inlier_thr=0.05, seed=0)
+    assert np.array_equal(o["pnp_num_inliers"].cpu().numpy(), ni)
+    assert np.array_equal(o["pnp_inlier_mask"].cpu().numpy(), mo)
+    assert np.abs(o["pnp_pose"].cpu().numpy() - po).max() < 1e-4
+    assert o["pnp_pose"].shape == (4, 12)
