@@ -4,9 +4,10 @@
 //   A[m][k] is gathered on the fly from the NHWC activation (one contiguous 64-byte run of
 //   16 channels per (pixel, tap)), B[n][k] is the packed weight [Npad][ntaps][Cin].
 //   Workgroup = 256 threads = 4 wavefronts (2x2); each wavefront owns a (BM/2)x(BN/2) sub-tile
-//   made of 32x32 MFMA accumulators.  K advances in chunks of 16: global -> VGPR prefetch of
-//   chunk k+1 is issued before the 8 MFMA k-steps of chunk k, then written to the other LDS
-//   buffer (one barrier per chunk).  LDS rows are 16 data + 4 pad floats (80 B): both the
+//   made of 32x32 MFMA accumulators.  K advances in chunks of 16 through a 3-stage pipeline: while
+//   the 8 MFMA k-steps of chunk k issue from one fragment register set, the fragments of chunk k+1
+//   are read from LDS into the other set and chunk k+2 travels global -> VGPR -> LDS (one barrier per
+//   chunk, no LDS latency exposed after it).  LDS rows are 16 data + 4 pad floats (80 B): both the
 //   ds_write_b128 staging stores and the ds_read_b128 fragment loads are bank-conflict free.
 //   Lane l feeds the MFMA with k = s (l < 32) and k = 8 + s (l >= 32) at step s, so each
 //   lane reads its eight k-values as two 16-byte LDS loads.
@@ -29,19 +30,23 @@ struct ConvKArgs {
     int Ktot;     // ntaps * Cin
     int mtiles, ntiles;
     int linear_out;
+    int tap_inner;
+    unsigned x_bytes;  // size of the input tensor in bytes (buffer descriptor bound)
+    unsigned long long dy_pack, dx_pack;  // tap offsets, 4 bits each, biased by +8
 };
 
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs a)
 {
     constexpr int LDS = 20;           // floats per LDS row (16 + 4 pad)
+    constexpr int NST = 3;            // LDS stages (chunk k in flight in MFMA, k+1 in fragments, k+2 being staged)
     constexpr int TM = BM / 64;       // 32x32 tiles per wave along M
     constexpr int TN = BN / 64;       // ... along N
     constexpr int AR = BM / 64;       // A rows staged per thread
     constexpr int BR = BN / 64;       // B rows staged per thread
-    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDS];
+    __shared__ __attribute__((aligned(16))) float smem[NST * (BM + BN) * LDS];
     float* As = smem;
-    float* Bs = smem + 2 * BM * LDS;
+    float* Bs = smem + NST * BM * LDS;
 
     const rdpn6d_conv_desc& d = a.d;
     // ---- XCD-aware tile mapping (bijective for any grid size)
@@ -78,36 +83,80 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs a)
 #pragma unroll
     for (int i = 0; i < BR; ++i) wrow[i] = d.w + (long long)(n0 + r0 + 64 * i) * a.Ktot + kq * 4;
 
+    // A rows are fetched with raw buffer loads: the buffer descriptor bounds-checks in hardware, so a
+    // tap that falls outside the image (or a row past M) simply gets an out-of-range offset and reads
+    // zeros - no branch, no select, and therefore no s_waitcnt between the loads of one chunk.
+    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x), 0, a.x_bytes, 0x00020000);
+    const unsigned oob = a.x_bytes;  // any offset >= num_records returns 0
+    unsigned a_off[AR];              // byte offset of (pixel 0 of the row's image, channel in_co + kq*4)
+#pragma unroll
+    for (int i = 0; i < AR; ++i) a_off[i] = ((unsigned)a_pix[i] * (unsigned)d.in_cs + (unsigned)(d.in_co + kq * 4)) * 4u;
+    const unsigned px_bytes = (unsigned)d.in_cs * 4u;
+
+    // K order: tap_inner = 1 walks channel-chunk-major with the taps innermost (the 9 shifted reads of one
+    // 16-channel slab of the block's input footprint follow each other: L1/L2 locality); 0 = tap-major.
     f32x4 ra[AR], rb[BR];
-    auto load_global = [&](int tap, int c0, int kc) {
-        const int dy = d.dy[tap], dx = d.dx[tap];
+    auto load_global = [&](const int tap, const int cc) {
+        // tap offsets are packed 4 bits each (+8 bias) in two kernel arguments: pure ALU, no memory access
+        const int dy = (int)((a.dy_pack >> (4 * tap)) & 15ull) - 8, dx = (int)((a.dx_pack >> (4 * tap)) & 15ull) - 8;
+        const int c0 = cc * 16;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
             const bool ok = a_ok[i] && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
-            if (ok) {
-                const float* p = d.x + ((long long)(a_pix[i] + iy * d.W + ix) * d.in_cs + d.in_co + c0 + kq * 4);
-                ra[i] = *reinterpret_cast<const f32x4*>(p);
-            } else {
-                ra[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+            const unsigned off = ok ? a_off[i] + (unsigned)(iy * d.W + ix) * px_bytes + (unsigned)c0 * 4u : oob;
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, (int)off, 0, 0));
         }
+        const int woff = tap * d.Cin + c0;
 #pragma unroll
-        for (int i = 0; i < BR; ++i) rb[i] = *reinterpret_cast<const f32x4*>(wrow[i] + kc * 16);
+        for (int i = 0; i < BR; ++i) rb[i] = *reinterpret_cast<const f32x4*>(wrow[i] + woff);
     };
-    auto store_lds = [&](int buf) {
+    // chunk counter -> (tap, cc), advanced branch-free; clamped at the last chunk so that the loop body can
+    // load unconditionally (the two redundant loads past the end re-read the last chunk and are never used)
+    int ld_tap = 0, ld_cc = 0, ld_left = a.nk - 1;
+    auto next_chunk = [](int& tap, int& cc, int& left, const int ntaps, const int cchunks, const int tap_inner) {
+        const int go = left > 0 ? 1 : 0;
+        left -= go;
+        if (tap_inner) {
+            tap += go;
+            const int wrap = tap == ntaps ? 1 : 0;
+            tap = wrap ? 0 : tap;
+            cc += wrap;
+        } else {
+            cc += go;
+            const int wrap = cc == cchunks ? 1 : 0;
+            cc = wrap ? 0 : cc;
+            tap += wrap;
+        }
+    };
+    auto store_lds = [&](int st) {
 #pragma unroll
         for (int i = 0; i < AR; ++i)
-            *reinterpret_cast<f32x4*>(&As[(buf * BM + r0 + 64 * i) * LDS + kq * 4]) = ra[i];
+            *reinterpret_cast<f32x4*>(&As[(st * BM + r0 + 64 * i) * LDS + kq * 4]) = ra[i];
 #pragma unroll
         for (int i = 0; i < BR; ++i)
-            *reinterpret_cast<f32x4*>(&Bs[(buf * BN + r0 + 64 * i) * LDS + kq * 4]) = rb[i];
+            *reinterpret_cast<f32x4*>(&Bs[(st * BN + r0 + 64 * i) * LDS + kq * 4]) = rb[i];
     };
 
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int frow = lane & 31;          // fragment row (A: pixel, B: channel) inside a 32-tile
     const int koff = (lane >> 5) * 8;    // this lane's 8 k-values start here
+
+    auto read_frags = [&](int st, f32x4 (&fa)[TM][2], f32x4 (&fb)[TN][2]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float* p = &As[(st * BM + wm * (BM / 2) + i * 32 + frow) * LDS + koff];
+            fa[i][0] = *reinterpret_cast<const f32x4*>(p);
+            fa[i][1] = *reinterpret_cast<const f32x4*>(p + 4);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const float* p = &Bs[(st * BN + wn * (BN / 2) + j * 32 + frow) * LDS + koff];
+            fb[j][0] = *reinterpret_cast<const f32x4*>(p);
+            fb[j][1] = *reinterpret_cast<const f32x4*>(p + 4);
+        }
+    };
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -117,31 +166,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs a)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    int tap = 0, cc = 0;  // chunk kc = tap*cchunks + cc
-    load_global(0, 0, 0);
-    store_lds(0);
-    __syncthreads();
-
-    for (int kc = 0; kc < a.nk; ++kc) {
-        const int buf = kc & 1;
-        const bool more = kc + 1 < a.nk;
-        if (more) {
-            if (++cc == a.cchunks) { cc = 0; ++tap; }
-            load_global(tap, cc * 16, kc + 1);
-        }
-        f32x4 fa[TM][2], fb[TN][2];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const float* p = &As[(buf * BM + wm * (BM / 2) + i * 32 + frow) * LDS + koff];
-            fa[i][0] = *reinterpret_cast<const f32x4*>(p);
-            fa[i][1] = *reinterpret_cast<const f32x4*>(p + 4);
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const float* p = &Bs[(buf * BN + wn * (BN / 2) + j * 32 + frow) * LDS + koff];
-            fb[j][0] = *reinterpret_cast<const f32x4*>(p);
-            fb[j][1] = *reinterpret_cast<const f32x4*>(p + 4);
-        }
+    auto mma = [&](const f32x4 (&fa)[TM][2], const f32x4 (&fb)[TN][2]) {
 #pragma unroll
         for (int s = 0; s < 8; ++s)
 #pragma unroll
@@ -150,9 +175,45 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs a)
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s >> 2][s & 3], fb[j][s >> 2][s & 3],
                                                                      acc[i][j], 0, 0, 0);
-        if (more) store_lds(buf ^ 1);
+    };
+
+    // ---- prologue: chunks 0 and 1 into LDS stages 0 and 1, fragments of chunk 0 into registers
+    const int nk = a.nk;
+    load_global(ld_tap, ld_cc);
+    next_chunk(ld_tap, ld_cc, ld_left, d.ntaps, a.cchunks, a.tap_inner);
+    store_lds(0);
+    load_global(ld_tap, ld_cc);
+    next_chunk(ld_tap, ld_cc, ld_left, d.ntaps, a.cchunks, a.tap_inner);
+    store_lds(1);
+    __syncthreads();
+    f32x4 fa0[TM][2], fb0[TN][2], fa1[TM][2], fb1[TN][2];
+    read_frags(0, fa0, fb0);
+
+    // ---- main loop over chunk PAIRS (fragment double buffer statically indexed, body branch-free).
+    // step for chunk kc: (1) global loads of chunk kc+2, (2) LDS->register fragments of chunk kc+1,
+    // (3) 8 MFMA k-steps of chunk kc, (4) stage chunk kc+2 into LDS, (5) one barrier.
+    int st_next = 1, st_stage = 2;  // LDS stage holding chunk kc+1 / receiving chunk kc+2
+    const int npairs = nk >> 1;
+    for (int pr = 0; pr < npairs; ++pr) {
+        load_global(ld_tap, ld_cc);
+        next_chunk(ld_tap, ld_cc, ld_left, d.ntaps, a.cchunks, a.tap_inner);
+        read_frags(st_next, fa1, fb1);
+        mma(fa0, fb0);
+        store_lds(st_stage);
         __syncthreads();
+        st_next = st_next == NST - 1 ? 0 : st_next + 1;
+        st_stage = st_stage == NST - 1 ? 0 : st_stage + 1;
+
+        load_global(ld_tap, ld_cc);
+        next_chunk(ld_tap, ld_cc, ld_left, d.ntaps, a.cchunks, a.tap_inner);
+        read_frags(st_next, fa0, fb0);
+        mma(fa1, fb1);
+        store_lds(st_stage);
+        __syncthreads();
+        st_next = st_next == NST - 1 ? 0 : st_next + 1;
+        st_stage = st_stage == NST - 1 ? 0 : st_stage + 1;
     }
+    if (nk & 1) mma(fa0, fb0);  // odd chunk count: the last chunk's fragments are already in registers
 
     // ---- fused epilogue
     const int hi = lane >> 5;
@@ -190,7 +251,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs a)
     }
 }
 
-static int g_force_bm = 0, g_force_bn = 0;
+static int g_force_bm = 0, g_force_bn = 0, g_tap_inner = 1;
+extern "C" void rdpn6d_conv_set_tap_inner(int v) { g_tap_inner = v; }
 extern "C" void rdpn6d_conv_force_tile(int bm, int bn) { g_force_bm = bm; g_force_bn = bn; }
 
 static void conv_pick_tile(const rdpn6d_conv_desc* d, long long M, int* pbm, int* pbn)
@@ -235,6 +297,16 @@ extern "C" int rdpn6d_conv2d_f32(const rdpn6d_conv_desc* d, void* stream)
     a.nk = d->ntaps * a.cchunks;
     a.Ktot = d->ntaps * d->Cin;
     a.linear_out = (d->osy == 1 && d->osx == 1 && d->ooy == 0 && d->oox == 0 && d->OH == d->Ho && d->OW == d->Wo);
+    const long long xb = (long long)d->B * d->H * d->W * d->in_cs * 4;
+    RD_REQUIRE(xb < (1LL << 32) - 64, "input tensor must be smaller than 4 GiB (32-bit buffer offsets)");
+    a.x_bytes = (unsigned)xb;
+    a.tap_inner = g_tap_inner;
+    a.dy_pack = a.dx_pack = 0;
+    for (int t = 0; t < d->ntaps; ++t) {
+        RD_REQUIRE(d->dy[t] >= -8 && d->dy[t] <= 7 && d->dx[t] >= -8 && d->dx[t] <= 7, "tap offsets must be in -8..7");
+        a.dy_pack |= (unsigned long long)(d->dy[t] + 8) << (4 * t);
+        a.dx_pack |= (unsigned long long)(d->dx[t] + 8) << (4 * t);
+    }
     int bm, bn;
     conv_pick_tile(d, a.M, &bm, &bn);
     a.mtiles = rd_cdiv(a.M, bm);
