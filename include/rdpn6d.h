@@ -143,6 +143,61 @@ int rdpn6d_ransac_kabsch_ex(const float* out_nchw, const float* coord2d, const f
                             float mask_thr, float inlier_thr, int iters, float confidence, unsigned seed,
                             float* pose_out, int* n_inliers, unsigned char* inlier_mask, int* best_hyp, void* stream);
 
+
+/* ================================================================== training step (forward with batch statistics,
+ * losses, backward).  Rows L / O of SURVEY.md section 8a: GDRN.gdrn_loss (models/GDRN.py:373-633), the autograd graph
+ * PyTorch builds for GDRN.forward(do_loss=True), torch BatchNorm2d/GroupNorm train-mode semantics.
+ * dgrad of every conv reuses rdpn6d_conv2d_f32 with re-packed (flipped / transposed / phase-split) weights. */
+
+/* conv1 7x7/2 raw output (no folded BN, no ReLU) for training */
+int rdpn6d_stem_conv7x7_raw_f32(const float* x, int B, int xc, int R, const float* w, float* y, void* stream);
+/* BatchNorm2d train mode, statistics over the M rows of x[M, cs] channels [co, co+C): mean, 1/sqrt(var+eps) (biased var),
+ * running stats updated with `momentum` (unbiased var) when given.  scratch >= 64*C*2 doubles. */
+int rdpn6d_bn_train_stats_f32(const float* x, long long M, int C, int cs, int co, float eps, float momentum, float* mean,
+                              float* invstd, float* running_mean, float* running_var, double* scratch, void* stream);
+/* y = act((x-mean)*invstd*gamma + beta (+ res)) */
+int rdpn6d_bn_apply_f32(const float* x, int xcs, int xco, const float* mean, const float* invstd, const float* gamma,
+                        const float* beta, const float* res, int rcs, int rco, float* y, int ycs, int yco, long long M, int C,
+                        int relu, void* stream);
+/* BN backward (g = dy*(y>0) if relu): dgamma, dbeta, dx; dres (optional) = g for the identity branch */
+int rdpn6d_bn_backward_f32(const float* x, int xcs, int xco, const float* dy, int dcs, int dco, const float* y, int ycs,
+                           int yco, const float* mean, const float* invstd, const float* gamma, float* dgamma, float* dbeta,
+                           float* dx, int xgcs, int xgco, float* dres, int rcs, int rco, long long M, int C, int relu,
+                           double* scratch, void* stream);
+/* out[c] (+)= sum over rows of x[m, co+c]  (bias gradients) */
+int rdpn6d_channel_sum_f32(const float* x, long long M, int C, int cs, int co, float* out, int accumulate, double* scratch,
+                           void* stream);
+/* GroupNorm(G, C=4G)+ReLU, out of place, statistics [B][G][2] saved; and its backward */
+int rdpn6d_groupnorm_relu_train_f32(const float* x, float* y, int B, int HW, int C, int G, const float* gamma,
+                                    const float* beta, float* stats, void* stream);
+int rdpn6d_groupnorm_relu_backward_f32(const float* x, const float* y, const float* dy, const float* gamma, const float* stats,
+                                       float* dx, float* dgamma, float* dbeta, float* dgb_scratch, double* scratch, int B,
+                                       int HW, int C, int G, void* stream);
+/* weight gradient as an implicit GEMM reducing over pixels: out[a][t][b] = sum_m A[m][a] * Bg[gather(m,t)][b] */
+long long rdpn6d_wgrad_scratch_floats(int Bn, int Ha, int Wa, int Ca, int Cb, int ntaps);
+int rdpn6d_wgrad_f32(const float* A, int a_cs, int a_co, int Ca, const float* Bg, int b_cs, int b_co, int Cb, int Bn, int Ha,
+                     int Wa, int Hb, int Wb, int stride, int ntaps, const int* dy, const int* dx, float* out, float* partial,
+                     void* stream);
+int rdpn6d_maxpool3x3s2_backward_f32(const float* x, const float* dy, int B, int H, int W, int C, float* dx, void* stream);
+int rdpn6d_upsample_bilinear_backward_f32(const float* dy, int B, int H, int W, int C, int factor, float* dx, void* stream);
+int rdpn6d_global_max_concat_backward_f32(const float* feat, const float* dfeat, int B, int HW, int C, int cs, float* dl3,
+                                          void* stream);
+/* dense losses (loss_coor_x/y/z, loss_mask, loss_region, loss_region_my) and d(loss)/d(head) in one pass */
+int rdpn6d_dense_losses_f32(const float* head, int head_cs, const float* gt_xyz, const float* mask_visib,
+                            const float* mask_trunc, const long long* gt_region, int B, int HW, int K, float xyz_lw,
+                            float mask_lw, float region_lw, float* dhead, float* losses, double* scratch, void* stream);
+int rdpn6d_dense_glue_backward_f32(const float* head, int head_cs, const float* coord2d, const float* fps, const int* argmax,
+                                   const float* dpnp, int pnp_cs, int B, int HW, int K, int mask_attention,
+                                   const float* minmax, float* dhead, float* datt_scratch, void* stream);
+/* pose decode (train variant) + loss_PM_R, loss_centroid, loss_z and their gradient w.r.t. the 9 head outputs */
+int rdpn6d_pose_train_f32(const float* rt, int rt_stride, const float* roi_cams, const float* roi_centers,
+                          const float* roi_whs, const float* resize_ratios, const float* roi_extents, const float* gt_rot,
+                          const float* gt_trans_ratio, const float* points, int npts, int B, int is_allo, float pm_lw,
+                          int pm_norm_by_extent, float centroid_lw, float z_lw, float* rot, float* trans, float* d_rt,
+                          float* losses, float* scratch, void* stream);
+int rdpn6d_act_backward_f32(float* dy, const float* y, long long n, float slope, void* stream);
+int rdpn6d_rgb_to_nhwc4_f32(const float* x, int B, int xc, int R, float* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,6 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "librdpn6d_hip.so")
 
+_ll = ctypes.c_longlong
 c_float_p = ctypes.c_void_p
 c_int_p = ctypes.c_void_p
 _vp, _i, _f, _u = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_uint
@@ -48,6 +49,25 @@ SIGNATURES = {
     "rdpn6d_pose_decode_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "rdpn6d_ransac_kabsch_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _f, _u, _vp, _vp, _vp, _vp]),
     "rdpn6d_ransac_kabsch_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _f, _u, _vp, _vp, _vp, _vp, _vp]),
+    "rdpn6d_stem_conv7x7_raw_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    "rdpn6d_bn_train_stats_f32": (_i, [_vp, _ll, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rdpn6d_bn_apply_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _ll, _i, _i, _vp]),
+    "rdpn6d_bn_backward_f32": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i,
+                                    _ll, _i, _i, _vp, _vp]),
+    "rdpn6d_channel_sum_f32": (_i, [_vp, _ll, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "rdpn6d_groupnorm_relu_train_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "rdpn6d_groupnorm_relu_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "rdpn6d_wgrad_scratch_floats": (_ll, [_i, _i, _i, _i, _i, _i]),
+    "rdpn6d_wgrad_f32": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "rdpn6d_maxpool3x3s2_backward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "rdpn6d_upsample_bilinear_backward_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "rdpn6d_global_max_concat_backward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "rdpn6d_dense_losses_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp]),
+    "rdpn6d_dense_glue_backward_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "rdpn6d_pose_train_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _f, _vp, _vp, _vp,
+                                   _vp, _vp, _vp]),
+    "rdpn6d_act_backward_f32": (_i, [_vp, _vp, _ll, _f, _vp]),
+    "rdpn6d_rgb_to_nhwc4_f32": (_i, [_vp, _i, _i, _i, _vp, _vp]),
 }
 
 _lib = None

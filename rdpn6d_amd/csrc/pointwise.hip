@@ -12,7 +12,7 @@
 __global__ __launch_bounds__(256) void stem_conv7x7_kernel(const float* __restrict__ x, int xc, int R,
                                                            const float* __restrict__ w,
                                                            const float* __restrict__ scale,
-                                                           const float* __restrict__ shift, float* __restrict__ y)
+                                                           const float* __restrict__ shift, float* __restrict__ y, int relu)
 {
     constexpr int T = 16, P = 2 * T + 5;  // 37
     __shared__ float s_in[3][P][P + 1];
@@ -63,24 +63,37 @@ __global__ __launch_bounds__(256) void stem_conv7x7_kernel(const float* __restri
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int n = n4 * 4 + e;
-                const float v = acc[n] * scale[n] + shift[n];
-                o[e] = v > 0.f ? v : 0.f;
+                const float v = scale ? acc[n] * scale[n] + shift[n] : acc[n];
+                o[e] = (v > 0.f || !relu) ? v : 0.f;
             }
             yp[n4] = o;
         }
     }
 }
 
-extern "C" int rdpn6d_stem_conv7x7_f32(const float* x, int B, int xc, int R, const float* w, const float* scale,
-                                       const float* shift, float* y, void* stream)
+static int stem_launch(const float* x, int B, int xc, int R, const float* w, const float* scale, const float* shift,
+                       float* y, int relu, void* stream)
 {
-    RD_REQUIRE(x && w && scale && shift && y, "null pointer");
+    RD_REQUIRE(x && w && y && (!scale == !shift), "null pointer");
     RD_REQUIRE(B > 0 && xc >= 3 && R > 0 && R % 2 == 0, "shape");
     const int Ro = R / 2;
     dim3 grid(rd_cdiv(Ro, 16), rd_cdiv(Ro, 16), B);
-    hipLaunchKernelGGL(stem_conv7x7_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, xc, R, w, scale, shift, y);
+    hipLaunchKernelGGL(stem_conv7x7_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, xc, R, w, scale, shift, y, relu);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
+}
+
+extern "C" int rdpn6d_stem_conv7x7_f32(const float* x, int B, int xc, int R, const float* w, const float* scale,
+                                       const float* shift, float* y, void* stream)
+{
+    RD_REQUIRE(scale && shift, "null pointer");
+    return stem_launch(x, B, xc, R, w, scale, shift, y, 1, stream);
+}
+
+// training form: raw convolution output (no folded BN, no ReLU)
+extern "C" int rdpn6d_stem_conv7x7_raw_f32(const float* x, int B, int xc, int R, const float* w, float* y, void* stream)
+{
+    return stem_launch(x, B, xc, R, w, nullptr, nullptr, y, 0, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

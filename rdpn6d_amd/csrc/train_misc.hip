@@ -1,0 +1,634 @@
+// Backward / loss kernels of the RDPN6D training step that are not GEMMs (NHWC fp32).
+//   - maxpool / bilinear-upsample / global-max backward           (resnet_backbone.py:275,280,51-54)
+//   - dense losses + their gradients in one pass                   (GDRN.py:411-424,452-454,470-483)
+//   - glue backward (softmax / concat / mask attention)            (GDRN.py:196-233, conv_pnp_net.py:129-137)
+//   - pose decode (train variant) + PM / centroid / z losses with forward-mode dual numbers
+//                                                                  (pose_from_pred_centroid_z.py:144-227,
+//                                                                   utils.py:208-236, rot_reps.py:34-49,
+//                                                                   pm_loss.py:102-114, GDRN.py:529-554)
+#include "common.h"
+#include <float.h>
+
+// ------------------------------------------------------------------------------------------------
+// MaxPool2d(3,2,1) backward, gather form (deterministic): an input element receives the gradient of every
+// window in which it is the FIRST maximum in scan order (torch's CPU/GPU kernels keep the first max).
+__global__ void maxpool3x3s2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int B, int H, int W, int C,
+                                        float* __restrict__ dx)
+{
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const long long total = (long long)B * H * W * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long p = i / C;
+        const int ix = (int)(p % W);
+        p /= W;
+        const int iy = (int)(p % H);
+        const int b = (int)(p / H);
+        const float v = x[i];
+        float g = 0.f;
+        // windows (oy,ox) covering (iy,ix): oy*2-1 <= iy <= oy*2+1
+        for (int oy = (iy) / 2; oy <= (iy + 1) / 2; ++oy) {
+            if (oy < 0 || oy >= Ho) continue;
+            for (int ox = (ix) / 2; ox <= (ix + 1) / 2; ++ox) {
+                if (ox < 0 || ox >= Wo) continue;
+                // is (iy,ix) the first max of this window?
+                bool first = true;
+                for (int ky = 0; ky < 3 && first; ++ky) {
+                    const int yy = oy * 2 - 1 + ky;
+                    if ((unsigned)yy >= (unsigned)H) continue;
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int xx = ox * 2 - 1 + kx;
+                        if ((unsigned)xx >= (unsigned)W) continue;
+                        const float u = x[(((long long)b * H + yy) * W + xx) * C + c];
+                        const bool before = yy < iy || (yy == iy && xx < ix);
+                        if (u > v || (before && u == v)) { first = false; break; }
+                    }
+                }
+                if (first) g += dy[(((long long)b * Ho + oy) * Wo + ox) * C + c];
+            }
+        }
+        dx[i] = g;
+    }
+}
+
+extern "C" int rdpn6d_maxpool3x3s2_backward_f32(const float* x, const float* dy, int B, int H, int W, int C, float* dx,
+                                                void* stream)
+{
+    RD_REQUIRE(x && dy && dx && B > 0 && H > 0 && W > 0 && C > 0, "shape");
+    const long long total = (long long)B * H * W * C;
+    const int blocks = (int)((total + 255) / 256 < 32768 ? (total + 255) / 256 : 32768);
+    hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, dy, B, H, W, C, dx);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bilinear (align_corners) upsample backward, gather form: dx[iy,ix] = sum over outputs of weight * dy.
+__global__ void upsample_bilinear_bwd_kernel(const float* __restrict__ dy, int B, int H, int W, int C, int f,
+                                             float* __restrict__ dx)
+{
+    const int Ho = H * f, Wo = W * f;
+    const float sy = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
+    const float sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    const long long total = (long long)B * H * W * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long long p = i / C;
+        const int ix = (int)(p % W);
+        p /= W;
+        const int iy = (int)(p % H);
+        const int b = (int)(p / H);
+        float g = 0.f;
+        // outputs oy whose (y0, y1) touch iy: y0 = floor(sy*oy) in {iy-1, iy}
+        const int oy_lo = iy == 0 ? 0 : (int)ceilf((float)(iy - 1) / sy) - 1, oy_hi = (int)floorf((float)(iy + 1) / sy) + 1;
+        const int ox_lo = ix == 0 ? 0 : (int)ceilf((float)(ix - 1) / sx) - 1, ox_hi = (int)floorf((float)(ix + 1) / sx) + 1;
+        for (int oy = oy_lo < 0 ? 0 : oy_lo; oy <= oy_hi && oy < Ho; ++oy) {
+            const float fy = sy * oy;
+            const int y0 = (int)fy, y1 = y0 + (y0 < H - 1);
+            const float ly = fy - y0, hy = 1.f - ly;
+            float wy = 0.f;
+            if (y0 == iy) wy += hy;
+            if (y1 == iy) wy += ly;
+            if (wy == 0.f) continue;
+            for (int ox = ox_lo < 0 ? 0 : ox_lo; ox <= ox_hi && ox < Wo; ++ox) {
+                const float fx = sx * ox;
+                const int x0 = (int)fx, x1 = x0 + (x0 < W - 1);
+                const float lx = fx - x0, hx = 1.f - lx;
+                float wx = 0.f;
+                if (x0 == ix) wx += hx;
+                if (x1 == ix) wx += lx;
+                if (wx == 0.f) continue;
+                g += wy * wx * dy[(((long long)b * Ho + oy) * Wo + ox) * C + c];
+            }
+        }
+        dx[i] = g;
+    }
+}
+
+extern "C" int rdpn6d_upsample_bilinear_backward_f32(const float* dy, int B, int H, int W, int C, int factor, float* dx,
+                                                     void* stream)
+{
+    RD_REQUIRE(dy && dx && B > 0 && H > 1 && W > 1 && C > 0 && factor >= 2, "shape");
+    const long long total = (long long)B * H * W * C;
+    const int blocks = (int)((total + 255) / 256 < 32768 ? (total + 255) / 256 : 32768);
+    hipLaunchKernelGGL(upsample_bilinear_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, B, H, W, C, factor, dx);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of [l3 | broadcast(global max l3)]: dl3[p,c] = dfeat[p,c] + (p == first arg-max pixel of channel c) * sum_p' dfeat[p', C+c]
+// feat / dfeat NHWC [B,HW,cs] with cs >= 2C; dl3 [B,HW,C].  grid = (C/64, B), block 256 = 4 pixel lanes x 64 channels.
+__global__ __launch_bounds__(256) void global_max_concat_bwd_kernel(const float* __restrict__ feat, const float* __restrict__ dfeat,
+                                                                   int HW, int C, int cs, float* __restrict__ dl3)
+{
+    __shared__ float s_m[4][64], s_s[4][64];
+    __shared__ int s_i[4][64];
+    const int b = blockIdx.y, cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, pl = threadIdx.x >> 6;
+    const float* f = feat + (long long)b * HW * cs;
+    const float* g = dfeat + (long long)b * HW * cs;
+    float m = -FLT_MAX, s = 0.f;
+    int mi = 0x7fffffff;
+    for (int p = pl; p < HW; p += 4) {
+        const float v = f[(long long)p * cs + c];
+        if (v > m) { m = v; mi = p; }
+        s += g[(long long)p * cs + C + c];
+    }
+    s_m[pl][cl] = m; s_i[pl][cl] = mi; s_s[pl][cl] = s;
+    __syncthreads();
+    float bm = s_m[0][cl], tot = s_s[0][cl];
+    int bi = s_i[0][cl];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+        const float om = s_m[k][cl];
+        const int oi = s_i[k][cl];
+        if (om > bm || (om == bm && oi < bi)) { bm = om; bi = oi; }
+        tot += s_s[k][cl];
+    }
+    float* o = dl3 + (long long)b * HW * C;
+    for (int p = pl; p < HW; p += 4) o[(long long)p * C + c] = g[(long long)p * cs + c] + (p == bi ? tot : 0.f);
+}
+
+extern "C" int rdpn6d_global_max_concat_backward_f32(const float* feat, const float* dfeat, int B, int HW, int C, int cs,
+                                                     float* dl3, void* stream)
+{
+    RD_REQUIRE(feat && dfeat && dl3 && B > 0 && HW > 0 && C > 0 && C % 64 == 0 && 2 * C <= cs, "shape");
+    hipLaunchKernelGGL(global_max_concat_bwd_kernel, dim3(C / 64, B), dim3(256), 0, (hipStream_t)stream, feat, dfeat, HW, C, cs, dl3);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dense losses + gradients.  head NHWC [B,HW,head_cs] = [mask | x y z | region bg+K]; gt tensors in the batch_data
+// layout: gt_xyz [B,3,HW], masks [B,HW], gt_region [B,HW] int64.
+// sums[0] = sum(mask_visib) (first kernel); partial[blk][6] = (coor_x, coor_y, coor_z, mask, region_ce, region_my) raw sums.
+__global__ __launch_bounds__(256) void mask_sum_kernel(const float* __restrict__ m, long long n, double* __restrict__ out)
+{
+    __shared__ double s[4];
+    double a = 0.0;
+    for (long long i = threadIdx.x; i < n; i += 256) a += (double)m[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(256) void dense_loss_kernel(const float* __restrict__ head, int head_cs, const float* __restrict__ gt_xyz,
+                                                         const float* __restrict__ m_visib, const float* __restrict__ m_trunc,
+                                                         const long long* __restrict__ gt_region, int B, int HW, int K,
+                                                         const double* __restrict__ sums, float xyz_lw, float mask_lw,
+                                                         float region_lw, float* __restrict__ dhead,
+                                                         double* __restrict__ partial)
+{
+    __shared__ double s_red[4][6];
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long n = (long long)B * HW;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    if (i < n) {
+        const int b = (int)(i / HW), p = (int)(i - (long long)b * HW);
+        const float denom = fmaxf((float)sums[0], 1.0f);
+        const float inv_d = 1.0f / denom, inv_n = 1.0f / (float)n;
+        const float* h = head + i * head_cs;
+        float* dh = dhead + i * head_cs;
+        const float mv = m_visib[i], mt = m_trunc[i];
+        // xyz L1 on the visible mask
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float d = h[1 + c] * mv - gt_xyz[((long long)b * 3 + c) * HW + p] * mv;
+            acc[c] = fabs((double)d);
+            const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+            dh[1 + c] = xyz_lw * sg * mv * inv_d;
+        }
+        // mask L1 (mean)
+        {
+            const float d = h[0] - mt;
+            acc[3] = fabs((double)d);
+            dh[0] = mask_lw * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * inv_n;
+        }
+        // region cross-entropy on logits*mask, target gt*mask (sum reduction / denom)
+        const int tgt = (int)(gt_region[i] * (long long)mv);
+        float z[KMAX + 1], mx = -FLT_MAX;
+#pragma unroll
+        for (int k = 0; k <= KMAX; ++k)
+            if (k <= K) { z[k] = h[4 + k] * mv; mx = fmaxf(mx, z[k]); }
+        float se = 0.f, zt = 0.f;
+#pragma unroll
+        for (int k = 0; k <= KMAX; ++k)
+            if (k <= K) { z[k] = expf(z[k] - mx); se += z[k]; }
+#pragma unroll
+        for (int k = 0; k <= KMAX; ++k)
+            if (k <= K && k == tgt) zt = h[4 + k] * mv;
+        acc[4] = (double)(logf(se) + mx - zt);
+        // region_my: L1(mask_visib, bg logit), mean
+        const float dm = mv - h[4];
+        acc[5] = fabs((double)dm);
+        const float g_my = -region_lw * (dm > 0.f ? 1.f : (dm < 0.f ? -1.f : 0.f)) * inv_n;
+#pragma unroll
+        for (int k = 0; k <= KMAX; ++k)
+            if (k <= K) {
+                float g = region_lw * (z[k] / se - (k == tgt ? 1.f : 0.f)) * mv * inv_d;
+                if (k == 0) g += g_my;
+                dh[4 + k] = g;
+            }
+        for (int c = 5 + K; c < head_cs; ++c) dh[c] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o);
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6][k] = acc[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 6)
+        partial[(long long)blockIdx.x * 6 + threadIdx.x] =
+            (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+}
+
+// losses[0..5] = loss_coor_x, _y, _z, loss_mask, loss_region, loss_region_my
+__global__ void dense_loss_finalize_kernel(const double* __restrict__ partial, int nblk, const double* __restrict__ sums,
+                                           long long n, float xyz_lw, float mask_lw, float region_lw,
+                                           float* __restrict__ losses)
+{
+    const int k = threadIdx.x;
+    if (k >= 6) return;
+    double a = 0.0;
+    for (int i = 0; i < nblk; ++i) a += partial[(long long)i * 6 + k];
+    const double denom = sums[0] > 1.0 ? sums[0] : 1.0;
+    double v;
+    if (k < 3) v = xyz_lw * a / denom;
+    else if (k == 3) v = mask_lw * a / (double)n;
+    else if (k == 4) v = region_lw * a / denom;
+    else v = region_lw * a / (double)n;
+    losses[k] = (float)v;
+}
+
+extern "C" int rdpn6d_dense_losses_f32(const float* head, int head_cs, const float* gt_xyz, const float* mask_visib,
+                                       const float* mask_trunc, const long long* gt_region, int B, int HW, int K, float xyz_lw,
+                                       float mask_lw, float region_lw, float* dhead, float* losses /* [6] */,
+                                       double* scratch /* >= 8 + 6*ceil(B*HW/256) doubles */, void* stream)
+{
+    RD_REQUIRE(head && gt_xyz && mask_visib && mask_trunc && gt_region && dhead && losses && scratch, "null pointer");
+    RD_REQUIRE(B > 0 && HW > 0 && K >= 2 && K <= 64 && head_cs >= 5 + K, "shape");
+    hipStream_t s = (hipStream_t)stream;
+    const long long n = (long long)B * HW;
+    const int nblk = (int)((n + 255) / 256);
+    hipLaunchKernelGGL(mask_sum_kernel, dim3(1), dim3(256), 0, s, mask_visib, n, scratch);
+    RD_LAUNCH_CHECK();
+    if (K <= 32)
+        hipLaunchKernelGGL(dense_loss_kernel<32>, dim3(nblk), dim3(256), 0, s, head, head_cs, gt_xyz, mask_visib, mask_trunc, gt_region,
+                           B, HW, K, scratch, xyz_lw, mask_lw, region_lw, dhead, scratch + 8);
+    else
+        hipLaunchKernelGGL(dense_loss_kernel<64>, dim3(nblk), dim3(256), 0, s, head, head_cs, gt_xyz, mask_visib, mask_trunc, gt_region,
+                           B, HW, K, scratch, xyz_lw, mask_lw, region_lw, dhead, scratch + 8);
+    RD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dense_loss_finalize_kernel, dim3(1), dim3(64), 0, s, scratch + 8, nblk, scratch, n, xyz_lw, mask_lw, region_lw, losses);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Glue backward: dpnp [B,HW,pnp_cs] (gradient of the ConvPnPNet input) -> accumulated into dhead [B,HW,head_cs].
+//   pnp_in = att * [x y z | coord2d(5) | anchor(3) | softmax(region[1:])],  att = 1 or (mask-mn)/(mx-mn)
+// datt_out [B,HW] (only with mask attention) feeds the per-sample min/max terms handled by the second kernel.
+template <int KMAX>
+__global__ __launch_bounds__(256) void dense_glue_bwd_kernel(const float* __restrict__ head, int head_cs,
+                                                             const float* __restrict__ coord2d, const float* __restrict__ fps,
+                                                             const int* __restrict__ argmax, const float* __restrict__ dpnp,
+                                                             int pnp_cs, int B, int HW, int K, int mask_attention,
+                                                             const float* __restrict__ minmax, float* __restrict__ dhead,
+                                                             float* __restrict__ datt_out)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)B * HW) return;
+    const int b = (int)(i / HW), p = (int)(i - (long long)b * HW);
+    const float* h = head + i * head_cs;
+    const float* g = dpnp + i * pnp_cs;
+    float* dh = dhead + i * head_cs;
+    float att = 1.f, range = 1.f;
+    if (mask_attention) {
+        range = minmax[b * 2 + 1] - minmax[b * 2];
+        att = (h[0] - minmax[b * 2]) / range;
+    }
+    // softmax over region[1..K]
+    float e[KMAX], mx = -FLT_MAX, se = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+        if (k < K) mx = fmaxf(mx, h[5 + k]);
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+        if (k < K) { e[k] = expf(h[5 + k] - mx); se += e[k]; }
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+        if (k < K) { e[k] = e[k] / se; dot += e[k] * g[11 + k] * att; }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) dh[1 + c] += g[c] * att;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+        if (k < K) dh[5 + k] += e[k] * (g[11 + k] * att - dot);
+    if (mask_attention) {
+        // datt = sum_c dpnp[c] * (un-attenuated input c)
+        float da = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) da += g[c] * h[1 + c];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) da += g[3 + c] * coord2d[((long long)b * 5 + c) * HW + p];
+        const float* an = fps + ((long long)b * K + argmax[i]) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) da += g[8 + c] * an[c];
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k)
+            if (k < K) da += g[11 + k] * e[k];
+        dh[0] += da / range;
+        datt_out[i] = da;
+    }
+}
+
+// per-sample min/max terms of att = (m - mn)/(mx - mn): d/dmn = sum datt*(m - mx)/range^2 -> first arg-min pixel,
+// d/dmx = -sum datt*(m - mn)/range^2 -> first arg-max pixel
+__global__ __launch_bounds__(256) void mask_attention_extrema_bwd_kernel(const float* __restrict__ head, int head_cs,
+                                                                        const float* __restrict__ datt, int HW,
+                                                                        const float* __restrict__ minmax,
+                                                                        float* __restrict__ dhead)
+{
+    __shared__ float s_a[4], s_b[4], s_mn[4], s_mx[4];
+    __shared__ int s_imn[4], s_imx[4];
+    const int b = blockIdx.x;
+    const float mn = minmax[b * 2], mx = minmax[b * 2 + 1], r2 = (mx - mn) * (mx - mn);
+    float a = 0.f, c = 0.f, vmn = FLT_MAX, vmx = -FLT_MAX;
+    int imn = 0x7fffffff, imx = 0x7fffffff;
+    for (int p = threadIdx.x; p < HW; p += 256) {
+        const float m = head[((long long)b * HW + p) * head_cs];
+        const float da = datt[(long long)b * HW + p];
+        a += da * (m - mx) / r2;
+        c -= da * (m - mn) / r2;
+        if (m < vmn) { vmn = m; imn = p; }
+        if (m > vmx) { vmx = m; imx = p; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o);
+        c += __shfl_xor(c, o);
+        const float omn = __shfl_xor(vmn, o), omx = __shfl_xor(vmx, o);
+        const int oimn = __shfl_xor(imn, o), oimx = __shfl_xor(imx, o);
+        if (omn < vmn || (omn == vmn && oimn < imn)) { vmn = omn; imn = oimn; }
+        if (omx > vmx || (omx == vmx && oimx < imx)) { vmx = omx; imx = oimx; }
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_a[w] = a; s_b[w] = c; s_mn[w] = vmn; s_mx[w] = vmx; s_imn[w] = imn; s_imx[w] = imx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = (s_a[0] + s_a[1]) + (s_a[2] + s_a[3]);
+        c = (s_b[0] + s_b[1]) + (s_b[2] + s_b[3]);
+        vmn = s_mn[0]; imn = s_imn[0]; vmx = s_mx[0]; imx = s_imx[0];
+        for (int k = 1; k < 4; ++k) {
+            if (s_mn[k] < vmn || (s_mn[k] == vmn && s_imn[k] < imn)) { vmn = s_mn[k]; imn = s_imn[k]; }
+            if (s_mx[k] > vmx || (s_mx[k] == vmx && s_imx[k] < imx)) { vmx = s_mx[k]; imx = s_imx[k]; }
+        }
+        dhead[((long long)b * HW + imn) * head_cs] += a;
+        dhead[((long long)b * HW + imx) * head_cs] += c;
+    }
+}
+
+extern "C" int rdpn6d_dense_glue_backward_f32(const float* head, int head_cs, const float* coord2d, const float* fps,
+                                              const int* argmax, const float* dpnp, int pnp_cs, int B, int HW, int K,
+                                              int mask_attention, const float* minmax, float* dhead, float* datt_scratch,
+                                              void* stream)
+{
+    RD_REQUIRE(head && coord2d && fps && argmax && dpnp && dhead, "null pointer");
+    RD_REQUIRE(B > 0 && HW > 0 && K >= 2 && K <= 64, "K in 2..64");
+    RD_REQUIRE(!mask_attention || (minmax && datt_scratch), "mask attention needs minmax and a [B,HW] scratch");
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned blocks = (unsigned)(((long long)B * HW + 255) / 256);
+    if (K <= 32)
+        hipLaunchKernelGGL(dense_glue_bwd_kernel<32>, dim3(blocks), dim3(256), 0, s, head, head_cs, coord2d, fps, argmax, dpnp, pnp_cs, B,
+                           HW, K, mask_attention, minmax, dhead, datt_scratch);
+    else
+        hipLaunchKernelGGL(dense_glue_bwd_kernel<64>, dim3(blocks), dim3(256), 0, s, head, head_cs, coord2d, fps, argmax, dpnp, pnp_cs, B,
+                           HW, K, mask_attention, minmax, dhead, datt_scratch);
+    RD_LAUNCH_CHECK();
+    if (mask_attention) {
+        hipLaunchKernelGGL(mask_attention_extrema_bwd_kernel, dim3(B), dim3(256), 0, s, head, head_cs, datt_scratch, HW, minmax, dhead);
+        RD_LAUNCH_CHECK();
+    }
+    return RDPN6D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pose decode (train variant) + PM_R / centroid / z losses, forward AND gradient w.r.t. the 9 head outputs,
+// by forward-mode automatic differentiation (dual numbers with 9 tangents): exact derivatives of
+// rot6d -> R_allo, SITE translation, allo->ego (acos / axis / quaternion, eps = 1e-4), without hand-derived formulas.
+struct Dual9 {
+    float v;
+    float d[9];
+};
+__device__ __forceinline__ Dual9 dconst(float c) { Dual9 r; r.v = c; for (int i = 0; i < 9; ++i) r.d[i] = 0.f; return r; }
+__device__ __forceinline__ Dual9 dvar(float c, int k) { Dual9 r = dconst(c); r.d[k] = 1.f; return r; }
+__device__ __forceinline__ Dual9 operator+(const Dual9& a, const Dual9& b) { Dual9 r; r.v = a.v + b.v; for (int i = 0; i < 9; ++i) r.d[i] = a.d[i] + b.d[i]; return r; }
+__device__ __forceinline__ Dual9 operator-(const Dual9& a, const Dual9& b) { Dual9 r; r.v = a.v - b.v; for (int i = 0; i < 9; ++i) r.d[i] = a.d[i] - b.d[i]; return r; }
+__device__ __forceinline__ Dual9 operator*(const Dual9& a, const Dual9& b) { Dual9 r; r.v = a.v * b.v; for (int i = 0; i < 9; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+__device__ __forceinline__ Dual9 operator/(const Dual9& a, const Dual9& b) { Dual9 r; r.v = a.v / b.v; for (int i = 0; i < 9; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) / b.v; return r; }
+__device__ __forceinline__ Dual9 operator*(const Dual9& a, float s) { Dual9 r; r.v = a.v * s; for (int i = 0; i < 9; ++i) r.d[i] = a.d[i] * s; return r; }
+__device__ __forceinline__ Dual9 operator+(const Dual9& a, float s) { Dual9 r = a; r.v += s; return r; }
+__device__ __forceinline__ Dual9 operator-(const Dual9& a, float s) { Dual9 r = a; r.v -= s; return r; }
+__device__ __forceinline__ Dual9 dneg(const Dual9& a) { Dual9 r; r.v = -a.v; for (int i = 0; i < 9; ++i) r.d[i] = -a.d[i]; return r; }
+__device__ __forceinline__ Dual9 dsqrt(const Dual9& a) { Dual9 r; r.v = sqrtf(a.v); const float k = 0.5f / r.v; for (int i = 0; i < 9; ++i) r.d[i] = a.d[i] * k; return r; }
+__device__ __forceinline__ Dual9 dacos(const Dual9& a) { Dual9 r; r.v = acosf(a.v); const float k = -1.0f / sqrtf(1.0f - a.v * a.v); for (int i = 0; i < 9; ++i) r.d[i] = a.d[i] * k; return r; }
+__device__ __forceinline__ Dual9 dsin(const Dual9& a) { Dual9 r; r.v = sinf(a.v); const float k = cosf(a.v); for (int i = 0; i < 9; ++i) r.d[i] = a.d[i] * k; return r; }
+__device__ __forceinline__ Dual9 dcos(const Dual9& a) { Dual9 r; r.v = cosf(a.v); const float k = -sinf(a.v); for (int i = 0; i < 9; ++i) r.d[i] = a.d[i] * k; return r; }
+// F.normalize: v / max(||v||, 1e-12)
+__device__ __forceinline__ void dnormalize3(Dual9* v)
+{
+    Dual9 n = dsqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    if (n.v < 1e-12f) n = dconst(1e-12f);
+    v[0] = v[0] / n; v[1] = v[1] / n; v[2] = v[2] / n;
+}
+
+// grid = B, block = 256.  losses_part [B][3] = per-sample (sum |w (R P - Rgt P)|, sum |dc|, |dz|)
+__global__ __launch_bounds__(256) void pose_train_kernel(const float* __restrict__ rt, int rt_stride, const float* __restrict__ cams,
+                                                         const float* __restrict__ centers, const float* __restrict__ whs,
+                                                         const float* __restrict__ ratios, const float* __restrict__ extents,
+                                                         const float* __restrict__ gt_rot, const float* __restrict__ gt_ratio,
+                                                         const float* __restrict__ points, int npts, int B, int is_allo,
+                                                         float pm_lw, int pm_norm_by_extent, float centroid_lw, float z_lw,
+                                                         float* __restrict__ rot, float* __restrict__ trans,
+                                                         float* __restrict__ d_rt, float* __restrict__ losses_part)
+{
+    __shared__ float s_R[9], s_G[4][10];
+    __shared__ Dual9 s_RD[9];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* p = rt + (long long)b * rt_stride;
+    if (tid == 0) {
+        Dual9 x[3], a2[3], z[3], y[3];
+        for (int i = 0; i < 3; ++i) { x[i] = dvar(p[i], i); a2[i] = dvar(p[3 + i], 3 + i); }
+        dnormalize3(x);
+        z[0] = x[1] * a2[2] - x[2] * a2[1];
+        z[1] = x[2] * a2[0] - x[0] * a2[2];
+        z[2] = x[0] * a2[1] - x[1] * a2[0];
+        dnormalize3(z);
+        y[0] = z[1] * x[2] - z[2] * x[1];
+        y[1] = z[2] * x[0] - z[0] * x[2];
+        y[2] = z[0] * x[1] - z[1] * x[0];
+        Dual9 Ra[9] = {x[0], y[0], z[0], x[1], y[1], z[1], x[2], y[2], z[2]};
+        const float* K = cams + b * 9;
+        const Dual9 cx = dvar(p[6], 6) * whs[b * 2 + 0] + centers[b * 2 + 0];
+        const Dual9 cy = dvar(p[7], 7) * whs[b * 2 + 1] + centers[b * 2 + 1];
+        const Dual9 tz = dvar(p[8], 8) * ratios[b];
+        Dual9 t[3] = {tz * (cx - K[2]) / dconst(K[0]), tz * (cy - K[5]) / dconst(K[4]), tz};
+        for (int i = 0; i < 3; ++i) trans[b * 3 + i] = t[i].v;
+        Dual9 R[9];
+        if (is_allo) {
+            const float eps = 1e-4f;
+            const Dual9 tn = dsqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]) + eps;
+            const Dual9 ray[3] = {t[0] / tn, t[1] / tn, t[2] / tn};
+            const Dual9 angle = dacos(ray[2]);
+            Dual9 ax = dneg(ray[1]), ay = ray[0];  // cross((0,0,1), ray) = (-ry, rx, 0)
+            const Dual9 an = dsqrt(ax * ax + ay * ay) + eps;
+            ax = ax / an; ay = ay / an;
+            const Dual9 half = angle * 0.5f;
+            const Dual9 sh = dsin(half);
+            Dual9 qw = dcos(half), qx = ax * sh, qy = ay * sh, qz = dconst(0.f);
+            const Dual9 qn = dsqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+            qw = qw / qn; qx = qx / qn; qy = qy / qn; qz = qz / qn;
+            const Dual9 X = qx * 2.f, Y = qy * 2.f, Z = qz * 2.f;
+            const Dual9 wX = qw * X, wY = qw * Y, wZ = qw * Z, xX = qx * X, xY = qx * Y, xZ = qx * Z, yY = qy * Y, yZ = qy * Z, zZ = qz * Z;
+            const Dual9 one = dconst(1.f);
+            const Dual9 M[9] = {one - (yY + zZ), xY - wZ, xZ + wY, xY + wZ, one - (xX + zZ), yZ - wX, xZ - wY, yZ + wX, one - (xX + yY)};
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) R[i * 3 + j] = M[i * 3] * Ra[j] + M[i * 3 + 1] * Ra[3 + j] + M[i * 3 + 2] * Ra[6 + j];
+        } else {
+            for (int i = 0; i < 9; ++i) R[i] = Ra[i];
+        }
+        for (int i = 0; i < 9; ++i) { s_RD[i] = R[i]; s_R[i] = R[i].v; rot[b * 9 + i] = R[i].v; }
+    }
+    __syncthreads();
+    // PM loss (R only): sum_p sum_i | w * ((R - Rgt) P)_i |, G_ij = sum_p w * sign(.)_i * P_j
+    const float* Rg = gt_rot + b * 9;
+    float w = 1.f;
+    if (pm_norm_by_extent) w = 1.0f / fmaxf(fmaxf(extents[b * 3], extents[b * 3 + 1]), extents[b * 3 + 2]);
+    float G[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, ls = 0.f;
+    for (int k = tid; k < npts; k += 256) {
+        const float* P = points + ((long long)b * npts + k) * 3;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float e = w * (s_R[i * 3] * P[0] + s_R[i * 3 + 1] * P[1] + s_R[i * 3 + 2] * P[2]) -
+                            w * (Rg[i * 3] * P[0] + Rg[i * 3 + 1] * P[1] + Rg[i * 3 + 2] * P[2]);
+            ls += fabsf(e);
+            const float sg = e > 0.f ? w : (e < 0.f ? -w : 0.f);
+            G[i * 3] += sg * P[0]; G[i * 3 + 1] += sg * P[1]; G[i * 3 + 2] += sg * P[2];
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ls += __shfl_xor(ls, o);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) G[i] += __shfl_xor(G[i], o);
+    }
+    if ((tid & 63) == 0) {
+        for (int i = 0; i < 9; ++i) s_G[tid >> 6][i] = G[i];
+        s_G[tid >> 6][9] = ls;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float Gt[9], lsum = (s_G[0][9] + s_G[1][9]) + (s_G[2][9] + s_G[3][9]);
+        for (int i = 0; i < 9; ++i) Gt[i] = (s_G[0][i] + s_G[1][i]) + (s_G[2][i] + s_G[3][i]);
+        // loss_PM_R = 3 * pm_lw * mean over (B, npts, 3)
+        const float pm_scale = 3.0f * pm_lw / ((float)B * (float)npts * 3.0f);
+        float g[9];
+        for (int k = 0; k < 9; ++k) {
+            float a = 0.f;
+            for (int i = 0; i < 9; ++i) a += Gt[i] * s_RD[i].d[k];
+            g[k] = a * pm_scale;
+        }
+        // centroid (mean over B*2) and z (mean over B) L1 on the raw head outputs
+        const float* gr = gt_ratio + b * 3;
+        float lc = 0.f;
+        for (int i = 0; i < 2; ++i) {
+            const float d = p[6 + i] - gr[i];
+            lc += fabsf(d);
+            g[6 + i] += centroid_lw * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) / ((float)B * 2.f);
+        }
+        const float dz = p[8] - gr[2];
+        g[8] += z_lw * (dz > 0.f ? 1.f : (dz < 0.f ? -1.f : 0.f)) / (float)B;
+        for (int k = 0; k < 9; ++k) d_rt[(long long)b * rt_stride + k] = g[k];
+        for (int k = 9; k < rt_stride; ++k) d_rt[(long long)b * rt_stride + k] = 0.f;
+        losses_part[b * 3 + 0] = lsum;
+        losses_part[b * 3 + 1] = lc;
+        losses_part[b * 3 + 2] = fabsf(dz);
+    }
+}
+
+// losses[0..2] = loss_PM_R, loss_centroid, loss_z
+__global__ void pose_loss_finalize_kernel(const float* __restrict__ part, int B, int npts, float pm_lw, float centroid_lw, float z_lw,
+                                          float* __restrict__ losses)
+{
+    if (threadIdx.x != 0) return;
+    double a = 0, c = 0, z = 0;
+    for (int b = 0; b < B; ++b) { a += part[b * 3]; c += part[b * 3 + 1]; z += part[b * 3 + 2]; }
+    losses[0] = (float)(3.0 * pm_lw * a / ((double)B * npts * 3.0));
+    losses[1] = (float)(centroid_lw * c / ((double)B * 2.0));
+    losses[2] = (float)(z_lw * z / (double)B);
+}
+
+extern "C" int rdpn6d_pose_train_f32(const float* rt, int rt_stride, const float* roi_cams, const float* roi_centers,
+                                     const float* roi_whs, const float* resize_ratios, const float* roi_extents,
+                                     const float* gt_rot, const float* gt_trans_ratio, const float* points, int npts, int B,
+                                     int is_allo, float pm_lw, int pm_norm_by_extent, float centroid_lw, float z_lw, float* rot,
+                                     float* trans, float* d_rt, float* losses /* [3] */, float* scratch /* [3B] */,
+                                     void* stream)
+{
+    RD_REQUIRE(rt && roi_cams && roi_centers && roi_whs && resize_ratios && roi_extents && gt_rot && gt_trans_ratio && points, "null pointer");
+    RD_REQUIRE(rot && trans && d_rt && losses && scratch && B > 0 && npts > 0 && rt_stride >= 9, "null/shape");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(pose_train_kernel, dim3(B), dim3(256), 0, s, rt, rt_stride, roi_cams, roi_centers, roi_whs, resize_ratios,
+                       roi_extents, gt_rot, gt_trans_ratio, points, npts, B, is_allo, pm_lw, pm_norm_by_extent, centroid_lw, z_lw,
+                       rot, trans, d_rt, scratch);
+    RD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(pose_loss_finalize_kernel, dim3(1), dim3(64), 0, s, scratch, B, npts, pm_lw, centroid_lw, z_lw, losses);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dy *= (y > 0 ? 1 : slope)   (ReLU: slope 0, LeakyReLU(0.1): slope 0.1; the activation output has the sign of
+// its input, so the saved output is enough)
+__global__ void act_backward_kernel(float* __restrict__ dy, const float* __restrict__ y, long long n, float slope)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        dy[i] = y[i] > 0.f ? dy[i] : dy[i] * slope;
+}
+
+extern "C" int rdpn6d_act_backward_f32(float* dy, const float* y, long long n, float slope, void* stream)
+{
+    RD_REQUIRE(dy && y && n > 0, "null/shape");
+    const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(act_backward_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, y, n, slope);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}
+
+// channels 0..2 of the NCHW crop -> NHWC [B,R,R,4] (4th channel zero): the stem's wgrad operand
+__global__ void rgb_to_nhwc4_kernel(const float* __restrict__ x, int B, int xc, int R, float* __restrict__ y)
+{
+    const long long total = (long long)B * R * R;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / ((long long)R * R), p = i - b * R * R;
+        f32x4 o;
+        o[0] = x[(b * xc + 0) * R * R + p];
+        o[1] = x[(b * xc + 1) * R * R + p];
+        o[2] = x[(b * xc + 2) * R * R + p];
+        o[3] = 0.f;
+        *reinterpret_cast<f32x4*>(y + i * 4) = o;
+    }
+}
+
+extern "C" int rdpn6d_rgb_to_nhwc4_f32(const float* x, int B, int xc, int R, float* y, void* stream)
+{
+    RD_REQUIRE(x && y && B > 0 && xc >= 3 && R > 0, "shape");
+    const long long total = (long long)B * R * R;
+    hipLaunchKernelGGL(rgb_to_nhwc4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, B, xc, R, y);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}

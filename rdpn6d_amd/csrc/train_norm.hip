@@ -1,0 +1,386 @@
+// Training-mode normalisation kernels (forward with batch statistics, and backward), NHWC fp32.
+//
+// BatchNorm2d in train mode (torch defaults: eps 1e-5, momentum 0.1, biased variance for the
+// normalisation, unbiased for the running estimate) as used by every BN of
+// core/gdrn_modeling/models/{resnet_backbone.py, cdpn_rot_head_region.py} (NORM="BN" -> plain
+// per-GPU BatchNorm, core/utils/layer_utils.py:30), and GroupNorm(32,128)+ReLU of
+// models/conv_pnp_net.py:80-82.  All are HBM-bound: one 256-byte coalesced row segment (64
+// channels) per wavefront, double-precision partial sums, two-stage reductions (partials in
+// global memory + a tiny finalize kernel) so results do not depend on atomics ordering.
+#include "common.h"
+#include <float.h>
+
+#define NS_MAX 64  // row splits of the partial reductions
+
+// ---------------------------------------------------------------------------------------------
+// Stage 1 of every per-channel reduction.  MODE 0: (sum x, sum x^2)         [BN statistics, bias grads]
+//                                            MODE 1: (sum g, sum g*xhat)       [BN backward], g = dy*(y>0) if relu
+// grid = (C/64, S); block = 256 = 4 row lanes x 64 channels
+template <int MODE>
+__global__ __launch_bounds__(256) void chan_partial_kernel(const float* __restrict__ x, int xcs, int xco,
+                                                           const float* __restrict__ dy, int dcs, int dco,
+                                                           const float* __restrict__ y, int ycs, int yco,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           long long M, int C, int relu, double* __restrict__ partial)
+{
+    __shared__ double s_a[4][64], s_b[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int S = gridDim.y;
+    const long long rows_per = (M + S - 1) / S;
+    const long long m_lo = (long long)blockIdx.y * rows_per, m_hi = m_lo + rows_per < M ? m_lo + rows_per : M;
+    double a = 0.0, b = 0.0;
+    if (c < C) {
+        float mu = 0.f, is = 0.f;
+        if (MODE == 1) { mu = mean[c]; is = invstd[c]; }
+        for (long long m = m_lo + rl; m < m_hi; m += 4) {
+            if (MODE == 0) {
+                const float v = x[m * xcs + xco + c];
+                a += (double)v;
+                b += (double)v * (double)v;
+            } else {
+                float g = dy[m * dcs + dco + c];
+                if (relu && !(y[m * ycs + yco + c] > 0.f)) g = 0.f;
+                const float xh = (x[m * xcs + xco + c] - mu) * is;
+                a += (double)g;
+                b += (double)g * (double)xh;
+            }
+        }
+    }
+    s_a[rl][cl] = a;
+    s_b[rl][cl] = b;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        a = (s_a[0][cl] + s_a[1][cl]) + (s_a[2][cl] + s_a[3][cl]);
+        b = (s_b[0][cl] + s_b[1][cl]) + (s_b[2][cl] + s_b[3][cl]);
+        partial[((long long)blockIdx.y * C + c) * 2 + 0] = a;
+        partial[((long long)blockIdx.y * C + c) * 2 + 1] = b;
+    }
+}
+
+// Stage 2 for BN statistics: mean, invstd, running-stat update.
+__global__ void bn_stats_finalize_kernel(const double* __restrict__ partial, int S, int C, long long M, float eps,
+                                         float momentum, float* __restrict__ mean, float* __restrict__ invstd,
+                                         float* __restrict__ running_mean, float* __restrict__ running_var)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int s = 0; s < S; ++s) { a += partial[((long long)s * C + c) * 2]; b += partial[((long long)s * C + c) * 2 + 1]; }
+    const double mu = a / (double)M;
+    double var = b / (double)M - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)mu;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
+        running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mu);
+        running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+    }
+}
+
+// Stage 2 for plain sums (bias gradients) and for BN backward (dgamma, dbeta).
+__global__ void chan_sum_finalize_kernel(const double* __restrict__ partial, int S, int C, float* __restrict__ out_a,
+                                         float* __restrict__ out_b, int accumulate)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int s = 0; s < S; ++s) { a += partial[((long long)s * C + c) * 2]; b += partial[((long long)s * C + c) * 2 + 1]; }
+    if (out_a) out_a[c] = (accumulate ? out_a[c] : 0.f) + (float)a;
+    if (out_b) out_b[c] = (accumulate ? out_b[c] : 0.f) + (float)b;
+}
+
+static int pick_splits(long long M, int C)
+{
+    long long s = (M + 511) / 512;
+    const long long want = 2048 / ((C + 63) / 64) + 1;  // enough workgroups to fill the chip
+    if (s > want) s = want;
+    if (s > NS_MAX) s = NS_MAX;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+extern "C" int rdpn6d_bn_train_stats_f32(const float* x, long long M, int C, int cs, int co, float eps, float momentum,
+                                         float* mean, float* invstd, float* running_mean, float* running_var,
+                                         double* scratch /* >= 64*C*2 doubles */, void* stream)
+{
+    RD_REQUIRE(x && mean && invstd && scratch, "null pointer");
+    RD_REQUIRE(M > 0 && C > 0 && co + C <= cs, "shape");
+    const int S = pick_splits(M, C);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(chan_partial_kernel<0>, dim3((C + 63) / 64, S), dim3(256), 0, s, x, cs, co, nullptr, 0, 0, nullptr, 0, 0,
+                       nullptr, nullptr, M, C, 0, scratch);
+    RD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, scratch, S, C, M, eps, momentum, mean,
+                       invstd, running_mean, running_var);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}
+
+// per-channel sum of rows (bias gradient): out[c] (+)= sum_m x[m, co + c]
+extern "C" int rdpn6d_channel_sum_f32(const float* x, long long M, int C, int cs, int co, float* out, int accumulate,
+                                      double* scratch, void* stream)
+{
+    RD_REQUIRE(x && out && scratch && M > 0 && C > 0 && co + C <= cs, "shape");
+    const int S = pick_splits(M, C);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(chan_partial_kernel<0>, dim3((C + 63) / 64, S), dim3(256), 0, s, x, cs, co, nullptr, 0, 0, nullptr, 0, 0,
+                       nullptr, nullptr, M, C, 0, scratch);
+    RD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, scratch, S, C, out, nullptr, accumulate);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// y = act(((x - mean) * invstd) * gamma + beta (+ res)), 4 channels per thread
+__global__ void bn_apply_kernel(const float* __restrict__ x, int xcs, int xco, const float* __restrict__ mean,
+                                const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, const float* __restrict__ res, int rcs, int rco,
+                                float* __restrict__ y, int ycs, int yco, long long M, int C, int relu)
+{
+    const int C4 = C / 4;
+    const long long total = M * C4;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        const long long m = i / C4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + m * xcs + xco + c);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (v[e] - mu[e]) * is[e] * ga[e] + be[e];
+        if (res) {
+            const f32x4 r = *reinterpret_cast<const f32x4*>(res + m * rcs + rco + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += r[e];
+        }
+        if (relu)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : 0.f;
+        *reinterpret_cast<f32x4*>(y + m * ycs + yco + c) = o;
+    }
+}
+
+extern "C" int rdpn6d_bn_apply_f32(const float* x, int xcs, int xco, const float* mean, const float* invstd,
+                                   const float* gamma, const float* beta, const float* res, int rcs, int rco, float* y,
+                                   int ycs, int yco, long long M, int C, int relu, void* stream)
+{
+    RD_REQUIRE(x && mean && invstd && gamma && beta && y, "null pointer");
+    RD_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && xco % 4 == 0 && yco % 4 == 0 && xcs % 4 == 0 && ycs % 4 == 0, "shape/alignment");
+    const long long total = M * (C / 4);
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, xcs, xco, mean, invstd, gamma, beta, res,
+                       rcs, rco, y, ycs, yco, M, C, relu);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// BN backward.  g = dy * (y > 0) when the BN was followed by ReLU.
+//   dgamma = sum g*xhat, dbeta = sum g
+//   dx = gamma*invstd * (g - dbeta/M - xhat*dgamma/M);   dres (optional) = g  (identity branch of a residual block)
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ x, int xcs, int xco, const float* __restrict__ dy, int dcs, int dco,
+                                    const float* __restrict__ y, int ycs, int yco, const float* __restrict__ mean,
+                                    const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                    float* __restrict__ dx, int xgcs, int xgco, float* __restrict__ dres, int rcs, int rco,
+                                    long long M, int C, int relu)
+{
+    const int C4 = C / 4;
+    const long long total = M * C4;
+    const float invM = 1.0f / (float)M;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        const long long m = i / C4;
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + m * xcs + xco + c);
+        f32x4 g = *reinterpret_cast<const f32x4*>(dy + m * dcs + dco + c);
+        if (relu) {
+            const f32x4 yv = *reinterpret_cast<const f32x4*>(y + m * ycs + yco + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = yv[e] > 0.f ? g[e] : 0.f;
+        }
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xh = (xv[e] - mean[c + e]) * invstd[c + e];
+            o[e] = gamma[c + e] * invstd[c + e] * (g[e] - dbeta[c + e] * invM - xh * dgamma[c + e] * invM);
+        }
+        *reinterpret_cast<f32x4*>(dx + m * xgcs + xgco + c) = o;
+        if (dres) *reinterpret_cast<f32x4*>(dres + m * rcs + rco + c) = g;
+    }
+}
+
+extern "C" int rdpn6d_bn_backward_f32(const float* x, int xcs, int xco, const float* dy, int dcs, int dco, const float* y,
+                                      int ycs, int yco, const float* mean, const float* invstd, const float* gamma,
+                                      float* dgamma, float* dbeta, float* dx, int xgcs, int xgco, float* dres, int rcs,
+                                      int rco, long long M, int C, int relu, double* scratch, void* stream)
+{
+    RD_REQUIRE(x && dy && mean && invstd && gamma && dgamma && dbeta && dx && scratch, "null pointer");
+    RD_REQUIRE(!relu || y, "ReLU mask needs the forward output");
+    RD_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "shape");
+    const int S = pick_splits(M, C);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(chan_partial_kernel<1>, dim3((C + 63) / 64, S), dim3(256), 0, s, x, xcs, xco, dy, dcs, dco, y, ycs, yco,
+                       mean, invstd, M, C, relu, scratch);
+    RD_LAUNCH_CHECK();
+    // partial = (sum g, sum g*xhat) -> dbeta, dgamma
+    hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, scratch, S, C, dbeta, dgamma, 0);
+    RD_LAUNCH_CHECK();
+    const long long total = M * (C / 4);
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, s, x, xcs, xco, dy, dcs, dco, y, ycs, yco, mean, invstd,
+                       gamma, dgamma, dbeta, dx, xgcs, xgco, dres, rcs, rco, M, C, relu);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm(G groups of 4 channels) + ReLU, training form: out-of-place, statistics saved.
+__global__ __launch_bounds__(256) void gn4_fwd_train_kernel(const float* __restrict__ x, float* __restrict__ y, int HW, int C,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ stats /* [B][G][2] mean, rstd */)
+{
+    const int G = C / 4, PL = 256 / G;
+    __shared__ float s_part[256];
+    __shared__ float s_mean[64], s_rstd[64];
+    const int g = threadIdx.x % G, pl = threadIdx.x / G;
+    const float* xb = x + (long long)blockIdx.x * HW * C + g * 4;
+    float* yb = y + (long long)blockIdx.x * HW * C + g * 4;
+    float s = 0.f;
+    for (int p = pl; p < HW; p += PL) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (long long)p * C);
+        s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    s_part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < G) {
+        float t = 0.f;
+        for (int i = 0; i < PL; ++i) t += s_part[i * G + threadIdx.x];
+        s_mean[threadIdx.x] = t / (float)(HW * 4);
+    }
+    __syncthreads();
+    const float mean = s_mean[g];
+    float q = 0.f;
+    for (int p = pl; p < HW; p += PL) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (long long)p * C);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[e] - mean; q += d * d; }
+    }
+    __syncthreads();
+    s_part[threadIdx.x] = q;
+    __syncthreads();
+    if (threadIdx.x < G) {
+        float t = 0.f;
+        for (int i = 0; i < PL; ++i) t += s_part[i * G + threadIdx.x];
+        const float r = 1.0f / sqrtf(t / (float)(HW * 4) + 1e-5f);
+        s_rstd[threadIdx.x] = r;
+        stats[((long long)blockIdx.x * G + threadIdx.x) * 2 + 0] = s_mean[threadIdx.x];
+        stats[((long long)blockIdx.x * G + threadIdx.x) * 2 + 1] = r;
+    }
+    __syncthreads();
+    const float rstd = s_rstd[g];
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + g * 4), be = *reinterpret_cast<const f32x4*>(beta + g * 4);
+    for (int p = pl; p < HW; p += PL) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(xb + (long long)p * C);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float o = (v[e] - mean) * rstd * ga[e] + be[e]; v[e] = o > 0.f ? o : 0.f; }
+        *reinterpret_cast<f32x4*>(yb + (long long)p * C) = v;
+    }
+}
+
+// backward: g = dy*(y>0); per (b, group): s1 = sum g*gamma, s2 = sum g*gamma*xhat over the group's HW*4 elements;
+// dx = rstd*(g*gamma - s1/n - xhat*s2/n); per-sample partial dgamma/dbeta -> [B][C][2] (reduced by channel_sum afterwards)
+__global__ __launch_bounds__(256) void gn4_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                      const float* __restrict__ dy, const float* __restrict__ gamma,
+                                                      const float* __restrict__ stats, float* __restrict__ dx,
+                                                      float* __restrict__ dgb /* [B][2][C] */, int HW, int C)
+{
+    const int G = C / 4, PL = 256 / G;
+    __shared__ float s_p1[256], s_p2[256];
+    __shared__ float s_s1[64], s_s2[64];
+    __shared__ float s_dg[256][4], s_db[256][4];
+    const int g = threadIdx.x % G, pl = threadIdx.x / G;
+    const long long base = (long long)blockIdx.x * HW * C + g * 4;
+    const float mean = stats[((long long)blockIdx.x * G + g) * 2], rstd = stats[((long long)blockIdx.x * G + g) * 2 + 1];
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + g * 4);
+    float s1 = 0.f, s2 = 0.f;
+    float dg[4] = {0, 0, 0, 0}, db[4] = {0, 0, 0, 0};
+    for (int p = pl; p < HW; p += PL) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + base + (long long)p * C);
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(y + base + (long long)p * C);
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(dy + base + (long long)p * C);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gg = yv[e] > 0.f ? gv[e] : 0.f;
+            const float xh = (xv[e] - mean) * rstd;
+            s1 += gg * ga[e];
+            s2 += gg * ga[e] * xh;
+            dg[e] += gg * xh;
+            db[e] += gg;
+        }
+    }
+    s_p1[threadIdx.x] = s1;
+    s_p2[threadIdx.x] = s2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s_dg[threadIdx.x][e] = dg[e]; s_db[threadIdx.x][e] = db[e]; }
+    __syncthreads();
+    if (threadIdx.x < G) {
+        float t1 = 0.f, t2 = 0.f, tg[4] = {0, 0, 0, 0}, tb[4] = {0, 0, 0, 0};
+        for (int i = 0; i < PL; ++i) {
+            t1 += s_p1[i * G + threadIdx.x];
+            t2 += s_p2[i * G + threadIdx.x];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { tg[e] += s_dg[i * G + threadIdx.x][e]; tb[e] += s_db[i * G + threadIdx.x][e]; }
+        }
+        s_s1[threadIdx.x] = t1;
+        s_s2[threadIdx.x] = t2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            dgb[((long long)blockIdx.x * 2 + 0) * C + threadIdx.x * 4 + e] = tg[e];
+            dgb[((long long)blockIdx.x * 2 + 1) * C + threadIdx.x * 4 + e] = tb[e];
+        }
+    }
+    __syncthreads();
+    const float n = (float)(HW * 4);
+    const float m1 = s_s1[g] / n, m2 = s_s2[g] / n;
+    for (int p = pl; p < HW; p += PL) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + base + (long long)p * C);
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(y + base + (long long)p * C);
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(dy + base + (long long)p * C);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gg = yv[e] > 0.f ? gv[e] : 0.f;
+            const float xh = (xv[e] - mean) * rstd;
+            o[e] = rstd * (gg * ga[e] - m1 - xh * m2);
+        }
+        *reinterpret_cast<f32x4*>(dx + base + (long long)p * C) = o;
+    }
+}
+
+extern "C" int rdpn6d_groupnorm_relu_train_f32(const float* x, float* y, int B, int HW, int C, int G, const float* gamma,
+                                               const float* beta, float* stats, void* stream)
+{
+    RD_REQUIRE(x && y && gamma && beta && stats && B > 0 && HW > 0, "null/shape");
+    RD_REQUIRE(C == 4 * G && G <= 64 && 256 % G == 0, "only C/G == 4 with G | 256 is implemented (GroupNorm(32,128))");
+    hipLaunchKernelGGL(gn4_fwd_train_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, y, HW, C, gamma, beta, stats);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}
+
+extern "C" int rdpn6d_groupnorm_relu_backward_f32(const float* x, const float* y, const float* dy, const float* gamma,
+                                                  const float* stats, float* dx, float* dgamma, float* dbeta,
+                                                  float* dgb_scratch /* [B][2][C] */, double* scratch, int B, int HW, int C,
+                                                  int G, void* stream)
+{
+    RD_REQUIRE(x && y && dy && gamma && stats && dx && dgamma && dbeta && dgb_scratch && scratch, "null pointer");
+    RD_REQUIRE(C == 4 * G && G <= 64 && 256 % G == 0, "only C/G == 4 with G | 256 is implemented");
+    hipLaunchKernelGGL(gn4_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, y, dy, gamma, stats, dx, dgb_scratch, HW, C);
+    RD_LAUNCH_CHECK();
+    // [B][2C] rows -> per-column sums: dgamma = cols [0,C), dbeta = cols [C,2C)
+    int rc = rdpn6d_channel_sum_f32(dgb_scratch, B, C, 2 * C, 0, dgamma, 0, scratch, stream);
+    if (rc) return rc;
+    return rdpn6d_channel_sum_f32(dgb_scratch, B, C, 2 * C, C, dbeta, 0, scratch, stream);
+}

@@ -1,0 +1,225 @@
+// Weight-gradient implicit GEMM on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32).
+//
+//   out[a][t][b] = sum over pixels m of  A[m][a] * Bg[gather(m, t)][b]
+//     conv wgrad     : A = dY (pixels x Cout),        Bg = X gathered at (oy*s+dy_t, ox*s+dx_t)  -> dW packed [Cout][taps][Cin]
+//     convT wgrad    : A = X  (input pixels x Cin),   Bg = dY gathered at (2iy-1+ky, 2ix-1+kx)   -> [Cin][taps][Cout]
+//     linear wgrad   : A = dY (B x Nout), Bg = X (B x K), taps = 1
+//   The reduction runs over PIXELS (the NHWC row index), so both operands are staged pixel-major
+//   [16 pixels][128 channels] exactly as they lie in HBM (512-byte coalesced rows, no transpose) and the MFMA
+//   fragments are read column-wise with conflict-free ds_read_b32 (32 consecutive channels per half-wave).
+//   Split-K over pixel ranges: grid.y splits write fp32 partial tiles that a second kernel sums in a fixed
+//   order (deterministic, no atomics).
+// Backward of nn.Conv2d / nn.ConvTranspose2d / nn.Linear weights in core/gdrn_modeling/models/*.py.
+#include "common.h"
+
+struct WgradKArgs {
+    const float* A;
+    const float* Bg;
+    float* partial;  // [S][Ca][ntaps][Cb]
+    long long M;     // pixels of A = Bn*Ha*Wa
+    int Ha, Wa, HaWa;
+    int Hb, Wb;
+    int stride;
+    int ntaps;
+    unsigned long long dy_pack, dx_pack;
+    int Ca, Cb;
+    int a_cs, a_co, b_cs, b_co;
+    int atiles, btiles;  // tiles over Ca and over Cb (per tap)
+    long long rows_per_split;
+    unsigned a_bytes, b_bytes;
+};
+
+template <int BA, int BB>
+__global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradKArgs a)
+{
+    constexpr int TA = BA / 64, TB = BB / 64;  // 32x32 tiles per wave (2x2 waves)
+    __shared__ __attribute__((aligned(16))) float As[2][16][BA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][16][BB];
+
+    const int tile = blockIdx.x;
+    const int at = tile % a.atiles;
+    const int rest = tile / a.atiles;
+    const int bt = rest % a.btiles;
+    const int tap = rest / a.btiles;
+    const int a0 = at * BA, b0 = bt * BB;
+    const int dy = (int)((a.dy_pack >> (4 * tap)) & 15ull) - 8, dx = (int)((a.dx_pack >> (4 * tap)) & 15ull) - 8;
+    const long long m_lo = (long long)blockIdx.y * a.rows_per_split;
+    const long long m_hi = m_lo + a.rows_per_split < a.M ? m_lo + a.rows_per_split : a.M;
+    const int nchunks = m_hi > m_lo ? (int)((m_hi - m_lo + 15) / 16) : 0;
+
+    const __amdgpu_buffer_rsrc_t asrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.A), 0, a.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t bsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Bg), 0, a.b_bytes, 0x00020000);
+
+    const int tid = threadIdx.x;
+    // staging: A tile row = 16 pixels x BA channels = BA/4 float4 per pixel row; thread -> (row, c4)
+    constexpr int A4 = BA / 4, B4 = BB / 4;       // float4 per row
+    constexpr int AROWS = 256 / A4, BROWS = 256 / B4;  // rows covered per pass (BA=128: 8, BA=64: 16)
+    constexpr int APASS = 16 / AROWS, BPASS = 16 / BROWS;
+    const int ar = tid / A4, ac4 = tid % A4, br = tid / B4, bc4 = tid % B4;
+    const bool a_cok = a0 + ac4 * 4 < a.Ca, b_cok = b0 + bc4 * 4 < a.Cb;
+
+    f32x4 ra[APASS], rb[BPASS];
+    auto load_chunk = [&](int ch) {
+        const long long mb = m_lo + (long long)ch * 16;
+#pragma unroll
+        for (int p = 0; p < APASS; ++p) {
+            const long long m = mb + ar + p * AROWS;
+            const bool ok = a_cok && m < m_hi;
+            const unsigned off = ok ? (unsigned)((m * a.a_cs + a.a_co + a0 + ac4 * 4) * 4) : a.a_bytes;
+            ra[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(asrc, (int)off, 0, 0));
+        }
+#pragma unroll
+        for (int p = 0; p < BPASS; ++p) {
+            const long long m = mb + br + p * BROWS;
+            bool ok = b_cok && m < m_hi;
+            unsigned off = a.b_bytes;
+            if (ok) {
+                const int mm = (int)m;
+                const int bi = mm / a.HaWa;
+                const int rem = mm - bi * a.HaWa;
+                const int oy = rem / a.Wa;
+                const int ox = rem - oy * a.Wa;
+                const int iy = oy * a.stride + dy, ix = ox * a.stride + dx;
+                ok = (unsigned)iy < (unsigned)a.Hb && (unsigned)ix < (unsigned)a.Wb;
+                if (ok) off = (unsigned)((((long long)bi * a.Hb + iy) * a.Wb + ix) * a.b_cs + a.b_co + b0 + bc4 * 4) * 4u;
+            }
+            rb[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bsrc, (int)off, 0, 0));
+        }
+    };
+    auto store_lds = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < APASS; ++p) *reinterpret_cast<f32x4*>(&As[buf][ar + p * AROWS][ac4 * 4]) = ra[p];
+#pragma unroll
+        for (int p = 0; p < BPASS; ++p) *reinterpret_cast<f32x4*>(&Bs[buf][br + p * BROWS][bc4 * 4]) = rb[p];
+    };
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wa = wave >> 1, wb = wave & 1;
+    const int frow = lane & 31, koff = (lane >> 5) * 8;
+
+    f32x16 acc[TA][TB];
+#pragma unroll
+    for (int i = 0; i < TA; ++i)
+#pragma unroll
+        for (int j = 0; j < TB; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    if (nchunks > 0) {
+        load_chunk(0);
+        store_lds(0);
+        __syncthreads();
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const int buf = ch & 1;
+            load_chunk(ch + 1 < nchunks ? ch + 1 : ch);  // clamped: the redundant last load is never stored
+            float fa[TA][8], fb[TB][8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+#pragma unroll
+                for (int i = 0; i < TA; ++i) fa[i][s] = As[buf][koff + s][wa * (BA / 2) + i * 32 + frow];
+#pragma unroll
+                for (int j = 0; j < TB; ++j) fb[j][s] = Bs[buf][koff + s][wb * (BB / 2) + j * 32 + frow];
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+#pragma unroll
+                for (int i = 0; i < TA; ++i)
+#pragma unroll
+                    for (int j = 0; j < TB; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+            if (ch + 1 < nchunks) store_lds(buf ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // partial[split][a][tap][b]: lanes hold consecutive b (32 x 4 B = 128-byte runs)
+    const int hi = lane >> 5;
+    float* po = a.partial + (long long)blockIdx.y * a.Ca * a.ntaps * a.Cb;
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+        const int bch = b0 + wb * (BB / 2) + j * 32 + frow;
+        if (bch >= a.Cb) continue;
+#pragma unroll
+        for (int i = 0; i < TA; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ach = a0 + wa * (BA / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                if (ach < a.Ca) po[((long long)ach * a.ntaps + tap) * a.Cb + bch] = acc[i][j][e];
+            }
+    }
+}
+
+__global__ void splitk_reduce_kernel(const float* __restrict__ partial, int S, long long n, float* __restrict__ out)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < S; ++k) s += partial[(long long)k * n + i];
+        out[i] = s;
+    }
+}
+
+// A [Bn*Ha*Wa rows, a_cs] ; Bg NHWC [Bn,Hb,Wb,b_cs]; out [Ca][ntaps][Cb] fp32;
+// partial = scratch of at least rdpn6d_wgrad_scratch_floats(...) floats
+extern "C" long long rdpn6d_wgrad_scratch_floats(int Bn, int Ha, int Wa, int Ca, int Cb, int ntaps);
+
+static int wgrad_pick_splits(long long M, int tiles)
+{
+    long long s = (1024 + tiles - 1) / tiles;          // aim for ~1024 workgroups
+    const long long maxs = (M + 255) / 256;            // at least 16 chunks of 16 pixels per split
+    if (s > maxs) s = maxs;
+    if (s > 64) s = 64;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+extern "C" long long rdpn6d_wgrad_scratch_floats(int Bn, int Ha, int Wa, int Ca, int Cb, int ntaps)
+{
+    const int ba = Ca > 64 ? 128 : 64, bb = Cb > 64 ? 128 : 64;
+    const int tiles = ((Ca + ba - 1) / ba) * ((Cb + bb - 1) / bb) * ntaps;
+    return (long long)wgrad_pick_splits((long long)Bn * Ha * Wa, tiles) * Ca * ntaps * Cb;
+}
+
+extern "C" int rdpn6d_wgrad_f32(const float* A, int a_cs, int a_co, int Ca, const float* Bg, int b_cs, int b_co, int Cb,
+                                int Bn, int Ha, int Wa, int Hb, int Wb, int stride, int ntaps, const int* dy,
+                                const int* dx, float* out, float* partial, void* stream)
+{
+    RD_REQUIRE(A && Bg && out && partial && dy && dx, "null pointer");
+    RD_REQUIRE(Bn > 0 && Ha > 0 && Wa > 0 && Hb > 0 && Wb > 0 && stride >= 1, "shape");
+    RD_REQUIRE(Ca > 0 && Cb > 0 && Ca % 4 == 0 && Cb % 4 == 0, "channel counts must be multiples of 4");
+    RD_REQUIRE(a_cs % 4 == 0 && a_co % 4 == 0 && b_cs % 4 == 0 && b_co % 4 == 0, "channel slices must be 16-byte aligned");
+    RD_REQUIRE(a_co + Ca <= a_cs && b_co + Cb <= b_cs, "channel slices");
+    RD_REQUIRE(ntaps >= 1 && ntaps <= 9, "ntaps in 1..9");
+    WgradKArgs a;
+    a.A = A; a.Bg = Bg; a.partial = partial;
+    a.M = (long long)Bn * Ha * Wa;
+    RD_REQUIRE(a.M < (1LL << 31), "pixel count must fit 31 bits");
+    a.Ha = Ha; a.Wa = Wa; a.HaWa = Ha * Wa; a.Hb = Hb; a.Wb = Wb; a.stride = stride; a.ntaps = ntaps;
+    a.dy_pack = a.dx_pack = 0;
+    for (int t = 0; t < ntaps; ++t) {
+        RD_REQUIRE(dy[t] >= -8 && dy[t] <= 7 && dx[t] >= -8 && dx[t] <= 7, "tap offsets must be in -8..7");
+        a.dy_pack |= (unsigned long long)(dy[t] + 8) << (4 * t);
+        a.dx_pack |= (unsigned long long)(dx[t] + 8) << (4 * t);
+    }
+    a.Ca = Ca; a.Cb = Cb; a.a_cs = a_cs; a.a_co = a_co; a.b_cs = b_cs; a.b_co = b_co;
+    const long long ab = a.M * a_cs * 4, bb_ = (long long)Bn * Hb * Wb * b_cs * 4;
+    RD_REQUIRE(ab < (1LL << 32) - 64 && bb_ < (1LL << 32) - 64, "operands must be smaller than 4 GiB (32-bit buffer offsets)");
+    a.a_bytes = (unsigned)ab; a.b_bytes = (unsigned)bb_;
+    const int ba = Ca > 64 ? 128 : 64, bb = Cb > 64 ? 128 : 64;
+    a.atiles = (Ca + ba - 1) / ba;
+    a.btiles = (Cb + bb - 1) / bb;
+    const int tiles = a.atiles * a.btiles * ntaps;
+    const int S = wgrad_pick_splits(a.M, tiles);
+    a.rows_per_split = ((a.M + S - 1) / S + 15) / 16 * 16;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(tiles, S), block(256);
+    if (ba == 128 && bb == 128) hipLaunchKernelGGL((wgrad_f32_kernel<128, 128>), grid, block, 0, s, a);
+    else if (ba == 128) hipLaunchKernelGGL((wgrad_f32_kernel<128, 64>), grid, block, 0, s, a);
+    else if (bb == 128) hipLaunchKernelGGL((wgrad_f32_kernel<64, 128>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((wgrad_f32_kernel<64, 64>), grid, block, 0, s, a);
+    RD_LAUNCH_CHECK();
+    const long long n = (long long)Ca * ntaps * Cb;
+    const int rblocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rblocks), dim3(256), 0, s, partial, S, n, out);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}

@@ -1,0 +1,533 @@
+"""Training step of the RDPN6D hot path on the HIP kernels: forward with batch statistics, the nine
+losses of the shipped configs, and the full backward into ``param.grad``.
+
+Mirrors what ``GDRN.forward(do_loss=True)`` + ``losses.backward()`` do in the reference
+(core/gdrn_modeling/models/GDRN.py:107-371 forward, :373-633 losses; engine.py:292-308), but every
+tensor op is a C-ABI launch of librdpn6d_hip.so:
+
+  forward   raw conv (rdpn6d_conv2d_f32, no folded BN) -> rdpn6d_bn_train_stats -> rdpn6d_bn_apply
+            (+residual, ReLU); GroupNorm train form; same glue / FC kernels as inference
+  losses    rdpn6d_dense_losses (coor x/y/z, mask, region CE, region_my + d/dhead in one pass),
+            rdpn6d_pose_train (pose decode train variant + PM_R / centroid / z, gradient by dual numbers)
+  backward  dgrad = rdpn6d_conv2d_f32 with flipped / transposed / phase-split weights,
+            wgrad = rdpn6d_wgrad_f32 (split-K implicit GEMM over pixels), BN/GN backward,
+            maxpool / upsample / global-max / glue backward kernels
+
+PyTorch is used for memory, for the (tiny, once per step) weight re-packing and for moving the packed
+gradient tiles into ``param.grad`` layout.  Gradients of all 164 parameter tensors are produced.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from .gdrn import _pad_to, _pad_vec, _ptr, pack_conv_weight
+
+BN_EPS, BN_MOM = 1e-5, 0.1
+
+
+def _taps(k, pad):
+    return [(ky - pad, kx - pad) for ky in range(k) for kx in range(k)]
+
+
+class TrainEngine:
+    def __init__(self, model, B, device):
+        self.lib = _lib.load()
+        self.model, self.B, self.dev = model, B, device
+        cfg = model.cfg
+        self.R = int(cfg.MODEL.CDPN.BACKBONE.INPUT_RES)
+        self.K = int(cfg.MODEL.CDPN.ROT_HEAD.NUM_REGIONS)
+        pc, rc = cfg.MODEL.CDPN.PNP_NET, cfg.MODEL.CDPN.ROT_HEAD
+        self.mask_attention = 1 if pc.MASK_ATTENTION == "mul" else 0
+        if pc.MASK_ATTENTION not in ("none", "mul"):
+            raise ValueError("MASK_ATTENTION must be none | mul")
+        if rc.XYZ_LOSS_TYPE != "L1" or rc.MASK_LOSS_TYPE != "L1" or rc.REGION_LOSS_TYPE != "CE":
+            raise NotImplementedError("only the loss types of the shipped RGB-D configs (L1 / L1 / CE) are implemented")
+        if rc.XYZ_LOSS_MASK_GT != "visib" or rc.MASK_LOSS_GT != "trunc" or rc.REGION_LOSS_MASK_GT != "visib":
+            raise NotImplementedError("loss mask selection other than visib/trunc/visib is not implemented")
+        if not (pc.PM_R_ONLY and pc.PM_LOSS_TYPE == "L1" and not pc.PM_LOSS_SYM and pc.PM_LW > 0):
+            raise NotImplementedError("only PM_R_ONLY L1 non-symmetric point-matching loss is implemented")
+        if pc.CENTROID_LOSS_TYPE != "L1" or pc.Z_LOSS_TYPE != "L1" or pc.ROT_LW > 0 or pc.TRANS_LW > 0 or pc.get("BIND_LW", 0) > 0:
+            raise NotImplementedError("only L1 centroid / z losses (ROT_LW = TRANS_LW = BIND_LW = 0) are implemented")
+        self.lw = dict(xyz=float(rc.XYZ_LW), mask=float(rc.MASK_LW), region=float(rc.REGION_LW), pm=float(pc.PM_LW),
+                       centroid=float(pc.CENTROID_LW), z=float(pc.Z_LW), pm_norm=1 if pc.PM_NORM_BY_EXTENT else 0)
+        self.is_allo = 1 if "allo" in pc.ROT_TYPE else 0
+        self.bufs = {}
+        self.packed = []     # (refresh_fn) closures re-packing weights into persistent buffers
+        self.fwd, self.bwd = [], []   # launch closures
+        self._scratch_d = torch.empty(64 * 1024 * 2 + 64, dtype=torch.float64, device=device)
+        self._wg_floats = 0
+        self._build()
+        self._wg_partial = torch.empty(max(self._wg_floats, 1), dtype=torch.float32, device=device)
+        self.refresh_weights()
+
+    # ------------------------------------------------------------------ helpers
+    def buf(self, name, *shape, dtype=torch.float32, zero=False):
+        if name not in self.bufs:
+            self.bufs[name] = (torch.zeros if zero else torch.empty)(*shape, dtype=dtype, device=self.dev)
+        return self.bufs[name]
+
+    def st(self):
+        return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def _grad(self, p):
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+        return p.grad
+
+    def _conv_desc(self, x, xhw, in_cs, in_co, cin, w, y, yhw, out_cs, out_co, N, taps, stride=1, phase=None, shift=None,
+                   res=None, res_cs=0, act=0, slope=0.0):
+        d = _lib.ConvDesc()
+        d.x, d.w, d.scale, d.shift, d.res, d.y = _ptr(x), _ptr(w), None, _ptr(shift), _ptr(res), _ptr(y)
+        d.B, d.H, d.W = self.B, xhw[0], xhw[1]
+        d.Cin, d.in_cs, d.in_co = cin, in_cs, in_co
+        d.ntaps = len(taps)
+        for t, (dy, dx) in enumerate(taps):
+            d.dy[t], d.dx[t] = dy, dx
+        d.stride = stride
+        d.N, d.Npad = N, w.shape[0]
+        d.OH, d.OW = yhw
+        if phase is None:
+            d.Ho, d.Wo, d.osy, d.osx, d.ooy, d.oox = yhw[0], yhw[1], 1, 1, 0, 0
+        else:
+            d.Ho, d.Wo, d.osy, d.osx, d.ooy, d.oox = phase
+        d.out_cs, d.out_co, d.res_cs, d.res_co = out_cs, out_co, res_cs, 0
+        d.act, d.slope = act, slope
+        assert w.shape[1] == d.ntaps and w.shape[2] == cin, (tuple(w.shape), d.ntaps, cin)
+        return d
+
+    def _launch_conv(self, name, d, keep):
+        lib = self.lib
+
+        def run():
+            _lib.check(lib.rdpn6d_conv2d_f32(ctypes.byref(d), self.st()), name)
+
+        run.keep = (d, keep)
+        return run
+
+    # persistent packed-weight buffer refreshed from the live parameter by `fn`
+    def _packed(self, shape, fn):
+        t = torch.zeros(*shape, dtype=torch.float32, device=self.dev)
+        self.packed.append((t, fn))
+        return t
+
+    def refresh_weights(self):
+        """re-pack forward / dgrad weights from the current parameters (call after every optimizer step)"""
+        with torch.no_grad():
+            for t, fn in self.packed:
+                fn(t)
+
+    # ------------------------------------------------------------------ layer builders
+    def conv_unit(self, name, P, x, xhw, in_cs, in_co, cin_real, y, yhw, out_cs, out_co, *, stride=1, perm=None, bias=None,
+                  dx=None, dx_cs=None, dx_res=None, act_out=None, slope=0.0, first=False):
+        """One convolution: forward launch now, backward launches pushed on self.bwd (executed in reverse).
+        x: input activation tensor; y: raw output tensor; dx: gradient buffer for the input (None = not needed).
+        The gradient w.r.t. y is expected in self.bufs['d:'+name] when the backward runs."""
+        w = P.weight
+        cout, _, k, _ = w.shape
+        pad = k // 2
+        cin_pad = _pad_to(cin_real, 16)
+        npad = _pad_to(cout, 64)
+        lib, B = self.lib, self.B
+        # ---- forward weights
+        wf = self._packed((npad, k * k, cin_pad), lambda t, w=w, perm=perm, cin_pad=cin_pad: t.copy_(
+            pack_conv_weight(w.detach().float(), cin_pad=cin_pad, perm=perm)))
+        bvec = None
+        if bias is not None:
+            bvec = self._packed((npad,), lambda t, b=bias: t[: b.numel()].copy_(b.detach().float()))
+        taps = _taps(k, pad)
+        d = self._conv_desc(x, xhw, in_cs, in_co, cin_pad, wf, y, yhw, out_cs, out_co, cout, taps, stride=stride, shift=bvec,
+                            act=act_out or 0, slope=slope)
+        self.fwd.append(self._launch_conv(name, d, (wf, bvec)))
+        # ---- backward
+        dy = self.buf("d:" + name, *y.shape, zero=True)  # gradient w.r.t. the raw conv output (same layout as y)
+        M = B * yhw[0] * yhw[1]
+        ca = _pad_to(cout, 4)
+        cb = _pad_to(cin_real, 4)
+        tdy = (ctypes.c_int * 9)(*[t[0] for t in taps] + [0] * (9 - len(taps)))
+        tdx = (ctypes.c_int * 9)(*[t[1] for t in taps] + [0] * (9 - len(taps)))
+        wg_out = self.buf("wg:" + name, ca, k * k, cb)
+        self._wg_floats = max(self._wg_floats, int(lib.rdpn6d_wgrad_scratch_floats(B, yhw[0], yhw[1], ca, cb, k * k)))
+        inv_perm = None
+        if perm is not None:
+            inv_perm = torch.empty(len(perm), dtype=torch.long)
+            inv_perm[torch.tensor(perm)] = torch.arange(len(perm))
+            inv_perm = inv_perm.to(self.dev)
+
+        def wgrad():
+            _lib.check(lib.rdpn6d_wgrad_f32(_ptr(dy), out_cs, out_co, ca, _ptr(x), in_cs, in_co, cb, B, yhw[0], yhw[1], xhw[0],
+                                            xhw[1], stride, k * k, tdy, tdx, _ptr(wg_out), _ptr(self._wg_partial), self.st()),
+                       "wgrad " + name)
+            g = wg_out[:cout, :, :cin_real].view(cout, k, k, cin_real).permute(0, 3, 1, 2)
+            if inv_perm is not None:
+                g = g[:, inv_perm]
+            self._grad(w).copy_(g)
+            if bias is not None:
+                bg = self.buf("bg:" + name, npad)
+                _lib.check(lib.rdpn6d_channel_sum_f32(_ptr(dy), M, ca, out_cs, out_co, _ptr(bg), 0, _ptr(self._scratch_d),
+                                                      self.st()), "bias grad " + name)
+                self._grad(bias).copy_(bg[:cout])
+
+        launches = [wgrad]
+        if dx is not None:
+            n_red = _pad_to(cout, 16)  # reduction channels of the dgrad = output channels of the forward
+            assert out_cs - out_co >= n_red, (name, out_cs, n_red)
+            cdx = _pad_to(cin_real, 64)
+            dx_cs = dx_cs or in_cs
+            if stride == 1:
+                def pk(t, w=w, perm=perm):
+                    ww = w.detach().float()
+                    if perm is not None:
+                        ww = ww[:, perm]
+                    t.copy_(pack_conv_weight(ww.flip(2, 3).permute(1, 0, 2, 3), cin_pad=n_red))
+                wd = self._packed((cdx, k * k, n_red), pk)
+                dd = self._conv_desc(dy, yhw, out_cs, out_co, n_red, wd, dx, xhw, dx_cs, in_co, cin_real, taps, stride=1,
+                                     res=dx_res, res_cs=dx_cs)
+                launches.append(self._launch_conv("dgrad " + name, dd, wd))
+            else:
+                assert stride == 2 and perm is None
+                if k == 3:
+                    for py in (0, 1):
+                        for px in (0, 1):
+                            ys = [(1, 0)] if py == 0 else [(0, 1), (2, 0)]
+                            xs = [(1, 0)] if px == 0 else [(0, 1), (2, 0)]
+                            ptaps = [(dyo, dxo) for _, dyo in ys for _, dxo in xs]
+                            kk = [(ky, kx) for ky, _ in ys for kx, _ in xs]
+
+                            def pk(t, w=w, kk=kk, n_red=n_red):
+                                ww = w.detach().float()
+                                for ti, (ky, kx) in enumerate(kk):
+                                    t[: ww.shape[1], ti, : ww.shape[0]].copy_(ww[:, :, ky, kx].t())
+                            wd = self._packed((cdx, len(ptaps), n_red), pk)
+                            dd = self._conv_desc(dy, yhw, out_cs, out_co, n_red, wd, dx, xhw, dx_cs, in_co, cin_real, ptaps,
+                                                 phase=(yhw[0], yhw[1], 2, 2, py, px))
+                            launches.append(self._launch_conv(f"dgrad {name} phase{py}{px}", dd, wd))
+                else:  # 1x1 stride 2: only the even pixels receive a gradient; accumulate onto what is there
+                    def pk(t, w=w):
+                        ww = w.detach().float()
+                        t[: ww.shape[1], 0, : ww.shape[0]].copy_(ww[:, :, 0, 0].t())
+                    wd = self._packed((cdx, 1, n_red), pk)
+                    dd = self._conv_desc(dy, yhw, out_cs, out_co, n_red, wd, dx, xhw, dx_cs, in_co, cin_real, [(0, 0)],
+                                         phase=(yhw[0], yhw[1], 2, 2, 0, 0), res=dx, res_cs=dx_cs)
+                    launches.append(self._launch_conv("dgrad " + name, dd, wd))
+        self.bwd.append(launches)
+        return dy
+
+    def bn_unit(self, name, bn, x_raw, cs, co, C, M, y, ycs, yco, relu, res=None, res_cs=0, dx=None, dres=None, dy=None,
+                dy_cs=None):
+        """BatchNorm (train) forward now; the backward consumes dy (gradient w.r.t. y; allocated here with y's layout
+        unless given) and writes dx (same layout as x_raw) and optionally dres (the ReLU-masked gradient, which is
+        the gradient of the residual branch)."""
+        lib = self.lib
+        mean, invstd = self.buf("mean:" + name, _pad_to(C, 4)), self.buf("istd:" + name, _pad_to(C, 4))
+        ga = self._packed((_pad_to(C, 4),), lambda t, p=bn.weight: t[: p.numel()].copy_(p.detach()))
+        be = self._packed((_pad_to(C, 4),), lambda t, p=bn.bias: t[: p.numel()].copy_(p.detach()))
+
+        def fwd():
+            _lib.check(lib.rdpn6d_bn_train_stats_f32(_ptr(x_raw), M, C, cs, co, BN_EPS, BN_MOM, _ptr(mean), _ptr(invstd),
+                                                     _ptr(bn.running_mean), _ptr(bn.running_var), _ptr(self._scratch_d),
+                                                     self.st()), "bn stats " + name)
+            _lib.check(lib.rdpn6d_bn_apply_f32(_ptr(x_raw), cs, co, _ptr(mean), _ptr(invstd), _ptr(ga), _ptr(be), _ptr(res),
+                                               res_cs, 0, _ptr(y), ycs, yco, M, C, 1 if relu else 0, self.st()), "bn apply " + name)
+            bn.num_batches_tracked += 1
+
+        self.fwd.append(fwd)
+        if dy is None:
+            dy, dy_cs, dy_co = self.buf("d:" + name, *y.shape, zero=True), ycs, yco
+        else:
+            dy_co = 0
+        dga, dbe = self.buf("dga:" + name, _pad_to(C, 4)), self.buf("dbe:" + name, _pad_to(C, 4))
+
+        def bwd():
+            _lib.check(lib.rdpn6d_bn_backward_f32(_ptr(x_raw), cs, co, _ptr(dy), dy_cs, dy_co, _ptr(y), ycs, yco, _ptr(mean),
+                                                  _ptr(invstd), _ptr(ga), _ptr(dga), _ptr(dbe), _ptr(dx), cs, co, _ptr(dres),
+                                                  (dres.shape[-1] if dres is not None else 0), 0, M, C, 1 if relu else 0,
+                                                  _ptr(self._scratch_d), self.st()), "bn bwd " + name)
+            self._grad(bn.weight).copy_(dga[:C])
+            self._grad(bn.bias).copy_(dbe[:C])
+
+        self.bwd.append([bwd])
+        return dy
+
+    # ------------------------------------------------------------------ the network
+    def _build(self):
+        m, B, R, K, lib = self.model, self.B, self.R, self.K, self.lib
+        bb, head, pnp = m.backbone, m.rot_head_net, m.pnp_net
+        R2, R4, R8 = R // 2, R // 4, R // 8
+        self.x = self.buf("x", B, 6, R, R)
+        # ---- stem
+        wst = self._packed((64, 7, 7, 3), lambda t: t.copy_(bb.conv1.weight.detach().float().permute(0, 2, 3, 1)))
+        raw0 = self.buf("raw:stem", B, R2, R2, 64)
+        a0 = self.buf("act:stem", B, R2, R2, 64)
+        self.fwd.append(lambda: _lib.check(lib.rdpn6d_stem_conv7x7_raw_f32(_ptr(self.x), B, 6, R, _ptr(wst), _ptr(raw0), self.st()), "stem"))
+        d_raw0 = self.buf("d:stem", B, R2, R2, 64, zero=True)
+        x4 = self.buf("x_nhwc4", B, R, R, 4)
+        wg_stem = self.buf("wg:stem", 64, 7, 4)
+        self._wg_floats = max(self._wg_floats, int(lib.rdpn6d_wgrad_scratch_floats(B, R2, R2, 64, 4, 7)))
+
+        def stem_wgrad():
+            _lib.check(lib.rdpn6d_rgb_to_nhwc4_f32(_ptr(self.x), B, 6, R, _ptr(x4), self.st()), "rgb->nhwc4")
+            g = self._grad(bb.conv1.weight)
+            for ky in range(7):
+                tdy = (ctypes.c_int * 9)(*([ky - 3] * 7 + [0, 0]))
+                tdx = (ctypes.c_int * 9)(*([kx - 3 for kx in range(7)] + [0, 0]))
+                _lib.check(lib.rdpn6d_wgrad_f32(_ptr(d_raw0), 64, 0, 64, _ptr(x4), 4, 0, 4, B, R2, R2, R, R, 2, 7, tdy, tdx,
+                                                _ptr(wg_stem), _ptr(self._wg_partial), self.st()), "wgrad stem")
+                g[:, :, ky, :].copy_(wg_stem[:, :, :3].permute(0, 2, 1))
+
+        self.bwd.append([stem_wgrad])
+        d_a0 = self.bn_unit("bn1", bb.bn1, raw0, 64, 0, 64, B * R2 * R2, a0, 64, 0, True, dx=d_raw0)
+        p0 = self.buf("act:pool", B, R4, R4, 64)
+        self.fwd.append(lambda: _lib.check(lib.rdpn6d_maxpool3x3s2_f32(_ptr(a0), B, R2, R2, 64, _ptr(p0), self.st()), "maxpool"))
+        d_p0 = self.buf("d:pool", B, R4, R4, 64, zero=True)
+        self.bwd.append([lambda: _lib.check(lib.rdpn6d_maxpool3x3s2_backward_f32(_ptr(a0), _ptr(d_p0), B, R2, R2, 64, _ptr(d_a0),
+                                                                              self.st()), "maxpool bwd")])
+        # ---- residual trunk
+        cur, d_cur, hw, c = p0, d_p0, R4, 64
+        for li in range(4):
+            for bi, blk in enumerate(getattr(bb, f"layer{li + 1}")):
+                nm = f"layer{li + 1}.{bi}"
+                cout, s = blk.conv1.weight.shape[0], blk.conv1.stride
+                ohw = hw // s
+                M = B * ohw * ohw
+                r1, a1 = self.buf(f"raw:{nm}.c1", B, ohw, ohw, cout), self.buf(f"act:{nm}.c1", B, ohw, ohw, cout)
+                r2, out = self.buf(f"raw:{nm}.c2", B, ohw, ohw, cout), self.buf(f"act:{nm}", B, ohw, ohw, cout)
+                d_out = self.buf(f"d:{nm}.out", B, ohw, ohw, cout, zero=True)  # gradient w.r.t. the block output
+                dres = self.buf(f"dres:{nm}", B, ohw, ohw, cout)
+                has_ds = blk.downsample is not None
+                # registration order = forward order; the backward runs it in reverse:
+                #   bn2 -> conv2 -> bn1 -> [ds.bn] -> conv1 (dgrad writes d_cur, + identity gradient) -> [ds.conv (accumulates)]
+                res_t = cur
+                if has_ds:
+                    rd, ad = self.buf(f"raw:{nm}.ds", B, ohw, ohw, cout), self.buf(f"act:{nm}.ds", B, ohw, ohw, cout)
+                    d_rd = self.conv_unit(f"{nm}.downsample.0", blk.downsample[0], cur, (hw, hw), c, 0, c, rd, (ohw, ohw), cout, 0,
+                                          stride=s, dx=d_cur)
+                    res_t = ad
+                d_r1 = self.conv_unit(f"{nm}.conv1", blk.conv1, cur, (hw, hw), c, 0, c, r1, (ohw, ohw), cout, 0, stride=s,
+                                      dx=d_cur, dx_res=None if has_ds else dres)
+                if has_ds:
+                    self.bn_unit(f"{nm}.downsample.1", blk.downsample[1], rd, cout, 0, cout, M, ad, cout, 0, False, dx=d_rd,
+                                 dy=dres, dy_cs=cout)
+                d_a1 = self.bn_unit(f"{nm}.bn1", blk.bn1, r1, cout, 0, cout, M, a1, cout, 0, True, dx=d_r1)
+                d_r2 = self.conv_unit(f"{nm}.conv2", blk.conv2, a1, (ohw, ohw), cout, 0, cout, r2, (ohw, ohw), cout, 0, dx=d_a1)
+                self.bn_unit(f"{nm}.bn2", blk.bn2, r2, cout, 0, cout, M, out, cout, 0, True, res=res_t, res_cs=cout, dx=d_r2,
+                             dres=dres, dy=d_out, dy_cs=cout)
+                cur, d_cur, hw, c = out, d_out, ohw, cout
+        # ---- upsample + point-wise fusion
+        up = self.buf("act:up", B, R8, R8, 512)
+        f = R8 // hw
+        l4out, d_l4out, l4hw = cur, d_cur, hw
+        self.fwd.append(lambda: _lib.check(lib.rdpn6d_upsample_bilinear_f32(_ptr(l4out), B, l4hw, l4hw, 512, f, _ptr(up), self.st()), "upsample"))
+        d_up = self.buf("d:up", B, R8, R8, 512, zero=True)
+        self.bwd.append([lambda: _lib.check(lib.rdpn6d_upsample_bilinear_backward_f32(_ptr(d_up), B, l4hw, l4hw, 512, f, _ptr(d_l4out),
+                                                                                   self.st()), "upsample bwd")])
+        sn = bb.spatial_net
+        Mp = B * R8 * R8
+        pin = self.buf("act:pn_in", B, R8, R8, 80, zero=True)   # [emb(64) | xyz(3) | 0-pad]
+        d_pin = self.buf("d:pn_in", B, R8, R8, 80, zero=True)
+        self.fwd.append(lambda: _lib.check(lib.rdpn6d_xyz_subsample_f32(_ptr(self.x), B, 6, R, 8, _ptr(pin), 80, 64, self.st()), "xyz"))
+        r_e = self.buf("raw:pn.emb", B, R8, R8, 64)
+        d_re = self.conv_unit("spatial_net.xyz_emb", sn.xyz_emb, up, (R8, R8), 512, 0, 512, r_e, (R8, R8), 64, 0, bias=sn.xyz_emb.bias, dx=d_up)
+        self.bn_unit("spatial_net.xb", sn.xb, r_e, 64, 0, 64, Mp, pin, 80, 0, True, dx=d_re, dy=d_pin, dy_cs=80)
+        r1p, a1p = self.buf("raw:pn.c1", B, R8, R8, 128), self.buf("act:pn.c1", B, R8, R8, 128)
+        perm = list(range(3, 67)) + [0, 1, 2]
+        d_r1p = self.conv_unit("spatial_net.conv1", sn.conv1, pin, (R8, R8), 80, 0, 67, r1p, (R8, R8), 128, 0, perm=perm,
+                               bias=sn.conv1.bias, dx=d_pin)
+        d_a1p = self.bn_unit("spatial_net.b1", sn.b1, r1p, 128, 0, 128, Mp, a1p, 128, 0, True, dx=d_r1p)
+        r2p, a2p = self.buf("raw:pn.c2", B, R8, R8, 256), self.buf("act:pn.c2", B, R8, R8, 256)
+        d_r2p = self.conv_unit("spatial_net.conv2", sn.conv2, a1p, (R8, R8), 128, 0, 128, r2p, (R8, R8), 256, 0, bias=sn.conv2.bias, dx=d_a1p)
+        d_a2p = self.bn_unit("spatial_net.b2", sn.b2, r2p, 256, 0, 256, Mp, a2p, 256, 0, True, dx=d_r2p)
+        r3p = self.buf("raw:pn.c3", B, R8, R8, 512)
+        feat = self.buf("act:feat", B, R8, R8, 1024)
+        d_feat = self.buf("d:feat", B, R8, R8, 1024, zero=True)
+        d_l3 = self.buf("d:l3", B, R8, R8, 512, zero=True)
+        d_r3p = self.conv_unit("spatial_net.conv3", sn.conv3, a2p, (R8, R8), 256, 0, 256, r3p, (R8, R8), 512, 0, bias=sn.conv3.bias, dx=d_a2p)
+        # b3 writes channels [0,512) of feat; its output gradient arrives as a dense [.,512] tensor from the gmax backward
+        self.bn_unit("spatial_net.b3", sn.b3, r3p, 512, 0, 512, Mp, feat, 1024, 0, False, dx=d_r3p, dy=d_l3, dy_cs=512)
+        self.fwd.append(lambda: _lib.check(lib.rdpn6d_global_max_concat_f32(_ptr(feat), B, R8 * R8, 512, 1024, self.st()), "gmax"))
+        self.bwd.append([lambda: _lib.check(lib.rdpn6d_global_max_concat_backward_f32(_ptr(feat), _ptr(d_feat), B, R8 * R8, 512, 1024,
+                                                                                   _ptr(d_l3), self.st()), "gmax bwd")])
+        # ---- dense head: ConvTranspose as 4 phase convs (forward), stride-2 conv (dgrad), gathered wgrad
+        F = head.features[0].weight.shape[1]
+        Mh = B * R4 * R4
+        rt0, at0 = self.buf("raw:head0", B, R4, R4, F), self.buf("act:head0", B, R4, R4, F)
+        wt = head.features[0].weight
+        for py in (0, 1):
+            for px in (0, 1):
+                ys = [(1, 0)] if py == 0 else [(0, 1), (2, 0)]
+                xs = [(1, 0)] if px == 0 else [(0, 1), (2, 0)]
+                ptaps = [(dyo, dxo) for _, dyo in ys for _, dxo in xs]
+                kk = [(ky, kx) for ky, _ in ys for kx, _ in xs]
+
+                def pk(t, kk=kk):
+                    ww = wt.detach().float()
+                    for ti, (ky, kx) in enumerate(kk):
+                        t[:F, ti].copy_(ww[:, :, ky, kx].t())
+                wp = self._packed((_pad_to(F, 64), len(ptaps), 1024), pk)
+                d = self._conv_desc(feat, (R8, R8), 1024, 0, 1024, wp, rt0, (R4, R4), F, 0, F, ptaps, phase=(R8, R8, 2, 2, py, px))
+                self.fwd.append(self._launch_conv(f"convT phase{py}{px}", d, wp))
+        d_rt0 = self.buf("d:head0", B, R4, R4, F, zero=True)
+        wdT = self._packed((1024, 9, F), lambda t: t.copy_(pack_conv_weight(wt.detach().float())))  # ConvT weight IS the OIHW of its dgrad conv
+        ddT = self._conv_desc(d_rt0, (R4, R4), F, 0, F, wdT, d_feat, (R8, R8), 1024, 0, 1024, _taps(3, 1), stride=2)
+        wgT = self.buf("wg:convT", 1024, 9, F)
+        self._wg_floats = max(self._wg_floats, int(lib.rdpn6d_wgrad_scratch_floats(B, R8, R8, 1024, F, 9)))
+        t9y = (ctypes.c_int * 9)(*[t[0] for t in _taps(3, 1)])
+        t9x = (ctypes.c_int * 9)(*[t[1] for t in _taps(3, 1)])
+
+        def convT_wgrad():
+            _lib.check(lib.rdpn6d_wgrad_f32(_ptr(feat), 1024, 0, 1024, _ptr(d_rt0), F, 0, F, B, R8, R8, R4, R4, 2, 9, t9y, t9x,
+                                            _ptr(wgT), _ptr(self._wg_partial), self.st()), "wgrad convT")
+            self._grad(wt).copy_(wgT.view(1024, 3, 3, F).permute(0, 3, 1, 2))
+
+        self.bwd.append([convT_wgrad, self._launch_conv("dgrad convT", ddT, wdT)])
+        d_prev = self.bn_unit("head.bn0", head.features[1], rt0, F, 0, F, Mh, at0, F, 0, True, dx=d_rt0)
+        a_prev = at0
+        nfeat = len(head.features)
+        for i in range(3, nfeat - 1, 3):
+            r_i, a_i = self.buf(f"raw:head{i}", B, R4, R4, F), self.buf(f"act:head{i}", B, R4, R4, F)
+            d_ri = self.conv_unit(f"rot_head.features.{i}", head.features[i], a_prev, (R4, R4), F, 0, F, r_i, (R4, R4), F, 0, dx=d_prev)
+            d_prev = self.bn_unit(f"head.bn{i}", head.features[i + 1], r_i, F, 0, F, Mh, a_i, F, 0, True, dx=d_ri)
+            a_prev = a_i
+        last = head.features[nfeat - 1]
+        nout = last.weight.shape[0]
+        self.head_cs = _pad_to(nout, 16)
+        ho = self.buf("act:head_out", B, R4 * R4, self.head_cs, zero=True)
+        self.head_out = ho
+        d_ho = self.conv_unit("rot_head.out", last, a_prev, (R4, R4), F, 0, F, ho.view(B, R4, R4, self.head_cs), (R4, R4), self.head_cs, 0,
+                              bias=last.bias, dx=d_prev)
+        self.d_head = d_ho
+        # ---- glue
+        HW = R4 * R4
+        self.pnp_cs = _pad_to(11 + K, 16)
+        self.out_nchw = self.buf("out_nchw", B, nout, R4, R4)
+        pnp_in = self.buf("act:pnp_in", B, R4, R4, self.pnp_cs)
+        d_pnp_in = self.buf("d:pnp_in", B, R4, R4, self.pnp_cs, zero=True)
+        self.argmax = self.buf("argmax", B, HW, dtype=torch.int32)
+        self.minmax = self.buf("minmax", B, 2)
+        datt = self.buf("datt", B, HW)
+        self.coord2d = self.buf("coord2d", B, 5, R4, R4)
+        self.fps_t = self.buf("fps", B, K, 3)
+        self.fwd.append(lambda: _lib.check(lib.rdpn6d_dense_glue_f32(_ptr(ho), self.head_cs, _ptr(self.coord2d), _ptr(self.fps_t), B, HW, K,
+                                                                  self.mask_attention, _ptr(self.minmax), _ptr(self.out_nchw), _ptr(pnp_in),
+                                                                  self.pnp_cs, _ptr(self.argmax), self.st()), "glue"))
+        self.bwd.append([lambda: _lib.check(lib.rdpn6d_dense_glue_backward_f32(_ptr(ho), self.head_cs, _ptr(self.coord2d), _ptr(self.fps_t),
+                                                                            _ptr(self.argmax), _ptr(d_pnp_in), self.pnp_cs, B, HW, K,
+                                                                            self.mask_attention, _ptr(self.minmax), _ptr(d_ho), _ptr(datt),
+                                                                            self.st()), "glue bwd")])
+        # ---- ConvPnPNet
+        x, d_x, hw, cin_real, cs = pnp_in, d_pnp_in, R4, 11 + K, self.pnp_cs
+        for i in range(0, 9, 3):
+            conv, gn = pnp.features[i], pnp.features[i + 1]
+            fd = conv.weight.shape[0]
+            oh = hw // 2
+            r_i, a_i = self.buf(f"raw:pnp{i}", B, oh, oh, fd), self.buf(f"act:pnp{i}", B, oh, oh, fd)
+            d_ri = self.conv_unit(f"pnp_net.features.{i}", conv, x, (hw, hw), cs, 0, cin_real, r_i, (oh, oh), fd, 0, stride=2, dx=d_x)
+            stats = self.buf(f"gnstats:{i}", B, gn.groups, 2)
+            ga = self._packed((fd,), lambda t, p=gn.weight: t.copy_(p.detach()))
+            be = self._packed((fd,), lambda t, p=gn.bias: t.copy_(p.detach()))
+            self.fwd.append(lambda r_i=r_i, a_i=a_i, oh=oh, fd=fd, gn=gn, ga=ga, be=be, stats=stats: _lib.check(
+                lib.rdpn6d_groupnorm_relu_train_f32(_ptr(r_i), _ptr(a_i), B, oh * oh, fd, gn.groups, _ptr(ga), _ptr(be), _ptr(stats), self.st()), "gn"))
+            d_ai = self.buf(f"d:pnp_act{i}", B, oh, oh, fd, zero=True)
+            dga, dbe, dgb = self.buf(f"dga:pnp{i}", fd), self.buf(f"dbe:pnp{i}", fd), self.buf(f"dgb:pnp{i}", B, 2, fd)
+
+            def gn_bwd(r_i=r_i, a_i=a_i, d_ai=d_ai, d_ri=d_ri, oh=oh, fd=fd, gn=gn, ga=ga, stats=stats, dga=dga, dbe=dbe, dgb=dgb):
+                _lib.check(lib.rdpn6d_groupnorm_relu_backward_f32(_ptr(r_i), _ptr(a_i), _ptr(d_ai), _ptr(ga), _ptr(stats), _ptr(d_ri), _ptr(dga),
+                                                                  _ptr(dbe), _ptr(dgb), _ptr(self._scratch_d), B, oh * oh, fd, gn.groups,
+                                                                  self.st()), "gn bwd")
+                self._grad(gn.weight).copy_(dga)
+                self._grad(gn.bias).copy_(dbe)
+
+            self.bwd.append([gn_bwd])
+            x, d_x, hw, cin_real, cs = a_i, d_ai, oh, fd, fd
+        # FC stack (1x1 convs over B "pixels"); LeakyReLU(0.1) fused in the forward epilogue, masked in backward
+        kin = cs * hw * hw
+        f1, f2 = self.buf("act:fc1", B, 1024), self.buf("act:fc2", B, 256)
+        self.rt = self.buf("act:rt", B, 16, zero=True)
+        d_f1, d_f2 = self.buf("d:fc1", B, 1024, zero=True), self.buf("d:fc2", B, 256, zero=True)
+        self.d_rt = self.buf("d:rt", B, 16, zero=True)
+        self._fc("fc1", pnp.fc1.weight, pnp.fc1.bias, x.view(B, kin), d_x.view(B, kin), kin, f1, d_f1, 1024, act=2,
+                 w_view=lambda w: w.view(-1, cs, hw, hw).permute(0, 2, 3, 1).reshape(-1, kin),
+                 g_view=lambda g: g.view(-1, hw, hw, cs).permute(0, 3, 1, 2).reshape(-1, kin))
+        self._fc("fc2", pnp.fc2.weight, pnp.fc2.bias, f1, d_f1, 1024, f2, d_f2, 256, act=2)
+        self._fc("fc_rt", (pnp.fc_r.weight, pnp.fc_t.weight), (pnp.fc_r.bias, pnp.fc_t.bias), f2, d_f2, 256, self.rt, self.d_rt, 9, act=0, out_cs=16)
+        self.rot, self.trans = self.buf("rot", B, 3, 3), self.buf("trans", B, 3)
+        self.losses9 = self.buf("losses", 16, zero=True)
+
+    def _fc(self, name, w, b, x, d_x, kin, y, d_y, nout, act, out_cs=None, w_view=None, g_view=None):
+        lib, B = self.lib, self.B
+        ws = w if isinstance(w, tuple) else (w,)
+        bs = b if isinstance(b, tuple) else (b,)
+        out_cs = out_cs or nout
+        npad = _pad_to(nout, 64)
+
+        def pk(t):
+            ww = torch.cat([p.detach().float() for p in ws], 0)
+            if w_view:
+                ww = w_view(ww)
+            t[:nout, 0].copy_(ww)
+        wf = self._packed((npad, 1, kin), pk)
+        bvec = self._packed((npad,), lambda t: t[:nout].copy_(torch.cat([p.detach().float() for p in bs], 0)))
+        d = self._conv_desc(x, (1, 1), kin, 0, kin, wf, y, (1, 1), out_cs, 0, nout, [(0, 0)], shift=bvec, act=act, slope=0.1)
+        self.fwd.append(self._launch_conv(name, d, (wf, bvec)))
+        ca = _pad_to(nout, 4)
+        wg_out = self.buf("wg:" + name, ca, 1, kin)
+        self._wg_floats = max(self._wg_floats, int(lib.rdpn6d_wgrad_scratch_floats(B, 1, 1, ca, kin, 1)))
+        z9 = (ctypes.c_int * 9)(*([0] * 9))
+        bg = self.buf("bg:" + name, npad)
+        n_red = _pad_to(nout, 16)
+        assert out_cs >= n_red
+        wd = self._packed((_pad_to(kin, 64), 1, n_red), lambda t: t[:kin, 0, :nout].copy_(
+            (w_view(torch.cat([p.detach().float() for p in ws], 0)) if w_view else torch.cat([p.detach().float() for p in ws], 0)).t()))
+        dd = self._conv_desc(d_y, (1, 1), out_cs, 0, n_red, wd, d_x, (1, 1), kin, 0, kin, [(0, 0)])
+
+        def bwd():
+            if act == 2:
+                _lib.check(lib.rdpn6d_act_backward_f32(_ptr(d_y), _ptr(y), B * out_cs, 0.1, self.st()), "leaky bwd " + name)
+            _lib.check(lib.rdpn6d_wgrad_f32(_ptr(d_y), out_cs, 0, ca, _ptr(x), kin, 0, kin, B, 1, 1, 1, 1, 1, 1, z9, z9, _ptr(wg_out),
+                                            _ptr(self._wg_partial), self.st()), "wgrad " + name)
+            g = wg_out[:nout, 0]
+            if g_view:
+                g = g_view(g)
+            _lib.check(lib.rdpn6d_channel_sum_f32(_ptr(d_y), B, ca, out_cs, 0, _ptr(bg), 0, _ptr(self._scratch_d), self.st()), "bias " + name)
+            o = 0
+            for wp, bp in zip(ws, bs):
+                n = wp.shape[0]
+                self._grad(wp).copy_(g[o:o + n])
+                self._grad(bp).copy_(bg[o:o + n])
+                o += n
+
+        self.bwd.append([bwd, self._launch_conv("dgrad " + name, dd, wd)])
+
+    # ------------------------------------------------------------------ one step
+    LOSS_NAMES = ("loss_coor_x", "loss_coor_y", "loss_coor_z", "loss_mask", "loss_region", "loss_region_my", "loss_PM_R",
+                  "loss_centroid", "loss_z")
+
+    def forward_backward(self, batch):
+        """batch: dict in the reference's batch_data contract (engine_utils.py:6-63), device tensors.
+        Returns {loss name: 0-dim device tensor}; gradients are left in param.grad."""
+        lib, B, K = self.lib, self.B, self.K
+        f32 = lambda t: t.detach().to(device=self.dev, dtype=torch.float32).contiguous()  # noqa: E731
+        self.x.copy_(f32(batch["roi_img"]))
+        self.coord2d.copy_(f32(batch["roi_coord_2d"]))
+        self.fps_t.copy_(f32(batch["fps"]))
+        cams, centers, whs = f32(batch["roi_cam"]), f32(batch["roi_center"]), f32(batch["roi_wh"])
+        ratios, extents = f32(batch["resize_ratio"]), f32(batch["roi_extent"])
+        gt_xyz, mv, mt = f32(batch["roi_xyz"]), f32(batch["roi_mask_visib"]), f32(batch["roi_mask_trunc"])
+        gt_region = batch["roi_region"].to(device=self.dev, dtype=torch.int64).contiguous()
+        gt_rot, gt_ratio, pts = f32(batch["ego_rot"]), f32(batch["roi_trans_ratio"]), f32(batch["roi_points"])
+        for fn in self.fwd:
+            fn()
+        HW = (self.R // 4) ** 2
+        lw = self.lw
+        sc = self.buf("pose_scratch", 3 * B)
+        _lib.check(lib.rdpn6d_pose_train_f32(_ptr(self.rt), 16, _ptr(cams), _ptr(centers), _ptr(whs), _ptr(ratios), _ptr(extents),
+                                             _ptr(gt_rot), _ptr(gt_ratio), _ptr(pts), pts.shape[1], B, self.is_allo, lw["pm"],
+                                             lw["pm_norm"], lw["centroid"], lw["z"], _ptr(self.rot), _ptr(self.trans), _ptr(self.d_rt),
+                                             _ptr(self.losses9[6:]), _ptr(sc), self.st()), "pose_train")
+        _lib.check(lib.rdpn6d_dense_losses_f32(_ptr(self.head_out), self.head_cs, _ptr(gt_xyz), _ptr(mv), _ptr(mt), _ptr(gt_region), B, HW,
+                                               K, lw["xyz"], lw["mask"], lw["region"], _ptr(self.d_head), _ptr(self.losses9),
+                                               _ptr(self._scratch_d), self.st()), "dense_losses")
+        for launches in reversed(self.bwd):
+            for fn in launches:
+                fn()
+        return {n: self.losses9[i] for i, n in enumerate(self.LOSS_NAMES)}
