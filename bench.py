@@ -144,6 +144,64 @@ def cpu_baseline(sd, budget_s=20.0):
                       f"{dt:.1f} s with {best_nt} threads (best of an 8/16/32/64 sweep; host has {ncpu} logical CPUs)"}
 
 
+def train_bench(args, rank, world, device, dist):
+    """Training throughput (SURVEY.md C3 shape in fp32: 32 crops per GPU, data parallel, gradient all-reduce over RCCL).
+    Not the headline metric; printed as its own JSON line."""
+    from rdpn6d_amd import synth
+    from rdpn6d_amd.parallel import GradBuckets
+    from rdpn6d_amd.ranger import Ranger
+
+    B = args.batch if args.batch != 64 else 32
+    model, _ = build_model(device, "mul")
+    model.cfg.TEST.USE_PNP = False
+    eng = model.train_engine(B, device)
+    buckets = GradBuckets(model)
+    opt = Ranger([p for p in model.parameters()], lr=1e-4)
+    inp = synth.make_inputs(B, seed=200 + rank)
+    batch = {k: torch.from_numpy(v).to(device) for k, v in {**inp, **synth.make_train_gt(B, inp)}.items()}
+
+    def one_step():
+        losses = eng.forward_losses(batch)
+        eng.backward(on_group_done=buckets.reduce)
+        buckets.finish()
+        opt.step()
+        eng.refresh_weights()
+        return losses
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses = one_step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    barrier()
+    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    if rank == 0:
+        value = world * B * args.steps / elapsed
+        print(json.dumps({
+            "metric": "RGB-D crops/sec, TRAINING step (fwd+losses+bwd+allreduce+Ranger) at 256x256", "value": round(value, 1),
+            "unit": "crops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "LM-O style training step, MASK_ATTENTION=mul, K=32, ResNet-34, fp32, per-GPU BatchNorm",
+                       "batch_per_gpu": B, "global_batch": B * world,
+                       "parallelism": f"dp{world}: flat gradient buffer, 3 bucketed RCCL all-reduces overlapped with backward"},
+            "achieved_tflops_whole_step": round(132.3e9 * value / 1e12, 2),
+            "loss_total": round(float(sum(v.item() for v in losses.values())), 4)}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,6 +210,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="crops per GPU per step (BASELINE configs[1]: 64)")
     ap.add_argument("--mask-attention", default="none", choices=["none", "mul"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train", action="store_true",
+                    help="secondary line: fp32 training step (fwd + losses + bwd + bucketed RCCL all-reduce + Ranger), B=32/GPU")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -170,6 +230,8 @@ def main():
 
     from rdpn6d_amd import synth
 
+    if args.train:
+        return train_bench(args, rank, world, device, dist)
     model, sd = build_model(device, args.mask_attention)
     B = args.batch
     t = {k: torch.from_numpy(v).to(device) for k, v in synth.make_inputs(B, seed=100 + rank).items()}

@@ -475,6 +475,34 @@ class GDRN(nn.Module):
         self._plans = {}
         return super()._apply(fn, *a, **k)
 
+    def train_engine(self, B, device):
+        from .train import TrainEngine
+
+        key = ("train", B, str(device))
+        if key not in self._plans:
+            self._plans[key] = TrainEngine(self, B, device)
+        return self._plans[key]
+
+    def _forward_train(self, x, roi_coord_2d, fps, roi_cams, roi_centers, roi_whs, roi_extents, resize_ratios, gt_xyz,
+                       gt_mask_trunc, gt_mask_visib, gt_region, gt_ego_rot, gt_points, gt_trans, gt_trans_ratio, sym_infos):
+        """do_loss=True: returns ({}, loss_dict) like the reference (GDRN.py:370).  The loss tensors hang off one autograd
+        node whose backward runs the HIP backward pass, so ``sum(loss_dict.values()).backward()`` fills ``param.grad``."""
+        assert (gt_xyz is not None) and (gt_trans is not None) and (gt_trans_ratio is not None) and (gt_region is not None)
+        assert gt_mask_trunc is not None and gt_mask_visib is not None and gt_ego_rot is not None and gt_points is not None
+        assert roi_extents is not None
+        eng = self.train_engine(x.shape[0], x.device)
+        eng.refresh_weights()  # parameters may have been stepped since the last call
+        batch = {"roi_img": x, "roi_coord_2d": roi_coord_2d, "fps": fps, "roi_cam": roi_cams, "roi_center": roi_centers,
+                 "roi_wh": roi_whs, "resize_ratio": resize_ratios, "roi_extent": roi_extents, "roi_xyz": gt_xyz,
+                 "roi_mask_visib": gt_mask_visib, "roi_mask_trunc": gt_mask_trunc, "roi_region": gt_region, "ego_rot": gt_ego_rot,
+                 "roi_trans_ratio": gt_trans_ratio, "roi_points": gt_points}
+        losses = eng.forward_losses(batch)
+        names = list(losses)
+        anchor = next(p for p in self.parameters() if p.requires_grad)
+        outs = _HipBackward.apply(anchor, eng, *[losses[n] for n in names])
+        self.last_train_pose = (eng.rot, eng.trans)
+        return {}, dict(zip(names, outs))
+
     def plan(self, B, device):
         key = (B, str(device))
         if key not in self._plans:
@@ -486,8 +514,6 @@ class GDRN(nn.Module):
                 gt_ego_rot=None, gt_points=None, sym_infos=None, gt_trans=None, gt_trans_ratio=None, roi_classes=None,
                 roi_coord_2d=None, roi_cams=None, roi_centers=None, roi_whs=None, roi_extents=None, resize_ratios=None,
                 do_loss=False, fps=None):
-        if do_loss:
-            raise NotImplementedError("training path (losses + backward kernels) is not wired into this build yet")
         if not x.is_cuda:
             raise RuntimeError("rdpn6d_amd.GDRN runs on the MI355X HIP kernels only; got a CPU tensor (no CPU fallback)")
         pcfg = self.cfg.MODEL.CDPN.PNP_NET
@@ -503,6 +529,10 @@ class GDRN(nn.Module):
         if fps.dim() == 2:
             fps = fps.unsqueeze(0).expand(B, -1, -1).contiguous()
         roi_cams, roi_centers, roi_whs, resize_ratios = f32c(roi_cams), f32c(roi_centers), f32c(roi_whs), f32c(resize_ratios)
+        if do_loss:
+            return self._forward_train(x, roi_coord_2d, fps, roi_cams, roi_centers, roi_whs, roi_extents, resize_ratios, gt_xyz,
+                                       gt_mask_trunc, gt_mask_visib, gt_region, gt_ego_rot, gt_points, gt_trans, gt_trans_ratio,
+                                       sym_infos)
         plan = self.plan(B, x.device)
         if tuple(x.shape[1:]) != (6, plan.R, plan.R):
             raise ValueError(f"expected x of shape (B,6,{plan.R},{plan.R}), got {tuple(x.shape)}")
@@ -530,6 +560,25 @@ class GDRN(nn.Module):
             out.update({"pnp_pose": plan.pnp_pose.clone(),
                         "pnp_num_inliers": plan.pnp_ninl.clone(), "pnp_inlier_mask": plan.pnp_mask.clone()})
         return out
+
+
+class _HipBackward(torch.autograd.Function):
+    """Glue between ``losses.backward()`` (engine.py:308) and the HIP backward pass: the nine loss tensors come out of
+    this node; when autograd reaches it, the whole hand-written backward runs and writes ``param.grad`` directly."""
+
+    @staticmethod
+    def forward(ctx, anchor, engine, *losses):
+        ctx.engine = engine
+        return tuple(l.clone() for l in losses)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        # d(total)/d(loss_i) must be 1 for every loss (the reference sums the dict un-weighted: engine.py:292)
+        ctx.engine.backward()
+        hook = getattr(ctx.engine, "after_backward", None)
+        if hook is not None:
+            hook()
+        return (None, None) + (None,) * len(gouts)
 
 
 def build_model_optimizer(cfg):

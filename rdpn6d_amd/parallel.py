@@ -1,0 +1,85 @@
+"""Data parallelism of the hot path: one process per GPU, RCCL (``backend="nccl"``) over xGMI.
+
+* Inference shards crops with NO collective on the measured path - the reference's ``InferenceSampler``
+  contiguous split (core/utils/my_distributed_sampler.py:191-194) - plus an optional gather of the (B,12) poses.
+* Training is pure data parallel: replicated weights, per-rank BatchNorm statistics, one
+  gradient all-reduce per step.  The reference lets torch DDP bucket 164 tensors (25 MB buckets); here all
+  gradients live in ONE flat HBM buffer laid out [pnp_net | rot_head_net | backbone] = the order in which the
+  backward completes them, and three large all-reduces are issued as soon as each group is done, overlapping the
+  rest of the backward (xGMI is point-to-point: few, large collectives).  BN buffers are not broadcast (each rank
+  keeps its own statistics, a stated choice; the reference's DDP default broadcasts rank 0's).
+"""
+import torch
+import torch.distributed as dist
+
+GROUPS = ("pnp_net", "rot_head_net", "backbone")  # completion order of the backward
+
+
+def shard_range(n, rank, world):
+    """contiguous shard [begin, end) of n items for this rank (InferenceSampler semantics)"""
+    shard = (n - 1) // world + 1 if n > 0 else 0
+    begin = shard * rank
+    return min(begin, n), min(shard * (rank + 1), n)
+
+
+class GradBuckets:
+    """Flat gradient storage + bucketed all-reduce.  ``param.grad`` of every parameter becomes a view into one
+    contiguous buffer; ``reduce(group)`` starts the (asynchronous) all-reduce of that group's slice,
+    ``finish()`` waits for all of them and turns sums into means."""
+
+    def __init__(self, model, groups=GROUPS, process_group=None):
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        params = {g: [p for p in getattr(model, g).parameters() if p.requires_grad] for g in groups}
+        n = sum(p.numel() for ps in params.values() for p in ps)
+        ref = next(p for ps in params.values() for p in ps)
+        self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
+        self.slices, o = {}, 0
+        for g in groups:
+            b = o
+            for p in params[g]:
+                p.grad = self.flat[o:o + p.numel()].view_as(p)
+                o += p.numel()
+            self.slices[g] = (b, o)
+        self.handles = []
+        # gloo has no AVG: reduce with SUM and scale in finish()
+        self.avg_op = self.world > 1 and dist.get_backend(process_group) == "nccl"
+
+    def zero_(self):
+        self.flat.zero_()
+
+    def reduce(self, group):
+        if self.world == 1:
+            return
+        b, e = self.slices[group]
+        op = dist.ReduceOp.AVG if self.avg_op else dist.ReduceOp.SUM
+        self.handles.append(dist.all_reduce(self.flat[b:e], op=op, group=self.pg, async_op=True))
+
+    def finish(self):
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+        if self.world > 1 and not self.avg_op:
+            self.flat.div_(self.world)
+
+
+def gather_poses(rot, trans, process_group=None):
+    """all ranks' (R|t) rows, rank-major: the (B,12)-float counterpart of the reference's pickle all_gather at the end
+    of evaluation (gdrn_evaluator.py:440-441)"""
+    pose = torch.cat([rot.reshape(rot.shape[0], 9), trans.reshape(trans.shape[0], 3)], 1).contiguous()
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:
+        return pose
+    out = [torch.empty_like(pose) for _ in range(dist.get_world_size(process_group))]
+    dist.all_gather(out, pose, group=process_group)
+    return torch.cat(out, 0)
+
+
+def reduce_loss_dict(loss_dict, process_group=None):
+    """mean of the 9 scalar losses over ranks in ONE small all-reduce, no host sync
+    (the reference: comm.reduce_dict + .item() per key, engine.py:299-300)"""
+    names = sorted(loss_dict)
+    v = torch.stack([loss_dict[k].detach().float() for k in names])
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1:
+        dist.all_reduce(v, group=process_group)
+        v = v / dist.get_world_size(process_group)
+    return dict(zip(names, v.unbind(0)))

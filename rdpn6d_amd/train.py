@@ -348,6 +348,7 @@ class TrainEngine:
         self.bwd.append([lambda: _lib.check(lib.rdpn6d_global_max_concat_backward_f32(_ptr(feat), _ptr(d_feat), B, R8 * R8, 512, 1024,
                                                                                    _ptr(d_l3), self.st()), "gmax bwd")])
         # ---- dense head: ConvTranspose as 4 phase convs (forward), stride-2 conv (dgrad), gathered wgrad
+        self._group_marks = {0: "backbone", len(self.bwd): "rot_head_net"}  # bwd index where a group's gradients are complete
         F = head.features[0].weight.shape[1]
         Mh = B * R4 * R4
         rt0, at0 = self.buf("raw:head0", B, R4, R4, F), self.buf("act:head0", B, R4, R4, F)
@@ -415,6 +416,7 @@ class TrainEngine:
                                                                             self.mask_attention, _ptr(self.minmax), _ptr(d_ho), _ptr(datt),
                                                                             self.st()), "glue bwd")])
         # ---- ConvPnPNet
+        self._group_marks[len(self.bwd)] = "pnp_net"
         x, d_x, hw, cin_real, cs = pnp_in, d_pnp_in, R4, 11 + K, self.pnp_cs
         for i in range(0, 9, 3):
             conv, gn = pnp.features[i], pnp.features[i + 1]
@@ -502,9 +504,10 @@ class TrainEngine:
     LOSS_NAMES = ("loss_coor_x", "loss_coor_y", "loss_coor_z", "loss_mask", "loss_region", "loss_region_my", "loss_PM_R",
                   "loss_centroid", "loss_z")
 
-    def forward_backward(self, batch):
-        """batch: dict in the reference's batch_data contract (engine_utils.py:6-63), device tensors.
-        Returns {loss name: 0-dim device tensor}; gradients are left in param.grad."""
+    def forward_losses(self, batch):
+        """Forward in training mode + the nine losses (also seeds the gradient buffers d_head / d_rt).
+        batch: dict in the reference's batch_data contract (engine_utils.py:6-63), device tensors.
+        Returns {loss name: 0-dim device tensor}."""
         lib, B, K = self.lib, self.B, self.K
         f32 = lambda t: t.detach().to(device=self.dev, dtype=torch.float32).contiguous()  # noqa: E731
         self.x.copy_(f32(batch["roi_img"]))
@@ -527,7 +530,19 @@ class TrainEngine:
         _lib.check(lib.rdpn6d_dense_losses_f32(_ptr(self.head_out), self.head_cs, _ptr(gt_xyz), _ptr(mv), _ptr(mt), _ptr(gt_region), B, HW,
                                                K, lw["xyz"], lw["mask"], lw["region"], _ptr(self.d_head), _ptr(self.losses9),
                                                _ptr(self._scratch_d), self.st()), "dense_losses")
-        for launches in reversed(self.bwd):
-            for fn in launches:
-                fn()
         return {n: self.losses9[i] for i, n in enumerate(self.LOSS_NAMES)}
+
+    def backward(self, on_group_done=None):
+        """Backward of sum(losses) into param.grad.  on_group_done(name) is called after the gradients of
+        'pnp_net', 'rot_head_net' and 'backbone' are complete (gradient-bucket all-reduce hook)."""
+        marks = getattr(self, "_group_marks", None)
+        for idx in range(len(self.bwd) - 1, -1, -1):
+            for fn in self.bwd[idx]:
+                fn()
+            if on_group_done is not None and marks and idx in marks:
+                on_group_done(marks[idx])
+
+    def forward_backward(self, batch):
+        losses = self.forward_losses(batch)
+        self.backward()
+        return losses

@@ -120,3 +120,36 @@ def test_bn_running_stats_updated_like_torch(train_setup):
             assert (a - b).abs().max().item() <= 1e-4 * max(1.0, b.abs().max().item()), k
         if k.endswith("num_batches_tracked"):
             assert int(sd_h[k]) == int(sd_o[k]) == 1
+
+
+def test_reference_api_do_loss_backward_and_optimizer_step(train_setup):
+    """the reference's call sequence (engine.py:265-309): model(..., do_loss=True) -> sum(loss_dict) ->
+    zero_grad -> backward -> step, through GDRN.forward and the Ranger mirror; the loss must go down."""
+    from rdpn6d_amd import synth
+    from rdpn6d_amd.ranger import Ranger
+
+    out, _ = train_setup
+    model = out["mul"][0]
+    dev = torch.device("cuda:0")
+    inp = synth.make_inputs(4, seed=0)
+    gt = synth.make_train_gt(4, inp)
+    b = {k: torch.from_numpy(v).to(dev) for k, v in {**inp, **gt}.items()}
+    opt = Ranger([p for p in model.parameters()], lr=2e-3)
+    hist = []
+    for it in range(6):
+        od, ld = model(b["roi_img"], gt_xyz=b["roi_xyz"], gt_mask_trunc=b["roi_mask_trunc"], gt_mask_visib=b["roi_mask_visib"],
+                       gt_mask_obj=b["roi_mask_obj"], gt_region=b["roi_region"], gt_ego_rot=b["ego_rot"], gt_points=b["roi_points"],
+                       sym_infos=None, gt_trans=b["trans"], gt_trans_ratio=b["roi_trans_ratio"], roi_classes=b["roi_cls"],
+                       roi_coord_2d=b["roi_coord_2d"], roi_cams=b["roi_cam"], roi_centers=b["roi_center"], roi_whs=b["roi_wh"],
+                       roi_extents=b["roi_extent"], resize_ratios=b["resize_ratio"], do_loss=True, fps=b["fps"])
+        assert od == {} and set(ld) == {"loss_coor_x", "loss_coor_y", "loss_coor_z", "loss_mask", "loss_region", "loss_region_my",
+                                        "loss_PM_R", "loss_centroid", "loss_z"}
+        losses = sum(ld.values())
+        assert torch.isfinite(losses).all()
+        opt.zero_grad(set_to_none=True)
+        losses.backward()
+        assert all(p.grad is not None for p in model.parameters())
+        opt.step()
+        hist.append(losses.item())
+    print("total loss over 6 Ranger steps:", [round(h, 4) for h in hist])
+    assert hist[-1] < hist[0]

@@ -59,8 +59,9 @@ def test_factory_surface():
     # K = 64 (the reference cannot build this: nIn is hard-coded to 43)
     model64, _ = build_model_optimizer(gdrn_base_cfg(num_regions=64, device="cpu"))
     assert tuple(model64.state_dict()["pnp_net.features.0.weight"].shape) == (128, 75, 3, 3)
-    with pytest.raises(NotImplementedError):
-        model(torch.zeros(1, 6, 256, 256), do_loss=True)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        model(torch.zeros(1, 6, 256, 256), do_loss=True, roi_coord_2d=torch.zeros(1, 5, 64, 64), fps=torch.zeros(1, 32, 3),
+              roi_cams=torch.eye(3)[None])
 
 
 def test_weight_packing_and_bn_fold():
