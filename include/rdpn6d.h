@@ -152,7 +152,7 @@ int rdpn6d_ransac_kabsch_ex(const float* out_nchw, const float* coord2d, const f
 /* conv1 7x7/2 raw output (no folded BN, no ReLU) for training */
 int rdpn6d_stem_conv7x7_raw_f32(const float* x, int B, int xc, int R, const float* w, float* y, void* stream);
 /* BatchNorm2d train mode, statistics over the M rows of x[M, cs] channels [co, co+C): mean, 1/sqrt(var+eps) (biased var),
- * running stats updated with `momentum` (unbiased var) when given.  scratch >= 64*C*2 doubles. */
+ * running stats updated with `momentum` (unbiased var) when given.  scratch >= 512*C*2 doubles. */
 int rdpn6d_bn_train_stats_f32(const float* x, long long M, int C, int cs, int co, float eps, float momentum, float* mean,
                               float* invstd, float* running_mean, float* running_var, double* scratch, void* stream);
 /* y = act((x-mean)*invstd*gamma + beta (+ res)) */

@@ -10,12 +10,12 @@
 #include "common.h"
 #include <float.h>
 
-#define NS_MAX 64  // row splits of the partial reductions
+#define NS_MAX 512  // row splits of the partial reductions
 
 // ---------------------------------------------------------------------------------------------
 // Stage 1 of every per-channel reduction.  MODE 0: (sum x, sum x^2)         [BN statistics, bias grads]
 //                                            MODE 1: (sum g, sum g*xhat)       [BN backward], g = dy*(y>0) if relu
-// grid = (C/64, S); block = 256 = 4 row lanes x 64 channels
+// grid = (C/64, S); block = 256 = 16 row lanes x 16 channel quads (16-byte loads)
 template <int MODE>
 __global__ __launch_bounds__(256) void chan_partial_kernel(const float* __restrict__ x, int xcs, int xco,
                                                            const float* __restrict__ dy, int dcs, int dco,
@@ -23,38 +23,48 @@ __global__ __launch_bounds__(256) void chan_partial_kernel(const float* __restri
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            long long M, int C, int relu, double* __restrict__ partial)
 {
-    __shared__ double s_a[4][64], s_b[4][64];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    // block = 16 row lanes x 16 channel quads: every thread streams 16-byte loads, a wavefront covers 4 rows x 256 B
+    __shared__ double s_a[16][64], s_b[16][64];
+    const int q = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + q * 4;
     const int S = gridDim.y;
     const long long rows_per = (M + S - 1) / S;
     const long long m_lo = (long long)blockIdx.y * rows_per, m_hi = m_lo + rows_per < M ? m_lo + rows_per : M;
-    double a = 0.0, b = 0.0;
-    if (c < C) {
-        float mu = 0.f, is = 0.f;
-        if (MODE == 1) { mu = mean[c]; is = invstd[c]; }
-        for (long long m = m_lo + rl; m < m_hi; m += 4) {
+    double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+    if (c < C) {  // C % 4 == 0 is required by the callers
+        f32x4 mu = {0, 0, 0, 0}, is = {0, 0, 0, 0};
+        if (MODE == 1) { mu = *reinterpret_cast<const f32x4*>(mean + c); is = *reinterpret_cast<const f32x4*>(invstd + c); }
+        for (long long m = m_lo + rl; m < m_hi; m += 16) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + m * xcs + xco + c);
             if (MODE == 0) {
-                const float v = x[m * xcs + xco + c];
-                a += (double)v;
-                b += (double)v * (double)v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { a[e] += (double)xv[e]; b[e] += (double)xv[e] * (double)xv[e]; }
             } else {
-                float g = dy[m * dcs + dco + c];
-                if (relu && !(y[m * ycs + yco + c] > 0.f)) g = 0.f;
-                const float xh = (x[m * xcs + xco + c] - mu) * is;
-                a += (double)g;
-                b += (double)g * (double)xh;
+                f32x4 g = *reinterpret_cast<const f32x4*>(dy + m * dcs + dco + c);
+                if (relu) {
+                    const f32x4 yv = *reinterpret_cast<const f32x4*>(y + m * ycs + yco + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g[e] = yv[e] > 0.f ? g[e] : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xh = (xv[e] - mu[e]) * is[e];
+                    a[e] += (double)g[e];
+                    b[e] += (double)g[e] * (double)xh;
+                }
             }
         }
     }
-    s_a[rl][cl] = a;
-    s_b[rl][cl] = b;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { s_a[rl][q * 4 + e] = a[e]; s_b[rl][q * 4 + e] = b[e]; }
     __syncthreads();
-    if (rl == 0 && c < C) {
-        a = (s_a[0][cl] + s_a[1][cl]) + (s_a[2][cl] + s_a[3][cl]);
-        b = (s_b[0][cl] + s_b[1][cl]) + (s_b[2][cl] + s_b[3][cl]);
-        partial[((long long)blockIdx.y * C + c) * 2 + 0] = a;
-        partial[((long long)blockIdx.y * C + c) * 2 + 1] = b;
+    if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < C) {
+        double ta = 0.0, tb = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ta += s_a[r][threadIdx.x]; tb += s_b[r][threadIdx.x]; }
+        const int cc = blockIdx.x * 64 + threadIdx.x;
+        partial[((long long)blockIdx.y * C + cc) * 2 + 0] = ta;
+        partial[((long long)blockIdx.y * C + cc) * 2 + 1] = tb;
     }
 }
 
@@ -93,8 +103,8 @@ __global__ void chan_sum_finalize_kernel(const double* __restrict__ partial, int
 
 static int pick_splits(long long M, int C)
 {
-    long long s = (M + 511) / 512;
-    const long long want = 2048 / ((C + 63) / 64) + 1;  // enough workgroups to fill the chip
+    long long s = (M + 255) / 256;                       // >= 16 rows per row lane
+    const long long want = 4096 / ((C + 63) / 64) + 1;  // enough workgroups to fill the chip (16 per CU)
     if (s > want) s = want;
     if (s > NS_MAX) s = NS_MAX;
     if (s < 1) s = 1;
@@ -103,10 +113,10 @@ static int pick_splits(long long M, int C)
 
 extern "C" int rdpn6d_bn_train_stats_f32(const float* x, long long M, int C, int cs, int co, float eps, float momentum,
                                          float* mean, float* invstd, float* running_mean, float* running_var,
-                                         double* scratch /* >= 64*C*2 doubles */, void* stream)
+                                         double* scratch /* >= 512*C*2 doubles */, void* stream)
 {
     RD_REQUIRE(x && mean && invstd && scratch, "null pointer");
-    RD_REQUIRE(M > 0 && C > 0 && co + C <= cs, "shape");
+    RD_REQUIRE(M > 0 && C > 0 && co + C <= cs && C % 4 == 0 && cs % 4 == 0 && co % 4 == 0, "shape / 16-byte alignment");
     const int S = pick_splits(M, C);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(chan_partial_kernel<0>, dim3((C + 63) / 64, S), dim3(256), 0, s, x, cs, co, nullptr, 0, 0, nullptr, 0, 0,
@@ -122,7 +132,7 @@ extern "C" int rdpn6d_bn_train_stats_f32(const float* x, long long M, int C, int
 extern "C" int rdpn6d_channel_sum_f32(const float* x, long long M, int C, int cs, int co, float* out, int accumulate,
                                       double* scratch, void* stream)
 {
-    RD_REQUIRE(x && out && scratch && M > 0 && C > 0 && co + C <= cs, "shape");
+    RD_REQUIRE(x && out && scratch && M > 0 && C > 0 && co + C <= cs && C % 4 == 0 && cs % 4 == 0 && co % 4 == 0, "shape / alignment");
     const int S = pick_splits(M, C);
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(chan_partial_kernel<0>, dim3((C + 63) / 64, S), dim3(256), 0, s, x, cs, co, nullptr, 0, 0, nullptr, 0, 0,

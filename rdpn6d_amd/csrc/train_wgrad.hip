@@ -33,8 +33,9 @@ template <int BA, int BB>
 __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradKArgs a)
 {
     constexpr int TA = BA / 64, TB = BB / 64;  // 32x32 tiles per wave (2x2 waves)
-    __shared__ __attribute__((aligned(16))) float As[2][16][BA];
-    __shared__ __attribute__((aligned(16))) float Bs[2][16][BB];
+    constexpr int NST = 3;                      // LDS stages (same 3-stage pipeline as conv_igemm_f32_kernel)
+    __shared__ __attribute__((aligned(16))) float As[NST][16][BA];
+    __shared__ __attribute__((aligned(16))) float Bs[NST][16][BB];
 
     const int tile = blockIdx.x;
     const int at = tile % a.atiles;
@@ -51,46 +52,54 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradKArgs a)
     const __amdgpu_buffer_rsrc_t bsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Bg), 0, a.b_bytes, 0x00020000);
 
     const int tid = threadIdx.x;
-    // staging: A tile row = 16 pixels x BA channels = BA/4 float4 per pixel row; thread -> (row, c4)
-    constexpr int A4 = BA / 4, B4 = BB / 4;       // float4 per row
+    // staging: a tile row = one pixel x BA channels = BA/4 float4; thread -> (row, c4)
+    constexpr int A4 = BA / 4, B4 = BB / 4;            // float4 per row
     constexpr int AROWS = 256 / A4, BROWS = 256 / B4;  // rows covered per pass (BA=128: 8, BA=64: 16)
     constexpr int APASS = 16 / AROWS, BPASS = 16 / BROWS;
     const int ar = tid / A4, ac4 = tid % A4, br = tid / B4, bc4 = tid % B4;
     const bool a_cok = a0 + ac4 * 4 < a.Ca, b_cok = b0 + bc4 * 4 < a.Cb;
+    const unsigned a_col = (unsigned)(a.a_co + a0 + ac4 * 4) * 4u, b_col = (unsigned)(a.b_co + b0 + bc4 * 4) * 4u;
+    const unsigned a_row_bytes = (unsigned)a.a_cs * 4u, b_px_bytes = (unsigned)a.b_cs * 4u;
 
+    // pixel coordinates of this thread's B rows, advanced incrementally (16 pixels per chunk): no divisions in the loop
+    int b_ox[BPASS], b_oy[BPASS], b_bi[BPASS];
+#pragma unroll
+    for (int p = 0; p < BPASS; ++p) {
+        const long long m = m_lo + br + p * BROWS;
+        const int mm = m < a.M ? (int)m : 0;
+        b_bi[p] = mm / a.HaWa;
+        const int rem = mm - b_bi[p] * a.HaWa;
+        b_oy[p] = rem / a.Wa;
+        b_ox[p] = rem - b_oy[p] * a.Wa;
+    }
+    long long ld_m = m_lo;  // first pixel of the next chunk to load
     f32x4 ra[APASS], rb[BPASS];
-    auto load_chunk = [&](int ch) {
-        const long long mb = m_lo + (long long)ch * 16;
+    auto load_chunk = [&]() {
 #pragma unroll
         for (int p = 0; p < APASS; ++p) {
-            const long long m = mb + ar + p * AROWS;
+            const long long m = ld_m + ar + p * AROWS;
             const bool ok = a_cok && m < m_hi;
-            const unsigned off = ok ? (unsigned)((m * a.a_cs + a.a_co + a0 + ac4 * 4) * 4) : a.a_bytes;
+            const unsigned off = ok ? (unsigned)m * a_row_bytes + a_col : a.a_bytes;
             ra[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(asrc, (int)off, 0, 0));
         }
 #pragma unroll
         for (int p = 0; p < BPASS; ++p) {
-            const long long m = mb + br + p * BROWS;
-            bool ok = b_cok && m < m_hi;
-            unsigned off = a.b_bytes;
-            if (ok) {
-                const int mm = (int)m;
-                const int bi = mm / a.HaWa;
-                const int rem = mm - bi * a.HaWa;
-                const int oy = rem / a.Wa;
-                const int ox = rem - oy * a.Wa;
-                const int iy = oy * a.stride + dy, ix = ox * a.stride + dx;
-                ok = (unsigned)iy < (unsigned)a.Hb && (unsigned)ix < (unsigned)a.Wb;
-                if (ok) off = (unsigned)((((long long)bi * a.Hb + iy) * a.Wb + ix) * a.b_cs + a.b_co + b0 + bc4 * 4) * 4u;
-            }
+            const long long m = ld_m + br + p * BROWS;
+            const int iy = b_oy[p] * a.stride + dy, ix = b_ox[p] * a.stride + dx;
+            const bool ok = b_cok && m < m_hi && (unsigned)iy < (unsigned)a.Hb && (unsigned)ix < (unsigned)a.Wb;
+            const unsigned off = ok ? (unsigned)((b_bi[p] * a.Hb + iy) * a.Wb + ix) * b_px_bytes + b_col : a.b_bytes;
             rb[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bsrc, (int)off, 0, 0));
+            // advance this row by 16 pixels
+            b_ox[p] += 16;
+            while (b_ox[p] >= a.Wa) { b_ox[p] -= a.Wa; if (++b_oy[p] == a.Ha) { b_oy[p] = 0; ++b_bi[p]; } }
         }
+        ld_m += 16;
     };
-    auto store_lds = [&](int buf) {
+    auto store_lds = [&](int st) {
 #pragma unroll
-        for (int p = 0; p < APASS; ++p) *reinterpret_cast<f32x4*>(&As[buf][ar + p * AROWS][ac4 * 4]) = ra[p];
+        for (int p = 0; p < APASS; ++p) *reinterpret_cast<f32x4*>(&As[st][ar + p * AROWS][ac4 * 4]) = ra[p];
 #pragma unroll
-        for (int p = 0; p < BPASS; ++p) *reinterpret_cast<f32x4*>(&Bs[buf][br + p * BROWS][bc4 * 4]) = rb[p];
+        for (int p = 0; p < BPASS; ++p) *reinterpret_cast<f32x4*>(&Bs[st][br + p * BROWS][bc4 * 4]) = rb[p];
     };
 
     const int lane = tid & 63, wave = tid >> 6;
@@ -105,31 +114,54 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradKArgs a)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    if (nchunks > 0) {
-        load_chunk(0);
-        store_lds(0);
-        __syncthreads();
-        for (int ch = 0; ch < nchunks; ++ch) {
-            const int buf = ch & 1;
-            load_chunk(ch + 1 < nchunks ? ch + 1 : ch);  // clamped: the redundant last load is never stored
-            float fa[TA][8], fb[TB][8];
+    auto read_frags = [&](int st, float (&fa)[TA][8], float (&fb)[TB][8]) {
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
+        for (int s = 0; s < 8; ++s) {
 #pragma unroll
-                for (int i = 0; i < TA; ++i) fa[i][s] = As[buf][koff + s][wa * (BA / 2) + i * 32 + frow];
+            for (int i = 0; i < TA; ++i) fa[i][s] = As[st][koff + s][wa * (BA / 2) + i * 32 + frow];
 #pragma unroll
-                for (int j = 0; j < TB; ++j) fb[j][s] = Bs[buf][koff + s][wb * (BB / 2) + j * 32 + frow];
-            }
-#pragma unroll
-            for (int s = 0; s < 8; ++s)
-#pragma unroll
-                for (int i = 0; i < TA; ++i)
-#pragma unroll
-                    for (int j = 0; j < TB; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
-            if (ch + 1 < nchunks) store_lds(buf ^ 1);
-            __syncthreads();
+            for (int j = 0; j < TB; ++j) fb[j][s] = Bs[st][koff + s][wb * (BB / 2) + j * 32 + frow];
         }
+    };
+    auto mma = [&](const float (&fa)[TA][8], const float (&fb)[TB][8]) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int i = 0; i < TA; ++i)
+#pragma unroll
+                for (int j = 0; j < TB; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+    };
+
+    if (nchunks > 0) {
+        // loads past the split's end are bounds-checked to zero (m >= m_hi), so the loop body needs no branches
+        load_chunk();
+        store_lds(0);
+        load_chunk();
+        store_lds(1);
+        __syncthreads();
+        float fa0[TA][8], fb0[TB][8], fa1[TA][8], fb1[TB][8];
+        read_frags(0, fa0, fb0);
+        int st_next = 1, st_stage = 2;
+        const int npairs = nchunks >> 1;
+        for (int pr = 0; pr < npairs; ++pr) {
+            load_chunk();
+            read_frags(st_next, fa1, fb1);
+            mma(fa0, fb0);
+            store_lds(st_stage);
+            __syncthreads();
+            st_next = st_next == NST - 1 ? 0 : st_next + 1;
+            st_stage = st_stage == NST - 1 ? 0 : st_stage + 1;
+
+            load_chunk();
+            read_frags(st_next, fa0, fb0);
+            mma(fa1, fb1);
+            store_lds(st_stage);
+            __syncthreads();
+            st_next = st_next == NST - 1 ? 0 : st_next + 1;
+            st_stage = st_stage == NST - 1 ? 0 : st_stage + 1;
+        }
+        if (nchunks & 1) mma(fa0, fb0);
     }
 
     // partial[split][a][tap][b]: lanes hold consecutive b (32 x 4 B = 128-byte runs)
@@ -162,21 +194,33 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int S, l
 // partial = scratch of at least rdpn6d_wgrad_scratch_floats(...) floats
 extern "C" long long rdpn6d_wgrad_scratch_floats(int Bn, int Ha, int Wa, int Ca, int Cb, int ntaps);
 
-static int wgrad_pick_splits(long long M, int tiles)
+// Split-K factor: fill an integral number of "rounds" of resident workgroups (256 CUs x blocks/CU that the
+// tile variant's registers allow) - a grid of 1044 workgroups on 512 slots would run 3 rounds at 68 % utilisation.
+static int wgrad_pick_splits(long long M, int tiles, int ba, int bb)
 {
-    long long s = (1024 + tiles - 1) / tiles;          // aim for ~1024 workgroups
-    const long long maxs = (M + 255) / 256;            // at least 16 chunks of 16 pixels per split
-    if (s > maxs) s = maxs;
-    if (s > 64) s = 64;
-    if (s < 1) s = 1;
-    return (int)s;
+    const int occ = (ba == 128 && bb == 128) ? 2 : ((ba == 64 && bb == 64) ? 5 : 3);
+    const long long slots = 256LL * occ;
+    const long long maxs = (M + 255) / 256 > 0 ? (M + 255) / 256 : 1;  // >= 16 chunks of 16 pixels per split
+    long long best = 1;
+    double best_util = 0.0;
+    for (int r = 1; r <= 4; ++r) {
+        long long s = slots * r / tiles;
+        if (s < 1) continue;
+        if (s > maxs) s = maxs;
+        if (s > 256) s = 256;
+        const long long blocks = s * tiles;
+        const long long rounds = (blocks + slots - 1) / slots;
+        const double util = (double)blocks / (double)(rounds * slots);
+        if (util > best_util + 1e-9) { best_util = util; best = s; }
+    }
+    return (int)best;
 }
 
 extern "C" long long rdpn6d_wgrad_scratch_floats(int Bn, int Ha, int Wa, int Ca, int Cb, int ntaps)
 {
     const int ba = Ca > 64 ? 128 : 64, bb = Cb > 64 ? 128 : 64;
     const int tiles = ((Ca + ba - 1) / ba) * ((Cb + bb - 1) / bb) * ntaps;
-    return (long long)wgrad_pick_splits((long long)Bn * Ha * Wa, tiles) * Ca * ntaps * Cb;
+    return (long long)wgrad_pick_splits((long long)Bn * Ha * Wa, tiles, ba, bb) * Ca * ntaps * Cb;
 }
 
 extern "C" int rdpn6d_wgrad_f32(const float* A, int a_cs, int a_co, int Ca, const float* Bg, int b_cs, int b_co, int Cb,
@@ -208,7 +252,7 @@ extern "C" int rdpn6d_wgrad_f32(const float* A, int a_cs, int a_co, int Ca, cons
     a.atiles = (Ca + ba - 1) / ba;
     a.btiles = (Cb + bb - 1) / bb;
     const int tiles = a.atiles * a.btiles * ntaps;
-    const int S = wgrad_pick_splits(a.M, tiles);
+    const int S = wgrad_pick_splits(a.M, tiles, ba, bb);
     a.rows_per_split = ((a.M + S - 1) / S + 15) / 16 * 16;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(tiles, S), block(256);

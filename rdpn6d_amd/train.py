@@ -55,7 +55,7 @@ class TrainEngine:
         self.bufs = {}
         self.packed = []     # (refresh_fn) closures re-packing weights into persistent buffers
         self.fwd, self.bwd = [], []   # launch closures
-        self._scratch_d = torch.empty(64 * 1024 * 2 + 64, dtype=torch.float64, device=device)
+        self._scratch_d = torch.empty(512 * 1024 * 2 + 4096, dtype=torch.float64, device=device)
         self._wg_floats = 0
         self._build()
         self._wg_partial = torch.empty(max(self._wg_floats, 1), dtype=torch.float32, device=device)
