@@ -6,9 +6,10 @@
 //   Workgroup = 256 threads = 4 wavefronts (2x2); each wavefront owns a (BM/2)x(BN/2) sub-tile
 //   made of 32x32 MFMA accumulators.  K advances in chunks of 16 through a 3-stage pipeline: while
 //   the 8 MFMA k-steps of chunk k issue from one fragment register set, the fragments of chunk k+1
-//   are read from LDS into the other set and chunk k+2 travels global -> VGPR -> LDS (one barrier per
-//   chunk, no LDS latency exposed after it).  LDS rows are 16 data + 4 pad floats (80 B): both the
-//   ds_write_b128 staging stores and the ds_read_b128 fragment loads are bank-conflict free.
+//   are read from LDS into the other set and chunk k+2 is DMA'd HBM/L2 -> LDS directly
+//   (buffer_load_dwordx4 ... lds: no staging VGPRs, no ds_write; one barrier per chunk, no LDS
+//   latency exposed after it).  LDS rows are 64 B, XOR-swizzled on the DMA source address and on
+//   the ds_read_b128 fragment loads, which are bank-conflict free.
 //   Lane l feeds the MFMA with k = s (l < 32) and k = 8 + s (l >= 32) at step s, so each
 //   lane reads its eight k-values as two 16-byte LDS loads.
 //   Epilogue (fused): per-channel scale/shift (folded BatchNorm or bias), optional residual
@@ -32,21 +33,24 @@ struct ConvKArgs {
     int linear_out;
     int tap_inner;
     unsigned x_bytes;  // size of the input tensor in bytes (buffer descriptor bound)
+    unsigned w_bytes;  // size of the packed weight tensor in bytes
     unsigned long long dy_pack, dx_pack;  // tap offsets, 4 bits each, biased by +8
 };
 
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
 template <int BM, int BN>
-__global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs a)
+__global__ __launch_bounds__(256, 3) void conv_igemm_f32_kernel(const ConvKArgs a)
 {
-    constexpr int LDS = 20;           // floats per LDS row (16 + 4 pad)
-    constexpr int NST = 3;            // LDS stages (chunk k in flight in MFMA, k+1 in fragments, k+2 being staged)
+    constexpr int ROWF = 16;          // floats per LDS row (one 64-byte k-chunk, no padding: LDS-DMA writes lane-linear)
+    constexpr int NST = 3;            // LDS stages (chunk k in MFMA, k+1 in fragment registers, k+2 landing by DMA)
     constexpr int TM = BM / 64;       // 32x32 tiles per wave along M
     constexpr int TN = BN / 64;       // ... along N
-    constexpr int AR = BM / 64;       // A rows staged per thread
-    constexpr int BR = BN / 64;       // B rows staged per thread
-    __shared__ __attribute__((aligned(16))) float smem[NST * (BM + BN) * LDS];
+    constexpr int AG = BM / 64;       // 16-row groups (1 KiB DMA pieces) per wave for the A tile
+    constexpr int BG = BN / 64;       // ... for the B tile
+    __shared__ __attribute__((aligned(1024))) float smem[NST * (BM + BN) * ROWF];
     float* As = smem;
-    float* Bs = smem + NST * BM * LDS;
+    float* Bs = smem + NST * BM * ROWF;
 
     const rdpn6d_conv_desc& d = a.d;
     // ---- XCD-aware tile mapping (bijective for any grid size)
@@ -60,15 +64,21 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs a)
     const int n0 = nt * BN;
 
     const int tid = threadIdx.x;
-    const int kq = tid & 3;    // which float4 of the 16-float k-chunk this thread stages
-    const int r0 = tid >> 2;   // staging row (0..63)
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    // ---- per-thread A-row geometry (fixed for the whole K loop)
-    int a_pix[AR], a_iy[AR], a_ix[AR];
-    bool a_ok[AR];
+    // ---- staging geometry.  One buffer_load_dwordx4 ... lds per wave moves 16 rows x 64 B straight into LDS:
+    // lane L lands at byte L*16 of the piece = (row L/4, physical 16-byte slot L%4).  The slot is XOR-swizzled with
+    // bits 2..3 of the row so that the ds_read_b128 fragment loads (16 lanes = 16 different rows, same logical
+    // slot) hit 16 distinct 16-byte bank groups; the swizzle is applied to the SOURCE address here and to the read.
+    const int prow = lane >> 2;                       // row inside the 16-row piece
+    const int pslot = lane & 3;                       // physical slot written by this lane
+    int a_pix[AG], a_iy[AG], a_ix[AG], a_ch[AG];
+    bool a_ok[AG];
 #pragma unroll
-    for (int i = 0; i < AR; ++i) {
-        const long long m = m0 + r0 + 64 * i;
+    for (int i = 0; i < AG; ++i) {
+        const int row = (wave + 4 * i) * 16 + prow;
+        const long long m = m0 + row;
         a_ok[i] = m < a.M;
         const int mm = a_ok[i] ? (int)m : 0;
         const int b = mm / a.HoWo;
@@ -78,41 +88,48 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs a)
         a_pix[i] = b * d.H * d.W;
         a_iy[i] = oy * d.stride;
         a_ix[i] = ox * d.stride;
+        a_ch[i] = (pslot ^ ((row >> 2) & 3)) * 4;    // logical channel offset (floats) inside the 16-channel chunk
     }
-    const float* wrow[BR];
+    unsigned w_off[BG];  // byte offset of (weight row, logical slot) inside the packed weight tensor
 #pragma unroll
-    for (int i = 0; i < BR; ++i) wrow[i] = d.w + (long long)(n0 + r0 + 64 * i) * a.Ktot + kq * 4;
+    for (int i = 0; i < BG; ++i) {
+        const int row = (wave + 4 * i) * 16 + prow;
+        w_off[i] = ((unsigned)(n0 + row) * (unsigned)a.Ktot + (unsigned)((pslot ^ ((row >> 2) & 3)) * 4)) * 4u;
+    }
 
-    // A rows are fetched with raw buffer loads: the buffer descriptor bounds-checks in hardware, so a
-    // tap that falls outside the image (or a row past M) simply gets an out-of-range offset and reads
-    // zeros - no branch, no select, and therefore no s_waitcnt between the loads of one chunk.
+    // buffer descriptors: bounds-checked in hardware, so a tap that falls outside the image (or a row past M) gets an
+    // out-of-range offset and DMA-writes zeros - no branch, no select, nothing to wait for inside a chunk.
     const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.w), 0, a.w_bytes, 0x00020000);
     const unsigned oob = a.x_bytes;  // any offset >= num_records returns 0
-    unsigned a_off[AR];              // byte offset of (pixel 0 of the row's image, channel in_co + kq*4)
+    unsigned a_off[AG];
 #pragma unroll
-    for (int i = 0; i < AR; ++i) a_off[i] = ((unsigned)a_pix[i] * (unsigned)d.in_cs + (unsigned)(d.in_co + kq * 4)) * 4u;
+    for (int i = 0; i < AG; ++i) a_off[i] = ((unsigned)a_pix[i] * (unsigned)d.in_cs + (unsigned)(d.in_co + a_ch[i])) * 4u;
     const unsigned px_bytes = (unsigned)d.in_cs * 4u;
 
     // K order: tap_inner = 1 walks channel-chunk-major with the taps innermost (the 9 shifted reads of one
     // 16-channel slab of the block's input footprint follow each other: L1/L2 locality); 0 = tap-major.
-    f32x4 ra[AR], rb[BR];
-    auto load_global = [&](const int tap, const int cc) {
+    auto stage_chunk = [&](const int tap, const int cc, const int st) {
         // tap offsets are packed 4 bits each (+8 bias) in two kernel arguments: pure ALU, no memory access
         const int dy = (int)((a.dy_pack >> (4 * tap)) & 15ull) - 8, dx = (int)((a.dx_pack >> (4 * tap)) & 15ull) - 8;
-        const int c0 = cc * 16;
+        const unsigned c0b = (unsigned)cc * 64u;
 #pragma unroll
-        for (int i = 0; i < AR; ++i) {
+        for (int i = 0; i < AG; ++i) {
             const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
             const bool ok = a_ok[i] && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
-            const unsigned off = ok ? a_off[i] + (unsigned)(iy * d.W + ix) * px_bytes + (unsigned)c0 * 4u : oob;
-            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xsrc, (int)off, 0, 0));
+            const unsigned off = ok ? a_off[i] + (unsigned)(iy * d.W + ix) * px_bytes + c0b : oob;
+            float* dst = As + (st * BM + (wave + 4 * i) * 16) * ROWF;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_ptr_t)dst, 16, (int)off, 0, 0, 0);
         }
-        const int woff = tap * d.Cin + c0;
+        const unsigned wk = ((unsigned)tap * (unsigned)d.Cin) * 4u + c0b;
 #pragma unroll
-        for (int i = 0; i < BR; ++i) rb[i] = *reinterpret_cast<const f32x4*>(wrow[i] + woff);
+        for (int i = 0; i < BG; ++i) {
+            float* dst = Bs + (st * BN + (wave + 4 * i) * 16) * ROWF;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrc, (lds_ptr_t)dst, 16, (int)(w_off[i] + wk), 0, 0, 0);
+        }
     };
     // chunk counter -> (tap, cc), advanced branch-free; clamped at the last chunk so that the loop body can
-    // load unconditionally (the two redundant loads past the end re-read the last chunk and are never used)
+    // stage unconditionally (the two redundant DMAs past the end re-read the last chunk into a stage nobody reads)
     int ld_tap = 0, ld_cc = 0, ld_left = a.nk - 1;
     auto next_chunk = [](int& tap, int& cc, int& left, const int ntaps, const int cchunks, const int tap_inner) {
         const int go = left > 0 ? 1 : 0;
@@ -129,32 +146,27 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs a)
             tap += wrap;
         }
     };
-    auto store_lds = [&](int st) {
-#pragma unroll
-        for (int i = 0; i < AR; ++i)
-            *reinterpret_cast<f32x4*>(&As[(st * BM + r0 + 64 * i) * LDS + kq * 4]) = ra[i];
-#pragma unroll
-        for (int i = 0; i < BR; ++i)
-            *reinterpret_cast<f32x4*>(&Bs[(st * BN + r0 + 64 * i) * LDS + kq * 4]) = rb[i];
-    };
 
-    const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int frow = lane & 31;          // fragment row (A: pixel, B: channel) inside a 32-tile
-    const int koff = (lane >> 5) * 8;    // this lane's 8 k-values start here
+    const int half = lane >> 5;          // this lane's 8 k-values are logical slots 2*half, 2*half+1
 
     auto read_frags = [&](int st, f32x4 (&fa)[TM][2], f32x4 (&fb)[TN][2]) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const float* p = &As[(st * BM + wm * (BM / 2) + i * 32 + frow) * LDS + koff];
-            fa[i][0] = *reinterpret_cast<const f32x4*>(p);
-            fa[i][1] = *reinterpret_cast<const f32x4*>(p + 4);
+            const int R = wm * (BM / 2) + i * 32 + frow;
+            const int sw = (R >> 2) & 3;
+            const float* p = &As[(st * BM + R) * ROWF];
+            fa[i][0] = *reinterpret_cast<const f32x4*>(p + (((2 * half) ^ sw) << 2));
+            fa[i][1] = *reinterpret_cast<const f32x4*>(p + (((2 * half + 1) ^ sw) << 2));
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const float* p = &Bs[(st * BN + wn * (BN / 2) + j * 32 + frow) * LDS + koff];
-            fb[j][0] = *reinterpret_cast<const f32x4*>(p);
-            fb[j][1] = *reinterpret_cast<const f32x4*>(p + 4);
+            const int R = wn * (BN / 2) + j * 32 + frow;
+            const int sw = (R >> 2) & 3;
+            const float* p = &Bs[(st * BN + R) * ROWF];
+            fb[j][0] = *reinterpret_cast<const f32x4*>(p + (((2 * half) ^ sw) << 2));
+            fb[j][1] = *reinterpret_cast<const f32x4*>(p + (((2 * half + 1) ^ sw) << 2));
         }
     };
 
@@ -179,36 +191,32 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvKArgs a)
 
     // ---- prologue: chunks 0 and 1 into LDS stages 0 and 1, fragments of chunk 0 into registers
     const int nk = a.nk;
-    load_global(ld_tap, ld_cc);
+    stage_chunk(ld_tap, ld_cc, 0);
     next_chunk(ld_tap, ld_cc, ld_left, d.ntaps, a.cchunks, a.tap_inner);
-    store_lds(0);
-    load_global(ld_tap, ld_cc);
+    stage_chunk(ld_tap, ld_cc, 1);
     next_chunk(ld_tap, ld_cc, ld_left, d.ntaps, a.cchunks, a.tap_inner);
-    store_lds(1);
-    __syncthreads();
+    __syncthreads();  // (waits for the LDS-DMA: vmcnt(0) + barrier)
     f32x4 fa0[TM][2], fb0[TN][2], fa1[TM][2], fb1[TN][2];
     read_frags(0, fa0, fb0);
 
     // ---- main loop over chunk PAIRS (fragment double buffer statically indexed, body branch-free).
-    // step for chunk kc: (1) global loads of chunk kc+2, (2) LDS->register fragments of chunk kc+1,
-    // (3) 8 MFMA k-steps of chunk kc, (4) stage chunk kc+2 into LDS, (5) one barrier.
+    // step for chunk kc: (1) start the DMA of chunk kc+2 into its LDS stage, (2) LDS->register fragments of chunk
+    // kc+1, (3) 8 MFMA k-steps of chunk kc, (4) one barrier (which also waits for the DMA issued in (1)).
     int st_next = 1, st_stage = 2;  // LDS stage holding chunk kc+1 / receiving chunk kc+2
     const int npairs = nk >> 1;
     for (int pr = 0; pr < npairs; ++pr) {
-        load_global(ld_tap, ld_cc);
+        stage_chunk(ld_tap, ld_cc, st_stage);
         next_chunk(ld_tap, ld_cc, ld_left, d.ntaps, a.cchunks, a.tap_inner);
         read_frags(st_next, fa1, fb1);
         mma(fa0, fb0);
-        store_lds(st_stage);
         __syncthreads();
         st_next = st_next == NST - 1 ? 0 : st_next + 1;
         st_stage = st_stage == NST - 1 ? 0 : st_stage + 1;
 
-        load_global(ld_tap, ld_cc);
+        stage_chunk(ld_tap, ld_cc, st_stage);
         next_chunk(ld_tap, ld_cc, ld_left, d.ntaps, a.cchunks, a.tap_inner);
         read_frags(st_next, fa0, fb0);
         mma(fa1, fb1);
-        store_lds(st_stage);
         __syncthreads();
         st_next = st_next == NST - 1 ? 0 : st_next + 1;
         st_stage = st_stage == NST - 1 ? 0 : st_stage + 1;
@@ -301,6 +309,9 @@ extern "C" int rdpn6d_conv2d_f32(const rdpn6d_conv_desc* d, void* stream)
     RD_REQUIRE(xb < (1LL << 32) - 64, "input tensor must be smaller than 4 GiB (32-bit buffer offsets)");
     a.x_bytes = (unsigned)xb;
     a.tap_inner = g_tap_inner;
+    const long long wb = (long long)d->Npad * d->ntaps * d->Cin * 4;
+    RD_REQUIRE(wb < (1LL << 32) - 64, "packed weights must be smaller than 4 GiB");
+    a.w_bytes = (unsigned)wb;
     a.dy_pack = a.dx_pack = 0;
     for (int t = 0; t < d->ntaps; ++t) {
         RD_REQUIRE(d->dy[t] >= -8 && d->dy[t] <= 7 && d->dx[t] >= -8 && d->dx[t] <= 7, "tap offsets must be in -8..7");
