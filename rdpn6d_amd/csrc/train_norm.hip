@@ -10,7 +10,7 @@
 #include "common.h"
 #include <float.h>
 
-#define NS_MAX 512  // row splits of the partial reductions
+#define NS_MAX 128  // row splits of the partial reductions
 
 // ---------------------------------------------------------------------------------------------
 // Stage 1 of every per-channel reduction.  MODE 0: (sum x, sum x^2)         [BN statistics, bias grads]
@@ -68,15 +68,33 @@ __global__ __launch_bounds__(256) void chan_partial_kernel(const float* __restri
     }
 }
 
-// Stage 2 for BN statistics: mean, invstd, running-stat update.
-__global__ void bn_stats_finalize_kernel(const double* __restrict__ partial, int S, int C, long long M, float eps,
-                                         float momentum, float* __restrict__ mean, float* __restrict__ invstd,
-                                         float* __restrict__ running_mean, float* __restrict__ running_var)
+// Stage 2 helpers: block = 256 threads = 4 split lanes x 64 channels; the S partials of a channel are summed by 4
+// lanes (fixed order) and combined through LDS.
+__device__ __forceinline__ void combine_partials(const double* __restrict__ partial, int S, int C, int c, bool ok, double& a,
+                                                 double& b)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double a = 0.0, b = 0.0;
-    for (int s = 0; s < S; ++s) { a += partial[((long long)s * C + c) * 2]; b += partial[((long long)s * C + c) * 2 + 1]; }
+    __shared__ double s_a[4][64], s_b[4][64];
+    const int sl = threadIdx.x >> 6, cl = threadIdx.x & 63;
+    a = 0.0; b = 0.0;
+    if (ok)
+        for (int s = sl; s < S; s += 4) { a += partial[((long long)s * C + c) * 2]; b += partial[((long long)s * C + c) * 2 + 1]; }
+    s_a[sl][cl] = a; s_b[sl][cl] = b;
+    __syncthreads();
+    a = (s_a[0][cl] + s_a[1][cl]) + (s_a[2][cl] + s_a[3][cl]);
+    b = (s_b[0][cl] + s_b[1][cl]) + (s_b[2][cl] + s_b[3][cl]);
+}
+
+// Stage 2 for BN statistics: mean, invstd, running-stat update.
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double* __restrict__ partial, int S, int C, long long M,
+                                                                float eps, float momentum, float* __restrict__ mean,
+                                                                float* __restrict__ invstd, float* __restrict__ running_mean,
+                                                                float* __restrict__ running_var)
+{
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const bool ok = c < C;
+    double a, b;
+    combine_partials(partial, S, C, c, ok, a, b);
+    if (!ok || threadIdx.x >= 64) return;
     const double mu = a / (double)M;
     double var = b / (double)M - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -90,13 +108,15 @@ __global__ void bn_stats_finalize_kernel(const double* __restrict__ partial, int
 }
 
 // Stage 2 for plain sums (bias gradients) and for BN backward (dgamma, dbeta).
-__global__ void chan_sum_finalize_kernel(const double* __restrict__ partial, int S, int C, float* __restrict__ out_a,
-                                         float* __restrict__ out_b, int accumulate)
+__global__ __launch_bounds__(256) void chan_sum_finalize_kernel(const double* __restrict__ partial, int S, int C,
+                                                                float* __restrict__ out_a, float* __restrict__ out_b,
+                                                                int accumulate)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double a = 0.0, b = 0.0;
-    for (int s = 0; s < S; ++s) { a += partial[((long long)s * C + c) * 2]; b += partial[((long long)s * C + c) * 2 + 1]; }
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const bool ok = c < C;
+    double a, b;
+    combine_partials(partial, S, C, c, ok, a, b);
+    if (!ok || threadIdx.x >= 64) return;
     if (out_a) out_a[c] = (accumulate ? out_a[c] : 0.f) + (float)a;
     if (out_b) out_b[c] = (accumulate ? out_b[c] : 0.f) + (float)b;
 }
@@ -104,7 +124,7 @@ __global__ void chan_sum_finalize_kernel(const double* __restrict__ partial, int
 static int pick_splits(long long M, int C)
 {
     long long s = (M + 255) / 256;                       // >= 16 rows per row lane
-    const long long want = 4096 / ((C + 63) / 64) + 1;  // enough workgroups to fill the chip (16 per CU)
+    const long long want = 2048 / ((C + 63) / 64) + 1;  // enough workgroups to fill the chip (8 per CU)
     if (s > want) s = want;
     if (s > NS_MAX) s = NS_MAX;
     if (s < 1) s = 1;
@@ -122,7 +142,7 @@ extern "C" int rdpn6d_bn_train_stats_f32(const float* x, long long M, int C, int
     hipLaunchKernelGGL(chan_partial_kernel<0>, dim3((C + 63) / 64, S), dim3(256), 0, s, x, cs, co, nullptr, 0, 0, nullptr, 0, 0,
                        nullptr, nullptr, M, C, 0, scratch);
     RD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, scratch, S, C, M, eps, momentum, mean,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, s, scratch, S, C, M, eps, momentum, mean,
                        invstd, running_mean, running_var);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
@@ -138,7 +158,7 @@ extern "C" int rdpn6d_channel_sum_f32(const float* x, long long M, int C, int cs
     hipLaunchKernelGGL(chan_partial_kernel<0>, dim3((C + 63) / 64, S), dim3(256), 0, s, x, cs, co, nullptr, 0, 0, nullptr, 0, 0,
                        nullptr, nullptr, M, C, 0, scratch);
     RD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, scratch, S, C, out, nullptr, accumulate);
+    hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, s, scratch, S, C, out, nullptr, accumulate);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
 }
@@ -236,7 +256,7 @@ extern "C" int rdpn6d_bn_backward_f32(const float* x, int xcs, int xco, const fl
                        mean, invstd, M, C, relu, scratch);
     RD_LAUNCH_CHECK();
     // partial = (sum g, sum g*xhat) -> dbeta, dgamma
-    hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, s, scratch, S, C, dbeta, dgamma, 0);
+    hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, s, scratch, S, C, dbeta, dgamma, 0);
     RD_LAUNCH_CHECK();
     const long long total = M * (C / 4);
     const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);

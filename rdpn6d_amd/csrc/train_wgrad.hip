@@ -5,8 +5,9 @@
 //     convT wgrad    : A = X  (input pixels x Cin),   Bg = dY gathered at (2iy-1+ky, 2ix-1+kx)   -> [Cin][taps][Cout]
 //     linear wgrad   : A = dY (B x Nout), Bg = X (B x K), taps = 1
 //   The reduction runs over PIXELS (the NHWC row index), so both operands are staged pixel-major
-//   [16 pixels][128 channels] exactly as they lie in HBM (512-byte coalesced rows, no transpose) and the MFMA
-//   fragments are read column-wise with conflict-free ds_read_b32 (32 consecutive channels per half-wave).
+//   [16 pixels][128 channels] exactly as they lie in HBM (512-byte coalesced rows, no transpose) by LDS-DMA
+//   (buffer_load_dwordx4 ... lds, no staging VGPRs / ds_write), 3 stages; the MFMA fragments are read column-wise
+//   with conflict-free ds_read_b32 (32 consecutive channels per half-wave) into a double-buffered register set.
 //   Split-K over pixel ranges: grid.y splits write fp32 partial tiles that a second kernel sums in a fixed
 //   order (deterministic, no atomics).
 // Backward of nn.Conv2d / nn.ConvTranspose2d / nn.Linear weights in core/gdrn_modeling/models/*.py.
@@ -25,26 +26,37 @@ struct WgradKArgs {
     int Ca, Cb;
     int a_cs, a_co, b_cs, b_co;
     int atiles, btiles;  // tiles over Ca and over Cb (per tap)
+    int nsplit;
     long long rows_per_split;
     unsigned a_bytes, b_bytes;
 };
 
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
 template <int BA, int BB>
-__global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradKArgs a)
+__global__ __launch_bounds__(256, 3) void wgrad_f32_kernel(const WgradKArgs a)
 {
     constexpr int TA = BA / 64, TB = BB / 64;  // 32x32 tiles per wave (2x2 waves)
     constexpr int NST = 3;                      // LDS stages (same 3-stage pipeline as conv_igemm_f32_kernel)
-    __shared__ __attribute__((aligned(16))) float As[NST][16][BA];
-    __shared__ __attribute__((aligned(16))) float Bs[NST][16][BB];
+    __shared__ __attribute__((aligned(1024))) float As[NST][16][BA];
+    __shared__ __attribute__((aligned(1024))) float Bs[NST][16][BB];
 
-    const int tile = blockIdx.x;
+    // XCD-aware mapping: workgroup b runs on XCD b % 8; give every XCD whole splits (all tiles of a split stream through
+    // the same pixel range in lockstep, so each dY / X row is fetched into one L2 only, once).
+    const int ntile = a.atiles * a.btiles * a.ntaps;
+    const int nblk = ntile * a.nsplit;
+    const int bid = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, kk = bid >> 3;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + kk;
+    const int tile = logical % ntile;
+    const int split = logical / ntile;
     const int at = tile % a.atiles;
     const int rest = tile / a.atiles;
     const int bt = rest % a.btiles;
     const int tap = rest / a.btiles;
     const int a0 = at * BA, b0 = bt * BB;
     const int dy = (int)((a.dy_pack >> (4 * tap)) & 15ull) - 8, dx = (int)((a.dx_pack >> (4 * tap)) & 15ull) - 8;
-    const long long m_lo = (long long)blockIdx.y * a.rows_per_split;
+    const long long m_lo = (long long)split * a.rows_per_split;
     const long long m_hi = m_lo + a.rows_per_split < a.M ? m_lo + a.rows_per_split : a.M;
     const int nchunks = m_hi > m_lo ? (int)((m_hi - m_lo + 15) / 16) : 0;
 
@@ -52,57 +64,55 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradKArgs a)
     const __amdgpu_buffer_rsrc_t bsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.Bg), 0, a.b_bytes, 0x00020000);
 
     const int tid = threadIdx.x;
-    // staging: a tile row = one pixel x BA channels = BA/4 float4; thread -> (row, c4)
-    constexpr int A4 = BA / 4, B4 = BB / 4;            // float4 per row
-    constexpr int AROWS = 256 / A4, BROWS = 256 / B4;  // rows covered per pass (BA=128: 8, BA=64: 16)
-    constexpr int APASS = 16 / AROWS, BPASS = 16 / BROWS;
-    const int ar = tid / A4, ac4 = tid % A4, br = tid / B4, bc4 = tid % B4;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // staging by LDS-DMA (buffer_load_dwordx4 ... lds): one wave instruction moves 1 KiB = (1024 / (BA*4)) pixel rows of
+    // BA channels straight into the pixel-major LDS tile (lane-linear = exactly the tile's layout, no swizzle needed:
+    // the fragment reads are ds_read_b32 over 32 consecutive channels).
+    constexpr int A4 = BA / 4, B4 = BB / 4;              // float4 (= lanes) per pixel row
+    constexpr int AROWS = 64 / A4, BROWS = 64 / B4;      // pixel rows per DMA piece (BA=128: 2, BA=64: 4)
+    constexpr int APIECES = 16 / AROWS / 4, BPIECES = 16 / BROWS / 4;  // pieces per wave (BA=128: 2, BA=64: 1)
+    const int ar = lane / A4, ac4 = lane % A4, br = lane / B4, bc4 = lane % B4;
     const bool a_cok = a0 + ac4 * 4 < a.Ca, b_cok = b0 + bc4 * 4 < a.Cb;
     const unsigned a_col = (unsigned)(a.a_co + a0 + ac4 * 4) * 4u, b_col = (unsigned)(a.b_co + b0 + bc4 * 4) * 4u;
     const unsigned a_row_bytes = (unsigned)a.a_cs * 4u, b_px_bytes = (unsigned)a.b_cs * 4u;
 
-    // pixel coordinates of this thread's B rows, advanced incrementally (16 pixels per chunk): no divisions in the loop
-    int b_ox[BPASS], b_oy[BPASS], b_bi[BPASS];
+    // pixel coordinates of this lane's B rows, advanced incrementally (16 pixels per chunk): no divisions in the loop
+    int b_ox[BPIECES], b_oy[BPIECES], b_bi[BPIECES];
 #pragma unroll
-    for (int p = 0; p < BPASS; ++p) {
-        const long long m = m_lo + br + p * BROWS;
+    for (int p = 0; p < BPIECES; ++p) {
+        const long long m = m_lo + (wave + 4 * p) * BROWS + br;
         const int mm = m < a.M ? (int)m : 0;
         b_bi[p] = mm / a.HaWa;
         const int rem = mm - b_bi[p] * a.HaWa;
         b_oy[p] = rem / a.Wa;
         b_ox[p] = rem - b_oy[p] * a.Wa;
     }
-    long long ld_m = m_lo;  // first pixel of the next chunk to load
-    f32x4 ra[APASS], rb[BPASS];
-    auto load_chunk = [&]() {
+    long long ld_m = m_lo;  // first pixel of the next chunk to stage
+    auto stage_chunk = [&](const int st) {
 #pragma unroll
-        for (int p = 0; p < APASS; ++p) {
-            const long long m = ld_m + ar + p * AROWS;
+        for (int p = 0; p < APIECES; ++p) {
+            const int row0 = (wave + 4 * p) * AROWS;
+            const long long m = ld_m + row0 + ar;
             const bool ok = a_cok && m < m_hi;
             const unsigned off = ok ? (unsigned)m * a_row_bytes + a_col : a.a_bytes;
-            ra[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(asrc, (int)off, 0, 0));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(asrc, (lds_ptr_t)&As[st][row0][0], 16, (int)off, 0, 0, 0);
         }
 #pragma unroll
-        for (int p = 0; p < BPASS; ++p) {
-            const long long m = ld_m + br + p * BROWS;
+        for (int p = 0; p < BPIECES; ++p) {
+            const int row0 = (wave + 4 * p) * BROWS;
+            const long long m = ld_m + row0 + br;
             const int iy = b_oy[p] * a.stride + dy, ix = b_ox[p] * a.stride + dx;
             const bool ok = b_cok && m < m_hi && (unsigned)iy < (unsigned)a.Hb && (unsigned)ix < (unsigned)a.Wb;
             const unsigned off = ok ? (unsigned)((b_bi[p] * a.Hb + iy) * a.Wb + ix) * b_px_bytes + b_col : a.b_bytes;
-            rb[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bsrc, (int)off, 0, 0));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(bsrc, (lds_ptr_t)&Bs[st][row0][0], 16, (int)off, 0, 0, 0);
             // advance this row by 16 pixels
             b_ox[p] += 16;
             while (b_ox[p] >= a.Wa) { b_ox[p] -= a.Wa; if (++b_oy[p] == a.Ha) { b_oy[p] = 0; ++b_bi[p]; } }
         }
         ld_m += 16;
     };
-    auto store_lds = [&](int st) {
-#pragma unroll
-        for (int p = 0; p < APASS; ++p) *reinterpret_cast<f32x4*>(&As[st][ar + p * AROWS][ac4 * 4]) = ra[p];
-#pragma unroll
-        for (int p = 0; p < BPASS; ++p) *reinterpret_cast<f32x4*>(&Bs[st][br + p * BROWS][bc4 * 4]) = rb[p];
-    };
 
-    const int lane = tid & 63, wave = tid >> 6;
     const int wa = wave >> 1, wb = wave & 1;
     const int frow = lane & 31, koff = (lane >> 5) * 8;
 
@@ -134,29 +144,29 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradKArgs a)
     };
 
     if (nchunks > 0) {
-        // loads past the split's end are bounds-checked to zero (m >= m_hi), so the loop body needs no branches
-        load_chunk();
-        store_lds(0);
-        load_chunk();
-        store_lds(1);
-        __syncthreads();
+        // rows past the split's end are bounds-checked to zero (m >= m_hi), so the loop body needs no branches
+        stage_chunk(0);
+        stage_chunk(1);
+        __syncthreads();  // waits for the DMA (vmcnt(0)) + barrier
         float fa0[TA][8], fb0[TB][8], fa1[TA][8], fb1[TB][8];
         read_frags(0, fa0, fb0);
         int st_next = 1, st_stage = 2;
         const int npairs = nchunks >> 1;
         for (int pr = 0; pr < npairs; ++pr) {
-            load_chunk();
+            // fragment reads are issued BEFORE the DMA in program order: the compiler cannot prove that the DMA target
+            // stage differs from the stage being read and would otherwise drain vmcnt(0) in the middle of the MFMAs
             read_frags(st_next, fa1, fb1);
+            __builtin_amdgcn_sched_barrier(0);
+            stage_chunk(st_stage);
             mma(fa0, fb0);
-            store_lds(st_stage);
             __syncthreads();
             st_next = st_next == NST - 1 ? 0 : st_next + 1;
             st_stage = st_stage == NST - 1 ? 0 : st_stage + 1;
 
-            load_chunk();
             read_frags(st_next, fa0, fb0);
+            __builtin_amdgcn_sched_barrier(0);
+            stage_chunk(st_stage);
             mma(fa1, fb1);
-            store_lds(st_stage);
             __syncthreads();
             st_next = st_next == NST - 1 ? 0 : st_next + 1;
             st_stage = st_stage == NST - 1 ? 0 : st_stage + 1;
@@ -166,7 +176,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(const WgradKArgs a)
 
     // partial[split][a][tap][b]: lanes hold consecutive b (32 x 4 B = 128-byte runs)
     const int hi = lane >> 5;
-    float* po = a.partial + (long long)blockIdx.y * a.Ca * a.ntaps * a.Cb;
+    float* po = a.partial + (long long)split * a.Ca * a.ntaps * a.Cb;
 #pragma unroll
     for (int j = 0; j < TB; ++j) {
         const int bch = b0 + wb * (BB / 2) + j * 32 + frow;
@@ -198,7 +208,7 @@ extern "C" long long rdpn6d_wgrad_scratch_floats(int Bn, int Ha, int Wa, int Ca,
 // tile variant's registers allow) - a grid of 1044 workgroups on 512 slots would run 3 rounds at 68 % utilisation.
 static int wgrad_pick_splits(long long M, int tiles, int ba, int bb)
 {
-    const int occ = (ba == 128 && bb == 128) ? 2 : ((ba == 64 && bb == 64) ? 5 : 3);
+    const int occ = (ba == 128 && bb == 128) ? 3 : ((ba == 64 && bb == 64) ? 5 : 4);
     const long long slots = 256LL * occ;
     const long long maxs = (M + 255) / 256 > 0 ? (M + 255) / 256 : 1;  // >= 16 chunks of 16 pixels per split
     long long best = 1;
@@ -255,7 +265,8 @@ extern "C" int rdpn6d_wgrad_f32(const float* A, int a_cs, int a_co, int Ca, cons
     const int S = wgrad_pick_splits(a.M, tiles, ba, bb);
     a.rows_per_split = ((a.M + S - 1) / S + 15) / 16 * 16;
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid(tiles, S), block(256);
+    a.nsplit = S;
+    dim3 grid(tiles * S), block(256);
     if (ba == 128 && bb == 128) hipLaunchKernelGGL((wgrad_f32_kernel<128, 128>), grid, block, 0, s, a);
     else if (ba == 128) hipLaunchKernelGGL((wgrad_f32_kernel<128, 64>), grid, block, 0, s, a);
     else if (bb == 128) hipLaunchKernelGGL((wgrad_f32_kernel<64, 128>), grid, block, 0, s, a);
