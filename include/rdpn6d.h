@@ -195,6 +195,14 @@ int rdpn6d_pose_train_f32(const float* rt, int rt_stride, const float* roi_cams,
                           const float* gt_trans_ratio, const float* points, int npts, int B, int is_allo, float pm_lw,
                           int pm_norm_by_extent, float centroid_lw, float z_lw, float* rot, float* trans, float* d_rt,
                           float* losses, float* scratch, void* stream);
+/* Fused multi-tensor Ranger step over flat buffers (replaces lib/torch_utils/solver/ranger.py:100-200).
+ * work = array of {int64 off; int32 len; int32 row} runs (row = index of the centralisation mean, -1 = none);
+ * row_off/row_len describe the rows whose gradient mean is subtracted (gradient centralisation);
+ * neg_step_lr = -step_size*lr and rectified = (N_sma > threshold) are computed on the host from the step count. */
+int rdpn6d_ranger_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* slow, const void* work,
+                           int nwork, const long long* row_off, const int* row_len, int nrows, float* row_mean, float beta1,
+                           float beta2, float eps, float neg_step_lr, float wd_lr, int rectified, int lookahead, float alpha,
+                           void* stream);
 int rdpn6d_act_backward_f32(float* dy, const float* y, long long n, float slope, void* stream);
 int rdpn6d_rgb_to_nhwc4_f32(const float* x, int B, int xc, int R, float* y, void* stream);
 

@@ -1,20 +1,31 @@
-"""Ranger = RAdam + Lookahead + gradient centralisation, as a multi-tensor (torch._foreach) step.
+"""Ranger (RAdam + Lookahead + gradient centralisation) as ONE fused HIP step over flat HBM buffers.
 
-Same update rule and hyper-parameter names as the reference's optimizer
-(/root/reference/lib/torch_utils/solver/ranger.py:100-200: lr 1e-3, alpha 0.5, k 6,
-N_sma_threshhold 5, betas (0.95, 0.999), eps 1e-5, GC on conv + fc), but the per-tensor Python
-loop (164 tensors x ~12 ops) is replaced by a handful of fused foreach launches per group.
-SURVEY.md §8f ranks a single fused HIP kernel for this step as "next"; this is its host mirror.
+Same update rule, hyper-parameter names and defaults as the reference's optimizer
+(lib/torch_utils/solver/ranger.py:27-200: lr 1e-3, alpha 0.5, k 6, N_sma_threshhold 5, betas (0.95, 0.999),
+eps 1e-5, gradient centralisation on conv + fc weights), so ``SOLVER.OPTIMIZER_CFG=dict(type="Ranger", ...)``
+works unchanged; the 164-tensor Python loop becomes two kernel launches per parameter group
+(rdpn6d_amd/csrc/ranger.hip).  Parameters, gradients, exp_avg, exp_avg_sq and the lookahead slow weights each
+live in one contiguous buffer; ``param.data`` / ``param.grad`` / ``state[p][...]`` are views into them, so
+``state_dict()`` keeps the reference's per-parameter layout (step, exp_avg, exp_avg_sq, slow_buffer).
+
+There is no CPU path: parameters must live on the GPU (the torch restatement used by the tests is
+oracle/ranger_oracle.py).  SURVEY.md section 8f rank 2.
 """
+import ctypes
 import math
 
+import numpy as np
 import torch
 from torch.optim.optimizer import Optimizer
+
+from . import _lib
+
+_CHUNK = 4096  # elements per work item (one 256-thread workgroup)
 
 
 class Ranger(Optimizer):
     def __init__(self, params, lr=1e-3, alpha=0.5, k=6, N_sma_threshhold=5, betas=(0.95, 0.999), eps=1e-5,
-                 weight_decay=0, use_gc=True, gc_conv_only=False):
+                 weight_decay=0, use_gc=True, gc_conv_only=False, flat_grad=None):
         if not 0.0 <= alpha <= 1.0:
             raise ValueError(f"Invalid slow update rate: {alpha}")
         if not 1 <= k:
@@ -27,49 +38,139 @@ class Ranger(Optimizer):
                                       weight_decay=weight_decay))
         self.use_gc = use_gc
         self.gc_min_dim = 3 if gc_conv_only else 1
+        self._flat = None
+        self._ext_flat_grad = flat_grad
+        self._step = 0
 
+    # ------------------------------------------------------------------ flat storage
+    def _build(self):
+        ps = [p for g in self.param_groups for p in g["params"] if p.requires_grad]
+        if not ps:
+            raise ValueError("Ranger: no trainable parameters")
+        dev = ps[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("rdpn6d_amd.Ranger runs its fused step on the GPU only (no CPU fallback); got CPU parameters")
+        n = sum(p.numel() for p in ps)
+        f32 = dict(dtype=torch.float32, device=dev)
+        fp = torch.empty(n, **f32)
+        # gradients: adopt an existing flat buffer (GradBuckets) when every p.grad already is a view into it, in order
+        fg = self._ext_flat_grad
+        offs, o = {}, 0
+        adopt = fg is not None and fg.numel() == n
+        for p in ps:
+            offs[id(p)] = o
+            if adopt and not (p.grad is not None and p.grad.data_ptr() == fg.data_ptr() + 4 * o):
+                adopt = False
+            o += p.numel()
+        if not adopt:
+            fg = torch.zeros(n, **f32)
+        fm, fv, fs = torch.zeros(n, **f32), torch.zeros(n, **f32), torch.empty(n, **f32)
+        for p in ps:
+            o, k = offs[id(p)], p.numel()
+            fp[o:o + k].copy_(p.detach().reshape(-1))
+            p.data = fp[o:o + k].view_as(p)
+            if not adopt:
+                if p.grad is not None:
+                    fg[o:o + k].copy_(p.grad.reshape(-1))
+                p.grad = fg[o:o + k].view_as(p)
+            st = self.state[p]
+            st["step"] = self._step
+            st["exp_avg"], st["exp_avg_sq"] = fm[o:o + k].view_as(p), fv[o:o + k].view_as(p)
+            st["slow_buffer"] = fs[o:o + k].view_as(p)
+        fs.copy_(fp)
+        # work tables per group
+        self._groups = []
+        row_off, row_len = [], []
+        for g in self.param_groups:
+            work = []
+            for p in g["params"]:
+                if not p.requires_grad:
+                    continue
+                o, k = offs[id(p)], p.numel()
+                if self.use_gc and p.dim() > self.gc_min_dim:
+                    rl = k // p.shape[0]
+                    for r in range(p.shape[0]):
+                        ridx = len(row_off)
+                        row_off.append(o + r * rl)
+                        row_len.append(rl)
+                        for c in range(0, rl, _CHUNK):
+                            work.append((o + r * rl + c, min(_CHUNK, rl - c), ridx))
+                else:
+                    for c in range(0, k, _CHUNK):
+                        work.append((o + c, min(_CHUNK, k - c), -1))
+            wt = np.zeros(len(work), dtype=np.dtype([("off", "<i8"), ("len", "<i4"), ("row", "<i4")]))
+            for i, (a, b, c) in enumerate(work):
+                wt[i] = (a, b, c)
+            self._groups.append(torch.from_numpy(wt.view(np.uint8).copy()).to(dev))
+        self._nwork = [g.numel() // 16 for g in self._groups]
+        self._row_off = torch.tensor(row_off or [0], dtype=torch.int64, device=dev)
+        self._row_len = torch.tensor(row_len or [1], dtype=torch.int32, device=dev)
+        self._nrows = len(row_off)
+        self._row_mean = torch.zeros(max(self._nrows, 1), **f32)
+        self._flat = dict(p=fp, g=fg, m=fm, v=fv, s=fs)
+        self._params = ps
+
+    @property
+    def flat_grad(self):
+        if self._flat is None:
+            self._build()
+        return self._flat["g"]
+
+    def zero_grad(self, set_to_none=False):
+        """keeps param.grad as views of the flat gradient buffer (set_to_none would break the fused step's layout)"""
+        if self._flat is None:
+            return super().zero_grad(set_to_none=set_to_none)
+        self._flat["g"].zero_()
+
+    # ------------------------------------------------------------------ step
     @torch.no_grad()
     def step(self, closure=None):
-        for group in self.param_groups:
-            ps = [p for p in group["params"] if p.grad is not None]
-            if not ps:
+        if self._flat is None:
+            self._build()
+        F = self._flat
+        for p in self._params:  # a caller may have replaced p.grad (e.g. zero_grad(set_to_none=True) + backward)
+            o = p.data_ptr() - F["p"].data_ptr()
+            if p.grad is None:
+                raise RuntimeError("Ranger.step: a parameter has no gradient")
+            if p.grad.data_ptr() != F["g"].data_ptr() + o:
+                F["g"][o // 4:o // 4 + p.numel()].copy_(p.grad.reshape(-1))
+                p.grad = F["g"][o // 4:o // 4 + p.numel()].view_as(p)
+        self._step += 1
+        step = self._step
+        lib = _lib.load()
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        P = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        first = True
+        for gi, g in enumerate(self.param_groups):
+            if self._nwork[gi] == 0:
                 continue
-            beta1, beta2 = group["betas"]
-            grads = []
-            for p in ps:
-                st = self.state[p]
-                if not st:
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p, dtype=torch.float32)
-                    st["exp_avg_sq"] = torch.zeros_like(p, dtype=torch.float32)
-                    st["slow_buffer"] = p.detach().clone()
-                g = p.grad.float()
-                if self.use_gc and g.dim() > self.gc_min_dim:
-                    g = g - g.mean(dim=tuple(range(1, g.dim())), keepdim=True)
-                grads.append(g)
-                st["step"] += 1
-            step = self.state[ps[0]]["step"]  # all tensors of a group step together
-            m = [self.state[p]["exp_avg"] for p in ps]
-            v = [self.state[p]["exp_avg_sq"] for p in ps]
-            torch._foreach_mul_(v, beta2)
-            torch._foreach_addcmul_(v, grads, grads, value=1 - beta2)
-            torch._foreach_mul_(m, beta1)
-            torch._foreach_add_(m, grads, alpha=1 - beta1)
+            beta1, beta2 = g["betas"]
             beta2_t = beta2 ** step
             n_max = 2 / (1 - beta2) - 1
             n_sma = n_max - 2 * step * beta2_t / (1 - beta2_t)
-            if group["weight_decay"] != 0:
-                torch._foreach_mul_(ps, 1 - group["weight_decay"] * group["lr"])
-            if n_sma > group["N_sma_threshhold"]:
-                step_size = math.sqrt((1 - beta2_t) * (n_sma - 4) / (n_max - 4) * (n_sma - 2) / n_sma * n_max /
-                                      (n_max - 2)) / (1 - beta1 ** step)
-                denom = torch._foreach_sqrt(v)
-                torch._foreach_add_(denom, group["eps"])
-                torch._foreach_addcdiv_(ps, m, denom, value=-step_size * group["lr"])
+            rect = n_sma > g["N_sma_threshhold"]
+            if rect:
+                step_size = math.sqrt((1 - beta2_t) * (n_sma - 4) / (n_max - 4) * (n_sma - 2) / n_sma * n_max / (n_max - 2)) / (1 - beta1 ** step)
             else:
-                torch._foreach_add_(ps, m, alpha=-group["lr"] / (1 - beta1 ** step))
-            if step % group["k"] == 0:
-                slow = [self.state[p]["slow_buffer"] for p in ps]
-                torch._foreach_lerp_(slow, ps, group["alpha"])
-                torch._foreach_copy_(ps, slow)
+                step_size = 1.0 / (1 - beta1 ** step)
+            _lib.check(lib.rdpn6d_ranger_step_f32(
+                P(F["p"]), P(F["g"]), P(F["m"]), P(F["v"]), P(F["s"]), P(self._groups[gi]), self._nwork[gi], P(self._row_off),
+                P(self._row_len), self._nrows if first else 0, P(self._row_mean), beta1, beta2, g["eps"], -step_size * g["lr"],
+                g["weight_decay"] * g["lr"], 1 if rect else 0, 1 if step % g["k"] == 0 else 0, g["alpha"], st), "ranger_step")
+            first = False  # the row means cover all groups and are computed once
+        for p in self._params:
+            self.state[p]["step"] = step
         return None
+
+    def load_state_dict(self, state_dict):
+        """copy a reference-format optimizer state (per-parameter step / exp_avg / exp_avg_sq / slow_buffer) into the flat buffers"""
+        if self._flat is None:
+            self._build()
+        views = {id(p): dict(self.state[p]) for p in self._params}
+        super().load_state_dict(state_dict)
+        for p in self._params:
+            st, v = self.state[p], views[id(p)]
+            for k in ("exp_avg", "exp_avg_sq", "slow_buffer"):
+                v[k].copy_(st[k])
+                st[k] = v[k]
+            self._step = int(st.get("step", self._step))
