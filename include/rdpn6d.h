@@ -206,6 +206,17 @@ int rdpn6d_ranger_step_f32(float* param, const float* grad, float* exp_avg, floa
 int rdpn6d_act_backward_f32(float* dy, const float* y, long long n, float slope, void* stream);
 int rdpn6d_rgb_to_nhwc4_f32(const float* x, int B, int xc, int R, float* y, void* stream);
 
+/* ================================================================== "next" rows of SURVEY.md section 8f
+ * rank 3: region / residual training targets (core/utils/data_utils.py:229-244, data_loader.py:881-903).
+ *   xyz_hwc [B,HW,3] f32 (model-space crop, 0 = background), fps [B,K,3] f64 (the loader's float64 anchors),
+ *   rot [B,9] f32 (GT pose), extent [B,3] -> roi_xyz [B,3,HW] f32, roi_region [B,HW] int64 (0 = bg, 1..K) */
+int rdpn6d_region_targets_f32(const float* xyz_hwc, const double* fps, const float* rot, const float* extent, int B, int HW,
+                              int K, float* roi_xyz_chw, long long* roi_region, void* stream);
+/* rank 4: ADD / ADI / re (deg) / te per pose in float64 (lib/pysixd/pose_error.py:297-337,400-436).
+ *   est, gt [B,12] = R row-major | t; pts [n,3] shared (pts_per_pose = 0) or [B,n,3]; out [B,4] = add, adi, re, te */
+int rdpn6d_pose_errors_f64(const double* est, const double* gt, const double* pts, int pts_per_pose, int n, int B,
+                           double* scratch, double* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

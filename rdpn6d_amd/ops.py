@@ -138,3 +138,33 @@ def ransac_kabsch(out_nchw, coord2d, fps, extents, resize_ratios, region_argmax,
                                                    confidence, seed, _ptr(pose), _ptr(nin), _ptr(mask), _ptr(best),
                                                    _stream()), "ransac_kabsch")
     return pose, nin, mask, best
+
+
+def region_targets(xyz_hwc, fps64, rot, extent):
+    """Training targets on device (data_utils.xyz_to_region + data_loader.py:881-903): xyz_hwc [B,H,W,3] f32 model-space
+    crop, fps64 [B,K,3] float64 anchors, rot [B,3,3], extent [B,3] -> roi_xyz [B,3,H,W] f32, roi_region [B,H,W] int64."""
+    _need_gpu(xyz_hwc, fps64, rot, extent)
+    B, H, W, _ = xyz_hwc.shape
+    K = fps64.shape[1]
+    assert fps64.dtype == torch.float64
+    out = torch.empty(B, 3, H, W, dtype=torch.float32, device=xyz_hwc.device)
+    reg = torch.empty(B, H, W, dtype=torch.int64, device=xyz_hwc.device)
+    args = [xyz_hwc.float().contiguous(), fps64.contiguous(), rot.float().contiguous(), extent.float().contiguous()]
+    _lib.check(_lib.load().rdpn6d_region_targets_f32(*[_ptr(t) for t in args], B, H * W, K, _ptr(out), _ptr(reg), _stream()), "region_targets")
+    return out, reg
+
+
+def pose_errors(R_est, t_est, R_gt, t_gt, pts):
+    """ADD / ADI / re[deg] / te per pose on device in float64 (lib/pysixd/pose_error.py add, adi, re, te).
+    R_* [B,3,3], t_* [B,3], pts [n,3] or [B,n,3] -> [B,4] float64"""
+    _need_gpu(R_est, t_est, R_gt, t_gt, pts)
+    B = R_est.shape[0]
+    est = torch.cat([R_est.reshape(B, 9), t_est.reshape(B, 3)], 1).double().contiguous()
+    gt = torch.cat([R_gt.reshape(B, 9), t_gt.reshape(B, 3)], 1).double().contiguous()
+    p = pts.double().contiguous()
+    per_pose = 1 if p.dim() == 3 else 0
+    n = p.shape[-2]
+    out = torch.empty(B, 4, dtype=torch.float64, device=est.device)
+    scratch = torch.empty(B, n, 3, dtype=torch.float64, device=est.device) if n * 24 > 150 * 1024 else None
+    _lib.check(_lib.load().rdpn6d_pose_errors_f64(_ptr(est), _ptr(gt), _ptr(p), per_pose, n, B, _ptr(scratch), _ptr(out), _stream()), "pose_errors")
+    return out
