@@ -216,6 +216,13 @@ int rdpn6d_region_targets_f32(const float* xyz_hwc, const double* fps, const flo
  *   est, gt [B,12] = R row-major | t; pts [n,3] shared (pts_per_pose = 0) or [B,n,3]; out [B,4] = add, adi, re, te */
 int rdpn6d_pose_errors_f64(const double* est, const double* gt, const double* pts, int pts_per_pose, int n, int B,
                            double* scratch, double* out, void* stream);
+/* rank 1: GPU crop builder (core/gdrn_modeling/data_loader.py:523-627, core/utils/data_utils.py:81-152; cv2.warpAffine
+ * bilinear arithmetic restated, parity with cv2 unpinned).  images [N,H,W,3] u8, depths [N,H,W] f32; per ROI: image index,
+ * inverse affine maps for the R and R/4 crops (6 doubles each), fx fy cx cy of (A @ K), resize_ratio ->
+ * roi_img [B,6,R,R], roi_coord_2d [B,5,R/4,R/4] */
+int rdpn6d_crop_builder_f32(const unsigned char* images, const float* depths, int N, int H, int W, const int* img_idx,
+                            const double* inv_in, const double* inv_out, const double* Knew, const double* ratio, int B, int R,
+                            float* roi_img, float* roi_coord_2d, void* stream);
 
 #ifdef __cplusplus
 }

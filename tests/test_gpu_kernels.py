@@ -412,3 +412,38 @@ def test_model_use_pnp_matches_oracle_on_model_maps(golden_setup, dev, oracle_li
     assert np.array_equal(o["pnp_inlier_mask"].cpu().numpy(), mo)
     assert np.abs(o["pnp_pose"].cpu().numpy() - po).max() < 1e-4
     assert o["pnp_pose"].shape == (4, 12)
+
+
+@pytest.mark.parametrize("att", ["none", "mul"])
+def test_pose_teacher_forced_on_reference_maps(golden_setup, dev, att):
+    """tier (ii) of SURVEY.md section 8d: feed the REFERENCE's dense maps (golden) into the HIP glue -> ConvPnPNet -> pose decode,
+    so that trunk/head round-off and arg-max flips are out of the picture: the pose then agrees with the reference to well
+    inside the north star's 1e-4 (measured ~1e-6), i.e. the remaining end-to-end gap is the 45-layer fp32 round-off, not the pose path."""
+    import ctypes
+    from rdpn6d_amd import _lib
+    from rdpn6d_amd.gdrn import _ptr
+
+    models, t, gold = golden_setup
+    model = models[att]
+    plan = model.plan(4, dev)
+    _run(model, t)  # builds every buffer, leaves real maps behind - now overwrite the head output with the reference's
+    maps = np.concatenate([gold["eval_mask"], gold["eval_coor_x"], gold["eval_coor_y"], gold["eval_coor_z"], gold["eval_region"]], 1)  # (4,37,64,64)
+    ho = plan.bufs["head_out"]
+    ho.zero_()
+    ho[:, :, :37] = torch.from_numpy(maps).to(dev).reshape(4, 37, 4096).permute(0, 2, 1)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(plan.lib.rdpn6d_dense_glue_f32(*plan.glue_args(t["roi_coord_2d"].contiguous(), t["fps"].contiguous()), st), "glue")
+    for L in plan.post:
+        _lib.check(L.fn(*L.args, st), L.name)
+    g = {k: t[k].float().contiguous() for k in ("roi_cam", "roi_center", "roi_wh", "resize_ratio")}
+    _lib.check(plan.lib.rdpn6d_pose_decode_f32(_ptr(plan.rt), 16, _ptr(g["roi_cam"]), _ptr(g["roi_center"]), _ptr(g["roi_wh"]),
+                                               _ptr(g["resize_ratio"]), 4, 1, 0, _ptr(plan.rot), _ptr(plan.trans), st), "pose")
+    torch.cuda.synchronize()
+    assert np.array_equal(plan.argmax.cpu().numpy().reshape(4, 64, 64), gold["eval_region_argmax"])  # same maps -> same anchors
+    R, T = gold[f"eval_{att}_rot"].astype(np.float64), gold[f"eval_{att}_trans"].astype(np.float64)
+    r, tr = plan.rot.cpu().numpy().astype(np.float64), plan.trans.cpu().numpy().astype(np.float64)
+    wr = max(_rel(r[i], R[i]) for i in range(4))
+    wt = max(_rel(tr[i], T[i]) for i in range(4))
+    print(f"[{att}] teacher-forced pose rel err (worst sample): R {wr:.2e} t {wt:.2e}")
+    assert wr < 1e-4 and wt < 1e-4
+    assert np.abs(plan.rt[:, :6].cpu().numpy() - gold[f"eval_{att}_pred_rot6d"]).max() < 1e-4
