@@ -32,15 +32,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (same guide; never the 2:1-sparsity figure)
 
 
-def build_model(device, mask_attention="none"):
+def build_model(device, mask_attention="none", bf16=False):
     from rdpn6d_amd import synth
     from rdpn6d_amd.config import gdrn_base_cfg
     from rdpn6d_amd.gdrn import build_model_optimizer
 
     cfg = gdrn_base_cfg(mask_attention=mask_attention, device=str(device))
     cfg.TEST.USE_PNP = True  # the step includes the per-crop RANSAC/Kabsch solve ("fwd+PnP")
+    cfg.TEST.AMP_TEST = bool(bf16)  # secondary mode: trunk + fusion + head on the bf16 matrix pipe
     model, _ = build_model_optimizer(cfg)
     sd = synth.make_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=1234)
     bn = np.load(os.path.join(ROOT, "tests", "golden", "bn_stats_c1.npz"))
@@ -68,12 +70,13 @@ def roofline(model, t, B, device, reps=3):
     lib = plan.lib
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     sel = []
-    for L in plan.launches + plan.post:
-        if L.keep:
+    lowp_fn = lib.rdpn6d_conv2d_bf16
+    for L in plan.launches:
+        if L.keep and (L.fn is lowp_fn) == plan.bf16:
             d = L.keep[0]
             bm, bn = ctypes.c_int(), ctypes.c_int()
-            lib.rdpn6d_conv_tile_for(ctypes.byref(d), ctypes.byref(bm), ctypes.byref(bn))
-            if (bm.value, bn.value) == (128, 128):
+            lib.rdpn6d_conv_tile_for(ctypes.byref(d), ctypes.byref(bm), ctypes.byref(bn))  # same heuristic in both kernels
+            if (bm.value, bn.value) == (128, 128) and (not plan.bf16 or d.Cin % 64 == 0):
                 sel.append(L)
     flops = sum(conv_flops(L.keep[0]) for L in sel)
     total_ms, n = 0.0, 0
@@ -81,8 +84,8 @@ def roofline(model, t, B, device, reps=3):
     for _ in range(reps):
         # replay the plan with events around the selected launches (same stream the kernels run on)
         x = t["roi_img"]
-        _lib.check(lib.rdpn6d_stem_conv7x7_f32(ctypes.c_void_p(x.data_ptr()), plan.stem_args[0], x.shape[1], *plan.stem_args[2:], st))
-        _lib.check(lib.rdpn6d_xyz_subsample_f32(ctypes.c_void_p(x.data_ptr()), plan.xyz_args[0], x.shape[1], *plan.xyz_args[2:], st))
+        _lib.check(plan.stem_fn(ctypes.c_void_p(x.data_ptr()), plan.stem_args[0], x.shape[1], *plan.stem_args[2:], st))
+        _lib.check(plan.xyz_fn(ctypes.c_void_p(x.data_ptr()), plan.xyz_args[0], x.shape[1], *plan.xyz_args[2:], st))
         evs = []
         for L in plan.launches:
             if L in sel:
@@ -98,12 +101,14 @@ def roofline(model, t, B, device, reps=3):
         n += len(evs)
     avg_ms = total_ms / max(n, 1)
     achieved = flops / len(sel) / (avg_ms * 1e-3) / 1e12 if sel else 0.0
-    traffic, traffic_src = pmc_traffic("conv_igemm_f32_kernel<128, 128>") if B == 64 else (None, None)
+    kname = "conv_igemm_bf16_kernel<128, 128, 128>" if plan.bf16 else "conv_igemm_f32_kernel<128, 128>"
+    peak = BF16_MFMA_PEAK_TFLOPS if plan.bf16 else FP32_MFMA_PEAK_TFLOPS
+    traffic, traffic_src = pmc_traffic(kname) if B == 64 else (None, None)
     return {
-        "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch (HBM+fabric, PMC)",
+        "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+        "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch (HBM+fabric, PMC)",
         "traffic_source": traffic_src,
-        "kernel": "conv_igemm_f32_kernel<128,128>", "launches_per_step": len(sel),
+        "kernel": kname.replace(", ", ","), "launches_per_step": len(sel),
         "avg_launch_ms": round(avg_ms, 4), "algorithmic_gflop_per_launch": round(flops / max(len(sel), 1) / 1e9, 2),
         "share_of_step_flops": round(flops / (44.10e9 * B), 3),
     }
@@ -115,14 +120,13 @@ def pmc_traffic(kernel):
     Counters cannot be read from inside the timed process, so the figure comes from profiles/ (None if absent)."""
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
-    if not files:
-        return None, None
-    try:
-        e = json.load(open(files[-1]))[kernel]
-        return int((e["fetch_MB_x2"] + e["write_MB"]) * 1e6), os.path.relpath(files[-1], ROOT)
-    except (KeyError, ValueError):
-        return None, None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")), reverse=True):
+        try:
+            e = json.load(open(f))[kernel]
+            return int((e["fetch_MB_x2"] + e["write_MB"]) * 1e6), os.path.relpath(f, ROOT)
+        except (KeyError, ValueError):
+            continue
+    return None, None
 
 
 def cpu_baseline(sd, budget_s=20.0):
@@ -229,6 +233,9 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="crops per GPU per step (BASELINE configs[1]: 64)")
     ap.add_argument("--mask-attention", default="none", choices=["none", "mul"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="f32 (default, the parity-bearing headline) | bf16: secondary line, cfg.TEST.AMP_TEST mode "
+                         "(trunk + fusion + head on the bf16 matrix pipe, fp32 head output / ConvPnPNet / pose / RANSAC)")
     ap.add_argument("--train", action="store_true",
                     help="secondary line: fp32 training step (fwd + losses + bwd + bucketed RCCL all-reduce + Ranger), B=32/GPU")
     args = ap.parse_args()
@@ -251,7 +258,7 @@ def main():
 
     if args.train:
         return train_bench(args, rank, world, device, dist)
-    model, sd = build_model(device, args.mask_attention)
+    model, sd = build_model(device, args.mask_attention, bf16=args.dtype == "bf16")
     B = args.batch
     t = {k: torch.from_numpy(v).to(device) for k, v in synth.make_inputs(B, seed=100 + rank).items()}
 
@@ -289,7 +296,7 @@ def main():
             "metric": "RGB-D crops/sec (fwd+PnP) at 256x256", "value": round(value, 1), "unit": "crops/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "LM 13-object inference, batch=64 per GPU, 256x256 RGB-D crops, K=32 regions, "
                                    "ResNet-34 trunk + dense head + ConvPnPNet + pose decode + per-crop RANSAC/Kabsch (100 hyp.), all on-device",
                        "batch_per_gpu": B, "global_batch": B * world, "mask_attention": args.mask_attention,

@@ -80,6 +80,25 @@ int rdpn6d_conv2d_f32(const rdpn6d_conv_desc* d, void* stream);
  * kernel names / roofline figures to layers; rdpn6d_conv_force_tile(0,0) restores the heuristic */
 int rdpn6d_conv_tile_for(const rdpn6d_conv_desc* d, int* bm, int* bn);
 void rdpn6d_conv_force_tile(int bm, int bn);
+/* K order of the implicit GEMM: 1 (default) = taps innermost inside a 16-channel chunk, 0 = tap-major (A/B switch
+ * kept for profiling; results are identical up to fp32 summation order) */
+void rdpn6d_conv_set_tap_inner(int v);
+
+/* Reduced-precision mode of the same operator (the reference's autocast path: engine.py:279, gdrn_evaluator.py:625):
+ * x, w, res are bf16 (16-bit) arrays, y is bf16 or - when out_f32 != 0 - fp32; scale/shift are fp32; all channel
+ * strides/offsets are in elements.  Cin % 32 == 0, in_cs % 8 == 0, in_co % 8 == 0.  fp32 accumulation on
+ * v_mfma_f32_32x32x16_bf16, one rounding (RNE) on the store. */
+int rdpn6d_conv2d_bf16(const rdpn6d_conv_desc* d, int out_f32, void* stream);
+void rdpn6d_conv_bf16_force_tile(int bm, int bn);
+/* bf16 forms of the kernels between the bf16 convolutions (same argument meaning as the _f32 entry points; activations
+ * bf16 NHWC with C % 8 == 0; the stem and the xyz subsample read the fp32 NCHW crop and write bf16) */
+int rdpn6d_stem_conv7x7_bf16(const float* x, int B, int xc, int R, const float* w, const float* scale,
+                             const float* shift, void* y, void* stream);
+int rdpn6d_maxpool3x3s2_bf16(const void* x, int B, int H, int W, int C, void* y, void* stream);
+int rdpn6d_upsample_bilinear_bf16(const void* x, int B, int H, int W, int C, int factor, void* y, void* stream);
+int rdpn6d_xyz_subsample_bf16(const float* x, int B, int xc, int R, int step, void* y, int out_cs, int out_co,
+                              void* stream);
+int rdpn6d_global_max_concat_bf16(void* buf, int B, int HW, int C, int cs, void* stream);
 
 /* ------------------------------------------------------------------ stem & point-wise kernels
  * conv1 7x7/2 + BN + ReLU on channels 0..2 of the NCHW 6-channel crop (resnet_backbone.py:272,

@@ -255,7 +255,8 @@ class GDRNOracle(nn.Module):
         if train_pose:
             rot = allo_to_ego_torch(trans, rot_allo, eps=1e-4)
         else:
-            ra, tn = rot_allo.detach().numpy(), trans.detach().numpy()
+            up = (lambda v: v.float() if v.dtype == torch.bfloat16 else v)  # numpy has no bf16 (autocast runs)
+            ra, tn = up(rot_allo.detach()).numpy(), up(trans.detach()).numpy()
             rot = torch.from_numpy(np.stack([allo_to_ego_numpy(ra[i], tn[i]) for i in range(ra.shape[0])]))
         return {"rot": rot, "trans": trans, "mask": mask, "coor_x": cx, "coor_y": cy, "coor_z": cz, "region": region,
                 "pred_rot6d": rot6d, "pred_t_": pred_t, "region_argmax": amax}

@@ -1,0 +1,304 @@
+// Implicit-GEMM convolution on the gfx950 bf16 matrix pipe (v_mfma_f32_32x32x16_bf16), fp32 accumulation.
+//
+// Reduced-precision mode of the same operator as conv_igemm.hip (the reference's counterpart is its autocast
+// path: core/gdrn_modeling/engine.py:279 `autocast(enabled=AMP_ON)` / gdrn_evaluator.py:625 `AMP_TEST`).
+//   * activations and packed weights are bf16 in HBM (NHWC, [Npad][ntaps][Cin]); accumulators, the folded
+//     BatchNorm scale/shift and the residual add are fp32; the result is rounded once (RNE) on the store, or
+//     written as fp32 for the layers whose consumers are fp32 kernels (head output, FC layers).
+//   * GEMM view, tiling (2x2 wavefronts of 32x32 accumulators), LDS-DMA staging with hardware bounds checking,
+//     the XOR swizzle and the XCD-aware tile mapping follow conv_igemm.hip.  A K-chunk is RB bytes per row:
+//     RB = 128 (64 channels, four k16 MFMA steps) when Cin % 64 == 0, else RB = 64 (32 channels).
+//   * lane l feeds MFMA step j with the 16-byte slot 2j + (l >= 32): any bijection of the chunk's k-values onto
+//     (step, half, element) is valid as long as A and B use the same one.
+//   * two LDS stages: chunk k is in fragment registers (MFMA), chunk k+1 is being read LDS -> registers from one
+//     stage while chunk k+2 lands by DMA in the other (whose fragments were read one step earlier).
+#include "common.h"
+
+struct ConvBArgs {
+    rdpn6d_conv_desc d;
+    long long M;
+    int HoWo;
+    int cchunks;  // Cin*2 / RB
+    int nk;       // ntaps * cchunks
+    int Ktot;     // ntaps * Cin
+    int mtiles, ntiles;
+    int linear_out;
+    int out_f32;
+    unsigned x_bytes, w_bytes;
+    unsigned long long dy_pack, dx_pack;
+};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef rd_bf16_t bf16_t;
+#define f2bf rd_f2bf
+#define bf2f rd_bf2f
+
+template <int BM, int BN, int RB>
+__global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const ConvBArgs a)
+{
+    constexpr int SL = RB / 16;      // 16-byte slots per LDS row
+    constexpr int RPP = 1024 / RB;   // rows per 1-KiB DMA piece
+    constexpr int RPB = 256 / RB;    // rows per 256-byte bank period
+    constexpr int NJ = RB / 32;      // k16 MFMA steps per chunk
+    constexpr int NST = 2;
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int AG = BM / RPP / 4, BG = BN / RPP / 4;  // DMA pieces per wave
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * (BM + BN) * RB];
+    unsigned char* As = smem;
+    unsigned char* Bs = smem + NST * BM * RB;
+
+    const rdpn6d_conv_desc& d = a.d;
+    const int nblk = a.mtiles * a.ntiles;
+    const int bid = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, kk = bid >> 3;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + kk;
+    const int nt = logical % a.ntiles;
+    const int mt = logical / a.ntiles;
+    const long long m0 = (long long)mt * BM;
+    const int n0 = nt * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int prow = lane / SL;   // row inside the DMA piece
+    const int pslot = lane % SL;  // physical slot written by this lane
+    int a_iy[AG], a_ix[AG];
+    unsigned a_off[AG];
+    bool a_ok[AG];
+#pragma unroll
+    for (int i = 0; i < AG; ++i) {
+        const int row = (wave + 4 * i) * RPP + prow;
+        const long long m = m0 + row;
+        a_ok[i] = m < a.M;
+        const int mm = a_ok[i] ? (int)m : 0;
+        const int b = mm / a.HoWo;
+        const int rem = mm - b * a.HoWo;
+        const int oy = rem / d.Wo;
+        const int ox = rem - oy * d.Wo;
+        a_iy[i] = oy * d.stride;
+        a_ix[i] = ox * d.stride;
+        const int lslot = pslot ^ ((row / RPB) & (SL - 1));
+        a_off[i] = ((unsigned)(b * d.H * d.W) * (unsigned)d.in_cs + (unsigned)d.in_co) * 2u + (unsigned)lslot * 16u;
+    }
+    unsigned w_off[BG];
+#pragma unroll
+    for (int i = 0; i < BG; ++i) {
+        const int row = (wave + 4 * i) * RPP + prow;
+        const int lslot = pslot ^ ((row / RPB) & (SL - 1));
+        w_off[i] = (unsigned)(n0 + row) * (unsigned)a.Ktot * 2u + (unsigned)lslot * 16u;
+    }
+    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.w), 0, a.w_bytes, 0x00020000);
+    const unsigned oob = a.x_bytes;
+    const unsigned px_bytes = (unsigned)d.in_cs * 2u;
+
+    auto stage_chunk = [&](const int tap, const int cc, const int st) {
+        const int dy = (int)((a.dy_pack >> (4 * tap)) & 15ull) - 8, dx = (int)((a.dx_pack >> (4 * tap)) & 15ull) - 8;
+        const unsigned c0b = (unsigned)cc * (unsigned)RB;
+#pragma unroll
+        for (int i = 0; i < AG; ++i) {
+            const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
+            const bool ok = a_ok[i] && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
+            const unsigned off = ok ? a_off[i] + (unsigned)(iy * d.W + ix) * px_bytes + c0b : oob;
+            unsigned char* dst = As + (st * BM + (wave + 4 * i) * RPP) * RB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_ptr_t)dst, 16, (int)off, 0, 0, 0);
+        }
+        const unsigned wk = (unsigned)tap * (unsigned)d.Cin * 2u + c0b;
+#pragma unroll
+        for (int i = 0; i < BG; ++i) {
+            unsigned char* dst = Bs + (st * BN + (wave + 4 * i) * RPP) * RB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrc, (lds_ptr_t)dst, 16, (int)(w_off[i] + wk), 0, 0, 0);
+        }
+    };
+    // K order: channel-chunk major, taps innermost (see conv_igemm.hip)
+    int ld_tap = 0, ld_cc = 0, ld_left = a.nk - 1;
+    auto next_chunk = [](int& tap, int& cc, int& left, const int ntaps) {
+        const int go = left > 0 ? 1 : 0;
+        left -= go;
+        tap += go;
+        const int wrap = tap == ntaps ? 1 : 0;
+        tap = wrap ? 0 : tap;
+        cc += wrap;
+    };
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int frow = lane & 31;
+    const int half = lane >> 5;
+
+    auto read_frags = [&](int st, u32x4 (&fa)[TM][NJ], u32x4 (&fb)[TN][NJ]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int R = wm * (BM / 2) + i * 32 + frow;
+            const int sw = (R / RPB) & (SL - 1);
+            const unsigned char* p = As + (st * BM + R) * RB;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) fa[i][j] = *reinterpret_cast<const u32x4*>(p + (((2 * j + half) ^ sw) << 4));
+        }
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) {
+            const int R = wn * (BN / 2) + jn * 32 + frow;
+            const int sw = (R / RPB) & (SL - 1);
+            const unsigned char* p = Bs + (st * BN + R) * RB;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) fb[jn][j] = *reinterpret_cast<const u32x4*>(p + (((2 * j + half) ^ sw) << 4));
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    auto mma = [&](const u32x4 (&fa)[TM][NJ], const u32x4 (&fb)[TN][NJ]) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn)
+                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i][j]),
+                                                                         __builtin_bit_cast(bf16x8, fb[jn][j]),
+                                                                         acc[i][jn], 0, 0, 0);
+    };
+
+    const int nk = a.nk;
+    stage_chunk(ld_tap, ld_cc, 0);
+    next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
+    stage_chunk(ld_tap, ld_cc, 1);
+    next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
+    __syncthreads();
+    u32x4 fa0[TM][NJ], fb0[TN][NJ], fa1[TM][NJ], fb1[TN][NJ];
+    read_frags(0, fa0, fb0);
+    __syncthreads();  // stage 0 is re-filled by the first loop step: every wave must have its fragments first
+
+    const int npairs = nk >> 1;
+    for (int pr = 0; pr < npairs; ++pr) {
+        stage_chunk(ld_tap, ld_cc, 0);
+        next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
+        read_frags(1, fa1, fb1);
+        mma(fa0, fb0);
+        __syncthreads();
+
+        stage_chunk(ld_tap, ld_cc, 1);
+        next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
+        read_frags(0, fa0, fb0);
+        mma(fa1, fb1);
+        __syncthreads();
+    }
+    if (nk & 1) mma(fa0, fb0);
+
+    // ---- fused epilogue (fp32 math, one rounding on the store)
+    const int hi = lane >> 5;
+    const bf16_t* resb = reinterpret_cast<const bf16_t*>(d.res);
+    bf16_t* yb = reinterpret_cast<bf16_t*>(d.y);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 32 + frow;
+        const float sc = d.scale ? d.scale[n] : 1.f;
+        const float sh = d.shift ? d.shift[n] : 0.f;
+        const bool n_ok = n < d.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const long long m = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                if (m < a.M && n_ok) {
+                    long long pix;
+                    if (a.linear_out) {
+                        pix = m;
+                    } else {
+                        const int mm = (int)m;
+                        const int b = mm / a.HoWo;
+                        const int rem = mm - b * a.HoWo;
+                        const int oy = rem / d.Wo;
+                        const int ox = rem - oy * d.Wo;
+                        pix = ((long long)b * d.OH + (oy * d.osy + d.ooy)) * d.OW + (ox * d.osx + d.oox);
+                    }
+                    float v = acc[i][j][e] * sc + sh;
+                    if (resb) v += bf2f(resb[pix * d.res_cs + d.res_co + n]);
+                    if (d.act == 1) v = v > 0.f ? v : 0.f;
+                    else if (d.act == 2) v = v > 0.f ? v : v * d.slope;
+                    if (a.out_f32) d.y[pix * d.out_cs + d.out_co + n] = v;
+                    else yb[pix * d.out_cs + d.out_co + n] = f2bf(v);
+                }
+            }
+        }
+    }
+}
+
+static int g_bforce_bm = 0, g_bforce_bn = 0;
+extern "C" void rdpn6d_conv_bf16_force_tile(int bm, int bn) { g_bforce_bm = bm; g_bforce_bn = bn; }
+
+static void conv_bf16_pick_tile(const rdpn6d_conv_desc* d, long long M, int* pbm, int* pbn)
+{
+    int bn = (d->Npad % 128 == 0) ? 128 : 64;
+    int bm = 128;
+    if ((long long)rd_cdiv(M, 128) * (d->Npad / bn) < 512) bm = 64;
+    if (bm == 64 && bn == 128 && (long long)rd_cdiv(M, 64) * (d->Npad / 128) < 512) bn = 64;
+    if (g_bforce_bm) bm = g_bforce_bm;
+    if (g_bforce_bn && d->Npad % g_bforce_bn == 0) bn = g_bforce_bn;
+    *pbm = bm;
+    *pbn = bn;
+}
+
+template <int RB>
+static void conv_bf16_launch(const ConvBArgs& a, int bm, int bn, hipStream_t s)
+{
+    dim3 grid((unsigned)(a.mtiles * a.ntiles)), block(256);
+    if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_igemm_bf16_kernel<128, 128, RB>), grid, block, 0, s, a);
+    else if (bm == 128 && bn == 64) hipLaunchKernelGGL((conv_igemm_bf16_kernel<128, 64, RB>), grid, block, 0, s, a);
+    else if (bm == 64 && bn == 128) hipLaunchKernelGGL((conv_igemm_bf16_kernel<64, 128, RB>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((conv_igemm_bf16_kernel<64, 64, RB>), grid, block, 0, s, a);
+}
+
+extern "C" int rdpn6d_conv2d_bf16(const rdpn6d_conv_desc* d, int out_f32, void* stream)
+{
+    RD_REQUIRE(d && d->x && d->w && d->y, "null pointer");
+    RD_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0, "empty tensor");
+    RD_REQUIRE(d->Cin > 0 && d->Cin % 32 == 0, "Cin must be a positive multiple of 32");
+    RD_REQUIRE(d->in_cs % 8 == 0 && d->in_co % 8 == 0 && d->in_co + d->Cin <= d->in_cs, "input channel slice");
+    RD_REQUIRE(d->ntaps >= 1 && d->ntaps <= 9, "ntaps in 1..9");
+    RD_REQUIRE(d->N > 0 && d->Npad >= d->N && d->Npad % 64 == 0, "Npad must be a multiple of 64 >= N");
+    RD_REQUIRE(d->out_co + d->N <= d->out_cs, "output channel slice");
+    RD_REQUIRE(d->stride >= 1 && d->osy >= 1 && d->osx >= 1, "strides");
+    RD_REQUIRE((d->Ho - 1) * d->osy + d->ooy < d->OH && (d->Wo - 1) * d->osx + d->oox < d->OW, "output geometry");
+    RD_REQUIRE(!d->res || d->res_co + d->N <= d->res_cs, "residual channel slice");
+    ConvBArgs a;
+    a.d = *d;
+    a.M = (long long)d->B * d->Ho * d->Wo;
+    RD_REQUIRE(a.M < (1LL << 31), "B*Ho*Wo must fit 31 bits");
+    a.HoWo = d->Ho * d->Wo;
+    const int rb = d->Cin % 64 == 0 ? 128 : 64;
+    a.cchunks = d->Cin * 2 / rb;
+    a.nk = d->ntaps * a.cchunks;
+    a.Ktot = d->ntaps * d->Cin;
+    a.linear_out = (d->osy == 1 && d->osx == 1 && d->ooy == 0 && d->oox == 0 && d->OH == d->Ho && d->OW == d->Wo);
+    a.out_f32 = out_f32 ? 1 : 0;
+    const long long xb = (long long)d->B * d->H * d->W * d->in_cs * 2;
+    RD_REQUIRE(xb < (1LL << 32) - 64, "input tensor must be smaller than 4 GiB (32-bit buffer offsets)");
+    a.x_bytes = (unsigned)xb;
+    const long long wb = (long long)d->Npad * d->ntaps * d->Cin * 2;
+    RD_REQUIRE(wb < (1LL << 32) - 64, "packed weights must be smaller than 4 GiB");
+    a.w_bytes = (unsigned)wb;
+    a.dy_pack = a.dx_pack = 0;
+    for (int t = 0; t < d->ntaps; ++t) {
+        RD_REQUIRE(d->dy[t] >= -8 && d->dy[t] <= 7 && d->dx[t] >= -8 && d->dx[t] <= 7, "tap offsets must be in -8..7");
+        a.dy_pack |= (unsigned long long)(d->dy[t] + 8) << (4 * t);
+        a.dx_pack |= (unsigned long long)(d->dx[t] + 8) << (4 * t);
+    }
+    int bm, bn;
+    conv_bf16_pick_tile(d, a.M, &bm, &bn);
+    a.mtiles = rd_cdiv(a.M, bm);
+    a.ntiles = d->Npad / bn;
+    hipStream_t s = (hipStream_t)stream;
+    if (rb == 128) conv_bf16_launch<128>(a, bm, bn, s);
+    else conv_bf16_launch<64>(a, bm, bn, s);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}

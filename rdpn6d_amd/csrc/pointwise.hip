@@ -9,10 +9,12 @@
 // is 0.7 % of the FLOPs: a direct LDS-tiled VALU kernel.  Workgroup = 16x16 output pixels; the
 // 37x37x3 input patch and the 147x64 weights sit in LDS; each thread owns one pixel x 64 channels
 // (weights are wave-uniform LDS broadcasts, 16 B per read).
+// OUT_BF16: the 64 output channels are rounded (RNE) to bf16 - the input of the bf16 trunk (conv_igemm_bf16.hip).
+template <bool OUT_BF16>
 __global__ __launch_bounds__(256) void stem_conv7x7_kernel(const float* __restrict__ x, int xc, int R,
                                                            const float* __restrict__ w,
                                                            const float* __restrict__ scale,
-                                                           const float* __restrict__ shift, float* __restrict__ y, int relu)
+                                                           const float* __restrict__ shift, void* __restrict__ yv, int relu)
 {
     constexpr int T = 16, P = 2 * T + 5;  // 37
     __shared__ float s_in[3][P][P + 1];
@@ -56,7 +58,7 @@ __global__ __launch_bounds__(256) void stem_conv7x7_kernel(const float* __restri
                 }
             }
     if (oy < Ro && ox < Ro) {
-        f32x4* yp = reinterpret_cast<f32x4*>(y + (((long long)b * Ro + oy) * Ro + ox) * 64);
+        const long long pix = ((long long)b * Ro + oy) * Ro + ox;
 #pragma unroll
         for (int n4 = 0; n4 < 16; ++n4) {
             f32x4 o;
@@ -66,21 +68,36 @@ __global__ __launch_bounds__(256) void stem_conv7x7_kernel(const float* __restri
                 const float v = scale ? acc[n] * scale[n] + shift[n] : acc[n];
                 o[e] = (v > 0.f || !relu) ? v : 0.f;
             }
-            yp[n4] = o;
+            if constexpr (OUT_BF16) {
+                uint2 pk;
+                pk.x = (unsigned)rd_f2bf(o[0]) | ((unsigned)rd_f2bf(o[1]) << 16);
+                pk.y = (unsigned)rd_f2bf(o[2]) | ((unsigned)rd_f2bf(o[3]) << 16);
+                reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(yv) + pix * 64)[n4] = pk;
+            } else {
+                reinterpret_cast<f32x4*>(reinterpret_cast<float*>(yv) + pix * 64)[n4] = o;
+            }
         }
     }
 }
 
 static int stem_launch(const float* x, int B, int xc, int R, const float* w, const float* scale, const float* shift,
-                       float* y, int relu, void* stream)
+                       void* y, int relu, void* stream, bool out_bf16 = false)
 {
     RD_REQUIRE(x && w && y && (!scale == !shift), "null pointer");
     RD_REQUIRE(B > 0 && xc >= 3 && R > 0 && R % 2 == 0, "shape");
     const int Ro = R / 2;
     dim3 grid(rd_cdiv(Ro, 16), rd_cdiv(Ro, 16), B);
-    hipLaunchKernelGGL(stem_conv7x7_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, xc, R, w, scale, shift, y, relu);
+    if (out_bf16) hipLaunchKernelGGL(stem_conv7x7_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, xc, R, w, scale, shift, y, relu);
+    else hipLaunchKernelGGL(stem_conv7x7_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, xc, R, w, scale, shift, y, relu);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
+}
+
+extern "C" int rdpn6d_stem_conv7x7_bf16(const float* x, int B, int xc, int R, const float* w, const float* scale,
+                                        const float* shift, void* y, void* stream)
+{
+    RD_REQUIRE(scale && shift, "null pointer");
+    return stem_launch(x, B, xc, R, w, scale, shift, y, 1, stream, true);
 }
 
 extern "C" int rdpn6d_stem_conv7x7_f32(const float* x, int B, int xc, int R, const float* w, const float* scale,

@@ -193,9 +193,12 @@ class _Launch:
 class InferencePlan:
     """Packed weights, NHWC activation buffers and the launch list for one (batch, device)."""
 
-    def __init__(self, model, B, device):
+    def __init__(self, model, B, device, bf16=False):
+        """bf16=True: the trunk, the point-wise fusion and the dense head (99 % of the FLOPs) run on the bf16 matrix
+        pipe with bf16 activations (the reference's autocast mode, gdrn_evaluator.py:625); the head output, the
+        glue, ConvPnPNet, the pose decode and RANSAC stay fp32."""
         self.lib = _lib.load()
-        self.B, self.device = B, device
+        self.B, self.device, self.bf16 = B, device, bool(bf16)
         self.launches = []
         self.bufs = {}
         self.keep = []  # packed weights etc. kept alive
@@ -216,7 +219,8 @@ class InferencePlan:
 
     # ---- launch builders
     def conv(self, name, x, xshape, w, scale, shift, y, yshape, *, cin, in_cs, in_co=0, k=1, stride=1, pad=0, N,
-             out_cs, out_co=0, res=None, res_cs=0, res_co=0, act=0, slope=0.0, taps=None, phase=None):
+             out_cs, out_co=0, res=None, res_cs=0, res_co=0, act=0, slope=0.0, taps=None, phase=None, lowp=False,
+             out_f32=False):
         """xshape = (H, W) of the input, yshape = (OH, OW) of the full output."""
         d = _lib.ConvDesc()
         d.x, d.w, d.scale, d.shift, d.res, d.y = _ptr(x), _ptr(w), _ptr(scale), _ptr(shift), _ptr(res), _ptr(y)
@@ -238,7 +242,12 @@ class InferencePlan:
         d.act, d.slope = act, slope
         assert w.shape[1] == d.ntaps and w.shape[2] == cin, (name, tuple(w.shape), d.ntaps, cin)
         self.keep += [w, scale, shift]
-        self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_f32, (ctypes.byref(d),), keep=(d,)))
+        if lowp:
+            assert w.dtype == torch.bfloat16, name
+            self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_bf16, (ctypes.byref(d), 1 if out_f32 else 0), keep=(d,)))
+        else:
+            assert w.dtype == torch.float32, name
+            self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_f32, (ctypes.byref(d),), keep=(d,)))
 
     def call(self, name, fn, *args):
         self.launches.append(_Launch(name, fn, args))
@@ -248,17 +257,27 @@ class InferencePlan:
         B, R, K, lib = self.B, self.R, self.K, self.lib
         bb, head, pnp = model.backbone, model.rot_head_net, model.pnp_net
         f32 = dict(dtype=torch.float32, device=self.device)
+        lp = self.bf16
+        adt = torch.bfloat16 if lp else torch.float32  # activation dtype up to the head output
+        sfx = "bf16" if lp else "f32"
+
+        def pw(w, **kw):
+            t = pack_conv_weight(w, **kw)
+            return t.to(torch.bfloat16) if lp else t
+
         self.x_in = None  # bound per call
         R2, R4, R8, R16, R32 = R // 2, R // 4, R // 8, R // 16, R // 32
 
         # --- stem + maxpool
         w = bb.conv1.weight.detach().float().permute(0, 2, 3, 1).contiguous()  # [64][7][7][3]
         sc, sh = fold_bn(bb.bn1)
-        s0 = self.buf("stem", B, R2, R2, 64)
+        s0 = self.buf("stem", B, R2, R2, 64, dtype=adt)
         self.keep += [w, sc, sh]
+        self.stem_fn = getattr(lib, f"rdpn6d_stem_conv7x7_{sfx}")
+        self.xyz_fn = getattr(lib, f"rdpn6d_xyz_subsample_{sfx}")
         self.stem_args = (B, 6, R, _ptr(w), _ptr(sc), _ptr(sh), _ptr(s0))
-        p0 = self.buf("pool", B, R4, R4, 64)
-        self.call("maxpool", lib.rdpn6d_maxpool3x3s2_f32, _ptr(s0), B, R2, R2, 64, _ptr(p0))
+        p0 = self.buf("pool", B, R4, R4, 64, dtype=adt)
+        self.call("maxpool", getattr(lib, f"rdpn6d_maxpool3x3s2_{sfx}"), _ptr(s0), B, R2, R2, 64, _ptr(p0))
 
         # --- residual trunk
         cur, cur_hw, cur_c = p0, R4, 64
@@ -268,56 +287,60 @@ class InferencePlan:
                 cout = blk.conv1.weight.shape[0]
                 s = blk.conv1.stride
                 ohw = cur_hw // s
-                t = self.buf(f"l{li}_t{bi % 2}", B, ohw, ohw, cout)
-                o = self.buf(f"l{li}_o{bi % 2}", B, ohw, ohw, cout)
-                w1 = pack_conv_weight(blk.conv1.weight.detach().float())
+                t = self.buf(f"l{li}_t{bi % 2}", B, ohw, ohw, cout, dtype=adt)
+                o = self.buf(f"l{li}_o{bi % 2}", B, ohw, ohw, cout, dtype=adt)
+                w1 = pw(blk.conv1.weight.detach().float())
                 sc1, sh1 = fold_bn(blk.bn1, npad=w1.shape[0])
                 self.conv(f"layer{li + 1}.{bi}.conv1", cur, (cur_hw, cur_hw), w1, sc1, sh1, t, (ohw, ohw), cin=cur_c,
-                          in_cs=cur_c, k=3, stride=s, pad=1, N=cout, out_cs=cout, act=1)
+                          in_cs=cur_c, k=3, stride=s, pad=1, N=cout, out_cs=cout, act=1, lowp=lp)
                 res = cur
                 if blk.downsample is not None:
-                    dsb = self.buf(f"l{li}_ds", B, ohw, ohw, cout)
-                    wd = pack_conv_weight(blk.downsample[0].weight.detach().float())
+                    dsb = self.buf(f"l{li}_ds", B, ohw, ohw, cout, dtype=adt)
+                    wd = pw(blk.downsample[0].weight.detach().float())
                     scd, shd = fold_bn(blk.downsample[1], npad=wd.shape[0])
                     self.conv(f"layer{li + 1}.{bi}.downsample", cur, (cur_hw, cur_hw), wd, scd, shd, dsb, (ohw, ohw),
-                              cin=cur_c, in_cs=cur_c, k=1, stride=s, pad=0, N=cout, out_cs=cout, act=0)
+                              cin=cur_c, in_cs=cur_c, k=1, stride=s, pad=0, N=cout, out_cs=cout, act=0, lowp=lp)
                     res = dsb
-                w2 = pack_conv_weight(blk.conv2.weight.detach().float())
+                w2 = pw(blk.conv2.weight.detach().float())
                 sc2, sh2 = fold_bn(blk.bn2, npad=w2.shape[0])
                 self.conv(f"layer{li + 1}.{bi}.conv2", t, (ohw, ohw), w2, sc2, sh2, o, (ohw, ohw), cin=cout, in_cs=cout,
-                          k=3, stride=1, pad=1, N=cout, out_cs=cout, res=res, res_cs=cout, act=1)
+                          k=3, stride=1, pad=1, N=cout, out_cs=cout, res=res, res_cs=cout, act=1, lowp=lp)
                 cur, cur_hw, cur_c = o, ohw, cout
 
         # --- x4 bilinear up-sampling + point-wise fusion with the depth xyz
-        up = self.buf("up", B, R8, R8, 512)
-        self.call("upsample", lib.rdpn6d_upsample_bilinear_f32, _ptr(cur), B, cur_hw, cur_hw, 512, R8 // cur_hw, _ptr(up))
+        up = self.buf("up", B, R8, R8, 512, dtype=adt)
+        self.call("upsample", getattr(lib, f"rdpn6d_upsample_bilinear_{sfx}"), _ptr(cur), B, cur_hw, cur_hw, 512,
+                  R8 // cur_hw, _ptr(up))
         sn = bb.spatial_net
-        pin = self.buf("pn_in", B, R8, R8, 80, zero=True)  # [emb(64) | xyz(3) | 0-pad(13)]
-        self.xyz_args = (B, 6, R, 8, _ptr(pin), 80, 64)
-        we = pack_conv_weight(sn.xyz_emb.weight.detach().float())
+        pcs = 96 if lp else 80  # [emb(64) | xyz(3) | 0-pad] to the K-chunk granularity of the conv kernel
+        pin = self.buf("pn_in", B, R8, R8, pcs, zero=True, dtype=adt)
+        self.xyz_args = (B, 6, R, 8, _ptr(pin), pcs, 64)
+        we = pw(sn.xyz_emb.weight.detach().float())
         sce, she = fold_bn(sn.xb, sn.xyz_emb.bias, npad=we.shape[0])
-        self.conv("spatial_net.xyz_emb", up, (R8, R8), we, sce, she, pin, (R8, R8), cin=512, in_cs=512, N=64, out_cs=80,
-                  act=1)
+        self.conv("spatial_net.xyz_emb", up, (R8, R8), we, sce, she, pin, (R8, R8), cin=512, in_cs=512, N=64, out_cs=pcs,
+                  act=1, lowp=lp)
         perm = list(range(3, 67)) + [0, 1, 2]  # reference order [xyz | emb] -> buffer order [emb | xyz]
-        wc1 = pack_conv_weight(sn.conv1.weight.detach().float(), cin_pad=80, perm=perm)
+        wc1 = pw(sn.conv1.weight.detach().float(), cin_pad=pcs, perm=perm)
         s1, h1 = fold_bn(sn.b1, sn.conv1.bias, npad=wc1.shape[0])
-        l1 = self.buf("pn_l1", B, R8, R8, 128)
-        self.conv("spatial_net.conv1", pin, (R8, R8), wc1, s1, h1, l1, (R8, R8), cin=80, in_cs=80, N=128, out_cs=128, act=1)
-        wc2 = pack_conv_weight(sn.conv2.weight.detach().float())
+        l1 = self.buf("pn_l1", B, R8, R8, 128, dtype=adt)
+        self.conv("spatial_net.conv1", pin, (R8, R8), wc1, s1, h1, l1, (R8, R8), cin=pcs, in_cs=pcs, N=128, out_cs=128,
+                  act=1, lowp=lp)
+        wc2 = pw(sn.conv2.weight.detach().float())
         s2, h2 = fold_bn(sn.b2, sn.conv2.bias, npad=wc2.shape[0])
-        l2 = self.buf("pn_l2", B, R8, R8, 256)
-        self.conv("spatial_net.conv2", l1, (R8, R8), wc2, s2, h2, l2, (R8, R8), cin=128, in_cs=128, N=256, out_cs=256, act=1)
-        wc3 = pack_conv_weight(sn.conv3.weight.detach().float())
+        l2 = self.buf("pn_l2", B, R8, R8, 256, dtype=adt)
+        self.conv("spatial_net.conv2", l1, (R8, R8), wc2, s2, h2, l2, (R8, R8), cin=128, in_cs=128, N=256, out_cs=256,
+                  act=1, lowp=lp)
+        wc3 = pw(sn.conv3.weight.detach().float())
         s3, h3 = fold_bn(sn.b3, sn.conv3.bias, npad=wc3.shape[0])
-        feat = self.buf("feat", B, R8, R8, 1024)
+        feat = self.buf("feat", B, R8, R8, 1024, dtype=adt)
         self.conv("spatial_net.conv3", l2, (R8, R8), wc3, s3, h3, feat, (R8, R8), cin=256, in_cs=256, N=512, out_cs=1024,
-                  act=0)
-        self.call("global_max_concat", lib.rdpn6d_global_max_concat_f32, _ptr(feat), B, R8 * R8, 512, 1024)
+                  act=0, lowp=lp)
+        self.call("global_max_concat", getattr(lib, f"rdpn6d_global_max_concat_{sfx}"), _ptr(feat), B, R8 * R8, 512, 1024)
 
         # --- dense head: ConvTranspose(3, s2, p1, op1) as 4 sub-pixel phase convolutions
         F = head.features[0].weight.shape[1]
-        hA = self.buf("head_a", B, R4, R4, F)
-        hB = self.buf("head_b", B, R4, R4, F)
+        hA = self.buf("head_a", B, R4, R4, F, dtype=adt)
+        hB = self.buf("head_b", B, R4, R4, F, dtype=adt)
         wt = head.features[0].weight.detach().float()  # (Cin, Cout, 3, 3)
         sct, sht = fold_bn(head.features[1], npad=_pad_to(F, 64))
         for py in (0, 1):
@@ -331,24 +354,25 @@ class InferencePlan:
                         slabs.append(wt[:, :, ky, kx].t())  # (Cout, Cin)
                 wp = torch.zeros(_pad_to(F, 64), len(taps), 1024, **f32)
                 wp[:F] = torch.stack(slabs, dim=1)
-                self.conv(f"rot_head.convT.phase{py}{px}", feat, (R8, R8), wp.contiguous(), sct, sht, hA, (R4, R4),
-                          cin=1024, in_cs=1024, N=F, out_cs=F, act=1, taps=taps, phase=(R8, R8, 2, 2, py, px))
+                self.conv(f"rot_head.convT.phase{py}{px}", feat, (R8, R8), wp.contiguous().to(adt), sct, sht, hA, (R4, R4),
+                          cin=1024, in_cs=1024, N=F, out_cs=F, act=1, taps=taps, phase=(R8, R8, 2, 2, py, px), lowp=lp)
         a, b = hA, hB
         nfeat = len(head.features)
         for i in range(3, nfeat - 1, 3):
-            wh = pack_conv_weight(head.features[i].weight.detach().float())
+            wh = pw(head.features[i].weight.detach().float())
             sch, shh = fold_bn(head.features[i + 1], npad=wh.shape[0])
             self.conv(f"rot_head.features.{i}", a, (R4, R4), wh, sch, shh, b, (R4, R4), cin=F, in_cs=F, k=3, stride=1,
-                      pad=1, N=F, out_cs=F, act=1)
+                      pad=1, N=F, out_cs=F, act=1, lowp=lp)
             a, b = b, a
         last = head.features[nfeat - 1]
         nout = last.weight.shape[0]
         assert nout == 5 + K
         self.head_cs = _pad_to(nout, 4)
-        wl = pack_conv_weight(last.weight.detach().float())
+        wl = pw(last.weight.detach().float())
         bl = _pad_vec(last.bias.detach().float(), wl.shape[0], 0.0)
-        ho = self.buf("head_out", B, R4 * R4, self.head_cs, zero=True)
-        self.conv("rot_head.out", a, (R4, R4), wl, None, bl, ho, (R4, R4), cin=F, in_cs=F, N=nout, out_cs=self.head_cs)
+        ho = self.buf("head_out", B, R4 * R4, self.head_cs, zero=True)  # fp32 in both modes
+        self.conv("rot_head.out", a, (R4, R4), wl, None, bl, ho, (R4, R4), cin=F, in_cs=F, N=nout, out_cs=self.head_cs,
+                  lowp=lp, out_f32=True)
 
         # --- glue -> NCHW API maps + ConvPnPNet input
         HW = R4 * R4
@@ -416,8 +440,8 @@ class InferencePlan:
         lib = self.lib
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         B = self.B
-        _lib.check(lib.rdpn6d_stem_conv7x7_f32(_ptr(x), self.stem_args[0], x.shape[1], *self.stem_args[2:], st), "stem")
-        _lib.check(lib.rdpn6d_xyz_subsample_f32(_ptr(x), self.xyz_args[0], x.shape[1], *self.xyz_args[2:], st), "xyz")
+        _lib.check(self.stem_fn(_ptr(x), self.stem_args[0], x.shape[1], *self.stem_args[2:], st), "stem")
+        _lib.check(self.xyz_fn(_ptr(x), self.xyz_args[0], x.shape[1], *self.xyz_args[2:], st), "xyz")
         for L in self.launches:
             _lib.check(L.fn(*L.args, st), L.name)
         _lib.check(lib.rdpn6d_dense_glue_f32(*self.glue_args(roi_coord_2d, fps), st), "dense_glue")
@@ -503,10 +527,13 @@ class GDRN(nn.Module):
         self.last_train_pose = (eng.rot, eng.trans)
         return {}, dict(zip(names, outs))
 
-    def plan(self, B, device):
-        key = (B, str(device))
+    def plan(self, B, device, bf16=None):
+        """bf16=None follows cfg.TEST.AMP_TEST (the reference's autocast switch, gdrn_evaluator.py:625)."""
+        if bf16 is None:
+            bf16 = bool(self.cfg.get("TEST", {}).get("AMP_TEST", False))
+        key = (B, str(device), bool(bf16))
         if key not in self._plans:
-            self._plans[key] = InferencePlan(self, B, device)
+            self._plans[key] = InferencePlan(self, B, device, bf16=bf16)
         return self._plans[key]
 
     def forward(self, x, gt_xyz=None, gt_xyz_bin=None, gt_mask_trunc=None, gt_mask_visib=None, gt_mask_obj=None,

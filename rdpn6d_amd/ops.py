@@ -23,20 +23,25 @@ def _need_gpu(*ts):
 
 
 def conv2d_nhwc(x, weight, scale=None, shift=None, stride=1, pad=0, residual=None, act=0, slope=0.0, out=None,
-                out_co=0, in_co=0, cin=None):
+                out_co=0, in_co=0, cin=None, out_f32=False):
     """x NHWC [B,H,W,Cs] fp32 (Cs multiple of 4), weight OIHW (torch layout).  Returns NHWC [B,Ho,Wo,N]
-    (or writes channels [out_co, out_co+N) of ``out``)."""
+    (or writes channels [out_co, out_co+N) of ``out``).  A bfloat16 ``x`` selects the bf16 matrix-pipe kernel
+    (Cs multiple of 8, reduction width padded to 32; output bf16, or fp32 with ``out_f32``)."""
     _need_gpu(x, weight, scale, shift, residual, out)
     lib = _lib.load()
     B, H, W, cs = x.shape
     N, wcin, k, _ = weight.shape
     cin_real = cin or wcin
-    cin_pad = _pad_to(cin_real, 16)
-    assert in_co + cin_pad <= cs, "input slice must cover the 16-padded reduction width"
+    bf = x.dtype == torch.bfloat16
+    cin_pad = _pad_to(cin_real, 32 if bf else 16)
+    assert in_co + cin_pad <= cs, "input slice must cover the padded reduction width"
     wp = pack_conv_weight(weight.float(), cin_pad=cin_pad)
+    if bf:
+        wp = wp.to(torch.bfloat16)
+        assert residual is None or residual.dtype == torch.bfloat16
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     if out is None:
-        out = torch.empty(B, Ho, Wo, N, dtype=torch.float32, device=x.device)
+        out = torch.empty(B, Ho, Wo, N, dtype=torch.bfloat16 if bf and not out_f32 else torch.float32, device=x.device)
     sc = _pad_vec(scale.float(), wp.shape[0], 1.0) if scale is not None else None
     sh = _pad_vec(shift.float(), wp.shape[0], 0.0) if shift is not None else None
     d = _lib.ConvDesc()
@@ -54,7 +59,11 @@ def conv2d_nhwc(x, weight, scale=None, shift=None, stride=1, pad=0, residual=Non
     if residual is not None:
         d.res_cs, d.res_co = residual.shape[-1], 0
     d.act, d.slope = act, slope
-    _lib.check(lib.rdpn6d_conv2d_f32(ctypes.byref(d), _stream()), "conv2d")
+    if bf:
+        assert out.dtype == (torch.float32 if out_f32 else torch.bfloat16)
+        _lib.check(lib.rdpn6d_conv2d_bf16(ctypes.byref(d), 1 if out_f32 else 0, _stream()), "conv2d_bf16")
+    else:
+        _lib.check(lib.rdpn6d_conv2d_f32(ctypes.byref(d), _stream()), "conv2d")
     return out
 
 
