@@ -76,6 +76,12 @@ typedef struct {
     float slope;
 } rdpn6d_conv_desc;
 int rdpn6d_conv2d_f32(const rdpn6d_conv_desc* d, void* stream);
+/* Split-K form for skinny problems (the FC layers of ConvPnPNet, conv_pnp_net.py:101-104,158-162: M = batch rows,
+ * K up to 8192): ksplit K-slices are computed by separate workgroups into `workspace`
+ * (rdpn6d_conv_splitk_ws_floats(d, ksplit) floats) and reduced in a fixed order by a second kernel that applies the
+ * epilogue.  Needs a linear output geometry (osy=osx=1, no phase offsets). */
+long long rdpn6d_conv_splitk_ws_floats(const rdpn6d_conv_desc* d, int ksplit);
+int rdpn6d_conv2d_splitk_f32(const rdpn6d_conv_desc* d, int ksplit, float* workspace, void* stream);
 /* tile configuration (BM x BN) the launcher picks for this descriptor - used to attribute rocprof
  * kernel names / roofline figures to layers; rdpn6d_conv_force_tile(0,0) restores the heuristic */
 int rdpn6d_conv_tile_for(const rdpn6d_conv_desc* d, int* bm, int* bn);

@@ -35,6 +35,8 @@ struct ConvKArgs {
     unsigned x_bytes;  // size of the input tensor in bytes (buffer descriptor bound)
     unsigned w_bytes;  // size of the packed weight tensor in bytes
     unsigned long long dy_pack, dx_pack;  // tap offsets, 4 bits each, biased by +8
+    int kper;        // split-K: chunks per split (blockIdx.y = split); nk when not split
+    float* partial;  // split-K: raw accumulators [split][M][Npad]; nullptr = fused epilogue
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -130,7 +132,16 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_f32_kernel(const ConvKArgs 
     };
     // chunk counter -> (tap, cc), advanced branch-free; clamped at the last chunk so that the loop body can
     // stage unconditionally (the two redundant DMAs past the end re-read the last chunk into a stage nobody reads)
-    int ld_tap = 0, ld_cc = 0, ld_left = a.nk - 1;
+    const int k_begin = (int)blockIdx.y * a.kper;
+    const int nk = min(a.kper, a.nk - k_begin);
+    int ld_tap, ld_cc, ld_left = nk - 1;
+    if (a.tap_inner) {
+        ld_cc = k_begin / d.ntaps;
+        ld_tap = k_begin - ld_cc * d.ntaps;
+    } else {
+        ld_tap = k_begin / a.cchunks;
+        ld_cc = k_begin - ld_tap * a.cchunks;
+    }
     auto next_chunk = [](int& tap, int& cc, int& left, const int ntaps, const int cchunks, const int tap_inner) {
         const int go = left > 0 ? 1 : 0;
         left -= go;
@@ -190,7 +201,6 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_f32_kernel(const ConvKArgs 
     };
 
     // ---- prologue: chunks 0 and 1 into LDS stages 0 and 1, fragments of chunk 0 into registers
-    const int nk = a.nk;
     stage_chunk(ld_tap, ld_cc, 0);
     next_chunk(ld_tap, ld_cc, ld_left, d.ntaps, a.cchunks, a.tap_inner);
     stage_chunk(ld_tap, ld_cc, 1);
@@ -223,8 +233,24 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_f32_kernel(const ConvKArgs 
     }
     if (nk & 1) mma(fa0, fb0);  // odd chunk count: the last chunk's fragments are already in registers
 
-    // ---- fused epilogue
     const int hi = lane >> 5;
+    // ---- split-K: raw partial sums, reduced (with the epilogue) by splitk_epilogue_kernel
+    if (a.partial) {
+        float* part = a.partial + (long long)blockIdx.y * a.M * d.Npad;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / 2) + j * 32 + frow;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const long long m = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                    if (m < a.M) part[m * d.Npad + n] = acc[i][j][e];
+                }
+        }
+        return;
+    }
+    // ---- fused epilogue
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * (BN / 2) + j * 32 + frow;
@@ -259,6 +285,23 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_f32_kernel(const ConvKArgs 
     }
 }
 
+// split-K second pass: sum the partial accumulators over the splits (fixed order: deterministic) and apply the epilogue
+__global__ void splitk_epilogue_kernel(const float* __restrict__ partial, int nsplit, long long M, rdpn6d_conv_desc d)
+{
+    const long long total = M * d.N;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long m = i / d.N;
+        const int n = (int)(i - m * d.N);
+        float v = 0.f;
+        for (int s = 0; s < nsplit; ++s) v += partial[((long long)s * M + m) * d.Npad + n];
+        v = v * (d.scale ? d.scale[n] : 1.f) + (d.shift ? d.shift[n] : 0.f);
+        if (d.res) v += d.res[m * d.res_cs + d.res_co + n];
+        if (d.act == 1) v = v > 0.f ? v : 0.f;
+        else if (d.act == 2) v = v > 0.f ? v : v * d.slope;
+        d.y[m * d.out_cs + d.out_co + n] = v;
+    }
+}
+
 static int g_force_bm = 0, g_force_bn = 0, g_tap_inner = 1;
 extern "C" void rdpn6d_conv_set_tap_inner(int v) { g_tap_inner = v; }
 extern "C" void rdpn6d_conv_force_tile(int bm, int bn) { g_force_bm = bm; g_force_bn = bn; }
@@ -284,7 +327,26 @@ extern "C" int rdpn6d_conv_tile_for(const rdpn6d_conv_desc* d, int* bm, int* bn)
     return RDPN6D_OK;
 }
 
-extern "C" int rdpn6d_conv2d_f32(const rdpn6d_conv_desc* d, void* stream)
+static int conv2d_f32_impl(const rdpn6d_conv_desc* d, int ksplit, float* workspace, void* stream);
+
+extern "C" int rdpn6d_conv2d_f32(const rdpn6d_conv_desc* d, void* stream) { return conv2d_f32_impl(d, 1, nullptr, stream); }
+
+// Split-K form for skinny problems (the FC layers: M = batch rows, K up to 8192): the K range is cut into ksplit
+// slices computed by separate workgroups (grid.y), partial sums land in `workspace` and a second kernel reduces
+// them in a fixed order and applies the epilogue.  Output geometry must be linear (no phase offsets).
+extern "C" long long rdpn6d_conv_splitk_ws_floats(const rdpn6d_conv_desc* d, int ksplit)
+{
+    if (!d || ksplit < 1) return 0;
+    return (long long)ksplit * d->B * d->Ho * d->Wo * d->Npad;
+}
+
+extern "C" int rdpn6d_conv2d_splitk_f32(const rdpn6d_conv_desc* d, int ksplit, float* workspace, void* stream)
+{
+    RD_REQUIRE(ksplit >= 1 && (ksplit == 1 || workspace), "split-K needs a workspace");
+    return conv2d_f32_impl(d, ksplit, workspace, stream);
+}
+
+static int conv2d_f32_impl(const rdpn6d_conv_desc* d, int ksplit, float* workspace, void* stream)
 {
     RD_REQUIRE(d && d->x && d->w && d->y, "null pointer");
     RD_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0, "empty tensor");
@@ -322,12 +384,28 @@ extern "C" int rdpn6d_conv2d_f32(const rdpn6d_conv_desc* d, void* stream)
     conv_pick_tile(d, a.M, &bm, &bn);
     a.mtiles = rd_cdiv(a.M, bm);
     a.ntiles = d->Npad / bn;
-    dim3 grid((unsigned)(a.mtiles * a.ntiles)), block(256);
+    a.kper = a.nk;
+    a.partial = nullptr;
+    int nsplit = 1;
+    if (ksplit > 1) {
+        RD_REQUIRE(a.linear_out, "split-K needs a linear output geometry");
+        a.kper = rd_cdiv(a.nk, ksplit);
+        nsplit = rd_cdiv(a.nk, a.kper);
+        if (nsplit > 1) a.partial = workspace;
+        else a.kper = a.nk;
+    }
+    dim3 grid((unsigned)(a.mtiles * a.ntiles), (unsigned)nsplit), block(256);
     hipStream_t s = (hipStream_t)stream;
     if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_igemm_f32_kernel<128, 128>), grid, block, 0, s, a);
     else if (bm == 128 && bn == 64) hipLaunchKernelGGL((conv_igemm_f32_kernel<128, 64>), grid, block, 0, s, a);
     else if (bm == 64 && bn == 128) hipLaunchKernelGGL((conv_igemm_f32_kernel<64, 128>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((conv_igemm_f32_kernel<64, 64>), grid, block, 0, s, a);
     RD_LAUNCH_CHECK();
+    if (nsplit > 1) {
+        const long long total = a.M * d->N;
+        const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, s, workspace, nsplit, a.M, *d);
+        RD_LAUNCH_CHECK();
+    }
     return RDPN6D_OK;
 }

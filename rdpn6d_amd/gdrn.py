@@ -181,6 +181,13 @@ def _pad_vec(v, npad, fill):
     return out
 
 
+def pick_ksplit(M, npad, nk):
+    """K-slices for a skinny GEMM (FC layers): enough workgroups to fill 256 CUs, at least 8 K-chunks per slice."""
+    blocks = ((M + 63) // 64) * (npad // 64)
+    ks = min(nk // 8, max(1, 512 // blocks))
+    return ks if ks >= 4 else 1
+
+
 class _Launch:
     """One pre-built C-ABI call (function + argument tuple); the stream is appended at run time."""
 
@@ -220,7 +227,7 @@ class InferencePlan:
     # ---- launch builders
     def conv(self, name, x, xshape, w, scale, shift, y, yshape, *, cin, in_cs, in_co=0, k=1, stride=1, pad=0, N,
              out_cs, out_co=0, res=None, res_cs=0, res_co=0, act=0, slope=0.0, taps=None, phase=None, lowp=False,
-             out_f32=False):
+             out_f32=False, ksplit=False):
         """xshape = (H, W) of the input, yshape = (OH, OW) of the full output."""
         d = _lib.ConvDesc()
         d.x, d.w, d.scale, d.shift, d.res, d.y = _ptr(x), _ptr(w), _ptr(scale), _ptr(shift), _ptr(res), _ptr(y)
@@ -242,7 +249,11 @@ class InferencePlan:
         d.act, d.slope = act, slope
         assert w.shape[1] == d.ntaps and w.shape[2] == cin, (name, tuple(w.shape), d.ntaps, cin)
         self.keep += [w, scale, shift]
-        if lowp:
+        ks = pick_ksplit(self.B * d.Ho * d.Wo, d.Npad, d.ntaps * cin // 16) if (ksplit and not lowp) else 1
+        if ks > 1:
+            ws = self.buf("splitk_ws:" + name, int(self.lib.rdpn6d_conv_splitk_ws_floats(ctypes.byref(d), ks)))
+            self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_splitk_f32, (ctypes.byref(d), ks, _ptr(ws)), keep=(d,)))
+        elif lowp:
             assert w.dtype == torch.bfloat16, name
             self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_bf16, (ctypes.byref(d), 1 if out_f32 else 0), keep=(d,)))
         else:
@@ -433,7 +444,7 @@ class InferencePlan:
     def _fc(self, name, x, kin, wp, bias, y, nout, act, out_cs=None):
         b = _pad_vec(bias.detach().float(), wp.shape[0], 0.0)
         self.conv(name, x, (1, 1), wp, None, b, y, (1, 1), cin=kin, in_cs=kin, N=nout, out_cs=out_cs or nout, act=act,
-                  slope=0.1)
+                  slope=0.1, ksplit=True)
 
     # ---- run
     def run(self, x, roi_coord_2d, fps, roi_cams, roi_centers, roi_whs, resize_ratios, is_allo=True, train_pose=False):

@@ -96,11 +96,19 @@ class TrainEngine:
         assert w.shape[1] == d.ntaps and w.shape[2] == cin, (tuple(w.shape), d.ntaps, cin)
         return d
 
-    def _launch_conv(self, name, d, keep):
+    def _launch_conv(self, name, d, keep, ksplit=False):
         lib = self.lib
+        from .gdrn import pick_ksplit
 
-        def run():
-            _lib.check(lib.rdpn6d_conv2d_f32(ctypes.byref(d), self.st()), name)
+        ks = pick_ksplit(d.B * d.Ho * d.Wo, d.Npad, d.ntaps * d.Cin // 16) if ksplit else 1
+        if ks > 1:
+            ws = self.buf("splitk_ws:" + name, int(lib.rdpn6d_conv_splitk_ws_floats(ctypes.byref(d), ks)))
+
+            def run():
+                _lib.check(lib.rdpn6d_conv2d_splitk_f32(ctypes.byref(d), ks, _ptr(ws), self.st()), name)
+        else:
+            def run():
+                _lib.check(lib.rdpn6d_conv2d_f32(ctypes.byref(d), self.st()), name)
 
         run.keep = (d, keep)
         return run
@@ -138,7 +146,7 @@ class TrainEngine:
         taps = _taps(k, pad)
         d = self._conv_desc(x, xhw, in_cs, in_co, cin_pad, wf, y, yhw, out_cs, out_co, cout, taps, stride=stride, shift=bvec,
                             act=act_out or 0, slope=slope)
-        self.fwd.append(self._launch_conv(name, d, (wf, bvec)))
+        self.fwd.append(self._launch_conv(name, d, (wf, bvec), ksplit=True))
         # ---- backward
         dy = self.buf("d:" + name, *y.shape, zero=True)  # gradient w.r.t. the raw conv output (same layout as y)
         M = B * yhw[0] * yhw[1]
@@ -470,7 +478,7 @@ class TrainEngine:
         wf = self._packed((npad, 1, kin), pk)
         bvec = self._packed((npad,), lambda t: t[:nout].copy_(torch.cat([p.detach().float() for p in bs], 0)))
         d = self._conv_desc(x, (1, 1), kin, 0, kin, wf, y, (1, 1), out_cs, 0, nout, [(0, 0)], shift=bvec, act=act, slope=0.1)
-        self.fwd.append(self._launch_conv(name, d, (wf, bvec)))
+        self.fwd.append(self._launch_conv(name, d, (wf, bvec), ksplit=True))
         ca = _pad_to(nout, 4)
         wg_out = self.buf("wg:" + name, ca, 1, kin)
         self._wg_floats = max(self._wg_floats, int(lib.rdpn6d_wgrad_scratch_floats(B, 1, 1, ca, kin, 1)))
@@ -498,7 +506,7 @@ class TrainEngine:
                 self._grad(bp).copy_(bg[o:o + n])
                 o += n
 
-        self.bwd.append([bwd, self._launch_conv("dgrad " + name, dd, wd)])
+        self.bwd.append([bwd, self._launch_conv("dgrad " + name, dd, wd, ksplit=True)])
 
     # ------------------------------------------------------------------ one step
     LOSS_NAMES = ("loss_coor_x", "loss_coor_y", "loss_coor_z", "loss_mask", "loss_region", "loss_region_my", "loss_PM_R",

@@ -623,3 +623,37 @@ def test_bf16_mode_vs_autocast_yardstick(dev):
     for k in ("rot", "trans"):
         e16, eac = _rel(o16[k].cpu().numpy().astype(np.float64), o64[k].numpy()), _rel(oac[k].float().numpy().astype(np.float64), o64[k].numpy())
         print(f"{k}: rel err HIP-bf16 {e16:.3e} | autocast oracle {eac:.3e}")
+
+
+@pytest.mark.parametrize("M,K,N,ks", [(64, 8192, 1024, 32), (32, 1024, 256, 8), (5, 512, 9, 3), (64, 8192, 1024, 1000)])
+def test_conv_splitk_matches_fused(dev, M, K, N, ks):
+    """split-K FC path (partial sums + fixed-order reduce + epilogue) vs the single-pass kernel: same products, different
+    fp32 summation order."""
+    import ctypes
+    from rdpn6d_amd import _lib
+    from rdpn6d_amd.gdrn import _pad_to, _pad_vec, _ptr
+
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g).to(dev)
+    w = torch.zeros(_pad_to(N, 64), 1, K, device=dev)
+    w[:N, 0] = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+    sh = _pad_vec(torch.randn(N, generator=g).to(dev), w.shape[0], 0.0)
+    res = torch.randn(M, N, generator=g).to(dev)
+    outs = []
+    for split in (1, ks):
+        y = torch.full((M, _pad_to(N, 4)), 7.0, device=dev)
+        d = _lib.ConvDesc()
+        d.x, d.w, d.shift, d.res, d.y = _ptr(x), _ptr(w), _ptr(sh), _ptr(res), _ptr(y)
+        d.B, d.H, d.W, d.Cin, d.in_cs, d.Ho, d.Wo, d.stride, d.ntaps = M, 1, 1, K, K, 1, 1, 1, 1
+        d.N, d.Npad, d.OH, d.OW, d.osy, d.osx = N, w.shape[0], 1, 1, 1, 1
+        d.out_cs, d.res_cs, d.act, d.slope = y.shape[1], N, 2, 0.1
+        ws = torch.empty(max(1, int(lib.rdpn6d_conv_splitk_ws_floats(ctypes.byref(d), split))), device=dev)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(lib.rdpn6d_conv2d_splitk_f32(ctypes.byref(d), split, _ptr(ws), st))
+        torch.cuda.synchronize()
+        outs.append(y)
+    ref = F.leaky_relu(x.double() @ w[:N, 0].double().t() + sh[:N].double() + res.double(), 0.1)
+    _close(outs[0][:, :N], ref, 2e-6, "fused")
+    _close(outs[1][:, :N], ref, 2e-6, "split-K")
+    assert (outs[1][:, N:] == 7.0).all()  # padding columns untouched
