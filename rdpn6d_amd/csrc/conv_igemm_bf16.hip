@@ -10,8 +10,14 @@
 //     RB = 128 (64 channels, four k16 MFMA steps) when Cin % 64 == 0, else RB = 64 (32 channels).
 //   * lane l feeds MFMA step j with the 16-byte slot 2j + (l >= 32): any bijection of the chunk's k-values onto
 //     (step, half, element) is valid as long as A and B use the same one.
-//   * two LDS stages: chunk k is in fragment registers (MFMA), chunk k+1 is being read LDS -> registers from one
-//     stage while chunk k+2 lands by DMA in the other (whose fragments were read one step earlier).
+//   * NST = 2 LDS stages (4-wave tiles up to 128x128, two workgroups per CU): chunk k is in fragment registers (MFMA),
+//     chunk k+1 is being read LDS -> registers from one stage while chunk k+2 lands by DMA in the other (whose
+//     fragments were read one step earlier); one __syncthreads per chunk (which drains the DMA queue).
+//   * NST = 3 stages (the 256x128 tile, 8 wavefronts as 4x2, 144 KiB of LDS, one workgroup per CU): the DMA runs TWO
+//     chunks ahead and is never drained inside the loop - each step ends with s_waitcnt vmcnt(<DMAs of one chunk>)
+//     + a raw s_barrier, so the loads of chunk k+3 stay in flight across the barrier that publishes chunk k+2.  The
+//     L2 -> LDS round trip (~1.5 us under load) is what bounds the 2-stage form; the wider tile also moves 25 % fewer
+//     bytes per FLOP.
 #include "common.h"
 
 struct ConvBArgs {
@@ -35,17 +41,19 @@ typedef rd_bf16_t bf16_t;
 #define f2bf rd_f2bf
 #define bf2f rd_bf2f
 
-template <int BM, int BN, int RB>
-__global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const ConvBArgs a)
+template <int BM, int BN, int RB, int WM, int WN, int NST>
+__global__ __launch_bounds__(64 * WM * WN, NST == 2 ? 2 : 1) void conv_igemm_bf16_kernel(const ConvBArgs a)
 {
+    constexpr int NW = WM * WN;      // wavefronts per workgroup
     constexpr int SL = RB / 16;      // 16-byte slots per LDS row
     constexpr int RPP = 1024 / RB;   // rows per 1-KiB DMA piece
     constexpr int RPB = 256 / RB;    // rows per 256-byte bank period
     constexpr int NJ = RB / 32;      // k16 MFMA steps per chunk
-    constexpr int NST = 2;
-    constexpr int TM = BM / 64, TN = BN / 64;
-    constexpr int AG = BM / RPP / 4, BG = BN / RPP / 4;  // DMA pieces per wave
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * (BM + BN) * RB];
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;    // 32x32 accumulator tiles per wave
+    constexpr int AG = BM / RPP / NW, BG = BN / RPP / NW;  // DMA pieces per wave
+    constexpr int NDMA = AG + BG;                          // LDS-DMA instructions per wave per chunk
+    static_assert(TM >= 1 && TN >= 1 && AG >= 1 && BG >= 1, "tile / wave layout");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];  // NST * (BM + BN) * RB bytes
     unsigned char* As = smem;
     unsigned char* Bs = smem + NST * BM * RB;
 
@@ -70,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const ConvBArgs
     bool a_ok[AG];
 #pragma unroll
     for (int i = 0; i < AG; ++i) {
-        const int row = (wave + 4 * i) * RPP + prow;
+        const int row = (wave + NW * i) * RPP + prow;
         const long long m = m0 + row;
         a_ok[i] = m < a.M;
         const int mm = a_ok[i] ? (int)m : 0;
@@ -86,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const ConvBArgs
     unsigned w_off[BG];
 #pragma unroll
     for (int i = 0; i < BG; ++i) {
-        const int row = (wave + 4 * i) * RPP + prow;
+        const int row = (wave + NW * i) * RPP + prow;
         const int lslot = pslot ^ ((row / RPB) & (SL - 1));
         w_off[i] = (unsigned)(n0 + row) * (unsigned)a.Ktot * 2u + (unsigned)lslot * 16u;
     }
@@ -103,13 +111,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const ConvBArgs
             const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
             const bool ok = a_ok[i] && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
             const unsigned off = ok ? a_off[i] + (unsigned)(iy * d.W + ix) * px_bytes + c0b : oob;
-            unsigned char* dst = As + (st * BM + (wave + 4 * i) * RPP) * RB;
+            unsigned char* dst = As + (st * BM + (wave + NW * i) * RPP) * RB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_ptr_t)dst, 16, (int)off, 0, 0, 0);
         }
         const unsigned wk = (unsigned)tap * (unsigned)d.Cin * 2u + c0b;
 #pragma unroll
         for (int i = 0; i < BG; ++i) {
-            unsigned char* dst = Bs + (st * BN + (wave + 4 * i) * RPP) * RB;
+            unsigned char* dst = Bs + (st * BN + (wave + NW * i) * RPP) * RB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrc, (lds_ptr_t)dst, 16, (int)(w_off[i] + wk), 0, 0, 0);
         }
     };
@@ -124,14 +132,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const ConvBArgs
         cc += wrap;
     };
 
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int frow = lane & 31;
     const int half = lane >> 5;
 
     auto read_frags = [&](int st, u32x4 (&fa)[TM][NJ], u32x4 (&fb)[TN][NJ]) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int R = wm * (BM / 2) + i * 32 + frow;
+            const int R = wm * (BM / WM) + i * 32 + frow;
             const int sw = (R / RPB) & (SL - 1);
             const unsigned char* p = As + (st * BM + R) * RB;
 #pragma unroll
@@ -139,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const ConvBArgs
         }
 #pragma unroll
         for (int jn = 0; jn < TN; ++jn) {
-            const int R = wn * (BN / 2) + jn * 32 + frow;
+            const int R = wn * (BN / WN) + jn * 32 + frow;
             const int sw = (R / RPB) & (SL - 1);
             const unsigned char* p = Bs + (st * BN + R) * RB;
 #pragma unroll
@@ -168,30 +176,75 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const ConvBArgs
     };
 
     const int nk = a.nk;
-    stage_chunk(ld_tap, ld_cc, 0);
-    next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
-    stage_chunk(ld_tap, ld_cc, 1);
-    next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
-    __syncthreads();
     u32x4 fa0[TM][NJ], fb0[TN][NJ], fa1[TM][NJ], fb1[TN][NJ];
-    read_frags(0, fa0, fb0);
-    __syncthreads();  // stage 0 is re-filled by the first loop step: every wave must have its fragments first
-
-    const int npairs = nk >> 1;
-    for (int pr = 0; pr < npairs; ++pr) {
+    if constexpr (NST == 2) {
         stage_chunk(ld_tap, ld_cc, 0);
         next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
-        read_frags(1, fa1, fb1);
-        mma(fa0, fb0);
-        __syncthreads();
-
         stage_chunk(ld_tap, ld_cc, 1);
         next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
-        read_frags(0, fa0, fb0);
-        mma(fa1, fb1);
         __syncthreads();
+        read_frags(0, fa0, fb0);
+        __syncthreads();  // stage 0 is re-filled by the first loop step: every wave must have its fragments first
+
+        const int npairs = nk >> 1;
+        for (int pr = 0; pr < npairs; ++pr) {
+            stage_chunk(ld_tap, ld_cc, 0);
+            next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
+            read_frags(1, fa1, fb1);
+            mma(fa0, fb0);
+            __syncthreads();
+
+            stage_chunk(ld_tap, ld_cc, 1);
+            next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
+            read_frags(0, fa0, fb0);
+            mma(fa1, fb1);
+            __syncthreads();
+        }
+        if (nk & 1) mma(fa0, fb0);
+    } else {
+        // Invariant at the top of step kc: fragments of chunk kc in registers; stage (kc+1)%3 holds chunk kc+1, landed
+        // and published; chunk kc+2 is in flight into stage (kc+2)%3; stage kc%3 is free (its fragments were read one
+        // step ago and a barrier has passed).  Step: DMA chunk kc+3 -> stage kc%3; LDS -> registers of chunk kc+1; MFMA
+        // of chunk kc; wait until only this step's NDMA loads are outstanding (chunk kc+2 has landed for this wave)
+        // and the fragment reads have returned; barrier (publishes chunk kc+2, frees stage (kc+1)%3).
+        auto publish = [&]() {
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NDMA) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        stage_chunk(ld_tap, ld_cc, 0);
+        next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
+        stage_chunk(ld_tap, ld_cc, 1);
+        next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
+        stage_chunk(ld_tap, ld_cc, 2);
+        next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        read_frags(0, fa0, fb0);
+        publish();
+        int st_free = 0, st_next = 1;
+        const int npairs = nk >> 1;
+        for (int pr = 0; pr < npairs; ++pr) {
+            stage_chunk(ld_tap, ld_cc, st_free);
+            next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
+            read_frags(st_next, fa1, fb1);
+            mma(fa0, fb0);
+            publish();
+            st_free = st_next;
+            st_next = st_next == 2 ? 0 : st_next + 1;
+
+            stage_chunk(ld_tap, ld_cc, st_free);
+            next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
+            read_frags(st_next, fa0, fb0);
+            mma(fa1, fb1);
+            publish();
+            st_free = st_next;
+            st_next = st_next == 2 ? 0 : st_next + 1;
+        }
+        if (nk & 1) mma(fa0, fb0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may still be landing in LDS when the block retires
     }
-    if (nk & 1) mma(fa0, fb0);
 
     // ---- fused epilogue (fp32 math, one rounding on the store)
     const int hi = lane >> 5;
@@ -199,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const ConvBArgs
     bf16_t* yb = reinterpret_cast<bf16_t*>(d.y);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (BN / 2) + j * 32 + frow;
+        const int n = n0 + wn * (BN / WN) + j * 32 + frow;
         const float sc = d.scale ? d.scale[n] : 1.f;
         const float sh = d.shift ? d.shift[n] : 0.f;
         const bool n_ok = n < d.N;
@@ -207,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const ConvBArgs
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const long long m = m0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                const long long m = m0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
                 if (m < a.M && n_ok) {
                     long long pix;
                     if (a.linear_out) {
@@ -235,26 +288,54 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf16_kernel(const ConvBArgs
 static int g_bforce_bm = 0, g_bforce_bn = 0;
 extern "C" void rdpn6d_conv_bf16_force_tile(int bm, int bn) { g_bforce_bm = bm; g_bforce_bn = bn; }
 
-static void conv_bf16_pick_tile(const rdpn6d_conv_desc* d, long long M, int* pbm, int* pbn)
+static void conv_bf16_pick_tile(const rdpn6d_conv_desc* d, long long M, int rb, int* pbm, int* pbn)
 {
     int bn = (d->Npad % 128 == 0) ? 128 : 64;
     int bm = 128;
-    if ((long long)rd_cdiv(M, 128) * (d->Npad / bn) < 512) bm = 64;
+    // big problems: the 256x128 tile (one 8-wave workgroup per CU, deep DMA pipeline) once it fills the chip twice over
+    if (bn == 128 && rb == 128 && (long long)rd_cdiv(M, 256) * (d->Npad / 128) >= 512) bm = 256;
+    if (bm == 128 && (long long)rd_cdiv(M, 128) * (d->Npad / bn) < 512) bm = 64;
     if (bm == 64 && bn == 128 && (long long)rd_cdiv(M, 64) * (d->Npad / 128) < 512) bn = 64;
-    if (g_bforce_bm) bm = g_bforce_bm;
+    if (g_bforce_bm && (g_bforce_bm != 256 || (rb == 128 && d->Npad % 128 == 0))) bm = g_bforce_bm;
     if (g_bforce_bn && d->Npad % g_bforce_bn == 0) bn = g_bforce_bn;
+    if (bm == 256) bn = 128;
     *pbm = bm;
     *pbn = bn;
 }
 
-template <int RB>
-static void conv_bf16_launch(const ConvBArgs& a, int bm, int bn, hipStream_t s)
+extern "C" int rdpn6d_conv_bf16_tile_for(const rdpn6d_conv_desc* d, int* bm, int* bn)
 {
-    dim3 grid((unsigned)(a.mtiles * a.ntiles)), block(256);
-    if (bm == 128 && bn == 128) hipLaunchKernelGGL((conv_igemm_bf16_kernel<128, 128, RB>), grid, block, 0, s, a);
-    else if (bm == 128 && bn == 64) hipLaunchKernelGGL((conv_igemm_bf16_kernel<128, 64, RB>), grid, block, 0, s, a);
-    else if (bm == 64 && bn == 128) hipLaunchKernelGGL((conv_igemm_bf16_kernel<64, 128, RB>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((conv_igemm_bf16_kernel<64, 64, RB>), grid, block, 0, s, a);
+    RD_REQUIRE(d && bm && bn, "null pointer");
+    conv_bf16_pick_tile(d, (long long)d->B * d->Ho * d->Wo, d->Cin % 64 == 0 ? 128 : 64, bm, bn);
+    return RDPN6D_OK;
+}
+
+template <int BM, int BN, int RB, int WM, int WN, int NST>
+static int conv_bf16_launch_one(const ConvBArgs& a, hipStream_t s)
+{
+    constexpr int lds = NST * (BM + BN) * RB;
+    auto kern = conv_igemm_bf16_kernel<BM, BN, RB, WM, WN, NST>;
+    if (lds > 64 * 1024) {
+        static bool configured = false;  // one-time opt-in to > 64 KiB of dynamic LDS
+        if (!configured) {
+            RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            configured = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(a.mtiles * a.ntiles)), dim3(64 * WM * WN), lds, s, a);
+    return RDPN6D_OK;
+}
+
+template <int RB>
+static int conv_bf16_launch(const ConvBArgs& a, int bm, int bn, hipStream_t s)
+{
+    if constexpr (RB == 128) {
+        if (bm == 256) return conv_bf16_launch_one<256, 128, RB, 4, 2, 3>(a, s);
+    }
+    if (bm == 128 && bn == 128) return conv_bf16_launch_one<128, 128, RB, 2, 2, 2>(a, s);
+    if (bm == 128 && bn == 64) return conv_bf16_launch_one<128, 64, RB, 2, 2, 2>(a, s);
+    if (bm == 64 && bn == 128) return conv_bf16_launch_one<64, 128, RB, 2, 2, 2>(a, s);
+    return conv_bf16_launch_one<64, 64, RB, 2, 2, 2>(a, s);
 }
 
 extern "C" int rdpn6d_conv2d_bf16(const rdpn6d_conv_desc* d, int out_f32, void* stream)
@@ -293,12 +374,12 @@ extern "C" int rdpn6d_conv2d_bf16(const rdpn6d_conv_desc* d, int out_f32, void* 
         a.dx_pack |= (unsigned long long)(d->dx[t] + 8) << (4 * t);
     }
     int bm, bn;
-    conv_bf16_pick_tile(d, a.M, &bm, &bn);
+    conv_bf16_pick_tile(d, a.M, rb, &bm, &bn);
     a.mtiles = rd_cdiv(a.M, bm);
     a.ntiles = d->Npad / bn;
     hipStream_t s = (hipStream_t)stream;
-    if (rb == 128) conv_bf16_launch<128>(a, bm, bn, s);
-    else conv_bf16_launch<64>(a, bm, bn, s);
+    const int rc = rb == 128 ? conv_bf16_launch<128>(a, bm, bn, s) : conv_bf16_launch<64>(a, bm, bn, s);
+    if (rc != RDPN6D_OK) return rc;
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
 }

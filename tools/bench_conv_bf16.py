@@ -18,6 +18,7 @@ SHAPES = [  # name, H, Cin, Cout, k, stride
     ("1x1 512->64 @32", 32, 512, 64, 1, 1),
     ("1x1 96->64 @64 (RB=64)", 64, 96, 64, 1, 1),
     ("head out 1x1 256->37 @64", 64, 256, 37, 1, 1),
+    ("convT phase 2x2 1024->256 @32", 32, 1024, 256, 2, 1),
 ]
 torch.manual_seed(0)
 def check(name, H, Cin, Cout, k, stride):
@@ -37,27 +38,38 @@ def check(name, H, Cin, Cout, k, stride):
     print(f"check {name:34s} f32-out rel err {e32:.2e}   bf16-out vs rounded ref {e16:.2e}")
     assert e32 < 2e-5 and e16 < 1e-2
 def bench(name, H, Cin, Cout, k, stride, tiles=None, reps=20):
+    from rdpn6d_amd.gdrn import _pad_to, _ptr, pack_conv_weight
     x = torch.randn(B, H, H, Cin, device=dev).bfloat16()
-    w = (torch.randn(Cout, Cin, k, k, device=dev) / (Cin * k * k) ** 0.5).bfloat16()
-    Ho = (H + 2 * (k // 2) - k) // stride + 1
-    from rdpn6d_amd.gdrn import _pad_to
-    out = torch.empty(B, Ho, Ho, _pad_to(Cout, 8), device=dev, dtype=torch.bfloat16)
+    w = torch.randn(Cout, Cin, k, k, device=dev) / (Cin * k * k) ** 0.5
+    wp = pack_conv_weight(w, cin_pad=_pad_to(Cin, 32)).bfloat16()
+    pad = k // 2
+    Ho = (H + 2 * pad - k) // stride + 1
+    y = torch.empty(B, Ho, Ho, _pad_to(Cout, 8), device=dev, dtype=torch.bfloat16)
+    d = _lib.ConvDesc()
+    d.x, d.w, d.y = _ptr(x), _ptr(wp), _ptr(y)
+    d.B, d.H, d.W, d.Cin, d.in_cs, d.in_co = B, H, H, Cin, Cin, 0
+    d.Ho, d.Wo, d.stride = Ho, Ho, stride
+    taps = [(ky - pad, kx - pad) for ky in range(k) for kx in range(k)]
+    d.ntaps = len(taps)
+    for t, (dy, dx) in enumerate(taps): d.dy[t], d.dx[t] = dy, dx
+    d.N, d.Npad, d.OH, d.OW = Cout, wp.shape[0], Ho, Ho
+    d.osy = d.osx = 1; d.out_cs = y.shape[-1]; d.act = 1
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     if tiles: lib.rdpn6d_conv_bf16_force_tile(*tiles)
-    f = lambda: ops.conv2d_nhwc(x, w, None, None, stride=stride, pad=k // 2, act=1, out=out)
-    for _ in range(3): f()
-    # time only the kernel: re-launch the prepared descriptor through ops is python-heavy, so use events around reps
-    torch.cuda.synchronize()
+    bm, bn = ctypes.c_int(), ctypes.c_int()
+    lib.rdpn6d_conv_bf16_tile_for(ctypes.byref(d), ctypes.byref(bm), ctypes.byref(bn))
+    for _ in range(3): _lib.check(lib.rdpn6d_conv2d_bf16(ctypes.byref(d), 0, st))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    best = 1e9
-    for _ in range(reps):
-        e0.record(); f(); e1.record(); torch.cuda.synchronize()
-        best = min(best, e0.elapsed_time(e1))
+    e0.record()
+    for _ in range(reps): lib.rdpn6d_conv2d_bf16(ctypes.byref(d), 0, st)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
     fl = 2.0 * B * Ho * Ho * Cout * k * k * Cin
     lib.rdpn6d_conv_bf16_force_tile(0, 0)
-    print(f"{name:34s} tiles {str(tiles):10s} {best*1e3:9.1f} us  {fl/best/1e9:7.1f} TF/s  ({fl/best/1e9/2500*100:5.1f}% of bf16 MFMA peak)")
+    print(f"{name:34s} tile {bm.value:3d}x{bn.value:3d} {ms*1e3:9.1f} us  {fl/ms/1e9:7.1f} TF/s  ({fl/ms/1e9/2500*100:5.1f}% of bf16 MFMA peak)")
 for s in SHAPES: check(*s)
 for s in SHAPES: bench(*s)
 if os.environ.get("SWEEP"):
     for s in SHAPES[:6]:
-        for t in ((128, 128), (128, 64), (64, 128), (64, 64)):
+        for t in ((256, 128), (128, 128), (128, 64), (64, 128), (64, 64)):
             if max(64, s[3]) % t[1] == 0: bench(*s, tiles=t)
