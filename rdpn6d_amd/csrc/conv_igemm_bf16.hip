@@ -292,8 +292,8 @@ static void conv_bf16_pick_tile(const rdpn6d_conv_desc* d, long long M, int rb, 
 {
     int bn = (d->Npad % 128 == 0) ? 128 : 64;
     int bm = 128;
-    // big problems: the 256x128 tile (one 8-wave workgroup per CU, deep DMA pipeline) once it fills the chip twice over
-    if (bn == 128 && rb == 128 && (long long)rd_cdiv(M, 256) * (d->Npad / 128) >= 512) bm = 256;
+    // (the 256x128 / 8-wave / 3-stage form measures 0.96x of 128x128 on the head layers - 791 vs 821 TFLOP/s - and is
+    //  therefore only reachable through rdpn6d_conv_bf16_force_tile(256, 128))
     if (bm == 128 && (long long)rd_cdiv(M, 128) * (d->Npad / bn) < 512) bm = 64;
     if (bm == 64 && bn == 128 && (long long)rd_cdiv(M, 64) * (d->Npad / 128) < 512) bn = 64;
     if (g_bforce_bm && (g_bforce_bm != 256 || (rb == 128 && d->Npad % 128 == 0))) bm = g_bforce_bm;

@@ -657,3 +657,32 @@ def test_conv_splitk_matches_fused(dev, M, K, N, ks):
     _close(outs[0][:, :N], ref, 2e-6, "fused")
     _close(outs[1][:, :N], ref, 2e-6, "split-K")
     assert (outs[1][:, N:] == 7.0).all()  # padding columns untouched
+
+
+def test_hip_graph_replay_is_bit_identical(golden_setup, dev):
+    """cfg.TEST.HIP_GRAPH: first call eager, second call captures, third replays - same kernels in the same order, so every
+    output is bit-identical to the eager step; new input buffers fall back to eager / a new capture."""
+    models, t, _ = golden_setup
+    model = models["mul"]
+    ref = _run(model, t)
+    ref = {k: v.clone() for k, v in ref.items() if v is not None}
+    model.cfg.TEST.HIP_GRAPH = True
+    model.cfg.TEST.USE_PNP = True
+    model.cfg.TEST.PNP_INLIER_THR = 0.05
+    try:
+        eager = {k: v.clone() for k, v in _run(model, t).items() if v is not None}
+        outs = [_run(model, t) for _ in range(3)]
+        plan = model.plan(4, dev)
+        assert any(isinstance(g, torch.cuda.CUDAGraph) for g in plan._graphs.values())
+        for o in outs:
+            for k, v in eager.items():
+                assert torch.equal(o[k], v), k
+        for k in ("mask", "coor_x", "region", "rot", "trans"):
+            assert torch.equal(eager[k], ref[k]), k
+        t2 = {k: v.clone() for k, v in t.items()}
+        t2["roi_img"] = t2["roi_img"].flip(0).contiguous()
+        o2 = _run(model, t2)  # other buffers: eager again, and the old graph must not have been replayed on them
+        assert torch.equal(o2["mask"], ref["mask"].flip(0))
+    finally:
+        model.cfg.TEST.HIP_GRAPH = False
+        model.cfg.TEST.USE_PNP = False
