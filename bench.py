@@ -76,7 +76,7 @@ def roofline(model, t, B, device, reps=3):
         if L.keep and (L.fn is lowp_fn) == plan.bf16:
             d = L.keep[0]
             bm, bn = ctypes.c_int(), ctypes.c_int()
-            lib.rdpn6d_conv_tile_for(ctypes.byref(d), ctypes.byref(bm), ctypes.byref(bn))  # same heuristic in both kernels
+            (lib.rdpn6d_conv_bf16_tile_for if plan.bf16 else lib.rdpn6d_conv_tile_for)(ctypes.byref(d), ctypes.byref(bm), ctypes.byref(bn))
             if (bm.value, bn.value) == (128, 128) and (not plan.bf16 or d.Cin % 64 == 0):
                 sel.append(L)
     flops = sum(conv_flops(L.keep[0]) for L in sel)
@@ -102,7 +102,7 @@ def roofline(model, t, B, device, reps=3):
         n += len(evs)
     avg_ms = total_ms / max(n, 1)
     achieved = flops / len(sel) / (avg_ms * 1e-3) / 1e12 if sel else 0.0
-    kname = "conv_igemm_bf16_kernel<128, 128, 128>" if plan.bf16 else "conv_igemm_f32_kernel<128, 128>"
+    kname = "conv_igemm_bf16_kernel<128, 128, 128, 2, 2, 2>" if plan.bf16 else "conv_igemm_f32_kernel<128, 128>"
     peak = BF16_MFMA_PEAK_TFLOPS if plan.bf16 else FP32_MFMA_PEAK_TFLOPS
     traffic, traffic_src = pmc_traffic(kname) if B == 64 else (None, None)
     return {

@@ -32,6 +32,7 @@ struct ConvBArgs {
     int out_f32;
     unsigned x_bytes, w_bytes;
     unsigned long long dy_pack, dx_pack;
+    int vec_out;  // bf16 output with 16-byte aligned channel slices (out / residual): coalesced epilogue through LDS
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -250,6 +251,64 @@ __global__ __launch_bounds__(64 * WM * WN, NST == 2 ? 2 : 1) void conv_igemm_bf1
     const int hi = lane >> 5;
     const bf16_t* resb = reinterpret_cast<const bf16_t*>(d.res);
     bf16_t* yb = reinterpret_cast<bf16_t*>(d.y);
+    // Coalesced form for full tiles: the accumulator layout has one channel per lane and pixels across registers, i.e. a
+    // direct store moves 2 bytes per lane.  Each wave instead transposes its tile through its own slice of the (now
+    // idle) staging LDS - fp32, scale/shift already applied - and walks it back row-wise: 8 channels = 16 bytes per
+    // lane for the residual load and the store.  Same fp32 operations in the same order as the scalar path below.
+    if (a.vec_out && n0 + BN <= d.N && m0 + BM <= a.M) {
+        constexpr int WC = BN / WN;       // channels per wave tile
+        constexpr int CS = WC + 8;        // LDS row stride in floats (+32 B: the two half-waves hit disjoint banks)
+        constexpr int LPR = WC / 8;       // lanes per pixel row on the way back
+        constexpr int RPI = 64 / LPR;     // pixel rows per wave instruction
+        __syncthreads();                  // every wave is done with the staging buffers (and no DMA is still landing)
+        float* cst = reinterpret_cast<float*>(smem) + wave * (32 * CS);
+        const int rrow = lane / LPR, c8 = (lane % LPR) * 8;
+        const int nb = n0 + wn * WC;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = nb + j * 32 + frow;
+                const float sc = d.scale ? d.scale[n] : 1.f;
+                const float sh = d.shift ? d.shift[n] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    cst[((e & 3) + 8 * (e >> 2) + 4 * hi) * CS + j * 32 + frow] = acc[i][j][e] * sc + sh;
+            }
+#pragma unroll
+            for (int rr = 0; rr < 32 / RPI; ++rr) {
+                const int row = rr * RPI + rrow;
+                const long long m = m0 + wm * (BM / WM) + i * 32 + row;
+                long long pix;
+                if (a.linear_out) {
+                    pix = m;
+                } else {
+                    const int mm = (int)m;
+                    const int b = mm / a.HoWo;
+                    const int rem = mm - b * a.HoWo;
+                    const int oy = rem / d.Wo;
+                    const int ox = rem - oy * d.Wo;
+                    pix = ((long long)b * d.OH + (oy * d.osy + d.ooy)) * d.OW + (ox * d.osx + d.oox);
+                }
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(cst + row * CS + c8);
+                const f32x4 hi4 = *reinterpret_cast<const f32x4*>(cst + row * CS + c8 + 4);
+                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+                if (resb) {
+                    float rv[8];
+                    rd_unpack8(*reinterpret_cast<const rd_u32x4*>(resb + pix * d.res_cs + d.res_co + nb + c8), rv);
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] += rv[q];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    if (d.act == 1) v[q] = v[q] > 0.f ? v[q] : 0.f;
+                    else if (d.act == 2) v[q] = v[q] > 0.f ? v[q] : v[q] * d.slope;
+                }
+                *reinterpret_cast<rd_u32x4*>(yb + pix * d.out_cs + d.out_co + nb + c8) = rd_pack8(v);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * (BN / WN) + j * 32 + frow;
@@ -313,7 +372,9 @@ extern "C" int rdpn6d_conv_bf16_tile_for(const rdpn6d_conv_desc* d, int* bm, int
 template <int BM, int BN, int RB, int WM, int WN, int NST>
 static int conv_bf16_launch_one(const ConvBArgs& a, hipStream_t s)
 {
-    constexpr int lds = NST * (BM + BN) * RB;
+    constexpr int lds_stage = NST * (BM + BN) * RB;
+    constexpr int lds_epi = WM * WN * 32 * (BN / WN + 8) * 4;  // per-wave transpose slices of the coalesced epilogue
+    constexpr int lds = lds_stage > lds_epi ? lds_stage : lds_epi;
     auto kern = conv_igemm_bf16_kernel<BM, BN, RB, WM, WN, NST>;
     if (lds > 64 * 1024) {
         static bool configured = false;  // one-time opt-in to > 64 KiB of dynamic LDS
@@ -361,6 +422,7 @@ extern "C" int rdpn6d_conv2d_bf16(const rdpn6d_conv_desc* d, int out_f32, void* 
     a.Ktot = d->ntaps * d->Cin;
     a.linear_out = (d->osy == 1 && d->osx == 1 && d->ooy == 0 && d->oox == 0 && d->OH == d->Ho && d->OW == d->Wo);
     a.out_f32 = out_f32 ? 1 : 0;
+    a.vec_out = (!out_f32 && d->out_cs % 8 == 0 && d->out_co % 8 == 0 && (!d->res || (d->res_cs % 8 == 0 && d->res_co % 8 == 0))) ? 1 : 0;
     const long long xb = (long long)d->B * d->H * d->W * d->in_cs * 2;
     RD_REQUIRE(xb < (1LL << 32) - 64, "input tensor must be smaller than 4 GiB (32-bit buffer offsets)");
     a.x_bytes = (unsigned)xb;

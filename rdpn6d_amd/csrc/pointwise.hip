@@ -6,21 +6,22 @@
 // ------------------------------------------------------------------------------------------------
 // Stem: conv 7x7 stride 2 pad 3 on channels 0..2 of the NCHW crop + folded BN + ReLU -> NHWC 64.
 // (resnet_backbone.py:272,:321-323).  K = 147 is too ragged/small for the MFMA path and the layer
-// is 0.7 % of the FLOPs: a direct LDS-tiled VALU kernel.  Workgroup = 16x16 output pixels; the
-// 37x37x3 input patch and the 147x64 weights sit in LDS; each thread owns one pixel x 64 channels
-// (weights are wave-uniform LDS broadcasts, 16 B per read).
+// is 0.7 % of the FLOPs: a direct LDS-tiled VALU kernel.  The input patch and the 147x64 weights sit in
+// LDS; weights are wave-uniform LDS broadcasts, 16 B per read.
 // OUT_BF16: the 64 output channels are rounded (RNE) to bf16 - the input of the bf16 trunk (conv_igemm_bf16.hip).
+// Workgroup = 16 x 32 output pixels, two pixels (16 columns apart) per thread: every 16-byte weight read from LDS
+// feeds 8 FMAs instead of 4 - the kernel is bound by the LDS weight broadcasts, not by the FMA rate.
 template <bool OUT_BF16>
 __global__ __launch_bounds__(256) void stem_conv7x7_kernel(const float* __restrict__ x, int xc, int R,
                                                            const float* __restrict__ w,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift, void* __restrict__ yv, int relu)
 {
-    constexpr int T = 16, P = 2 * T + 5;  // 37
-    __shared__ float s_in[3][P][P + 1];
+    constexpr int TY = 16, TX = 32, PY = 2 * TY + 5, PX = 2 * TX + 5;  // 37 x 69 input patch
+    __shared__ float s_in[3][PY][PX + 1];
     __shared__ __attribute__((aligned(16))) float s_w[147 * 64];  // [tap(ky,kx,c)][64]
     const int Ro = R / 2;
-    const int b = blockIdx.z, ty0 = blockIdx.y * T, tx0 = blockIdx.x * T;
+    const int b = blockIdx.z, ty0 = blockIdx.y * TY, tx0 = blockIdx.x * TX;
     const int tid = threadIdx.x;
     // weights: global layout [64][7][7][3] -> LDS [147][64]
     for (int i = tid; i < 147 * 64; i += 256) {
@@ -28,8 +29,8 @@ __global__ __launch_bounds__(256) void stem_conv7x7_kernel(const float* __restri
         s_w[k * 64 + n] = w[i];
     }
     const int iy0 = ty0 * 2 - 3, ix0 = tx0 * 2 - 3;
-    for (int i = tid; i < 3 * P * P; i += 256) {
-        const int c = i / (P * P), rem = i - c * P * P, py = rem / P, px = rem - py * P;
+    for (int i = tid; i < 3 * PY * PX; i += 256) {
+        const int c = i / (PY * PX), rem = i - c * PY * PX, py = rem / PX, px = rem - py * PX;
         const int iy = iy0 + py, ix = ix0 + px;
         float v = 0.f;
         if ((unsigned)iy < (unsigned)R && (unsigned)ix < (unsigned)R)
@@ -37,44 +38,56 @@ __global__ __launch_bounds__(256) void stem_conv7x7_kernel(const float* __restri
         s_in[c][py][px] = v;
     }
     __syncthreads();
-    const int ly = tid / T, lx = tid - ly * T;
-    const int oy = ty0 + ly, ox = tx0 + lx;
-    float acc[64];
+    const int ly = tid / 16, lx = tid - ly * 16;
+    const int oy = ty0 + ly;
+    // two channels per instruction (v_pk_fma_f32): the same IEEE fma per channel in the same order
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 acc2[2][32];
 #pragma unroll
-    for (int n = 0; n < 64; ++n) acc[n] = 0.f;
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int n = 0; n < 32; ++n) acc2[p][n] = f32x2{0.f, 0.f};
     for (int ky = 0; ky < 7; ++ky)
         for (int kx = 0; kx < 7; ++kx)
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float v = s_in[c][ly * 2 + ky][lx * 2 + kx];
+                const float v0 = s_in[c][ly * 2 + ky][lx * 2 + kx];
+                const float v1 = s_in[c][ly * 2 + ky][(lx + 16) * 2 + kx];
+                const f32x2 vv0 = {v0, v0}, vv1 = {v1, v1};
                 const f32x4* wp = reinterpret_cast<const f32x4*>(&s_w[((ky * 7 + kx) * 3 + c) * 64]);
 #pragma unroll
                 for (int n4 = 0; n4 < 16; ++n4) {
                     const f32x4 wv = wp[n4];
-                    acc[n4 * 4 + 0] = fmaf(v, wv[0], acc[n4 * 4 + 0]);
-                    acc[n4 * 4 + 1] = fmaf(v, wv[1], acc[n4 * 4 + 1]);
-                    acc[n4 * 4 + 2] = fmaf(v, wv[2], acc[n4 * 4 + 2]);
-                    acc[n4 * 4 + 3] = fmaf(v, wv[3], acc[n4 * 4 + 3]);
+                    const f32x2 wlo = {wv[0], wv[1]}, whi = {wv[2], wv[3]};
+                    acc2[0][n4 * 2 + 0] = __builtin_elementwise_fma(vv0, wlo, acc2[0][n4 * 2 + 0]);
+                    acc2[0][n4 * 2 + 1] = __builtin_elementwise_fma(vv0, whi, acc2[0][n4 * 2 + 1]);
+                    acc2[1][n4 * 2 + 0] = __builtin_elementwise_fma(vv1, wlo, acc2[1][n4 * 2 + 0]);
+                    acc2[1][n4 * 2 + 1] = __builtin_elementwise_fma(vv1, whi, acc2[1][n4 * 2 + 1]);
                 }
             }
-    if (oy < Ro && ox < Ro) {
-        const long long pix = ((long long)b * Ro + oy) * Ro + ox;
 #pragma unroll
-        for (int n4 = 0; n4 < 16; ++n4) {
-            f32x4 o;
+    for (int p = 0; p < 2; ++p) {
+        const int ox = tx0 + lx + 16 * p;
+        if (oy < Ro && ox < Ro) {
+            const long long pix = ((long long)b * Ro + oy) * Ro + ox;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int n = n4 * 4 + e;
-                const float v = scale ? acc[n] * scale[n] + shift[n] : acc[n];
-                o[e] = (v > 0.f || !relu) ? v : 0.f;
-            }
-            if constexpr (OUT_BF16) {
-                uint2 pk;
-                pk.x = (unsigned)rd_f2bf(o[0]) | ((unsigned)rd_f2bf(o[1]) << 16);
-                pk.y = (unsigned)rd_f2bf(o[2]) | ((unsigned)rd_f2bf(o[3]) << 16);
-                reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(yv) + pix * 64)[n4] = pk;
-            } else {
-                reinterpret_cast<f32x4*>(reinterpret_cast<float*>(yv) + pix * 64)[n4] = o;
+            for (int n4 = 0; n4 < 16; ++n4) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int n = n4 * 4 + e;
+                    const float a = acc2[p][n >> 1][n & 1];
+                    const float v = scale ? a * scale[n] + shift[n] : a;
+                    o[e] = (v > 0.f || !relu) ? v : 0.f;
+                }
+                if constexpr (OUT_BF16) {
+                    uint2 pk;
+                    pk.x = (unsigned)rd_f2bf(o[0]) | ((unsigned)rd_f2bf(o[1]) << 16);
+                    pk.y = (unsigned)rd_f2bf(o[2]) | ((unsigned)rd_f2bf(o[3]) << 16);
+                    reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(yv) + pix * 64)[n4] = pk;
+                } else {
+                    reinterpret_cast<f32x4*>(reinterpret_cast<float*>(yv) + pix * 64)[n4] = o;
+                }
             }
         }
     }
@@ -86,7 +99,7 @@ static int stem_launch(const float* x, int B, int xc, int R, const float* w, con
     RD_REQUIRE(x && w && y && (!scale == !shift), "null pointer");
     RD_REQUIRE(B > 0 && xc >= 3 && R > 0 && R % 2 == 0, "shape");
     const int Ro = R / 2;
-    dim3 grid(rd_cdiv(Ro, 16), rd_cdiv(Ro, 16), B);
+    dim3 grid(rd_cdiv(Ro, 32), rd_cdiv(Ro, 16), B);
     if (out_bf16) hipLaunchKernelGGL(stem_conv7x7_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, xc, R, w, scale, shift, y, relu);
     else hipLaunchKernelGGL(stem_conv7x7_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, xc, R, w, scale, shift, y, relu);
     RD_LAUNCH_CHECK();
