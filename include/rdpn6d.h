@@ -168,6 +168,17 @@ int rdpn6d_ransac_kabsch_ex(const float* out_nchw, const float* coord2d, const f
                             const float* resize_ratios, const int* region_argmax, int B, int HW, int K,
                             float mask_thr, float inlier_thr, int iters, float confidence, unsigned seed,
                             float* pose_out, int* n_inliers, unsigned char* inlier_mask, int* best_hyp, void* stream);
+/* Network-initialised solve = process_net_and_pnp (gdrn_evaluator.py:187-314; cfg.TEST.PNP_TYPE "net_ransac_pnp" /
+ * "net_iter_pnp").  net_pose [B,12] = the learned pose (R row-major | t), device memory, must not alias pose_out.
+ * mode 1: net_pose is hypothesis 0 next to iters-1 sampled ones (the reference passes iterationsCount=20), then the
+ * inlier refit; mode 2: one closed-form least-squares fit over ALL selected correspondences (the role of
+ * solvePnP(ITERATIVE)).  Fewer than 3 correspondences -> net_pose (:297-300); |t - t_net| > max_t_diff -> t_net
+ * (:293-296, 1.0 there). */
+int rdpn6d_ransac_kabsch_net_f32(const float* out_nchw, const float* coord2d, const float* fps, const float* extents,
+                                 const float* resize_ratios, const int* region_argmax, const float* net_pose, int B,
+                                 int HW, int K, float mask_thr, float inlier_thr, int iters, float confidence,
+                                 unsigned seed, int mode, float max_t_diff, float* pose_out, int* n_inliers,
+                                 unsigned char* inlier_mask, int* best_hyp, void* stream);
 
 
 /* ================================================================== training step (forward with batch statistics,

@@ -148,10 +148,13 @@ static void rs_horn(const double S[9], double R[9])
  * fps [B,K,3], extents [B,3], ratios [B], region_argmax [B,HW] (0..K-1)
  * -> pose_out [B,12], n_inliers [B], inlier_mask [B,HW] (may be NULL), best_hyp [B] (may be NULL)
  */
-void oracle_ransac_kabsch(const float* out_nchw, const float* coord2d, const float* fps, const float* extents,
-                          const float* ratios, const int* region_argmax, int B, int HW, int K, float mask_thr,
-                          float inlier_thr, int iters, float confidence, unsigned seed, float* pose_out,
-                          int* n_inliers, unsigned char* inlier_mask, int* best_hyp)
+/* net_pose != NULL: the network-initialised solve (role of process_net_and_pnp, gdrn_evaluator.py:187-314): the
+ * learned pose is hypothesis 0, is kept when fewer than 3 correspondences survive (:297-300), and its translation is
+ * kept when the solved one moved by more than max_t_diff (:293-296). */
+static void ransac_impl(const float* out_nchw, const float* coord2d, const float* fps, const float* extents,
+                        const float* ratios, const int* region_argmax, int B, int HW, int K, float mask_thr,
+                        float inlier_thr, int iters, float confidence, unsigned seed, float* pose_out,
+                        int* n_inliers, unsigned char* inlier_mask, int* best_hyp, const float* net_pose, float max_t_diff)
 {
     const int C = 4 + K + 1;
     float* q = (float*)malloc(sizeof(float) * 3 * (size_t)HW);
@@ -192,6 +195,10 @@ void oracle_ransac_kabsch(const float* out_nchw, const float* coord2d, const flo
                 counts[h] = -1;
                 int ok = 0;
                 float* ps = poses + 12 * h;
+                if (net_pose && h == 0) {
+                    for (int i = 0; i < 12; i++) ps[i] = net_pose[b * 12 + i];
+                    ok = 1;
+                }
                 for (int t = 0; t < 8 && !ok; t++) {
                     int i0 = (int)(rs_hash(seed, b, h, t, 0) % (unsigned)n);
                     int i1 = (int)(rs_hash(seed, b, h, t, 1) % (unsigned)n);
@@ -228,7 +235,7 @@ void oracle_ransac_kabsch(const float* out_nchw, const float* coord2d, const flo
         if (best_hyp) best_hyp[b] = best;
         n_inliers[b] = best_cnt;
         if (best < 0) {
-            for (int i = 0; i < 12; i++) po[i] = -100.f;
+            for (int i = 0; i < 12; i++) po[i] = net_pose ? net_pose[b * 12 + i] : -100.f;
             continue;
         }
         /* inliers of the best hypothesis, then Kabsch/Horn refit on them (double accumulation) */
@@ -261,6 +268,38 @@ void oracle_ransac_kabsch(const float* out_nchw, const float* coord2d, const flo
         for (int i = 0; i < 9; i++) po[i] = (float)R[i];
         for (int i = 0; i < 3; i++)
             po[9 + i] = (float)(qbar[i] - (R[i * 3] * abar[0] + R[i * 3 + 1] * abar[1] + R[i * 3 + 2] * abar[2]));
+        if (net_pose) {
+            double d2 = 0.0;
+            for (int i = 0; i < 3; i++) {
+                double dt = (double)po[9 + i] - (double)net_pose[b * 12 + 9 + i];
+                d2 += dt * dt;
+            }
+            if (sqrt(d2) > (double)max_t_diff)
+                for (int i = 0; i < 3; i++) po[9 + i] = net_pose[b * 12 + 9 + i];
+        }
     }
     free(q); free(ai); free(pix); free(counts); free(poses); free(ta);
+}
+
+void oracle_ransac_kabsch(const float* out_nchw, const float* coord2d, const float* fps, const float* extents,
+                          const float* ratios, const int* region_argmax, int B, int HW, int K, float mask_thr,
+                          float inlier_thr, int iters, float confidence, unsigned seed, float* pose_out,
+                          int* n_inliers, unsigned char* inlier_mask, int* best_hyp)
+{
+    ransac_impl(out_nchw, coord2d, fps, extents, ratios, region_argmax, B, HW, K, mask_thr, inlier_thr, iters, confidence,
+                seed, pose_out, n_inliers, inlier_mask, best_hyp, NULL, 0.f);
+}
+
+/* mode 1: net pose + iters-1 sampled hypotheses + inlier refit; mode 2: one least-squares fit over all selected points */
+void oracle_ransac_kabsch_net(const float* out_nchw, const float* coord2d, const float* fps, const float* extents,
+                              const float* ratios, const int* region_argmax, const float* net_pose, int B, int HW, int K,
+                              float mask_thr, float inlier_thr, int iters, float confidence, unsigned seed, int mode,
+                              float max_t_diff, float* pose_out, int* n_inliers, unsigned char* inlier_mask, int* best_hyp)
+{
+    if (mode == 2) {
+        iters = 1;
+        inlier_thr = HUGE_VALF;
+    }
+    ransac_impl(out_nchw, coord2d, fps, extents, ratios, region_argmax, B, HW, K, mask_thr, inlier_thr, iters, confidence,
+                seed, pose_out, n_inliers, inlier_mask, best_hyp, net_pose, max_t_diff);
 }

@@ -185,7 +185,8 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_kabsch_kernel(
     const float* __restrict__ out_nchw, const float* __restrict__ coord2d, const float* __restrict__ fps,
     const float* __restrict__ extents, const float* __restrict__ ratios, const int* __restrict__ region_argmax, int HW,
     int K, float mask_thr, float inlier_thr, int iters, float confidence, unsigned seed, float* __restrict__ pose_out,
-    int* __restrict__ n_inliers, unsigned char* __restrict__ inlier_mask, int* __restrict__ best_hyp)
+    int* __restrict__ n_inliers, unsigned char* __restrict__ inlier_mask, int* __restrict__ best_hyp,
+    const float* __restrict__ net_pose, float max_t_diff)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     // carve (all offsets multiples of 16 bytes)
@@ -266,6 +267,11 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_kabsch_kernel(
         for (int h = wave; h < iters; h += RS_WAVES) {
             float pose[12];
             bool ok = false;
+            if (net_pose && h == 0) {  // hypothesis 0 = the network's own pose (process_net_and_pnp: extrinsic guess)
+#pragma unroll
+                for (int i = 0; i < 12; i++) pose[i] = net_pose[b * 12 + i];
+                ok = true;
+            }
             for (int t = 0; t < 8 && !ok; t++) {
                 const int i0 = (int)(rs_hash(seed, b, h, t, 0) % (unsigned)n);
                 const int i1 = (int)(rs_hash(seed, b, h, t, 1) % (unsigned)n);
@@ -337,7 +343,9 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_kabsch_kernel(
     }
     float* po = pose_out + b * 12;
     if (best < 0) {
-        if (tid < 12) po[tid] = -100.f;
+        // too few correspondences: the plain solve reports the -100 sentinel (gdrn_evaluator.py:408-411), the
+        // network-initialised one keeps the network pose (gdrn_evaluator.py:297-300)
+        if (tid < 12) po[tid] = net_pose ? net_pose[b * 12 + tid] : -100.f;
         return;
     }
 
@@ -386,6 +394,17 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_kabsch_kernel(
 #pragma unroll
         for (int i = 0; i < 3; i++)
             po[9 + i] = (float)(qbar[i] - (R[i * 3] * abar[0] + R[i * 3 + 1] * abar[1] + R[i * 3 + 2] * abar[2]));
+        if (net_pose) {  // "translation error too large" guard (gdrn_evaluator.py:293-296): keep the network's t
+            double d2 = 0.0;
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const double dt = (double)po[9 + i] - (double)net_pose[b * 12 + 9 + i];
+                d2 += dt * dt;
+            }
+            if (sqrt(d2) > (double)max_t_diff)
+#pragma unroll
+                for (int i = 0; i < 3; i++) po[9 + i] = net_pose[b * 12 + 9 + i];
+        }
     }
 }
 
@@ -397,17 +416,17 @@ static size_t rs_smem_bytes(int HW)
     return (s + 15) & ~(size_t)15;
 }
 
-extern "C" int rdpn6d_ransac_kabsch_ex(const float* out_nchw, const float* coord2d, const float* fps,
-                                       const float* extents, const float* resize_ratios, const int* region_argmax, int B,
-                                       int HW, int K, float mask_thr, float inlier_thr, int iters, float confidence,
-                                       unsigned seed, float* pose_out, int* n_inliers, unsigned char* inlier_mask,
-                                       int* best_hyp, void* stream)
+static int rs_launch(const float* out_nchw, const float* coord2d, const float* fps, const float* extents,
+                     const float* resize_ratios, const int* region_argmax, int B, int HW, int K, float mask_thr,
+                     float inlier_thr, int iters, float confidence, unsigned seed, float* pose_out, int* n_inliers,
+                     unsigned char* inlier_mask, int* best_hyp, const float* net_pose, float max_t_diff, void* stream)
 {
     RD_REQUIRE(out_nchw && coord2d && fps && extents && resize_ratios && region_argmax && pose_out && n_inliers, "null pointer");
     RD_REQUIRE(B > 0 && HW > 0 && HW <= 16384, "HW must be in 1..16384 (LDS-resident correspondences)");
     RD_REQUIRE(K >= 3 && K <= 64, "K in 3..64");
     RD_REQUIRE(iters >= 1 && iters <= RS_MAX_ITERS, "iters in 1..256");
     RD_REQUIRE(inlier_thr > 0.f && confidence > 0.f && confidence < 1.f, "thresholds");
+    RD_REQUIRE(pose_out != net_pose, "pose_out must not alias net_pose");
     const size_t smem = rs_smem_bytes(HW);
     RD_REQUIRE(smem <= 160 * 1024, "correspondences do not fit the 160 KiB LDS");
     static bool attr_set = false;
@@ -418,9 +437,42 @@ extern "C" int rdpn6d_ransac_kabsch_ex(const float* out_nchw, const float* coord
     }
     hipLaunchKernelGGL(ransac_kabsch_kernel, dim3(B), dim3(RS_THREADS), smem, (hipStream_t)stream, out_nchw, coord2d, fps,
                        extents, resize_ratios, region_argmax, HW, K, mask_thr, inlier_thr, iters, confidence, seed,
-                       pose_out, n_inliers, inlier_mask, best_hyp);
+                       pose_out, n_inliers, inlier_mask, best_hyp, net_pose, max_t_diff);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
+}
+
+extern "C" int rdpn6d_ransac_kabsch_ex(const float* out_nchw, const float* coord2d, const float* fps,
+                                       const float* extents, const float* resize_ratios, const int* region_argmax, int B,
+                                       int HW, int K, float mask_thr, float inlier_thr, int iters, float confidence,
+                                       unsigned seed, float* pose_out, int* n_inliers, unsigned char* inlier_mask,
+                                       int* best_hyp, void* stream)
+{
+    return rs_launch(out_nchw, coord2d, fps, extents, resize_ratios, region_argmax, B, HW, K, mask_thr, inlier_thr, iters,
+                     confidence, seed, pose_out, n_inliers, inlier_mask, best_hyp, nullptr, 0.f, stream);
+}
+
+// Network-initialised solve = process_net_and_pnp (gdrn_evaluator.py:187-314).  net_pose [B,12] (R row-major | t) is the
+// learned pose.  mode 1 ("ransac"): it enters as hypothesis 0 next to iters-1 sampled ones, then the inlier refit;
+// mode 2 ("iter", the reference's solvePnP(ITERATIVE) = a least-squares fit over ALL selected points): one closed-form
+// Kabsch fit over all correspondences.  Both keep the network pose when fewer than 3 correspondences survive, and
+// the network translation when the solved one moved by more than max_t_diff (1 m in the reference).
+extern "C" int rdpn6d_ransac_kabsch_net_f32(const float* out_nchw, const float* coord2d, const float* fps,
+                                            const float* extents, const float* resize_ratios, const int* region_argmax,
+                                            const float* net_pose, int B, int HW, int K, float mask_thr, float inlier_thr,
+                                            int iters, float confidence, unsigned seed, int mode, float max_t_diff,
+                                            float* pose_out, int* n_inliers, unsigned char* inlier_mask, int* best_hyp,
+                                            void* stream)
+{
+    RD_REQUIRE(net_pose, "null pointer");
+    RD_REQUIRE(mode == 1 || mode == 2, "mode: 1 = net + RANSAC, 2 = net + least-squares over all points");
+    RD_REQUIRE(max_t_diff > 0.f, "max_t_diff");
+    if (mode == 2) {
+        iters = 1;
+        inlier_thr = __builtin_huge_valf();  // every selected correspondence counts
+    }
+    return rs_launch(out_nchw, coord2d, fps, extents, resize_ratios, region_argmax, B, HW, K, mask_thr, inlier_thr, iters,
+                     confidence, seed, pose_out, n_inliers, inlier_mask, best_hyp, net_pose, max_t_diff, stream);
 }
 
 extern "C" int rdpn6d_ransac_kabsch_f32(const float* out_nchw, const float* coord2d, const float* fps,

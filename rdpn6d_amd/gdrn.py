@@ -485,10 +485,20 @@ class InferencePlan:
         g.replay()
 
     def run_ransac(self, roi_coord_2d, fps, roi_extents, resize_ratios, mask_thr=0.5, inlier_thr=0.01, iters=100,
-                   confidence=0.99, seed=0):
-        """per-crop RANSAC + Kabsch on the maps the last run() left in out_nchw / argmax"""
+                   confidence=0.99, seed=0, net_mode=0, max_t_diff=1.0):
+        """per-crop RANSAC + Kabsch on the maps the last run() left in out_nchw / argmax.  net_mode 1 / 2 = the
+        network-initialised variants (process_net_and_pnp): the pose run() just decoded seeds / guards the solve."""
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         HW = self.out_nchw.shape[2] * self.out_nchw.shape[3]
+        if net_mode:
+            netp = self.buf("net_pose", self.B, 12)
+            netp[:, :9].copy_(self.rot.view(self.B, 9))
+            netp[:, 9:].copy_(self.trans)
+            _lib.check(self.lib.rdpn6d_ransac_kabsch_net_f32(
+                _ptr(self.out_nchw), _ptr(roi_coord_2d), _ptr(fps), _ptr(roi_extents), _ptr(resize_ratios), _ptr(self.argmax),
+                _ptr(netp), self.B, HW, self.K, mask_thr, inlier_thr, iters, confidence, seed, net_mode, max_t_diff,
+                _ptr(self.pnp_pose), _ptr(self.pnp_ninl), _ptr(self.pnp_mask), _ptr(self.pnp_best), st), "ransac_kabsch_net")
+            return
         _lib.check(self.lib.rdpn6d_ransac_kabsch_ex(
             _ptr(self.out_nchw), _ptr(roi_coord_2d), _ptr(fps), _ptr(roi_extents), _ptr(resize_ratios), _ptr(self.argmax),
             self.B, HW, self.K, mask_thr, inlier_thr, iters, confidence, seed, _ptr(self.pnp_pose), _ptr(self.pnp_ninl),
@@ -601,8 +611,10 @@ class GDRN(nn.Module):
         tcfg = self.cfg.get("TEST", {})
         use_pnp = bool(tcfg.get("USE_PNP", False))
         if use_pnp:
-            if tcfg.get("PNP_TYPE", "ransac_pnp") != "ransac_pnp":
-                raise NotImplementedError(f"TEST.PNP_TYPE={tcfg.PNP_TYPE!r}: only 'ransac_pnp' is implemented")
+            pnp_type = str(tcfg.get("PNP_TYPE", "ransac_pnp")).lower()  # the three choices of gdrn_evaluator.py:136-145
+            if pnp_type not in ("ransac_pnp", "net_ransac_pnp", "net_iter_pnp"):
+                raise NotImplementedError(f"TEST.PNP_TYPE={pnp_type!r}: ransac_pnp | net_ransac_pnp | net_iter_pnp")
+            net_mode = {"ransac_pnp": 0, "net_ransac_pnp": 1, "net_iter_pnp": 2}[pnp_type]
             assert roi_extents is not None, "USE_PNP needs roi_extents"
             roi_extents = f32c(roi_extents)
         is_allo = "allo" in pcfg.ROT_TYPE
@@ -614,15 +626,18 @@ class GDRN(nn.Module):
                 # per-crop RANSAC + Kabsch on the residual correspondences, result next to the learned pose
                 plan.run_ransac(roi_coord_2d, fps, roi_extents, resize_ratios,
                                 mask_thr=float(self.cfg.MODEL.CDPN.ROT_HEAD.MASK_THR_TEST),
-                                inlier_thr=float(tcfg.get("PNP_INLIER_THR", 0.01)), iters=int(tcfg.get("PNP_ITERS", 100)),
-                                confidence=float(tcfg.get("PNP_CONFIDENCE", 0.99)), seed=int(tcfg.get("PNP_SEED", 0)))
+                                inlier_thr=float(tcfg.get("PNP_INLIER_THR", 0.01)),
+                                iters=int(tcfg.get("PNP_ITERS", 20 if net_mode == 1 else 100)),  # 20: gdrn_evaluator.py:275
+                                confidence=float(tcfg.get("PNP_CONFIDENCE", 0.99)), seed=int(tcfg.get("PNP_SEED", 0)),
+                                net_mode=net_mode, max_t_diff=float(tcfg.get("PNP_MAX_T_DIFF", 1.0)))
 
         if tcfg.get("HIP_GRAPH", False):
             # one hipGraph per set of input buffers: a serving loop that re-fills the same device buffers replays ~90
             # kernel launches with one call (extension over the reference's config surface, off by default)
             key = tuple(t.data_ptr() for t in (x, roi_coord_2d, fps, roi_cams, roi_centers, roi_whs, resize_ratios)) + (
                 roi_extents.data_ptr() if use_pnp else 0, is_allo, use_pnp, float(tcfg.get("PNP_INLIER_THR", 0.01)),
-                int(tcfg.get("PNP_ITERS", 100)), int(tcfg.get("PNP_SEED", 0)), torch.cuda.current_stream().cuda_stream)
+                int(tcfg.get("PNP_ITERS", 100)), int(tcfg.get("PNP_SEED", 0)), tcfg.get("PNP_TYPE", "ransac_pnp"),
+                torch.cuda.current_stream().cuda_stream)
             plan.run_graphed(key, launch)
         else:
             launch()

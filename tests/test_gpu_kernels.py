@@ -686,3 +686,52 @@ def test_hip_graph_replay_is_bit_identical(golden_setup, dev):
     finally:
         model.cfg.TEST.HIP_GRAPH = False
         model.cfg.TEST.USE_PNP = False
+
+
+@pytest.mark.parametrize("mode,iters", [("ransac", 20), ("ransac", 100), ("iter", 1)])
+def test_ransac_net_initialised_bit_exact_vs_oracle(dev, oracle_lib, mode, iters):
+    """A10 (process_net_and_pnp): network pose as hypothesis 0 / all-points fit, fallbacks and the translation guard -
+    masks, counts and winner bit-exact vs the C oracle, poses to 1e-5."""
+    from rdpn6d_amd import ops
+    from tests.ransac_cases import make_case
+    from tests.test_ransac_oracle import _gt_pose12, run_oracle_net
+
+    c = make_case(B=6, outliers=0.35 if mode == "ransac" else 0.0, seed=31)
+    net = _gt_pose12(c)
+    net[1, :9] = np.eye(3).reshape(9)            # crop 1: wrong rotation
+    net[2, 9:] += np.float32(1.5)                # crop 2: translation guard fires
+    c["out_nchw"][3, 0] = 0.0                    # crop 3: no correspondences -> network pose
+    c["out_nchw"][3, 0, 0], c["out_nchw"][3, 0, 1] = -1.0, 1.0
+    m = {"ransac": 1, "iter": 2}[mode]
+    po, ni, mo, bo = run_oracle_net(oracle_lib, c, net, mode=m, iters=iters, seed=5)
+    g = {k: torch.from_numpy(c[k]).to(dev) for k in ("out_nchw", "coord2d", "fps", "extents", "ratios", "argmax")}
+    pose, nin, msk, best = ops.ransac_kabsch(g["out_nchw"], g["coord2d"], g["fps"], g["extents"], g["ratios"], g["argmax"],
+                                             iters=iters, seed=5, net_pose=torch.from_numpy(net).to(dev), net_mode=mode)
+    torch.cuda.synchronize()
+    assert np.array_equal(best.cpu().numpy(), bo) and np.array_equal(nin.cpu().numpy(), ni)
+    assert np.array_equal(msk.cpu().numpy(), mo)
+    assert np.abs(pose.cpu().numpy() - po).max() < 1e-5
+    assert np.array_equal(pose[3].cpu().numpy(), net[3]) and np.array_equal(pose[2, 9:].cpu().numpy(), net[2, 9:])
+
+
+@pytest.mark.parametrize("pnp_type", ["net_ransac_pnp", "net_iter_pnp"])
+def test_model_pnp_type_net_variants(golden_setup, dev, oracle_lib, pnp_type):
+    """cfg.TEST.PNP_TYPE (gdrn_evaluator.py:136-145) inside GDRN.forward: equals the C oracle run on the model's own maps and
+    its own decoded pose."""
+    from tests.test_ransac_oracle import run_oracle_net
+
+    models, t, _ = golden_setup
+    model = models["none"]
+    model.cfg.TEST.USE_PNP, model.cfg.TEST.PNP_TYPE, model.cfg.TEST.PNP_INLIER_THR = True, pnp_type, 0.05
+    try:
+        o = _run(model, t)
+    finally:
+        model.cfg.TEST.USE_PNP, model.cfg.TEST.PNP_TYPE = False, "ransac_pnp"
+    plan = model.plan(4, dev)
+    c = dict(out_nchw=plan.out_nchw.cpu().numpy().reshape(4, 37, 4096), coord2d=t["roi_coord_2d"].cpu().numpy().reshape(4, 5, 4096),
+             fps=t["fps"].cpu().numpy(), extents=t["roi_extent"].cpu().numpy(), ratios=t["resize_ratio"].cpu().numpy(),
+             argmax=plan.argmax.cpu().numpy(), B=4, HW=4096, K=32)
+    net = np.concatenate([o["rot"].cpu().numpy().reshape(4, 9), o["trans"].cpu().numpy()], 1)
+    po, ni, mo, bo = run_oracle_net(oracle_lib, c, net, mode=1 if pnp_type == "net_ransac_pnp" else 2, inlier_thr=0.05, iters=20, seed=0)
+    assert np.array_equal(o["pnp_num_inliers"].cpu().numpy(), ni) and np.array_equal(o["pnp_inlier_mask"].cpu().numpy(), mo)
+    assert np.abs(o["pnp_pose"].cpu().numpy() - po).max() < 1e-4
