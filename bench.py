@@ -177,6 +177,8 @@ def train_bench(args, rank, world, device, dist):
     B = args.batch if args.batch != 64 else 32
     model, _ = build_model(device, "mul")
     model.cfg.TEST.USE_PNP = False
+    amp = args.dtype == "bf16"
+    model.cfg.SOLVER.AMP.ENABLED = amp  # --dtype bf16: mixed precision (bf16 fwd/dgrad convolutions, fp32 everything else)
     eng = model.train_engine(B, device)
     buckets = GradBuckets(model)
     order = [p for g in ("pnp_net", "rot_head_net", "backbone") for p in getattr(model, g).parameters()]
@@ -216,8 +218,9 @@ def train_bench(args, rank, world, device, dist):
             "metric": "RGB-D crops/sec, TRAINING step (fwd+losses+bwd+allreduce+Ranger) at 256x256", "value": round(value, 1),
             "unit": "crops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "LM-O style training step, MASK_ATTENTION=mul, K=32, ResNet-34, fp32, per-GPU BatchNorm",
+            "dtype": "bf16 convolutions (fwd + dgrad), fp32 BN / losses / wgrad / optimizer" if amp else "f32", "data": "synthetic",
+            "config": {"workload": "LM-O style training step, MASK_ATTENTION=mul, K=32, ResNet-34, per-GPU BatchNorm, "
+                                   + ("SOLVER.AMP.ENABLED" if amp else "fp32"),
                        "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": f"dp{world}: flat gradient buffer, 3 bucketed RCCL all-reduces overlapped with backward, fused HIP Ranger"},
             "achieved_tflops_whole_step": round(132.3e9 * value / 1e12, 2),

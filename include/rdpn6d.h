@@ -91,8 +91,8 @@ void rdpn6d_conv_force_tile(int bm, int bn);
 void rdpn6d_conv_set_tap_inner(int v);
 
 /* Reduced-precision mode of the same operator (the reference's autocast path: engine.py:279, gdrn_evaluator.py:625):
- * x, w, res are bf16 (16-bit) arrays, y is bf16 or - when out_f32 != 0 - fp32; scale/shift are fp32; all channel
- * strides/offsets are in elements.  Cin % 32 == 0, in_cs % 8 == 0, in_co % 8 == 0.  fp32 accumulation on
+ * x and w are bf16 (16-bit) arrays; y and res are bf16 or - when out_f32 != 0 - both fp32; scale/shift are fp32; all
+ * channel strides/offsets are in elements.  Cin % 32 == 0, in_cs % 8 == 0, in_co % 8 == 0.  fp32 accumulation on
  * v_mfma_f32_32x32x16_bf16, one rounding (RNE) on the store. */
 int rdpn6d_conv2d_bf16(const rdpn6d_conv_desc* d, int out_f32, void* stream);
 void rdpn6d_conv_bf16_force_tile(int bm, int bn);
@@ -106,6 +106,10 @@ int rdpn6d_upsample_bilinear_bf16(const void* x, int B, int H, int W, int C, int
 int rdpn6d_xyz_subsample_bf16(const float* x, int B, int xc, int R, int step, void* y, int out_cs, int out_co,
                               void* stream);
 int rdpn6d_global_max_concat_bf16(void* buf, int B, int HW, int C, int cs, void* stream);
+/* fp32 NHWC channel slice -> compact bf16 NHWC (RNE): dst[p][c] = src[p*src_cs + src_co + c] for c < C, 0 for
+ * C <= c < dst_cs (dst_cs % 8 == 0).  Feeds the bf16 convolutions of the mixed-precision training step. */
+int rdpn6d_cast_f32_bf16(const float* src, int src_cs, int src_co, int C, void* dst, int dst_cs, long long npix,
+                         void* stream);
 
 /* ------------------------------------------------------------------ stem & point-wise kernels
  * conv1 7x7/2 + BN + ReLU on channels 0..2 of the NCHW 6-channel crop (resnet_backbone.py:272,

@@ -50,6 +50,7 @@ SIGNATURES = {
     "rdpn6d_upsample_bilinear_bf16": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "rdpn6d_xyz_subsample_bf16": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "rdpn6d_global_max_concat_bf16": (_i, [_vp, _i, _i, _i, _i, _vp]),
+    "rdpn6d_cast_f32_bf16": (_i, [_vp, _i, _i, _i, _vp, _i, ctypes.c_longlong, _vp]),
     "rdpn6d_stem_conv7x7_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "rdpn6d_maxpool3x3s2_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "rdpn6d_upsample_bilinear_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -32,7 +32,7 @@ struct ConvBArgs {
     int out_f32;
     unsigned x_bytes, w_bytes;
     unsigned long long dy_pack, dx_pack;
-    int vec_out;  // bf16 output with 16-byte aligned channel slices (out / residual): coalesced epilogue through LDS
+    int vec_out;  // 16-byte aligned output / residual channel slices: coalesced epilogue through LDS
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -258,12 +258,18 @@ __global__ __launch_bounds__(64 * WM * WN, NST == 2 ? 2 : 1) void conv_igemm_bf1
     if (a.vec_out && n0 + BN <= d.N && m0 + BM <= a.M) {
         constexpr int WC = BN / WN;       // channels per wave tile
         constexpr int CS = WC + 8;        // LDS row stride in floats (+32 B: the two half-waves hit disjoint banks)
-        constexpr int LPR = WC / 8;       // lanes per pixel row on the way back
-        constexpr int RPI = 64 / LPR;     // pixel rows per wave instruction
         __syncthreads();                  // every wave is done with the staging buffers (and no DMA is still landing)
         float* cst = reinterpret_cast<float*>(smem) + wave * (32 * CS);
-        const int rrow = lane / LPR, c8 = (lane % LPR) * 8;
         const int nb = n0 + wn * WC;
+        auto pixel_of = [&](const long long m) -> long long {
+            if (a.linear_out) return m;
+            const int mm = (int)m;
+            const int b = mm / a.HoWo;
+            const int rem = mm - b * a.HoWo;
+            const int oy = rem / d.Wo;
+            const int ox = rem - oy * d.Wo;
+            return ((long long)b * d.OH + (oy * d.osy + d.ooy)) * d.OW + (ox * d.osx + d.oox);
+        };
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -275,36 +281,49 @@ __global__ __launch_bounds__(64 * WM * WN, NST == 2 ? 2 : 1) void conv_igemm_bf1
                 for (int e = 0; e < 16; ++e)
                     cst[((e & 3) + 8 * (e >> 2) + 4 * hi) * CS + j * 32 + frow] = acc[i][j][e] * sc + sh;
             }
+            if (a.out_f32) {  // fp32 output (training: raw conv results / input gradients): 4 channels = 16 bytes per lane
+                constexpr int LPR = WC / 4, RPI = 64 / LPR;
+                const int rrow = lane / LPR, c4 = (lane % LPR) * 4;
 #pragma unroll
-            for (int rr = 0; rr < 32 / RPI; ++rr) {
-                const int row = rr * RPI + rrow;
-                const long long m = m0 + wm * (BM / WM) + i * 32 + row;
-                long long pix;
-                if (a.linear_out) {
-                    pix = m;
-                } else {
-                    const int mm = (int)m;
-                    const int b = mm / a.HoWo;
-                    const int rem = mm - b * a.HoWo;
-                    const int oy = rem / d.Wo;
-                    const int ox = rem - oy * d.Wo;
-                    pix = ((long long)b * d.OH + (oy * d.osy + d.ooy)) * d.OW + (ox * d.osx + d.oox);
-                }
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(cst + row * CS + c8);
-                const f32x4 hi4 = *reinterpret_cast<const f32x4*>(cst + row * CS + c8 + 4);
-                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
-                if (resb) {
-                    float rv[8];
-                    rd_unpack8(*reinterpret_cast<const rd_u32x4*>(resb + pix * d.res_cs + d.res_co + nb + c8), rv);
+                for (int rr = 0; rr < 32 / RPI; ++rr) {
+                    const int row = rr * RPI + rrow;
+                    const long long pix = pixel_of(m0 + wm * (BM / WM) + i * 32 + row);
+                    f32x4 v = *reinterpret_cast<const f32x4*>(cst + row * CS + c4);
+                    if (d.res) {
+                        const f32x4 rv = *reinterpret_cast<const f32x4*>(d.res + pix * d.res_cs + d.res_co + nb + c4);
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) v[q] += rv[q];
-                }
+                        for (int q = 0; q < 4; ++q) v[q] += rv[q];
+                    }
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    if (d.act == 1) v[q] = v[q] > 0.f ? v[q] : 0.f;
-                    else if (d.act == 2) v[q] = v[q] > 0.f ? v[q] : v[q] * d.slope;
+                    for (int q = 0; q < 4; ++q) {
+                        if (d.act == 1) v[q] = v[q] > 0.f ? v[q] : 0.f;
+                        else if (d.act == 2) v[q] = v[q] > 0.f ? v[q] : v[q] * d.slope;
+                    }
+                    *reinterpret_cast<f32x4*>(d.y + pix * d.out_cs + d.out_co + nb + c4) = v;
                 }
-                *reinterpret_cast<rd_u32x4*>(yb + pix * d.out_cs + d.out_co + nb + c8) = rd_pack8(v);
+            } else {
+                constexpr int LPR = WC / 8, RPI = 64 / LPR;
+                const int rrow = lane / LPR, c8 = (lane % LPR) * 8;
+#pragma unroll
+                for (int rr = 0; rr < 32 / RPI; ++rr) {
+                    const int row = rr * RPI + rrow;
+                    const long long pix = pixel_of(m0 + wm * (BM / WM) + i * 32 + row);
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(cst + row * CS + c8);
+                    const f32x4 hi4 = *reinterpret_cast<const f32x4*>(cst + row * CS + c8 + 4);
+                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+                    if (resb) {
+                        float rv[8];
+                        rd_unpack8(*reinterpret_cast<const rd_u32x4*>(resb + pix * d.res_cs + d.res_co + nb + c8), rv);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] += rv[q];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        if (d.act == 1) v[q] = v[q] > 0.f ? v[q] : 0.f;
+                        else if (d.act == 2) v[q] = v[q] > 0.f ? v[q] : v[q] * d.slope;
+                    }
+                    *reinterpret_cast<rd_u32x4*>(yb + pix * d.out_cs + d.out_co + nb + c8) = rd_pack8(v);
+                }
             }
         }
         return;
@@ -333,7 +352,7 @@ __global__ __launch_bounds__(64 * WM * WN, NST == 2 ? 2 : 1) void conv_igemm_bf1
                         pix = ((long long)b * d.OH + (oy * d.osy + d.ooy)) * d.OW + (ox * d.osx + d.oox);
                     }
                     float v = acc[i][j][e] * sc + sh;
-                    if (resb) v += bf2f(resb[pix * d.res_cs + d.res_co + n]);
+                    if (d.res) v += a.out_f32 ? d.res[pix * d.res_cs + d.res_co + n] : bf2f(resb[pix * d.res_cs + d.res_co + n]);
                     if (d.act == 1) v = v > 0.f ? v : 0.f;
                     else if (d.act == 2) v = v > 0.f ? v : v * d.slope;
                     if (a.out_f32) d.y[pix * d.out_cs + d.out_co + n] = v;
@@ -422,7 +441,8 @@ extern "C" int rdpn6d_conv2d_bf16(const rdpn6d_conv_desc* d, int out_f32, void* 
     a.Ktot = d->ntaps * d->Cin;
     a.linear_out = (d->osy == 1 && d->osx == 1 && d->ooy == 0 && d->oox == 0 && d->OH == d->Ho && d->OW == d->Wo);
     a.out_f32 = out_f32 ? 1 : 0;
-    a.vec_out = (!out_f32 && d->out_cs % 8 == 0 && d->out_co % 8 == 0 && (!d->res || (d->res_cs % 8 == 0 && d->res_co % 8 == 0))) ? 1 : 0;
+    const int al = out_f32 ? 4 : 8;  // elements per 16 bytes
+    a.vec_out = (d->out_cs % al == 0 && d->out_co % al == 0 && (!d->res || (d->res_cs % al == 0 && d->res_co % al == 0))) ? 1 : 0;
     const long long xb = (long long)d->B * d->H * d->W * d->in_cs * 2;
     RD_REQUIRE(xb < (1LL << 32) - 64, "input tensor must be smaller than 4 GiB (32-bit buffer offsets)");
     a.x_bytes = (unsigned)xb;

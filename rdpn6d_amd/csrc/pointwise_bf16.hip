@@ -158,3 +158,39 @@ extern "C" int rdpn6d_global_max_concat_bf16(void* buf, int B, int HW, int C, in
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
 }
+
+// fp32 NHWC channel slice -> compact bf16 NHWC, zero-padded to dst_cs channels (one lane = 8 output channels)
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ src, int src_cs, int src_co, int C, rd_bf16_t* __restrict__ dst,
+                                     int dst_cs, long long npix, int vec)
+{
+    const int C8 = dst_cs / 8;
+    const long long total = npix * C8;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long p = i / C8;
+        const int c0 = (int)(i - p * C8) * 8;
+        const float* sp = src + p * src_cs + src_co + c0;
+        float v[8];
+        if (vec && c0 + 8 <= C) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(sp), b = *reinterpret_cast<const f32x4*>(sp + 4);
+            v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = c0 + e < C ? sp[e] : 0.f;
+        }
+        *reinterpret_cast<rd_u32x4*>(dst + p * dst_cs + c0) = rd_pack8(v);
+    }
+}
+
+extern "C" int rdpn6d_cast_f32_bf16(const float* src, int src_cs, int src_co, int C, void* dst, int dst_cs, long long npix,
+                                    void* stream)
+{
+    RD_REQUIRE(src && dst && npix > 0 && C > 0 && src_co >= 0 && src_co + C <= src_cs, "source slice");
+    RD_REQUIRE(dst_cs >= C && dst_cs % 8 == 0, "dst_cs must be a multiple of 8 >= C");
+    const int vec = (src_cs % 4 == 0 && src_co % 4 == 0) ? 1 : 0;
+    const long long total = npix * (dst_cs / 8);
+    const int blocks = (int)((total + 255) / 256 < 32768 ? (total + 255) / 256 : 32768);
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, src_cs, src_co, C,
+                       (rd_bf16_t*)dst, dst_cs, npix, vec);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}

@@ -545,9 +545,10 @@ class GDRN(nn.Module):
     def train_engine(self, B, device):
         from .train import TrainEngine
 
-        key = ("train", B, str(device))
+        amp = bool(self.cfg.get("SOLVER", {}).get("AMP", {}).get("ENABLED", False))  # common_base.py:130, engine.py:279
+        key = ("train", B, str(device), amp)
         if key not in self._plans:
-            self._plans[key] = TrainEngine(self, B, device)
+            self._plans[key] = TrainEngine(self, B, device, amp=amp)
         return self._plans[key]
 
     def _forward_train(self, x, roi_coord_2d, fps, roi_cams, roi_centers, roi_whs, roi_extents, resize_ratios, gt_xyz,

@@ -31,9 +31,17 @@ def _taps(k, pad):
 
 
 class TrainEngine:
-    def __init__(self, model, B, device):
+    def __init__(self, model, B, device, amp=False):
+        """amp=True (cfg.SOLVER.AMP.ENABLED, the reference's autocast + GradScaler switch: engine.py:279-309): the forward and
+        input-gradient convolutions of the trunk, the fusion branch and the dense head run on the bf16 matrix pipe (fp32
+        accumulation, fp32 outputs); BatchNorm, losses, ConvPnPNet, weight gradients, the optimizer and all stored
+        activations stay fp32 - the same split torch.autocast makes (convolutions low precision, normalisation fp32).
+        bf16 keeps the fp32 exponent range, so no loss scaling is needed."""
         self.lib = _lib.load()
         self.model, self.B, self.dev = model, B, device
+        self.amp = bool(amp)
+        self._casts = {}     # (address, stride, offset, channels) of an fp32 activation slice -> its bf16 copy
+        self.mirrors = []    # (bf16 tensor, fp32 packed weight) pairs refreshed with the weights
         cfg = model.cfg
         self.R = int(cfg.MODEL.CDPN.BACKBONE.INPUT_RES)
         self.K = int(cfg.MODEL.CDPN.ROT_HEAD.NUM_REGIONS)
@@ -96,9 +104,40 @@ class TrainEngine:
         assert w.shape[1] == d.ntaps and w.shape[2] == cin, (tuple(w.shape), d.ntaps, cin)
         return d
 
-    def _launch_conv(self, name, d, keep, ksplit=False):
+    def _bf16_of(self, launches, src, src_cs, src_co, C, npix, cache):
+        """compact bf16 copy [npix, pad32(C)] of an fp32 channel slice; the cast launch is appended to `launches`
+        (forward activations are cast once and shared by their consumers)"""
+        Cp = _pad_to(C, 32)
+        key = (src.data_ptr(), src_cs, src_co, C)
+        if cache and key in self._casts:
+            return self._casts[key], Cp
+        t = torch.zeros(npix, Cp, dtype=torch.bfloat16, device=self.dev)
+        lib = self.lib
+
+        def run():
+            _lib.check(lib.rdpn6d_cast_f32_bf16(_ptr(src), src_cs, src_co, C, _ptr(t), Cp, npix, self.st()), "cast bf16")
+
+        run.keep = (src, t)
+        launches.append(run)
+        if cache:
+            self._casts[key] = t
+        return t, Cp
+
+    def _mirror(self, t):
+        tb = torch.zeros(*t.shape, dtype=torch.bfloat16, device=self.dev)
+        self.mirrors.append((tb, t))
+        return tb
+
+    def _launch_conv(self, name, d, keep, ksplit=False, lowp=False):
         lib = self.lib
         from .gdrn import pick_ksplit
+
+        if lowp:
+            def run():
+                _lib.check(lib.rdpn6d_conv2d_bf16(ctypes.byref(d), 1, self.st()), name)
+
+            run.keep = (d, keep)
+            return run
 
         ks = pick_ksplit(d.B * d.Ho * d.Wo, d.Npad, d.ntaps * d.Cin // 16) if ksplit else 1
         if ks > 1:
@@ -124,6 +163,8 @@ class TrainEngine:
         with torch.no_grad():
             for t, fn in self.packed:
                 fn(t)
+            for tb, t in self.mirrors:
+                tb.copy_(t)
 
     # ------------------------------------------------------------------ layer builders
     def conv_unit(self, name, P, x, xhw, in_cs, in_co, cin_real, y, yhw, out_cs, out_co, *, stride=1, perm=None, bias=None,
@@ -134,7 +175,8 @@ class TrainEngine:
         w = P.weight
         cout, _, k, _ = w.shape
         pad = k // 2
-        cin_pad = _pad_to(cin_real, 16)
+        lowp = self.amp and not name.startswith("pnp_net")  # ConvPnPNet stays fp32 (pose regression)
+        cin_pad = _pad_to(cin_real, 32 if lowp else 16)
         npad = _pad_to(cout, 64)
         lib, B = self.lib, self.B
         # ---- forward weights
@@ -144,9 +186,16 @@ class TrainEngine:
         if bias is not None:
             bvec = self._packed((npad,), lambda t, b=bias: t[: b.numel()].copy_(b.detach().float()))
         taps = _taps(k, pad)
-        d = self._conv_desc(x, xhw, in_cs, in_co, cin_pad, wf, y, yhw, out_cs, out_co, cout, taps, stride=stride, shift=bvec,
-                            act=act_out or 0, slope=slope)
-        self.fwd.append(self._launch_conv(name, d, (wf, bvec), ksplit=True))
+        if lowp:
+            xb, _ = self._bf16_of(self.fwd, x, in_cs, in_co, cin_real, B * xhw[0] * xhw[1], cache=True)
+            wfb = self._mirror(wf)
+            d = self._conv_desc(xb, xhw, cin_pad, 0, cin_pad, wfb, y, yhw, out_cs, out_co, cout, taps, stride=stride, shift=bvec,
+                                act=act_out or 0, slope=slope)
+            self.fwd.append(self._launch_conv(name, d, (wf, wfb, bvec, xb), lowp=True))
+        else:
+            d = self._conv_desc(x, xhw, in_cs, in_co, cin_pad, wf, y, yhw, out_cs, out_co, cout, taps, stride=stride, shift=bvec,
+                                act=act_out or 0, slope=slope)
+            self.fwd.append(self._launch_conv(name, d, (wf, bvec), ksplit=True))
         # ---- backward
         dy = self.buf("d:" + name, *y.shape, zero=True)  # gradient w.r.t. the raw conv output (same layout as y)
         M = B * yhw[0] * yhw[1]
@@ -178,10 +227,23 @@ class TrainEngine:
 
         launches = [wgrad]
         if dx is not None:
-            n_red = _pad_to(cout, 16)  # reduction channels of the dgrad = output channels of the forward
-            assert out_cs - out_co >= n_red, (name, out_cs, n_red)
+            n_red = _pad_to(cout, 32 if lowp else 16)  # reduction channels of the dgrad = output channels of the forward
             cdx = _pad_to(cin_real, 64)
             dx_cs = dx_cs or in_cs
+            if lowp:
+                # the dgrad reads a compact bf16 copy of dy (cast right before it), weights from the bf16 mirror
+                g_src, g_cs, g_co = self._bf16_of(launches, dy, out_cs, out_co, cout, M, cache=False)[0], n_red, 0
+            else:
+                assert out_cs - out_co >= n_red, (name, out_cs, n_red)
+                g_src, g_cs, g_co = dy, out_cs, out_co
+
+            def dlaunch(nm, dd, wd):
+                if lowp:
+                    wdb = self._mirror(wd)
+                    dd.w = _ptr(wdb)
+                    return self._launch_conv(nm, dd, (wd, wdb, g_src), lowp=True)
+                return self._launch_conv(nm, dd, wd)
+
             if stride == 1:
                 def pk(t, w=w, perm=perm):
                     ww = w.detach().float()
@@ -189,9 +251,9 @@ class TrainEngine:
                         ww = ww[:, perm]
                     t.copy_(pack_conv_weight(ww.flip(2, 3).permute(1, 0, 2, 3), cin_pad=n_red))
                 wd = self._packed((cdx, k * k, n_red), pk)
-                dd = self._conv_desc(dy, yhw, out_cs, out_co, n_red, wd, dx, xhw, dx_cs, in_co, cin_real, taps, stride=1,
+                dd = self._conv_desc(g_src, yhw, g_cs, g_co, n_red, wd, dx, xhw, dx_cs, in_co, cin_real, taps, stride=1,
                                      res=dx_res, res_cs=dx_cs)
-                launches.append(self._launch_conv("dgrad " + name, dd, wd))
+                launches.append(dlaunch("dgrad " + name, dd, wd))
             else:
                 assert stride == 2 and perm is None
                 if k == 3:
@@ -207,17 +269,17 @@ class TrainEngine:
                                 for ti, (ky, kx) in enumerate(kk):
                                     t[: ww.shape[1], ti, : ww.shape[0]].copy_(ww[:, :, ky, kx].t())
                             wd = self._packed((cdx, len(ptaps), n_red), pk)
-                            dd = self._conv_desc(dy, yhw, out_cs, out_co, n_red, wd, dx, xhw, dx_cs, in_co, cin_real, ptaps,
+                            dd = self._conv_desc(g_src, yhw, g_cs, g_co, n_red, wd, dx, xhw, dx_cs, in_co, cin_real, ptaps,
                                                  phase=(yhw[0], yhw[1], 2, 2, py, px))
-                            launches.append(self._launch_conv(f"dgrad {name} phase{py}{px}", dd, wd))
+                            launches.append(dlaunch(f"dgrad {name} phase{py}{px}", dd, wd))
                 else:  # 1x1 stride 2: only the even pixels receive a gradient; accumulate onto what is there
                     def pk(t, w=w):
                         ww = w.detach().float()
                         t[: ww.shape[1], 0, : ww.shape[0]].copy_(ww[:, :, 0, 0].t())
                     wd = self._packed((cdx, 1, n_red), pk)
-                    dd = self._conv_desc(dy, yhw, out_cs, out_co, n_red, wd, dx, xhw, dx_cs, in_co, cin_real, [(0, 0)],
+                    dd = self._conv_desc(g_src, yhw, g_cs, g_co, n_red, wd, dx, xhw, dx_cs, in_co, cin_real, [(0, 0)],
                                          phase=(yhw[0], yhw[1], 2, 2, 0, 0), res=dx, res_cs=dx_cs)
-                    launches.append(self._launch_conv("dgrad " + name, dd, wd))
+                    launches.append(dlaunch("dgrad " + name, dd, wd))
         self.bwd.append(launches)
         return dy
 
@@ -373,11 +435,24 @@ class TrainEngine:
                     for ti, (ky, kx) in enumerate(kk):
                         t[:F, ti].copy_(ww[:, :, ky, kx].t())
                 wp = self._packed((_pad_to(F, 64), len(ptaps), 1024), pk)
-                d = self._conv_desc(feat, (R8, R8), 1024, 0, 1024, wp, rt0, (R4, R4), F, 0, F, ptaps, phase=(R8, R8, 2, 2, py, px))
-                self.fwd.append(self._launch_conv(f"convT phase{py}{px}", d, wp))
+                if self.amp:
+                    featb, _ = self._bf16_of(self.fwd, feat, 1024, 0, 1024, B * R8 * R8, cache=True)
+                    wpb = self._mirror(wp)
+                    d = self._conv_desc(featb, (R8, R8), 1024, 0, 1024, wpb, rt0, (R4, R4), F, 0, F, ptaps, phase=(R8, R8, 2, 2, py, px))
+                    self.fwd.append(self._launch_conv(f"convT phase{py}{px}", d, (wp, wpb, featb), lowp=True))
+                else:
+                    d = self._conv_desc(feat, (R8, R8), 1024, 0, 1024, wp, rt0, (R4, R4), F, 0, F, ptaps, phase=(R8, R8, 2, 2, py, px))
+                    self.fwd.append(self._launch_conv(f"convT phase{py}{px}", d, wp))
         d_rt0 = self.buf("d:head0", B, R4, R4, F, zero=True)
         wdT = self._packed((1024, 9, F), lambda t: t.copy_(pack_conv_weight(wt.detach().float())))  # ConvT weight IS the OIHW of its dgrad conv
-        ddT = self._conv_desc(d_rt0, (R4, R4), F, 0, F, wdT, d_feat, (R8, R8), 1024, 0, 1024, _taps(3, 1), stride=2)
+        convT_bwd = []
+        if self.amp:
+            assert F % 32 == 0
+            d_rt0b, _ = self._bf16_of(convT_bwd, d_rt0, F, 0, F, B * R4 * R4, cache=False)
+            wdTb = self._mirror(wdT)
+            ddT = self._conv_desc(d_rt0b, (R4, R4), F, 0, F, wdTb, d_feat, (R8, R8), 1024, 0, 1024, _taps(3, 1), stride=2)
+        else:
+            ddT = self._conv_desc(d_rt0, (R4, R4), F, 0, F, wdT, d_feat, (R8, R8), 1024, 0, 1024, _taps(3, 1), stride=2)
         wgT = self.buf("wg:convT", 1024, 9, F)
         self._wg_floats = max(self._wg_floats, int(lib.rdpn6d_wgrad_scratch_floats(B, R8, R8, 1024, F, 9)))
         t9y = (ctypes.c_int * 9)(*[t[0] for t in _taps(3, 1)])
@@ -388,7 +463,7 @@ class TrainEngine:
                                             _ptr(wgT), _ptr(self._wg_partial), self.st()), "wgrad convT")
             self._grad(wt).copy_(wgT.view(1024, 3, 3, F).permute(0, 3, 1, 2))
 
-        self.bwd.append([convT_wgrad, self._launch_conv("dgrad convT", ddT, wdT)])
+        self.bwd.append([convT_wgrad] + convT_bwd + [self._launch_conv("dgrad convT", ddT, wdT, lowp=self.amp)])
         d_prev = self.bn_unit("head.bn0", head.features[1], rt0, F, 0, F, Mh, at0, F, 0, True, dx=d_rt0)
         a_prev = at0
         nfeat = len(head.features)

@@ -153,3 +153,103 @@ def test_reference_api_do_loss_backward_and_optimizer_step(train_setup):
         hist.append(losses.item())
     print("total loss over 6 Ranger steps:", [round(h, 4) for h in hist])
     assert hist[-1] < hist[0]
+
+
+def test_amp_training_step_vs_autocast_yardstick(golden_dir):
+    """cfg.SOLVER.AMP.ENABLED (the reference's autocast switch, engine.py:279-309): bf16 forward / input-gradient convolutions,
+    fp32 everything else.  Yardstick as for the bf16 inference mode: the torch-CPU oracle under torch.autocast(bfloat16), both
+    measured against the fp64 evaluation, on the network with damped residual branches (the undamped random-weight network
+    turns any 8-bit-mantissa run into noise).  The HIP step keeps more in fp32 than autocast does (weight gradients,
+    BatchNorm, ConvPnPNet), so its losses and gradients must be at least as close to the exact ones."""
+    from oracle import model_oracle
+    from rdpn6d_amd import synth
+    from rdpn6d_amd.config import gdrn_base_cfg
+    from rdpn6d_amd.gdrn import build_model_optimizer
+
+    dev = torch.device("cuda:0")
+    inp = synth.make_inputs(4, seed=0)
+    gt = synth.make_train_gt(4, inp)
+    cfg = gdrn_base_cfg(mask_attention="mul", device="cuda")
+    cfg.SOLVER.AMP.ENABLED = True
+    model, _ = build_model_optimizer(cfg)
+    sd = synth.make_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=1234)
+    sd = {k: torch.from_numpy(np.asarray(v)).clone() for k, v in sd.items()}
+    for k in sd:
+        if k.endswith("bn2.weight"):
+            sd[k] *= 0.1
+    model.load_state_dict(sd, strict=True)
+    eng = model.train_engine(4, dev)
+    assert eng.amp and len(eng.mirrors) > 80
+    batch = {k: torch.from_numpy(v).to(dev) for k, v in {**inp, **gt}.items()}
+    losses = eng.forward_backward(batch)
+    torch.cuda.synchronize()
+    t = {k: torch.from_numpy(v) for k, v in {**inp, **gt}.items()}
+
+    def run_oracle(dtype, autocast):
+        o = model_oracle.GDRNOracle(32, "mul")
+        o.load_state_dict(sd, strict=True)
+        o = o.to(dtype).train()
+        tt = {k: (v.to(dtype) if v.dtype.is_floating_point else v) for k, v in t.items()}
+        with torch.autocast("cpu", dtype=torch.bfloat16, enabled=autocast):
+            out = o(tt["roi_img"], tt["roi_coord_2d"], tt["fps"], tt["roi_cam"], tt["roi_center"], tt["roi_wh"], tt["resize_ratio"],
+                    train_pose=True)
+            L = model_oracle.gdrn_losses({k: (v.float() if autocast and torch.is_tensor(v) and v.is_floating_point() else v)
+                                          for k, v in out.items()}, tt, tt["roi_extent"])
+        sum(L.values()).backward()
+        return o, L
+
+    o64, L64 = run_oracle(torch.float64, False)
+    oac, Lac = run_oracle(torch.float32, True)
+    tot64 = sum(v.item() for v in L64.values())
+    e_hip = abs(sum(v.item() for v in losses.values()) - tot64)
+    e_ac = abs(sum(v.item() for v in Lac.values()) - tot64)
+    print(f"total loss: fp64 {tot64:.5f} | HIP-AMP off by {e_hip:.2e} | autocast oracle off by {e_ac:.2e}")
+    r64, rac = dict(o64.named_parameters()), dict(oac.named_parameters())
+    eh, ea = [], []
+    for name, p in model.named_parameters():
+        g64 = r64[name].grad
+        n = g64.norm().item()
+        if n < 1e-4:
+            continue
+        eh.append((p.grad.cpu().double() - g64).norm().item() / n)
+        ea.append((rac[name].grad.double() - g64).norm().item() / n)
+    med_h, med_a = float(np.median(eh)), float(np.median(ea))
+    print(f"median relative gradient error vs fp64 over {len(eh)} tensors: HIP-AMP {med_h:.3e} | autocast oracle {med_a:.3e};"
+          f" worst: HIP-AMP {max(eh):.3e} | autocast {max(ea):.3e}")
+    assert med_h <= 1.1 * med_a and max(eh) <= 1.5 * max(ea)
+    assert e_hip <= 5e-3 * tot64 and e_ac <= 5e-3 * tot64  # both within 0.5 % of the exact total loss (a scalar: one noise draw)
+
+
+def test_amp_reference_loop_loss_goes_down(golden_dir):
+    from rdpn6d_amd import synth
+    from rdpn6d_amd.config import gdrn_base_cfg
+    from rdpn6d_amd.gdrn import build_model_optimizer
+    from rdpn6d_amd.ranger import Ranger
+
+    dev = torch.device("cuda:0")
+    cfg = gdrn_base_cfg(mask_attention="mul", device="cuda")
+    cfg.SOLVER.AMP.ENABLED = True
+    model, _ = build_model_optimizer(cfg)
+    bn = np.load(os.path.join(golden_dir, "bn_stats_c1.npz"))
+    sd = synth.make_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=1234)
+    sd.update({k: bn[k] for k in bn.files})
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    inp = synth.make_inputs(4, seed=0)
+    b = {k: torch.from_numpy(v).to(dev) for k, v in {**inp, **synth.make_train_gt(4, inp)}.items()}
+    opt = Ranger([p for p in model.parameters()], lr=2e-3)
+    hist = []
+    for it in range(6):
+        _, ld = model(b["roi_img"], gt_xyz=b["roi_xyz"], gt_mask_trunc=b["roi_mask_trunc"], gt_mask_visib=b["roi_mask_visib"],
+                      gt_mask_obj=b["roi_mask_obj"], gt_region=b["roi_region"], gt_ego_rot=b["ego_rot"], gt_points=b["roi_points"],
+                      sym_infos=None, gt_trans=b["trans"], gt_trans_ratio=b["roi_trans_ratio"], roi_classes=b["roi_cls"],
+                      roi_coord_2d=b["roi_coord_2d"], roi_cams=b["roi_cam"], roi_centers=b["roi_center"], roi_whs=b["roi_wh"],
+                      roi_extents=b["roi_extent"], resize_ratios=b["resize_ratio"], do_loss=True, fps=b["fps"])
+        losses = sum(ld.values())
+        assert torch.isfinite(losses).all()
+        opt.zero_grad(set_to_none=True)
+        losses.backward()
+        opt.step()
+        hist.append(losses.item())
+    assert model.train_engine(4, dev).amp
+    print("AMP: total loss over 6 Ranger steps:", [round(h, 4) for h in hist])
+    assert hist[-1] < hist[0]
