@@ -219,6 +219,12 @@ long long rdpn6d_wgrad_scratch_floats(int Bn, int Ha, int Wa, int Ca, int Cb, in
 int rdpn6d_wgrad_f32(const float* A, int a_cs, int a_co, int Ca, const float* Bg, int b_cs, int b_co, int Cb, int Bn, int Ha,
                      int Wa, int Hb, int Wb, int stride, int ntaps, const int* dy, const int* dx, float* out, float* partial,
                      void* stream);
+/* bf16 form for the mixed-precision training step: A and Bg are compact bf16 NHWC copies (channel strides / offsets in
+ * elements, multiples of 8); Ca_ld / Cb_ld = readable channels of the slices (multiples of 8, >= Ca / Cb, zero beyond the
+ * real count); fp32 accumulation, fp32 out / partial exactly as rdpn6d_wgrad_f32 (same scratch size). */
+int rdpn6d_wgrad_bf16(const void* A, int a_cs, int a_co, int Ca, int Ca_ld, const void* Bg, int b_cs, int b_co, int Cb,
+                      int Cb_ld, int Bn, int Ha, int Wa, int Hb, int Wb, int stride, int ntaps, const int* dy, const int* dx,
+                      float* out, float* partial, void* stream);
 int rdpn6d_maxpool3x3s2_backward_f32(const float* x, const float* dy, int B, int H, int W, int C, float* dx, void* stream);
 int rdpn6d_upsample_bilinear_backward_f32(const float* dy, int B, int H, int W, int C, int factor, float* dx, void* stream);
 int rdpn6d_global_max_concat_backward_f32(const float* feat, const float* dfeat, int B, int HW, int C, int cs, float* dl3,

@@ -73,6 +73,7 @@ SIGNATURES = {
     "rdpn6d_groupnorm_relu_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "rdpn6d_wgrad_scratch_floats": (_ll, [_i, _i, _i, _i, _i, _i]),
     "rdpn6d_wgrad_f32": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "rdpn6d_wgrad_bf16": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "rdpn6d_maxpool3x3s2_backward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "rdpn6d_upsample_bilinear_backward_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "rdpn6d_global_max_concat_backward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),

@@ -191,6 +191,239 @@ __global__ __launch_bounds__(256, 3) void wgrad_f32_kernel(const WgradKArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 form (mixed-precision training, cfg.SOLVER.AMP.ENABLED): operands are the compact bf16 copies of dY and X
+// that the bf16 forward / dgrad convolutions read anyway; fp32 accumulation on v_mfma_f32_32x32x16_bf16; fp32
+// partial tiles, same split-K and reduce.  The reduction index (pixels) is the SLOW index of both NHWC operands,
+// while an MFMA lane wants 8 consecutive k-values of one channel: the tiles are staged pixel-major [32 pixels][BA
+// channels] by LDS-DMA exactly as they lie in HBM and the fragments are read with the gfx950 transpose read
+// ds_read_b64_tr_b16 (each 16-lane group fetches a [4 pixels][16 channels] block, lane L receives channel L of the
+// four pixels): two reads per 8-k fragment, no ds_write, no register shuffles.  16-byte chunks of a row are
+// XOR-swizzled with the pixel index (on the DMA source address and on the read) so that the 8 row segments one
+// read cycle touches cover all 64 banks.
+struct WgradBArgs {
+    const unsigned short* A;
+    const unsigned short* Bg;
+    float* partial;
+    long long M;
+    int Ha, Wa, HaWa;
+    int Hb, Wb;
+    int stride;
+    int ntaps;
+    unsigned long long dy_pack, dx_pack;
+    int Ca, Cb;          // output extents (real channel counts)
+    int Ca_ld, Cb_ld;    // readable channels of the operand slices (multiples of 8; zero beyond the real count)
+    int a_cs, a_co, b_cs, b_co;
+    int atiles, btiles;
+    int nsplit;
+    long long rows_per_split;
+    unsigned a_bytes, b_bytes;
+};
+
+typedef short rd_s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((ext_vector_type(8))) __bf16 rd_bf16x8;
+
+__device__ __forceinline__ rd_s16x4 lds_tr_b64(const void* p)
+{
+    rd_s16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"((unsigned)(size_t)p));
+    return v;
+}
+
+template <int BA, int BB>
+__global__ __launch_bounds__(256, 3) void wgrad_bf16_kernel(const WgradBArgs a)
+{
+    constexpr int KP = 32;                       // pixels per chunk (two k16 MFMA steps)
+    constexpr int TA = BA / 64, TB = BB / 64;    // 32x32 tiles per wave (2x2 waves)
+    constexpr int NST = 3;
+    constexpr int ARB = BA * 2, BRB = BB * 2;    // row bytes
+    __shared__ __attribute__((aligned(1024))) unsigned char As[NST][KP * ARB];
+    __shared__ __attribute__((aligned(1024))) unsigned char Bs[NST][KP * BRB];
+
+    const int ntile = a.atiles * a.btiles * a.ntaps;
+    const int nblk = ntile * a.nsplit;
+    const int bid = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, kk = bid >> 3;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + kk;
+    const int tile = logical % ntile;
+    const int split = logical / ntile;
+    const int at = tile % a.atiles;
+    const int rest = tile / a.atiles;
+    const int bt = rest % a.btiles;
+    const int tap = rest / a.btiles;
+    const int a0 = at * BA, b0 = bt * BB;
+    const int dy = (int)((a.dy_pack >> (4 * tap)) & 15ull) - 8, dx = (int)((a.dx_pack >> (4 * tap)) & 15ull) - 8;
+    const long long m_lo = (long long)split * a.rows_per_split;
+    const long long m_hi = m_lo + a.rows_per_split < a.M ? m_lo + a.rows_per_split : a.M;
+    const int nchunks = m_hi > m_lo ? (int)((m_hi - m_lo + KP - 1) / KP) : 0;
+
+    const __amdgpu_buffer_rsrc_t asrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.A), 0, a.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t bsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.Bg), 0, a.b_bytes, 0x00020000);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // DMA geometry: one wave instruction = 1 KiB = AROWS pixel rows; lane -> (row, physical 16-byte chunk).  The
+    // chunk a lane FETCHES is the physical chunk XOR swz(row): swz = 4 * ((row / rows-per-256-bytes) mod (chunks/4)).
+    constexpr int ACH = ARB / 16, BCH = BRB / 16;                 // chunks per row (16 | 8)
+    constexpr int AROWS = 64 / ACH, BROWS = 64 / BCH;             // rows per piece (4 | 8)
+    constexpr int APIECES = KP / AROWS / 4, BPIECES = KP / BROWS / 4;
+    auto swz = [](int row, int ch) { return ch == 16 ? 4 * (row & 3) : 4 * ((row >> 1) & 1); };
+    const int ar = lane / ACH, aq = lane % ACH, br = lane / BCH, bq = lane % BCH;
+
+    int b_ox[BPIECES], b_oy[BPIECES], b_bi[BPIECES];
+#pragma unroll
+    for (int p = 0; p < BPIECES; ++p) {
+        const long long m = m_lo + (wave + 4 * p) * BROWS + br;
+        const int mm = m < a.M ? (int)m : 0;
+        b_bi[p] = mm / a.HaWa;
+        const int rem = mm - b_bi[p] * a.HaWa;
+        b_oy[p] = rem / a.Wa;
+        b_ox[p] = rem - b_oy[p] * a.Wa;
+    }
+    const unsigned a_row_bytes = (unsigned)a.a_cs * 2u, b_px_bytes = (unsigned)a.b_cs * 2u;
+    long long ld_m = m_lo;
+    auto stage_chunk = [&](const int st) {
+#pragma unroll
+        for (int p = 0; p < APIECES; ++p) {
+            const int row0 = (wave + 4 * p) * AROWS;
+            const int row = row0 + ar;
+            const int lq = aq ^ swz(row, ACH);                      // logical chunk fetched into physical slot aq
+            const long long m = ld_m + row;
+            const bool ok = m < m_hi && a0 + lq * 8 < a.Ca_ld;
+            const unsigned off = ok ? (unsigned)m * a_row_bytes + (unsigned)(a.a_co + a0 + lq * 8) * 2u : a.a_bytes;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(asrc, (lds_ptr_t)&As[st][row0 * ARB], 16, (int)off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int p = 0; p < BPIECES; ++p) {
+            const int row0 = (wave + 4 * p) * BROWS;
+            const int row = row0 + br;
+            const int lq = bq ^ swz(row, BCH);
+            const long long m = ld_m + row;
+            const int iy = b_oy[p] * a.stride + dy, ix = b_ox[p] * a.stride + dx;
+            const bool ok = m < m_hi && b0 + lq * 8 < a.Cb_ld && (unsigned)iy < (unsigned)a.Hb && (unsigned)ix < (unsigned)a.Wb;
+            const unsigned off = ok ? (unsigned)((b_bi[p] * a.Hb + iy) * a.Wb + ix) * b_px_bytes + (unsigned)(a.b_co + b0 + lq * 8) * 2u
+                                    : a.b_bytes;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(bsrc, (lds_ptr_t)&Bs[st][row0 * BRB], 16, (int)off, 0, 0, 0);
+            b_ox[p] += KP;
+            while (b_ox[p] >= a.Wa) { b_ox[p] -= a.Wa; if (++b_oy[p] == a.Ha) { b_oy[p] = 0; ++b_bi[p]; } }
+        }
+        ld_m += KP;
+    };
+
+    const int wa = wave >> 1, wb = wave & 1;
+    // transpose-read geometry: 16-lane group g: channel block (g & 1) * 16 of the 32-wide MFMA tile, k-block kb = g >> 1;
+    // lane L of the group addresses pixel row kb*8 + L/4 (+4 for the second read), channels (L%4)*4.. of its block
+    const int g = lane >> 4, L = lane & 15;
+    const int trow = (g >> 1) * 8 + (L >> 2);
+    const int tcol = (g & 1) * 16 + (L & 3) * 4;  // channel offset inside the 32-channel tile
+    auto frag_addr = [&](const unsigned char* base, int rowbytes, int nch, int row, int ch) {
+        const int chunk = (ch >> 3) ^ swz(row, nch);
+        return base + row * rowbytes + chunk * 16 + (ch & 7) * 2;
+    };
+
+    f32x16 acc[TA][TB];
+#pragma unroll
+    for (int i = 0; i < TA; ++i)
+#pragma unroll
+        for (int j = 0; j < TB; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // fragments of one chunk, flat: A piece (tile i, k16 step s, half h) at (i*2+s)*2+h, B pieces after the A pieces
+    constexpr int NF = (TA + TB) * 4;
+    auto read_frags = [&](int st, rd_s16x4 (&f)[NF]) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int row = s * 16 + trow + h * 4;
+#pragma unroll
+                for (int i = 0; i < TA; ++i)
+                    f[(i * 2 + s) * 2 + h] = lds_tr_b64(frag_addr(As[st], ARB, ACH, row, wa * (BA / 2) + i * 32 + tcol));
+#pragma unroll
+                for (int j = 0; j < TB; ++j)
+                    f[TA * 4 + (j * 2 + s) * 2 + h] = lds_tr_b64(frag_addr(Bs[st], BRB, BCH, row, wb * (BB / 2) + j * 32 + tcol));
+            }
+    };
+    // The transpose reads are inline asm, invisible to the compiler's wait-count insertion: one s_waitcnt that formally
+    // (re)defines every fragment register, so that no consumer can be scheduled ahead of it.
+    auto settle = [&](rd_s16x4 (&f)[NF]) {
+        if constexpr (NF == 16)
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]), "+v"(f[8]),
+                           "+v"(f[9]), "+v"(f[10]), "+v"(f[11]), "+v"(f[12]), "+v"(f[13]), "+v"(f[14]), "+v"(f[15]));
+        else if constexpr (NF == 12)
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]), "+v"(f[8]),
+                           "+v"(f[9]), "+v"(f[10]), "+v"(f[11]));
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]));
+    };
+    auto mma = [&](const rd_s16x4 (&f)[NF]) {
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < TA; ++i) {
+                const s16x8 av = __builtin_shufflevector(f[(i * 2 + s) * 2], f[(i * 2 + s) * 2 + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                for (int j = 0; j < TB; ++j) {
+                    const s16x8 bv = __builtin_shufflevector(f[TA * 4 + (j * 2 + s) * 2], f[TA * 4 + (j * 2 + s) * 2 + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(rd_bf16x8, av),
+                                                                         __builtin_bit_cast(rd_bf16x8, bv), acc[i][j], 0, 0, 0);
+                }
+            }
+    };
+
+    if (nchunks > 0) {
+        stage_chunk(0);
+        stage_chunk(1);
+        __syncthreads();
+        rd_s16x4 f0[NF], f1[NF];
+        read_frags(0, f0);
+        settle(f0);
+        int st_next = 1, st_stage = 2;
+        const int npairs = nchunks >> 1;
+        for (int pr = 0; pr < npairs; ++pr) {
+            // step: fragment reads of the next chunk (async), DMA of the chunk after it, MFMAs of the current chunk,
+            // then wait for the reads and for the DMA (the barrier's vmcnt(0))
+            read_frags(st_next, f1);
+            stage_chunk(st_stage);
+            mma(f0);
+            settle(f1);
+            __syncthreads();
+            st_next = st_next == NST - 1 ? 0 : st_next + 1;
+            st_stage = st_stage == NST - 1 ? 0 : st_stage + 1;
+
+            read_frags(st_next, f0);
+            stage_chunk(st_stage);
+            mma(f1);
+            settle(f0);
+            __syncthreads();
+            st_next = st_next == NST - 1 ? 0 : st_next + 1;
+            st_stage = st_stage == NST - 1 ? 0 : st_stage + 1;
+        }
+        if (nchunks & 1) mma(f0);
+    }
+
+    const int frow = lane & 31, hi = lane >> 5;
+    float* po = a.partial + (long long)split * a.Ca * a.ntaps * a.Cb;
+#pragma unroll
+    for (int j = 0; j < TB; ++j) {
+        const int bch = b0 + wb * (BB / 2) + j * 32 + frow;
+        if (bch >= a.Cb) continue;
+#pragma unroll
+        for (int i = 0; i < TA; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ach = a0 + wa * (BA / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                if (ach < a.Ca) po[((long long)ach * a.ntaps + tap) * a.Cb + bch] = acc[i][j][e];
+            }
+    }
+}
+
 __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int S, long long n, float* __restrict__ out)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -271,6 +504,55 @@ extern "C" int rdpn6d_wgrad_f32(const float* A, int a_cs, int a_co, int Ca, cons
     else if (ba == 128) hipLaunchKernelGGL((wgrad_f32_kernel<128, 64>), grid, block, 0, s, a);
     else if (bb == 128) hipLaunchKernelGGL((wgrad_f32_kernel<64, 128>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((wgrad_f32_kernel<64, 64>), grid, block, 0, s, a);
+    RD_LAUNCH_CHECK();
+    const long long n = (long long)Ca * ntaps * Cb;
+    const int rblocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rblocks), dim3(256), 0, s, partial, S, n, out);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}
+
+// bf16 operands (compact NHWC copies, channel strides/offsets in elements, multiples of 8); Ca_ld / Cb_ld = readable
+// channels of the slices (>= Ca / Cb, zero beyond the real count); out / partial as rdpn6d_wgrad_f32
+extern "C" int rdpn6d_wgrad_bf16(const void* A, int a_cs, int a_co, int Ca, int Ca_ld, const void* Bg, int b_cs, int b_co, int Cb,
+                                 int Cb_ld, int Bn, int Ha, int Wa, int Hb, int Wb, int stride, int ntaps, const int* dy,
+                                 const int* dx, float* out, float* partial, void* stream)
+{
+    RD_REQUIRE(A && Bg && out && partial && dy && dx, "null pointer");
+    RD_REQUIRE(Bn > 0 && Ha > 0 && Wa > 0 && Hb > 0 && Wb > 0 && stride >= 1, "shape");
+    RD_REQUIRE(Ca > 0 && Cb > 0 && Ca % 4 == 0 && Cb % 4 == 0, "channel counts must be multiples of 4");
+    RD_REQUIRE(Ca_ld >= Ca && Cb_ld >= Cb && Ca_ld % 8 == 0 && Cb_ld % 8 == 0, "readable channel counts: multiples of 8 >= the real ones");
+    RD_REQUIRE(a_cs % 8 == 0 && a_co % 8 == 0 && b_cs % 8 == 0 && b_co % 8 == 0, "channel slices must be 16-byte aligned");
+    RD_REQUIRE(a_co + Ca_ld <= a_cs && b_co + Cb_ld <= b_cs, "channel slices");
+    RD_REQUIRE(ntaps >= 1 && ntaps <= 9, "ntaps in 1..9");
+    WgradBArgs a;
+    a.A = (const unsigned short*)A; a.Bg = (const unsigned short*)Bg; a.partial = partial;
+    a.M = (long long)Bn * Ha * Wa;
+    RD_REQUIRE(a.M < (1LL << 31), "pixel count must fit 31 bits");
+    a.Ha = Ha; a.Wa = Wa; a.HaWa = Ha * Wa; a.Hb = Hb; a.Wb = Wb; a.stride = stride; a.ntaps = ntaps;
+    a.dy_pack = a.dx_pack = 0;
+    for (int t = 0; t < ntaps; ++t) {
+        RD_REQUIRE(dy[t] >= -8 && dy[t] <= 7 && dx[t] >= -8 && dx[t] <= 7, "tap offsets must be in -8..7");
+        a.dy_pack |= (unsigned long long)(dy[t] + 8) << (4 * t);
+        a.dx_pack |= (unsigned long long)(dx[t] + 8) << (4 * t);
+    }
+    a.Ca = Ca; a.Cb = Cb; a.Ca_ld = Ca_ld; a.Cb_ld = Cb_ld; a.a_cs = a_cs; a.a_co = a_co; a.b_cs = b_cs; a.b_co = b_co;
+    const long long ab = a.M * a_cs * 2, bb_ = (long long)Bn * Hb * Wb * b_cs * 2;
+    RD_REQUIRE(ab < (1LL << 32) - 64 && bb_ < (1LL << 32) - 64, "operands must be smaller than 4 GiB (32-bit buffer offsets)");
+    a.a_bytes = (unsigned)ab; a.b_bytes = (unsigned)bb_;
+    const int ba = Ca > 64 ? 128 : 64, bb = Cb > 64 ? 128 : 64;
+    a.atiles = (Ca + ba - 1) / ba;
+    a.btiles = (Cb + bb - 1) / bb;
+    const int tiles = a.atiles * a.btiles * ntaps;
+    const int S = wgrad_pick_splits(a.M, tiles, ba, bb);  // same split count (and scratch size) as the fp32 form
+    a.rows_per_split = ((a.M + S - 1) / S + 31) / 32 * 32;
+    hipStream_t s = (hipStream_t)stream;
+    a.nsplit = S;
+    dim3 grid(tiles * S), block(256);
+    if (ba == 128 && bb == 128) hipLaunchKernelGGL((wgrad_bf16_kernel<128, 128>), grid, block, 0, s, a);
+    else if (ba == 128) hipLaunchKernelGGL((wgrad_bf16_kernel<128, 64>), grid, block, 0, s, a);
+    else if (bb == 128) hipLaunchKernelGGL((wgrad_bf16_kernel<64, 128>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((wgrad_bf16_kernel<64, 64>), grid, block, 0, s, a);
     RD_LAUNCH_CHECK();
     const long long n = (long long)Ca * ntaps * Cb;
     const int rblocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);

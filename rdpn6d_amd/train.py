@@ -211,10 +211,21 @@ class TrainEngine:
             inv_perm[torch.tensor(perm)] = torch.arange(len(perm))
             inv_perm = inv_perm.to(self.dev)
 
+        launches = []
+        if lowp:
+            # compact bf16 copy of dy: read by the weight-gradient kernel and by the input-gradient convolution
+            n_red_b = _pad_to(cout, 32)
+            dyb = self._bf16_of(launches, dy, out_cs, out_co, cout, M, cache=False)[0]
+
         def wgrad():
-            _lib.check(lib.rdpn6d_wgrad_f32(_ptr(dy), out_cs, out_co, ca, _ptr(x), in_cs, in_co, cb, B, yhw[0], yhw[1], xhw[0],
-                                            xhw[1], stride, k * k, tdy, tdx, _ptr(wg_out), _ptr(self._wg_partial), self.st()),
-                       "wgrad " + name)
+            if lowp:
+                _lib.check(lib.rdpn6d_wgrad_bf16(_ptr(dyb), n_red_b, 0, ca, n_red_b, _ptr(xb), cin_pad, 0, cb, cin_pad, B, yhw[0], yhw[1],
+                                                 xhw[0], xhw[1], stride, k * k, tdy, tdx, _ptr(wg_out), _ptr(self._wg_partial),
+                                                 self.st()), "wgrad " + name)
+            else:
+                _lib.check(lib.rdpn6d_wgrad_f32(_ptr(dy), out_cs, out_co, ca, _ptr(x), in_cs, in_co, cb, B, yhw[0], yhw[1], xhw[0],
+                                                xhw[1], stride, k * k, tdy, tdx, _ptr(wg_out), _ptr(self._wg_partial), self.st()),
+                           "wgrad " + name)
             g = wg_out[:cout, :, :cin_real].view(cout, k, k, cin_real).permute(0, 3, 1, 2)
             if inv_perm is not None:
                 g = g[:, inv_perm]
@@ -225,14 +236,13 @@ class TrainEngine:
                                                       self.st()), "bias grad " + name)
                 self._grad(bias).copy_(bg[:cout])
 
-        launches = [wgrad]
+        launches.append(wgrad)
         if dx is not None:
             n_red = _pad_to(cout, 32 if lowp else 16)  # reduction channels of the dgrad = output channels of the forward
             cdx = _pad_to(cin_real, 64)
             dx_cs = dx_cs or in_cs
             if lowp:
-                # the dgrad reads a compact bf16 copy of dy (cast right before it), weights from the bf16 mirror
-                g_src, g_cs, g_co = self._bf16_of(launches, dy, out_cs, out_co, cout, M, cache=False)[0], n_red, 0
+                g_src, g_cs, g_co = dyb, n_red, 0   # the bf16 copy made for the weight gradient; weights from the bf16 mirror
             else:
                 assert out_cs - out_co >= n_red, (name, out_cs, n_red)
                 g_src, g_cs, g_co = dy, out_cs, out_co
@@ -459,11 +469,15 @@ class TrainEngine:
         t9x = (ctypes.c_int * 9)(*[t[1] for t in _taps(3, 1)])
 
         def convT_wgrad():
-            _lib.check(lib.rdpn6d_wgrad_f32(_ptr(feat), 1024, 0, 1024, _ptr(d_rt0), F, 0, F, B, R8, R8, R4, R4, 2, 9, t9y, t9x,
-                                            _ptr(wgT), _ptr(self._wg_partial), self.st()), "wgrad convT")
+            if self.amp:
+                _lib.check(lib.rdpn6d_wgrad_bf16(_ptr(featb), 1024, 0, 1024, 1024, _ptr(d_rt0b), F, 0, F, F, B, R8, R8, R4, R4, 2, 9, t9y,
+                                                 t9x, _ptr(wgT), _ptr(self._wg_partial), self.st()), "wgrad convT")
+            else:
+                _lib.check(lib.rdpn6d_wgrad_f32(_ptr(feat), 1024, 0, 1024, _ptr(d_rt0), F, 0, F, B, R8, R8, R4, R4, 2, 9, t9y, t9x,
+                                                _ptr(wgT), _ptr(self._wg_partial), self.st()), "wgrad convT")
             self._grad(wt).copy_(wgT.view(1024, 3, 3, F).permute(0, 3, 1, 2))
 
-        self.bwd.append([convT_wgrad] + convT_bwd + [self._launch_conv("dgrad convT", ddT, wdT, lowp=self.amp)])
+        self.bwd.append(convT_bwd + [convT_wgrad, self._launch_conv("dgrad convT", ddT, wdT, lowp=self.amp)])
         d_prev = self.bn_unit("head.bn0", head.features[1], rt0, F, 0, F, Mh, at0, F, 0, True, dx=d_rt0)
         a_prev = at0
         nfeat = len(head.features)

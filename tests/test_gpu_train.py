@@ -253,3 +253,55 @@ def test_amp_reference_loop_loss_goes_down(golden_dir):
     assert model.train_engine(4, dev).amp
     print("AMP: total loss over 6 Ranger steps:", [round(h, 4) for h in hist])
     assert hist[-1] < hist[0]
+
+
+@pytest.mark.parametrize("case", [
+    # Bn, Ha, Hb, stride, Ca, Cb, k
+    (2, 16, 16, 1, 128, 128, 3),
+    (3, 8, 16, 2, 128, 64, 3),
+    (2, 16, 16, 1, 64, 96, 1),     # Cb not a multiple of the tile, 1x1
+    (1, 64, 64, 1, 256, 256, 3),   # several tiles, several splits
+    (5, 7, 7, 1, 36, 68, 3),       # ragged everything (channels multiples of 4 only)
+])
+def test_wgrad_bf16_vs_fp32_kernel(case):
+    """bf16 weight-gradient kernel (transpose LDS reads) vs the fp32 kernel on the same bf16-valued operands: products are exact
+    in fp32, only the summation order differs."""
+    import ctypes
+    from rdpn6d_amd import _lib
+    from rdpn6d_amd.gdrn import _pad_to, _ptr
+
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    Bn, Ha, Hb, stride, Ca, Cb, k = case
+    g = torch.Generator().manual_seed(sum(case))
+    Cap, Cbp = _pad_to(Ca, 32), _pad_to(Cb, 32)
+    dy = torch.zeros(Bn, Ha, Ha, Cap)
+    dy[..., :Ca] = torch.randn(Bn, Ha, Ha, Ca, generator=g)
+    x = torch.zeros(Bn, Hb, Hb, Cbp)
+    x[..., :Cb] = torch.randn(Bn, Hb, Hb, Cb, generator=g)
+    dyb, xb = dy.to(dev).bfloat16(), x.to(dev).bfloat16()
+    dyf, xf = dyb.float().contiguous(), xb.float().contiguous()
+    pad = k // 2
+    taps = [(ky - pad, kx - pad) for ky in range(k) for kx in range(k)]
+    tdy = (ctypes.c_int * 9)(*[t[0] for t in taps] + [0] * (9 - len(taps)))
+    tdx = (ctypes.c_int * 9)(*[t[1] for t in taps] + [0] * (9 - len(taps)))
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    scr = torch.empty(int(lib.rdpn6d_wgrad_scratch_floats(Bn, Ha, Ha, Ca, Cb, len(taps))), device=dev)
+    o32 = torch.full((Ca, len(taps), Cb), 7.0, device=dev)
+    o16 = torch.full((Ca, len(taps), Cb), 7.0, device=dev)
+    _lib.check(lib.rdpn6d_wgrad_f32(_ptr(dyf), Cap, 0, Ca, _ptr(xf), Cbp, 0, Cb, Bn, Ha, Ha, Hb, Hb, stride, len(taps), tdy, tdx,
+                                    _ptr(o32), _ptr(scr), st))
+    _lib.check(lib.rdpn6d_wgrad_bf16(_ptr(dyb), Cap, 0, Ca, Cap, _ptr(xb), Cbp, 0, Cb, Cbp, Bn, Ha, Ha, Hb, Hb, stride, len(taps), tdy,
+                                     tdx, _ptr(o16), _ptr(scr), st))
+    torch.cuda.synchronize()
+    # independent check of the fp32 kernel itself (and therefore of both) against autograd's weight gradient
+    xt = xf[..., :Cb].permute(0, 3, 1, 2).double().cpu().requires_grad_(False)
+    w = torch.zeros(Ca, Cb, k, k, dtype=torch.float64, requires_grad=True)
+    y = torch.nn.functional.conv2d(xt, w, stride=stride, padding=pad)
+    y.backward(dyf[..., :Ca].permute(0, 3, 1, 2).double().cpu())
+    ref = w.grad.permute(0, 2, 3, 1).reshape(Ca, k * k, Cb)
+    scale = ref.abs().max().item()
+    e32 = (o32.cpu().double() - ref).abs().max().item() / scale
+    e16 = (o16.cpu().double() - ref).abs().max().item() / scale
+    print(f"{case}: fp32 kernel {e32:.2e}, bf16 kernel {e16:.2e} (relative to max |dW| = {scale:.3g})")
+    assert e32 < 1e-5 and e16 < 1e-5
