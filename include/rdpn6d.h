@@ -252,6 +252,9 @@ int rdpn6d_ranger_step_f32(float* param, const float* grad, float* exp_avg, floa
                            void* stream);
 int rdpn6d_act_backward_f32(float* dy, const float* y, long long n, float slope, void* stream);
 int rdpn6d_rgb_to_nhwc4_f32(const float* x, int B, int xc, int R, float* y, void* stream);
+/* patch matrix of the stem for its weight gradient: out [B*(R/2)^2][160], column (ky*7+kx)*3+c = x[b][c][2oy-3+ky][2ox-3+kx]
+ * (0 outside the image; columns 147..159 zero) - dW(conv1) is then one rdpn6d_wgrad_f32 call with a single tap */
+int rdpn6d_stem_im2col_f32(const float* x, int B, int xc, int R, float* out, void* stream);
 
 /* ================================================================== "next" rows of SURVEY.md section 8f
  * rank 3: region / residual training targets (core/utils/data_utils.py:229-244, data_loader.py:881-903).

@@ -87,6 +87,7 @@ SIGNATURES = {
     "rdpn6d_crop_builder_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "rdpn6d_act_backward_f32": (_i, [_vp, _vp, _ll, _f, _vp]),
     "rdpn6d_rgb_to_nhwc4_f32": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "rdpn6d_stem_im2col_f32": (_i, [_vp, _i, _i, _i, _vp, _vp]),
 }
 
 _lib = None

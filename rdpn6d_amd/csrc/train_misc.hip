@@ -12,50 +12,57 @@
 // ------------------------------------------------------------------------------------------------
 // MaxPool2d(3,2,1) backward, gather form (deterministic): an input element receives the gradient of every
 // window in which it is the FIRST maximum in scan order (torch's CPU/GPU kernels keep the first max).
+// One thread = one input pixel x 4 channels (16-byte loads; the <= 4 windows x 9 taps it inspects are L1/L2 hits).
 __global__ void maxpool3x3s2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int B, int H, int W, int C,
                                         float* __restrict__ dx)
 {
-    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-    const long long total = (long long)B * H * W * C;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1, C4 = C / 4;
+    const long long total = (long long)B * H * W * C4;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        long long p = i / C;
+        const int c = (int)(i % C4) * 4;
+        long long p = i / C4;
         const int ix = (int)(p % W);
         p /= W;
         const int iy = (int)(p % H);
         const int b = (int)(p / H);
-        const float v = x[i];
-        float g = 0.f;
+        const float* xb = x + (long long)b * H * W * C + c;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xb + ((long long)iy * W + ix) * C);
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
         // windows (oy,ox) covering (iy,ix): oy*2-1 <= iy <= oy*2+1
-        for (int oy = (iy) / 2; oy <= (iy + 1) / 2; ++oy) {
-            if (oy < 0 || oy >= Ho) continue;
-            for (int ox = (ix) / 2; ox <= (ix + 1) / 2; ++ox) {
-                if (ox < 0 || ox >= Wo) continue;
-                // is (iy,ix) the first max of this window?
-                bool first = true;
-                for (int ky = 0; ky < 3 && first; ++ky) {
+        for (int oy = iy / 2; oy <= (iy + 1) / 2; ++oy) {
+            if (oy >= Ho) continue;
+            for (int ox = ix / 2; ox <= (ix + 1) / 2; ++ox) {
+                if (ox >= Wo) continue;
+                // per channel: is (iy,ix) the first max of this window?
+                bool first[4] = {true, true, true, true};
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
                     const int yy = oy * 2 - 1 + ky;
                     if ((unsigned)yy >= (unsigned)H) continue;
+#pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
                         const int xx = ox * 2 - 1 + kx;
                         if ((unsigned)xx >= (unsigned)W) continue;
-                        const float u = x[(((long long)b * H + yy) * W + xx) * C + c];
+                        const f32x4 u = *reinterpret_cast<const f32x4*>(xb + ((long long)yy * W + xx) * C);
                         const bool before = yy < iy || (yy == iy && xx < ix);
-                        if (u > v || (before && u == v)) { first = false; break; }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) first[e] = first[e] && !(u[e] > v[e] || (before && u[e] == v[e]));
                     }
                 }
-                if (first) g += dy[(((long long)b * Ho + oy) * Wo + ox) * C + c];
+                const f32x4 d = *reinterpret_cast<const f32x4*>(dy + (((long long)b * Ho + oy) * Wo + ox) * C + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] += first[e] ? d[e] : 0.f;
             }
         }
-        dx[i] = g;
+        *reinterpret_cast<f32x4*>(dx + (((long long)b * H + iy) * W + ix) * C + c) = g;
     }
 }
 
 extern "C" int rdpn6d_maxpool3x3s2_backward_f32(const float* x, const float* dy, int B, int H, int W, int C, float* dx,
                                                 void* stream)
 {
-    RD_REQUIRE(x && dy && dx && B > 0 && H > 0 && W > 0 && C > 0, "shape");
-    const long long total = (long long)B * H * W * C;
+    RD_REQUIRE(x && dy && dx && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "shape");
+    const long long total = (long long)B * H * W * (C / 4);
     const int blocks = (int)((total + 255) / 256 < 32768 ? (total + 255) / 256 : 32768);
     hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, dy, B, H, W, C, dx);
     RD_LAUNCH_CHECK();
@@ -622,6 +629,45 @@ __global__ void rgb_to_nhwc4_kernel(const float* __restrict__ x, int B, int xc, 
         o[3] = 0.f;
         *reinterpret_cast<f32x4*>(y + i * 4) = o;
     }
+}
+
+// Patch matrix of the 7x7 stride-2 stem for its weight gradient: out[(b,oy,ox)][(ky*7+kx)*3 + c] = x[b][c][2oy-3+ky][2ox-3+kx]
+// (0 outside the image, columns 147..159 zero), so that dW(conv1) is ONE pixel-reduction GEMM dY^T x out on the wgrad kernel
+// instead of seven 4-channel ones (resnet_backbone.py:272 backward).  One thread per (pixel, 4 columns): 16-byte stores.
+__global__ void stem_im2col_kernel(const float* __restrict__ x, int B, int xc, int R, float* __restrict__ out)
+{
+    const int Ro = R / 2;
+    const long long total = (long long)B * Ro * Ro * 40;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(i % 40);
+        long long p = i / 40;
+        const int ox = (int)(p % Ro);
+        const int oy = (int)((p / Ro) % Ro);
+        const int b = (int)(p / ((long long)Ro * Ro));
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int col = q * 4 + e;
+            float t = 0.f;
+            if (col < 147) {
+                const int tap = col / 3, c = col - tap * 3, ky = tap / 7, kx = tap - ky * 7;
+                const int iy = 2 * oy - 3 + ky, ix = 2 * ox - 3 + kx;
+                if ((unsigned)iy < (unsigned)R && (unsigned)ix < (unsigned)R) t = x[(((long long)b * xc + c) * R + iy) * R + ix];
+            }
+            v[e] = t;
+        }
+        *reinterpret_cast<f32x4*>(out + p * 160 + q * 4) = v;
+    }
+}
+
+extern "C" int rdpn6d_stem_im2col_f32(const float* x, int B, int xc, int R, float* out, void* stream)
+{
+    RD_REQUIRE(x && out && B > 0 && xc >= 3 && R > 0 && R % 2 == 0, "shape");
+    const long long total = (long long)B * (R / 2) * (R / 2) * 40;
+    const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(stem_im2col_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, B, xc, R, out);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
 }
 
 extern "C" int rdpn6d_rgb_to_nhwc4_f32(const float* x, int B, int xc, int R, float* y, void* stream)

@@ -341,19 +341,17 @@ class TrainEngine:
         a0 = self.buf("act:stem", B, R2, R2, 64)
         self.fwd.append(lambda: _lib.check(lib.rdpn6d_stem_conv7x7_raw_f32(_ptr(self.x), B, 6, R, _ptr(wst), _ptr(raw0), self.st()), "stem"))
         d_raw0 = self.buf("d:stem", B, R2, R2, 64, zero=True)
-        x4 = self.buf("x_nhwc4", B, R, R, 4)
-        wg_stem = self.buf("wg:stem", 64, 7, 4)
-        self._wg_floats = max(self._wg_floats, int(lib.rdpn6d_wgrad_scratch_floats(B, R2, R2, 64, 4, 7)))
+        xcol = self.buf("x_im2col", B * R2 * R2, 160)   # stem patch matrix (built in the backward, 335 MB at B=32)
+        wg_stem = self.buf("wg:stem", 64, 1, 160)
+        self._wg_floats = max(self._wg_floats, int(lib.rdpn6d_wgrad_scratch_floats(B, R2, R2, 64, 160, 1)))
+        z9 = (ctypes.c_int * 9)(*([0] * 9))
 
         def stem_wgrad():
-            _lib.check(lib.rdpn6d_rgb_to_nhwc4_f32(_ptr(self.x), B, 6, R, _ptr(x4), self.st()), "rgb->nhwc4")
-            g = self._grad(bb.conv1.weight)
-            for ky in range(7):
-                tdy = (ctypes.c_int * 9)(*([ky - 3] * 7 + [0, 0]))
-                tdx = (ctypes.c_int * 9)(*([kx - 3 for kx in range(7)] + [0, 0]))
-                _lib.check(lib.rdpn6d_wgrad_f32(_ptr(d_raw0), 64, 0, 64, _ptr(x4), 4, 0, 4, B, R2, R2, R, R, 2, 7, tdy, tdx,
-                                                _ptr(wg_stem), _ptr(self._wg_partial), self.st()), "wgrad stem")
-                g[:, :, ky, :].copy_(wg_stem[:, :, :3].permute(0, 2, 1))
+            # dW(conv1)[n][ky][kx][c] = sum over output pixels of dY[p][n] * patch[p][(ky,kx,c)]: one pixel-reduction GEMM
+            _lib.check(lib.rdpn6d_stem_im2col_f32(_ptr(self.x), B, 6, R, _ptr(xcol), self.st()), "stem im2col")
+            _lib.check(lib.rdpn6d_wgrad_f32(_ptr(d_raw0), 64, 0, 64, _ptr(xcol), 160, 0, 160, B, R2, R2, R2, R2, 1, 1, z9, z9,
+                                            _ptr(wg_stem), _ptr(self._wg_partial), self.st()), "wgrad stem")
+            self._grad(bb.conv1.weight).copy_(wg_stem[:, 0, :147].view(64, 7, 7, 3).permute(0, 3, 1, 2))
 
         self.bwd.append([stem_wgrad])
         d_a0 = self.bn_unit("bn1", bb.bn1, raw0, 64, 0, 64, B * R2 * R2, a0, 64, 0, True, dx=d_raw0)

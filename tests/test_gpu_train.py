@@ -305,3 +305,31 @@ def test_wgrad_bf16_vs_fp32_kernel(case):
     e16 = (o16.cpu().double() - ref).abs().max().item() / scale
     print(f"{case}: fp32 kernel {e32:.2e}, bf16 kernel {e16:.2e} (relative to max |dW| = {scale:.3g})")
     assert e32 < 1e-5 and e16 < 1e-5
+
+
+def test_maxpool_backward_first_max_rule_and_stem_im2col():
+    import ctypes
+    import torch.nn.functional as F
+    from rdpn6d_amd import _lib
+    from rdpn6d_amd.gdrn import _ptr
+
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator().manual_seed(3)
+    # coarse values -> many exact ties inside a window: the gradient must go to the FIRST maximum in scan order (torch)
+    x = torch.randint(0, 3, (2, 8, 11, 11), generator=g).float()
+    xr = x.clone().requires_grad_(True)
+    y = F.max_pool2d(xr, 3, 2, 1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    xd, dyd = x.permute(0, 2, 3, 1).contiguous().to(dev), dy.permute(0, 2, 3, 1).contiguous().to(dev)
+    dx = torch.empty_like(xd)
+    _lib.check(lib.rdpn6d_maxpool3x3s2_backward_f32(_ptr(xd), _ptr(dyd), 2, 11, 11, 8, _ptr(dx), st))
+    assert torch.equal(dx.cpu().permute(0, 3, 1, 2), xr.grad)
+    img = torch.rand(2, 6, 16, 16, generator=g).to(dev)
+    col = torch.empty(2 * 8 * 8, 160, device=dev)
+    _lib.check(lib.rdpn6d_stem_im2col_f32(_ptr(img), 2, 6, 16, _ptr(col), st))
+    ref = F.unfold(img[:, :3].cpu(), 7, padding=3, stride=2)            # (B, c*49 + ky*7 + kx, L)
+    ref = ref.view(2, 3, 49, 64).permute(0, 3, 2, 1).reshape(128, 147)  # -> [pixel][(ky*7+kx)*3 + c]
+    assert torch.equal(col[:, :147].cpu(), ref) and col[:, 147:].abs().max().item() == 0
