@@ -225,6 +225,15 @@ int rdpn6d_wgrad_f32(const float* A, int a_cs, int a_co, int Ca, const float* Bg
 int rdpn6d_wgrad_bf16(const void* A, int a_cs, int a_co, int Ca, int Ca_ld, const void* Bg, int b_cs, int b_co, int Cb,
                       int Cb_ld, int Bn, int Ha, int Wa, int Hb, int Wb, int stride, int ntaps, const int* dy, const int* dx,
                       float* out, float* partial, void* stream);
+/* the same two kernels with the result scattered straight into a caller-defined layout (e.g. the parameter's own OIHW
+ * gradient): element (a, tap, b) -> out[a*sa + tap*st + b*sb] for a < Ca_out <= Ca, b < Cb_out <= Cb */
+int rdpn6d_wgrad_f32_strided(const float* A, int a_cs, int a_co, int Ca, const float* Bg, int b_cs, int b_co, int Cb, int Bn,
+                             int Ha, int Wa, int Hb, int Wb, int stride, int ntaps, const int* dy, const int* dx, float* out,
+                             long long sa, long long st, long long sb, int Ca_out, int Cb_out, float* partial, void* stream);
+int rdpn6d_wgrad_bf16_strided(const void* A, int a_cs, int a_co, int Ca, int Ca_ld, const void* Bg, int b_cs, int b_co, int Cb,
+                              int Cb_ld, int Bn, int Ha, int Wa, int Hb, int Wb, int stride, int ntaps, const int* dy,
+                              const int* dx, float* out, long long sa, long long st, long long sb, int Ca_out, int Cb_out,
+                              float* partial, void* stream);
 int rdpn6d_maxpool3x3s2_backward_f32(const float* x, const float* dy, int B, int H, int W, int C, float* dx, void* stream);
 int rdpn6d_upsample_bilinear_backward_f32(const float* dy, int B, int H, int W, int C, int factor, float* dx, void* stream);
 int rdpn6d_global_max_concat_backward_f32(const float* feat, const float* dfeat, int B, int HW, int C, int cs, float* dl3,

@@ -433,6 +433,36 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int S, l
     }
 }
 
+// the same fixed-order sum, scattered straight into the parameter's own gradient layout:
+// out[a*sa + t*st + b*sb] for a < Ca_out, b < Cb_out (e.g. OIHW: sa = Cin*k*k, sb = k*k, st = 1)
+struct WgradOut {
+    float* out;
+    long long sa, st, sb;
+    int Ca_out, Cb_out;
+};
+__global__ void splitk_reduce_strided_kernel(const float* __restrict__ partial, int S, int Ca, int ntaps, int Cb, WgradOut o)
+{
+    const long long n = (long long)Ca * ntaps * Cb;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(i % Cb);
+        const long long r = i / Cb;
+        const int t = (int)(r % ntaps);
+        const int a = (int)(r / ntaps);
+        if (a >= o.Ca_out || b >= o.Cb_out) continue;
+        float s = 0.f;
+        for (int k = 0; k < S; ++k) s += partial[(long long)k * n + i];
+        o.out[a * o.sa + t * o.st + b * o.sb] = s;
+    }
+}
+
+static void wgrad_reduce(const float* partial, int S, int Ca, int ntaps, int Cb, float* out, const WgradOut* o, hipStream_t s)
+{
+    const long long n = (long long)Ca * ntaps * Cb;
+    const int rblocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    if (o) hipLaunchKernelGGL(splitk_reduce_strided_kernel, dim3(rblocks), dim3(256), 0, s, partial, S, Ca, ntaps, Cb, *o);
+    else hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rblocks), dim3(256), 0, s, partial, S, n, out);
+}
+
 // A [Bn*Ha*Wa rows, a_cs] ; Bg NHWC [Bn,Hb,Wb,b_cs]; out [Ca][ntaps][Cb] fp32;
 // partial = scratch of at least rdpn6d_wgrad_scratch_floats(...) floats
 extern "C" long long rdpn6d_wgrad_scratch_floats(int Bn, int Ha, int Wa, int Ca, int Cb, int ntaps);
@@ -466,9 +496,9 @@ extern "C" long long rdpn6d_wgrad_scratch_floats(int Bn, int Ha, int Wa, int Ca,
     return (long long)wgrad_pick_splits((long long)Bn * Ha * Wa, tiles, ba, bb) * Ca * ntaps * Cb;
 }
 
-extern "C" int rdpn6d_wgrad_f32(const float* A, int a_cs, int a_co, int Ca, const float* Bg, int b_cs, int b_co, int Cb,
-                                int Bn, int Ha, int Wa, int Hb, int Wb, int stride, int ntaps, const int* dy,
-                                const int* dx, float* out, float* partial, void* stream)
+static int wgrad_f32_impl(const float* A, int a_cs, int a_co, int Ca, const float* Bg, int b_cs, int b_co, int Cb, int Bn,
+                          int Ha, int Wa, int Hb, int Wb, int stride, int ntaps, const int* dy, const int* dx, float* out,
+                          const WgradOut* so, float* partial, void* stream)
 {
     RD_REQUIRE(A && Bg && out && partial && dy && dx, "null pointer");
     RD_REQUIRE(Bn > 0 && Ha > 0 && Wa > 0 && Hb > 0 && Wb > 0 && stride >= 1, "shape");
@@ -505,18 +535,35 @@ extern "C" int rdpn6d_wgrad_f32(const float* A, int a_cs, int a_co, int Ca, cons
     else if (bb == 128) hipLaunchKernelGGL((wgrad_f32_kernel<64, 128>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((wgrad_f32_kernel<64, 64>), grid, block, 0, s, a);
     RD_LAUNCH_CHECK();
-    const long long n = (long long)Ca * ntaps * Cb;
-    const int rblocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rblocks), dim3(256), 0, s, partial, S, n, out);
+    wgrad_reduce(partial, S, Ca, ntaps, Cb, out, so, s);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
 }
 
+extern "C" int rdpn6d_wgrad_f32(const float* A, int a_cs, int a_co, int Ca, const float* Bg, int b_cs, int b_co, int Cb,
+                                int Bn, int Ha, int Wa, int Hb, int Wb, int stride, int ntaps, const int* dy,
+                                const int* dx, float* out, float* partial, void* stream)
+{
+    return wgrad_f32_impl(A, a_cs, a_co, Ca, Bg, b_cs, b_co, Cb, Bn, Ha, Wa, Hb, Wb, stride, ntaps, dy, dx, out, nullptr, partial,
+                          stream);
+}
+
+// output scattered into a caller-defined layout: element (a, tap, b) -> out[a*sa + tap*st + b*sb], a < Ca_out, b < Cb_out
+extern "C" int rdpn6d_wgrad_f32_strided(const float* A, int a_cs, int a_co, int Ca, const float* Bg, int b_cs, int b_co, int Cb,
+                                        int Bn, int Ha, int Wa, int Hb, int Wb, int stride, int ntaps, const int* dy,
+                                        const int* dx, float* out, long long sa, long long st, long long sb, int Ca_out,
+                                        int Cb_out, float* partial, void* stream)
+{
+    RD_REQUIRE(Ca_out > 0 && Ca_out <= Ca && Cb_out > 0 && Cb_out <= Cb, "output extents");
+    const WgradOut so = {out, sa, st, sb, Ca_out, Cb_out};
+    return wgrad_f32_impl(A, a_cs, a_co, Ca, Bg, b_cs, b_co, Cb, Bn, Ha, Wa, Hb, Wb, stride, ntaps, dy, dx, out, &so, partial, stream);
+}
+
 // bf16 operands (compact NHWC copies, channel strides/offsets in elements, multiples of 8); Ca_ld / Cb_ld = readable
 // channels of the slices (>= Ca / Cb, zero beyond the real count); out / partial as rdpn6d_wgrad_f32
-extern "C" int rdpn6d_wgrad_bf16(const void* A, int a_cs, int a_co, int Ca, int Ca_ld, const void* Bg, int b_cs, int b_co, int Cb,
-                                 int Cb_ld, int Bn, int Ha, int Wa, int Hb, int Wb, int stride, int ntaps, const int* dy,
-                                 const int* dx, float* out, float* partial, void* stream)
+static int wgrad_bf16_impl(const void* A, int a_cs, int a_co, int Ca, int Ca_ld, const void* Bg, int b_cs, int b_co, int Cb,
+                           int Cb_ld, int Bn, int Ha, int Wa, int Hb, int Wb, int stride, int ntaps, const int* dy, const int* dx,
+                           float* out, const WgradOut* so, float* partial, void* stream)
 {
     RD_REQUIRE(A && Bg && out && partial && dy && dx, "null pointer");
     RD_REQUIRE(Bn > 0 && Ha > 0 && Wa > 0 && Hb > 0 && Wb > 0 && stride >= 1, "shape");
@@ -554,9 +601,26 @@ extern "C" int rdpn6d_wgrad_bf16(const void* A, int a_cs, int a_co, int Ca, int 
     else if (bb == 128) hipLaunchKernelGGL((wgrad_bf16_kernel<64, 128>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((wgrad_bf16_kernel<64, 64>), grid, block, 0, s, a);
     RD_LAUNCH_CHECK();
-    const long long n = (long long)Ca * ntaps * Cb;
-    const int rblocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rblocks), dim3(256), 0, s, partial, S, n, out);
+    wgrad_reduce(partial, S, Ca, ntaps, Cb, out, so, s);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
+}
+
+extern "C" int rdpn6d_wgrad_bf16(const void* A, int a_cs, int a_co, int Ca, int Ca_ld, const void* Bg, int b_cs, int b_co, int Cb,
+                                 int Cb_ld, int Bn, int Ha, int Wa, int Hb, int Wb, int stride, int ntaps, const int* dy,
+                                 const int* dx, float* out, float* partial, void* stream)
+{
+    return wgrad_bf16_impl(A, a_cs, a_co, Ca, Ca_ld, Bg, b_cs, b_co, Cb, Cb_ld, Bn, Ha, Wa, Hb, Wb, stride, ntaps, dy, dx, out,
+                           nullptr, partial, stream);
+}
+
+extern "C" int rdpn6d_wgrad_bf16_strided(const void* A, int a_cs, int a_co, int Ca, int Ca_ld, const void* Bg, int b_cs, int b_co,
+                                         int Cb, int Cb_ld, int Bn, int Ha, int Wa, int Hb, int Wb, int stride, int ntaps,
+                                         const int* dy, const int* dx, float* out, long long sa, long long st, long long sb,
+                                         int Ca_out, int Cb_out, float* partial, void* stream)
+{
+    RD_REQUIRE(Ca_out > 0 && Ca_out <= Ca && Cb_out > 0 && Cb_out <= Cb, "output extents");
+    const WgradOut so = {out, sa, st, sb, Ca_out, Cb_out};
+    return wgrad_bf16_impl(A, a_cs, a_co, Ca, Ca_ld, Bg, b_cs, b_co, Cb, Cb_ld, Bn, Ha, Wa, Hb, Wb, stride, ntaps, dy, dx, out, &so,
+                           partial, stream);
 }

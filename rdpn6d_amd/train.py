@@ -203,7 +203,7 @@ class TrainEngine:
         cb = _pad_to(cin_real, 4)
         tdy = (ctypes.c_int * 9)(*[t[0] for t in taps] + [0] * (9 - len(taps)))
         tdx = (ctypes.c_int * 9)(*[t[1] for t in taps] + [0] * (9 - len(taps)))
-        wg_out = self.buf("wg:" + name, ca, k * k, cb)
+        wg_out = self.buf("wg:" + name, ca, k * k, cb) if perm is not None else None
         self._wg_floats = max(self._wg_floats, int(lib.rdpn6d_wgrad_scratch_floats(B, yhw[0], yhw[1], ca, cb, k * k)))
         inv_perm = None
         if perm is not None:
@@ -218,23 +218,37 @@ class TrainEngine:
             dyb = self._bf16_of(launches, dy, out_cs, out_co, cout, M, cache=False)[0]
 
         def wgrad():
+            # the split-K reduce scatters straight into the parameter's own OIHW gradient (element (n, tap, c) at
+            # n*Cin*k*k + c*k*k + tap) unless the input channels are permuted in the activation buffer
+            direct = inv_perm is None
+            gw = self._grad(w)
+            tgt = (_ptr(gw), cin_real * k * k, 1, k * k, cout, cin_real) if direct else None
             if lowp:
-                _lib.check(lib.rdpn6d_wgrad_bf16(_ptr(dyb), n_red_b, 0, ca, n_red_b, _ptr(xb), cin_pad, 0, cb, cin_pad, B, yhw[0], yhw[1],
-                                                 xhw[0], xhw[1], stride, k * k, tdy, tdx, _ptr(wg_out), _ptr(self._wg_partial),
-                                                 self.st()), "wgrad " + name)
+                args = (_ptr(dyb), n_red_b, 0, ca, n_red_b, _ptr(xb), cin_pad, 0, cb, cin_pad, B, yhw[0], yhw[1], xhw[0], xhw[1],
+                        stride, k * k, tdy, tdx)
+                if direct:
+                    _lib.check(lib.rdpn6d_wgrad_bf16_strided(*args, *tgt, _ptr(self._wg_partial), self.st()), "wgrad " + name)
+                else:
+                    _lib.check(lib.rdpn6d_wgrad_bf16(*args, _ptr(wg_out), _ptr(self._wg_partial), self.st()), "wgrad " + name)
             else:
-                _lib.check(lib.rdpn6d_wgrad_f32(_ptr(dy), out_cs, out_co, ca, _ptr(x), in_cs, in_co, cb, B, yhw[0], yhw[1], xhw[0],
-                                                xhw[1], stride, k * k, tdy, tdx, _ptr(wg_out), _ptr(self._wg_partial), self.st()),
-                           "wgrad " + name)
-            g = wg_out[:cout, :, :cin_real].view(cout, k, k, cin_real).permute(0, 3, 1, 2)
-            if inv_perm is not None:
-                g = g[:, inv_perm]
-            self._grad(w).copy_(g)
+                args = (_ptr(dy), out_cs, out_co, ca, _ptr(x), in_cs, in_co, cb, B, yhw[0], yhw[1], xhw[0], xhw[1], stride, k * k,
+                        tdy, tdx)
+                if direct:
+                    _lib.check(lib.rdpn6d_wgrad_f32_strided(*args, *tgt, _ptr(self._wg_partial), self.st()), "wgrad " + name)
+                else:
+                    _lib.check(lib.rdpn6d_wgrad_f32(*args, _ptr(wg_out), _ptr(self._wg_partial), self.st()), "wgrad " + name)
+            if not direct:
+                g = wg_out[:cout, :, :cin_real].view(cout, k, k, cin_real).permute(0, 3, 1, 2)
+                gw.copy_(g[:, inv_perm])
             if bias is not None:
-                bg = self.buf("bg:" + name, npad)
-                _lib.check(lib.rdpn6d_channel_sum_f32(_ptr(dy), M, ca, out_cs, out_co, _ptr(bg), 0, _ptr(self._scratch_d),
-                                                      self.st()), "bias grad " + name)
-                self._grad(bias).copy_(bg[:cout])
+                if cout % 4 == 0:
+                    _lib.check(lib.rdpn6d_channel_sum_f32(_ptr(dy), M, ca, out_cs, out_co, _ptr(self._grad(bias)), 0,
+                                                          _ptr(self._scratch_d), self.st()), "bias grad " + name)
+                else:
+                    bg = self.buf("bg:" + name, npad)
+                    _lib.check(lib.rdpn6d_channel_sum_f32(_ptr(dy), M, ca, out_cs, out_co, _ptr(bg), 0, _ptr(self._scratch_d),
+                                                          self.st()), "bias grad " + name)
+                    self._grad(bias).copy_(bg[:cout])
 
         launches.append(wgrad)
         if dx is not None:
@@ -316,15 +330,14 @@ class TrainEngine:
             dy, dy_cs, dy_co = self.buf("d:" + name, *y.shape, zero=True), ycs, yco
         else:
             dy_co = 0
-        dga, dbe = self.buf("dga:" + name, _pad_to(C, 4)), self.buf("dbe:" + name, _pad_to(C, 4))
+        assert C % 4 == 0
 
         def bwd():
+            # dgamma / dbeta land directly in the parameters' gradients (C entries each, also read back by the dx pass)
             _lib.check(lib.rdpn6d_bn_backward_f32(_ptr(x_raw), cs, co, _ptr(dy), dy_cs, dy_co, _ptr(y), ycs, yco, _ptr(mean),
-                                                  _ptr(invstd), _ptr(ga), _ptr(dga), _ptr(dbe), _ptr(dx), cs, co, _ptr(dres),
-                                                  (dres.shape[-1] if dres is not None else 0), 0, M, C, 1 if relu else 0,
-                                                  _ptr(self._scratch_d), self.st()), "bn bwd " + name)
-            self._grad(bn.weight).copy_(dga[:C])
-            self._grad(bn.bias).copy_(dbe[:C])
+                                                  _ptr(invstd), _ptr(ga), _ptr(self._grad(bn.weight)), _ptr(self._grad(bn.bias)),
+                                                  _ptr(dx), cs, co, _ptr(dres), (dres.shape[-1] if dres is not None else 0), 0, M, C,
+                                                  1 if relu else 0, _ptr(self._scratch_d), self.st()), "bn bwd " + name)
 
         self.bwd.append([bwd])
         return dy
@@ -461,19 +474,19 @@ class TrainEngine:
             ddT = self._conv_desc(d_rt0b, (R4, R4), F, 0, F, wdTb, d_feat, (R8, R8), 1024, 0, 1024, _taps(3, 1), stride=2)
         else:
             ddT = self._conv_desc(d_rt0, (R4, R4), F, 0, F, wdT, d_feat, (R8, R8), 1024, 0, 1024, _taps(3, 1), stride=2)
-        wgT = self.buf("wg:convT", 1024, 9, F)
         self._wg_floats = max(self._wg_floats, int(lib.rdpn6d_wgrad_scratch_floats(B, R8, R8, 1024, F, 9)))
         t9y = (ctypes.c_int * 9)(*[t[0] for t in _taps(3, 1)])
         t9x = (ctypes.c_int * 9)(*[t[1] for t in _taps(3, 1)])
 
         def convT_wgrad():
+            # ConvTranspose weight is (Cin, Cout, 3, 3): element (cin, tap, cout) -> cin*F*9 + cout*9 + tap
+            tgt = (_ptr(self._grad(wt)), F * 9, 1, 9, 1024, F)
             if self.amp:
-                _lib.check(lib.rdpn6d_wgrad_bf16(_ptr(featb), 1024, 0, 1024, 1024, _ptr(d_rt0b), F, 0, F, F, B, R8, R8, R4, R4, 2, 9, t9y,
-                                                 t9x, _ptr(wgT), _ptr(self._wg_partial), self.st()), "wgrad convT")
+                _lib.check(lib.rdpn6d_wgrad_bf16_strided(_ptr(featb), 1024, 0, 1024, 1024, _ptr(d_rt0b), F, 0, F, F, B, R8, R8, R4, R4, 2,
+                                                         9, t9y, t9x, *tgt, _ptr(self._wg_partial), self.st()), "wgrad convT")
             else:
-                _lib.check(lib.rdpn6d_wgrad_f32(_ptr(feat), 1024, 0, 1024, _ptr(d_rt0), F, 0, F, B, R8, R8, R4, R4, 2, 9, t9y, t9x,
-                                                _ptr(wgT), _ptr(self._wg_partial), self.st()), "wgrad convT")
-            self._grad(wt).copy_(wgT.view(1024, 3, 3, F).permute(0, 3, 1, 2))
+                _lib.check(lib.rdpn6d_wgrad_f32_strided(_ptr(feat), 1024, 0, 1024, _ptr(d_rt0), F, 0, F, B, R8, R8, R4, R4, 2, 9, t9y,
+                                                        t9x, *tgt, _ptr(self._wg_partial), self.st()), "wgrad convT")
 
         self.bwd.append(convT_bwd + [convT_wgrad, self._launch_conv("dgrad convT", ddT, wdT, lowp=self.amp)])
         d_prev = self.bn_unit("head.bn0", head.features[1], rt0, F, 0, F, Mh, at0, F, 0, True, dx=d_rt0)
@@ -525,14 +538,12 @@ class TrainEngine:
             self.fwd.append(lambda r_i=r_i, a_i=a_i, oh=oh, fd=fd, gn=gn, ga=ga, be=be, stats=stats: _lib.check(
                 lib.rdpn6d_groupnorm_relu_train_f32(_ptr(r_i), _ptr(a_i), B, oh * oh, fd, gn.groups, _ptr(ga), _ptr(be), _ptr(stats), self.st()), "gn"))
             d_ai = self.buf(f"d:pnp_act{i}", B, oh, oh, fd, zero=True)
-            dga, dbe, dgb = self.buf(f"dga:pnp{i}", fd), self.buf(f"dbe:pnp{i}", fd), self.buf(f"dgb:pnp{i}", B, 2, fd)
+            dgb = self.buf(f"dgb:pnp{i}", B, 2, fd)
 
-            def gn_bwd(r_i=r_i, a_i=a_i, d_ai=d_ai, d_ri=d_ri, oh=oh, fd=fd, gn=gn, ga=ga, stats=stats, dga=dga, dbe=dbe, dgb=dgb):
-                _lib.check(lib.rdpn6d_groupnorm_relu_backward_f32(_ptr(r_i), _ptr(a_i), _ptr(d_ai), _ptr(ga), _ptr(stats), _ptr(d_ri), _ptr(dga),
-                                                                  _ptr(dbe), _ptr(dgb), _ptr(self._scratch_d), B, oh * oh, fd, gn.groups,
-                                                                  self.st()), "gn bwd")
-                self._grad(gn.weight).copy_(dga)
-                self._grad(gn.bias).copy_(dbe)
+            def gn_bwd(r_i=r_i, a_i=a_i, d_ai=d_ai, d_ri=d_ri, oh=oh, fd=fd, gn=gn, ga=ga, stats=stats, dgb=dgb):
+                _lib.check(lib.rdpn6d_groupnorm_relu_backward_f32(_ptr(r_i), _ptr(a_i), _ptr(d_ai), _ptr(ga), _ptr(stats), _ptr(d_ri),
+                                                                  _ptr(self._grad(gn.weight)), _ptr(self._grad(gn.bias)), _ptr(dgb),
+                                                                  _ptr(self._scratch_d), B, oh * oh, fd, gn.groups, self.st()), "gn bwd")
 
             self.bwd.append([gn_bwd])
             x, d_x, hw, cin_real, cs = a_i, d_ai, oh, fd, fd
