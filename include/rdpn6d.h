@@ -97,6 +97,7 @@ void rdpn6d_conv_set_tap_inner(int v);
 int rdpn6d_conv2d_bf16(const rdpn6d_conv_desc* d, int out_f32, void* stream);
 void rdpn6d_conv_bf16_force_tile(int bm, int bn);
 int rdpn6d_conv_bf16_tile_for(const rdpn6d_conv_desc* d, int* bm, int* bn); /* 256x128 | 128x128 | 128x64 | 64x128 | 64x64 */
+void rdpn6d_conv_bf16_force_chunk(int row_bytes); /* profiling: 0 = auto, 64 forces 32-channel K-chunks (measured slower) */
 /* bf16 forms of the kernels between the bf16 convolutions (same argument meaning as the _f32 entry points; activations
  * bf16 NHWC with C % 8 == 0; the stem and the xyz subsample read the fp32 NCHW crop and write bf16) */
 int rdpn6d_stem_conv7x7_bf16(const float* x, int B, int xc, int R, const float* w, const float* scale,

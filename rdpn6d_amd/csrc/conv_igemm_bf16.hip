@@ -363,7 +363,8 @@ __global__ __launch_bounds__(64 * WM * WN, NST == 2 ? 2 : 1) void conv_igemm_bf1
     }
 }
 
-static int g_bforce_bm = 0, g_bforce_bn = 0;
+static int g_bforce_bm = 0, g_bforce_bn = 0, g_bforce_rb = 0;
+extern "C" void rdpn6d_conv_bf16_force_chunk(int row_bytes) { g_bforce_rb = row_bytes; }  // 0 = auto, 64 | 128 (profiling)
 extern "C" void rdpn6d_conv_bf16_force_tile(int bm, int bn) { g_bforce_bm = bm; g_bforce_bn = bn; }
 
 static void conv_bf16_pick_tile(const rdpn6d_conv_desc* d, long long M, int rb, int* pbm, int* pbn)
@@ -435,7 +436,7 @@ extern "C" int rdpn6d_conv2d_bf16(const rdpn6d_conv_desc* d, int out_f32, void* 
     a.M = (long long)d->B * d->Ho * d->Wo;
     RD_REQUIRE(a.M < (1LL << 31), "B*Ho*Wo must fit 31 bits");
     a.HoWo = d->Ho * d->Wo;
-    const int rb = d->Cin % 64 == 0 ? 128 : 64;
+    const int rb = (d->Cin % 64 == 0 && g_bforce_rb != 64) ? 128 : 64;
     a.cchunks = d->Cin * 2 / rb;
     a.nk = d->ntaps * a.cchunks;
     a.Ktot = d->ntaps * d->Cin;

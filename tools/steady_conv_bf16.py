@@ -20,5 +20,16 @@ for t, (dy, dx) in enumerate(taps): d.dy[t], d.dx[t] = dy, dx
 d.N, d.Npad, d.OH, d.OW, d.osy, d.osx, d.out_cs, d.act = Cout, Cout, H, H, 1, 1, Cout, 1
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 lib.rdpn6d_conv_bf16_force_tile(*tiles)
+if "CHUNK" in os.environ:
+    lib.rdpn6d_conv_bf16_force_chunk.restype = None
+    lib.rdpn6d_conv_bf16_force_chunk(int(os.environ["CHUNK"]))
+if "TIME" in os.environ:
+    for _ in range(5): lib.rdpn6d_conv2d_bf16(ctypes.byref(d), 0, st)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(30): lib.rdpn6d_conv2d_bf16(ctypes.byref(d), 0, st)
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 30 * 1e3
+    print(f"tile {tiles} chunk {os.environ.get('CHUNK', 'auto')}: {us:8.1f} us  {2.0*B*H*H*Cout*9*Cin/us/1e6:7.1f} TF/s")
 for _ in range(int(os.environ.get("REPS", 30))): _lib.check(lib.rdpn6d_conv2d_bf16(ctypes.byref(d), 0, st))
 torch.cuda.synchronize()
