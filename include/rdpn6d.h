@@ -266,6 +266,22 @@ int rdpn6d_rgb_to_nhwc4_f32(const float* x, int B, int xc, int R, float* y, void
  * (0 outside the image; columns 147..159 zero) - dW(conv1) is then one rdpn6d_wgrad_f32 call with a single tap */
 int rdpn6d_stem_im2col_f32(const float* x, int B, int xc, int R, float* out, void* stream);
 
+/* Weight re-packing of the training step in one launch.  Entry: dst[(o*dT + t)*dIpad + i] = src[operm(o)*so +
+ * iperm(i)*si + toff[t]] for o < O, t < T, i < I (operm / iperm may be NULL = identity; dst and/or dst_bf16 are written;
+ * padding entries of dst are never touched).  `start` = number of elements of all previous entries (prefix sum);
+ * the table lives in device memory; total = sum of O*T*I. */
+typedef struct {
+    const float* src;
+    float* dst;
+    void* dst_bf16;
+    const int* operm;
+    const int* iperm;
+    long long so, si, start;
+    int O, T, I, dT, dIpad;
+    int toff[9];
+} rdpn6d_repack_desc;
+int rdpn6d_repack_f32(const rdpn6d_repack_desc* table_dev, int ndesc, long long total, void* stream);
+
 /* ================================================================== "next" rows of SURVEY.md section 8f
  * rank 3: region / residual training targets (core/utils/data_utils.py:229-244, data_loader.py:881-903).
  *   xyz_hwc [B,HW,3] f32 (model-space crop, 0 = background), fps [B,K,3] f64 (the loader's float64 anchors),

@@ -678,3 +678,41 @@ extern "C" int rdpn6d_rgb_to_nhwc4_f32(const float* x, int B, int xc, int R, flo
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Weight re-packing for the training step, all tensors in ONE launch (the optimizer changes every parameter every
+// step; the forward / dgrad kernels want [O][taps][I] slabs, flipped / transposed / phase-split, zero-padded, some with
+// a bf16 mirror).  A table entry maps the real elements of one packed tensor:
+//   dst[(o*dT + t)*dIpad + i] = src[operm(o)*so + iperm(i)*si + toff[t]]      o < O, t < T, i < I
+// (padding entries of dst are zeroed once at allocation and never touched).  Replaces ~700 tiny ATen launches per step.
+__global__ void repack_kernel(const rdpn6d_repack_desc* __restrict__ tab, int nd, long long total)
+{
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        int lo = 0, hi = nd - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (tab[mid].start <= e) lo = mid;
+            else hi = mid - 1;
+        }
+        const rdpn6d_repack_desc& D = tab[lo];
+        long long r = e - D.start;
+        const int i = (int)(r % D.I);
+        r /= D.I;
+        const int t = (int)(r % D.T);
+        const int o = (int)(r / D.T);
+        const int oo = D.operm ? D.operm[o] : o, ii = D.iperm ? D.iperm[i] : i;
+        const float v = D.src[oo * D.so + ii * D.si + D.toff[t]];
+        const long long idx = ((long long)o * D.dT + t) * D.dIpad + i;
+        if (D.dst) D.dst[idx] = v;
+        if (D.dst_bf16) reinterpret_cast<unsigned short*>(D.dst_bf16)[idx] = rd_f2bf(v);
+    }
+}
+
+extern "C" int rdpn6d_repack_f32(const rdpn6d_repack_desc* table_dev, int ndesc, long long total, void* stream)
+{
+    RD_REQUIRE(table_dev && ndesc > 0 && total > 0, "empty table");
+    const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(repack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table_dev, ndesc, total);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}

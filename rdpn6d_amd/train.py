@@ -61,7 +61,8 @@ class TrainEngine:
                        centroid=float(pc.CENTROID_LW), z=float(pc.Z_LW), pm_norm=1 if pc.PM_NORM_BY_EXTENT else 0)
         self.is_allo = 1 if "allo" in pc.ROT_TYPE else 0
         self.bufs = {}
-        self.packed = []     # (refresh_fn) closures re-packing weights into persistent buffers
+        self._bn_counters = []  # num_batches_tracked buffers, bumped together once per forward
+        self.repack = []     # table entries of the one-launch weight re-pack (see _pack_map)
         self.fwd, self.bwd = [], []   # launch closures
         self._scratch_d = torch.empty(512 * 1024 * 2 + 4096, dtype=torch.float64, device=device)
         self._wg_floats = 0
@@ -152,19 +153,51 @@ class TrainEngine:
         run.keep = (d, keep)
         return run
 
-    # persistent packed-weight buffer refreshed from the live parameter by `fn`
-    def _packed(self, shape, fn):
-        t = torch.zeros(*shape, dtype=torch.float32, device=self.dev)
-        self.packed.append((t, fn))
-        return t
+    # persistent packed-weight buffers, all refreshed from the live parameters by ONE rdpn6d_repack_f32 launch:
+    #   dst[(o*dT + t)*dIpad + i] = src[operm(o)*so + iperm(i)*si + toff[t]]   (see include/rdpn6d.h)
+    def _pack_map(self, shape, src, O, T, I, so, si, toff, operm=None, iperm=None, dst=None, dst_off=0, dT=None, dIpad=None):
+        if dst is None:
+            dst = torch.zeros(*shape, dtype=torch.float32, device=self.dev)
+        assert src.dtype == torch.float32 and T <= 9 and len(toff) == T
+        dev_i32 = lambda v: None if v is None else torch.as_tensor(list(v), dtype=torch.int32).to(self.dev)  # noqa: E731
+        self.repack.append(dict(src=src, dst=dst, off=int(dst_off), O=int(O), T=int(T), I=int(I), so=int(so), si=int(si),
+                                toff=[int(v) for v in toff], operm=dev_i32(operm), iperm=dev_i32(iperm),
+                                dT=int(dT if dT is not None else (shape[1] if len(shape) == 3 else 1)),
+                                dIpad=int(dIpad if dIpad is not None else shape[-1])))
+        return dst
+
+    def _repack_table(self):
+        import numpy as np
+
+        ptrs = tuple(e["src"].data_ptr() for e in self.repack)
+        if getattr(self, "_repack_ptrs", None) == ptrs:
+            return
+        dt = np.dtype([("src", "<u8"), ("dst", "<u8"), ("dst_bf16", "<u8"), ("operm", "<u8"), ("iperm", "<u8"), ("so", "<i8"),
+                       ("si", "<i8"), ("start", "<i8"), ("O", "<i4"), ("T", "<i4"), ("I", "<i4"), ("dT", "<i4"), ("dIpad", "<i4"),
+                       ("toff", "<i4", (9,))])
+        assert dt.itemsize == 120
+        tab = np.zeros(len(self.repack), dt)
+        start = 0
+        mirror_of = {id(t): tb for tb, t in self.mirrors}
+        for r, e in zip(tab, self.repack):
+            r["src"], r["dst"] = e["src"].data_ptr(), e["dst"].data_ptr() + 4 * e["off"]
+            tb = mirror_of.get(id(e["dst"]))
+            r["dst_bf16"] = tb.data_ptr() + 2 * e["off"] if tb is not None else 0
+            r["operm"] = e["operm"].data_ptr() if e["operm"] is not None else 0
+            r["iperm"] = e["iperm"].data_ptr() if e["iperm"] is not None else 0
+            r["so"], r["si"], r["start"] = e["so"], e["si"], start
+            r["O"], r["T"], r["I"], r["dT"], r["dIpad"] = e["O"], e["T"], e["I"], e["dT"], e["dIpad"]
+            r["toff"][: e["T"]] = e["toff"]
+            start += e["O"] * e["T"] * e["I"]
+        self._repack_dev = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(self.dev)
+        self._repack_total, self._repack_ptrs = start, ptrs
 
     def refresh_weights(self):
-        """re-pack forward / dgrad weights from the current parameters (call after every optimizer step)"""
-        with torch.no_grad():
-            for t, fn in self.packed:
-                fn(t)
-            for tb, t in self.mirrors:
-                tb.copy_(t)
+        """re-pack forward / dgrad weights (and their bf16 mirrors) from the current parameters: one launch.  Call after
+        every optimizer step.  The table is rebuilt only when a parameter's storage moved (e.g. an optimizer that re-homes
+        the parameters into a flat buffer)."""
+        self._repack_table()
+        _lib.check(self.lib.rdpn6d_repack_f32(_ptr(self._repack_dev), len(self.repack), self._repack_total, self.st()), "repack")
 
     # ------------------------------------------------------------------ layer builders
     def conv_unit(self, name, P, x, xhw, in_cs, in_co, cin_real, y, yhw, out_cs, out_co, *, stride=1, perm=None, bias=None,
@@ -180,11 +213,11 @@ class TrainEngine:
         npad = _pad_to(cout, 64)
         lib, B = self.lib, self.B
         # ---- forward weights
-        wf = self._packed((npad, k * k, cin_pad), lambda t, w=w, perm=perm, cin_pad=cin_pad: t.copy_(
-            pack_conv_weight(w.detach().float(), cin_pad=cin_pad, perm=perm)))
+        kk2, cin_w = k * k, w.shape[1]
+        wf = self._pack_map((npad, kk2, cin_pad), w, cout, kk2, cin_real, cin_w * kk2, kk2, range(kk2), iperm=perm)
         bvec = None
         if bias is not None:
-            bvec = self._packed((npad,), lambda t, b=bias: t[: b.numel()].copy_(b.detach().float()))
+            bvec = self._pack_map((npad,), bias, 1, 1, cout, 0, 1, [0])
         taps = _taps(k, pad)
         if lowp:
             xb, _ = self._bf16_of(self.fwd, x, in_cs, in_co, cin_real, B * xhw[0] * xhw[1], cache=True)
@@ -269,12 +302,9 @@ class TrainEngine:
                 return self._launch_conv(nm, dd, wd)
 
             if stride == 1:
-                def pk(t, w=w, perm=perm):
-                    ww = w.detach().float()
-                    if perm is not None:
-                        ww = ww[:, perm]
-                    t.copy_(pack_conv_weight(ww.flip(2, 3).permute(1, 0, 2, 3), cin_pad=n_red))
-                wd = self._packed((cdx, k * k, n_red), pk)
+                # dgrad weights: dst[c][t][n] = w[n][perm(c)][flipped t]
+                wd = self._pack_map((cdx, kk2, n_red), w, cin_real, kk2, cout, kk2, cin_w * kk2, [kk2 - 1 - t for t in range(kk2)],
+                                    operm=perm)
                 dd = self._conv_desc(g_src, yhw, g_cs, g_co, n_red, wd, dx, xhw, dx_cs, in_co, cin_real, taps, stride=1,
                                      res=dx_res, res_cs=dx_cs)
                 launches.append(dlaunch("dgrad " + name, dd, wd))
@@ -288,19 +318,13 @@ class TrainEngine:
                             ptaps = [(dyo, dxo) for _, dyo in ys for _, dxo in xs]
                             kk = [(ky, kx) for ky, _ in ys for kx, _ in xs]
 
-                            def pk(t, w=w, kk=kk, n_red=n_red):
-                                ww = w.detach().float()
-                                for ti, (ky, kx) in enumerate(kk):
-                                    t[: ww.shape[1], ti, : ww.shape[0]].copy_(ww[:, :, ky, kx].t())
-                            wd = self._packed((cdx, len(ptaps), n_red), pk)
+                            wd = self._pack_map((cdx, len(ptaps), n_red), w, cin_real, len(ptaps), cout, kk2, cin_w * kk2,
+                                                [ky * k + kx for ky, kx in kk])
                             dd = self._conv_desc(g_src, yhw, g_cs, g_co, n_red, wd, dx, xhw, dx_cs, in_co, cin_real, ptaps,
                                                  phase=(yhw[0], yhw[1], 2, 2, py, px))
                             launches.append(dlaunch(f"dgrad {name} phase{py}{px}", dd, wd))
                 else:  # 1x1 stride 2: only the even pixels receive a gradient; accumulate onto what is there
-                    def pk(t, w=w):
-                        ww = w.detach().float()
-                        t[: ww.shape[1], 0, : ww.shape[0]].copy_(ww[:, :, 0, 0].t())
-                    wd = self._packed((cdx, 1, n_red), pk)
+                    wd = self._pack_map((cdx, 1, n_red), w, cin_real, 1, cout, kk2, cin_w * kk2, [0])
                     dd = self._conv_desc(g_src, yhw, g_cs, g_co, n_red, wd, dx, xhw, dx_cs, in_co, cin_real, [(0, 0)],
                                          phase=(yhw[0], yhw[1], 2, 2, 0, 0), res=dx, res_cs=dx_cs)
                     launches.append(dlaunch("dgrad " + name, dd, wd))
@@ -314,8 +338,7 @@ class TrainEngine:
         the gradient of the residual branch)."""
         lib = self.lib
         mean, invstd = self.buf("mean:" + name, _pad_to(C, 4)), self.buf("istd:" + name, _pad_to(C, 4))
-        ga = self._packed((_pad_to(C, 4),), lambda t, p=bn.weight: t[: p.numel()].copy_(p.detach()))
-        be = self._packed((_pad_to(C, 4),), lambda t, p=bn.bias: t[: p.numel()].copy_(p.detach()))
+        ga, be = bn.weight, bn.bias  # read in place (C % 4 == 0); pointers are taken at launch time
 
         def fwd():
             _lib.check(lib.rdpn6d_bn_train_stats_f32(_ptr(x_raw), M, C, cs, co, BN_EPS, BN_MOM, _ptr(mean), _ptr(invstd),
@@ -323,9 +346,9 @@ class TrainEngine:
                                                      self.st()), "bn stats " + name)
             _lib.check(lib.rdpn6d_bn_apply_f32(_ptr(x_raw), cs, co, _ptr(mean), _ptr(invstd), _ptr(ga), _ptr(be), _ptr(res),
                                                res_cs, 0, _ptr(y), ycs, yco, M, C, 1 if relu else 0, self.st()), "bn apply " + name)
-            bn.num_batches_tracked += 1
 
         self.fwd.append(fwd)
+        self._bn_counters.append(bn.num_batches_tracked)
         if dy is None:
             dy, dy_cs, dy_co = self.buf("d:" + name, *y.shape, zero=True), ycs, yco
         else:
@@ -349,7 +372,9 @@ class TrainEngine:
         R2, R4, R8 = R // 2, R // 4, R // 8
         self.x = self.buf("x", B, 6, R, R)
         # ---- stem
-        wst = self._packed((64, 7, 7, 3), lambda t: t.copy_(bb.conv1.weight.detach().float().permute(0, 2, 3, 1)))
+        # [64][7][7][3] <- OIHW [64][3][7][7]: row o' = n*49 + tap reads src[n*147 + tap + c*49]
+        wst = self._pack_map((64, 7, 7, 3), bb.conv1.weight, 64 * 49, 1, 3, 1, 49, [0],
+                             operm=[n * 147 + t for n in range(64) for t in range(49)], dT=1, dIpad=3)
         raw0 = self.buf("raw:stem", B, R2, R2, 64)
         a0 = self.buf("act:stem", B, R2, R2, 64)
         self.fwd.append(lambda: _lib.check(lib.rdpn6d_stem_conv7x7_raw_f32(_ptr(self.x), B, 6, R, _ptr(wst), _ptr(raw0), self.st()), "stem"))
@@ -451,11 +476,8 @@ class TrainEngine:
                 ptaps = [(dyo, dxo) for _, dyo in ys for _, dxo in xs]
                 kk = [(ky, kx) for ky, _ in ys for kx, _ in xs]
 
-                def pk(t, kk=kk):
-                    ww = wt.detach().float()
-                    for ti, (ky, kx) in enumerate(kk):
-                        t[:F, ti].copy_(ww[:, :, ky, kx].t())
-                wp = self._packed((_pad_to(F, 64), len(ptaps), 1024), pk)
+                # dst[f][ti][cin] = wt[cin][f][ky][kx]
+                wp = self._pack_map((_pad_to(F, 64), len(ptaps), 1024), wt, F, len(ptaps), 1024, 9, F * 9, [ky * 3 + kx for ky, kx in kk])
                 if self.amp:
                     featb, _ = self._bf16_of(self.fwd, feat, 1024, 0, 1024, B * R8 * R8, cache=True)
                     wpb = self._mirror(wp)
@@ -465,7 +487,7 @@ class TrainEngine:
                     d = self._conv_desc(feat, (R8, R8), 1024, 0, 1024, wp, rt0, (R4, R4), F, 0, F, ptaps, phase=(R8, R8, 2, 2, py, px))
                     self.fwd.append(self._launch_conv(f"convT phase{py}{px}", d, wp))
         d_rt0 = self.buf("d:head0", B, R4, R4, F, zero=True)
-        wdT = self._packed((1024, 9, F), lambda t: t.copy_(pack_conv_weight(wt.detach().float())))  # ConvT weight IS the OIHW of its dgrad conv
+        wdT = self._pack_map((1024, 9, F), wt, 1024, 9, F, F * 9, 9, range(9))  # ConvT weight IS the OIHW of its dgrad conv
         convT_bwd = []
         if self.amp:
             assert F % 32 == 0
@@ -533,8 +555,7 @@ class TrainEngine:
             r_i, a_i = self.buf(f"raw:pnp{i}", B, oh, oh, fd), self.buf(f"act:pnp{i}", B, oh, oh, fd)
             d_ri = self.conv_unit(f"pnp_net.features.{i}", conv, x, (hw, hw), cs, 0, cin_real, r_i, (oh, oh), fd, 0, stride=2, dx=d_x)
             stats = self.buf(f"gnstats:{i}", B, gn.groups, 2)
-            ga = self._packed((fd,), lambda t, p=gn.weight: t.copy_(p.detach()))
-            be = self._packed((fd,), lambda t, p=gn.bias: t.copy_(p.detach()))
+            ga, be = gn.weight, gn.bias  # read in place
             self.fwd.append(lambda r_i=r_i, a_i=a_i, oh=oh, fd=fd, gn=gn, ga=ga, be=be, stats=stats: _lib.check(
                 lib.rdpn6d_groupnorm_relu_train_f32(_ptr(r_i), _ptr(a_i), B, oh * oh, fd, gn.groups, _ptr(ga), _ptr(be), _ptr(stats), self.st()), "gn"))
             d_ai = self.buf(f"d:pnp_act{i}", B, oh, oh, fd, zero=True)
@@ -568,13 +589,18 @@ class TrainEngine:
         out_cs = out_cs or nout
         npad = _pad_to(nout, 64)
 
-        def pk(t):
-            ww = torch.cat([p.detach().float() for p in ws], 0)
-            if w_view:
-                ww = w_view(ww)
-            t[:nout, 0].copy_(ww)
-        wf = self._packed((npad, 1, kin), pk)
-        bvec = self._packed((npad,), lambda t: t[:nout].copy_(torch.cat([p.detach().float() for p in bs], 0)))
+        # k_perm[k'] = position in the parameter's own (NCHW-flatten) K axis of the buffer's (NHWC-flatten) column k'
+        k_perm = None
+        if w_view is not None:
+            k_perm = w_view(torch.arange(kin, dtype=torch.float32).view(1, kin))[0].long().tolist()
+        wf = torch.zeros(npad, 1, kin, dtype=torch.float32, device=self.dev)
+        bvec = torch.zeros(npad, dtype=torch.float32, device=self.dev)
+        r0 = 0
+        for wp_, bp_ in zip(ws, bs):
+            n = wp_.shape[0]
+            self._pack_map(None, wp_, n, 1, kin, kin, 1, [0], iperm=k_perm, dst=wf, dst_off=r0 * kin, dT=1, dIpad=kin)
+            self._pack_map(None, bp_, 1, 1, n, 0, 1, [0], dst=bvec, dst_off=r0, dT=1, dIpad=npad)
+            r0 += n
         d = self._conv_desc(x, (1, 1), kin, 0, kin, wf, y, (1, 1), out_cs, 0, nout, [(0, 0)], shift=bvec, act=act, slope=0.1)
         self.fwd.append(self._launch_conv(name, d, (wf, bvec), ksplit=True))
         ca = _pad_to(nout, 4)
@@ -584,8 +610,12 @@ class TrainEngine:
         bg = self.buf("bg:" + name, npad)
         n_red = _pad_to(nout, 16)
         assert out_cs >= n_red
-        wd = self._packed((_pad_to(kin, 64), 1, n_red), lambda t: t[:kin, 0, :nout].copy_(
-            (w_view(torch.cat([p.detach().float() for p in ws], 0)) if w_view else torch.cat([p.detach().float() for p in ws], 0)).t()))
+        wd = torch.zeros(_pad_to(kin, 64), 1, n_red, dtype=torch.float32, device=self.dev)  # dst[k'][0][r0+j] = W_p[j][k_perm(k')]
+        r0 = 0
+        for wp_ in ws:
+            n = wp_.shape[0]
+            self._pack_map(None, wp_, kin, 1, n, 1, kin, [0], operm=k_perm, dst=wd, dst_off=r0, dT=1, dIpad=n_red)
+            r0 += n
         dd = self._conv_desc(d_y, (1, 1), out_cs, 0, n_red, wd, d_x, (1, 1), kin, 0, kin, [(0, 0)])
 
         def bwd():
@@ -626,6 +656,7 @@ class TrainEngine:
         gt_rot, gt_ratio, pts = f32(batch["ego_rot"]), f32(batch["roi_trans_ratio"]), f32(batch["roi_points"])
         for fn in self.fwd:
             fn()
+        torch._foreach_add_(self._bn_counters, 1)  # BatchNorm2d.num_batches_tracked (one fused launch)
         HW = (self.R // 4) ** 2
         lw = self.lw
         sc = self.buf("pose_scratch", 3 * B)
