@@ -26,7 +26,7 @@ def conv2d_nhwc(x, weight, scale=None, shift=None, stride=1, pad=0, residual=Non
                 out_co=0, in_co=0, cin=None, out_f32=False):
     """x NHWC [B,H,W,Cs] fp32 (Cs multiple of 4), weight OIHW (torch layout).  Returns NHWC [B,Ho,Wo,N]
     (or writes channels [out_co, out_co+N) of ``out``).  A bfloat16 ``x`` selects the bf16 matrix-pipe kernel
-    (Cs multiple of 8, reduction width padded to 32; output bf16, or fp32 with ``out_f32``)."""
+    (Cs multiple of 8, reduction width padded to 32; output and residual bf16, or both fp32 with ``out_f32``)."""
     _need_gpu(x, weight, scale, shift, residual, out)
     lib = _lib.load()
     B, H, W, cs = x.shape
@@ -38,7 +38,8 @@ def conv2d_nhwc(x, weight, scale=None, shift=None, stride=1, pad=0, residual=Non
     wp = pack_conv_weight(weight.float(), cin_pad=cin_pad)
     if bf:
         wp = wp.to(torch.bfloat16)
-        assert residual is None or residual.dtype == torch.bfloat16
+        # the residual has the output's dtype: bf16, or fp32 together with an fp32 output
+        assert residual is None or residual.dtype == (torch.float32 if out_f32 else torch.bfloat16)
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     if out is None:
         out = torch.empty(B, Ho, Wo, N, dtype=torch.bfloat16 if bf and not out_f32 else torch.float32, device=x.device)

@@ -518,7 +518,7 @@ def test_conv_igemm_bf16(dev, case):
     res = torch.randn(B, Ho, Ho, Cout, generator=g).to(dev).bfloat16() if use_res else None
     kw = dict(stride=stride, pad=k // 2, act=act, slope=0.1)
     ref = ops.conv2d_nhwc(x.float(), w.float(), sc, sh, residual=res.float() if use_res else None, **kw)
-    y32 = ops.conv2d_nhwc(x, w, sc, sh, residual=res, out_f32=True, **kw)
+    y32 = ops.conv2d_nhwc(x, w, sc, sh, residual=res.float() if use_res else None, out_f32=True, **kw)  # fp32 out <-> fp32 residual
     torch.cuda.synchronize()
     _close(y32, ref, 1e-5, "bf16 conv, fp32 store")
     if Cout % 8 == 0:

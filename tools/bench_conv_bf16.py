@@ -31,7 +31,7 @@ def check(name, H, Cin, Cout, k, stride):
     res = torch.randn(Bc, Ho, Ho, Cout, device=dev).bfloat16() if Cout % 8 == 0 else None
     ref = ops.conv2d_nhwc(x.float(), w.float(), sc, sh, stride=stride, pad=k // 2, act=1,
                           residual=res.float() if res is not None else None)
-    y32 = ops.conv2d_nhwc(x, w, sc, sh, stride=stride, pad=k // 2, act=1, residual=res, out_f32=True)
+    y32 = ops.conv2d_nhwc(x, w, sc, sh, stride=stride, pad=k // 2, act=1, residual=res.float() if res is not None else None, out_f32=True)
     y16 = ops.conv2d_nhwc(x, w, sc, sh, stride=stride, pad=k // 2, act=1, residual=res) if Cout % 8 == 0 else None
     e32 = ((y32 - ref).abs().max() / ref.abs().max()).item()
     e16 = ((y16.float() - ref.bfloat16().float()).abs().max() / ref.abs().max()).item() if y16 is not None else -1
