@@ -16,13 +16,11 @@ Generalisation over the reference's hard-coded geometry: ``nIn =
 xyz resize = ``INPUT_RES/8``, out = ``INPUT_RES/4``, ``fc1`` in = ``128*(OUT_RES/8)**2``.
 """
 import ctypes
-import math
 
 import torch
 import torch.nn as nn
 
 from . import _lib
-from .config import ConfigDict
 
 RESNET_SPEC = {18: (2, 2, 2, 2), 34: (3, 4, 6, 3)}  # BasicBlock trunks (resnet_backbone.py:15-21)
 

@@ -21,7 +21,7 @@ import ctypes
 import torch
 
 from . import _lib
-from .gdrn import _pad_to, _pad_vec, _ptr, pack_conv_weight
+from .gdrn import _pad_to, _ptr
 
 BN_EPS, BN_MOM = 1e-5, 0.1
 
