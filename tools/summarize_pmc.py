@@ -25,9 +25,10 @@ for k, v in agg.items():
     e = {"launches_profiled": v["FETCH_SIZE"][0], "avg_us": round(us, 1),
          "fetch_MB_raw": round(m["FETCH_SIZE"] * 1024 / 1e6, 1), "fetch_MB_x2": round(2 * m["FETCH_SIZE"] * 1024 / 1e6, 1),
          "write_MB": round(m["WRITE_SIZE"] * 1024 / 1e6, 1)}
-    if m.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0) > 0:
+    mops = m.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0) + m.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0)
+    if mops > 0:
         xcd_cycles = m["GRBM_GUI_ACTIVE"] / 8.0  # the counter is summed over the 8 XCDs
-        e["mfma_gflop_issued"] = round(m["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512 / 1e9, 2)
+        e["mfma_gflop_issued"] = round(mops * 512 / 1e9, 2)
         e["mfma_util_pct"] = round(100 * m["SQ_VALU_MFMA_BUSY_CYCLES"] / (xcd_cycles * 1024), 1)
         e["clock_GHz"] = round(xcd_cycles / (v["GRBM_GUI_ACTIVE"][2] / v["GRBM_GUI_ACTIVE"][0]), 2)
     out[k.replace("void ", "").split("(")[0]] = e
