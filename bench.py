@@ -104,7 +104,7 @@ def roofline(model, t, B, device, reps=3):
     achieved = flops / len(sel) / (avg_ms * 1e-3) / 1e12 if sel else 0.0
     kname = "conv_igemm_bf16_kernel<128, 128, 128, 2, 2, 2>" if plan.bf16 else "conv_igemm_f32_kernel<128, 128>"
     peak = BF16_MFMA_PEAK_TFLOPS if plan.bf16 else FP32_MFMA_PEAK_TFLOPS
-    traffic, traffic_src = pmc_traffic(kname) if B == 64 else (None, None)
+    traffic, traffic_src = pmc_traffic(kname, plan.bf16) if B == 64 else (None, None)
     return {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
         "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch (HBM+fabric, PMC)",
@@ -115,13 +115,16 @@ def roofline(model, t, B, device, reps=3):
     }
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, bf16=False):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950 rule of
-    MI355X_MICROARCH.md + WRITE_SIZE; collected in separate --pmc runs of this same command, tools/summarize_pmc.py).
-    Counters cannot be read from inside the timed process, so the figure comes from profiles/ (None if absent)."""
+    MI355X_MICROARCH.md + WRITE_SIZE; collected in separate --pmc runs of this same command, tools/pmc_bench.sh +
+    tools/summarize_pmc.py).  Counters cannot be read from inside the timed process, so the figure comes from profiles/
+    (latest summary of the same mode; None if absent)."""
     import glob
 
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")), reverse=True):
+        if ("bf16" in os.path.basename(f)) != bool(bf16):
+            continue
         try:
             e = json.load(open(f))[kernel]
             return int((e["fetch_MB_x2"] + e["write_MB"]) * 1e6), os.path.relpath(f, ROOT)
