@@ -51,6 +51,32 @@ class BasicBlock(nn.Module):
         return self.relu(y + idt)
 
 
+class Bottleneck(nn.Module):
+    """torchvision 0.17.1 Bottleneck (ResNet v1.5: the stride sits on the 3x3): 1x1-BN-ReLU, 3x3(s)-BN-ReLU, 1x1(x4)-BN,
+    (+downsample) add ReLU.  resnet_backbone.py:15-21 selects it for 50 / 101 / 152 layers; the reference itself cannot
+    RUN those (md_pointnet(512, ...) is hard-coded at :270 while layer4 then has 2048 channels), so for these trunks the
+    oracle is the build's own generalisation (pointnet in = channels of layer4) and parity with the reference is unpinned."""
+    expansion = 4
+
+    def __init__(self, cin, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        y = self.relu(self.bn1(self.conv1(x)))
+        y = self.relu(self.bn2(self.conv2(y)))
+        y = self.bn3(self.conv3(y))
+        idt = x if self.downsample is None else self.downsample(x)
+        return self.relu(y + idt)
+
+
 class PointFusion(nn.Module):
     """md_pointnet (resnet_backbone.py:23-54): point-wise MLP over (trunk feature, depth xyz)."""
 
@@ -75,25 +101,28 @@ class PointFusion(nn.Module):
 
 
 class Backbone(nn.Module):
-    LAYERS = {18: (2, 2, 2, 2), 34: (3, 4, 6, 3)}
+    LAYERS = {18: (BasicBlock, (2, 2, 2, 2)), 34: (BasicBlock, (3, 4, 6, 3)), 50: (Bottleneck, (3, 4, 6, 3)),
+              101: (Bottleneck, (3, 4, 23, 3)), 152: (Bottleneck, (3, 8, 36, 3))}  # resnet_backbone.py:15-21
 
     def __init__(self, num_layers=34):
         super().__init__()
-        self.spatial_net = PointFusion(512, (64, 128, 256, 512))
+        block, counts = self.LAYERS[num_layers]
+        self.spatial_net = PointFusion(512 * block.expansion, (64, 128, 256, 512))
         self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
         self.relu = nn.ReLU(inplace=True)
         self.maxpool = nn.MaxPool2d(3, 2, 1)
         cin = 64
-        for li, (planes, nblk) in enumerate(zip((64, 128, 256, 512), self.LAYERS[num_layers])):
+        for li, (planes, nblk) in enumerate(zip((64, 128, 256, 512), counts)):
             stride = 1 if li == 0 else 2
             blocks = []
             for bi in range(nblk):
                 ds = None
-                if bi == 0 and (stride != 1 or cin != planes):
-                    ds = nn.Sequential(nn.Conv2d(cin, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
-                blocks.append(BasicBlock(cin, planes, stride if bi == 0 else 1, ds))
-                cin = planes
+                cout = planes * block.expansion
+                if bi == 0 and (stride != 1 or cin != cout):
+                    ds = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+                blocks.append(block(cin, planes, stride if bi == 0 else 1, ds))
+                cin = cout
             setattr(self, f"layer{li + 1}", nn.Sequential(*blocks))
 
     def forward(self, x):

@@ -22,7 +22,11 @@ import torch.nn as nn
 
 from . import _lib
 
-RESNET_SPEC = {18: (2, 2, 2, 2), 34: (3, 4, 6, 3)}  # BasicBlock trunks (resnet_backbone.py:15-21)
+# resnet_backbone.py:15-21: (block expansion, blocks per layer).  Expansion 1 = torchvision BasicBlock, 4 = Bottleneck.
+# The reference cannot run the Bottleneck trunks (md_pointnet(512, ...) is hard-coded at :270 while layer4 then has
+# 2048 channels); here the point-wise fusion takes layer4's real channel count.
+RESNET_SPEC = {18: (1, (2, 2, 2, 2)), 34: (1, (3, 4, 6, 3)), 50: (4, (3, 4, 6, 3)), 101: (4, (3, 4, 23, 3)),
+               152: (4, (3, 8, 36, 3))}
 
 
 # ----------------------------------------------------------------------------- parameter holders
@@ -87,6 +91,23 @@ class BlockP(_Holder):
             self.downsample = None
 
 
+class BottleneckP(_Holder):
+    """torchvision Bottleneck (v1.5: stride on the 3x3): conv1 1x1, conv2 3x3(s), conv3 1x1 (x4)."""
+
+    def __init__(self, cin, planes, stride, downsample):
+        super().__init__()
+        self.conv1 = ConvP(cin, planes, 1, 1, 0)
+        self.bn1 = BNP(planes)
+        self.conv2 = ConvP(planes, planes, 3, stride, 1)
+        self.bn2 = BNP(planes)
+        self.conv3 = ConvP(planes, planes * 4, 1, 1, 0)
+        self.bn3 = BNP(planes * 4)
+        if downsample:
+            self.downsample = nn.Sequential(ConvP(cin, planes * 4, 1, stride, 0), BNP(planes * 4))
+        else:
+            self.downsample = None
+
+
 class PointFusionP(_Holder):
     def __init__(self, cin=512, ch=(64, 128, 256, 512)):
         super().__init__()
@@ -102,18 +123,22 @@ class BackboneP(_Holder):
     def __init__(self, num_layers=34):
         super().__init__()
         if num_layers not in RESNET_SPEC:
-            raise ValueError(f"only BasicBlock trunks {sorted(RESNET_SPEC)} are implemented, got {num_layers}")
-        self.spatial_net = PointFusionP(512, (64, 128, 256, 512))
+            raise ValueError(f"resnet trunks {sorted(RESNET_SPEC)} are implemented, got {num_layers}")
+        exp, counts = RESNET_SPEC[num_layers]
+        self.expansion = exp
+        self.spatial_net = PointFusionP(512 * exp, (64, 128, 256, 512))
         self.conv1 = ConvP(3, 64, 7, 2, 3)
         self.bn1 = BNP(64)
         cin = 64
-        for li, (planes, nblk) in enumerate(zip((64, 128, 256, 512), RESNET_SPEC[num_layers])):
+        for li, (planes, nblk) in enumerate(zip((64, 128, 256, 512), counts)):
             stride = 1 if li == 0 else 2
             blocks = []
             for bi in range(nblk):
                 s = stride if bi == 0 else 1
-                blocks.append(BlockP(cin, planes, s, bi == 0 and (s != 1 or cin != planes)))
-                cin = planes
+                cout = planes * exp
+                ds = bi == 0 and (s != 1 or cin != cout)
+                blocks.append(BlockP(cin, planes, s, ds) if exp == 1 else BottleneckP(cin, planes, s, ds))
+                cin = cout
             setattr(self, f"layer{li + 1}", nn.Sequential(*blocks))
 
 
@@ -289,37 +314,57 @@ class InferencePlan:
         p0 = self.buf("pool", B, R4, R4, 64, dtype=adt)
         self.call("maxpool", getattr(lib, f"rdpn6d_maxpool3x3s2_{sfx}"), _ptr(s0), B, R2, R2, 64, _ptr(p0))
 
-        # --- residual trunk
+        # --- residual trunk (BasicBlock: 3x3 - 3x3; Bottleneck: 1x1 - 3x3(s) - 1x1 x4; residual + ReLU in the last epilogue)
         cur, cur_hw, cur_c = p0, R4, 64
         for li in range(4):
             layer = getattr(bb, f"layer{li + 1}")
             for bi, blk in enumerate(layer):
-                cout = blk.conv1.weight.shape[0]
-                s = blk.conv1.stride
+                nm = f"layer{li + 1}.{bi}"
+                bottleneck = hasattr(blk, "conv3")
+                s = (blk.conv2 if bottleneck else blk.conv1).stride
+                cout = (blk.conv3 if bottleneck else blk.conv2).weight.shape[0]
                 ohw = cur_hw // s
-                t = self.buf(f"l{li}_t{bi % 2}", B, ohw, ohw, cout, dtype=adt)
-                o = self.buf(f"l{li}_o{bi % 2}", B, ohw, ohw, cout, dtype=adt)
-                w1 = pw(blk.conv1.weight.detach().float())
-                sc1, sh1 = fold_bn(blk.bn1, npad=w1.shape[0])
-                self.conv(f"layer{li + 1}.{bi}.conv1", cur, (cur_hw, cur_hw), w1, sc1, sh1, t, (ohw, ohw), cin=cur_c,
-                          in_cs=cur_c, k=3, stride=s, pad=1, N=cout, out_cs=cout, act=1, lowp=lp)
                 res = cur
                 if blk.downsample is not None:
                     dsb = self.buf(f"l{li}_ds", B, ohw, ohw, cout, dtype=adt)
                     wd = pw(blk.downsample[0].weight.detach().float())
                     scd, shd = fold_bn(blk.downsample[1], npad=wd.shape[0])
-                    self.conv(f"layer{li + 1}.{bi}.downsample", cur, (cur_hw, cur_hw), wd, scd, shd, dsb, (ohw, ohw),
+                    self.conv(f"{nm}.downsample", cur, (cur_hw, cur_hw), wd, scd, shd, dsb, (ohw, ohw),
                               cin=cur_c, in_cs=cur_c, k=1, stride=s, pad=0, N=cout, out_cs=cout, act=0, lowp=lp)
                     res = dsb
-                w2 = pw(blk.conv2.weight.detach().float())
-                sc2, sh2 = fold_bn(blk.bn2, npad=w2.shape[0])
-                self.conv(f"layer{li + 1}.{bi}.conv2", t, (ohw, ohw), w2, sc2, sh2, o, (ohw, ohw), cin=cout, in_cs=cout,
-                          k=3, stride=1, pad=1, N=cout, out_cs=cout, res=res, res_cs=cout, act=1, lowp=lp)
+                o = self.buf(f"l{li}_o{bi % 2}", B, ohw, ohw, cout, dtype=adt)
+                if bottleneck:
+                    width = blk.conv1.weight.shape[0]
+                    t1 = self.buf(f"l{li}_ta{bi % 2}", B, cur_hw, cur_hw, width, dtype=adt)
+                    t2 = self.buf(f"l{li}_tb{bi % 2}", B, ohw, ohw, width, dtype=adt)
+                    w1 = pw(blk.conv1.weight.detach().float())
+                    sc1, sh1 = fold_bn(blk.bn1, npad=w1.shape[0])
+                    self.conv(f"{nm}.conv1", cur, (cur_hw, cur_hw), w1, sc1, sh1, t1, (cur_hw, cur_hw), cin=cur_c, in_cs=cur_c,
+                              k=1, N=width, out_cs=width, act=1, lowp=lp)
+                    w2 = pw(blk.conv2.weight.detach().float())
+                    sc2, sh2 = fold_bn(blk.bn2, npad=w2.shape[0])
+                    self.conv(f"{nm}.conv2", t1, (cur_hw, cur_hw), w2, sc2, sh2, t2, (ohw, ohw), cin=width, in_cs=width, k=3,
+                              stride=s, pad=1, N=width, out_cs=width, act=1, lowp=lp)
+                    w3 = pw(blk.conv3.weight.detach().float())
+                    sc3, sh3 = fold_bn(blk.bn3, npad=w3.shape[0])
+                    self.conv(f"{nm}.conv3", t2, (ohw, ohw), w3, sc3, sh3, o, (ohw, ohw), cin=width, in_cs=width, k=1, N=cout,
+                              out_cs=cout, res=res, res_cs=cout, act=1, lowp=lp)
+                else:
+                    t = self.buf(f"l{li}_t{bi % 2}", B, ohw, ohw, cout, dtype=adt)
+                    w1 = pw(blk.conv1.weight.detach().float())
+                    sc1, sh1 = fold_bn(blk.bn1, npad=w1.shape[0])
+                    self.conv(f"{nm}.conv1", cur, (cur_hw, cur_hw), w1, sc1, sh1, t, (ohw, ohw), cin=cur_c,
+                              in_cs=cur_c, k=3, stride=s, pad=1, N=cout, out_cs=cout, act=1, lowp=lp)
+                    w2 = pw(blk.conv2.weight.detach().float())
+                    sc2, sh2 = fold_bn(blk.bn2, npad=w2.shape[0])
+                    self.conv(f"{nm}.conv2", t, (ohw, ohw), w2, sc2, sh2, o, (ohw, ohw), cin=cout, in_cs=cout,
+                              k=3, stride=1, pad=1, N=cout, out_cs=cout, res=res, res_cs=cout, act=1, lowp=lp)
                 cur, cur_hw, cur_c = o, ohw, cout
 
         # --- x4 bilinear up-sampling + point-wise fusion with the depth xyz
-        up = self.buf("up", B, R8, R8, 512, dtype=adt)
-        self.call("upsample", getattr(lib, f"rdpn6d_upsample_bilinear_{sfx}"), _ptr(cur), B, cur_hw, cur_hw, 512,
+        C4 = cur_c  # layer4 channels: 512 (BasicBlock) | 2048 (Bottleneck)
+        up = self.buf("up", B, R8, R8, C4, dtype=adt)
+        self.call("upsample", getattr(lib, f"rdpn6d_upsample_bilinear_{sfx}"), _ptr(cur), B, cur_hw, cur_hw, C4,
                   R8 // cur_hw, _ptr(up))
         sn = bb.spatial_net
         pcs = 96 if lp else 80  # [emb(64) | xyz(3) | 0-pad] to the K-chunk granularity of the conv kernel
@@ -327,7 +372,7 @@ class InferencePlan:
         self.xyz_args = (B, 6, R, 8, _ptr(pin), pcs, 64)
         we = pw(sn.xyz_emb.weight.detach().float())
         sce, she = fold_bn(sn.xb, sn.xyz_emb.bias, npad=we.shape[0])
-        self.conv("spatial_net.xyz_emb", up, (R8, R8), we, sce, she, pin, (R8, R8), cin=512, in_cs=512, N=64, out_cs=pcs,
+        self.conv("spatial_net.xyz_emb", up, (R8, R8), we, sce, she, pin, (R8, R8), cin=C4, in_cs=C4, N=64, out_cs=pcs,
                   act=1, lowp=lp)
         perm = list(range(3, 67)) + [0, 1, 2]  # reference order [xyz | emb] -> buffer order [emb | xyz]
         wc1 = pw(sn.conv1.weight.detach().float(), cin_pad=pcs, perm=perm)

@@ -119,12 +119,13 @@ def make_inputs(B, seed=0, res=256, num_regions=32, cam="lm"):
 def make_train_gt(B, inputs, seed=5):
     """Seeded GT tensors in the batch_data contract (engine_utils.py:6-63)."""
     rng = _rng(seed, 99)
-    r = 64
+    r = int(inputs["roi_coord_2d"].shape[-1])  # output resolution (64 for 256x256 crops)
+    sc = np.float32(r / 64.0)                  # blob geometry scales with it (exactly 1 at the reference resolution)
     yy, xx = np.mgrid[0:r, 0:r].astype(np.float32)
     gt = {}
-    cx = rng.random(B, dtype=np.float32) * 20 + 22
-    cy = rng.random(B, dtype=np.float32) * 20 + 22
-    rad = rng.random(B, dtype=np.float32) * 10 + 12
+    cx = (rng.random(B, dtype=np.float32) * 20 + 22) * sc
+    cy = (rng.random(B, dtype=np.float32) * 20 + 22) * sc
+    rad = (rng.random(B, dtype=np.float32) * 10 + 12) * sc
     blob = (((xx[None] - cx[:, None, None]) ** 2 + (yy[None] - cy[:, None, None]) ** 2) < rad[:, None, None] ** 2)
     gt["roi_mask_visib"] = blob.astype(np.float32)
     gt["roi_mask_trunc"] = blob.astype(np.float32)

@@ -403,6 +403,37 @@ class TrainEngine:
         for li in range(4):
             for bi, blk in enumerate(getattr(bb, f"layer{li + 1}")):
                 nm = f"layer{li + 1}.{bi}"
+                if hasattr(blk, "conv3"):  # Bottleneck: 1x1 - 3x3(s) - 1x1(x4)
+                    width, s, cout = blk.conv1.weight.shape[0], blk.conv2.stride, blk.conv3.weight.shape[0]
+                    ohw = hw // s
+                    M1, M = B * hw * hw, B * ohw * ohw
+                    r1, a1 = self.buf(f"raw:{nm}.c1", B, hw, hw, width), self.buf(f"act:{nm}.c1", B, hw, hw, width)
+                    r2, a2 = self.buf(f"raw:{nm}.c2", B, ohw, ohw, width), self.buf(f"act:{nm}.c2", B, ohw, ohw, width)
+                    r3, out = self.buf(f"raw:{nm}.c3", B, ohw, ohw, cout), self.buf(f"act:{nm}", B, ohw, ohw, cout)
+                    d_out = self.buf(f"d:{nm}.out", B, ohw, ohw, cout, zero=True)
+                    dres = self.buf(f"dres:{nm}", B, ohw, ohw, cout)
+                    has_ds = blk.downsample is not None
+                    res_t = cur
+                    if has_ds:
+                        rd, ad = self.buf(f"raw:{nm}.ds", B, ohw, ohw, cout), self.buf(f"act:{nm}.ds", B, ohw, ohw, cout)
+                        # registered first = runs last in the backward: accumulates onto conv1's input gradient
+                        d_rd = self.conv_unit(f"{nm}.downsample.0", blk.downsample[0], cur, (hw, hw), c, 0, c, rd, (ohw, ohw), cout, 0,
+                                              stride=s, dx=d_cur, dx_res=d_cur if s == 1 else None)
+                        res_t = ad
+                    d_r1 = self.conv_unit(f"{nm}.conv1", blk.conv1, cur, (hw, hw), c, 0, c, r1, (hw, hw), width, 0, dx=d_cur,
+                                          dx_res=None if has_ds else dres)
+                    if has_ds:
+                        self.bn_unit(f"{nm}.downsample.1", blk.downsample[1], rd, cout, 0, cout, M, ad, cout, 0, False, dx=d_rd,
+                                     dy=dres, dy_cs=cout)
+                    d_a1 = self.bn_unit(f"{nm}.bn1", blk.bn1, r1, width, 0, width, M1, a1, width, 0, True, dx=d_r1)
+                    d_r2 = self.conv_unit(f"{nm}.conv2", blk.conv2, a1, (hw, hw), width, 0, width, r2, (ohw, ohw), width, 0, stride=s,
+                                          dx=d_a1)
+                    d_a2 = self.bn_unit(f"{nm}.bn2", blk.bn2, r2, width, 0, width, M, a2, width, 0, True, dx=d_r2)
+                    d_r3 = self.conv_unit(f"{nm}.conv3", blk.conv3, a2, (ohw, ohw), width, 0, width, r3, (ohw, ohw), cout, 0, dx=d_a2)
+                    self.bn_unit(f"{nm}.bn3", blk.bn3, r3, cout, 0, cout, M, out, cout, 0, True, res=res_t, res_cs=cout, dx=d_r3,
+                                 dres=dres, dy=d_out, dy_cs=cout)
+                    cur, d_cur, hw, c = out, d_out, ohw, cout
+                    continue
                 cout, s = blk.conv1.weight.shape[0], blk.conv1.stride
                 ohw = hw // s
                 M = B * ohw * ohw
@@ -430,12 +461,13 @@ class TrainEngine:
                              dres=dres, dy=d_out, dy_cs=cout)
                 cur, d_cur, hw, c = out, d_out, ohw, cout
         # ---- upsample + point-wise fusion
-        up = self.buf("act:up", B, R8, R8, 512)
+        C4 = c  # layer4 channels: 512 (BasicBlock) | 2048 (Bottleneck)
+        up = self.buf("act:up", B, R8, R8, C4)
         f = R8 // hw
         l4out, d_l4out, l4hw = cur, d_cur, hw
-        self.fwd.append(lambda: _lib.check(lib.rdpn6d_upsample_bilinear_f32(_ptr(l4out), B, l4hw, l4hw, 512, f, _ptr(up), self.st()), "upsample"))
-        d_up = self.buf("d:up", B, R8, R8, 512, zero=True)
-        self.bwd.append([lambda: _lib.check(lib.rdpn6d_upsample_bilinear_backward_f32(_ptr(d_up), B, l4hw, l4hw, 512, f, _ptr(d_l4out),
+        self.fwd.append(lambda: _lib.check(lib.rdpn6d_upsample_bilinear_f32(_ptr(l4out), B, l4hw, l4hw, C4, f, _ptr(up), self.st()), "upsample"))
+        d_up = self.buf("d:up", B, R8, R8, C4, zero=True)
+        self.bwd.append([lambda: _lib.check(lib.rdpn6d_upsample_bilinear_backward_f32(_ptr(d_up), B, l4hw, l4hw, C4, f, _ptr(d_l4out),
                                                                                    self.st()), "upsample bwd")])
         sn = bb.spatial_net
         Mp = B * R8 * R8
@@ -443,7 +475,7 @@ class TrainEngine:
         d_pin = self.buf("d:pn_in", B, R8, R8, 80, zero=True)
         self.fwd.append(lambda: _lib.check(lib.rdpn6d_xyz_subsample_f32(_ptr(self.x), B, 6, R, 8, _ptr(pin), 80, 64, self.st()), "xyz"))
         r_e = self.buf("raw:pn.emb", B, R8, R8, 64)
-        d_re = self.conv_unit("spatial_net.xyz_emb", sn.xyz_emb, up, (R8, R8), 512, 0, 512, r_e, (R8, R8), 64, 0, bias=sn.xyz_emb.bias, dx=d_up)
+        d_re = self.conv_unit("spatial_net.xyz_emb", sn.xyz_emb, up, (R8, R8), C4, 0, C4, r_e, (R8, R8), 64, 0, bias=sn.xyz_emb.bias, dx=d_up)
         self.bn_unit("spatial_net.xb", sn.xb, r_e, 64, 0, 64, Mp, pin, 80, 0, True, dx=d_re, dy=d_pin, dy_cs=80)
         r1p, a1p = self.buf("raw:pn.c1", B, R8, R8, 128), self.buf("act:pn.c1", B, R8, R8, 128)
         perm = list(range(3, 67)) + [0, 1, 2]

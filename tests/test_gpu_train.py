@@ -333,3 +333,78 @@ def test_maxpool_backward_first_max_rule_and_stem_im2col():
     ref = F.unfold(img[:, :3].cpu(), 7, padding=3, stride=2)            # (B, c*49 + ky*7 + kx, L)
     ref = ref.view(2, 3, 49, 64).permute(0, 3, 2, 1).reshape(128, 147)  # -> [pixel][(ky*7+kx)*3 + c]
     assert torch.equal(col[:, :147].cpu(), ref) and col[:, 147:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("amp", [False, True])
+def test_resnet50_training_step(amp):
+    """Bottleneck trunk (BASELINE config 5: ResNet-50, 320x320, reduced precision): the whole training step against the
+    generalised oracle's autograd, fp64 graph as the yardstick (fp32), plus a loss-goes-down run in mixed precision."""
+    from oracle import model_oracle
+    from rdpn6d_amd import synth
+    from rdpn6d_amd.config import gdrn_base_cfg
+    from rdpn6d_amd.gdrn import build_model_optimizer
+    from rdpn6d_amd.ranger import Ranger
+
+    dev = torch.device("cuda:0")
+    R = 320
+    cfg = gdrn_base_cfg(mask_attention="mul", device="cuda")
+    cfg.MODEL.CDPN.BACKBONE.NUM_LAYERS = 50
+    cfg.MODEL.CDPN.BACKBONE.INPUT_RES, cfg.MODEL.CDPN.BACKBONE.OUTPUT_RES = R, R // 4
+    cfg.SOLVER.AMP.ENABLED = amp
+    model, _ = build_model_optimizer(cfg)
+    sd = synth.make_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=99)
+    sd = {k: torch.from_numpy(np.asarray(v)).clone() for k, v in sd.items()}
+    for k in sd:
+        if k.endswith("bn3.weight"):
+            sd[k] *= 0.25
+    model.load_state_dict(sd, strict=True)
+    inp = synth.make_inputs(2, seed=3, res=R)
+    gt = synth.make_train_gt(2, inp)
+    b = {k: torch.from_numpy(v).to(dev) for k, v in {**inp, **gt}.items()}
+    if amp:
+        opt = Ranger([p for p in model.parameters()], lr=1e-3)
+        hist = []
+        for it in range(8):
+            _, ld = model(b["roi_img"], gt_xyz=b["roi_xyz"], gt_mask_trunc=b["roi_mask_trunc"], gt_mask_visib=b["roi_mask_visib"],
+                          gt_mask_obj=b["roi_mask_obj"], gt_region=b["roi_region"], gt_ego_rot=b["ego_rot"], gt_points=b["roi_points"],
+                          sym_infos=None, gt_trans=b["trans"], gt_trans_ratio=b["roi_trans_ratio"], roi_classes=b["roi_cls"],
+                          roi_coord_2d=b["roi_coord_2d"], roi_cams=b["roi_cam"], roi_centers=b["roi_center"], roi_whs=b["roi_wh"],
+                          roi_extents=b["roi_extent"], resize_ratios=b["resize_ratio"], do_loss=True, fps=b["fps"])
+            losses = sum(ld.values())
+            assert torch.isfinite(losses).all()
+            opt.zero_grad(set_to_none=True)
+            losses.backward()
+            opt.step()
+            hist.append(losses.item())
+        print("resnet50 320x320 AMP: total loss over 8 Ranger steps:", [round(h, 4) for h in hist])
+        # two crops, batch statistics, lookahead: not monotone - the best of the later steps must beat the start
+        assert model.train_engine(2, dev).amp and min(hist[3:]) < hist[0]
+        return
+    eng = model.train_engine(2, dev)
+    losses = eng.forward_backward(b)
+    torch.cuda.synchronize()
+    t = {k: torch.from_numpy(v) for k, v in {**inp, **gt}.items()}
+    grads = {}
+    for dtype in (torch.float32, torch.float64):
+        o = model_oracle.GDRNOracle(32, "mul", out_res=R // 4, num_layers=50)
+        o.load_state_dict(sd, strict=True)
+        o = o.to(dtype).train()
+        tt = {k: (v.to(dtype) if v.dtype.is_floating_point else v) for k, v in t.items()}
+        out = o(tt["roi_img"], tt["roi_coord_2d"], tt["fps"], tt["roi_cam"], tt["roi_center"], tt["roi_wh"], tt["resize_ratio"], train_pose=True)
+        L = model_oracle.gdrn_losses(out, tt, tt["roi_extent"])
+        sum(L.values()).backward()
+        grads[dtype] = ({k: p.grad.double() for k, p in o.named_parameters()}, L)
+    g32, g64 = grads[torch.float32][0], grads[torch.float64][0]
+    for k, v in losses.items():
+        ref = grads[torch.float64][1][k].item()
+        assert abs(v.item() - ref) <= 2e-3 * max(1.0, abs(ref)), (k, v.item(), ref)
+    eh, ec = [], []
+    for name, p in model.named_parameters():
+        n = g64[name].norm().item()
+        if n < 1e-4:
+            continue
+        eh.append((p.grad.cpu().double() - g64[name]).norm().item() / n)
+        ec.append((g32[name] - g64[name]).norm().item() / n)
+    med_h, med_c = float(np.median(eh)), float(np.median(ec))
+    print(f"resnet50 320x320: {len(eh)} gradient tensors, median rel err vs fp64: HIP {med_h:.2e}, CPU fp32 {med_c:.2e}; worst HIP {max(eh):.2e} CPU {max(ec):.2e}")
+    assert med_h <= max(2.0 * med_c, 1e-3) and max(eh) <= max(3.0 * max(ec), 5e-2)
