@@ -81,3 +81,25 @@ def test_weight_packing_and_bn_fold():
     ref = torch.nn.functional.batch_norm(x + 1.0, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, 0.0, 1e-5)
     assert torch.allclose(x * sc[:4] + sh[:4], ref, atol=1e-6)
     assert sc.numel() == 64 and (sc[4:] == 1).all() and (sh[4:] == 0).all()
+
+
+@pytest.mark.parametrize("layers,nparams_trunk_m", [(18, 11.2), (50, 23.5), (101, 42.5)])
+def test_other_resnet_trunks_match_the_oracle_key_for_key(layers, nparams_trunk_m):
+    """resnet_backbone.py:15-21 (BasicBlock 18 / 34, Bottleneck 50 / 101 / 152): same state_dict keys and shapes as the
+    oracle's torchvision-style blocks (so torchvision://resnetNN checkpoints load), point-wise fusion input = layer4 width."""
+    from oracle import model_oracle
+
+    cfg = gdrn_base_cfg(device="cpu")
+    cfg.MODEL.CDPN.BACKBONE.NUM_LAYERS = layers
+    model, _ = build_model_optimizer(cfg)
+    orc = model_oracle.GDRNOracle(32, "none", num_layers=layers)
+    a, b = model.state_dict(), orc.state_dict()
+    assert set(a) == set(b) and all(tuple(a[k].shape) == tuple(b[k].shape) for k in a)
+    exp = 1 if layers < 50 else 4
+    assert tuple(a["backbone.spatial_net.xyz_emb.weight"].shape) == (64, 512 * exp, 1, 1)
+    trunk = sum(v.numel() for k, v in model.backbone.named_parameters() if k.startswith(("conv1", "bn1", "layer")))
+    assert abs(trunk / 1e6 - nparams_trunk_m) < 0.1  # torchvision resnet18 / 50 / 101 without the fc layer
+    bad = gdrn_base_cfg(device="cpu")
+    bad.MODEL.CDPN.BACKBONE.NUM_LAYERS = 35
+    with pytest.raises(ValueError):
+        build_model_optimizer(bad)
