@@ -18,29 +18,7 @@
 //     + a raw s_barrier, so the loads of chunk k+3 stay in flight across the barrier that publishes chunk k+2.  The
 //     L2 -> LDS round trip (~1.5 us under load) is what bounds the 2-stage form; the wider tile also moves 25 % fewer
 //     bytes per FLOP.
-#include "common.h"
-
-struct ConvBArgs {
-    rdpn6d_conv_desc d;
-    long long M;
-    int HoWo;
-    int cchunks;  // Cin*2 / RB
-    int nk;       // ntaps * cchunks
-    int Ktot;     // ntaps * Cin
-    int mtiles, ntiles;
-    int linear_out;
-    int out_f32;
-    unsigned x_bytes, w_bytes;
-    unsigned long long dy_pack, dx_pack;
-    int vec_out;  // 16-byte aligned output / residual channel slices: coalesced epilogue through LDS
-};
-
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef rd_bf16_t bf16_t;
-#define f2bf rd_f2bf
-#define bf2f rd_bf2f
+#include "conv_bf16_common.h"
 
 template <int BM, int BN, int RB, int WM, int WN, int NST>
 __global__ __launch_bounds__(64 * WM * WN, NST == 2 ? 2 : 1) void conv_igemm_bf16_kernel(const ConvBArgs a)
@@ -247,120 +225,7 @@ __global__ __launch_bounds__(64 * WM * WN, NST == 2 ? 2 : 1) void conv_igemm_bf1
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may still be landing in LDS when the block retires
     }
 
-    // ---- fused epilogue (fp32 math, one rounding on the store)
-    const int hi = lane >> 5;
-    const bf16_t* resb = reinterpret_cast<const bf16_t*>(d.res);
-    bf16_t* yb = reinterpret_cast<bf16_t*>(d.y);
-    // Coalesced form for full tiles: the accumulator layout has one channel per lane and pixels across registers, i.e. a
-    // direct store moves 2 bytes per lane.  Each wave instead transposes its tile through its own slice of the (now
-    // idle) staging LDS - fp32, scale/shift already applied - and walks it back row-wise: 8 channels = 16 bytes per
-    // lane for the residual load and the store.  Same fp32 operations in the same order as the scalar path below.
-    if (a.vec_out && n0 + BN <= d.N && m0 + BM <= a.M) {
-        constexpr int WC = BN / WN;       // channels per wave tile
-        constexpr int CS = WC + 8;        // LDS row stride in floats (+32 B: the two half-waves hit disjoint banks)
-        __syncthreads();                  // every wave is done with the staging buffers (and no DMA is still landing)
-        float* cst = reinterpret_cast<float*>(smem) + wave * (32 * CS);
-        const int nb = n0 + wn * WC;
-        auto pixel_of = [&](const long long m) -> long long {
-            if (a.linear_out) return m;
-            const int mm = (int)m;
-            const int b = mm / a.HoWo;
-            const int rem = mm - b * a.HoWo;
-            const int oy = rem / d.Wo;
-            const int ox = rem - oy * d.Wo;
-            return ((long long)b * d.OH + (oy * d.osy + d.ooy)) * d.OW + (ox * d.osx + d.oox);
-        };
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = nb + j * 32 + frow;
-                const float sc = d.scale ? d.scale[n] : 1.f;
-                const float sh = d.shift ? d.shift[n] : 0.f;
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    cst[((e & 3) + 8 * (e >> 2) + 4 * hi) * CS + j * 32 + frow] = acc[i][j][e] * sc + sh;
-            }
-            if (a.out_f32) {  // fp32 output (training: raw conv results / input gradients): 4 channels = 16 bytes per lane
-                constexpr int LPR = WC / 4, RPI = 64 / LPR;
-                const int rrow = lane / LPR, c4 = (lane % LPR) * 4;
-#pragma unroll
-                for (int rr = 0; rr < 32 / RPI; ++rr) {
-                    const int row = rr * RPI + rrow;
-                    const long long pix = pixel_of(m0 + wm * (BM / WM) + i * 32 + row);
-                    f32x4 v = *reinterpret_cast<const f32x4*>(cst + row * CS + c4);
-                    if (d.res) {
-                        const f32x4 rv = *reinterpret_cast<const f32x4*>(d.res + pix * d.res_cs + d.res_co + nb + c4);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) v[q] += rv[q];
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        if (d.act == 1) v[q] = v[q] > 0.f ? v[q] : 0.f;
-                        else if (d.act == 2) v[q] = v[q] > 0.f ? v[q] : v[q] * d.slope;
-                    }
-                    *reinterpret_cast<f32x4*>(d.y + pix * d.out_cs + d.out_co + nb + c4) = v;
-                }
-            } else {
-                constexpr int LPR = WC / 8, RPI = 64 / LPR;
-                const int rrow = lane / LPR, c8 = (lane % LPR) * 8;
-#pragma unroll
-                for (int rr = 0; rr < 32 / RPI; ++rr) {
-                    const int row = rr * RPI + rrow;
-                    const long long pix = pixel_of(m0 + wm * (BM / WM) + i * 32 + row);
-                    const f32x4 lo = *reinterpret_cast<const f32x4*>(cst + row * CS + c8);
-                    const f32x4 hi4 = *reinterpret_cast<const f32x4*>(cst + row * CS + c8 + 4);
-                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
-                    if (resb) {
-                        float rv[8];
-                        rd_unpack8(*reinterpret_cast<const rd_u32x4*>(resb + pix * d.res_cs + d.res_co + nb + c8), rv);
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) v[q] += rv[q];
-                    }
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        if (d.act == 1) v[q] = v[q] > 0.f ? v[q] : 0.f;
-                        else if (d.act == 2) v[q] = v[q] > 0.f ? v[q] : v[q] * d.slope;
-                    }
-                    *reinterpret_cast<rd_u32x4*>(yb + pix * d.out_cs + d.out_co + nb + c8) = rd_pack8(v);
-                }
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (BN / WN) + j * 32 + frow;
-        const float sc = d.scale ? d.scale[n] : 1.f;
-        const float sh = d.shift ? d.shift[n] : 0.f;
-        const bool n_ok = n < d.N;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const long long m = m0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
-                if (m < a.M && n_ok) {
-                    long long pix;
-                    if (a.linear_out) {
-                        pix = m;
-                    } else {
-                        const int mm = (int)m;
-                        const int b = mm / a.HoWo;
-                        const int rem = mm - b * a.HoWo;
-                        const int oy = rem / d.Wo;
-                        const int ox = rem - oy * d.Wo;
-                        pix = ((long long)b * d.OH + (oy * d.osy + d.ooy)) * d.OW + (ox * d.osx + d.oox);
-                    }
-                    float v = acc[i][j][e] * sc + sh;
-                    if (d.res) v += a.out_f32 ? d.res[pix * d.res_cs + d.res_co + n] : bf2f(resb[pix * d.res_cs + d.res_co + n]);
-                    if (d.act == 1) v = v > 0.f ? v : 0.f;
-                    else if (d.act == 2) v = v > 0.f ? v : v * d.slope;
-                    if (a.out_f32) d.y[pix * d.out_cs + d.out_co + n] = v;
-                    else yb[pix * d.out_cs + d.out_co + n] = f2bf(v);
-                }
-            }
-        }
-    }
+    conv_bf16_epilogue<BM, BN, WM, WN, TM, TN>(a, acc, smem, m0, n0, wave, lane, wm, wn);
 }
 
 static int g_bforce_bm = 0, g_bforce_bn = 0, g_bforce_rb = 0;
@@ -456,11 +321,11 @@ extern "C" int rdpn6d_conv2d_bf16(const rdpn6d_conv_desc* d, int out_f32, void* 
         a.dy_pack |= (unsigned long long)(d->dy[t] + 8) << (4 * t);
         a.dx_pack |= (unsigned long long)(d->dx[t] + 8) << (4 * t);
     }
+    hipStream_t s = (hipStream_t)stream;
     int bm, bn;
     conv_bf16_pick_tile(d, a.M, rb, &bm, &bn);
     a.mtiles = rd_cdiv(a.M, bm);
     a.ntiles = d->Npad / bn;
-    hipStream_t s = (hipStream_t)stream;
     const int rc = rb == 128 ? conv_bf16_launch<128>(a, bm, bn, s) : conv_bf16_launch<64>(a, bm, bn, s);
     if (rc != RDPN6D_OK) return rc;
     RD_LAUNCH_CHECK();
