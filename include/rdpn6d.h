@@ -268,8 +268,8 @@ int rdpn6d_stem_im2col_f32(const float* x, int B, int xc, int R, float* out, voi
 
 /* Weight re-packing of the training step in one launch.  Entry: dst[(o*dT + t)*dIpad + i] = src[operm(o)*so +
  * iperm(i)*si + toff[t]] for o < O, t < T, i < I (operm / iperm may be NULL = identity; dst and/or dst_bf16 are written;
- * padding entries of dst are never touched).  `start` = number of elements of all previous entries (prefix sum);
- * the table lives in device memory; total = sum of O*T*I. */
+ * padding entries of dst are never touched).  Workgroup b handles the 2048 elements of entry blk_desc[b] that start at
+ * element blk_off[b]; table and maps live in device memory (`start` is unused by the kernel, kept for bookkeeping). */
 typedef struct {
     const float* src;
     float* dst;
@@ -280,7 +280,8 @@ typedef struct {
     int O, T, I, dT, dIpad;
     int toff[9];
 } rdpn6d_repack_desc;
-int rdpn6d_repack_f32(const rdpn6d_repack_desc* table_dev, int ndesc, long long total, void* stream);
+int rdpn6d_repack_f32(const rdpn6d_repack_desc* table_dev, const int* blk_desc_dev, const long long* blk_off_dev, int nblocks,
+                      void* stream);
 
 /* ================================================================== "next" rows of SURVEY.md section 8f
  * rank 3: region / residual training targets (core/utils/data_utils.py:229-244, data_loader.py:881-903).

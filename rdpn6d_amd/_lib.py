@@ -93,7 +93,7 @@ SIGNATURES = {
     "rdpn6d_act_backward_f32": (_i, [_vp, _vp, _ll, _f, _vp]),
     "rdpn6d_rgb_to_nhwc4_f32": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "rdpn6d_stem_im2col_f32": (_i, [_vp, _i, _i, _i, _vp, _vp]),
-    "rdpn6d_repack_f32": (_i, [_vp, _i, _ll, _vp]),
+    "rdpn6d_repack_f32": (_i, [_vp, _vp, _vp, _i, _vp]),
 }
 
 _lib = None

@@ -169,16 +169,26 @@ extern "C" int rdpn6d_global_max_concat_backward_f32(const float* feat, const fl
 // Dense losses + gradients.  head NHWC [B,HW,head_cs] = [mask | x y z | region bg+K]; gt tensors in the batch_data
 // layout: gt_xyz [B,3,HW], masks [B,HW], gt_region [B,HW] int64.
 // sums[0] = sum(mask_visib) (first kernel); partial[blk][6] = (coor_x, coor_y, coor_z, mask, region_ce, region_my) raw sums.
-__global__ __launch_bounds__(256) void mask_sum_kernel(const float* __restrict__ m, long long n, double* __restrict__ out)
+__global__ __launch_bounds__(1024) void mask_sum_kernel(const float* __restrict__ m, long long n, double* __restrict__ out)
 {
-    __shared__ double s[4];
+    // one workgroup (the result feeds the very next kernel): 1024 lanes x 16-byte loads, double accumulation
+    __shared__ double s[16];
     double a = 0.0;
-    for (long long i = threadIdx.x; i < n; i += 256) a += (double)m[i];
+    const long long n4 = ((reinterpret_cast<size_t>(m) & 15) == 0) ? n / 4 : 0;
+    for (long long i = threadIdx.x; i < n4; i += 1024) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(m)[i];
+        a += ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
+    }
+    for (long long i = n4 * 4 + threadIdx.x; i < n; i += 1024) a += (double)m[i];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = a;
     __syncthreads();
-    if (threadIdx.x == 0) out[0] = (s[0] + s[1]) + (s[2] + s[3]);
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 16; ++i) t += s[i];
+        out[0] = t;
+    }
 }
 
 template <int KMAX>
@@ -281,7 +291,7 @@ extern "C" int rdpn6d_dense_losses_f32(const float* head, int head_cs, const flo
     hipStream_t s = (hipStream_t)stream;
     const long long n = (long long)B * HW;
     const int nblk = (int)((n + 255) / 256);
-    hipLaunchKernelGGL(mask_sum_kernel, dim3(1), dim3(256), 0, s, mask_visib, n, scratch);
+    hipLaunchKernelGGL(mask_sum_kernel, dim3(1), dim3(1024), 0, s, mask_visib, n, scratch);
     RD_LAUNCH_CHECK();
     if (K <= 32)
         hipLaunchKernelGGL(dense_loss_kernel<32>, dim3(nblk), dim3(256), 0, s, head, head_cs, gt_xyz, mask_visib, mask_trunc, gt_region,
@@ -685,17 +695,17 @@ extern "C" int rdpn6d_rgb_to_nhwc4_f32(const float* x, int B, int xc, int R, flo
 // a bf16 mirror).  A table entry maps the real elements of one packed tensor:
 //   dst[(o*dT + t)*dIpad + i] = src[operm(o)*so + iperm(i)*si + toff[t]]      o < O, t < T, i < I
 // (padding entries of dst are zeroed once at allocation and never touched).  Replaces ~700 tiny ATen launches per step.
-__global__ void repack_kernel(const rdpn6d_repack_desc* __restrict__ tab, int nd, long long total)
+__global__ __launch_bounds__(256) void repack_kernel(const rdpn6d_repack_desc* __restrict__ tab, const int* __restrict__ blk_desc,
+                                                     const long long* __restrict__ blk_off)
 {
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-        int lo = 0, hi = nd - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (tab[mid].start <= e) lo = mid;
-            else hi = mid - 1;
-        }
-        const rdpn6d_repack_desc& D = tab[lo];
-        long long r = e - D.start;
+    // workgroup -> (table entry, first element) comes from a host-built map: no per-element search
+    const rdpn6d_repack_desc& D = tab[blk_desc[blockIdx.x]];
+    const long long n = (long long)D.O * D.T * D.I;
+    const long long base = blk_off[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        long long r = base + k * 256 + threadIdx.x;
+        if (r >= n) break;
         const int i = (int)(r % D.I);
         r /= D.I;
         const int t = (int)(r % D.T);
@@ -708,11 +718,11 @@ __global__ void repack_kernel(const rdpn6d_repack_desc* __restrict__ tab, int nd
     }
 }
 
-extern "C" int rdpn6d_repack_f32(const rdpn6d_repack_desc* table_dev, int ndesc, long long total, void* stream)
+extern "C" int rdpn6d_repack_f32(const rdpn6d_repack_desc* table_dev, const int* blk_desc_dev, const long long* blk_off_dev,
+                                 int nblocks, void* stream)
 {
-    RD_REQUIRE(table_dev && ndesc > 0 && total > 0, "empty table");
-    const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-    hipLaunchKernelGGL(repack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table_dev, ndesc, total);
+    RD_REQUIRE(table_dev && blk_desc_dev && blk_off_dev && nblocks > 0, "empty table");
+    hipLaunchKernelGGL(repack_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, table_dev, blk_desc_dev, blk_off_dev);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
 }

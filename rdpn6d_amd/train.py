@@ -189,15 +189,25 @@ class TrainEngine:
             r["O"], r["T"], r["I"], r["dT"], r["dIpad"] = e["O"], e["T"], e["I"], e["dT"], e["dIpad"]
             r["toff"][: e["T"]] = e["toff"]
             start += e["O"] * e["T"] * e["I"]
+        # workgroup map: 2048 elements per workgroup, never straddling two entries
+        bd, bo = [], []
+        for di, e in enumerate(self.repack):
+            n = e["O"] * e["T"] * e["I"]
+            offs = np.arange(0, n, 2048, dtype=np.int64)
+            bo.append(offs)
+            bd.append(np.full(len(offs), di, dtype=np.int32))
         self._repack_dev = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(self.dev)
-        self._repack_total, self._repack_ptrs = start, ptrs
+        self._repack_bd = torch.from_numpy(np.concatenate(bd)).to(self.dev)
+        self._repack_bo = torch.from_numpy(np.concatenate(bo)).to(self.dev)
+        self._repack_ptrs = ptrs
 
     def refresh_weights(self):
         """re-pack forward / dgrad weights (and their bf16 mirrors) from the current parameters: one launch.  Call after
         every optimizer step.  The table is rebuilt only when a parameter's storage moved (e.g. an optimizer that re-homes
         the parameters into a flat buffer)."""
         self._repack_table()
-        _lib.check(self.lib.rdpn6d_repack_f32(_ptr(self._repack_dev), len(self.repack), self._repack_total, self.st()), "repack")
+        _lib.check(self.lib.rdpn6d_repack_f32(_ptr(self._repack_dev), _ptr(self._repack_bd), _ptr(self._repack_bo),
+                                              int(self._repack_bd.numel()), self.st()), "repack")
 
     # ------------------------------------------------------------------ layer builders
     def conv_unit(self, name, P, x, xhw, in_cs, in_co, cin_real, y, yhw, out_cs, out_co, *, stride=1, perm=None, bias=None,
