@@ -283,6 +283,27 @@ typedef struct {
 int rdpn6d_repack_f32(const rdpn6d_repack_desc* table_dev, const int* blk_desc_dev, const long long* blk_off_dev, int nblocks,
                       void* stream);
 
+/* bf16-stored training activations (mixed-precision step, cfg.SOLVER.AMP.ENABLED): the same kernels as their _f32
+ * namesakes with every activation / gradient tensor (x, y, dy, dx, res, dres, feat ...) in bf16 - strides and offsets in
+ * elements, multiples of 4 - and fp32 statistics, parameters, parameter gradients and arithmetic. */
+int rdpn6d_bn_train_stats_bf16(const void* x, long long M, int C, int cs, int co, float eps, float momentum, float* mean,
+                               float* invstd, float* running_mean, float* running_var, double* scratch, void* stream);
+int rdpn6d_bn_apply_bf16(const void* x, int xcs, int xco, const float* mean, const float* invstd, const float* gamma,
+                         const float* beta, const void* res, int rcs, int rco, void* y, int ycs, int yco, long long M, int C,
+                         int relu, void* stream);
+int rdpn6d_bn_backward_bf16(const void* x, int xcs, int xco, const void* dy, int dcs, int dco, const void* y, int ycs, int yco,
+                            const float* mean, const float* invstd, const float* gamma, float* dgamma, float* dbeta, void* dx,
+                            int xgcs, int xgco, void* dres, int rcs, int rco, long long M, int C, int relu, double* scratch,
+                            void* stream);
+int rdpn6d_channel_sum_bf16(const void* x, long long M, int C, int cs, int co, float* out, int accumulate, double* scratch,
+                            void* stream);
+int rdpn6d_maxpool3x3s2_backward_bf16(const void* x, const void* dy, int B, int H, int W, int C, void* dx, void* stream);
+int rdpn6d_upsample_bilinear_backward_bf16(const void* dy, int B, int H, int W, int C, int factor, void* dx, void* stream);
+int rdpn6d_global_max_concat_backward_bf16(const void* feat, const void* dfeat, int B, int HW, int C, int cs, void* dl3,
+                                           void* stream);
+int rdpn6d_stem_im2col_bf16(const float* x, int B, int xc, int R, void* out, void* stream);
+int rdpn6d_stem_conv7x7_raw_bf16(const float* x, int B, int xc, int R, const float* w, void* y, void* stream);
+
 /* ================================================================== "next" rows of SURVEY.md section 8f
  * rank 3: region / residual training targets (core/utils/data_utils.py:229-244, data_loader.py:881-903).
  *   xyz_hwc [B,HW,3] f32 (model-space crop, 0 = background), fps [B,K,3] f64 (the loader's float64 anchors),

@@ -93,6 +93,16 @@ SIGNATURES = {
     "rdpn6d_act_backward_f32": (_i, [_vp, _vp, _ll, _f, _vp]),
     "rdpn6d_rgb_to_nhwc4_f32": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "rdpn6d_stem_im2col_f32": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "rdpn6d_stem_conv7x7_raw_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    "rdpn6d_bn_train_stats_bf16": (_i, [_vp, _ll, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rdpn6d_bn_apply_bf16": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _ll, _i, _i, _vp]),
+    "rdpn6d_bn_backward_bf16": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i,
+                                     _ll, _i, _i, _vp, _vp]),
+    "rdpn6d_channel_sum_bf16": (_i, [_vp, _ll, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "rdpn6d_maxpool3x3s2_backward_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "rdpn6d_upsample_bilinear_backward_bf16": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "rdpn6d_global_max_concat_backward_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "rdpn6d_stem_im2col_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "rdpn6d_repack_f32": (_i, [_vp, _vp, _vp, _i, _vp]),
 }
 

@@ -65,3 +65,32 @@ __device__ __forceinline__ rd_u32x4 rd_pack8(const float (&v)[8])
     for (int i = 0; i < 4; ++i) p[i] = (unsigned)rd_f2bf(v[2 * i]) | ((unsigned)rd_f2bf(v[2 * i + 1]) << 16);
     return p;
 }
+
+// 4 consecutive channels of an fp32 or bf16 activation <-> f32x4 (the training kernels are templated on the storage type)
+template <typename T> __device__ __forceinline__ f32x4 rd_ld4(const T* p);
+template <> __device__ __forceinline__ f32x4 rd_ld4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <> __device__ __forceinline__ f32x4 rd_ld4<rd_bf16_t>(const rd_bf16_t* p)
+{
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    f32x4 v;
+    v[0] = __uint_as_float(u.x << 16);
+    v[1] = __uint_as_float(u.x & 0xffff0000u);
+    v[2] = __uint_as_float(u.y << 16);
+    v[3] = __uint_as_float(u.y & 0xffff0000u);
+    return v;
+}
+template <typename T> __device__ __forceinline__ void rd_st4(T* p, const f32x4 v);
+template <> __device__ __forceinline__ void rd_st4<float>(float* p, const f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+template <> __device__ __forceinline__ void rd_st4<rd_bf16_t>(rd_bf16_t* p, const f32x4 v)
+{
+    uint2 u;
+    u.x = (unsigned)rd_f2bf(v[0]) | ((unsigned)rd_f2bf(v[1]) << 16);
+    u.y = (unsigned)rd_f2bf(v[2]) | ((unsigned)rd_f2bf(v[3]) << 16);
+    *reinterpret_cast<uint2*>(p) = u;
+}
+template <typename T> __device__ __forceinline__ float rd_ld1(const T* p);
+template <> __device__ __forceinline__ float rd_ld1<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float rd_ld1<rd_bf16_t>(const rd_bf16_t* p) { return rd_bf2f(*p); }
+template <typename T> __device__ __forceinline__ void rd_st1(T* p, float v);
+template <> __device__ __forceinline__ void rd_st1<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void rd_st1<rd_bf16_t>(rd_bf16_t* p, float v) { *p = rd_f2bf(v); }

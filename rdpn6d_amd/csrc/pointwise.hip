@@ -125,6 +125,10 @@ extern "C" int rdpn6d_stem_conv7x7_raw_f32(const float* x, int B, int xc, int R,
 {
     return stem_launch(x, B, xc, R, w, nullptr, nullptr, y, 0, stream);
 }
+extern "C" int rdpn6d_stem_conv7x7_raw_bf16(const float* x, int B, int xc, int R, const float* w, void* y, void* stream)
+{
+    return stem_launch(x, B, xc, R, w, nullptr, nullptr, y, 0, stream, true);
+}
 
 // ------------------------------------------------------------------------------------------------
 // MaxPool2d(kernel 3, stride 2, pad 1): one thread per (output pixel, 4 channels).

@@ -13,8 +13,9 @@
 // MaxPool2d(3,2,1) backward, gather form (deterministic): an input element receives the gradient of every
 // window in which it is the FIRST maximum in scan order (torch's CPU/GPU kernels keep the first max).
 // One thread = one input pixel x 4 channels (16-byte loads; the <= 4 windows x 9 taps it inspects are L1/L2 hits).
-__global__ void maxpool3x3s2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int B, int H, int W, int C,
-                                        float* __restrict__ dx)
+template <typename T>
+__global__ void maxpool3x3s2_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, int B, int H, int W, int C,
+                                        T* __restrict__ dx)
 {
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1, C4 = C / 4;
     const long long total = (long long)B * H * W * C4;
@@ -25,8 +26,8 @@ __global__ void maxpool3x3s2_bwd_kernel(const float* __restrict__ x, const float
         p /= W;
         const int iy = (int)(p % H);
         const int b = (int)(p / H);
-        const float* xb = x + (long long)b * H * W * C + c;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(xb + ((long long)iy * W + ix) * C);
+        const T* xb = x + (long long)b * H * W * C + c;
+        const f32x4 v = rd_ld4<T>(xb + ((long long)iy * W + ix) * C);
         f32x4 g = {0.f, 0.f, 0.f, 0.f};
         // windows (oy,ox) covering (iy,ix): oy*2-1 <= iy <= oy*2+1
         for (int oy = iy / 2; oy <= (iy + 1) / 2; ++oy) {
@@ -43,36 +44,46 @@ __global__ void maxpool3x3s2_bwd_kernel(const float* __restrict__ x, const float
                     for (int kx = 0; kx < 3; ++kx) {
                         const int xx = ox * 2 - 1 + kx;
                         if ((unsigned)xx >= (unsigned)W) continue;
-                        const f32x4 u = *reinterpret_cast<const f32x4*>(xb + ((long long)yy * W + xx) * C);
+                        const f32x4 u = rd_ld4<T>(xb + ((long long)yy * W + xx) * C);
                         const bool before = yy < iy || (yy == iy && xx < ix);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) first[e] = first[e] && !(u[e] > v[e] || (before && u[e] == v[e]));
                     }
                 }
-                const f32x4 d = *reinterpret_cast<const f32x4*>(dy + (((long long)b * Ho + oy) * Wo + ox) * C + c);
+                const f32x4 d = rd_ld4<T>(dy + (((long long)b * Ho + oy) * Wo + ox) * C + c);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) g[e] += first[e] ? d[e] : 0.f;
             }
         }
-        *reinterpret_cast<f32x4*>(dx + (((long long)b * H + iy) * W + ix) * C + c) = g;
+        rd_st4<T>(dx + (((long long)b * H + iy) * W + ix) * C + c, g);
     }
 }
 
-extern "C" int rdpn6d_maxpool3x3s2_backward_f32(const float* x, const float* dy, int B, int H, int W, int C, float* dx,
-                                                void* stream)
+template <typename T>
+static int maxpool_bwd_impl(const T* x, const T* dy, int B, int H, int W, int C, T* dx, void* stream)
 {
     RD_REQUIRE(x && dy && dx && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "shape");
     const long long total = (long long)B * H * W * (C / 4);
     const int blocks = (int)((total + 255) / 256 < 32768 ? (total + 255) / 256 : 32768);
-    hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, dy, B, H, W, C, dx);
+    hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, dy, B, H, W, C, dx);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
+}
+extern "C" int rdpn6d_maxpool3x3s2_backward_f32(const float* x, const float* dy, int B, int H, int W, int C, float* dx,
+                                                void* stream)
+{
+    return maxpool_bwd_impl<float>(x, dy, B, H, W, C, dx, stream);
+}
+extern "C" int rdpn6d_maxpool3x3s2_backward_bf16(const void* x, const void* dy, int B, int H, int W, int C, void* dx, void* stream)
+{
+    return maxpool_bwd_impl<rd_bf16_t>((const rd_bf16_t*)x, (const rd_bf16_t*)dy, B, H, W, C, (rd_bf16_t*)dx, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
 // Bilinear (align_corners) upsample backward, gather form: dx[iy,ix] = sum over outputs of weight * dy.
-__global__ void upsample_bilinear_bwd_kernel(const float* __restrict__ dy, int B, int H, int W, int C, int f,
-                                             float* __restrict__ dx)
+template <typename T>
+__global__ void upsample_bilinear_bwd_kernel(const T* __restrict__ dy, int B, int H, int W, int C, int f,
+                                             T* __restrict__ dx)
 {
     const int Ho = H * f, Wo = W * f;
     const float sy = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
@@ -105,41 +116,51 @@ __global__ void upsample_bilinear_bwd_kernel(const float* __restrict__ dy, int B
                 if (x0 == ix) wx += hx;
                 if (x1 == ix) wx += lx;
                 if (wx == 0.f) continue;
-                g += wy * wx * dy[(((long long)b * Ho + oy) * Wo + ox) * C + c];
+                g += wy * wx * rd_ld1<T>(dy + (((long long)b * Ho + oy) * Wo + ox) * C + c);
             }
         }
-        dx[i] = g;
+        rd_st1<T>(dx + i, g);
     }
 }
 
-extern "C" int rdpn6d_upsample_bilinear_backward_f32(const float* dy, int B, int H, int W, int C, int factor, float* dx,
-                                                     void* stream)
+template <typename T>
+static int upsample_bwd_impl(const T* dy, int B, int H, int W, int C, int factor, T* dx, void* stream)
 {
     RD_REQUIRE(dy && dx && B > 0 && H > 1 && W > 1 && C > 0 && factor >= 2, "shape");
     const long long total = (long long)B * H * W * C;
     const int blocks = (int)((total + 255) / 256 < 32768 ? (total + 255) / 256 : 32768);
-    hipLaunchKernelGGL(upsample_bilinear_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, B, H, W, C, factor, dx);
+    hipLaunchKernelGGL(upsample_bilinear_bwd_kernel<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, B, H, W, C, factor, dx);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
+}
+extern "C" int rdpn6d_upsample_bilinear_backward_f32(const float* dy, int B, int H, int W, int C, int factor, float* dx,
+                                                     void* stream)
+{
+    return upsample_bwd_impl<float>(dy, B, H, W, C, factor, dx, stream);
+}
+extern "C" int rdpn6d_upsample_bilinear_backward_bf16(const void* dy, int B, int H, int W, int C, int factor, void* dx, void* stream)
+{
+    return upsample_bwd_impl<rd_bf16_t>((const rd_bf16_t*)dy, B, H, W, C, factor, (rd_bf16_t*)dx, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
 // Backward of [l3 | broadcast(global max l3)]: dl3[p,c] = dfeat[p,c] + (p == first arg-max pixel of channel c) * sum_p' dfeat[p', C+c]
 // feat / dfeat NHWC [B,HW,cs] with cs >= 2C; dl3 [B,HW,C].  grid = (C/64, B), block 256 = 4 pixel lanes x 64 channels.
-__global__ __launch_bounds__(256) void global_max_concat_bwd_kernel(const float* __restrict__ feat, const float* __restrict__ dfeat,
-                                                                   int HW, int C, int cs, float* __restrict__ dl3)
+template <typename T>
+__global__ __launch_bounds__(256) void global_max_concat_bwd_kernel(const T* __restrict__ feat, const T* __restrict__ dfeat,
+                                                                   int HW, int C, int cs, T* __restrict__ dl3)
 {
     __shared__ float s_m[4][64], s_s[4][64];
     __shared__ int s_i[4][64];
     const int b = blockIdx.y, cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, pl = threadIdx.x >> 6;
-    const float* f = feat + (long long)b * HW * cs;
-    const float* g = dfeat + (long long)b * HW * cs;
+    const T* f = feat + (long long)b * HW * cs;
+    const T* g = dfeat + (long long)b * HW * cs;
     float m = -FLT_MAX, s = 0.f;
     int mi = 0x7fffffff;
     for (int p = pl; p < HW; p += 4) {
-        const float v = f[(long long)p * cs + c];
+        const float v = rd_ld1<T>(f + (long long)p * cs + c);
         if (v > m) { m = v; mi = p; }
-        s += g[(long long)p * cs + C + c];
+        s += rd_ld1<T>(g + (long long)p * cs + C + c);
     }
     s_m[pl][cl] = m; s_i[pl][cl] = mi; s_s[pl][cl] = s;
     __syncthreads();
@@ -152,17 +173,27 @@ __global__ __launch_bounds__(256) void global_max_concat_bwd_kernel(const float*
         if (om > bm || (om == bm && oi < bi)) { bm = om; bi = oi; }
         tot += s_s[k][cl];
     }
-    float* o = dl3 + (long long)b * HW * C;
-    for (int p = pl; p < HW; p += 4) o[(long long)p * C + c] = g[(long long)p * cs + c] + (p == bi ? tot : 0.f);
+    T* o = dl3 + (long long)b * HW * C;
+    for (int p = pl; p < HW; p += 4) rd_st1<T>(o + (long long)p * C + c, rd_ld1<T>(g + (long long)p * cs + c) + (p == bi ? tot : 0.f));
 }
 
+template <typename T>
+static int gmax_bwd_impl(const T* feat, const T* dfeat, int B, int HW, int C, int cs, T* dl3, void* stream)
+{
+    RD_REQUIRE(feat && dfeat && dl3 && B > 0 && HW > 0 && C > 0 && C % 64 == 0 && 2 * C <= cs, "shape");
+    hipLaunchKernelGGL(global_max_concat_bwd_kernel<T>, dim3(C / 64, B), dim3(256), 0, (hipStream_t)stream, feat, dfeat, HW, C, cs, dl3);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}
 extern "C" int rdpn6d_global_max_concat_backward_f32(const float* feat, const float* dfeat, int B, int HW, int C, int cs,
                                                      float* dl3, void* stream)
 {
-    RD_REQUIRE(feat && dfeat && dl3 && B > 0 && HW > 0 && C > 0 && C % 64 == 0 && 2 * C <= cs, "shape");
-    hipLaunchKernelGGL(global_max_concat_bwd_kernel, dim3(C / 64, B), dim3(256), 0, (hipStream_t)stream, feat, dfeat, HW, C, cs, dl3);
-    RD_LAUNCH_CHECK();
-    return RDPN6D_OK;
+    return gmax_bwd_impl<float>(feat, dfeat, B, HW, C, cs, dl3, stream);
+}
+extern "C" int rdpn6d_global_max_concat_backward_bf16(const void* feat, const void* dfeat, int B, int HW, int C, int cs, void* dl3,
+                                                      void* stream)
+{
+    return gmax_bwd_impl<rd_bf16_t>((const rd_bf16_t*)feat, (const rd_bf16_t*)dfeat, B, HW, C, cs, (rd_bf16_t*)dl3, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -644,7 +675,8 @@ __global__ void rgb_to_nhwc4_kernel(const float* __restrict__ x, int B, int xc, 
 // Patch matrix of the 7x7 stride-2 stem for its weight gradient: out[(b,oy,ox)][(ky*7+kx)*3 + c] = x[b][c][2oy-3+ky][2ox-3+kx]
 // (0 outside the image, columns 147..159 zero), so that dW(conv1) is ONE pixel-reduction GEMM dY^T x out on the wgrad kernel
 // instead of seven 4-channel ones (resnet_backbone.py:272 backward).  One thread per (pixel, 4 columns): 16-byte stores.
-__global__ void stem_im2col_kernel(const float* __restrict__ x, int B, int xc, int R, float* __restrict__ out)
+template <typename T>
+__global__ void stem_im2col_kernel(const float* __restrict__ x, int B, int xc, int R, T* __restrict__ out)
 {
     const int Ro = R / 2;
     const long long total = (long long)B * Ro * Ro * 40;
@@ -666,18 +698,27 @@ __global__ void stem_im2col_kernel(const float* __restrict__ x, int B, int xc, i
             }
             v[e] = t;
         }
-        *reinterpret_cast<f32x4*>(out + p * 160 + q * 4) = v;
+        rd_st4<T>(out + p * 160 + q * 4, v);
     }
 }
 
-extern "C" int rdpn6d_stem_im2col_f32(const float* x, int B, int xc, int R, float* out, void* stream)
+template <typename T>
+static int stem_im2col_impl(const float* x, int B, int xc, int R, T* out, void* stream)
 {
     RD_REQUIRE(x && out && B > 0 && xc >= 3 && R > 0 && R % 2 == 0, "shape");
     const long long total = (long long)B * (R / 2) * (R / 2) * 40;
     const int blocks = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
-    hipLaunchKernelGGL(stem_im2col_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, B, xc, R, out);
+    hipLaunchKernelGGL(stem_im2col_kernel<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, B, xc, R, out);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
+}
+extern "C" int rdpn6d_stem_im2col_f32(const float* x, int B, int xc, int R, float* out, void* stream)
+{
+    return stem_im2col_impl<float>(x, B, xc, R, out, stream);
+}
+extern "C" int rdpn6d_stem_im2col_bf16(const float* x, int B, int xc, int R, void* out, void* stream)
+{
+    return stem_im2col_impl<rd_bf16_t>(x, B, xc, R, (rd_bf16_t*)out, stream);
 }
 
 extern "C" int rdpn6d_rgb_to_nhwc4_f32(const float* x, int B, int xc, int R, float* y, void* stream)

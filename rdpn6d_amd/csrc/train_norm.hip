@@ -16,10 +16,10 @@
 // Stage 1 of every per-channel reduction.  MODE 0: (sum x, sum x^2)         [BN statistics, bias grads]
 //                                            MODE 1: (sum g, sum g*xhat)       [BN backward], g = dy*(y>0) if relu
 // grid = (C/64, S); block = 256 = 16 row lanes x 16 channel quads (16-byte loads)
-template <int MODE>
-__global__ __launch_bounds__(256) void chan_partial_kernel(const float* __restrict__ x, int xcs, int xco,
-                                                           const float* __restrict__ dy, int dcs, int dco,
-                                                           const float* __restrict__ y, int ycs, int yco,
+template <int MODE, typename T>
+__global__ __launch_bounds__(256) void chan_partial_kernel(const T* __restrict__ x, int xcs, int xco,
+                                                           const T* __restrict__ dy, int dcs, int dco,
+                                                           const T* __restrict__ y, int ycs, int yco,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            long long M, int C, int relu, double* __restrict__ partial)
 {
@@ -35,14 +35,14 @@ __global__ __launch_bounds__(256) void chan_partial_kernel(const float* __restri
         f32x4 mu = {0, 0, 0, 0}, is = {0, 0, 0, 0};
         if (MODE == 1) { mu = *reinterpret_cast<const f32x4*>(mean + c); is = *reinterpret_cast<const f32x4*>(invstd + c); }
         for (long long m = m_lo + rl; m < m_hi; m += 16) {
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + m * xcs + xco + c);
+            const f32x4 xv = rd_ld4<T>(x + m * xcs + xco + c);
             if (MODE == 0) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { a[e] += (double)xv[e]; b[e] += (double)xv[e] * (double)xv[e]; }
             } else {
-                f32x4 g = *reinterpret_cast<const f32x4*>(dy + m * dcs + dco + c);
+                f32x4 g = rd_ld4<T>(dy + m * dcs + dco + c);
                 if (relu) {
-                    const f32x4 yv = *reinterpret_cast<const f32x4*>(y + m * ycs + yco + c);
+                    const f32x4 yv = rd_ld4<T>(y + m * ycs + yco + c);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) g[e] = yv[e] > 0.f ? g[e] : 0.f;
                 }
@@ -131,16 +131,16 @@ static int pick_splits(long long M, int C)
     return (int)s;
 }
 
-extern "C" int rdpn6d_bn_train_stats_f32(const float* x, long long M, int C, int cs, int co, float eps, float momentum,
-                                         float* mean, float* invstd, float* running_mean, float* running_var,
-                                         double* scratch /* >= 512*C*2 doubles */, void* stream)
+template <typename T>
+static int bn_train_stats_impl(const T* x, long long M, int C, int cs, int co, float eps, float momentum, float* mean,
+                               float* invstd, float* running_mean, float* running_var, double* scratch, void* stream)
 {
     RD_REQUIRE(x && mean && invstd && scratch, "null pointer");
     RD_REQUIRE(M > 0 && C > 0 && co + C <= cs && C % 4 == 0 && cs % 4 == 0 && co % 4 == 0, "shape / 16-byte alignment");
     const int S = pick_splits(M, C);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(chan_partial_kernel<0>, dim3((C + 63) / 64, S), dim3(256), 0, s, x, cs, co, nullptr, 0, 0, nullptr, 0, 0,
-                       nullptr, nullptr, M, C, 0, scratch);
+    hipLaunchKernelGGL((chan_partial_kernel<0, T>), dim3((C + 63) / 64, S), dim3(256), 0, s, x, cs, co, (const T*)nullptr, 0, 0,
+                       (const T*)nullptr, 0, 0, nullptr, nullptr, M, C, 0, scratch);
     RD_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, s, scratch, S, C, M, eps, momentum, mean,
                        invstd, running_mean, running_var);
@@ -148,74 +148,115 @@ extern "C" int rdpn6d_bn_train_stats_f32(const float* x, long long M, int C, int
     return RDPN6D_OK;
 }
 
+extern "C" int rdpn6d_bn_train_stats_f32(const float* x, long long M, int C, int cs, int co, float eps, float momentum,
+                                         float* mean, float* invstd, float* running_mean, float* running_var,
+                                         double* scratch /* >= 512*C*2 doubles */, void* stream)
+{
+    return bn_train_stats_impl<float>(x, M, C, cs, co, eps, momentum, mean, invstd, running_mean, running_var, scratch, stream);
+}
+// bf16 activation (mixed-precision training with bf16-stored activations): same statistics, fp64 partial sums
+extern "C" int rdpn6d_bn_train_stats_bf16(const void* x, long long M, int C, int cs, int co, float eps, float momentum,
+                                          float* mean, float* invstd, float* running_mean, float* running_var, double* scratch,
+                                          void* stream)
+{
+    return bn_train_stats_impl<rd_bf16_t>((const rd_bf16_t*)x, M, C, cs, co, eps, momentum, mean, invstd, running_mean,
+                                          running_var, scratch, stream);
+}
+
 // per-channel sum of rows (bias gradient): out[c] (+)= sum_m x[m, co + c]
-extern "C" int rdpn6d_channel_sum_f32(const float* x, long long M, int C, int cs, int co, float* out, int accumulate,
-                                      double* scratch, void* stream)
+template <typename T>
+static int channel_sum_impl(const T* x, long long M, int C, int cs, int co, float* out, int accumulate, double* scratch, void* stream)
 {
     RD_REQUIRE(x && out && scratch && M > 0 && C > 0 && co + C <= cs && C % 4 == 0 && cs % 4 == 0 && co % 4 == 0, "shape / alignment");
     const int S = pick_splits(M, C);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(chan_partial_kernel<0>, dim3((C + 63) / 64, S), dim3(256), 0, s, x, cs, co, nullptr, 0, 0, nullptr, 0, 0,
-                       nullptr, nullptr, M, C, 0, scratch);
+    hipLaunchKernelGGL((chan_partial_kernel<0, T>), dim3((C + 63) / 64, S), dim3(256), 0, s, x, cs, co, (const T*)nullptr, 0, 0,
+                       (const T*)nullptr, 0, 0, nullptr, nullptr, M, C, 0, scratch);
     RD_LAUNCH_CHECK();
     hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, s, scratch, S, C, out, nullptr, accumulate);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
 }
+extern "C" int rdpn6d_channel_sum_f32(const float* x, long long M, int C, int cs, int co, float* out, int accumulate,
+                                      double* scratch, void* stream)
+{
+    return channel_sum_impl<float>(x, M, C, cs, co, out, accumulate, scratch, stream);
+}
+extern "C" int rdpn6d_channel_sum_bf16(const void* x, long long M, int C, int cs, int co, float* out, int accumulate,
+                                       double* scratch, void* stream)
+{
+    return channel_sum_impl<rd_bf16_t>((const rd_bf16_t*)x, M, C, cs, co, out, accumulate, scratch, stream);
+}
 
 // ---------------------------------------------------------------------------------------------
 // y = act(((x - mean) * invstd) * gamma + beta (+ res)), 4 channels per thread
-__global__ void bn_apply_kernel(const float* __restrict__ x, int xcs, int xco, const float* __restrict__ mean,
+template <typename T>
+__global__ void bn_apply_kernel(const T* __restrict__ x, int xcs, int xco, const float* __restrict__ mean,
                                 const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                const float* __restrict__ beta, const float* __restrict__ res, int rcs, int rco,
-                                float* __restrict__ y, int ycs, int yco, long long M, int C, int relu)
+                                const float* __restrict__ beta, const T* __restrict__ res, int rcs, int rco,
+                                T* __restrict__ y, int ycs, int yco, long long M, int C, int relu)
 {
     const int C4 = C / 4;
     const long long total = M * C4;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4) * 4;
         const long long m = i / C4;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(x + m * xcs + xco + c);
+        const f32x4 v = rd_ld4<T>(x + m * xcs + xco + c);
         const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
         const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = (v[e] - mu[e]) * is[e] * ga[e] + be[e];
         if (res) {
-            const f32x4 r = *reinterpret_cast<const f32x4*>(res + m * rcs + rco + c);
+            const f32x4 r = rd_ld4<T>(res + m * rcs + rco + c);
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] += r[e];
         }
         if (relu)
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : 0.f;
-        *reinterpret_cast<f32x4*>(y + m * ycs + yco + c) = o;
+        rd_st4<T>(y + m * ycs + yco + c, o);
     }
 }
 
-extern "C" int rdpn6d_bn_apply_f32(const float* x, int xcs, int xco, const float* mean, const float* invstd,
-                                   const float* gamma, const float* beta, const float* res, int rcs, int rco, float* y,
-                                   int ycs, int yco, long long M, int C, int relu, void* stream)
+template <typename T>
+static int bn_apply_impl(const T* x, int xcs, int xco, const float* mean, const float* invstd, const float* gamma,
+                         const float* beta, const T* res, int rcs, int rco, T* y, int ycs, int yco, long long M, int C, int relu,
+                         void* stream)
 {
     RD_REQUIRE(x && mean && invstd && gamma && beta && y, "null pointer");
     RD_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && xco % 4 == 0 && yco % 4 == 0 && xcs % 4 == 0 && ycs % 4 == 0, "shape/alignment");
     const long long total = M * (C / 4);
     const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, xcs, xco, mean, invstd, gamma, beta, res,
+    hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, xcs, xco, mean, invstd, gamma, beta, res,
                        rcs, rco, y, ycs, yco, M, C, relu);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
+}
+extern "C" int rdpn6d_bn_apply_f32(const float* x, int xcs, int xco, const float* mean, const float* invstd,
+                                   const float* gamma, const float* beta, const float* res, int rcs, int rco, float* y,
+                                   int ycs, int yco, long long M, int C, int relu, void* stream)
+{
+    return bn_apply_impl<float>(x, xcs, xco, mean, invstd, gamma, beta, res, rcs, rco, y, ycs, yco, M, C, relu, stream);
+}
+extern "C" int rdpn6d_bn_apply_bf16(const void* x, int xcs, int xco, const float* mean, const float* invstd, const float* gamma,
+                                    const float* beta, const void* res, int rcs, int rco, void* y, int ycs, int yco, long long M,
+                                    int C, int relu, void* stream)
+{
+    return bn_apply_impl<rd_bf16_t>((const rd_bf16_t*)x, xcs, xco, mean, invstd, gamma, beta, (const rd_bf16_t*)res, rcs, rco,
+                                    (rd_bf16_t*)y, ycs, yco, M, C, relu, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
 // BN backward.  g = dy * (y > 0) when the BN was followed by ReLU.
 //   dgamma = sum g*xhat, dbeta = sum g
 //   dx = gamma*invstd * (g - dbeta/M - xhat*dgamma/M);   dres (optional) = g  (identity branch of a residual block)
-__global__ void bn_bwd_apply_kernel(const float* __restrict__ x, int xcs, int xco, const float* __restrict__ dy, int dcs, int dco,
-                                    const float* __restrict__ y, int ycs, int yco, const float* __restrict__ mean,
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ x, int xcs, int xco, const T* __restrict__ dy, int dcs, int dco,
+                                    const T* __restrict__ y, int ycs, int yco, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const float* __restrict__ dgamma, const float* __restrict__ dbeta,
-                                    float* __restrict__ dx, int xgcs, int xgco, float* __restrict__ dres, int rcs, int rco,
+                                    T* __restrict__ dx, int xgcs, int xgco, T* __restrict__ dres, int rcs, int rco,
                                     long long M, int C, int relu)
 {
     const int C4 = C / 4;
@@ -224,10 +265,10 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, int xcs, int xc
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4) * 4;
         const long long m = i / C4;
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + m * xcs + xco + c);
-        f32x4 g = *reinterpret_cast<const f32x4*>(dy + m * dcs + dco + c);
+        const f32x4 xv = rd_ld4<T>(x + m * xcs + xco + c);
+        f32x4 g = rd_ld4<T>(dy + m * dcs + dco + c);
         if (relu) {
-            const f32x4 yv = *reinterpret_cast<const f32x4*>(y + m * ycs + yco + c);
+            const f32x4 yv = rd_ld4<T>(y + m * ycs + yco + c);
 #pragma unroll
             for (int e = 0; e < 4; ++e) g[e] = yv[e] > 0.f ? g[e] : 0.f;
         }
@@ -237,22 +278,22 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, int xcs, int xc
             const float xh = (xv[e] - mean[c + e]) * invstd[c + e];
             o[e] = gamma[c + e] * invstd[c + e] * (g[e] - dbeta[c + e] * invM - xh * dgamma[c + e] * invM);
         }
-        *reinterpret_cast<f32x4*>(dx + m * xgcs + xgco + c) = o;
-        if (dres) *reinterpret_cast<f32x4*>(dres + m * rcs + rco + c) = g;
+        rd_st4<T>(dx + m * xgcs + xgco + c, o);
+        if (dres) rd_st4<T>(dres + m * rcs + rco + c, g);
     }
 }
 
-extern "C" int rdpn6d_bn_backward_f32(const float* x, int xcs, int xco, const float* dy, int dcs, int dco, const float* y,
-                                      int ycs, int yco, const float* mean, const float* invstd, const float* gamma,
-                                      float* dgamma, float* dbeta, float* dx, int xgcs, int xgco, float* dres, int rcs,
-                                      int rco, long long M, int C, int relu, double* scratch, void* stream)
+template <typename T>
+static int bn_backward_impl(const T* x, int xcs, int xco, const T* dy, int dcs, int dco, const T* y, int ycs, int yco,
+                            const float* mean, const float* invstd, const float* gamma, float* dgamma, float* dbeta, T* dx, int xgcs,
+                            int xgco, T* dres, int rcs, int rco, long long M, int C, int relu, double* scratch, void* stream)
 {
     RD_REQUIRE(x && dy && mean && invstd && gamma && dgamma && dbeta && dx && scratch, "null pointer");
     RD_REQUIRE(!relu || y, "ReLU mask needs the forward output");
     RD_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "shape");
     const int S = pick_splits(M, C);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(chan_partial_kernel<1>, dim3((C + 63) / 64, S), dim3(256), 0, s, x, xcs, xco, dy, dcs, dco, y, ycs, yco,
+    hipLaunchKernelGGL((chan_partial_kernel<1, T>), dim3((C + 63) / 64, S), dim3(256), 0, s, x, xcs, xco, dy, dcs, dco, y, ycs, yco,
                        mean, invstd, M, C, relu, scratch);
     RD_LAUNCH_CHECK();
     // partial = (sum g, sum g*xhat) -> dbeta, dgamma
@@ -260,10 +301,27 @@ extern "C" int rdpn6d_bn_backward_f32(const float* x, int xcs, int xco, const fl
     RD_LAUNCH_CHECK();
     const long long total = M * (C / 4);
     const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, s, x, xcs, xco, dy, dcs, dco, y, ycs, yco, mean, invstd,
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(blocks), dim3(256), 0, s, x, xcs, xco, dy, dcs, dco, y, ycs, yco, mean, invstd,
                        gamma, dgamma, dbeta, dx, xgcs, xgco, dres, rcs, rco, M, C, relu);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
+}
+extern "C" int rdpn6d_bn_backward_f32(const float* x, int xcs, int xco, const float* dy, int dcs, int dco, const float* y,
+                                      int ycs, int yco, const float* mean, const float* invstd, const float* gamma,
+                                      float* dgamma, float* dbeta, float* dx, int xgcs, int xgco, float* dres, int rcs,
+                                      int rco, long long M, int C, int relu, double* scratch, void* stream)
+{
+    return bn_backward_impl<float>(x, xcs, xco, dy, dcs, dco, y, ycs, yco, mean, invstd, gamma, dgamma, dbeta, dx, xgcs, xgco, dres, rcs,
+                                   rco, M, C, relu, scratch, stream);
+}
+extern "C" int rdpn6d_bn_backward_bf16(const void* x, int xcs, int xco, const void* dy, int dcs, int dco, const void* y, int ycs,
+                                       int yco, const float* mean, const float* invstd, const float* gamma, float* dgamma,
+                                       float* dbeta, void* dx, int xgcs, int xgco, void* dres, int rcs, int rco, long long M, int C,
+                                       int relu, double* scratch, void* stream)
+{
+    return bn_backward_impl<rd_bf16_t>((const rd_bf16_t*)x, xcs, xco, (const rd_bf16_t*)dy, dcs, dco, (const rd_bf16_t*)y, ycs, yco, mean,
+                                       invstd, gamma, dgamma, dbeta, (rd_bf16_t*)dx, xgcs, xgco, (rd_bf16_t*)dres, rcs, rco, M, C, relu,
+                                       scratch, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

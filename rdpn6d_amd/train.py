@@ -34,12 +34,14 @@ class TrainEngine:
     def __init__(self, model, B, device, amp=False):
         """amp=True (cfg.SOLVER.AMP.ENABLED, the reference's autocast + GradScaler switch: engine.py:279-309): the forward and
         input-gradient convolutions of the trunk, the fusion branch and the dense head run on the bf16 matrix pipe (fp32
-        accumulation, fp32 outputs); BatchNorm, losses, ConvPnPNet, weight gradients, the optimizer and all stored
-        activations stay fp32 - the same split torch.autocast makes (convolutions low precision, normalisation fp32).
-        bf16 keeps the fp32 exponent range, so no loss scaling is needed."""
+        accumulation) and their activations / gradients are STORED in bf16; BatchNorm arithmetic and statistics, losses, the
+        head output, ConvPnPNet, parameter gradients, master weights and the optimizer stay fp32 - the split torch.autocast
+        makes.  bf16 keeps the fp32 exponent range, so no loss scaling is needed."""
         self.lib = _lib.load()
         self.model, self.B, self.dev = model, B, device
         self.amp = bool(amp)
+        self.adt = torch.bfloat16 if self.amp else torch.float32  # storage type of trunk / head activations and gradients
+        self.sfx = "bf16" if self.amp else "f32"
         self._casts = {}     # (address, stride, offset, channels) of an fp32 activation slice -> its bf16 copy
         self.mirrors = []    # (bf16 tensor, fp32 packed weight) pairs refreshed with the weights
         cfg = model.cfg
@@ -71,7 +73,14 @@ class TrainEngine:
         self.refresh_weights()
 
     # ------------------------------------------------------------------ helpers
-    def buf(self, name, *shape, dtype=torch.float32, zero=False):
+    _FP32_TAGS = ("pnp", "fc1", "fc2", ":rt", "head_out")  # the pose branch and the head output stay fp32 under AMP
+
+    def buf(self, name, *shape, dtype=None, zero=False):
+        """named persistent buffer.  Under AMP the stored activations / gradients of trunk, fusion branch and dense head
+        (names raw:* act:* d:* dres:*) are bf16, everything else fp32."""
+        if dtype is None:
+            act = name.startswith(("raw:", "act:", "d:", "dres:")) and not any(t in name for t in self._FP32_TAGS)
+            dtype = self.adt if act else torch.float32
         if name not in self.bufs:
             self.bufs[name] = (torch.zeros if zero else torch.empty)(*shape, dtype=dtype, device=self.dev)
         return self.bufs[name]
@@ -129,13 +138,15 @@ class TrainEngine:
         self.mirrors.append((tb, t))
         return tb
 
-    def _launch_conv(self, name, d, keep, ksplit=False, lowp=False):
+    def _launch_conv(self, name, d, keep, ksplit=False, lowp=False, out_f32=True):
         lib = self.lib
         from .gdrn import pick_ksplit
 
         if lowp:
+            of = 1 if out_f32 else 0
+
             def run():
-                _lib.check(lib.rdpn6d_conv2d_bf16(ctypes.byref(d), 1, self.st()), name)
+                _lib.check(lib.rdpn6d_conv2d_bf16(ctypes.byref(d), of, self.st()), name)
 
             run.keep = (d, keep)
             return run
@@ -230,17 +241,21 @@ class TrainEngine:
             bvec = self._pack_map((npad,), bias, 1, 1, cout, 0, 1, [0])
         taps = _taps(k, pad)
         if lowp:
-            xb, _ = self._bf16_of(self.fwd, x, in_cs, in_co, cin_real, B * xhw[0] * xhw[1], cache=True)
+            if x.dtype == torch.bfloat16:  # stored in bf16: read in place (channels beyond cin_real inside the slice are zero)
+                assert in_cs % 8 == 0 and in_co % 8 == 0 and in_co + cin_pad <= in_cs, (name, in_cs, in_co, cin_pad)
+                xb, xb_cs, xb_co = x, in_cs, in_co
+            else:
+                xb, xb_cs, xb_co = self._bf16_of(self.fwd, x, in_cs, in_co, cin_real, B * xhw[0] * xhw[1], cache=True)[0], cin_pad, 0
             wfb = self._mirror(wf)
-            d = self._conv_desc(xb, xhw, cin_pad, 0, cin_pad, wfb, y, yhw, out_cs, out_co, cout, taps, stride=stride, shift=bvec,
+            d = self._conv_desc(xb, xhw, xb_cs, xb_co, cin_pad, wfb, y, yhw, out_cs, out_co, cout, taps, stride=stride, shift=bvec,
                                 act=act_out or 0, slope=slope)
-            self.fwd.append(self._launch_conv(name, d, (wf, wfb, bvec, xb), lowp=True))
+            self.fwd.append(self._launch_conv(name, d, (wf, wfb, bvec, xb), lowp=True, out_f32=y.dtype == torch.float32))
         else:
             d = self._conv_desc(x, xhw, in_cs, in_co, cin_pad, wf, y, yhw, out_cs, out_co, cout, taps, stride=stride, shift=bvec,
                                 act=act_out or 0, slope=slope)
             self.fwd.append(self._launch_conv(name, d, (wf, bvec), ksplit=True))
         # ---- backward
-        dy = self.buf("d:" + name, *y.shape, zero=True)  # gradient w.r.t. the raw conv output (same layout as y)
+        dy = self.buf("d:" + name, *y.shape, zero=True, dtype=y.dtype)  # gradient w.r.t. the raw conv output (same layout as y)
         M = B * yhw[0] * yhw[1]
         ca = _pad_to(cout, 4)
         cb = _pad_to(cin_real, 4)
@@ -256,9 +271,11 @@ class TrainEngine:
 
         launches = []
         if lowp:
-            # compact bf16 copy of dy: read by the weight-gradient kernel and by the input-gradient convolution
             n_red_b = _pad_to(cout, 32)
-            dyb = self._bf16_of(launches, dy, out_cs, out_co, cout, M, cache=False)[0]
+            if dy.dtype == torch.bfloat16 and out_cs % 8 == 0 and out_co % 8 == 0 and out_co + n_red_b <= out_cs:
+                dyb, dyb_cs, dyb_co = dy, out_cs, out_co      # stored in bf16: read in place
+            else:  # fp32 gradient (the head output's): one compact bf16 copy for the wgrad and the dgrad
+                dyb, dyb_cs, dyb_co = self._bf16_of(launches, dy, out_cs, out_co, cout, M, cache=False)[0], n_red_b, 0
 
         def wgrad():
             # the split-K reduce scatters straight into the parameter's own OIHW gradient (element (n, tap, c) at
@@ -267,8 +284,8 @@ class TrainEngine:
             gw = self._grad(w)
             tgt = (_ptr(gw), cin_real * k * k, 1, k * k, cout, cin_real) if direct else None
             if lowp:
-                args = (_ptr(dyb), n_red_b, 0, ca, n_red_b, _ptr(xb), cin_pad, 0, cb, cin_pad, B, yhw[0], yhw[1], xhw[0], xhw[1],
-                        stride, k * k, tdy, tdx)
+                args = (_ptr(dyb), dyb_cs, dyb_co, ca, min(_pad_to(cout, 8), dyb_cs - dyb_co), _ptr(xb), xb_cs, xb_co, cb,
+                        min(_pad_to(cin_real, 8), xb_cs - xb_co), B, yhw[0], yhw[1], xhw[0], xhw[1], stride, k * k, tdy, tdx)
                 if direct:
                     _lib.check(lib.rdpn6d_wgrad_bf16_strided(*args, *tgt, _ptr(self._wg_partial), self.st()), "wgrad " + name)
                 else:
@@ -284,13 +301,13 @@ class TrainEngine:
                 g = wg_out[:cout, :, :cin_real].view(cout, k, k, cin_real).permute(0, 3, 1, 2)
                 gw.copy_(g[:, inv_perm])
             if bias is not None:
+                csum = lib.rdpn6d_channel_sum_bf16 if dy.dtype == torch.bfloat16 else lib.rdpn6d_channel_sum_f32
                 if cout % 4 == 0:
-                    _lib.check(lib.rdpn6d_channel_sum_f32(_ptr(dy), M, ca, out_cs, out_co, _ptr(self._grad(bias)), 0,
-                                                          _ptr(self._scratch_d), self.st()), "bias grad " + name)
+                    _lib.check(csum(_ptr(dy), M, ca, out_cs, out_co, _ptr(self._grad(bias)), 0, _ptr(self._scratch_d), self.st()),
+                               "bias grad " + name)
                 else:
                     bg = self.buf("bg:" + name, npad)
-                    _lib.check(lib.rdpn6d_channel_sum_f32(_ptr(dy), M, ca, out_cs, out_co, _ptr(bg), 0, _ptr(self._scratch_d),
-                                                          self.st()), "bias grad " + name)
+                    _lib.check(csum(_ptr(dy), M, ca, out_cs, out_co, _ptr(bg), 0, _ptr(self._scratch_d), self.st()), "bias grad " + name)
                     self._grad(bias).copy_(bg[:cout])
 
         launches.append(wgrad)
@@ -299,7 +316,7 @@ class TrainEngine:
             cdx = _pad_to(cin_real, 64)
             dx_cs = dx_cs or in_cs
             if lowp:
-                g_src, g_cs, g_co = dyb, n_red, 0   # the bf16 copy made for the weight gradient; weights from the bf16 mirror
+                g_src, g_cs, g_co = dyb, dyb_cs, dyb_co   # bf16 gradient (in place or the compact copy); weights from the bf16 mirror
             else:
                 assert out_cs - out_co >= n_red, (name, out_cs, n_red)
                 g_src, g_cs, g_co = dy, out_cs, out_co
@@ -308,7 +325,7 @@ class TrainEngine:
                 if lowp:
                     wdb = self._mirror(wd)
                     dd.w = _ptr(wdb)
-                    return self._launch_conv(nm, dd, (wd, wdb, g_src), lowp=True)
+                    return self._launch_conv(nm, dd, (wd, wdb, g_src), lowp=True, out_f32=dx.dtype == torch.float32)
                 return self._launch_conv(nm, dd, wd)
 
             if stride == 1:
@@ -350,27 +367,30 @@ class TrainEngine:
         mean, invstd = self.buf("mean:" + name, _pad_to(C, 4)), self.buf("istd:" + name, _pad_to(C, 4))
         ga, be = bn.weight, bn.bias  # read in place (C % 4 == 0); pointers are taken at launch time
 
+        t = "bf16" if x_raw.dtype == torch.bfloat16 else "f32"   # storage type of x_raw / y / res / dy / dx / dres alike
+        assert y.dtype == x_raw.dtype and (res is None or res.dtype == x_raw.dtype), name
+        f_stats, f_apply, f_bwd = (getattr(lib, f"rdpn6d_bn_{n}_{t}") for n in ("train_stats", "apply", "backward"))
+
         def fwd():
-            _lib.check(lib.rdpn6d_bn_train_stats_f32(_ptr(x_raw), M, C, cs, co, BN_EPS, BN_MOM, _ptr(mean), _ptr(invstd),
-                                                     _ptr(bn.running_mean), _ptr(bn.running_var), _ptr(self._scratch_d),
-                                                     self.st()), "bn stats " + name)
-            _lib.check(lib.rdpn6d_bn_apply_f32(_ptr(x_raw), cs, co, _ptr(mean), _ptr(invstd), _ptr(ga), _ptr(be), _ptr(res),
-                                               res_cs, 0, _ptr(y), ycs, yco, M, C, 1 if relu else 0, self.st()), "bn apply " + name)
+            _lib.check(f_stats(_ptr(x_raw), M, C, cs, co, BN_EPS, BN_MOM, _ptr(mean), _ptr(invstd), _ptr(bn.running_mean),
+                               _ptr(bn.running_var), _ptr(self._scratch_d), self.st()), "bn stats " + name)
+            _lib.check(f_apply(_ptr(x_raw), cs, co, _ptr(mean), _ptr(invstd), _ptr(ga), _ptr(be), _ptr(res), res_cs, 0, _ptr(y), ycs, yco,
+                               M, C, 1 if relu else 0, self.st()), "bn apply " + name)
 
         self.fwd.append(fwd)
         self._bn_counters.append(bn.num_batches_tracked)
         if dy is None:
-            dy, dy_cs, dy_co = self.buf("d:" + name, *y.shape, zero=True), ycs, yco
+            dy, dy_cs, dy_co = self.buf("d:" + name, *y.shape, zero=True, dtype=y.dtype), ycs, yco
         else:
             dy_co = 0
         assert C % 4 == 0
 
         def bwd():
             # dgamma / dbeta land directly in the parameters' gradients (C entries each, also read back by the dx pass)
-            _lib.check(lib.rdpn6d_bn_backward_f32(_ptr(x_raw), cs, co, _ptr(dy), dy_cs, dy_co, _ptr(y), ycs, yco, _ptr(mean),
-                                                  _ptr(invstd), _ptr(ga), _ptr(self._grad(bn.weight)), _ptr(self._grad(bn.bias)),
-                                                  _ptr(dx), cs, co, _ptr(dres), (dres.shape[-1] if dres is not None else 0), 0, M, C,
-                                                  1 if relu else 0, _ptr(self._scratch_d), self.st()), "bn bwd " + name)
+            _lib.check(f_bwd(_ptr(x_raw), cs, co, _ptr(dy), dy_cs, dy_co, _ptr(y), ycs, yco, _ptr(mean), _ptr(invstd), _ptr(ga),
+                             _ptr(self._grad(bn.weight)), _ptr(self._grad(bn.bias)), _ptr(dx), cs, co, _ptr(dres),
+                             (dres.shape[-1] if dres is not None else 0), 0, M, C, 1 if relu else 0, _ptr(self._scratch_d), self.st()),
+                       "bn bwd " + name)
 
         self.bwd.append([bwd])
         return dy
@@ -387,27 +407,33 @@ class TrainEngine:
                              operm=[n * 147 + t for n in range(64) for t in range(49)], dT=1, dIpad=3)
         raw0 = self.buf("raw:stem", B, R2, R2, 64)
         a0 = self.buf("act:stem", B, R2, R2, 64)
-        self.fwd.append(lambda: _lib.check(lib.rdpn6d_stem_conv7x7_raw_f32(_ptr(self.x), B, 6, R, _ptr(wst), _ptr(raw0), self.st()), "stem"))
+        sfx = self.sfx  # "bf16" under AMP: the kernels between the convolutions work on bf16-stored activations
+        f_stem = getattr(lib, f"rdpn6d_stem_conv7x7_raw_{sfx}")
+        self.fwd.append(lambda: _lib.check(f_stem(_ptr(self.x), B, 6, R, _ptr(wst), _ptr(raw0), self.st()), "stem"))
         d_raw0 = self.buf("d:stem", B, R2, R2, 64, zero=True)
-        xcol = self.buf("x_im2col", B * R2 * R2, 160)   # stem patch matrix (built in the backward, 335 MB at B=32)
+        xcol = self.buf("x_im2col", B * R2 * R2, 160, dtype=self.adt)   # stem patch matrix (built in the backward)
         wg_stem = self.buf("wg:stem", 64, 1, 160)
         self._wg_floats = max(self._wg_floats, int(lib.rdpn6d_wgrad_scratch_floats(B, R2, R2, 64, 160, 1)))
         z9 = (ctypes.c_int * 9)(*([0] * 9))
 
         def stem_wgrad():
             # dW(conv1)[n][ky][kx][c] = sum over output pixels of dY[p][n] * patch[p][(ky,kx,c)]: one pixel-reduction GEMM
-            _lib.check(lib.rdpn6d_stem_im2col_f32(_ptr(self.x), B, 6, R, _ptr(xcol), self.st()), "stem im2col")
-            _lib.check(lib.rdpn6d_wgrad_f32(_ptr(d_raw0), 64, 0, 64, _ptr(xcol), 160, 0, 160, B, R2, R2, R2, R2, 1, 1, z9, z9,
-                                            _ptr(wg_stem), _ptr(self._wg_partial), self.st()), "wgrad stem")
+            _lib.check(getattr(lib, f"rdpn6d_stem_im2col_{sfx}")(_ptr(self.x), B, 6, R, _ptr(xcol), self.st()), "stem im2col")
+            if self.amp:
+                _lib.check(lib.rdpn6d_wgrad_bf16(_ptr(d_raw0), 64, 0, 64, 64, _ptr(xcol), 160, 0, 160, 160, B, R2, R2, R2, R2, 1, 1, z9, z9,
+                                                 _ptr(wg_stem), _ptr(self._wg_partial), self.st()), "wgrad stem")
+            else:
+                _lib.check(lib.rdpn6d_wgrad_f32(_ptr(d_raw0), 64, 0, 64, _ptr(xcol), 160, 0, 160, B, R2, R2, R2, R2, 1, 1, z9, z9,
+                                                _ptr(wg_stem), _ptr(self._wg_partial), self.st()), "wgrad stem")
             self._grad(bb.conv1.weight).copy_(wg_stem[:, 0, :147].view(64, 7, 7, 3).permute(0, 3, 1, 2))
 
         self.bwd.append([stem_wgrad])
         d_a0 = self.bn_unit("bn1", bb.bn1, raw0, 64, 0, 64, B * R2 * R2, a0, 64, 0, True, dx=d_raw0)
         p0 = self.buf("act:pool", B, R4, R4, 64)
-        self.fwd.append(lambda: _lib.check(lib.rdpn6d_maxpool3x3s2_f32(_ptr(a0), B, R2, R2, 64, _ptr(p0), self.st()), "maxpool"))
+        f_pool, f_pool_b = getattr(lib, f"rdpn6d_maxpool3x3s2_{sfx}"), getattr(lib, f"rdpn6d_maxpool3x3s2_backward_{sfx}")
+        self.fwd.append(lambda: _lib.check(f_pool(_ptr(a0), B, R2, R2, 64, _ptr(p0), self.st()), "maxpool"))
         d_p0 = self.buf("d:pool", B, R4, R4, 64, zero=True)
-        self.bwd.append([lambda: _lib.check(lib.rdpn6d_maxpool3x3s2_backward_f32(_ptr(a0), _ptr(d_p0), B, R2, R2, 64, _ptr(d_a0),
-                                                                              self.st()), "maxpool bwd")])
+        self.bwd.append([lambda: _lib.check(f_pool_b(_ptr(a0), _ptr(d_p0), B, R2, R2, 64, _ptr(d_a0), self.st()), "maxpool bwd")])
         # ---- residual trunk
         cur, d_cur, hw, c = p0, d_p0, R4, 64
         for li in range(4):
@@ -475,21 +501,23 @@ class TrainEngine:
         up = self.buf("act:up", B, R8, R8, C4)
         f = R8 // hw
         l4out, d_l4out, l4hw = cur, d_cur, hw
-        self.fwd.append(lambda: _lib.check(lib.rdpn6d_upsample_bilinear_f32(_ptr(l4out), B, l4hw, l4hw, C4, f, _ptr(up), self.st()), "upsample"))
+        f_up, f_up_b = getattr(lib, f"rdpn6d_upsample_bilinear_{sfx}"), getattr(lib, f"rdpn6d_upsample_bilinear_backward_{sfx}")
+        self.fwd.append(lambda: _lib.check(f_up(_ptr(l4out), B, l4hw, l4hw, C4, f, _ptr(up), self.st()), "upsample"))
         d_up = self.buf("d:up", B, R8, R8, C4, zero=True)
-        self.bwd.append([lambda: _lib.check(lib.rdpn6d_upsample_bilinear_backward_f32(_ptr(d_up), B, l4hw, l4hw, C4, f, _ptr(d_l4out),
-                                                                                   self.st()), "upsample bwd")])
+        self.bwd.append([lambda: _lib.check(f_up_b(_ptr(d_up), B, l4hw, l4hw, C4, f, _ptr(d_l4out), self.st()), "upsample bwd")])
         sn = bb.spatial_net
         Mp = B * R8 * R8
-        pin = self.buf("act:pn_in", B, R8, R8, 80, zero=True)   # [emb(64) | xyz(3) | 0-pad]
-        d_pin = self.buf("d:pn_in", B, R8, R8, 80, zero=True)
-        self.fwd.append(lambda: _lib.check(lib.rdpn6d_xyz_subsample_f32(_ptr(self.x), B, 6, R, 8, _ptr(pin), 80, 64, self.st()), "xyz"))
+        pcs = 96 if self.amp else 80  # [emb(64) | xyz(3) | 0-pad] to the K-chunk granularity of the conv kernel in use
+        pin = self.buf("act:pn_in", B, R8, R8, pcs, zero=True)
+        d_pin = self.buf("d:pn_in", B, R8, R8, pcs, zero=True)
+        f_xyz = getattr(lib, f"rdpn6d_xyz_subsample_{sfx}")
+        self.fwd.append(lambda: _lib.check(f_xyz(_ptr(self.x), B, 6, R, 8, _ptr(pin), pcs, 64, self.st()), "xyz"))
         r_e = self.buf("raw:pn.emb", B, R8, R8, 64)
         d_re = self.conv_unit("spatial_net.xyz_emb", sn.xyz_emb, up, (R8, R8), C4, 0, C4, r_e, (R8, R8), 64, 0, bias=sn.xyz_emb.bias, dx=d_up)
-        self.bn_unit("spatial_net.xb", sn.xb, r_e, 64, 0, 64, Mp, pin, 80, 0, True, dx=d_re, dy=d_pin, dy_cs=80)
+        self.bn_unit("spatial_net.xb", sn.xb, r_e, 64, 0, 64, Mp, pin, pcs, 0, True, dx=d_re, dy=d_pin, dy_cs=pcs)
         r1p, a1p = self.buf("raw:pn.c1", B, R8, R8, 128), self.buf("act:pn.c1", B, R8, R8, 128)
         perm = list(range(3, 67)) + [0, 1, 2]
-        d_r1p = self.conv_unit("spatial_net.conv1", sn.conv1, pin, (R8, R8), 80, 0, 67, r1p, (R8, R8), 128, 0, perm=perm,
+        d_r1p = self.conv_unit("spatial_net.conv1", sn.conv1, pin, (R8, R8), pcs, 0, 67, r1p, (R8, R8), 128, 0, perm=perm,
                                bias=sn.conv1.bias, dx=d_pin)
         d_a1p = self.bn_unit("spatial_net.b1", sn.b1, r1p, 128, 0, 128, Mp, a1p, 128, 0, True, dx=d_r1p)
         r2p, a2p = self.buf("raw:pn.c2", B, R8, R8, 256), self.buf("act:pn.c2", B, R8, R8, 256)
@@ -502,9 +530,9 @@ class TrainEngine:
         d_r3p = self.conv_unit("spatial_net.conv3", sn.conv3, a2p, (R8, R8), 256, 0, 256, r3p, (R8, R8), 512, 0, bias=sn.conv3.bias, dx=d_a2p)
         # b3 writes channels [0,512) of feat; its output gradient arrives as a dense [.,512] tensor from the gmax backward
         self.bn_unit("spatial_net.b3", sn.b3, r3p, 512, 0, 512, Mp, feat, 1024, 0, False, dx=d_r3p, dy=d_l3, dy_cs=512)
-        self.fwd.append(lambda: _lib.check(lib.rdpn6d_global_max_concat_f32(_ptr(feat), B, R8 * R8, 512, 1024, self.st()), "gmax"))
-        self.bwd.append([lambda: _lib.check(lib.rdpn6d_global_max_concat_backward_f32(_ptr(feat), _ptr(d_feat), B, R8 * R8, 512, 1024,
-                                                                                   _ptr(d_l3), self.st()), "gmax bwd")])
+        f_gm, f_gm_b = getattr(lib, f"rdpn6d_global_max_concat_{sfx}"), getattr(lib, f"rdpn6d_global_max_concat_backward_{sfx}")
+        self.fwd.append(lambda: _lib.check(f_gm(_ptr(feat), B, R8 * R8, 512, 1024, self.st()), "gmax"))
+        self.bwd.append([lambda: _lib.check(f_gm_b(_ptr(feat), _ptr(d_feat), B, R8 * R8, 512, 1024, _ptr(d_l3), self.st()), "gmax bwd")])
         # ---- dense head: ConvTranspose as 4 phase convs (forward), stride-2 conv (dgrad), gathered wgrad
         self._group_marks = {0: "backbone", len(self.bwd): "rot_head_net"}  # bwd index where a group's gradients are complete
         F = head.features[0].weight.shape[1]
@@ -521,10 +549,10 @@ class TrainEngine:
                 # dst[f][ti][cin] = wt[cin][f][ky][kx]
                 wp = self._pack_map((_pad_to(F, 64), len(ptaps), 1024), wt, F, len(ptaps), 1024, 9, F * 9, [ky * 3 + kx for ky, kx in kk])
                 if self.amp:
-                    featb, _ = self._bf16_of(self.fwd, feat, 1024, 0, 1024, B * R8 * R8, cache=True)
+                    featb = feat  # bf16-stored
                     wpb = self._mirror(wp)
                     d = self._conv_desc(featb, (R8, R8), 1024, 0, 1024, wpb, rt0, (R4, R4), F, 0, F, ptaps, phase=(R8, R8, 2, 2, py, px))
-                    self.fwd.append(self._launch_conv(f"convT phase{py}{px}", d, (wp, wpb, featb), lowp=True))
+                    self.fwd.append(self._launch_conv(f"convT phase{py}{px}", d, (wp, wpb, featb), lowp=True, out_f32=False))
                 else:
                     d = self._conv_desc(feat, (R8, R8), 1024, 0, 1024, wp, rt0, (R4, R4), F, 0, F, ptaps, phase=(R8, R8, 2, 2, py, px))
                     self.fwd.append(self._launch_conv(f"convT phase{py}{px}", d, wp))
@@ -533,7 +561,7 @@ class TrainEngine:
         convT_bwd = []
         if self.amp:
             assert F % 32 == 0
-            d_rt0b, _ = self._bf16_of(convT_bwd, d_rt0, F, 0, F, B * R4 * R4, cache=False)
+            d_rt0b = d_rt0  # bf16-stored
             wdTb = self._mirror(wdT)
             ddT = self._conv_desc(d_rt0b, (R4, R4), F, 0, F, wdTb, d_feat, (R8, R8), 1024, 0, 1024, _taps(3, 1), stride=2)
         else:
@@ -552,7 +580,7 @@ class TrainEngine:
                 _lib.check(lib.rdpn6d_wgrad_f32_strided(_ptr(feat), 1024, 0, 1024, _ptr(d_rt0), F, 0, F, B, R8, R8, R4, R4, 2, 9, t9y,
                                                         t9x, *tgt, _ptr(self._wg_partial), self.st()), "wgrad convT")
 
-        self.bwd.append(convT_bwd + [convT_wgrad, self._launch_conv("dgrad convT", ddT, wdT, lowp=self.amp)])
+        self.bwd.append(convT_bwd + [convT_wgrad, self._launch_conv("dgrad convT", ddT, wdT, lowp=self.amp, out_f32=not self.amp)])
         d_prev = self.bn_unit("head.bn0", head.features[1], rt0, F, 0, F, Mh, at0, F, 0, True, dx=d_rt0)
         a_prev = at0
         nfeat = len(head.features)
