@@ -10,44 +10,64 @@
 #include "common.h"
 #include <float.h>
 
-#define NS_MAX 128  // row splits of the partial reductions
+#define NS_MAX 256  // row splits of the partial reductions
 
 // ---------------------------------------------------------------------------------------------
 // Stage 1 of every per-channel reduction.  MODE 0: (sum x, sum x^2)         [BN statistics, bias grads]
 //                                            MODE 1: (sum g, sum g*xhat)       [BN backward], g = dy*(y>0) if relu
 // grid = (C/64, S); block = 256 = 16 row lanes x 16 channel quads (16-byte loads)
-template <int MODE, typename T>
+// V = channels per thread: 4 (16-byte fp32 loads, 64 channels per workgroup) or 8 (16-byte bf16 loads, 128 channels per
+// workgroup - the bf16-stored activations of the mixed-precision step, so that a wavefront still reads 256-byte rows)
+template <typename T, int V> __device__ __forceinline__ void rd_ldv(const T* p, float (&v)[V])
+{
+    if constexpr (V == 4) {
+        const f32x4 t = rd_ld4<T>(p);
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+    } else {
+        static_assert(sizeof(T) == 2 && V == 8, "8 channels per thread is the bf16 form");
+        rd_unpack8(*reinterpret_cast<const rd_u32x4*>(p), v);
+    }
+}
+
+template <int MODE, typename T, int V>
 __global__ __launch_bounds__(256) void chan_partial_kernel(const T* __restrict__ x, int xcs, int xco,
                                                            const T* __restrict__ dy, int dcs, int dco,
                                                            const T* __restrict__ y, int ycs, int yco,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            long long M, int C, int relu, double* __restrict__ partial)
 {
-    // block = 16 row lanes x 16 channel quads: every thread streams 16-byte loads, a wavefront covers 4 rows x 256 B
-    __shared__ double s_a[16][64], s_b[16][64];
+    // block = 16 row lanes x 16 channel groups of V: every thread streams 16-byte loads, a wavefront covers 4 rows x 256 B
+    constexpr int CB = 16 * V;  // channels per workgroup
+    __shared__ double s_a[16][CB], s_b[16][CB];
     const int q = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const int c = blockIdx.x * 64 + q * 4;
+    const int c = blockIdx.x * CB + q * V;
     const int S = gridDim.y;
     const long long rows_per = (M + S - 1) / S;
     const long long m_lo = (long long)blockIdx.y * rows_per, m_hi = m_lo + rows_per < M ? m_lo + rows_per : M;
-    double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
-    if (c < C) {  // C % 4 == 0 is required by the callers
-        f32x4 mu = {0, 0, 0, 0}, is = {0, 0, 0, 0};
-        if (MODE == 1) { mu = *reinterpret_cast<const f32x4*>(mean + c); is = *reinterpret_cast<const f32x4*>(invstd + c); }
+    double a[V], b[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) { a[e] = 0.0; b[e] = 0.0; }
+    if (c < C) {  // C % V == 0 is required by the callers
+        float mu[V], is[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) { mu[e] = MODE == 1 ? mean[c + e] : 0.f; is[e] = MODE == 1 ? invstd[c + e] : 0.f; }
         for (long long m = m_lo + rl; m < m_hi; m += 16) {
-            const f32x4 xv = rd_ld4<T>(x + m * xcs + xco + c);
+            float xv[V];
+            rd_ldv<T, V>(x + m * xcs + xco + c, xv);
             if (MODE == 0) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { a[e] += (double)xv[e]; b[e] += (double)xv[e] * (double)xv[e]; }
+                for (int e = 0; e < V; ++e) { a[e] += (double)xv[e]; b[e] += (double)xv[e] * (double)xv[e]; }
             } else {
-                f32x4 g = rd_ld4<T>(dy + m * dcs + dco + c);
+                float g[V];
+                rd_ldv<T, V>(dy + m * dcs + dco + c, g);
                 if (relu) {
-                    const f32x4 yv = rd_ld4<T>(y + m * ycs + yco + c);
+                    float yv[V];
+                    rd_ldv<T, V>(y + m * ycs + yco + c, yv);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) g[e] = yv[e] > 0.f ? g[e] : 0.f;
+                    for (int e = 0; e < V; ++e) g[e] = yv[e] > 0.f ? g[e] : 0.f;
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < V; ++e) {
                     const float xh = (xv[e] - mu[e]) * is[e];
                     a[e] += (double)g[e];
                     b[e] += (double)g[e] * (double)xh;
@@ -56,16 +76,35 @@ __global__ __launch_bounds__(256) void chan_partial_kernel(const T* __restrict__
         }
     }
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { s_a[rl][q * 4 + e] = a[e]; s_b[rl][q * 4 + e] = b[e]; }
+    for (int e = 0; e < V; ++e) { s_a[rl][q * V + e] = a[e]; s_b[rl][q * V + e] = b[e]; }
     __syncthreads();
-    if (threadIdx.x < 64 && blockIdx.x * 64 + threadIdx.x < C) {
+    if (threadIdx.x < CB && blockIdx.x * CB + threadIdx.x < C) {
         double ta = 0.0, tb = 0.0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { ta += s_a[r][threadIdx.x]; tb += s_b[r][threadIdx.x]; }
-        const int cc = blockIdx.x * 64 + threadIdx.x;
+        const int cc = blockIdx.x * CB + threadIdx.x;
         partial[((long long)blockIdx.y * C + cc) * 2 + 0] = ta;
         partial[((long long)blockIdx.y * C + cc) * 2 + 1] = tb;
     }
+}
+
+template <int MODE, typename T>
+static void chan_partial_launch(const T* x, int xcs, int xco, const T* dy, int dcs, int dco, const T* y, int ycs, int yco,
+                                const float* mean, const float* invstd, long long M, int C, int relu, double* partial, int S,
+                                hipStream_t s)
+{
+    // 8 channels per thread when every operand slice allows 16-byte bf16 accesses
+    const bool wide = sizeof(T) == 2 && C % 8 == 0 && xcs % 8 == 0 && xco % 8 == 0 &&
+                      (MODE == 0 || (dcs % 8 == 0 && dco % 8 == 0 && (!relu || (ycs % 8 == 0 && yco % 8 == 0))));
+    if constexpr (sizeof(T) == 2) {
+        if (wide) {
+            hipLaunchKernelGGL((chan_partial_kernel<MODE, T, 8>), dim3((C + 127) / 128, S), dim3(256), 0, s, x, xcs, xco, dy, dcs, dco, y,
+                               ycs, yco, mean, invstd, M, C, relu, partial);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((chan_partial_kernel<MODE, T, 4>), dim3((C + 63) / 64, S), dim3(256), 0, s, x, xcs, xco, dy, dcs, dco, y, ycs,
+                       yco, mean, invstd, M, C, relu, partial);
 }
 
 // Stage 2 helpers: block = 256 threads = 4 split lanes x 64 channels; the S partials of a channel are summed by 4
@@ -121,10 +160,10 @@ __global__ __launch_bounds__(256) void chan_sum_finalize_kernel(const double* __
     if (out_b) out_b[c] = (accumulate ? out_b[c] : 0.f) + (float)b;
 }
 
-static int pick_splits(long long M, int C)
+static int pick_splits(long long M, int C, int cb = 64)
 {
     long long s = (M + 255) / 256;                       // >= 16 rows per row lane
-    const long long want = 2048 / ((C + 63) / 64) + 1;  // enough workgroups to fill the chip (8 per CU)
+    const long long want = 2048 / ((C + cb - 1) / cb) + 1;  // enough workgroups to fill the chip (8 per CU)
     if (s > want) s = want;
     if (s > NS_MAX) s = NS_MAX;
     if (s < 1) s = 1;
@@ -137,10 +176,9 @@ static int bn_train_stats_impl(const T* x, long long M, int C, int cs, int co, f
 {
     RD_REQUIRE(x && mean && invstd && scratch, "null pointer");
     RD_REQUIRE(M > 0 && C > 0 && co + C <= cs && C % 4 == 0 && cs % 4 == 0 && co % 4 == 0, "shape / 16-byte alignment");
-    const int S = pick_splits(M, C);
+    const int S = pick_splits(M, C, sizeof(T) == 2 && C % 8 == 0 ? 128 : 64);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL((chan_partial_kernel<0, T>), dim3((C + 63) / 64, S), dim3(256), 0, s, x, cs, co, (const T*)nullptr, 0, 0,
-                       (const T*)nullptr, 0, 0, nullptr, nullptr, M, C, 0, scratch);
+    chan_partial_launch<0, T>(x, cs, co, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, M, C, 0, scratch, S, s);
     RD_LAUNCH_CHECK();
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, s, scratch, S, C, M, eps, momentum, mean,
                        invstd, running_mean, running_var);
@@ -168,10 +206,9 @@ template <typename T>
 static int channel_sum_impl(const T* x, long long M, int C, int cs, int co, float* out, int accumulate, double* scratch, void* stream)
 {
     RD_REQUIRE(x && out && scratch && M > 0 && C > 0 && co + C <= cs && C % 4 == 0 && cs % 4 == 0 && co % 4 == 0, "shape / alignment");
-    const int S = pick_splits(M, C);
+    const int S = pick_splits(M, C, sizeof(T) == 2 && C % 8 == 0 ? 128 : 64);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL((chan_partial_kernel<0, T>), dim3((C + 63) / 64, S), dim3(256), 0, s, x, cs, co, (const T*)nullptr, 0, 0,
-                       (const T*)nullptr, 0, 0, nullptr, nullptr, M, C, 0, scratch);
+    chan_partial_launch<0, T>(x, cs, co, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, M, C, 0, scratch, S, s);
     RD_LAUNCH_CHECK();
     hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, s, scratch, S, C, out, nullptr, accumulate);
     RD_LAUNCH_CHECK();
@@ -190,32 +227,37 @@ extern "C" int rdpn6d_channel_sum_bf16(const void* x, long long M, int C, int cs
 
 // ---------------------------------------------------------------------------------------------
 // y = act(((x - mean) * invstd) * gamma + beta (+ res)), 4 channels per thread
-template <typename T>
+template <typename T, int V> __device__ __forceinline__ void rd_stv(T* p, const float (&v)[V])
+{
+    if constexpr (V == 4) rd_st4<T>(p, f32x4{v[0], v[1], v[2], v[3]});
+    else *reinterpret_cast<rd_u32x4*>(p) = rd_pack8(v);
+}
+
+template <typename T, int V>
 __global__ void bn_apply_kernel(const T* __restrict__ x, int xcs, int xco, const float* __restrict__ mean,
                                 const float* __restrict__ invstd, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, const T* __restrict__ res, int rcs, int rco,
                                 T* __restrict__ y, int ycs, int yco, long long M, int C, int relu)
 {
-    const int C4 = C / 4;
-    const long long total = M * C4;
+    const int CV = C / V;
+    const long long total = M * CV;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C4) * 4;
-        const long long m = i / C4;
-        const f32x4 v = rd_ld4<T>(x + m * xcs + xco + c);
-        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c), is = *reinterpret_cast<const f32x4*>(invstd + c);
-        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
-        f32x4 o;
+        const int c = (int)(i % CV) * V;
+        const long long m = i / CV;
+        float v[V], o[V];
+        rd_ldv<T, V>(x + m * xcs + xco + c, v);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (v[e] - mu[e]) * is[e] * ga[e] + be[e];
+        for (int e = 0; e < V; ++e) o[e] = (v[e] - mean[c + e]) * invstd[c + e] * gamma[c + e] + beta[c + e];
         if (res) {
-            const f32x4 r = rd_ld4<T>(res + m * rcs + rco + c);
+            float r[V];
+            rd_ldv<T, V>(res + m * rcs + rco + c, r);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] += r[e];
+            for (int e = 0; e < V; ++e) o[e] += r[e];
         }
         if (relu)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = o[e] > 0.f ? o[e] : 0.f;
-        rd_st4<T>(y + m * ycs + yco + c, o);
+            for (int e = 0; e < V; ++e) o[e] = o[e] > 0.f ? o[e] : 0.f;
+        rd_stv<T, V>(y + m * ycs + yco + c, o);
     }
 }
 
@@ -226,10 +268,20 @@ static int bn_apply_impl(const T* x, int xcs, int xco, const float* mean, const 
 {
     RD_REQUIRE(x && mean && invstd && gamma && beta && y, "null pointer");
     RD_REQUIRE(M > 0 && C > 0 && C % 4 == 0 && xco % 4 == 0 && yco % 4 == 0 && xcs % 4 == 0 && ycs % 4 == 0, "shape/alignment");
+    if constexpr (sizeof(T) == 2) {
+        if (C % 8 == 0 && xcs % 8 == 0 && xco % 8 == 0 && ycs % 8 == 0 && yco % 8 == 0 && (!res || (rcs % 8 == 0 && rco % 8 == 0))) {
+            const long long total8 = M * (C / 8);
+            const int blocks8 = (int)((total8 + 255) / 256 < 16384 ? (total8 + 255) / 256 : 16384);
+            hipLaunchKernelGGL((bn_apply_kernel<T, 8>), dim3(blocks8), dim3(256), 0, (hipStream_t)stream, x, xcs, xco, mean, invstd, gamma,
+                               beta, res, rcs, rco, y, ycs, yco, M, C, relu);
+            RD_LAUNCH_CHECK();
+            return RDPN6D_OK;
+        }
+    }
     const long long total = M * (C / 4);
     const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, xcs, xco, mean, invstd, gamma, beta, res,
-                       rcs, rco, y, ycs, yco, M, C, relu);
+    hipLaunchKernelGGL((bn_apply_kernel<T, 4>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, xcs, xco, mean, invstd, gamma, beta,
+                       res, rcs, rco, y, ycs, yco, M, C, relu);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
 }
@@ -251,7 +303,7 @@ extern "C" int rdpn6d_bn_apply_bf16(const void* x, int xcs, int xco, const float
 // BN backward.  g = dy * (y > 0) when the BN was followed by ReLU.
 //   dgamma = sum g*xhat, dbeta = sum g
 //   dx = gamma*invstd * (g - dbeta/M - xhat*dgamma/M);   dres (optional) = g  (identity branch of a residual block)
-template <typename T>
+template <typename T, int V>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ x, int xcs, int xco, const T* __restrict__ dy, int dcs, int dco,
                                     const T* __restrict__ y, int ycs, int yco, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
@@ -259,27 +311,28 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ x, int xcs, int xco, c
                                     T* __restrict__ dx, int xgcs, int xgco, T* __restrict__ dres, int rcs, int rco,
                                     long long M, int C, int relu)
 {
-    const int C4 = C / 4;
-    const long long total = M * C4;
+    const int CV = C / V;
+    const long long total = M * CV;
     const float invM = 1.0f / (float)M;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C4) * 4;
-        const long long m = i / C4;
-        const f32x4 xv = rd_ld4<T>(x + m * xcs + xco + c);
-        f32x4 g = rd_ld4<T>(dy + m * dcs + dco + c);
+        const int c = (int)(i % CV) * V;
+        const long long m = i / CV;
+        float xv[V], g[V], o[V];
+        rd_ldv<T, V>(x + m * xcs + xco + c, xv);
+        rd_ldv<T, V>(dy + m * dcs + dco + c, g);
         if (relu) {
-            const f32x4 yv = rd_ld4<T>(y + m * ycs + yco + c);
+            float yv[V];
+            rd_ldv<T, V>(y + m * ycs + yco + c, yv);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) g[e] = yv[e] > 0.f ? g[e] : 0.f;
+            for (int e = 0; e < V; ++e) g[e] = yv[e] > 0.f ? g[e] : 0.f;
         }
-        f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < V; ++e) {
             const float xh = (xv[e] - mean[c + e]) * invstd[c + e];
             o[e] = gamma[c + e] * invstd[c + e] * (g[e] - dbeta[c + e] * invM - xh * dgamma[c + e] * invM);
         }
-        rd_st4<T>(dx + m * xgcs + xgco + c, o);
-        if (dres) rd_st4<T>(dres + m * rcs + rco + c, g);
+        rd_stv<T, V>(dx + m * xgcs + xgco + c, o);
+        if (dres) rd_stv<T, V>(dres + m * rcs + rco + c, g);
     }
 }
 
@@ -291,17 +344,27 @@ static int bn_backward_impl(const T* x, int xcs, int xco, const T* dy, int dcs, 
     RD_REQUIRE(x && dy && mean && invstd && gamma && dgamma && dbeta && dx && scratch, "null pointer");
     RD_REQUIRE(!relu || y, "ReLU mask needs the forward output");
     RD_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "shape");
-    const int S = pick_splits(M, C);
+    const int S = pick_splits(M, C, sizeof(T) == 2 && C % 8 == 0 ? 128 : 64);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL((chan_partial_kernel<1, T>), dim3((C + 63) / 64, S), dim3(256), 0, s, x, xcs, xco, dy, dcs, dco, y, ycs, yco,
-                       mean, invstd, M, C, relu, scratch);
+    chan_partial_launch<1, T>(x, xcs, xco, dy, dcs, dco, y, ycs, yco, mean, invstd, M, C, relu, scratch, S, s);
     RD_LAUNCH_CHECK();
     // partial = (sum g, sum g*xhat) -> dbeta, dgamma
     hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, s, scratch, S, C, dbeta, dgamma, 0);
     RD_LAUNCH_CHECK();
+    if constexpr (sizeof(T) == 2) {
+        if (C % 8 == 0 && xcs % 8 == 0 && xco % 8 == 0 && dcs % 8 == 0 && dco % 8 == 0 && xgcs % 8 == 0 && xgco % 8 == 0 &&
+            (!relu || (ycs % 8 == 0 && yco % 8 == 0)) && (!dres || (rcs % 8 == 0 && rco % 8 == 0))) {
+            const long long total8 = M * (C / 8);
+            const int blocks8 = (int)((total8 + 255) / 256 < 16384 ? (total8 + 255) / 256 : 16384);
+            hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 8>), dim3(blocks8), dim3(256), 0, s, x, xcs, xco, dy, dcs, dco, y, ycs, yco, mean,
+                               invstd, gamma, dgamma, dbeta, dx, xgcs, xgco, dres, rcs, rco, M, C, relu);
+            RD_LAUNCH_CHECK();
+            return RDPN6D_OK;
+        }
+    }
     const long long total = M * (C / 4);
     const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(blocks), dim3(256), 0, s, x, xcs, xco, dy, dcs, dco, y, ycs, yco, mean, invstd,
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 4>), dim3(blocks), dim3(256), 0, s, x, xcs, xco, dy, dcs, dco, y, ycs, yco, mean, invstd,
                        gamma, dgamma, dbeta, dx, xgcs, xgco, dres, rcs, rco, M, C, relu);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
