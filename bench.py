@@ -221,7 +221,8 @@ def train_bench(args, rank, world, device, dist):
             "metric": "RGB-D crops/sec, TRAINING step (fwd+losses+bwd+allreduce+Ranger) at 256x256", "value": round(value, 1),
             "unit": "crops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16 convolutions (fwd + dgrad), fp32 BN / losses / wgrad / optimizer" if amp else "f32", "data": "synthetic",
+            "dtype": "bf16 convolutions (fwd + dgrad + wgrad) and stored activations, fp32 BN math / losses / pose branch / optimizer" if amp else "f32",
+            "data": "synthetic",
             "config": {"workload": "LM-O style training step, MASK_ATTENTION=mul, K=32, ResNet-34, per-GPU BatchNorm, "
                                    + ("SOLVER.AMP.ENABLED" if amp else "fp32"),
                        "batch_per_gpu": B, "global_batch": B * world,
@@ -247,7 +248,8 @@ def main():
                     help="f32 (default, the parity-bearing headline) | bf16: secondary line, cfg.TEST.AMP_TEST mode "
                          "(trunk + fusion + head on the bf16 matrix pipe, fp32 head output / ConvPnPNet / pose / RANSAC)")
     ap.add_argument("--train", action="store_true",
-                    help="secondary line: fp32 training step (fwd + losses + bwd + bucketed RCCL all-reduce + Ranger), B=32/GPU")
+                    help="secondary line: training step (fwd + losses + bwd + bucketed RCCL all-reduce + Ranger), B=32/GPU; "
+                         "fp32, or mixed precision (cfg.SOLVER.AMP.ENABLED) with --dtype bf16")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
