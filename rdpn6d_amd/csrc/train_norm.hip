@@ -10,7 +10,7 @@
 #include "common.h"
 #include <float.h>
 
-#define NS_MAX 256  // row splits of the partial reductions
+#define NS_MAX 128  // row splits of the partial reductions
 
 // ---------------------------------------------------------------------------------------------
 // Stage 1 of every per-channel reduction.  MODE 0: (sum x, sum x^2)         [BN statistics, bias grads]
@@ -51,26 +51,40 @@ __global__ __launch_bounds__(256) void chan_partial_kernel(const T* __restrict__
         float mu[V], is[V];
 #pragma unroll
         for (int e = 0; e < V; ++e) { mu[e] = MODE == 1 ? mean[c + e] : 0.f; is[e] = MODE == 1 ? invstd[c + e] : 0.f; }
-        for (long long m = m_lo + rl; m < m_hi; m += 16) {
-            float xv[V];
-            rd_ldv<T, V>(x + m * xcs + xco + c, xv);
-            if (MODE == 0) {
+        // four rows per iteration: all loads of the group are issued before the first dependent use (memory-level
+        // parallelism - the kernel is latency-bound otherwise); rows past the end are clamped and contribute zero
+        for (long long m0 = m_lo + rl; m0 < m_hi; m0 += 64) {
+            float xv[4][V], g[4][V], yv[4][V];
+            bool ok[4];
 #pragma unroll
-                for (int e = 0; e < V; ++e) { a[e] += (double)xv[e]; b[e] += (double)xv[e] * (double)xv[e]; }
-            } else {
-                float g[V];
-                rd_ldv<T, V>(dy + m * dcs + dco + c, g);
-                if (relu) {
-                    float yv[V];
-                    rd_ldv<T, V>(y + m * ycs + yco + c, yv);
-#pragma unroll
-                    for (int e = 0; e < V; ++e) g[e] = yv[e] > 0.f ? g[e] : 0.f;
+            for (int u = 0; u < 4; ++u) {
+                const long long mr = m0 + 16 * u;
+                ok[u] = mr < m_hi;
+                const long long m = ok[u] ? mr : m0;
+                rd_ldv<T, V>(x + m * xcs + xco + c, xv[u]);
+                if (MODE == 1) {
+                    rd_ldv<T, V>(dy + m * dcs + dco + c, g[u]);
+                    if (relu) rd_ldv<T, V>(y + m * ycs + yco + c, yv[u]);
                 }
+            }
 #pragma unroll
-                for (int e = 0; e < V; ++e) {
-                    const float xh = (xv[e] - mu[e]) * is[e];
-                    a[e] += (double)g[e];
-                    b[e] += (double)g[e] * (double)xh;
+            for (int u = 0; u < 4; ++u) {
+                if (MODE == 0) {
+#pragma unroll
+                    for (int e = 0; e < V; ++e) {
+                        const double xd = ok[u] ? (double)xv[u][e] : 0.0;
+                        a[e] += xd;
+                        b[e] += xd * xd;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < V; ++e) {
+                        float ge = ok[u] ? g[u][e] : 0.f;
+                        if (relu) ge = yv[u][e] > 0.f ? ge : 0.f;
+                        const float xh = (xv[u][e] - mu[e]) * is[e];
+                        a[e] += (double)ge;
+                        b[e] += (double)ge * (double)xh;
+                    }
                 }
             }
         }
