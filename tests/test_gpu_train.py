@@ -408,3 +408,61 @@ def test_resnet50_training_step(amp):
     med_h, med_c = float(np.median(eh)), float(np.median(ec))
     print(f"resnet50 320x320: {len(eh)} gradient tensors, median rel err vs fp64: HIP {med_h:.2e}, CPU fp32 {med_c:.2e}; worst HIP {max(eh):.2e} CPU {max(ec):.2e}")
     assert med_h <= max(2.0 * med_c, 1e-3) and max(eh) <= max(3.0 * max(ec), 5e-2)
+
+
+@pytest.mark.parametrize("K,R,amp", [(64, 128, False), (64, 128, True), (8, 256, False)])
+def test_training_step_generalised_geometry(K, R, amp):
+    """NUM_REGIONS = 64 (ten LM-O configs; the reference's nIn = 43 cannot build it) and 128x128 crops through the whole
+    training step, against the generalised oracle's autograd (fp64 yardstick); under AMP only finiteness + loss agreement."""
+    from oracle import model_oracle
+    from rdpn6d_amd import synth
+    from rdpn6d_amd.config import gdrn_base_cfg
+    from rdpn6d_amd.gdrn import build_model_optimizer
+
+    dev = torch.device("cuda:0")
+    cfg = gdrn_base_cfg(num_regions=K, mask_attention="mul", device="cuda")
+    cfg.MODEL.CDPN.BACKBONE.INPUT_RES, cfg.MODEL.CDPN.BACKBONE.OUTPUT_RES = R, R // 4
+    cfg.SOLVER.AMP.ENABLED = amp
+    model, _ = build_model_optimizer(cfg)
+    sd = synth.make_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=4242)
+    sd = {k: torch.from_numpy(np.asarray(v)).clone() for k, v in sd.items()}
+    for k in sd:
+        if k.endswith("bn2.weight"):
+            sd[k] *= 0.25
+    model.load_state_dict(sd, strict=True)
+    inp = synth.make_inputs(3, seed=8, res=R, num_regions=K)
+    gt = synth.make_train_gt(3, inp)
+    gt["roi_region"] = (np.random.Generator(np.random.PCG64(5)).integers(1, K + 1, size=gt["roi_region"].shape) * (gt["roi_mask_visib"] > 0)).astype(np.int64)
+    b = {k: torch.from_numpy(v).to(dev) for k, v in {**inp, **gt}.items()}
+    eng = model.train_engine(3, dev)
+    assert eng.amp == amp
+    losses = eng.forward_backward(b)
+    torch.cuda.synchronize()
+    t = {k: torch.from_numpy(v) for k, v in {**inp, **gt}.items()}
+    res = {}
+    for dtype in (torch.float32, torch.float64):
+        o = model_oracle.GDRNOracle(K, "mul", out_res=R // 4)
+        o.load_state_dict(sd, strict=True)
+        o = o.to(dtype).train()
+        tt = {k: (v.to(dtype) if v.dtype.is_floating_point else v) for k, v in t.items()}
+        out = o(tt["roi_img"], tt["roi_coord_2d"], tt["fps"], tt["roi_cam"], tt["roi_center"], tt["roi_wh"], tt["resize_ratio"], train_pose=True)
+        L = model_oracle.gdrn_losses(out, tt, tt["roi_extent"])
+        sum(L.values()).backward()
+        res[dtype] = ({k: p.grad.double() for k, p in o.named_parameters()}, L)
+    L64 = res[torch.float64][1]
+    for k, v in losses.items():
+        # bf16: the dense losses move by a few per cent; the pose losses hang off an 8-bit-mantissa run of a random network
+        tol = (0.3 if k in ("loss_PM_R", "loss_centroid", "loss_z") else 5e-2) if amp else 2e-3
+        assert torch.isfinite(v).all() and abs(v.item() - L64[k].item()) <= tol * max(1.0, abs(L64[k].item())), (k, v.item(), L64[k].item())
+    g32, g64 = res[torch.float32][0], res[torch.float64][0]
+    eh, ec = [], []
+    for name, p in model.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+        n = g64[name].norm().item()
+        if n < 1e-4:
+            continue
+        eh.append((p.grad.cpu().double() - g64[name]).norm().item() / n)
+        ec.append((g32[name] - g64[name]).norm().item() / n)
+    print(f"K={K} R={R} amp={amp}: median rel grad err vs fp64 HIP {np.median(eh):.2e} (CPU fp32 {np.median(ec):.2e}), worst HIP {max(eh):.2e} (CPU {max(ec):.2e})")
+    if not amp:
+        assert np.median(eh) <= max(2.0 * np.median(ec), 1e-3) and max(eh) <= max(3.0 * max(ec), 5e-2)
