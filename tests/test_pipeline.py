@@ -1,0 +1,77 @@
+"""The hot path with its two neighbours, end to end ON DEVICE: full frames + boxes -> GPU crop builder ->
+GDRN forward + per-crop RANSAC (the path) -> ADD / ADI / re / te.  Weights are the seeded random ones, so
+the poses mean nothing; what is checked is the plumbing - every stage consumes the previous stage's device tensors as they
+are, and each stage's output equals its oracle fed the same inputs."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_frames_to_pose_errors_on_device(golden_dir):
+    import os
+
+    from oracle import crop_oracle, model_oracle, targets_eval_oracle as teo
+    from rdpn6d_amd import ops, synth
+    from rdpn6d_amd.config import gdrn_base_cfg
+    from rdpn6d_amd.crop import build_crops
+    from rdpn6d_amd.gdrn import build_model_optimizer
+    from tests.test_crop import _frames
+
+    dev = torch.device("cuda:0")
+    B = 4
+    img, depth = _frames(7, 2)
+    boxes = np.array([[200.0, 150.0, 330.0, 260.0], [60.0, 40.0, 190.0, 200.0], [400.0, 250.0, 560.0, 420.0], [300.5, 100.25, 380.75, 231.0]])
+    idx = np.array([0, 1, 1, 0])
+    cams = np.stack([synth.LM_K.astype(np.float32)] * B)
+    crops = build_crops(torch.from_numpy(img).to(dev), torch.from_numpy(depth).to(dev), idx, boxes, cams)
+
+    cfg = gdrn_base_cfg(mask_attention="mul", device="cuda")
+    cfg.TEST.USE_PNP = True
+    model, _ = build_model_optimizer(cfg)
+    sd = synth.make_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=1234)
+    bn = np.load(os.path.join(golden_dir, "bn_stats_c1.npz"))
+    sd.update({k: bn[k] for k in bn.files})
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    rng = np.random.Generator(np.random.PCG64(3))
+    extents = (rng.random((B, 3)) * 0.2 + 0.05).astype(np.float32)
+    fps = np.stack([synth.ellipsoid_points(tuple(extents[i]), 32, 10 + i) for i in range(B)]).astype(np.float32)
+    t_cams = torch.from_numpy(cams).to(dev)
+    with torch.no_grad():
+        out = model(crops["roi_img"], roi_classes=torch.zeros(B, dtype=torch.long, device=dev), roi_coord_2d=crops["roi_coord_2d"],
+                    roi_cams=t_cams, roi_centers=crops["bbox_center"], roi_whs=crops["roi_wh"], roi_extents=torch.from_numpy(extents).to(dev),
+                    resize_ratios=crops["resize_ratio"], do_loss=False, fps=torch.from_numpy(fps).to(dev))
+    torch.cuda.synchronize()
+    assert all(out[k].is_cuda for k in ("rot", "trans", "mask", "region", "pnp_pose"))
+
+    # stage 1 == its oracle; stage 2 on the oracle-built crops == oracle model (the usual fp32 yardstick is in test_gpu_kernels)
+    oc = [crop_oracle.build_roi(img[idx[i]], depth[idx[i]], cams[i], np.array([0.5 * (boxes[i, 0] + boxes[i, 2]), 0.5 * (boxes[i, 1] + boxes[i, 3])]),
+                                min(max(boxes[i, 2] - boxes[i, 0], boxes[i, 3] - boxes[i, 1], 1) * 1.5, 640) * 1.0) for i in range(B)]
+    roi_img = np.stack([o[0] for o in oc]).astype(np.float32)
+    assert np.abs(crops["roi_img"].cpu().numpy() - roi_img).max() <= 1e-5 * max(1.0, np.abs(roi_img).max())
+    orc = model_oracle.GDRNOracle(32, "mul")
+    orc.load_state_dict(sd, strict=True)
+    orc.eval()
+    with torch.no_grad():
+        oo = orc(crops["roi_img"].cpu(), crops["roi_coord_2d"].cpu(), torch.from_numpy(fps), torch.from_numpy(cams), crops["bbox_center"].cpu(),
+                 crops["roi_wh"].cpu(), crops["resize_ratio"].cpu())
+    for k in ("mask", "coor_x", "coor_y", "coor_z", "region"):
+        assert (out[k].cpu() - oo[k]).abs().max().item() < 5e-3, k
+
+    # stage 3: ADD / ADI / re / te of the network pose against a synthetic ground truth, on device vs the numpy restatement
+    pts = np.stack([synth.ellipsoid_points(tuple(extents[i]), 500, 50 + i) for i in range(B)]).astype(np.float32)
+    R_gt = np.stack([np.linalg.qr(rng.standard_normal((3, 3)))[0] for _ in range(B)]).astype(np.float32)
+    R_gt *= np.sign(np.linalg.det(R_gt))[:, None, None]
+    t_gt = np.stack([rng.random(B) * 0.2 - 0.1, rng.random(B) * 0.2 - 0.1, rng.random(B) + 0.5], 1).astype(np.float32)
+    err = ops.pose_errors(out["rot"], out["trans"], torch.from_numpy(R_gt).to(dev), torch.from_numpy(t_gt).to(dev), torch.from_numpy(pts).to(dev))
+    torch.cuda.synchronize()
+    Re, te_ = out["rot"].cpu().numpy().astype(np.float64), out["trans"].cpu().numpy().astype(np.float64)
+    for i in range(B):
+        want = [teo.add(Re[i], te_[i], R_gt[i].astype(np.float64), t_gt[i].astype(np.float64), pts[i].astype(np.float64)),
+                teo.adi(Re[i], te_[i], R_gt[i].astype(np.float64), t_gt[i].astype(np.float64), pts[i].astype(np.float64)),
+                teo.re(Re[i], R_gt[i].astype(np.float64)), teo.te(te_[i], t_gt[i].astype(np.float64))]
+        got = err[i].cpu().numpy()
+        assert np.allclose(got, want, rtol=1e-6, atol=1e-9), (i, got, want)
