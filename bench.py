@@ -211,7 +211,7 @@ def train_bench(args, rank, world, device, dist):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
-    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=device if dist is None or dist.get_backend() == "nccl" else "cpu")
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
@@ -257,14 +257,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if local_rank < ndev else local_rank % max(ndev, 1)  # (more ranks than GPUs only in the self-test below)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        # RCCL ("nccl" on ROCm) in every real run.  RDPN6D_BENCH_BACKEND=gloo exists only to exercise this multi-process
+        # path on a ONE-GPU box (two ranks sharing device 0 cannot form an RCCL communicator).
+        backend = os.environ.get("RDPN6D_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from rdpn6d_amd import synth
 
@@ -289,7 +297,7 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         barrier()
-    el = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=device if dist is None or dist.get_backend() == "nccl" else "cpu")
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())

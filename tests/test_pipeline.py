@@ -75,3 +75,26 @@ def test_frames_to_pose_errors_on_device(golden_dir):
                 teo.re(Re[i], R_gt[i].astype(np.float64)), teo.te(te_[i], t_gt[i].astype(np.float64))]
         got = err[i].cpu().numpy()
         assert np.allclose(got, want, rtol=1e-6, atol=1e-9), (i, got, want)
+
+
+def test_bench_contract_two_ranks_on_one_gpu():
+    """the driver's multi-GPU launch line (torch.distributed.run, one rank per GPU, barrier + max-over-ranks timing, ONE JSON
+    line from rank 0) exercised with two ranks sharing this box's GPU; RCCL cannot put two ranks on one device, so the
+    rendezvous uses gloo here (RDPN6D_BENCH_BACKEND) - everything else is the code path of a real N-GPU run."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RDPN6D_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8"]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["global_batch"] == 16
+    assert out["value"] > 0 and abs(out["value"] - 16 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-2 * out["value"]
+    assert out["roofline"]["frac"] > 0 and "cpu_baseline" not in out
