@@ -205,10 +205,11 @@ def _pad_vec(v, npad, fill):
 
 
 def pick_ksplit(M, npad, nk):
-    """K-slices for a skinny GEMM (FC layers): enough workgroups to fill 256 CUs, at least 8 K-chunks per slice."""
+    """K-slices for a launch too small to fill the chip (FC layers; every layer at per-image batch sizes): enough
+    workgroups for 256 CUs x 3 resident each, at least 8 K-chunks per slice."""
     blocks = ((M + 63) // 64) * (npad // 64)
-    ks = min(nk // 8, max(1, 512 // blocks))
-    return ks if ks >= 4 else 1
+    ks = min(nk // 8, max(1, 768 // blocks))
+    return ks if ks >= 2 else 1
 
 
 class _Launch:
@@ -273,7 +274,9 @@ class InferencePlan:
         d.act, d.slope = act, slope
         assert w.shape[1] == d.ntaps and w.shape[2] == cin, (name, tuple(w.shape), d.ntaps, cin)
         self.keep += [w, scale, shift]
-        ks = pick_ksplit(self.B * d.Ho * d.Wo, d.Npad, d.ntaps * cin // 16) if (ksplit and not lowp) else 1
+        # split-K whenever the launch would leave most of the chip idle (FC layers always; every layer at small batch -
+        # per-image inference runs 1..15 crops): fp32 kernel, linear output geometry only
+        ks = pick_ksplit(self.B * d.Ho * d.Wo, d.Npad, d.ntaps * cin // 16) if (not lowp and phase is None) else 1
         if ks > 1:
             ws = self.buf("splitk_ws:" + name, int(self.lib.rdpn6d_conv_splitk_ws_floats(ctypes.byref(d), ks)))
             self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_splitk_f32, (ctypes.byref(d), ks, _ptr(ws)), keep=(d,)))

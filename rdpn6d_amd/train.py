@@ -326,7 +326,7 @@ class TrainEngine:
                     wdb = self._mirror(wd)
                     dd.w = _ptr(wdb)
                     return self._launch_conv(nm, dd, (wd, wdb, g_src), lowp=True, out_f32=dx.dtype == torch.float32)
-                return self._launch_conv(nm, dd, wd)
+                return self._launch_conv(nm, dd, wd, ksplit=dd.osy == 1 and dd.ooy == 0 and dd.OH == dd.Ho)  # split-K needs a linear output
 
             if stride == 1:
                 # dgrad weights: dst[c][t][n] = w[n][perm(c)][flipped t]
