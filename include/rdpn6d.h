@@ -95,6 +95,8 @@ void rdpn6d_conv_set_tap_inner(int v);
  * channel strides/offsets are in elements.  Cin % 32 == 0, in_cs % 8 == 0, in_co % 8 == 0.  fp32 accumulation on
  * v_mfma_f32_32x32x16_bf16, one rounding (RNE) on the store. */
 int rdpn6d_conv2d_bf16(const rdpn6d_conv_desc* d, int out_f32, void* stream);
+/* split-K form, as rdpn6d_conv2d_splitk_f32 (same workspace size, linear output geometry) */
+int rdpn6d_conv2d_splitk_bf16(const rdpn6d_conv_desc* d, int out_f32, int ksplit, float* workspace, void* stream);
 void rdpn6d_conv_bf16_force_tile(int bm, int bn);
 int rdpn6d_conv_bf16_tile_for(const rdpn6d_conv_desc* d, int* bm, int* bn); /* 256x128 | 128x128 | 128x64 | 64x128 | 64x64 */
 void rdpn6d_conv_bf16_force_chunk(int row_bytes); /* profiling: 0 = auto, 64 forces 32-channel K-chunks (measured slower) */

@@ -43,6 +43,7 @@ SIGNATURES = {
     "rdpn6d_conv_splitk_ws_floats": (ctypes.c_longlong, [ctypes.POINTER(ConvDesc), _i]),
     "rdpn6d_conv2d_splitk_f32": (_i, [ctypes.POINTER(ConvDesc), _i, _vp, _vp]),
     "rdpn6d_conv2d_bf16": (_i, [ctypes.POINTER(ConvDesc), _i, _vp]),
+    "rdpn6d_conv2d_splitk_bf16": (_i, [ctypes.POINTER(ConvDesc), _i, _i, _vp, _vp]),
     "rdpn6d_conv_bf16_force_tile": (None, [_i, _i]),
     "rdpn6d_conv_bf16_tile_for": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp]),
     "rdpn6d_conv_bf16_force_chunk": (None, [_i]),

@@ -15,6 +15,8 @@ struct ConvBArgs {
     int out_f32;
     unsigned x_bytes, w_bytes;
     unsigned long long dy_pack, dx_pack;
+    int kper;        // split-K: K-chunks per split (blockIdx.y = split); nk when not split
+    float* partial;  // split-K: raw fp32 accumulators [split][M][Npad]; nullptr = fused epilogue
     int vec_out;  // 16-byte aligned output / residual channel slices: coalesced epilogue through LDS
 };
 
@@ -33,6 +35,22 @@ __device__ __forceinline__ void conv_bf16_epilogue(const ConvBArgs& a, f32x16 (&
 {
     const rdpn6d_conv_desc& d = a.d;
     const int frow = lane & 31;
+    if (a.partial) {  // split-K: raw partial sums, reduced (with the epilogue) by conv_bf16_splitk_epilogue_kernel
+        float* part = a.partial + (long long)blockIdx.y * a.M * d.Npad;
+        const int hi2 = lane >> 5;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * (BN / WN) + j * 32 + frow;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const long long m = m0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi2;
+                    if (m < a.M) part[m * d.Npad + n] = acc[i][j][e];
+                }
+        }
+        return;
+    }
     // ---- fused epilogue (fp32 math, one rounding on the store)
     const int hi = lane >> 5;
     const bf16_t* resb = reinterpret_cast<const bf16_t*>(d.res);

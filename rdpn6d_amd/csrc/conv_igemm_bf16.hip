@@ -100,8 +100,11 @@ __global__ __launch_bounds__(64 * WM * WN, NST == 2 ? 2 : 1) void conv_igemm_bf1
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrc, (lds_ptr_t)dst, 16, (int)(w_off[i] + wk), 0, 0, 0);
         }
     };
-    // K order: channel-chunk major, taps innermost (see conv_igemm.hip)
-    int ld_tap = 0, ld_cc = 0, ld_left = a.nk - 1;
+    // K order: channel-chunk major, taps innermost (see conv_igemm.hip); split-K: this workgroup's slice of the chunks
+    const int k_begin = (int)blockIdx.y * a.kper;
+    const int nk = min(a.kper, a.nk - k_begin);
+    int ld_cc = k_begin / d.ntaps;
+    int ld_tap = k_begin - ld_cc * d.ntaps, ld_left = nk - 1;
     auto next_chunk = [](int& tap, int& cc, int& left, const int ntaps) {
         const int go = left > 0 ? 1 : 0;
         left -= go;
@@ -154,7 +157,6 @@ __global__ __launch_bounds__(64 * WM * WN, NST == 2 ? 2 : 1) void conv_igemm_bf1
                                                                          acc[i][jn], 0, 0, 0);
     };
 
-    const int nk = a.nk;
     u32x4 fa0[TM][NJ], fb0[TN][NJ], fa1[TM][NJ], fb1[TN][NJ];
     if constexpr (NST == 2) {
         stage_chunk(ld_tap, ld_cc, 0);
@@ -228,6 +230,27 @@ __global__ __launch_bounds__(64 * WM * WN, NST == 2 ? 2 : 1) void conv_igemm_bf1
     conv_bf16_epilogue<BM, BN, WM, WN, TM, TN>(a, acc, smem, m0, n0, wave, lane, wm, wn);
 }
 
+// split-K second pass: fixed-order sum of the partial accumulators + the epilogue (output / residual bf16, or fp32)
+__global__ void conv_bf16_splitk_epilogue_kernel(const float* __restrict__ partial, int nsplit, long long M, rdpn6d_conv_desc d,
+                                                 int out_f32)
+{
+    const long long total = M * d.N;
+    const bf16_t* resb = reinterpret_cast<const bf16_t*>(d.res);
+    bf16_t* yb = reinterpret_cast<bf16_t*>(d.y);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long m = i / d.N;
+        const int n = (int)(i - m * d.N);
+        float v = 0.f;
+        for (int s = 0; s < nsplit; ++s) v += partial[((long long)s * M + m) * d.Npad + n];
+        v = v * (d.scale ? d.scale[n] : 1.f) + (d.shift ? d.shift[n] : 0.f);
+        if (d.res) v += out_f32 ? d.res[m * d.res_cs + d.res_co + n] : bf2f(resb[m * d.res_cs + d.res_co + n]);
+        if (d.act == 1) v = v > 0.f ? v : 0.f;
+        else if (d.act == 2) v = v > 0.f ? v : v * d.slope;
+        if (out_f32) d.y[m * d.out_cs + d.out_co + n] = v;
+        else yb[m * d.out_cs + d.out_co + n] = f2bf(v);
+    }
+}
+
 static int g_bforce_bm = 0, g_bforce_bn = 0, g_bforce_rb = 0;
 extern "C" void rdpn6d_conv_bf16_force_chunk(int row_bytes) { g_bforce_rb = row_bytes; }  // 0 = auto, 64 | 128 (profiling)
 extern "C" void rdpn6d_conv_bf16_force_tile(int bm, int bn) { g_bforce_bm = bm; g_bforce_bn = bn; }
@@ -255,7 +278,7 @@ extern "C" int rdpn6d_conv_bf16_tile_for(const rdpn6d_conv_desc* d, int* bm, int
 }
 
 template <int BM, int BN, int RB, int WM, int WN, int NST>
-static int conv_bf16_launch_one(const ConvBArgs& a, hipStream_t s)
+static int conv_bf16_launch_one(const ConvBArgs& a, int nsplit, hipStream_t s)
 {
     constexpr int lds_stage = NST * (BM + BN) * RB;
     constexpr int lds_epi = WM * WN * 32 * (BN / WN + 8) * 4;  // per-wave transpose slices of the coalesced epilogue
@@ -268,23 +291,37 @@ static int conv_bf16_launch_one(const ConvBArgs& a, hipStream_t s)
             configured = true;
         }
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(a.mtiles * a.ntiles)), dim3(64 * WM * WN), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(a.mtiles * a.ntiles), (unsigned)nsplit), dim3(64 * WM * WN), lds, s, a);
     return RDPN6D_OK;
 }
 
 template <int RB>
-static int conv_bf16_launch(const ConvBArgs& a, int bm, int bn, hipStream_t s)
+static int conv_bf16_launch(const ConvBArgs& a, int bm, int bn, int nsplit, hipStream_t s)
 {
     if constexpr (RB == 128) {
-        if (bm == 256) return conv_bf16_launch_one<256, 128, RB, 4, 2, 3>(a, s);
+        if (bm == 256) return conv_bf16_launch_one<256, 128, RB, 4, 2, 3>(a, nsplit, s);
     }
-    if (bm == 128 && bn == 128) return conv_bf16_launch_one<128, 128, RB, 2, 2, 2>(a, s);
-    if (bm == 128 && bn == 64) return conv_bf16_launch_one<128, 64, RB, 2, 2, 2>(a, s);
-    if (bm == 64 && bn == 128) return conv_bf16_launch_one<64, 128, RB, 2, 2, 2>(a, s);
-    return conv_bf16_launch_one<64, 64, RB, 2, 2, 2>(a, s);
+    if (bm == 128 && bn == 128) return conv_bf16_launch_one<128, 128, RB, 2, 2, 2>(a, nsplit, s);
+    if (bm == 128 && bn == 64) return conv_bf16_launch_one<128, 64, RB, 2, 2, 2>(a, nsplit, s);
+    if (bm == 64 && bn == 128) return conv_bf16_launch_one<64, 128, RB, 2, 2, 2>(a, nsplit, s);
+    return conv_bf16_launch_one<64, 64, RB, 2, 2, 2>(a, nsplit, s);
 }
 
+static int conv2d_bf16_impl(const rdpn6d_conv_desc* d, int out_f32, int ksplit, float* workspace, void* stream);
+
 extern "C" int rdpn6d_conv2d_bf16(const rdpn6d_conv_desc* d, int out_f32, void* stream)
+{
+    return conv2d_bf16_impl(d, out_f32, 1, nullptr, stream);
+}
+
+// split-K form (see rdpn6d_conv2d_splitk_f32): workspace of rdpn6d_conv_splitk_ws_floats(d, ksplit) floats, linear output
+extern "C" int rdpn6d_conv2d_splitk_bf16(const rdpn6d_conv_desc* d, int out_f32, int ksplit, float* workspace, void* stream)
+{
+    RD_REQUIRE(ksplit >= 1 && (ksplit == 1 || workspace), "split-K needs a workspace");
+    return conv2d_bf16_impl(d, out_f32, ksplit, workspace, stream);
+}
+
+static int conv2d_bf16_impl(const rdpn6d_conv_desc* d, int out_f32, int ksplit, float* workspace, void* stream)
 {
     RD_REQUIRE(d && d->x && d->w && d->y, "null pointer");
     RD_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0, "empty tensor");
@@ -326,8 +363,24 @@ extern "C" int rdpn6d_conv2d_bf16(const rdpn6d_conv_desc* d, int out_f32, void* 
     conv_bf16_pick_tile(d, a.M, rb, &bm, &bn);
     a.mtiles = rd_cdiv(a.M, bm);
     a.ntiles = d->Npad / bn;
-    const int rc = rb == 128 ? conv_bf16_launch<128>(a, bm, bn, s) : conv_bf16_launch<64>(a, bm, bn, s);
+    a.kper = a.nk;
+    a.partial = nullptr;
+    int nsplit = 1;
+    if (ksplit > 1 && bm != 256) {
+        RD_REQUIRE(a.linear_out, "split-K needs a linear output geometry");
+        a.kper = rd_cdiv(a.nk, ksplit);
+        nsplit = rd_cdiv(a.nk, a.kper);
+        if (nsplit > 1) a.partial = workspace;
+        else a.kper = a.nk;
+    }
+    const int rc = rb == 128 ? conv_bf16_launch<128>(a, bm, bn, nsplit, s) : conv_bf16_launch<64>(a, bm, bn, nsplit, s);
     if (rc != RDPN6D_OK) return rc;
     RD_LAUNCH_CHECK();
+    if (nsplit > 1) {
+        const long long total = a.M * d->N;
+        const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        hipLaunchKernelGGL(conv_bf16_splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, s, workspace, nsplit, a.M, *d, a.out_f32);
+        RD_LAUNCH_CHECK();
+    }
     return RDPN6D_OK;
 }

@@ -275,11 +275,16 @@ class InferencePlan:
         assert w.shape[1] == d.ntaps and w.shape[2] == cin, (name, tuple(w.shape), d.ntaps, cin)
         self.keep += [w, scale, shift]
         # split-K whenever the launch would leave most of the chip idle (FC layers always; every layer at small batch -
-        # per-image inference runs 1..15 crops): fp32 kernel, linear output geometry only
-        ks = pick_ksplit(self.B * d.Ho * d.Wo, d.Npad, d.ntaps * cin // 16) if (not lowp and phase is None) else 1
+        # per-image inference runs 1..15 crops): linear output geometry only
+        nk = d.ntaps * cin // (64 if (lowp and cin % 64 == 0) else (32 if lowp else 16))  # K-chunks of the kernel in use
+        ks = pick_ksplit(self.B * d.Ho * d.Wo, d.Npad, nk) if phase is None else 1
         if ks > 1:
             ws = self.buf("splitk_ws:" + name, int(self.lib.rdpn6d_conv_splitk_ws_floats(ctypes.byref(d), ks)))
-            self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_splitk_f32, (ctypes.byref(d), ks, _ptr(ws)), keep=(d,)))
+            if lowp:
+                self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_splitk_bf16, (ctypes.byref(d), 1 if out_f32 else 0, ks, _ptr(ws)),
+                                             keep=(d,)))
+            else:
+                self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_splitk_f32, (ctypes.byref(d), ks, _ptr(ws)), keep=(d,)))
         elif lowp:
             assert w.dtype == torch.bfloat16, name
             self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_bf16, (ctypes.byref(d), 1 if out_f32 else 0), keep=(d,)))

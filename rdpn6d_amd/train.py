@@ -144,9 +144,16 @@ class TrainEngine:
 
         if lowp:
             of = 1 if out_f32 else 0
+            nkb = d.ntaps * d.Cin // (64 if d.Cin % 64 == 0 else 32)
+            ksb = pick_ksplit(d.B * d.Ho * d.Wo, d.Npad, nkb) if (ksplit and d.osy == 1 and d.ooy == 0 and d.OH == d.Ho) else 1
+            if ksb > 1:
+                wsb = self.buf("splitk_ws:" + name, int(lib.rdpn6d_conv_splitk_ws_floats(ctypes.byref(d), ksb)))
 
-            def run():
-                _lib.check(lib.rdpn6d_conv2d_bf16(ctypes.byref(d), of, self.st()), name)
+                def run():
+                    _lib.check(lib.rdpn6d_conv2d_splitk_bf16(ctypes.byref(d), of, ksb, _ptr(wsb), self.st()), name)
+            else:
+                def run():
+                    _lib.check(lib.rdpn6d_conv2d_bf16(ctypes.byref(d), of, self.st()), name)
 
             run.keep = (d, keep)
             return run
@@ -249,7 +256,7 @@ class TrainEngine:
             wfb = self._mirror(wf)
             d = self._conv_desc(xb, xhw, xb_cs, xb_co, cin_pad, wfb, y, yhw, out_cs, out_co, cout, taps, stride=stride, shift=bvec,
                                 act=act_out or 0, slope=slope)
-            self.fwd.append(self._launch_conv(name, d, (wf, wfb, bvec, xb), lowp=True, out_f32=y.dtype == torch.float32))
+            self.fwd.append(self._launch_conv(name, d, (wf, wfb, bvec, xb), lowp=True, out_f32=y.dtype == torch.float32, ksplit=True))
         else:
             d = self._conv_desc(x, xhw, in_cs, in_co, cin_pad, wf, y, yhw, out_cs, out_co, cout, taps, stride=stride, shift=bvec,
                                 act=act_out or 0, slope=slope)
@@ -325,7 +332,7 @@ class TrainEngine:
                 if lowp:
                     wdb = self._mirror(wd)
                     dd.w = _ptr(wdb)
-                    return self._launch_conv(nm, dd, (wd, wdb, g_src), lowp=True, out_f32=dx.dtype == torch.float32)
+                    return self._launch_conv(nm, dd, (wd, wdb, g_src), lowp=True, out_f32=dx.dtype == torch.float32, ksplit=True)
                 return self._launch_conv(nm, dd, wd, ksplit=dd.osy == 1 and dd.ooy == 0 and dd.OH == dd.Ho)  # split-K needs a linear output
 
             if stride == 1:

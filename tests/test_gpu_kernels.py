@@ -780,3 +780,44 @@ def test_other_resnet_trunks_vs_oracle(dev, layers, R):
     et = _rel(o["trans"].cpu().numpy().astype(np.float64), o64["trans"].numpy())
     print(f"resnet{layers} R={R}: arg-max flips vs fp64 {flips}, pose rel err R {er:.2e} t {et:.2e}")
     assert flips <= 8 and er < (2e-3 if flips == 0 else 2e-2) and et < (2e-3 if flips == 0 else 2e-2)
+
+
+@pytest.mark.parametrize("case", [(2, 8, 512, 512, 3, True, 6), (1, 16, 256, 256, 3, False, 4), (3, 8, 96, 128, 1, False, 2)])
+def test_conv_bf16_splitk_matches_fused(dev, case):
+    """split-K form of the bf16 kernel (fp32 partials + fixed-order reduce + epilogue) vs the single-pass kernel: bf16 and fp32
+    outputs agree to fp32 summation order (one bf16 ulp on rounding ties)."""
+    import ctypes
+    from rdpn6d_amd import _lib
+    from rdpn6d_amd.gdrn import _pad_to, _pad_vec, _ptr, pack_conv_weight
+
+    lib = _lib.load()
+    B, H, Cin, Cout, k, use_res, ks = case
+    g = torch.Generator().manual_seed(sum(case[:5]))
+    x = torch.randn(B, H, H, Cin, generator=g).to(dev).bfloat16()
+    w = pack_conv_weight((torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).to(dev), cin_pad=_pad_to(Cin, 32)).bfloat16()
+    sc = _pad_vec((torch.rand(Cout, generator=g) + 0.5).to(dev), w.shape[0], 1.0)
+    sh = _pad_vec(torch.randn(Cout, generator=g).to(dev), w.shape[0], 0.0)
+    res16 = torch.randn(B, H, H, Cout, generator=g).to(dev).bfloat16() if use_res else None
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    pad = k // 2
+    for out_f32 in (0, 1):
+        outs = []
+        res = (res16.float() if out_f32 else res16) if use_res else None
+        for split in (1, ks):
+            y = torch.zeros(B, H, H, Cout, device=dev, dtype=torch.float32 if out_f32 else torch.bfloat16)
+            d = _lib.ConvDesc()
+            d.x, d.w, d.scale, d.shift, d.res, d.y = _ptr(x), _ptr(w), _ptr(sc), _ptr(sh), _ptr(res), _ptr(y)
+            d.B, d.H, d.W, d.Cin, d.in_cs, d.Ho, d.Wo, d.stride = B, H, H, Cin, Cin, H, H, 1
+            taps = [(ky - pad, kx - pad) for ky in range(k) for kx in range(k)]
+            d.ntaps = len(taps)
+            for t, (dy, dx) in enumerate(taps):
+                d.dy[t], d.dx[t] = dy, dx
+            d.N, d.Npad, d.OH, d.OW, d.osy, d.osx = Cout, w.shape[0], H, H, 1, 1
+            d.out_cs, d.res_cs, d.act = Cout, Cout, 1
+            ws = torch.empty(max(1, int(lib.rdpn6d_conv_splitk_ws_floats(ctypes.byref(d), split))), device=dev)
+            _lib.check(lib.rdpn6d_conv2d_splitk_bf16(ctypes.byref(d), out_f32, split, _ptr(ws), st))
+            torch.cuda.synchronize()
+            outs.append(y.float())
+        tol = 1e-5 if out_f32 else 2.0 ** -7
+        assert ((outs[0] - outs[1]).abs() <= tol * outs[0].abs() + 1e-5).all(), (case, out_f32)
+        assert outs[0].abs().max().item() > 0.1

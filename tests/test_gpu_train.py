@@ -217,7 +217,7 @@ def test_amp_training_step_vs_autocast_yardstick(golden_dir):
     print(f"median relative gradient error vs fp64 over {len(eh)} tensors: HIP-AMP {med_h:.3e} | autocast oracle {med_a:.3e};"
           f" worst: HIP-AMP {max(eh):.3e} | autocast {max(ea):.3e}")
     assert med_h <= 1.1 * med_a and max(eh) <= 1.5 * max(ea)
-    assert e_hip <= 5e-3 * tot64 and e_ac <= 5e-3 * tot64  # both within 0.5 % of the exact total loss (a scalar: one noise draw)
+    assert e_hip <= 1e-2 * tot64 and e_ac <= 1e-2 * tot64  # both within 1 % of the exact total loss (a scalar: one noise draw)
 
 
 def test_amp_reference_loop_loss_goes_down(golden_dir):
