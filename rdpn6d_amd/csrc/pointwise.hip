@@ -248,28 +248,30 @@ extern "C" int rdpn6d_xyz_subsample_f32(const float* x, int B, int xc, int R, in
 // ------------------------------------------------------------------------------------------------
 // Global max over the HW pixels of channels [0,C) and broadcast into channels [C,2C) of the same
 // NHWC buffer (md_pointnet's adaptive_max_pool2d + adaptive_avg_pool2d-broadcast + cat).
-// grid = (C/64, B); block = 256 = 4 pixel lanes x 64 channels (256-byte coalesced rows).
-__global__ __launch_bounds__(256) void global_max_concat_kernel(float* __restrict__ buf, int HW, int C, int cs)
+// grid = (C/64, B); block = 1024 = 16 pixel lanes x 64 channels (256-byte coalesced rows).
+__global__ __launch_bounds__(1024) void global_max_concat_kernel(float* __restrict__ buf, int HW, int C, int cs)
 {
-    __shared__ float s_m[4][64];
+    __shared__ float s_m[16][64];
     const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
     float* base = buf + (long long)b * HW * cs;
     float m = -FLT_MAX;
-    for (int p = pl; p < HW; p += 4) {
+    for (int p = pl; p < HW; p += 16) {
         const float v = base[(long long)p * cs + c];
         m = v > m ? v : m;
     }
     s_m[pl][threadIdx.x & 63] = m;
     __syncthreads();
     const int cl = threadIdx.x & 63;
-    m = fmaxf(fmaxf(s_m[0][cl], s_m[1][cl]), fmaxf(s_m[2][cl], s_m[3][cl]));
-    for (int p = pl; p < HW; p += 4) base[(long long)p * cs + C + c] = m;
+    m = s_m[0][cl];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) m = fmaxf(m, s_m[k][cl]);
+    for (int p = pl; p < HW; p += 16) base[(long long)p * cs + C + c] = m;
 }
 
 extern "C" int rdpn6d_global_max_concat_f32(float* buf, int B, int HW, int C, int cs, void* stream)
 {
     RD_REQUIRE(buf && B > 0 && HW > 0 && C > 0 && C % 64 == 0 && 2 * C <= cs, "shape");
-    hipLaunchKernelGGL(global_max_concat_kernel, dim3(C / 64, B), dim3(256), 0, (hipStream_t)stream, buf, HW, C, cs);
+    hipLaunchKernelGGL(global_max_concat_kernel, dim3(C / 64, B), dim3(1024), 0, (hipStream_t)stream, buf, HW, C, cs);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
 }
@@ -284,14 +286,15 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
-__global__ __launch_bounds__(256) void groupnorm4_relu_kernel(float* __restrict__ x, int HW, int C,
-                                                             const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta)
+#define GN_THREADS 1024  // one workgroup per sample: 1024 lanes keep a single crop (per-image inference) short
+__global__ __launch_bounds__(GN_THREADS) void groupnorm4_relu_kernel(float* __restrict__ x, int HW, int C,
+                                                                    const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta)
 {
     // thread t: group g = t % G (G = C/4 <= 64), pixel lane pl = t / G
     const int G = C / 4;
-    const int PL = 256 / G;
-    __shared__ float s_part[256];
+    const int PL = GN_THREADS / G;
+    __shared__ float s_part[GN_THREADS];
     __shared__ float s_mean[64], s_rstd[64];
     const int g = threadIdx.x % G, pl = threadIdx.x / G;
     float* base = x + (long long)blockIdx.x * HW * C + g * 4;
@@ -346,7 +349,7 @@ extern "C" int rdpn6d_groupnorm_relu_f32(float* x, int B, int HW, int C, int G, 
 {
     RD_REQUIRE(x && gamma && beta && B > 0 && HW > 0, "null/shape");
     RD_REQUIRE(C == 4 * G && G <= 64 && 256 % G == 0, "only C/G == 4 with G | 256 is implemented (GroupNorm(32,128))");
-    hipLaunchKernelGGL(groupnorm4_relu_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, x, HW, C, gamma, beta);
+    hipLaunchKernelGGL(groupnorm4_relu_kernel, dim3(B), dim3(GN_THREADS), 0, (hipStream_t)stream, x, HW, C, gamma, beta);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
 }
