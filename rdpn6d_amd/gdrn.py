@@ -725,10 +725,34 @@ class _HipBackward(torch.autograd.Function):
         return (None, None) + (None,) * len(gouts)
 
 
+def _check_supported(cfg):
+    """Config switches the reference accepts but this hot path does not implement raise here, loudly, instead of building a
+    silently different network (none of them is set by a shipped RGB-D config)."""
+    m = cfg.MODEL.CDPN
+    r, b, p = m.ROT_HEAD, m.BACKBONE, m.PNP_NET
+    want = [
+        (m.get("USE_MTL", False) is False, "MODEL.CDPN.USE_MTL"),
+        (int(b.get("INPUT_CHANNEL", 3)) == 3, "BACKBONE.INPUT_CHANNEL != 3"),
+        (not r.get("ROT_CONCAT", False), "ROT_HEAD.ROT_CONCAT"),
+        (not (r.get("ROT_CLASS_AWARE", False) or r.get("MASK_CLASS_AWARE", False) or r.get("REGION_CLASS_AWARE", False)),
+         "class-aware head outputs (ROT_/MASK_/REGION_CLASS_AWARE)"),
+        (r.get("NORM", "BN") == "BN", "ROT_HEAD.NORM != BN"),
+        (int(r.get("CONV_KERNEL_SIZE", 3)) == 3 and int(r.get("OUT_CONV_KERNEL_SIZE", 1)) == 1, "head kernel sizes other than 3 / 1"),
+        (int(r.get("NUM_LAYERS", 3)) >= 1 and int(r.get("NUM_FILTERS", 256)) % 64 == 0, "ROT_HEAD.NUM_FILTERS must be a multiple of 64"),
+        (p.get("TRANS_WITH_BOX_INFO", "none") == "none", "PNP_NET.TRANS_WITH_BOX_INFO"),
+        (dict(p.PNP_HEAD_CFG).get("norm", "GN") == "GN" and int(dict(p.PNP_HEAD_CFG).get("num_gn_groups", 32)) == 32
+         and float(dict(p.PNP_HEAD_CFG).get("drop_prob", 0.0)) == 0.0, "PNP_HEAD_CFG other than GN(32), drop_prob 0"),
+    ]
+    for ok, what in want:
+        if not ok:
+            raise NotImplementedError(f"rdpn6d_amd: {what} is not implemented on the HIP path")
+
+
 def build_model_optimizer(cfg):
     """Factory with the reference's signature and side effects (GDRN.py:662-855)."""
     m = cfg.MODEL.CDPN
     backbone_cfg, r_head_cfg, t_head_cfg, pnp_net_cfg = m.BACKBONE, m.ROT_HEAD, m.TRANS_HEAD, m.PNP_NET
+    _check_supported(cfg)
     if "resnet" not in backbone_cfg.ARCH:
         raise ValueError(f"unknown backbone arch {backbone_cfg.ARCH}")
     params_lr_list = []

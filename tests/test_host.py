@@ -103,3 +103,20 @@ def test_other_resnet_trunks_match_the_oracle_key_for_key(layers, nparams_trunk_
     bad.MODEL.CDPN.BACKBONE.NUM_LAYERS = 35
     with pytest.raises(ValueError):
         build_model_optimizer(bad)
+
+
+@pytest.mark.parametrize("path,value", [
+    ("MODEL.CDPN.ROT_HEAD.ROT_CLASS_AWARE", True), ("MODEL.CDPN.ROT_HEAD.REGION_CLASS_AWARE", True),
+    ("MODEL.CDPN.ROT_HEAD.ROT_CONCAT", True), ("MODEL.CDPN.ROT_HEAD.NORM", "GN"), ("MODEL.CDPN.BACKBONE.INPUT_CHANNEL", 4),
+    ("MODEL.CDPN.PNP_NET.TRANS_WITH_BOX_INFO", "ltrb"), ("MODEL.CDPN.USE_MTL", True), ("MODEL.CDPN.TRANS_HEAD.ENABLED", True),
+])
+def test_unsupported_switches_fail_loudly(path, value):
+    """switches the reference accepts but the HIP path does not implement must not build a silently different network"""
+    cfg = gdrn_base_cfg(device="cpu")
+    node = cfg
+    keys = path.split(".")
+    for k in keys[:-1]:
+        node = node[k]
+    node[keys[-1]] = value
+    with pytest.raises(NotImplementedError):
+        build_model_optimizer(cfg)
