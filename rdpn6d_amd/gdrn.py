@@ -753,6 +753,16 @@ def build_model_optimizer(cfg):
     m = cfg.MODEL.CDPN
     backbone_cfg, r_head_cfg, t_head_cfg, pnp_net_cfg = m.BACKBONE, m.ROT_HEAD, m.TRANS_HEAD, m.PNP_NET
     _check_supported(cfg)
+    if "BASE_LR" not in cfg.SOLVER:
+        # main_gdrn.py:63-74 derives these from OPTIMIZER_CFG before it calls the factory; do the same when handed a raw config
+        ocfg = cfg.SOLVER.OPTIMIZER_CFG
+        if isinstance(ocfg, str):
+            ocfg = eval(ocfg)  # noqa: S307 - the reference's own convention for string-typed optimizer configs
+            cfg.SOLVER.OPTIMIZER_CFG = ocfg
+        cfg.SOLVER.OPTIMIZER_NAME = ocfg["type"]
+        cfg.SOLVER.BASE_LR = ocfg["lr"]
+        cfg.SOLVER.MOMENTUM = ocfg.get("momentum", 0.9)
+        cfg.SOLVER.WEIGHT_DECAY = ocfg.get("weight_decay", 1e-4)
     if "resnet" not in backbone_cfg.ARCH:
         raise ValueError(f"unknown backbone arch {backbone_cfg.ARCH}")
     params_lr_list = []

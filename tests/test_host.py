@@ -120,3 +120,28 @@ def test_unsupported_switches_fail_loudly(path, value):
     node[keys[-1]] = value
     with pytest.raises(NotImplementedError):
         build_model_optimizer(cfg)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/configs/gdrn"), reason="needs the reference checkout (build container only)")
+def test_every_shipped_rgbd_config_builds_through_the_factory():
+    """all model configs under configs/gdrn (138: K = 32 / 64, MASK_ATTENTION mul / none, 30 with SOLVER.AMP) load unchanged and
+    build: same 305 state_dict keys, Ranger with three parameter groups.  BASE_LR is derived from OPTIMIZER_CFG the way
+    main_gdrn.py:63-74 does before it calls the factory."""
+    import glob
+
+    n = amp = k64 = 0
+    for f in sorted(glob.glob("/root/reference/configs/gdrn/**/*.py", recursive=True)):
+        try:
+            cfg = Config.fromfile(f)
+        except ModuleNotFoundError:
+            continue  # tlessSO/icp.py imports mmcv at module level
+        if "MODEL" not in cfg:
+            continue  # empty placeholder files
+        cfg.MODEL.DEVICE = "cpu"
+        model, opt = build_model_optimizer(cfg)
+        assert len(model.state_dict()) == 305 and type(opt).__name__ == "Ranger" and len(opt.param_groups) == 3, f
+        assert float(cfg.SOLVER.BASE_LR) == float(cfg.SOLVER.OPTIMIZER_CFG["lr"])
+        n += 1
+        amp += bool(cfg.SOLVER.AMP.ENABLED)
+        k64 += int(cfg.MODEL.CDPN.ROT_HEAD.NUM_REGIONS) == 64
+    assert n == 138 and amp == 30 and k64 == 10
