@@ -254,6 +254,17 @@ int rdpn6d_pose_train_f32(const float* rt, int rt_stride, const float* roi_cams,
                           const float* gt_trans_ratio, const float* points, int npts, int B, int is_allo, float pm_lw,
                           int pm_norm_by_extent, float centroid_lw, float z_lw, float* rot, float* trans, float* d_rt,
                           float* losses, float* scratch, void* stream);
+/* Same with PNP_NET.PM_LOSS_SYM (losses/pm_loss.py:97-99 -> core/utils/pose_utils.py:430-482, which the reference runs on
+ * the host with a device->host copy of every predicted rotation): sym_rots [B][ksym][9] holds each crop's model-to-model
+ * symmetry rotations, sym_counts[b] <= ksym how many are valid (0 = not symmetric); per crop the target becomes the
+ * candidate among {Rgt, Rgt*S_k} closest (rotation error, first best wins) to the predicted rotation.  gt_rot_used
+ * [B][9] (optional) receives the chosen targets. */
+int rdpn6d_pose_train_sym_f32(const float* rt, int rt_stride, const float* roi_cams, const float* roi_centers,
+                              const float* roi_whs, const float* resize_ratios, const float* roi_extents,
+                              const float* gt_rot, const float* gt_trans_ratio, const float* points, int npts, int B,
+                              int is_allo, float pm_lw, int pm_norm_by_extent, float centroid_lw, float z_lw,
+                              const float* sym_rots, const int* sym_counts, int ksym, float* gt_rot_used, float* rot,
+                              float* trans, float* d_rt, float* losses, float* scratch, void* stream);
 /* Fused multi-tensor Ranger step over flat buffers (replaces lib/torch_utils/solver/ranger.py:100-200).
  * work = array of {int64 off; int32 len; int32 row} runs (row = index of the centralisation mean, -1 = none);
  * row_off/row_len describe the rows whose gradient mean is subtracted (gradient centralisation);

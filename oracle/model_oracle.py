@@ -292,9 +292,36 @@ class GDRNOracle(nn.Module):
 
 
 # --------------------------------------------------------------------------------------- losses
-def gdrn_losses(out, gt, roi_extents):
+def rot_error_deg(r_est, r_gt):
+    """Rotation error in degrees (lib/pysixd/pose_error.py:400-415): acos of the clamped (trace(R_est R_gt^T) - 1) / 2."""
+    tr = float(np.trace(np.asarray(r_est) @ np.asarray(r_gt).T))
+    tr = min(tr, 3.0)
+    return float(np.rad2deg(np.arccos(min(1.0, max(-1.0, 0.5 * (tr - 1.0))))))
+
+
+def closest_sym_rots(pred_rots, gt_rots, sym_infos):
+    """PM_LOSS_SYM target choice (core/utils/pose_utils.py:430-482): per sample, among R_gt and R_gt @ S_k (S_k the
+    model-to-model symmetry rotations, None / empty = not symmetric) the one with the smallest rotation error to the
+    detached prediction; a later candidate replaces the incumbent only when strictly better."""
+    pr = pred_rots.detach().cpu().numpy()
+    out = gt_rots.detach().cpu().numpy().copy()
+    for i, sym in enumerate(sym_infos):
+        if sym is None:
+            continue
+        sym = np.asarray(sym.cpu().numpy() if isinstance(sym, torch.Tensor) else sym).reshape(-1, 3, 3)
+        g0 = out[i].copy()
+        best = rot_error_deg(pr[i], g0)
+        for k in range(sym.shape[0]):
+            cand = g0 @ sym[k]
+            e = rot_error_deg(pr[i], cand)
+            if e < best:
+                best, out[i] = e, cand
+    return torch.as_tensor(out, dtype=gt_rots.dtype, device=gt_rots.device)
+
+
+def gdrn_losses(out, gt, roi_extents, sym_infos=None):
     """Active losses of the shipped configs (GDRN.py:411-424,452-454,470-483,529-531,552-554;
-    pm_loss.py:102-114 with PM_R_ONLY, PM_NORM_BY_EXTENT, L1, no symmetry)."""
+    pm_loss.py:97-114 with PM_R_ONLY, PM_NORM_BY_EXTENT, L1; sym_infos != None = PM_LOSS_SYM)."""
     mv = gt["roi_mask_visib"]
     denom = mv.sum().float().clamp(min=1.0)
     L = {}
@@ -307,7 +334,8 @@ def gdrn_losses(out, gt, roi_extents):
     pts = gt["roi_points"]
     w = 1.0 / roi_extents.max(1, keepdim=True)[0]
     pe = torch.bmm(pts, out["rot"].transpose(1, 2))
-    pg = torch.bmm(pts, gt["ego_rot"].transpose(1, 2))
+    gt_rot = gt["ego_rot"] if sym_infos is None else closest_sym_rots(out["rot"], gt["ego_rot"], sym_infos)
+    pg = torch.bmm(pts, gt_rot.transpose(1, 2))
     L["loss_PM_R"] = 3 * F.l1_loss(w[:, :, None] * pe, w[:, :, None] * pg, reduction="mean")
     L["loss_centroid"] = F.l1_loss(out["pred_t_"][:, :2], gt["roi_trans_ratio"][:, :2], reduction="mean")
     L["loss_z"] = F.l1_loss(out["pred_t_"][:, 2], gt["roi_trans_ratio"][:, 2], reduction="mean")

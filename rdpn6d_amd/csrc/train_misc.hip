@@ -501,10 +501,12 @@ __global__ __launch_bounds__(256) void pose_train_kernel(const float* __restrict
                                                          const float* __restrict__ gt_rot, const float* __restrict__ gt_ratio,
                                                          const float* __restrict__ points, int npts, int B, int is_allo,
                                                          float pm_lw, int pm_norm_by_extent, float centroid_lw, float z_lw,
+                                                         const float* __restrict__ sym_rots, const int* __restrict__ sym_counts,
+                                                         int ksym, float* __restrict__ gt_rot_used,
                                                          float* __restrict__ rot, float* __restrict__ trans,
                                                          float* __restrict__ d_rt, float* __restrict__ losses_part)
 {
-    __shared__ float s_R[9], s_G[4][10];
+    __shared__ float s_R[9], s_Rg[9], s_G[4][10];
     __shared__ Dual9 s_RD[9];
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* p = rt + (long long)b * rt_stride;
@@ -550,10 +552,40 @@ __global__ __launch_bounds__(256) void pose_train_kernel(const float* __restrict
             for (int i = 0; i < 9; ++i) R[i] = Ra[i];
         }
         for (int i = 0; i < 9; ++i) { s_RD[i] = R[i]; s_R[i] = R[i].v; rot[b * 9 + i] = R[i].v; }
+        // PM_LOSS_SYM (pm_loss.py:97-99 -> pose_utils.py:430-454): among Rgt and Rgt*S_k keep the one with the smallest
+        // rotation error to the (detached) prediction.  re = acos(clamp((tr(R Rg^T) - 1) / 2)) is decreasing in the clamped
+        // cosine, so the strict '<' on the angle is a strict '>' on the cosine; the first best candidate wins.
+        const float* G0 = gt_rot + b * 9;
+        float sel[9];
+        for (int i = 0; i < 9; ++i) sel[i] = G0[i];
+        const int ns = (sym_rots && sym_counts) ? min(sym_counts[b], ksym) : 0;
+        if (ns > 0) {
+            float tr = 0.f;
+            for (int i = 0; i < 9; ++i) tr += R[i].v * G0[i];
+            float best = fminf(1.0f, fmaxf(-1.0f, 0.5f * (fminf(tr, 3.0f) - 1.0f)));
+            for (int k = 0; k < ns; ++k) {
+                const float* S = sym_rots + ((long long)b * ksym + k) * 9;
+                float c[9];
+                tr = 0.f;
+                for (int i = 0; i < 3; ++i)
+                    for (int j = 0; j < 3; ++j) {
+                        c[i * 3 + j] = G0[i * 3] * S[j] + G0[i * 3 + 1] * S[3 + j] + G0[i * 3 + 2] * S[6 + j];
+                        tr += R[i * 3 + j].v * c[i * 3 + j];
+                    }
+                const float cs = fminf(1.0f, fmaxf(-1.0f, 0.5f * (fminf(tr, 3.0f) - 1.0f)));
+                if (cs > best) {
+                    best = cs;
+                    for (int i = 0; i < 9; ++i) sel[i] = c[i];
+                }
+            }
+        }
+        for (int i = 0; i < 9; ++i) s_Rg[i] = sel[i];
+        if (gt_rot_used)
+            for (int i = 0; i < 9; ++i) gt_rot_used[b * 9 + i] = sel[i];
     }
     __syncthreads();
     // PM loss (R only): sum_p sum_i | w * ((R - Rgt) P)_i |, G_ij = sum_p w * sign(.)_i * P_j
-    const float* Rg = gt_rot + b * 9;
+    const float* Rg = s_Rg;
     float w = 1.f;
     if (pm_norm_by_extent) w = 1.0f / fmaxf(fmaxf(extents[b * 3], extents[b * 3 + 1]), extents[b * 3 + 2]);
     float G[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, ls = 0.f;
@@ -620,6 +652,27 @@ __global__ void pose_loss_finalize_kernel(const float* __restrict__ part, int B,
     losses[2] = (float)(z_lw * z / (double)B);
 }
 
+extern "C" int rdpn6d_pose_train_sym_f32(const float* rt, int rt_stride, const float* roi_cams, const float* roi_centers,
+                                         const float* roi_whs, const float* resize_ratios, const float* roi_extents,
+                                         const float* gt_rot, const float* gt_trans_ratio, const float* points, int npts, int B,
+                                         int is_allo, float pm_lw, int pm_norm_by_extent, float centroid_lw, float z_lw,
+                                         const float* sym_rots /* [B][ksym][9] or NULL */, const int* sym_counts /* [B] */,
+                                         int ksym, float* gt_rot_used /* [B][9] or NULL */, float* rot, float* trans,
+                                         float* d_rt, float* losses /* [3] */, float* scratch /* [3B] */, void* stream)
+{
+    RD_REQUIRE(rt && roi_cams && roi_centers && roi_whs && resize_ratios && roi_extents && gt_rot && gt_trans_ratio && points, "null pointer");
+    RD_REQUIRE(rot && trans && d_rt && losses && scratch && B > 0 && npts > 0 && rt_stride >= 9, "null/shape");
+    RD_REQUIRE(ksym >= 0 && ((sym_rots && sym_counts) || ksym == 0), "symmetry table");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(pose_train_kernel, dim3(B), dim3(256), 0, s, rt, rt_stride, roi_cams, roi_centers, roi_whs, resize_ratios,
+                       roi_extents, gt_rot, gt_trans_ratio, points, npts, B, is_allo, pm_lw, pm_norm_by_extent, centroid_lw, z_lw,
+                       ksym > 0 ? sym_rots : nullptr, ksym > 0 ? sym_counts : nullptr, ksym, gt_rot_used, rot, trans, d_rt, scratch);
+    RD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(pose_loss_finalize_kernel, dim3(1), dim3(64), 0, s, scratch, B, npts, pm_lw, centroid_lw, z_lw, losses);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}
+
 extern "C" int rdpn6d_pose_train_f32(const float* rt, int rt_stride, const float* roi_cams, const float* roi_centers,
                                      const float* roi_whs, const float* resize_ratios, const float* roi_extents,
                                      const float* gt_rot, const float* gt_trans_ratio, const float* points, int npts, int B,
@@ -627,16 +680,9 @@ extern "C" int rdpn6d_pose_train_f32(const float* rt, int rt_stride, const float
                                      float* trans, float* d_rt, float* losses /* [3] */, float* scratch /* [3B] */,
                                      void* stream)
 {
-    RD_REQUIRE(rt && roi_cams && roi_centers && roi_whs && resize_ratios && roi_extents && gt_rot && gt_trans_ratio && points, "null pointer");
-    RD_REQUIRE(rot && trans && d_rt && losses && scratch && B > 0 && npts > 0 && rt_stride >= 9, "null/shape");
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(pose_train_kernel, dim3(B), dim3(256), 0, s, rt, rt_stride, roi_cams, roi_centers, roi_whs, resize_ratios,
-                       roi_extents, gt_rot, gt_trans_ratio, points, npts, B, is_allo, pm_lw, pm_norm_by_extent, centroid_lw, z_lw,
-                       rot, trans, d_rt, scratch);
-    RD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(pose_loss_finalize_kernel, dim3(1), dim3(64), 0, s, scratch, B, npts, pm_lw, centroid_lw, z_lw, losses);
-    RD_LAUNCH_CHECK();
-    return RDPN6D_OK;
+    return rdpn6d_pose_train_sym_f32(rt, rt_stride, roi_cams, roi_centers, roi_whs, resize_ratios, roi_extents, gt_rot,
+                                     gt_trans_ratio, points, npts, B, is_allo, pm_lw, pm_norm_by_extent, centroid_lw, z_lw,
+                                     nullptr, nullptr, 0, nullptr, rot, trans, d_rt, losses, scratch, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

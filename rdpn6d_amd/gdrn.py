@@ -614,7 +614,7 @@ class GDRN(nn.Module):
         batch = {"roi_img": x, "roi_coord_2d": roi_coord_2d, "fps": fps, "roi_cam": roi_cams, "roi_center": roi_centers,
                  "roi_wh": roi_whs, "resize_ratio": resize_ratios, "roi_extent": roi_extents, "roi_xyz": gt_xyz,
                  "roi_mask_visib": gt_mask_visib, "roi_mask_trunc": gt_mask_trunc, "roi_region": gt_region, "ego_rot": gt_ego_rot,
-                 "roi_trans_ratio": gt_trans_ratio, "roi_points": gt_points}
+                 "roi_trans_ratio": gt_trans_ratio, "roi_points": gt_points, "sym_info": sym_infos}
         losses = eng.forward_losses(batch)
         names = list(losses)
         anchor = next(p for p in self.parameters() if p.requires_grad)

@@ -55,14 +55,16 @@ class TrainEngine:
             raise NotImplementedError("only the loss types of the shipped RGB-D configs (L1 / L1 / CE) are implemented")
         if rc.XYZ_LOSS_MASK_GT != "visib" or rc.MASK_LOSS_GT != "trunc" or rc.REGION_LOSS_MASK_GT != "visib":
             raise NotImplementedError("loss mask selection other than visib/trunc/visib is not implemented")
-        if not (pc.PM_R_ONLY and pc.PM_LOSS_TYPE == "L1" and not pc.PM_LOSS_SYM and pc.PM_LW > 0):
-            raise NotImplementedError("only PM_R_ONLY L1 non-symmetric point-matching loss is implemented")
+        if not (pc.PM_R_ONLY and pc.PM_LOSS_TYPE == "L1" and pc.PM_LW > 0):
+            raise NotImplementedError("only the PM_R_ONLY L1 point-matching loss is implemented")
+        self.pm_sym = bool(pc.PM_LOSS_SYM)  # closest symmetric target, pm_loss.py:97-99
         if pc.CENTROID_LOSS_TYPE != "L1" or pc.Z_LOSS_TYPE != "L1" or pc.ROT_LW > 0 or pc.TRANS_LW > 0 or pc.get("BIND_LW", 0) > 0:
             raise NotImplementedError("only L1 centroid / z losses (ROT_LW = TRANS_LW = BIND_LW = 0) are implemented")
         self.lw = dict(xyz=float(rc.XYZ_LW), mask=float(rc.MASK_LW), region=float(rc.REGION_LW), pm=float(pc.PM_LW),
                        centroid=float(pc.CENTROID_LW), z=float(pc.Z_LW), pm_norm=1 if pc.PM_NORM_BY_EXTENT else 0)
         self.is_allo = 1 if "allo" in pc.ROT_TYPE else 0
         self.bufs = {}
+        self._sym_cache = None
         self._bn_counters = []  # num_batches_tracked buffers, bumped together once per forward
         self.repack = []     # table entries of the one-launch weight re-pack (see _pack_map)
         self.fwd, self.bwd = [], []   # launch closures
@@ -657,6 +659,7 @@ class TrainEngine:
         self._fc("fc2", pnp.fc2.weight, pnp.fc2.bias, f1, d_f1, 1024, f2, d_f2, 256, act=2)
         self._fc("fc_rt", (pnp.fc_r.weight, pnp.fc_t.weight), (pnp.fc_r.bias, pnp.fc_t.bias), f2, d_f2, 256, self.rt, self.d_rt, 9, act=0, out_cs=16)
         self.rot, self.trans = self.buf("rot", B, 3, 3), self.buf("trans", B, 3)
+        self.gt_rot_used = self.buf("gt_rot_used", B, 3, 3)  # PM target after the symmetry choice
         self.losses9 = self.buf("losses", 16, zero=True)
 
     def _fc(self, name, w, b, x, d_x, kin, y, d_y, nout, act, out_cs=None, w_view=None, g_view=None):
@@ -717,6 +720,32 @@ class TrainEngine:
     LOSS_NAMES = ("loss_coor_x", "loss_coor_y", "loss_coor_z", "loss_mask", "loss_region", "loss_region_my", "loss_PM_R",
                   "loss_centroid", "loss_z")
 
+    def _pack_sym_infos(self, sym_infos):
+        """list of [K,3,3] / [3,3] / None per crop (engine_utils.py:60-61) -> ([B,Kmax,9] fp32, [B] int32, Kmax) on the
+        device.  One small upload; the selection itself runs inside the pose kernel (the reference copies every predicted
+        rotation to the host instead, pose_utils.py:475-481)."""
+        if sym_infos is None:
+            raise ValueError("PNP_NET.PM_LOSS_SYM is set: sym_infos (list of Kx3x3 or None per crop) is required")
+        if len(sym_infos) != self.B:
+            raise ValueError(f"sym_infos has {len(sym_infos)} entries for a batch of {self.B}")
+        key = tuple(id(s) for s in sym_infos)
+        if self._sym_cache is not None and self._sym_cache[0] == key:
+            return self._sym_cache[2]
+        mats = [None if s is None else torch.as_tensor(s, dtype=torch.float32).reshape(-1, 9).cpu() for s in sym_infos]
+        kmax = max([0] + [m.shape[0] for m in mats if m is not None])
+        if kmax == 0:
+            packed = (None, None, 0)
+        else:
+            tab = torch.zeros(self.B, kmax, 9, dtype=torch.float32)
+            cnt = torch.zeros(self.B, dtype=torch.int32)
+            for i, m in enumerate(mats):
+                if m is not None:
+                    tab[i, :m.shape[0]] = m
+                    cnt[i] = m.shape[0]
+            packed = (tab.to(self.dev), cnt.to(self.dev), kmax)
+        self._sym_cache = (key, list(sym_infos), packed)  # holds the objects so the ids stay valid
+        return packed
+
     def forward_losses(self, batch):
         """Forward in training mode + the nine losses (also seeds the gradient buffers d_head / d_rt).
         batch: dict in the reference's batch_data contract (engine_utils.py:6-63), device tensors.
@@ -737,10 +766,13 @@ class TrainEngine:
         HW = (self.R // 4) ** 2
         lw = self.lw
         sc = self.buf("pose_scratch", 3 * B)
-        _lib.check(lib.rdpn6d_pose_train_f32(_ptr(self.rt), 16, _ptr(cams), _ptr(centers), _ptr(whs), _ptr(ratios), _ptr(extents),
-                                             _ptr(gt_rot), _ptr(gt_ratio), _ptr(pts), pts.shape[1], B, self.is_allo, lw["pm"],
-                                             lw["pm_norm"], lw["centroid"], lw["z"], _ptr(self.rot), _ptr(self.trans), _ptr(self.d_rt),
-                                             _ptr(self.losses9[6:]), _ptr(sc), self.st()), "pose_train")
+        sym_rots, sym_counts, ksym = self._pack_sym_infos(batch.get("sym_info")) if self.pm_sym else (None, None, 0)
+        _lib.check(lib.rdpn6d_pose_train_sym_f32(_ptr(self.rt), 16, _ptr(cams), _ptr(centers), _ptr(whs), _ptr(ratios),
+                                                 _ptr(extents), _ptr(gt_rot), _ptr(gt_ratio), _ptr(pts), pts.shape[1], B,
+                                                 self.is_allo, lw["pm"], lw["pm_norm"], lw["centroid"], lw["z"],
+                                                 _ptr(sym_rots) if ksym else None, _ptr(sym_counts) if ksym else None, ksym,
+                                                 _ptr(self.gt_rot_used), _ptr(self.rot), _ptr(self.trans), _ptr(self.d_rt),
+                                                 _ptr(self.losses9[6:]), _ptr(sc), self.st()), "pose_train")
         _lib.check(lib.rdpn6d_dense_losses_f32(_ptr(self.head_out), self.head_cs, _ptr(gt_xyz), _ptr(mv), _ptr(mt), _ptr(gt_region), B, HW,
                                                K, lw["xyz"], lw["mask"], lw["region"], _ptr(self.d_head), _ptr(self.losses9),
                                                _ptr(self._scratch_d), self.st()), "dense_losses")

@@ -466,3 +466,114 @@ def test_training_step_generalised_geometry(K, R, amp):
     print(f"K={K} R={R} amp={amp}: median rel grad err vs fp64 HIP {np.median(eh):.2e} (CPU fp32 {np.median(ec):.2e}), worst HIP {max(eh):.2e} (CPU {max(ec):.2e})")
     if not amp:
         assert np.median(eh) <= max(2.0 * np.median(ec), 1e-3) and max(eh) <= max(3.0 * max(ec), 5e-2)
+
+
+def test_pose_train_sym_kernel_vs_reference_golden(golden_dir):
+    """PNP_NET.PM_LOSS_SYM: the pose kernel's on-device choice of the closest symmetric target, loss_PM_R and its gradient
+    against the vectors of the reference's own PyPMLoss / get_closest_rot_batch (tests/golden/pm_sym_golden.npz).  The
+    predicted rotation enters as its rot6d (first two columns, ego), so the kernel rebuilds it to round-off."""
+    from oracle import model_oracle
+    from rdpn6d_amd import _lib
+    from rdpn6d_amd.gdrn import _ptr
+    from tests.pm_sym_cases import make_case, pack_sym
+
+    dev = torch.device("cuda:0")
+    gold = np.load(os.path.join(golden_dir, "pm_sym_golden.npz"))
+    c = make_case()
+    Bn, npts = c["pred_rots"].shape[0], c["points"].shape[1]
+    rt = torch.zeros(Bn, 16)
+    rt[:, 0:3] = torch.from_numpy(c["pred_rots"][:, :, 0])
+    rt[:, 3:6] = torch.from_numpy(c["pred_rots"][:, :, 1])
+    rt[:, 8] = 1.0
+    tab, cnt, kmax = pack_sym(c["sym_infos"])
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    cams = torch.eye(3).repeat(Bn, 1, 1).to(dev)
+    centers, whs, ratios = torch.zeros(Bn, 2, device=dev), torch.ones(Bn, 2, device=dev), torch.ones(Bn, device=dev)
+    gt_ratio = torch.zeros(Bn, 3, device=dev)
+    lib = _lib.load()
+    for name, use_sym in (("sym", True), ("plain", False)):
+        rot, trans, used = torch.empty(Bn, 3, 3, device=dev), torch.empty(Bn, 3, device=dev), torch.empty(Bn, 3, 3, device=dev)
+        d_rt, losses, sc = torch.empty(Bn, 16, device=dev), torch.empty(3, device=dev), torch.empty(3 * Bn, device=dev)
+        tab_d, cnt_d, rt_d = d(tab), d(cnt), rt.to(dev)
+        ext_d, gtr_d, pts_d = d(c["extents"]), d(c["gt_rots"]), d(c["points"])  # named: they must outlive the launch
+        _lib.check(lib.rdpn6d_pose_train_sym_f32(_ptr(rt_d), 16, _ptr(cams), _ptr(centers), _ptr(whs), _ptr(ratios),
+                                                 _ptr(ext_d), _ptr(gtr_d), _ptr(gt_ratio), _ptr(pts_d),
+                                                 npts, Bn, 0, 1.0, 1, 0.0, 0.0, _ptr(tab_d) if use_sym else None,
+                                                 _ptr(cnt_d) if use_sym else None, kmax if use_sym else 0, _ptr(used), _ptr(rot),
+                                                 _ptr(trans), _ptr(d_rt), _ptr(losses), _ptr(sc), None), "pose_train_sym")
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(rot.cpu().numpy(), c["pred_rots"], atol=5e-7)
+        want_used = gold["closest_gt_rots"] if use_sym else c["gt_rots"]
+        np.testing.assert_allclose(used.cpu().numpy(), want_used, atol=2e-7)  # same choice for every crop
+        want = float(gold[f"loss_PM_R_{name}"])
+        got = losses[0].item()
+        print(f"loss_PM_R[{name}] hip {got:.8f} reference {want:.8f}")
+        assert abs(got - want) <= 2e-6 * want
+        # gradient: chain the reference's d(loss)/d(pred_rots) through rot6d -> R with autograd
+        p6 = rt[:, :6].clone().requires_grad_(True)
+        R = model_oracle.rot6d_to_mat(p6)
+        (g6,) = torch.autograd.grad(R, p6, torch.from_numpy(gold[f"grad_pred_rots_{name}"]))
+        got_g = d_rt.cpu()[:, :6]
+        keep = torch.ones(Bn, dtype=torch.bool)
+        keep[6] = False  # prediction == target there: every residual is +-round-off and the L1 sign is arbitrary
+        assert (got_g - g6)[keep].abs().max().item() <= 1e-5 * g6.abs().max().item()
+        assert d_rt[:, 6:].abs().max().item() == 0.0  # centroid_lw = z_lw = 0
+
+
+def test_training_step_with_pm_loss_sym_vs_oracle(golden_dir):
+    """the full engine with PM_LOSS_SYM=True (the seven shipped '...Rsym...' configs) through the reference's forward
+    signature: loss_PM_R, the chosen targets and the gradients against the oracle given the same sym_infos."""
+    from oracle import model_oracle
+    from rdpn6d_amd import synth
+    from rdpn6d_amd.config import gdrn_base_cfg
+    from rdpn6d_amd.gdrn import build_model_optimizer
+    from tests.pm_sym_cases import sym_sets
+
+    dev = torch.device("cuda:0")
+    bn = np.load(os.path.join(golden_dir, "bn_stats_c1.npz"))
+    inp = synth.make_inputs(4, seed=0)
+    gt = synth.make_train_gt(4, inp)
+    cfg = gdrn_base_cfg(mask_attention="none", device="cuda")
+    cfg.MODEL.CDPN.PNP_NET.PM_LOSS_SYM = True
+    model, _ = build_model_optimizer(cfg)
+    sd = synth.make_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=1234)
+    sd.update({k: bn[k] for k in bn.files})
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+    model.load_state_dict(sd, strict=True)
+    sets = sym_sets()
+    sym_infos = [sets[3], None, sets[4], sets[2]]
+    b = {k: torch.from_numpy(v).to(dev) for k, v in {**inp, **gt}.items()}
+    model.train()
+    kw = dict(gt_xyz=b["roi_xyz"], gt_mask_trunc=b["roi_mask_trunc"], gt_mask_visib=b["roi_mask_visib"], gt_mask_obj=b["roi_mask_obj"],
+              gt_region=b["roi_region"], gt_ego_rot=b["ego_rot"], gt_points=b["roi_points"], gt_trans=b["trans"],
+              gt_trans_ratio=b["roi_trans_ratio"], roi_classes=b["roi_cls"], roi_coord_2d=b["roi_coord_2d"], roi_cams=b["roi_cam"],
+              roi_centers=b["roi_center"], roi_whs=b["roi_wh"], roi_extents=b["roi_extent"], resize_ratios=b["resize_ratio"],
+              do_loss=True, fps=b["fps"])
+    with pytest.raises(ValueError, match="sym_infos"):
+        model(b["roi_img"], sym_infos=None, **kw)
+    _, ld = model(b["roi_img"], sym_infos=sym_infos, **kw)
+    sum(ld.values()).backward()
+    torch.cuda.synchronize()
+    eng = model.train_engine(4, dev)
+    orc = model_oracle.GDRNOracle(32, "none")
+    orc.load_state_dict(sd, strict=True)
+    orc.train()
+    t = {k: torch.from_numpy(v) for k, v in {**inp, **gt}.items()}
+    o = orc(t["roi_img"], t["roi_coord_2d"], t["fps"], t["roi_cam"], t["roi_center"], t["roi_wh"], t["resize_ratio"], train_pose=True)
+    L = model_oracle.gdrn_losses(o, t, t["roi_extent"], sym_infos=sym_infos)
+    Lplain = model_oracle.gdrn_losses(o, t, t["roi_extent"])
+    sum(L.values()).backward()
+    want_used = model_oracle.closest_sym_rots(o["rot"], t["ego_rot"], sym_infos)
+    changed = int((want_used - t["ego_rot"]).abs().amax(dim=(1, 2)).gt(1e-6).sum())
+    print(f"targets changed by symmetry: {changed} of 4; loss_PM_R sym {L['loss_PM_R'].item():.5f} plain {Lplain['loss_PM_R'].item():.5f}"
+          f" hip {ld['loss_PM_R'].item():.5f}")
+    assert changed >= 1 and L["loss_PM_R"].item() < Lplain["loss_PM_R"].item()
+    assert (eng.gt_rot_used.cpu() - want_used).abs().max().item() <= 1e-6
+    for k in L:
+        assert abs(ld[k].item() - L[k].item()) <= 1e-3 * max(1.0, abs(L[k].item())), k
+    named = dict(orc.named_parameters())
+    for k in ("pnp_net.fc_r.weight", "pnp_net.fc1.weight", "rot_head_net.features.21.weight", "backbone.conv1.weight"):
+        a, g = dict(model.named_parameters())[k].grad.cpu().double(), named[k].grad.double()
+        rel = ((a - g).norm() / g.norm()).item()
+        print(f"grad {k}: rel {rel:.2e}")
+        assert rel < (0.2 if k.startswith("backbone") else 5e-2), k  # fp32 round-off through ~45 layers, see the test above
