@@ -41,13 +41,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // bf16 storage helpers (bf16 = the upper 16 bits of an fp32; conversion rounds to nearest even)
 typedef unsigned short rd_bf16_t;
 typedef unsigned rd_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ rd_bf16_t rd_f2bf(float f)
+// gfx950 converts in hardware (v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN) - one instruction per PAIR
+// instead of the ~7-instruction integer sequence per value
+typedef __bf16 rd_bf16x2_hw __attribute__((ext_vector_type(2)));
+typedef float rd_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned rd_f2bf_pk(float lo, float hi)
 {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (rd_bf16_t)((u >> 16) | 0x40);  // NaN stays NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (rd_bf16_t)(u >> 16);
+    const rd_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, rd_bf16x2_hw));
 }
+__device__ __forceinline__ rd_bf16_t rd_f2bf(float f) { return __builtin_bit_cast(rd_bf16_t, (__bf16)f); }
 __device__ __forceinline__ float rd_bf2f(rd_bf16_t h) { return __uint_as_float((unsigned)h << 16); }
 // 8 packed bf16 (one 16-byte access) <-> 8 floats
 __device__ __forceinline__ void rd_unpack8(const rd_u32x4 p, float (&v)[8])
@@ -62,7 +65,7 @@ __device__ __forceinline__ rd_u32x4 rd_pack8(const float (&v)[8])
 {
     rd_u32x4 p;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) p[i] = (unsigned)rd_f2bf(v[2 * i]) | ((unsigned)rd_f2bf(v[2 * i + 1]) << 16);
+    for (int i = 0; i < 4; ++i) p[i] = rd_f2bf_pk(v[2 * i], v[2 * i + 1]);
     return p;
 }
 
@@ -84,8 +87,8 @@ template <> __device__ __forceinline__ void rd_st4<float>(float* p, const f32x4 
 template <> __device__ __forceinline__ void rd_st4<rd_bf16_t>(rd_bf16_t* p, const f32x4 v)
 {
     uint2 u;
-    u.x = (unsigned)rd_f2bf(v[0]) | ((unsigned)rd_f2bf(v[1]) << 16);
-    u.y = (unsigned)rd_f2bf(v[2]) | ((unsigned)rd_f2bf(v[3]) << 16);
+    u.x = rd_f2bf_pk(v[0], v[1]);
+    u.y = rd_f2bf_pk(v[2], v[3]);
     *reinterpret_cast<uint2*>(p) = u;
 }
 template <typename T> __device__ __forceinline__ float rd_ld1(const T* p);

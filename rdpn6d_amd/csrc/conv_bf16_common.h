@@ -27,6 +27,112 @@ typedef rd_bf16_t bf16_t;
 #define f2bf rd_f2bf
 #define bf2f rd_bf2f
 
+// activation of N values behind ONE wave-uniform branch (a per-element `if (act == ..)` inside the unrolled loops made
+// the compiler shuffle the whole value array through a branch ladder: ~75 instructions per output)
+template <int N>
+__device__ __forceinline__ void conv_bf16_act(float (&v)[N], const int act, const float slope)
+{
+    if (act == 1) {
+#pragma unroll
+        for (int q = 0; q < N; ++q) v[q] = v[q] > 0.f ? v[q] : 0.f;
+    } else if (act == 2) {
+#pragma unroll
+        for (int q = 0; q < N; ++q) v[q] = v[q] > 0.f ? v[q] : v[q] * slope;
+    }
+}
+
+// Coalesced form of the fused epilogue (full column tiles, 16-byte aligned channel slices).  MASK_ROWS: rows >= M of a
+// ragged last tile are skipped (their accumulators are zeros from out-of-range input rows).
+template <int BM, int BN, int WM, int WN, int TM, int TN, bool MASK_ROWS>
+__device__ __forceinline__ void conv_bf16_epilogue_vec(const ConvBArgs& a, f32x16 (&acc)[TM][TN], unsigned char* smem,
+                                                       const long long m0, const int n0, const int wave, const int lane,
+                                                       const int wm, const int wn)
+{
+    const rdpn6d_conv_desc& d = a.d;
+    const int frow = lane & 31;
+    const int hi = lane >> 5;
+    const bf16_t* resb = reinterpret_cast<const bf16_t*>(d.res);
+    bf16_t* yb = reinterpret_cast<bf16_t*>(d.y);
+    // Coalesced form for full tiles: the accumulator layout has one channel per lane and pixels across registers, i.e. a
+    // direct store moves 2 bytes per lane.  Each wave instead transposes its tile through its own slice of the (now
+    // idle) staging LDS - fp32, scale/shift already applied - and walks it back row-wise: 8 channels = 16 bytes per
+    // lane for the residual load and the store.  Same fp32 operations in the same order as the scalar path below.
+    {
+        constexpr int WC = BN / WN;       // channels per wave tile
+        constexpr int CS = WC + 8;        // LDS row stride in floats (+32 B: the two half-waves hit disjoint banks)
+        __syncthreads();                  // every wave is done with the staging buffers (and no DMA is still landing)
+        float* cst = reinterpret_cast<float*>(smem) + wave * (32 * CS);
+        const int nb = n0 + wn * WC;
+        auto pixel_of = [&](const long long m) -> long long {
+            if (a.linear_out) return m;
+            const int mm = (int)m;
+            const int b = mm / a.HoWo;
+            const int rem = mm - b * a.HoWo;
+            const int oy = rem / d.Wo;
+            const int ox = rem - oy * d.Wo;
+            return ((long long)b * d.OH + (oy * d.osy + d.ooy)) * d.OW + (ox * d.osx + d.oox);
+        };
+        float scj[TN], shj[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = nb + j * 32 + frow;
+            scj[j] = d.scale ? d.scale[n] : 1.f;
+            shj[j] = d.shift ? d.shift[n] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    cst[((e & 3) + 8 * (e >> 2) + 4 * hi) * CS + j * 32 + frow] = acc[i][j][e] * scj[j] + shj[j];
+            }
+            if (a.out_f32) {  // fp32 output (training: raw conv results / input gradients): 4 channels = 16 bytes per lane
+                constexpr int LPR = WC / 4, RPI = 64 / LPR;
+                const int rrow = lane / LPR, c4 = (lane % LPR) * 4;
+#pragma unroll
+                for (int rr = 0; rr < 32 / RPI; ++rr) {
+                    const int row = rr * RPI + rrow;
+                    const long long mrow = m0 + wm * (BM / WM) + i * 32 + row;
+                    if (MASK_ROWS && mrow >= a.M) continue;
+                    const long long pix = pixel_of(mrow);
+                    const f32x4 cv = *reinterpret_cast<const f32x4*>(cst + row * CS + c4);
+                    float v[4] = {cv[0], cv[1], cv[2], cv[3]};
+                    if (d.res) {
+                        const f32x4 rv = *reinterpret_cast<const f32x4*>(d.res + pix * d.res_cs + d.res_co + nb + c4);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] += rv[q];
+                    }
+                    conv_bf16_act(v, d.act, d.slope);
+                    const f32x4 ov = {v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(d.y + pix * d.out_cs + d.out_co + nb + c4) = ov;
+                }
+            } else {
+                constexpr int LPR = WC / 8, RPI = 64 / LPR;
+                const int rrow = lane / LPR, c8 = (lane % LPR) * 8;
+#pragma unroll
+                for (int rr = 0; rr < 32 / RPI; ++rr) {
+                    const int row = rr * RPI + rrow;
+                    const long long mrow = m0 + wm * (BM / WM) + i * 32 + row;
+                    if (MASK_ROWS && mrow >= a.M) continue;
+                    const long long pix = pixel_of(mrow);
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(cst + row * CS + c8);
+                    const f32x4 hi4 = *reinterpret_cast<const f32x4*>(cst + row * CS + c8 + 4);
+                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+                    if (resb) {
+                        float rv[8];
+                        rd_unpack8(*reinterpret_cast<const rd_u32x4*>(resb + pix * d.res_cs + d.res_co + nb + c8), rv);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] += rv[q];
+                    }
+                    conv_bf16_act(v, d.act, d.slope);
+                    *reinterpret_cast<rd_u32x4*>(yb + pix * d.out_cs + d.out_co + nb + c8) = rd_pack8(v);
+                }
+            }
+        }
+    }
+}
+
 // acc: the wave's (BM/WM) x (BN/WN) tile as TM x TN 32x32 MFMA accumulators; smem: the workgroup's dynamic LDS (idle
 // once the K loop is done); wm / wn: the wave's position in the WM x WN grid.
 template <int BM, int BN, int WM, int WN, int TM, int TN>
@@ -55,81 +161,8 @@ __device__ __forceinline__ void conv_bf16_epilogue(const ConvBArgs& a, f32x16 (&
     const int hi = lane >> 5;
     const bf16_t* resb = reinterpret_cast<const bf16_t*>(d.res);
     bf16_t* yb = reinterpret_cast<bf16_t*>(d.y);
-    // Coalesced form for full tiles: the accumulator layout has one channel per lane and pixels across registers, i.e. a
-    // direct store moves 2 bytes per lane.  Each wave instead transposes its tile through its own slice of the (now
-    // idle) staging LDS - fp32, scale/shift already applied - and walks it back row-wise: 8 channels = 16 bytes per
-    // lane for the residual load and the store.  Same fp32 operations in the same order as the scalar path below.
     if (a.vec_out && n0 + BN <= d.N && m0 + BM <= a.M) {
-        constexpr int WC = BN / WN;       // channels per wave tile
-        constexpr int CS = WC + 8;        // LDS row stride in floats (+32 B: the two half-waves hit disjoint banks)
-        __syncthreads();                  // every wave is done with the staging buffers (and no DMA is still landing)
-        float* cst = reinterpret_cast<float*>(smem) + wave * (32 * CS);
-        const int nb = n0 + wn * WC;
-        auto pixel_of = [&](const long long m) -> long long {
-            if (a.linear_out) return m;
-            const int mm = (int)m;
-            const int b = mm / a.HoWo;
-            const int rem = mm - b * a.HoWo;
-            const int oy = rem / d.Wo;
-            const int ox = rem - oy * d.Wo;
-            return ((long long)b * d.OH + (oy * d.osy + d.ooy)) * d.OW + (ox * d.osx + d.oox);
-        };
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = nb + j * 32 + frow;
-                const float sc = d.scale ? d.scale[n] : 1.f;
-                const float sh = d.shift ? d.shift[n] : 0.f;
-#pragma unroll
-                for (int e = 0; e < 16; ++e)
-                    cst[((e & 3) + 8 * (e >> 2) + 4 * hi) * CS + j * 32 + frow] = acc[i][j][e] * sc + sh;
-            }
-            if (a.out_f32) {  // fp32 output (training: raw conv results / input gradients): 4 channels = 16 bytes per lane
-                constexpr int LPR = WC / 4, RPI = 64 / LPR;
-                const int rrow = lane / LPR, c4 = (lane % LPR) * 4;
-#pragma unroll
-                for (int rr = 0; rr < 32 / RPI; ++rr) {
-                    const int row = rr * RPI + rrow;
-                    const long long pix = pixel_of(m0 + wm * (BM / WM) + i * 32 + row);
-                    f32x4 v = *reinterpret_cast<const f32x4*>(cst + row * CS + c4);
-                    if (d.res) {
-                        const f32x4 rv = *reinterpret_cast<const f32x4*>(d.res + pix * d.res_cs + d.res_co + nb + c4);
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) v[q] += rv[q];
-                    }
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        if (d.act == 1) v[q] = v[q] > 0.f ? v[q] : 0.f;
-                        else if (d.act == 2) v[q] = v[q] > 0.f ? v[q] : v[q] * d.slope;
-                    }
-                    *reinterpret_cast<f32x4*>(d.y + pix * d.out_cs + d.out_co + nb + c4) = v;
-                }
-            } else {
-                constexpr int LPR = WC / 8, RPI = 64 / LPR;
-                const int rrow = lane / LPR, c8 = (lane % LPR) * 8;
-#pragma unroll
-                for (int rr = 0; rr < 32 / RPI; ++rr) {
-                    const int row = rr * RPI + rrow;
-                    const long long pix = pixel_of(m0 + wm * (BM / WM) + i * 32 + row);
-                    const f32x4 lo = *reinterpret_cast<const f32x4*>(cst + row * CS + c8);
-                    const f32x4 hi4 = *reinterpret_cast<const f32x4*>(cst + row * CS + c8 + 4);
-                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
-                    if (resb) {
-                        float rv[8];
-                        rd_unpack8(*reinterpret_cast<const rd_u32x4*>(resb + pix * d.res_cs + d.res_co + nb + c8), rv);
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) v[q] += rv[q];
-                    }
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        if (d.act == 1) v[q] = v[q] > 0.f ? v[q] : 0.f;
-                        else if (d.act == 2) v[q] = v[q] > 0.f ? v[q] : v[q] * d.slope;
-                    }
-                    *reinterpret_cast<rd_u32x4*>(yb + pix * d.out_cs + d.out_co + nb + c8) = rd_pack8(v);
-                }
-            }
-        }
+        conv_bf16_epilogue_vec<BM, BN, WM, WN, TM, TN, false>(a, acc, smem, m0, n0, wave, lane, wm, wn);
         return;
     }
 #pragma unroll

@@ -251,6 +251,10 @@ __global__ void conv_bf16_splitk_epilogue_kernel(const float* __restrict__ parti
     }
 }
 
+// conv_igemm_bf16_8ph.hip: the 256x256 8-phase form for the large GEMM-like layers
+bool conv_bf16_8ph_eligible(const ConvBArgs& a, int rb);
+int conv_bf16_launch_8ph(const ConvBArgs& a, hipStream_t s);
+
 static int g_bforce_bm = 0, g_bforce_bn = 0, g_bforce_rb = 0;
 extern "C" void rdpn6d_conv_bf16_force_chunk(int row_bytes) { g_bforce_rb = row_bytes; }  // 0 = auto, 64 | 128 (profiling)
 extern "C" void rdpn6d_conv_bf16_force_tile(int bm, int bn) { g_bforce_bm = bm; g_bforce_bn = bn; }
@@ -263,9 +267,13 @@ static void conv_bf16_pick_tile(const rdpn6d_conv_desc* d, long long M, int rb, 
     //  therefore only reachable through rdpn6d_conv_bf16_force_tile(256, 128))
     if (bm == 128 && (long long)rd_cdiv(M, 128) * (d->Npad / bn) < 512) bm = 64;
     if (bm == 64 && bn == 128 && (long long)rd_cdiv(M, 64) * (d->Npad / 128) < 512) bn = 64;
+    // 256x256 8-phase kernel (conv_igemm_bf16_8ph.hip): GEMM-like layers with at least one full round of 256-row tiles
+    const int nk = d->ntaps * (d->Cin / 64);
+    const bool can8 = rb == 128 && d->Npad % 256 == 0 && d->N == d->Npad && nk >= 2 && (nk & 1) == 0;
+    if (can8 && !g_bforce_bm && (long long)rd_cdiv(M, 256) * (d->Npad / 256) >= 256) bm = bn = 256;
     if (g_bforce_bm && (g_bforce_bm != 256 || (rb == 128 && d->Npad % 128 == 0))) bm = g_bforce_bm;
     if (g_bforce_bn && d->Npad % g_bforce_bn == 0) bn = g_bforce_bn;
-    if (bm == 256) bn = 128;
+    if (bm == 256 && !(bn == 256 && can8)) bn = 128;
     *pbm = bm;
     *pbn = bn;
 }
@@ -366,6 +374,18 @@ static int conv2d_bf16_impl(const rdpn6d_conv_desc* d, int out_f32, int ksplit, 
     a.kper = a.nk;
     a.partial = nullptr;
     int nsplit = 1;
+    if (bm == 256 && bn == 256 && (ksplit > 1 || !a.vec_out)) {  // no split-K / unaligned-slice form of the 8-phase kernel
+        bm = bn = 128;
+        a.mtiles = rd_cdiv(a.M, bm);
+        a.ntiles = d->Npad / bn;
+    }
+    if (bm == 256 && bn == 256) {
+        RD_REQUIRE(conv_bf16_8ph_eligible(a, rb), "256x256 tile needs Cin % 64 == 0, Npad % 256 == 0 and an even K-tile count");
+        const int rc8 = conv_bf16_launch_8ph(a, s);
+        if (rc8 != RDPN6D_OK) return rc8;
+        RD_LAUNCH_CHECK();
+        return RDPN6D_OK;
+    }
     if (ksplit > 1 && bm != 256) {
         RD_REQUIRE(a.linear_out, "split-K needs a linear output geometry");
         a.kper = rd_cdiv(a.nk, ksplit);

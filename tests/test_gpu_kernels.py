@@ -821,3 +821,91 @@ def test_conv_bf16_splitk_matches_fused(dev, case):
         tol = 1e-5 if out_f32 else 2.0 ** -7
         assert ((outs[0] - outs[1]).abs() <= tol * outs[0].abs() + 1e-5).all(), (case, out_f32)
         assert outs[0].abs().max().item() > 0.1
+
+
+BF16_8PH_CASES = [
+    # B, H, Cin, Cout, k, stride, res
+    (4, 64, 256, 256, 3, 1, True),     # the dense head's layer shape (64 full tiles)
+    (3, 30, 128, 256, 3, 1, False),    # M = 2700: last tile ragged, odd spatial size
+    (2, 32, 128, 512, 1, 1, True),     # 1x1, two K-tiles only (prologue + tail), two column tiles
+    (2, 32, 128, 256, 3, 2, False),    # stride 2
+    (1, 16, 1024, 256, 3, 1, False),   # long K (144 K-tiles), single tile
+]
+
+
+@pytest.mark.parametrize("case", BF16_8PH_CASES)
+def test_conv_bf16_8phase_kernel_bit_identical_to_128_tile(dev, case):
+    """the 256x256 8-phase ping-pong kernel accumulates every output in the same order as the 128x128 kernel (K-tiles in
+    order, four k16 steps each), so forcing either tile must give the SAME bits - fp32 and bf16 stores, with / without
+    residual - and repeated launches must reproduce them (race screen for the counted-vmcnt / barrier schedule)."""
+    from rdpn6d_amd import _lib, ops
+
+    lib = _lib.load()
+    B, H, Cin, Cout, k, stride, use_res = case
+    g = torch.Generator().manual_seed(sum(case) * 3 + 5)
+    x = torch.randn(B, H, H, Cin, generator=g).to(dev).bfloat16()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).to(dev).bfloat16()
+    sc, sh = (torch.rand(Cout, generator=g) + 0.5).to(dev), torch.randn(Cout, generator=g).to(dev)
+    Ho = (H + 2 * (k // 2) - k) // stride + 1
+    res = torch.randn(B, Ho, Ho, Cout, generator=g).to(dev).bfloat16() if use_res else None
+    kw = dict(stride=stride, pad=k // 2, act=1, slope=0.1)
+    try:
+        for out_f32 in (True, False):
+            r = (res.float() if out_f32 else res) if use_res else None
+            lib.rdpn6d_conv_bf16_force_tile(128, 128)
+            want = ops.conv2d_nhwc(x, w, sc, sh, residual=r, out_f32=out_f32, **kw)
+            torch.cuda.synchronize()
+            lib.rdpn6d_conv_bf16_force_tile(256, 256)
+            for rep in range(6):
+                got = ops.conv2d_nhwc(x, w, sc, sh, residual=r, out_f32=out_f32, **kw)
+                torch.cuda.synchronize()
+                assert torch.equal(got, want), (case, out_f32, rep, (got.float() - want.float()).abs().max().item())
+            assert want.float().abs().max().item() > 0.1
+    finally:
+        lib.rdpn6d_conv_bf16_force_tile(0, 0)
+
+
+def test_bf16_model_with_8phase_head_is_bit_identical(dev):
+    """whole bf16 inference step at B=16 (the head layers, incl. the ConvTranspose phases, then pick the 8-phase kernel)
+    vs the same step with the 128x128 tile forced: identical maps and poses."""
+    from rdpn6d_amd import _lib, synth
+    from rdpn6d_amd.config import gdrn_base_cfg
+    from rdpn6d_amd.gdrn import build_model_optimizer
+
+    lib = _lib.load()
+    cfg = gdrn_base_cfg(mask_attention="mul", device="cuda")
+    cfg.TEST.AMP_TEST = True
+    model, _ = build_model_optimizer(cfg)
+    sd = synth.make_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=1234)
+    bn = np.load(os.path.join(os.path.dirname(__file__), "golden", "bn_stats_c1.npz"))
+    sd.update({k: bn[k] for k in bn.files})
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    model.eval()
+    inp = {k: torch.from_numpy(v).to(dev) for k, v in synth.make_inputs(16, seed=3).items()}
+    outs = []
+    try:
+        for tile in ((128, 128), (0, 0)):
+            lib.rdpn6d_conv_bf16_force_tile(*tile)
+            bm, bn = ctypes_tile_of_head(lib, 16)
+            o = _run(model, inp)
+            torch.cuda.synchronize()
+            outs.append(({k: o[k].clone() for k in ("mask", "coor_x", "region", "rot", "trans")}, (bm, bn)))
+    finally:
+        lib.rdpn6d_conv_bf16_force_tile(0, 0)
+    assert outs[0][1] == (128, 128) and outs[1][1] == (256, 256), (outs[0][1], outs[1][1])
+    for k in outs[0][0]:
+        assert torch.isfinite(outs[0][0][k]).all(), k
+        assert torch.equal(outs[0][0][k].cpu(), outs[1][0][k].cpu()), k
+
+
+def ctypes_tile_of_head(lib, B):
+    """tile the bf16 dispatcher picks for the head's 3x3 / 256-channel layers at batch B"""
+    import ctypes
+
+    from rdpn6d_amd import _lib
+
+    d = _lib.ConvDesc()
+    d.B, d.H, d.W, d.Cin, d.in_cs, d.Ho, d.Wo, d.stride, d.ntaps, d.N, d.Npad = B, 64, 64, 256, 256, 64, 64, 1, 9, 256, 256
+    bm, bn = ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(lib.rdpn6d_conv_bf16_tile_for(ctypes.byref(d), ctypes.byref(bm), ctypes.byref(bn)))
+    return bm.value, bn.value
