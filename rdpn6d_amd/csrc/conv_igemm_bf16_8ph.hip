@@ -10,19 +10,23 @@
 // group issues its LDS fragment reads and its share of the LDS-DMA, and the roles swap at the next barrier.
 //
 //   phase j of K-tile t (buffer t&1)     fragment reads (ds_read_b128)        MFMA quadrant      DMA issued (2 x 1 KiB per wave)
-//     0                                  A-h0 (8), B-h0 (4)                   C00 += A0 B0       B-h1 of tile t+1
-//     1                                  B-h1 (4)                             C01 += A0 B1       A-h1 of tile t+1
-//     2                                  A-h1 (8)                             C11 += A1 B1       A-h0 of tile t+2
-//     3                                  -                                    C10 += A1 B0       B-h0 of tile t+2
+//     0                                  A-h0 (8), B-h0 (4)                   C00 += A0 B0       A-h1 of tile t+1
+//     1                                  B-h1 (4)                             C01 += A0 B1       A-h0 of tile t+2
+//     2                                  A-h1 (8)                             C11 += A1 B1       B-h0 of tile t+2
+//     3                                  -                                    C10 += A1 B0       B-h1 of tile t+2
 //
 // LDS: 2 buffers x {A-h0, A-h1, B-h0, B-h1} x 16 KiB = 128 KiB.  A "half" gathers what ONE phase reads: A-h{q} = rows
 // {wr*128 + q*64 .. +64} of both wave rows, B-h{q} = columns {wc*64 + q*32 .. +32} of the four wave columns, so a slot
-// is dead two phases after its single reading phase and can be re-staged four..five phases before the next use.
-// The DMA stream runs SIX half-tiles ahead of the phase counter; every phase ends its issue part with
-// s_waitcnt vmcnt(8): at most the four newest half-tiles are still in flight, the one issued four phases ago has
-// landed, is published by the phase's barriers and is first read one phase later (never in the waiting phase).  Past
-// the last K-tile the stream issues out-of-range (zero, no memory traffic) pieces into dead slots so that the counts
-// stay uniform.  Row layout inside a slot, XOR swizzle and fragment mapping are those of conv_igemm_bf16.hip.
+// has a single reading phase R and may be re-staged from the MFMA part of phase R+1 on (by then both groups have
+// waited for their reads).  A phase is: fragment reads | barrier | lgkmcnt(0), two MFMAs, the phase's two DMA pieces
+// (address = row base + wave-uniform tap offset, border handling by a per-row tap bit mask), six MFMAs,
+// s_waitcnt vmcnt(8) | barrier.  The DMA stream runs SEVEN half-tiles ahead of the phase counter (half-tile g is issued
+// in phase g-7); after the wait of phase P the four newest half-tiles (P+4..P+7) may still be in flight, P+3 has landed
+// for this wave.  Because the groups are one barrier apart, group 1's wait of phase P overlaps group 0's reads of phase
+// P+1: data retired in phase P is first read in phase P+2 (reads of phase R need half-tiles <= R+1, retired by phase
+// R-2: issued <= R+5, in flight R+2..R+5).  Past the last K-tile the stream issues out-of-range pieces (zeros, no
+// memory traffic) into dead slots so that the counts stay uniform.  Row layout inside a slot, XOR swizzle and fragment
+// mapping are those of conv_igemm_bf16.hip; every output accumulates in the same order, so results are bit-identical.
 #include "conv_bf16_common.h"
 
 #include <cstdlib>
@@ -62,23 +66,28 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_8ph_kernel(const ConvBArg
     const int prow = lane >> 3;                    // row inside the piece
     const int lr_lo = wave * 8 + prow;             // local row of piece 0 (piece 1: + 64)
     const unsigned lslot16 = (unsigned)((lane & 7) ^ ((lr_lo >> 1) & 7)) * 16u;  // (lr + 64) >> 1 has the same low 3 bits
-    int a_iy[2][2], a_ix[2][2];
-    unsigned a_off[2][2];
-    bool a_ok[2][2];
+    // per staged row: byte offset of its centre pixel (+ the lane's swizzled 16-byte slot) and one validity bit per tap
+    // (image border / rows past M), so that staging a piece costs an add, a bit test and an OR inside the loop
+    unsigned a_base[2][2], a_mask[2][2];
 #pragma unroll
     for (int qm = 0; qm < 2; ++qm)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const long long m = m0 + i * 128 + qm * 64 + lr_lo;
-            a_ok[qm][i] = m < a.M;
-            const int mm = a_ok[qm][i] ? (int)m : 0;
+            const bool ok = m < a.M;
+            const int mm = ok ? (int)m : 0;
             const int b = mm / a.HoWo;
             const int rem = mm - b * a.HoWo;
             const int oy = rem / d.Wo;
             const int ox = rem - oy * d.Wo;
-            a_iy[qm][i] = oy * d.stride;
-            a_ix[qm][i] = ox * d.stride;
-            a_off[qm][i] = ((unsigned)(b * d.H * d.W) * (unsigned)d.in_cs + (unsigned)d.in_co) * 2u + lslot16;
+            const int iy = oy * d.stride, ix = ox * d.stride;
+            a_base[qm][i] = ((unsigned)((b * d.H + iy) * d.W + ix) * (unsigned)d.in_cs + (unsigned)d.in_co) * 2u + lslot16;
+            unsigned mask = 0;
+            for (int t = 0; t < d.ntaps; ++t) {
+                const int dy = (int)((a.dy_pack >> (4 * t)) & 15ull) - 8, dx = (int)((a.dx_pack >> (4 * t)) & 15ull) - 8;
+                mask |= (ok && (unsigned)(iy + dy) < (unsigned)d.H && (unsigned)(ix + dx) < (unsigned)d.W) ? (1u << t) : 0u;
+            }
+            a_mask[qm][i] = mask;
         }
     unsigned w_off[2][2];
 #pragma unroll
@@ -91,31 +100,46 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_8ph_kernel(const ConvBArg
         }
     const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x), 0, a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.w), 0, a.w_bytes, 0x00020000);
-    const unsigned oob = 0xFFFFFF00u;  // beyond num_records of either descriptor: the hardware returns zeros
-    const unsigned px_bytes = (unsigned)d.in_cs * 2u;
+    const int px_bytes = d.in_cs * 2;
 
-    auto stage_A = [&](auto qmc, const int buf, const int tap, const int cc, const bool valid) {
+    // Staging a half-tile is split in two: the per-lane offsets of the wave's two pieces (computed in the reading part of
+    // a phase, where the wave has issue slots to spare) and the two LDS-DMA instructions (placed between the MFMAs).
+    // valid = false (K-tiles past the end): every lane's offset becomes 0xFFFFFFFF, beyond num_records of either
+    // descriptor - the hardware then writes zeros without touching memory
+    unsigned st_off[2];
+    auto addr_A = [&](auto qmc, const int tap, const int cc, const bool valid) {
         constexpr int qm = decltype(qmc)::value;
         const int dy = (int)((a.dy_pack >> (4 * tap)) & 15ull) - 8, dx = (int)((a.dx_pack >> (4 * tap)) & 15ull) - 8;
-        const unsigned c0b = (unsigned)cc * 128u;
+        const unsigned toff = (unsigned)((dy * d.W + dx) * px_bytes + cc * 128);  // wave-uniform
+        const unsigned sel = valid ? 0u : 0xFFFFFFFFu;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int iy = a_iy[qm][i] + dy, ix = a_ix[qm][i] + dx;
-            const bool ok = valid && a_ok[qm][i] && (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
-            const unsigned off = ok ? a_off[qm][i] + (unsigned)(iy * d.W + ix) * px_bytes + c0b : oob;
-            unsigned char* dst = smem + (buf * 2 + qm) * HT_BYTES + (wave + 8 * i) * 1024;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_ptr_t)dst, 16, (int)off, 0, 0, 0);
+            const unsigned kill = ((a_mask[qm][i] >> tap) & 1u) - 1u;  // 0 when the tap is inside the image, else all ones
+            st_off[i] = (a_base[qm][i] + toff) | kill | sel;
         }
     };
-    auto stage_B = [&](auto qnc, const int buf, const int tap, const int cc, const bool valid) {
+    auto addr_B = [&](auto qnc, const int tap, const int cc, const bool valid) {
         constexpr int qn = decltype(qnc)::value;
         const unsigned wk = (unsigned)tap * (unsigned)d.Cin * 2u + (unsigned)cc * 128u;
+        const unsigned sel = valid ? 0u : 0xFFFFFFFFu;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const unsigned off = valid ? w_off[qn][i] + wk : oob;
-            unsigned char* dst = smem + 4 * HT_BYTES + (buf * 2 + qn) * HT_BYTES + (wave + 8 * i) * 1024;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrc, (lds_ptr_t)dst, 16, (int)off, 0, 0, 0);
-        }
+        for (int i = 0; i < 2; ++i) st_off[i] = (w_off[qn][i] + wk) | sel;
+    };
+    // piece i of half-tile (isB, q) of buffer buf
+    auto issue = [&](auto isBc, auto qc, const int buf, auto ic_) {
+        constexpr int isB = decltype(isBc)::value, q = decltype(qc)::value, i = decltype(ic_)::value;
+        unsigned char* dst = smem + isB * 4 * HT_BYTES + (buf * 2 + q) * HT_BYTES + (wave + 8 * i) * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(isB ? wsrc : xsrc, (lds_ptr_t)dst, 16, (int)st_off[i], 0, 0, 0);
+    };
+    auto stage_A = [&](auto qmc, const int buf, const int tap, const int cc, const bool valid) {
+        addr_A(qmc, tap, cc, valid);
+        issue(ic<0>{}, qmc, buf, ic<0>{});
+        issue(ic<0>{}, qmc, buf, ic<1>{});
+    };
+    auto stage_B = [&](auto qnc, const int buf, const int tap, const int cc, const bool valid) {
+        addr_B(qnc, tap, cc, valid);
+        issue(ic<1>{}, qnc, buf, ic<0>{});
+        issue(ic<1>{}, qnc, buf, ic<1>{});
     };
 
     // ---- fragment addressing
@@ -155,10 +179,11 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_8ph_kernel(const ConvBArg
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    auto mma = [&](auto qmc, auto qnc, const u32x4 (&fb)[4]) {
+    // k16 steps [j0, j1) of one quadrant: acc[qm*2 + i][qn] += A(i, j) * B(j)
+    auto mma_part = [&](auto qmc, auto qnc, const u32x4 (&fb)[4], auto j0c, auto j1c) {
         constexpr int qm = decltype(qmc)::value, qn = decltype(qnc)::value;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = decltype(j0c)::value; j < decltype(j1c)::value; ++j)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
                 acc[qm * 2 + i][qn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i][j]),
@@ -176,7 +201,7 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_8ph_kernel(const ConvBArg
         cc += wrap;
     };
 
-    // ---- prologue: half-tiles 0..5 = all of K-tile 0 and {A-h0, B-h0} of K-tile 1
+    // ---- prologue: half-tiles 0..6 = all of K-tile 0 and {A-h0, B-h0, B-h1} of K-tile 1
     stage_A(ic<0>{}, 0, 0, 0, true);
     stage_B(ic<0>{}, 0, 0, 0, true);
     stage_B(ic<1>{}, 0, 0, 0, true);
@@ -184,50 +209,62 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_8ph_kernel(const ConvBArg
     advance(t1_tap, t1_cc);  // K-tile 1
     stage_A(ic<0>{}, 1, t1_tap, t1_cc, nk > 1);
     stage_B(ic<0>{}, 1, t1_tap, t1_cc, nk > 1);
+    stage_B(ic<1>{}, 1, t1_tap, t1_cc, nk > 1);
     t2_tap = t1_tap;
     t2_cc = t1_cc;
     advance(t2_tap, t2_cc);  // K-tile 2
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // A-h0, B-h0 of K-tile 0 have landed (this wave's pieces)
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // A-h0, B-h0, B-h1 of K-tile 0 have landed (this wave's pieces)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (wr == 1) __builtin_amdgcn_s_barrier();  // the second wave group runs one barrier behind from here on
 
-    // One phase.  L part: fragment reads + DMA issue + counted wait; barrier; M part: 8 MFMAs at raised priority; barrier.
+    // One phase.  L part: fragment reads + the offsets of this phase's two DMA pieces; barrier; M part: 8 MFMAs at raised
+    // priority with one DMA instruction after the 2nd and one after the 4th, then the counted wait; barrier.
     auto phase = [&](auto jc, auto bufc, const int t) {
         constexpr int j = decltype(jc)::value, buf = decltype(bufc)::value;
+        constexpr bool RD = !(ABL & 2), DMA = !(ABL & 1), MMA = !(ABL & 4);
+        // half-tile staged by this phase: j = 0: A-h1 of tile t+1 (other buffer); 1: A-h0, 2: B-h0, 3: B-h1 of tile t+2
+        constexpr int sB = j >= 2 ? 1 : 0, sQ = (j == 0 || j == 3) ? 1 : 0, sBuf = j == 0 ? (buf ^ 1) : buf;
         __builtin_amdgcn_sched_barrier(0);
-        constexpr bool RD = !(ABL & 2), DMA = !(ABL & 1);
-        if constexpr (j == 0) {
-            if constexpr (RD) {
+        if constexpr (RD) {
+            if constexpr (j == 0) {
                 read_B(0, buf, fb0);
                 read_A(0, buf);
+            } else if constexpr (j == 1) {
+                read_B(1, buf, fb1);
+            } else if constexpr (j == 2) {
+                read_A(1, buf);
             }
-            if constexpr (DMA) stage_B(ic<1>{}, buf ^ 1, t1_tap, t1_cc, t + 1 < nk);
-        } else if constexpr (j == 1) {
-            if constexpr (RD) read_B(1, buf, fb1);
-            if constexpr (DMA) stage_A(ic<1>{}, buf ^ 1, t1_tap, t1_cc, t + 1 < nk);
-        } else if constexpr (j == 2) {
-            if constexpr (RD) read_A(1, buf);
-            if constexpr (DMA) stage_A(ic<0>{}, buf, t2_tap, t2_cc, t + 2 < nk);
-        } else {
-            if constexpr (DMA) stage_B(ic<0>{}, buf, t2_tap, t2_cc, t + 2 < nk);
+        }
+        if constexpr (DMA) {
+            if constexpr (j == 0) addr_A(ic<1>{}, t1_tap, t1_cc, t + 1 < nk);
+            else if constexpr (j == 1) addr_A(ic<0>{}, t2_tap, t2_cc, t + 2 < nk);
+            else if constexpr (j == 2) addr_B(ic<0>{}, t2_tap, t2_cc, t + 2 < nk);
+            else addr_B(ic<1>{}, t2_tap, t2_cc, t + 2 < nk);
+        }
+        if constexpr (j == 3) {
             t1_tap = t2_tap;
             t1_cc = t2_cc;
             advance(t2_tap, t2_cc);
         }
-        if constexpr (!(ABL & 8) && DMA) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
-        if constexpr (!(ABL & 4)) {
-            if constexpr (j == 0) mma(ic<0>{}, ic<0>{}, fb0);
-            else if constexpr (j == 1) mma(ic<0>{}, ic<1>{}, fb1);
-            else if constexpr (j == 2) mma(ic<1>{}, ic<1>{}, fb1);
-            else mma(ic<1>{}, ic<0>{}, fb0);
-        }
+        constexpr int qm = (j >> 1), qn = (j == 1 || j == 2) ? 1 : 0;
+        const u32x4 (&fb)[4] = qn ? fb1 : fb0;
+        if constexpr (MMA) mma_part(ic<qm>{}, ic<qn>{}, fb, ic<0>{}, ic<1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (DMA) issue(ic<sB>{}, ic<sQ>{}, sBuf, ic<0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MMA) mma_part(ic<qm>{}, ic<qn>{}, fb, ic<1>{}, ic<2>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (DMA) issue(ic<sB>{}, ic<sQ>{}, sBuf, ic<1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MMA) mma_part(ic<qm>{}, ic<qn>{}, fb, ic<2>{}, ic<4>{});
         __builtin_amdgcn_s_setprio(0);
+        if constexpr (!(ABL & 8) && DMA) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
