@@ -9,15 +9,17 @@
 // that run ONE BARRIER APART: while a group issues its 8 MFMAs of a phase (one 64x32 quadrant x K=64), the other
 // group issues its LDS fragment reads and its share of the LDS-DMA, and the roles swap at the next barrier.
 //
-//   phase j of K-tile t (buffer t&1)     fragment reads (ds_read_b128)        MFMA quadrant      DMA issued (2 x 1 KiB per wave)
-//     0                                  A-h0 (8), B-h0 (4)                   C00 += A0 B0       A-h1 of tile t+1
-//     1                                  B-h1 (4)                             C01 += A0 B1       A-h0 of tile t+2
-//     2                                  A-h1 (8)                             C11 += A1 B1       B-h0 of tile t+2
-//     3                                  -                                    C10 += A1 B0       B-h1 of tile t+2
+//   phase j of an EVEN K-tile t           fragment reads (ds_read_b128)        MFMA quadrant      DMA issued (2 x 1 KiB per wave)
+//     0                                  A-h0 (8)                             C00 += A0 B0       A-h1 of tile t+1
+//     1                                  B-h1 (4)                             C01 += A0 B1       B-h0 of tile t+2
+//     2                                  A-h1 (8)                             C11 += A1 B1       A-h0 of tile t+2
+//     3                                  B-h1 of tile t+1 (4)                 C10 += A1 B0       B-h1 of tile t+2
+//   odd K-tiles mirror this in N (C01, C00, C10, C11; B-h0 <-> B-h1), so the B fragments of a K-tile's first quadrant
+//   are always read one phase early into the B register set the running quadrant does not use.
 //
 // LDS: 2 buffers x {A-h0, A-h1, B-h0, B-h1} x 16 KiB = 128 KiB.  A "half" gathers what ONE phase reads: A-h{q} = rows
 // {wr*128 + q*64 .. +64} of both wave rows, B-h{q} = columns {wc*64 + q*32 .. +32} of the four wave columns, so a slot
-// has a single reading phase R and may be re-staged from the MFMA part of phase R+1 on (by then both groups have
+// has a single reading phase R (4t-1 for the first B half, 4t, 4t+1, 4t+2) and may be re-staged from the MFMA part of phase R+1 on (by then both groups have
 // waited for their reads).  A phase is: fragment reads | barrier | lgkmcnt(0), two MFMAs, the phase's two DMA pieces
 // (address = row base + wave-uniform tap offset, border handling by a per-row tap bit mask), six MFMAs,
 // s_waitcnt vmcnt(8) | barrier.  The DMA stream runs SEVEN half-tiles ahead of the phase counter (half-tile g is issued
@@ -202,20 +204,21 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_8ph_kernel(const ConvBArg
     };
 
     // ---- prologue: half-tiles 0..6 = all of K-tile 0 and {A-h0, B-h0, B-h1} of K-tile 1
+    stage_B(ic<0>{}, 0, 0, 0, true);  // even K-tiles: B-h0, A-h0, B-h1, A-h1
     stage_A(ic<0>{}, 0, 0, 0, true);
-    stage_B(ic<0>{}, 0, 0, 0, true);
     stage_B(ic<1>{}, 0, 0, 0, true);
     stage_A(ic<1>{}, 0, 0, 0, true);
-    advance(t1_tap, t1_cc);  // K-tile 1
+    advance(t1_tap, t1_cc);  // K-tile 1 (odd K-tiles: B-h1, A-h0, B-h0, A-h1)
+    stage_B(ic<1>{}, 1, t1_tap, t1_cc, nk > 1);
     stage_A(ic<0>{}, 1, t1_tap, t1_cc, nk > 1);
     stage_B(ic<0>{}, 1, t1_tap, t1_cc, nk > 1);
-    stage_B(ic<1>{}, 1, t1_tap, t1_cc, nk > 1);
     t2_tap = t1_tap;
     t2_cc = t1_cc;
     advance(t2_tap, t2_cc);  // K-tile 2
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // A-h0, B-h0, B-h1 of K-tile 0 have landed (this wave's pieces)
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // B-h0, A-h0, B-h1 of K-tile 0 have landed (this wave's pieces)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if constexpr (!(ABL & 2)) read_B(0, 0, fb0);  // "phase -1": the first quadrant's B fragments
     if (wr == 1) __builtin_amdgcn_s_barrier();  // the second wave group runs one barrier behind from here on
 
     // One phase.  L part: fragment reads + the offsets of this phase's two DMA pieces; barrier; M part: 8 MFMAs at raised
@@ -223,24 +226,32 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_8ph_kernel(const ConvBArg
     auto phase = [&](auto jc, auto bufc, const int t) {
         constexpr int j = decltype(jc)::value, buf = decltype(bufc)::value;
         constexpr bool RD = !(ABL & 2), DMA = !(ABL & 1), MMA = !(ABL & 4);
-        // half-tile staged by this phase: j = 0: A-h1 of tile t+1 (other buffer); 1: A-h0, 2: B-h0, 3: B-h1 of tile t+2
-        constexpr int sB = j >= 2 ? 1 : 0, sQ = (j == 0 || j == 3) ? 1 : 0, sBuf = j == 0 ? (buf ^ 1) : buf;
+        // buf = parity of the K-tile.  Odd K-tiles walk the quadrants mirrored in N (C01, C00, C10, C11) so that the B
+        // fragments of a K-tile's first quadrant can be read one phase early (phase 3 of the previous K-tile, whose MFMAs
+        // use the other B register set): 8 / 4 / 8 / 4 fragment reads per phase instead of 12 / 4 / 8 / 0.
+        // half-tile staged by this phase: j = 0: A-h1 of K-tile t+1 (other buffer); j = 1, 2, 3: first B half, A-h0, second
+        // B half of K-tile t+2 (first B half = B-h0 for even, B-h1 for odd K-tiles)
+        constexpr int sB = (j == 1 || j == 3) ? 1 : 0;
+        constexpr int sQ = j == 0 ? 1 : (j == 2 ? 0 : (j == 1 ? buf : (buf ^ 1)));
+        constexpr int sBuf = j == 0 ? (buf ^ 1) : buf;
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (RD) {
             if constexpr (j == 0) {
-                read_B(0, buf, fb0);
                 read_A(0, buf);
             } else if constexpr (j == 1) {
-                read_B(1, buf, fb1);
+                if constexpr (buf == 0) read_B(1, buf, fb1);
+                else read_B(0, buf, fb0);
             } else if constexpr (j == 2) {
                 read_A(1, buf);
+            } else {  // first B half of the next K-tile
+                if constexpr (buf == 0) read_B(1, buf ^ 1, fb1);
+                else read_B(0, buf ^ 1, fb0);
             }
         }
         if constexpr (DMA) {
             if constexpr (j == 0) addr_A(ic<1>{}, t1_tap, t1_cc, t + 1 < nk);
-            else if constexpr (j == 1) addr_A(ic<0>{}, t2_tap, t2_cc, t + 2 < nk);
-            else if constexpr (j == 2) addr_B(ic<0>{}, t2_tap, t2_cc, t + 2 < nk);
-            else addr_B(ic<1>{}, t2_tap, t2_cc, t + 2 < nk);
+            else if constexpr (j == 2) addr_A(ic<0>{}, t2_tap, t2_cc, t + 2 < nk);
+            else addr_B(ic<sQ>{}, t2_tap, t2_cc, t + 2 < nk);
         }
         if constexpr (j == 3) {
             t1_tap = t2_tap;
@@ -252,7 +263,7 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_8ph_kernel(const ConvBArg
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
-        constexpr int qm = (j >> 1), qn = (j == 1 || j == 2) ? 1 : 0;
+        constexpr int qm = (j >> 1), qn = ((j == 1 || j == 2) ? 1 : 0) ^ buf;
         const u32x4 (&fb)[4] = qn ? fb1 : fb0;
         if constexpr (MMA) mma_part(ic<qm>{}, ic<qn>{}, fb, ic<0>{}, ic<1>{});
         __builtin_amdgcn_sched_barrier(0);
