@@ -18,7 +18,7 @@ for n in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES"):
         d[0] += 1; d[1] += float(r["Counter_Value"]); d[2] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 out = {}
 for k, v in agg.items():
-    if not k.startswith(("void conv_igemm", "stem_", "maxpool", "global_max", "upsample", "void dense_glue", "groupnorm", "ransac")):
+    if not k.replace("(anonymous namespace)::", "").startswith(("void conv_igemm", "stem_", "maxpool", "global_max", "upsample", "void dense_glue", "groupnorm", "ransac")):
         continue
     m = {c: s / n for c, (n, s, t) in v.items()}
     us = v["FETCH_SIZE"][2] / v["FETCH_SIZE"][0] / 1e3
@@ -31,7 +31,7 @@ for k, v in agg.items():
         e["mfma_gflop_issued"] = round(mops * 512 / 1e9, 2)
         e["mfma_util_pct"] = round(100 * m["SQ_VALU_MFMA_BUSY_CYCLES"] / (xcd_cycles * 1024), 1)
         e["clock_GHz"] = round(xcd_cycles / (v["GRBM_GUI_ACTIVE"][2] / v["GRBM_GUI_ACTIVE"][0]), 2)
-    out[k.replace("void ", "").split("(")[0]] = e
+    out[k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]] = e
 json.dump(out, open(dst + ".json", "w"), indent=1)
 with open(dst + ".md", "w") as f:
     f.write("| kernel | launches | avg us | FETCH raw MB | FETCH x2 MB | WRITE MB | MFMA GFLOP issued | MfmaUtil % | clock GHz |\n|---|---|---|---|---|---|---|---|---|\n")
