@@ -440,18 +440,34 @@ struct WgradOut {
     long long sa, st, sb;
     int Ca_out, Cb_out;
 };
+// four consecutive b per thread (Cb % 4 == 0): 16-byte loads of every split's partial, four splits in flight; the sum over
+// the splits runs in the fixed order 0..S-1 for every element (deterministic, same order as the scalar form)
 __global__ void splitk_reduce_strided_kernel(const float* __restrict__ partial, int S, int Ca, int ntaps, int Cb, WgradOut o)
 {
     const long long n = (long long)Ca * ntaps * Cb;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-        const int b = (int)(i % Cb);
-        const long long r = i / Cb;
+    const long long n4 = n >> 2;
+    const int cb4 = Cb >> 2;
+    for (long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i4 < n4; i4 += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(i4 % cb4) * 4;
+        const long long r = i4 / cb4;
         const int t = (int)(r % ntaps);
         const int a = (int)(r / ntaps);
         if (a >= o.Ca_out || b >= o.Cb_out) continue;
-        float s = 0.f;
-        for (int k = 0; k < S; ++k) s += partial[(long long)k * n + i];
-        o.out[a * o.sa + t * o.st + b * o.sb] = s;
+        const float* p = partial + i4 * 4;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        int k = 0;
+        for (; k + 4 <= S; k += 4) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(p + (long long)k * n);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (long long)(k + 1) * n);
+            const f32x4 v2 = *reinterpret_cast<const f32x4*>(p + (long long)(k + 2) * n);
+            const f32x4 v3 = *reinterpret_cast<const f32x4*>(p + (long long)(k + 3) * n);
+            s = (((s + v0) + v1) + v2) + v3;
+        }
+        for (; k < S; ++k) s = s + *reinterpret_cast<const f32x4*>(p + (long long)k * n);
+        float* q = o.out + a * o.sa + t * o.st + b * o.sb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (b + e < o.Cb_out) q[e * o.sb] = s[e];
     }
 }
 
@@ -459,7 +475,8 @@ static void wgrad_reduce(const float* partial, int S, int Ca, int ntaps, int Cb,
 {
     const long long n = (long long)Ca * ntaps * Cb;
     const int rblocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    if (o) hipLaunchKernelGGL(splitk_reduce_strided_kernel, dim3(rblocks), dim3(256), 0, s, partial, S, Ca, ntaps, Cb, *o);
+    const int rblocks4 = (int)((n / 4 + 255) / 256 < 4096 ? (n / 4 + 255) / 256 : 4096);
+    if (o) hipLaunchKernelGGL(splitk_reduce_strided_kernel, dim3(rblocks4), dim3(256), 0, s, partial, S, Ca, ntaps, Cb, *o);
     else hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rblocks), dim3(256), 0, s, partial, S, n, out);
 }
 
