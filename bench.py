@@ -35,7 +35,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak F
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (same guide; never the 2:1-sparsity figure)
 
 
-def build_model(device, mask_attention="none", bf16=False, graph=False):
+def build_model(device, mask_attention="none", bf16=False, graph=False, x3=True):
     from rdpn6d_amd import synth
     from rdpn6d_amd.config import gdrn_base_cfg
     from rdpn6d_amd.gdrn import build_model_optimizer
@@ -44,6 +44,7 @@ def build_model(device, mask_attention="none", bf16=False, graph=False):
     cfg.TEST.USE_PNP = True  # the step includes the per-crop RANSAC/Kabsch solve ("fwd+PnP")
     cfg.TEST.AMP_TEST = bool(bf16)  # secondary mode: trunk + fusion + head on the bf16 matrix pipe
     cfg.TEST.HIP_GRAPH = bool(graph)  # the ~90 launches of a step replay as one hipGraph (same kernels, same order)
+    cfg.TEST.BF16X3 = bool(x3)  # fp32 mode: wide head layers as exact-product bf16x3 convolutions (fp32 accuracy)
     model, _ = build_model_optimizer(cfg)
     sd = synth.make_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=1234)
     bn = np.load(os.path.join(ROOT, "tests", "golden", "bn_stats_c1.npz"))
@@ -73,7 +74,9 @@ def roofline(model, t, B, device, reps=3):
     classes = {}  # tile -> launches of the conv kernel instance with that tile (bf16: the 64-channel K-chunk variants)
     lowp_fn = lib.rdpn6d_conv2d_bf16
     for L in plan.launches:
-        if L.keep and (L.fn is lowp_fn) == plan.bf16:
+        if L.keep and L.fn is lib.rdpn6d_conv2d_bf16x3:
+            classes.setdefault("x3", []).append(L)
+        elif L.keep and L.fn in (lowp_fn, lib.rdpn6d_conv2d_f32) and (L.fn is lowp_fn) == plan.bf16:
             d = L.keep[0]
             bm, bn = ctypes.c_int(), ctypes.c_int()
             (lib.rdpn6d_conv_bf16_tile_for if plan.bf16 else lib.rdpn6d_conv_tile_for)(ctypes.byref(d), ctypes.byref(bm), ctypes.byref(bn))
@@ -105,12 +108,18 @@ def roofline(model, t, B, device, reps=3):
         n += len(evs)
     avg_ms = total_ms / max(n, 1)
     achieved = flops / len(sel) / (avg_ms * 1e-3) / 1e12 if sel else 0.0
-    if plan.bf16:
+    extra = {}
+    if tile == "x3":
+        # fp32-accurate products as six bf16 partial products: the ceiling for ALGORITHMIC flops is the bf16 pipe / 6
+        kname, peak = "conv_igemm_bf16x3_kernel", round(BF16_MFMA_PEAK_TFLOPS / 6.0, 1)
+        extra = {"peak_note": "2500 TFLOP/s dense bf16 MFMA / 6 partial products per fp32 product (157.3 on the fp32 MFMA pipe)",
+                 "mfma_tflops_issued": round(6.0 * achieved, 1)}
+    elif plan.bf16:
         kname = ("conv_igemm_bf16_8ph_kernel<0>" if tile == (256, 256)
                  else f"conv_igemm_bf16_kernel<{tile[0]}, {tile[1]}, 128, 2, 2, 2>")
+        peak = BF16_MFMA_PEAK_TFLOPS
     else:
-        kname = f"conv_igemm_f32_kernel<{tile[0]}, {tile[1]}>"
-    peak = BF16_MFMA_PEAK_TFLOPS if plan.bf16 else FP32_MFMA_PEAK_TFLOPS
+        kname, peak = f"conv_igemm_f32_kernel<{tile[0]}, {tile[1]}>", FP32_MFMA_PEAK_TFLOPS
     traffic, traffic_src = pmc_traffic(kname, plan.bf16) if B == 64 else (None, None)
     return {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
@@ -118,7 +127,7 @@ def roofline(model, t, B, device, reps=3):
         "traffic_source": traffic_src,
         "kernel": kname.replace(", ", ","), "launches_per_step": len(sel),
         "avg_launch_ms": round(avg_ms, 4), "algorithmic_gflop_per_launch": round(flops / max(len(sel), 1) / 1e9, 2),
-        "share_of_step_flops": round(flops / (44.10e9 * B), 3),
+        "share_of_step_flops": round(flops / (44.10e9 * B), 3), **extra,
     }
 
 
@@ -249,6 +258,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="crops per GPU per step (BASELINE configs[1]: 64)")
     ap.add_argument("--mask-attention", default="none", choices=["none", "mul"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-x3", action="store_true",
+                    help="fp32 mode: keep every convolution on the fp32 MFMA pipe (cfg.TEST.BF16X3 = False)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as one hipGraph instead of launching kernel by kernel (measured: no gain, the "
                          "launch queue already runs ahead of the GPU - 2776 vs 2779 crops/s fp32, 10729 vs 10820 bf16)")
@@ -286,7 +297,7 @@ def main():
 
     if args.train:
         return train_bench(args, rank, world, device, dist)
-    model, sd = build_model(device, args.mask_attention, bf16=args.dtype == "bf16", graph=args.graph)
+    model, sd = build_model(device, args.mask_attention, bf16=args.dtype == "bf16", graph=args.graph, x3=not args.no_x3)
     B = args.batch
     t = {k: torch.from_numpy(v).to(device) for k, v in synth.make_inputs(B, seed=100 + rank).items()}
 
@@ -311,6 +322,11 @@ def main():
     elapsed = float(el.item())
 
     roof, cpu = None, None
+    dtype_label = args.dtype
+    if args.dtype == "f32" and model.plan(B, device).x3_launches:
+        dtype_label = ("f32 (fp32 storage and accumulation; the head's wide convolutions evaluate every fp32 product exactly as six "
+                       "bf16 partial products on the bf16 MFMA pipe - error vs fp64 no larger than the fp32 MFMA kernel's; "
+                       "fp32 MFMA elsewhere)")
     if rank == 0:
         with torch.no_grad():
             roof = roofline(model, t, B, device)
@@ -324,7 +340,7 @@ def main():
             "metric": "RGB-D crops/sec (fwd+PnP) at 256x256", "value": round(value, 1), "unit": "crops/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "vs_baseline": None, "dtype": dtype_label, "data": "synthetic",
             "config": {"workload": "LM 13-object inference, batch=64 per GPU, 256x256 RGB-D crops, K=32 regions, "
                                    "ResNet-34 trunk + dense head + ConvPnPNet + pose decode + per-crop RANSAC/Kabsch (100 hyp.), all on-device",
                        "batch_per_gpu": B, "global_batch": B * world, "mask_attention": args.mask_attention,

@@ -98,7 +98,20 @@ int rdpn6d_conv2d_bf16(const rdpn6d_conv_desc* d, int out_f32, void* stream);
 /* split-K form, as rdpn6d_conv2d_splitk_f32 (same workspace size, linear output geometry) */
 int rdpn6d_conv2d_splitk_bf16(const rdpn6d_conv_desc* d, int out_f32, int ksplit, float* workspace, void* stream);
 void rdpn6d_conv_bf16_force_tile(int bm, int bn);
-int rdpn6d_conv_bf16_tile_for(const rdpn6d_conv_desc* d, int* bm, int* bn); /* 256x128 | 128x128 | 128x64 | 64x128 | 64x64 */
+int rdpn6d_conv_bf16_tile_for(const rdpn6d_conv_desc* d, int* bm, int* bn);
+/* fp32-ACCURATE convolution on the bf16 matrix pipe ("bf16x3", csrc/conv_igemm_bf16x3.hip): every fp32 operand is held as
+ * three bf16 planes (a = a1 + a2 + a3, 24 significand bits) and a product is the six partial products a_i*b_j, i+j <= 4,
+ * accumulated in fp32 - the dropped terms are <= 2^-26 relative, below one fp32 rounding.  Same operator and descriptor as
+ * rdpn6d_conv2d_f32 (cuDNN fp32 convolution in the reference), with
+ *   d->x = plane 0 of the activation planes  [3][x_plane_elems] bf16 (each plane NHWC [B,H,W,in_cs]),
+ *   d->w = plane 0 of the packed weight planes [3][w_plane_elems] bf16 (each [Npad][ntaps][Cin]),
+ *   d->y = fp32 output (may be NULL), d->res = fp32 residual, y_planes = optional [3][y_plane_elems] bf16 planes of the
+ *   result (the next layer's input).  Requirements: rdpn6d_conv_bf16x3_eligible(d) != 0.
+ * rdpn6d_split_bf16x3 converts n fp32 values to the three planes (plane_elems >= n, multiple of 8). */
+int rdpn6d_split_bf16x3(const float* x, long long n, void* planes, long long plane_elems, void* stream);
+int rdpn6d_conv_bf16x3_eligible(const rdpn6d_conv_desc* d);
+int rdpn6d_conv2d_bf16x3(const rdpn6d_conv_desc* d, long long x_plane_elems, long long w_plane_elems, void* y_planes,
+                         long long y_plane_elems, void* stream); /* 256x128 | 128x128 | 128x64 | 64x128 | 64x64 */
 void rdpn6d_conv_bf16_force_chunk(int row_bytes); /* profiling: 0 = auto, 64 forces 32-channel K-chunks (measured slower) */
 /* bf16 forms of the kernels between the bf16 convolutions (same argument meaning as the _f32 entry points; activations
  * bf16 NHWC with C % 8 == 0; the stem and the xyz subsample read the fp32 NCHW crop and write bf16) */

@@ -240,6 +240,10 @@ class InferencePlan:
         self.mask_attention = cfg.MODEL.CDPN.PNP_NET.MASK_ATTENTION
         if self.mask_attention not in ("none", "mul"):
             raise ValueError(f"MASK_ATTENTION={self.mask_attention!r} is not implemented (none | mul)")
+        # fp32 mode: the wide head layers run as exact-product bf16x3 convolutions on the bf16 matrix pipe (fp32 accuracy,
+        # csrc/conv_igemm_bf16x3.hip) when the batch fills the chip; cfg.TEST.BF16X3 = False keeps them on the fp32 MFMA.
+        self.x3 = (not self.bf16) and bool(cfg.get("TEST", {}).get("BF16X3", True))
+        self.x3_launches = 0
         self._build(model)
 
     # ---- buffers
@@ -291,6 +295,56 @@ class InferencePlan:
         else:
             assert w.dtype == torch.float32, name
             self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_f32, (ctypes.byref(d),), keep=(d,)))
+
+    def x3_ok(self, M, N, cin, ntaps):
+        """use the bf16x3 kernel for a conv with M output rows?  One 256x256 tile per CU and round: it pays (1.66x per
+        tile-round against the fp32-MFMA kernel) when the last round is not mostly empty."""
+        if not self.x3 or N % 256 or cin % 16 or (ntaps * (cin // 16)) % 2:
+            return False
+        tiles = ((M + 255) // 256) * (N // 256)
+        rounds = (tiles + 255) // 256
+        return tiles >= 160 and tiles / (256.0 * rounds) >= 0.62
+
+    def split3(self, name, x, planes):
+        """launch: fp32 tensor -> its three bf16 planes ([3, plane_elems])"""
+        self.launches.append(_Launch(name, self.lib.rdpn6d_split_bf16x3, (_ptr(x), x.numel(), _ptr(planes), planes.shape[1])))
+
+    def weight_planes(self, w32):
+        """packed fp32 weights -> [3, n] bf16 planes (once, at plan time)"""
+        n = w32.numel()
+        wp = torch.empty(3, _pad_to(n, 8), dtype=torch.bfloat16, device=self.device)
+        _lib.check(self.lib.rdpn6d_split_bf16x3(_ptr(w32.contiguous()), n, _ptr(wp), wp.shape[1], None), "split weights")
+        torch.cuda.synchronize(self.device)
+        return wp
+
+    def conv_x3(self, name, xp, xshape, w32, scale, shift, y, yp, yshape, *, cin, in_cs, k=1, pad=0, N, out_cs, act=0,
+                slope=0.0, taps=None, phase=None):
+        """bf16x3 convolution: xp = input planes [3, >= B*H*W*in_cs]; y fp32 output or None; yp output planes or None."""
+        wp = self.weight_planes(w32)
+        d = _lib.ConvDesc()
+        d.x, d.w, d.scale, d.shift, d.res, d.y = _ptr(xp), _ptr(wp), _ptr(scale), _ptr(shift), None, _ptr(y)
+        d.B, d.H, d.W = self.B, xshape[0], xshape[1]
+        d.Cin, d.in_cs, d.in_co = cin, in_cs, 0
+        if taps is None:
+            taps = [(ky - pad, kx - pad) for ky in range(k) for kx in range(k)]
+        d.ntaps = len(taps)
+        for t, (dy, dx) in enumerate(taps):
+            d.dy[t], d.dx[t] = dy, dx
+        d.stride = 1
+        d.N, d.Npad = N, w32.shape[0]
+        d.OH, d.OW = yshape
+        if phase is None:
+            d.Ho, d.Wo, d.osy, d.osx, d.ooy, d.oox = yshape[0], yshape[1], 1, 1, 0, 0
+        else:
+            d.Ho, d.Wo, d.osy, d.osx, d.ooy, d.oox = phase
+        d.out_cs, d.out_co, d.res_cs, d.res_co = out_cs, 0, 0, 0
+        d.act, d.slope = act, slope
+        assert w32.shape[1] == d.ntaps and w32.shape[2] == cin and self.lib.rdpn6d_conv_bf16x3_eligible(ctypes.byref(d)), name
+        self.keep += [wp, scale, shift]
+        self.x3_launches += 1
+        self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_bf16x3,
+                                     (ctypes.byref(d), xp.shape[1], wp.shape[1], _ptr(yp), yp.shape[1] if yp is not None else 0),
+                                     keep=(d,)))
 
     def call(self, name, fn, *args):
         self.launches.append(_Launch(name, fn, args))
@@ -406,6 +460,15 @@ class InferencePlan:
         hB = self.buf("head_b", B, R4, R4, F, dtype=adt)
         wt = head.features[0].weight.detach().float()  # (Cin, Cout, 3, 3)
         sct, sht = fold_bn(head.features[1], npad=_pad_to(F, 64))
+        Fp = _pad_to(F, 64)
+        x3_head = F == Fp and len(head.features) > 4 and self.x3_ok(B * R4 * R4, F, F, 9)  # the 3x3 layers of the head
+        x3_ct = x3_head and self.x3_ok(B * R8 * R8, F, 1024, 1)      # ... and the ConvTranspose phases (a quarter of the rows)
+        if x3_head:
+            pA = self.buf("head_planes_a", 3, B * R4 * R4 * F, dtype=torch.bfloat16)
+            pB = self.buf("head_planes_b", 3, B * R4 * R4 * F, dtype=torch.bfloat16)
+        if x3_ct:
+            pF = self.buf("feat_planes", 3, feat.numel(), dtype=torch.bfloat16)
+            self.split3("rot_head.split_feat", feat, pF)
         for py in (0, 1):
             for px in (0, 1):
                 ys = [(1, 0)] if py == 0 else [(0, 1), (2, 0)]  # (kernel index, input offset)
@@ -415,17 +478,33 @@ class InferencePlan:
                     for kx, dx in xs:
                         taps.append((dy, dx))
                         slabs.append(wt[:, :, ky, kx].t())  # (Cout, Cin)
-                wp = torch.zeros(_pad_to(F, 64), len(taps), 1024, **f32)
+                wp = torch.zeros(Fp, len(taps), 1024, **f32)
                 wp[:F] = torch.stack(slabs, dim=1)
-                self.conv(f"rot_head.convT.phase{py}{px}", feat, (R8, R8), wp.contiguous().to(adt), sct, sht, hA, (R4, R4),
-                          cin=1024, in_cs=1024, N=F, out_cs=F, act=1, taps=taps, phase=(R8, R8, 2, 2, py, px), lowp=lp)
+                if x3_ct:  # planes in, planes out (the fp32 tensor is never materialised)
+                    self.conv_x3(f"rot_head.convT.phase{py}{px}", pF, (R8, R8), wp.contiguous(), sct, sht, None, pA, (R4, R4),
+                                 cin=1024, in_cs=1024, N=F, out_cs=F, act=1, taps=taps, phase=(R8, R8, 2, 2, py, px))
+                else:
+                    self.conv(f"rot_head.convT.phase{py}{px}", feat, (R8, R8), wp.contiguous().to(adt), sct, sht, hA, (R4, R4),
+                              cin=1024, in_cs=1024, N=F, out_cs=F, act=1, taps=taps, phase=(R8, R8, 2, 2, py, px), lowp=lp)
+        if x3_head and not x3_ct:
+            self.split3("rot_head.split_convT", hA, pA)
         a, b = hA, hB
+        pa, pb = (pA, pB) if x3_head else (None, None)
         nfeat = len(head.features)
-        for i in range(3, nfeat - 1, 3):
-            wh = pw(head.features[i].weight.detach().float())
-            sch, shh = fold_bn(head.features[i + 1], npad=wh.shape[0])
-            self.conv(f"rot_head.features.{i}", a, (R4, R4), wh, sch, shh, b, (R4, R4), cin=F, in_cs=F, k=3, stride=1,
-                      pad=1, N=F, out_cs=F, act=1, lowp=lp)
+        convs = list(range(3, nfeat - 1, 3))
+        for i in convs:
+            if x3_head:  # planes -> planes; the last layer writes the fp32 tensor the 1x1 output convolution reads
+                w32 = pack_conv_weight(head.features[i].weight.detach().float())
+                sch, shh = fold_bn(head.features[i + 1], npad=w32.shape[0])
+                is_last = i == convs[-1]
+                self.conv_x3(f"rot_head.features.{i}", pa, (R4, R4), w32, sch, shh, b if is_last else None,
+                             None if is_last else pb, (R4, R4), cin=F, in_cs=F, k=3, pad=1, N=F, out_cs=F, act=1)
+                pa, pb = pb, pa
+            else:
+                wh = pw(head.features[i].weight.detach().float())
+                sch, shh = fold_bn(head.features[i + 1], npad=wh.shape[0])
+                self.conv(f"rot_head.features.{i}", a, (R4, R4), wh, sch, shh, b, (R4, R4), cin=F, in_cs=F, k=3, stride=1,
+                          pad=1, N=F, out_cs=F, act=1, lowp=lp)
             a, b = b, a
         last = head.features[nfeat - 1]
         nout = last.weight.shape[0]

@@ -68,6 +68,60 @@ def conv2d_nhwc(x, weight, scale=None, shift=None, stride=1, pad=0, residual=Non
     return out
 
 
+def split_bf16x3(x):
+    """fp32 tensor -> [3, *x.shape] bf16 planes with x == p0 + p1 + p2 to 2^-27 (input format of conv2d_nhwc_x3)."""
+    _need_gpu(x)
+    x = x.contiguous()
+    n = x.numel()
+    pe = _pad_to(n, 8)
+    planes = torch.empty(3, pe, dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.load().rdpn6d_split_bf16x3(_ptr(x), n, _ptr(planes), pe, _stream()), "split_bf16x3")
+    return planes
+
+
+def conv2d_nhwc_x3(x, weight, scale=None, shift=None, stride=1, pad=0, residual=None, act=0, slope=0.0, want_planes=False):
+    """fp32-accurate convolution on the bf16 matrix pipe (rdpn6d_conv2d_bf16x3): x NHWC fp32 [B,H,W,C] or its planes from
+    split_bf16x3 / a previous call (tuple (planes, shape)); weight OIHW fp32.  Returns y fp32 NHWC and, with want_planes,
+    (planes, shape) of y for the next layer."""
+    lib = _lib.load()
+    if isinstance(x, tuple):
+        xp, (B, H, W, cs) = x
+    else:
+        B, H, W, cs = x.shape
+        xp = split_bf16x3(x)
+    _need_gpu(xp, weight, scale, shift, residual)
+    N, wcin, k, _ = weight.shape
+    cin_pad = _pad_to(wcin, 16)
+    assert cin_pad <= cs
+    wp32 = pack_conv_weight(weight.float(), cin_pad=cin_pad)
+    wp = split_bf16x3(wp32)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    out = torch.empty(B, Ho, Wo, N, dtype=torch.float32, device=xp.device)
+    npe = _pad_to(out.numel(), 8)
+    yp = torch.empty(3, npe, dtype=torch.bfloat16, device=xp.device) if want_planes else None
+    sc = _pad_vec(scale.float(), wp32.shape[0], 1.0) if scale is not None else None
+    sh = _pad_vec(shift.float(), wp32.shape[0], 0.0) if shift is not None else None
+    d = _lib.ConvDesc()
+    d.x, d.w, d.scale, d.shift, d.res, d.y = _ptr(xp), _ptr(wp), _ptr(sc), _ptr(sh), _ptr(residual), _ptr(out)
+    d.B, d.H, d.W, d.Cin, d.in_cs, d.in_co = B, H, W, cin_pad, cs, 0
+    d.Ho, d.Wo, d.stride = Ho, Wo, stride
+    taps = [(ky - pad, kx - pad) for ky in range(k) for kx in range(k)]
+    d.ntaps = len(taps)
+    for t, (dy, dx) in enumerate(taps):
+        d.dy[t], d.dx[t] = dy, dx
+    d.N, d.Npad, d.OH, d.OW = N, wp32.shape[0], Ho, Wo
+    d.osy = d.osx = 1
+    d.ooy = d.oox = 0
+    d.out_cs, d.out_co = N, 0
+    if residual is not None:
+        d.res_cs, d.res_co = residual.shape[-1], 0
+    d.act, d.slope = act, slope
+    if not lib.rdpn6d_conv_bf16x3_eligible(ctypes.byref(d)):
+        raise ValueError("layer not eligible for the bf16x3 kernel (Cin % 16, N % 256, even K-tile count)")
+    _lib.check(lib.rdpn6d_conv2d_bf16x3(ctypes.byref(d), xp.shape[1], wp.shape[1], _ptr(yp), npe, _stream()), "conv2d_bf16x3")
+    return (out, (yp, tuple(out.shape))) if want_planes else out
+
+
 def stem_conv7x7(x_nchw, weight, scale, shift):
     _need_gpu(x_nchw, weight, scale, shift)
     B, xc, R, _ = x_nchw.shape

@@ -963,3 +963,64 @@ def test_full_bench_batch_b64_properties(golden_setup, truth, dev, bf16):
         copies_identical({k: v.clone() for k, v in o.items() if torch.is_tensor(v)}, ("rot", "trans"))
     finally:
         tcfg.AMP_TEST, tcfg.USE_PNP = old_amp, old_pnp
+
+
+BF16X3_CASES = [
+    # B, H, Cin, Cout, k, stride, res, act
+    (2, 32, 256, 256, 3, 1, True, 1),     # head layer shape (8 tiles)
+    (3, 30, 64, 256, 3, 1, False, 2),     # ragged M (2700 rows), odd size, leaky
+    (2, 32, 32, 512, 1, 1, True, 0),      # 1x1, two K-tiles (prologue + tail only), two column tiles
+    (2, 32, 128, 256, 3, 2, False, 1),    # stride 2
+    (1, 16, 1024, 256, 3, 1, False, 0),   # K = 9216
+]
+
+
+@pytest.mark.parametrize("case", BF16X3_CASES)
+def test_conv_bf16x3_has_fp32_accuracy(dev, case):
+    """rdpn6d_conv2d_bf16x3 (three bf16 planes per operand, six partial products on the bf16 matrix pipe) against an fp64
+    convolution: its error must be no larger than the fp32-MFMA kernel's own (both are fp32-accumulated sums of products
+    that are exact resp. correctly rounded), i.e. the kernel is an fp32 convolution, not a reduced-precision one.  Also: the
+    three output planes re-assemble the fp32 output to 2^-24, and a second launch fed with those planes (layer chaining)
+    equals a launch fed with the fp32 tensor."""
+    from rdpn6d_amd import ops
+
+    B, H, Cin, Cout, k, stride, use_res, act = case
+    g = torch.Generator().manual_seed(sum(case) * 11 + 3)
+    x = torch.randn(B, H, H, Cin, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    Ho = (H + 2 * (k // 2) - k) // stride + 1
+    res = torch.randn(B, Ho, Ho, Cout, generator=g) if use_res else None
+    # fp64 reference
+    y64 = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double(), stride=stride, padding=k // 2).permute(0, 2, 3, 1)
+    y64 = y64 * sc.double() + sh.double()
+    if use_res:
+        y64 = y64 + res.double()
+    if act == 1:
+        y64 = y64.clamp(min=0)
+    elif act == 2:
+        y64 = torch.where(y64 > 0, y64, y64 * 0.1)
+    kw = dict(stride=stride, pad=k // 2, act=act, slope=0.1)
+    xd, wd, scd, shd = x.to(dev), w.to(dev), sc.to(dev), sh.to(dev)
+    resd = res.to(dev) if use_res else None
+    y32 = ops.conv2d_nhwc(xd, wd, scd, shd, residual=resd, **kw)
+    yx3, (planes, shape) = ops.conv2d_nhwc_x3(xd, wd, scd, shd, residual=resd, want_planes=True, **kw)
+    torch.cuda.synchronize()
+    e32 = (y32.cpu().double() - y64).abs()
+    ex3 = (yx3.cpu().double() - y64).abs()
+    scale = y64.abs().max().item()
+    print(f"{case}: max err vs fp64  fp32-MFMA {e32.max().item():.3e}  bf16x3 {ex3.max().item():.3e}  "
+          f"(rms {e32.pow(2).mean().sqrt().item():.2e} / {ex3.pow(2).mean().sqrt().item():.2e}, |y|max {scale:.2f})")
+    assert ex3.max().item() <= 1.5 * e32.max().item() + 1e-7 * scale
+    assert ex3.pow(2).mean().sqrt().item() <= 1.5 * e32.pow(2).mean().sqrt().item() + 1e-8 * scale
+    # the planes of the output
+    n = yx3.numel()
+    back = planes[:, :n].float().sum(0).reshape(shape)
+    assert (back - yx3).abs().max().item() <= 2.0 ** -23 * scale
+    if Cout % 16 == 0 and k == 3 and stride == 1:
+        # chain: y -> next conv, once from the fp32 tensor (split on the fly) and once from the planes the kernel wrote
+        w2 = (torch.randn(256, Cout, 3, 3, generator=g) / (Cout * 9) ** 0.5).to(dev)
+        a1 = ops.conv2d_nhwc_x3(yx3, w2, pad=1)
+        a2 = ops.conv2d_nhwc_x3((planes, shape), w2, pad=1)
+        torch.cuda.synchronize()
+        assert torch.equal(a1, a2)
