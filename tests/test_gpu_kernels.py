@@ -1024,3 +1024,40 @@ def test_conv_bf16x3_has_fp32_accuracy(dev, case):
         a2 = ops.conv2d_nhwc_x3((planes, shape), w2, pad=1)
         torch.cuda.synchronize()
         assert torch.equal(a1, a2)
+
+
+def test_fp32_plan_uses_bf16x3_head_only_when_it_pays_and_matches_the_fp32_mfma_path(golden_setup, truth, dev):
+    """fp32 mode: at B = 16 / 64 the head's wide layers run as bf16x3 convolutions (cfg.TEST.BF16X3, default on), at B = 4
+    they stay on the fp32 MFMA pipe.  Both paths are fp32 evaluations of the same network: against the fp64 oracle the
+    bf16x3 path must be no further away than the fp32-MFMA path (x1.25 + noise floor), and close to it."""
+    models, t, gold = golden_setup
+    model = models["mul"]
+    assert model.plan(4, dev).x3_launches == 0
+    rep = torch.arange(16, device=dev) % 4
+    t16 = {k: (v[rep].contiguous() if v.shape[0] == 4 else v) for k, v in t.items()}
+    tcfg = model.cfg.TEST
+    outs = {}
+    try:
+        for x3 in (True, False):
+            tcfg.BF16X3 = x3
+            model._plans.clear()
+            # six 3x3 layers (the ConvTranspose phases have a quarter of the rows: fp32 MFMA + a split pass at this batch)
+            assert model.plan(16, dev).x3_launches == (6 if x3 else 0)
+            o = _run(model, t16)
+            outs[x3] = {k: o[k].clone().cpu().double() for k in ("mask", "coor_x", "coor_y", "coor_z", "region", "rot", "trans")}
+    finally:
+        tcfg.BF16X3 = True
+        model._plans.clear()
+    for k in ("mask", "coor_x", "coor_y", "coor_z", "region"):
+        exact = truth["mul"][k].double()
+        e3 = (outs[True][k][:4] - exact).abs().max().item()
+        e1 = (outs[False][k][:4] - exact).abs().max().item()
+        dd = (outs[True][k] - outs[False][k]).abs().max().item()
+        print(f"{k}: vs fp64  bf16x3 path {e3:.3e}  fp32-MFMA path {e1:.3e}   between the two {dd:.3e}")
+        assert e3 <= 1.25 * e1 + 1e-5 and dd <= 2.0 * e1 + 1e-5, k
+    for k in ("rot", "trans"):
+        exact = truth["mul"][k].double()
+        e3 = max(_rel(outs[True][k][i].numpy(), exact[i].numpy()) for i in range(4))
+        e1 = max(_rel(outs[False][k][i].numpy(), exact[i].numpy()) for i in range(4))
+        print(f"{k}: worst rel err vs fp64  bf16x3 path {e3:.3e}  fp32-MFMA path {e1:.3e}")
+        assert e3 <= 2.0 * max(e1, 1e-4), k
