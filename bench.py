@@ -12,9 +12,10 @@ point-wise depth fusion -> dense mask/residual/region head -> glue -> ConvPnPNet
 runs its own batch ("weak" scaling); value = all ranks' crops / max-over-ranks time.
 
 Prints ONE JSON line (rank 0) with the driver's contract plus
-  "roofline"     - the dominant kernel (conv_igemm_f32_kernel<128,128>) timed live with events on the
-                   launch stream: algorithmic FLOPs of its launches / their total duration vs the fp32
-                   MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md);
+  "roofline"     - the dominant kernel (the conv kernel instance that carries most of the step's FLOPs: the fp32-accurate
+                   bf16x3 kernel by default, conv_igemm_f32_kernel<128,128> with --no-x3, the 8-phase bf16 kernel with
+                   --dtype bf16) timed live with events on the launch stream: algorithmic FLOPs of its launches / their
+                   total duration vs its MFMA ceiling (416.7 = 2500/6, 157.3, 2500 TFLOP/s; MI355X_MICROARCH.md);
   "cpu_baseline" - the torch-CPU oracle (a port of the reference path, pinned to it by golden vectors)
                    timed on this box's host cores on a bounded sample of the same workload.
 """

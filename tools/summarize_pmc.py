@@ -18,7 +18,8 @@ for n in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES"):
         d[0] += 1; d[1] += float(r["Counter_Value"]); d[2] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 out = {}
 for k, v in agg.items():
-    if not k.replace("(anonymous namespace)::", "").startswith(("void conv_igemm", "stem_", "maxpool", "global_max", "upsample", "void dense_glue", "groupnorm", "ransac")):
+    kk = k.replace("void ", "").replace("(anonymous namespace)::", "")
+    if not kk.startswith(("conv_igemm", "stem_", "maxpool", "global_max", "upsample", "dense_glue", "groupnorm", "ransac")):
         continue
     m = {c: s / n for c, (n, s, t) in v.items()}
     us = v["FETCH_SIZE"][2] / v["FETCH_SIZE"][0] / 1e3
