@@ -110,8 +110,13 @@ int rdpn6d_conv_bf16_tile_for(const rdpn6d_conv_desc* d, int* bm, int* bn);
  * rdpn6d_split_bf16x3 converts n fp32 values to the three planes (plane_elems >= n, multiple of 8). */
 int rdpn6d_split_bf16x3(const float* x, long long n, void* planes, long long plane_elems, void* stream);
 int rdpn6d_conv_bf16x3_eligible(const rdpn6d_conv_desc* d);
+/* which kernel would run: 2 = 256x256 8-phase (N % 256 == 0, >= 160 tiles), 1 = 128x128..64x64 tile kernel, 0 = none */
+int rdpn6d_conv_bf16x3_kernel_for(const rdpn6d_conv_desc* d);
 int rdpn6d_conv2d_bf16x3(const rdpn6d_conv_desc* d, long long x_plane_elems, long long w_plane_elems, void* y_planes,
-                         long long y_plane_elems, void* stream); /* 256x128 | 128x128 | 128x64 | 64x128 | 64x64 */
+                         long long y_plane_elems, void* stream);
+/* ... with the residual given as three bf16 planes [3][res_plane_elems] (geometry d->res_cs / d->res_co, d->res == NULL) */
+int rdpn6d_conv2d_bf16x3_ex(const rdpn6d_conv_desc* d, long long x_plane_elems, long long w_plane_elems, void* y_planes,
+                            long long y_plane_elems, const void* res_planes, long long res_plane_elems, void* stream); /* 256x128 | 128x128 | 128x64 | 64x128 | 64x64 */
 void rdpn6d_conv_bf16_force_chunk(int row_bytes); /* profiling: 0 = auto, 64 forces 32-channel K-chunks (measured slower) */
 /* bf16 forms of the kernels between the bf16 convolutions (same argument meaning as the _f32 entry points; activations
  * bf16 NHWC with C % 8 == 0; the stem and the xyz subsample read the fp32 NCHW crop and write bf16) */

@@ -49,6 +49,8 @@ SIGNATURES = {
     "rdpn6d_split_bf16x3": (_i, [_vp, _ll, _vp, _ll, _vp]),
     "rdpn6d_conv_bf16x3_eligible": (_i, [ctypes.POINTER(ConvDesc)]),
     "rdpn6d_conv2d_bf16x3": (_i, [ctypes.POINTER(ConvDesc), _ll, _ll, _vp, _ll, _vp]),
+    "rdpn6d_conv_bf16x3_kernel_for": (_i, [ctypes.POINTER(ConvDesc)]),
+    "rdpn6d_conv2d_bf16x3_ex": (_i, [ctypes.POINTER(ConvDesc), _ll, _ll, _vp, _ll, _vp, _ll, _vp]),
     "rdpn6d_conv_bf16_force_chunk": (None, [_i]),
     "rdpn6d_stem_conv7x7_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "rdpn6d_maxpool3x3s2_bf16": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),

@@ -15,17 +15,9 @@
 // A half-tile is 12 one-KiB DMA pieces (3 planes x 4 blocks of 32 rows): wave w moves piece (plane w>>2, block w&3) and,
 // for w < 4, piece (plane 2, block w) - group 0 issues two pieces per phase and waits with vmcnt(8), group 1 one and
 // vmcnt(4); both keep the four newest half-tiles in flight.
-#include "conv_bf16_common.h"
+#include "conv_x3_args.h"
 
 #include <type_traits>
-
-struct ConvX3Args {
-    ConvBArgs b;             // d.x / d.w = plane 0 of the bf16 planes; b.out_f32 = 1 (d.y fp32, may be null when only planes)
-    unsigned x_plane_bytes;  // distance between activation planes
-    unsigned w_plane_bytes;  // distance between weight planes
-    void* y_planes;          // optional: the result as three bf16 planes (input of the next bf16x3 layer) or null
-    long long y_plane_elems;
-};
 
 namespace {
 
@@ -36,16 +28,6 @@ constexpr int X3_LDS = X3_STAGE_BYTES > X3_EPI_BYTES ? X3_STAGE_BYTES : X3_EPI_B
 
 template <int V>
 using ic = std::integral_constant<int, V>;
-
-// fp32 -> three bf16 terms (round to nearest even each; the remainders are exact in fp32)
-__device__ __forceinline__ void split3(const float v, bf16_t& t1, bf16_t& t2, bf16_t& t3)
-{
-    t1 = f2bf(v);
-    const float r1 = v - bf2f(t1);
-    t2 = f2bf(r1);
-    const float r2 = r1 - bf2f(t2);
-    t3 = f2bf(r2);
-}
 
 __global__ __launch_bounds__(512) void conv_igemm_bf16x3_kernel(const ConvX3Args ax)
 {
@@ -294,7 +276,6 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16x3_kernel(const ConvX3Args
             scj[j] = d.scale ? d.scale[n] : 1.f;
             shj[j] = d.shift ? d.shift[n] : 0.f;
         }
-        bf16_t* yp = reinterpret_cast<bf16_t*>(ax.y_planes);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -313,35 +294,7 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16x3_kernel(const ConvX3Args
                 const f32x4 lo = *reinterpret_cast<const f32x4*>(cst + row * CS + c8);
                 const f32x4 hi4 = *reinterpret_cast<const f32x4*>(cst + row * CS + c8 + 4);
                 float v[8] = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
-                if (d.res) {
-                    const float* rp = d.res + pix * d.res_cs + d.res_co + nb + c8;
-                    const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        v[q] += r0[q];
-                        v[4 + q] += r1[q];
-                    }
-                }
-                conv_bf16_act(v, d.act, d.slope);
-                if (d.y) {
-                    float* op = d.y + pix * d.out_cs + d.out_co + nb + c8;
-                    const f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-                    *reinterpret_cast<f32x4*>(op) = o0;
-                    *reinterpret_cast<f32x4*>(op + 4) = o1;
-                }
-                if (yp) {
-                    bf16_t t[3][8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) split3(v[q], t[0][q], t[1][q], t[2][q]);
-                    bf16_t* pp = yp + pix * d.out_cs + d.out_co + nb + c8;
-#pragma unroll
-                    for (int p = 0; p < 3; ++p) {
-                        rd_u32x4 u;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) u[q] = (unsigned)t[p][2 * q] | ((unsigned)t[p][2 * q + 1] << 16);
-                        *reinterpret_cast<rd_u32x4*>(pp + p * ax.y_plane_elems) = u;
-                    }
-                }
+                x3_finish_row8(ax, v, pix, nb + c8);
             }
         }
     }
@@ -355,7 +308,7 @@ __global__ void split_bf16x3_kernel(const float* __restrict__ x, long long n, bf
         const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * i);
         bf16_t t[3][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) split3(v[q], t[0][q], t[1][q], t[2][q]);
+        for (int q = 0; q < 4; ++q) rd_split3(v[q], t[0][q], t[1][q], t[2][q]);
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             uint2 u;
@@ -365,7 +318,7 @@ __global__ void split_bf16x3_kernel(const float* __restrict__ x, long long n, bf
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0)
-        for (long long i = n4 * 4; i < n; ++i) split3(x[i], planes[i], planes[plane_elems + i], planes[2 * plane_elems + i]);
+        for (long long i = n4 * 4; i < n; ++i) rd_split3(x[i], planes[i], planes[plane_elems + i], planes[2 * plane_elems + i]);
 }
 
 }  // namespace
@@ -380,23 +333,53 @@ extern "C" int rdpn6d_split_bf16x3(const float* x, long long n, void* planes, lo
     return RDPN6D_OK;
 }
 
-// 1 when rdpn6d_conv2d_bf16x3 can run the layer (the caller decides whether it should)
-extern "C" int rdpn6d_conv_bf16x3_eligible(const rdpn6d_conv_desc* d)
+// conv_igemm_bf16x3_tile.hip: 128x128 .. 64x64 tiles for the narrow / short layers
+void conv_x3_pick_tile(const rdpn6d_conv_desc* d, long long M, int* pbm, int* pbn);
+int conv_x3_launch_tile(ConvX3Args& ax, int bm, int bn, hipStream_t s);
+
+static bool x3_common_ok(const rdpn6d_conv_desc* d)
 {
-    if (!d) return 0;
+    return d->Cin % 16 == 0 && d->in_cs % 8 == 0 && d->in_co % 8 == 0 && d->out_cs % 8 == 0 && d->out_co % 8 == 0 &&
+           (!d->res || (d->res_cs % 4 == 0 && d->res_co % 4 == 0));
+}
+// the 256x256 8-phase kernel can run the layer
+static bool x3_big_ok(const rdpn6d_conv_desc* d)
+{
     const int nk = d->ntaps * (d->Cin / 16);
-    return d->Cin % 16 == 0 && d->Npad % 256 == 0 && d->N == d->Npad && nk >= 2 && (nk & 1) == 0 && d->in_cs % 8 == 0 &&
-           d->in_co % 8 == 0 && d->out_cs % 8 == 0 && d->out_co % 8 == 0 && (!d->res || (d->res_cs % 4 == 0 && d->res_co % 4 == 0));
+    return x3_common_ok(d) && d->Npad % 256 == 0 && d->N == d->Npad && nk >= 2 && (nk & 1) == 0;
+}
+// ... and should: at least 160 tiles and a last round of tiles (one per CU) that is not mostly empty
+static bool x3_big_pays(const rdpn6d_conv_desc* d, long long M)
+{
+    const long long tiles = (long long)rd_cdiv(M, 256) * (d->Npad / 256);
+    const long long rounds = (tiles + 255) / 256;
+    return tiles >= 160 && (double)tiles >= 0.62 * 256.0 * (double)rounds;
 }
 
-extern "C" int rdpn6d_conv2d_bf16x3(const rdpn6d_conv_desc* d, long long x_plane_elems, long long w_plane_elems, void* y_planes,
-                                    long long y_plane_elems, void* stream)
+// which bf16x3 kernel rdpn6d_conv2d_bf16x3[_ex] would use: 2 = 256x256 8-phase, 1 = 128x128..64x64 tile kernel, 0 = none
+extern "C" int rdpn6d_conv_bf16x3_kernel_for(const rdpn6d_conv_desc* d)
+{
+    if (!d || !x3_common_ok(d)) return 0;
+    const long long M = (long long)d->B * d->Ho * d->Wo;
+    if (x3_big_ok(d) && x3_big_pays(d, M)) return 2;
+    int bm, bn;
+    conv_x3_pick_tile(d, M, &bm, &bn);
+    if (bm) return 1;
+    return x3_big_ok(d) ? 2 : 0;
+}
+extern "C" int rdpn6d_conv_bf16x3_eligible(const rdpn6d_conv_desc* d) { return rdpn6d_conv_bf16x3_kernel_for(d) != 0; }
+
+extern "C" int rdpn6d_conv2d_bf16x3_ex(const rdpn6d_conv_desc* d, long long x_plane_elems, long long w_plane_elems, void* y_planes,
+                                       long long y_plane_elems, const void* res_planes, long long res_plane_elems, void* stream)
 {
     RD_REQUIRE(d && d->x && d->w && (d->y || y_planes), "null pointer");
-    RD_REQUIRE(rdpn6d_conv_bf16x3_eligible(d), "bf16x3 needs Cin % 16 == 0, N % 256 == 0, an even K-tile count, 16-byte aligned slices");
+    const int which = rdpn6d_conv_bf16x3_kernel_for(d);
+    RD_REQUIRE(which != 0, "bf16x3 needs Cin % 16 == 0 (% 32 for 64-wide tiles), Npad % 64 == 0, N % 8 == 0, 16-byte aligned slices");
     RD_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0 && d->ntaps >= 1 && d->ntaps <= 9, "shape");
     RD_REQUIRE(d->in_co + d->Cin <= d->in_cs && d->out_co + d->N <= d->out_cs, "channel slices");
     RD_REQUIRE((d->Ho - 1) * d->osy + d->ooy < d->OH && (d->Wo - 1) * d->osx + d->oox < d->OW, "output geometry");
+    RD_REQUIRE(!(d->res && res_planes), "residual either as an fp32 tensor or as planes");
+    RD_REQUIRE(!res_planes || (d->res_cs % 8 == 0 && d->res_co % 8 == 0 && d->res_co + d->N <= d->res_cs), "residual planes slice");
     ConvX3Args ax;
     ConvBArgs& a = ax.b;
     a.d = *d;
@@ -414,29 +397,48 @@ extern "C" int rdpn6d_conv2d_bf16x3(const rdpn6d_conv_desc* d, long long x_plane
     const long long w_elems = (long long)d->Npad * d->ntaps * d->Cin;
     RD_REQUIRE(w_plane_elems >= w_elems && (2 * w_plane_elems + w_elems) * 2 < (1LL << 32) - 64, "weight planes (32-bit offsets)");
     RD_REQUIRE(!y_planes || y_plane_elems >= (long long)d->B * d->OH * d->OW * d->out_cs, "output planes");
+    RD_REQUIRE(!res_planes || res_plane_elems >= (long long)d->B * d->OH * d->OW * d->res_cs, "residual planes");
     a.x_bytes = (unsigned)((2 * x_plane_elems + in_elems) * 2);
     a.w_bytes = (unsigned)((2 * w_plane_elems + w_elems) * 2);
     ax.x_plane_bytes = (unsigned)(x_plane_elems * 2);
     ax.w_plane_bytes = (unsigned)(w_plane_elems * 2);
     ax.y_planes = y_planes;
     ax.y_plane_elems = y_plane_elems;
+    ax.res_planes = res_planes;
+    ax.res_plane_elems = res_plane_elems;
     a.dy_pack = a.dx_pack = 0;
     for (int t = 0; t < d->ntaps; ++t) {
         RD_REQUIRE(d->dy[t] >= -8 && d->dy[t] <= 7 && d->dx[t] >= -8 && d->dx[t] <= 7, "tap offsets must be in -8..7");
         a.dy_pack |= (unsigned long long)(d->dy[t] + 8) << (4 * t);
         a.dx_pack |= (unsigned long long)(d->dx[t] + 8) << (4 * t);
     }
+    a.kper = 0;
+    a.partial = nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    if (which == 1) {
+        int bm, bn;
+        conv_x3_pick_tile(d, a.M, &bm, &bn);
+        const int rc = conv_x3_launch_tile(ax, bm, bn, s);
+        if (rc != RDPN6D_OK) return rc;
+        RD_LAUNCH_CHECK();
+        return RDPN6D_OK;
+    }
     a.mtiles = rd_cdiv(a.M, 256);
     a.ntiles = d->Npad / 256;
     a.kper = a.nk;
-    a.partial = nullptr;
     static bool configured = false;
     if (!configured) {
         RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_bf16x3_kernel),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS));
         configured = true;
     }
-    hipLaunchKernelGGL(conv_igemm_bf16x3_kernel, dim3((unsigned)(a.mtiles * a.ntiles)), dim3(512), X3_LDS, (hipStream_t)stream, ax);
+    hipLaunchKernelGGL(conv_igemm_bf16x3_kernel, dim3((unsigned)(a.mtiles * a.ntiles)), dim3(512), X3_LDS, s, ax);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
+}
+
+extern "C" int rdpn6d_conv2d_bf16x3(const rdpn6d_conv_desc* d, long long x_plane_elems, long long w_plane_elems, void* y_planes,
+                                    long long y_plane_elems, void* stream)
+{
+    return rdpn6d_conv2d_bf16x3_ex(d, x_plane_elems, w_plane_elems, y_planes, y_plane_elems, nullptr, 0, stream);
 }

@@ -317,9 +317,10 @@ class InferencePlan:
         torch.cuda.synchronize(self.device)
         return wp
 
-    def conv_x3(self, name, xp, xshape, w32, scale, shift, y, yp, yshape, *, cin, in_cs, k=1, pad=0, N, out_cs, act=0,
-                slope=0.0, taps=None, phase=None):
-        """bf16x3 convolution: xp = input planes [3, >= B*H*W*in_cs]; y fp32 output or None; yp output planes or None."""
+    def conv_x3(self, name, xp, xshape, w32, scale, shift, y, yp, yshape, *, cin, in_cs, k=1, stride=1, pad=0, N, out_cs, act=0,
+                slope=0.0, taps=None, phase=None, res_planes=None, res_cs=0):
+        """bf16x3 convolution: xp = input planes [3, >= B*H*W*in_cs]; y fp32 output or None; yp output planes or None;
+        res_planes = the residual as planes (output geometry, res_cs channels per pixel)."""
         wp = self.weight_planes(w32)
         d = _lib.ConvDesc()
         d.x, d.w, d.scale, d.shift, d.res, d.y = _ptr(xp), _ptr(wp), _ptr(scale), _ptr(shift), None, _ptr(y)
@@ -330,20 +331,21 @@ class InferencePlan:
         d.ntaps = len(taps)
         for t, (dy, dx) in enumerate(taps):
             d.dy[t], d.dx[t] = dy, dx
-        d.stride = 1
+        d.stride = stride
         d.N, d.Npad = N, w32.shape[0]
         d.OH, d.OW = yshape
         if phase is None:
             d.Ho, d.Wo, d.osy, d.osx, d.ooy, d.oox = yshape[0], yshape[1], 1, 1, 0, 0
         else:
             d.Ho, d.Wo, d.osy, d.osx, d.ooy, d.oox = phase
-        d.out_cs, d.out_co, d.res_cs, d.res_co = out_cs, 0, 0, 0
+        d.out_cs, d.out_co, d.res_cs, d.res_co = out_cs, 0, res_cs, 0
         d.act, d.slope = act, slope
         assert w32.shape[1] == d.ntaps and w32.shape[2] == cin and self.lib.rdpn6d_conv_bf16x3_eligible(ctypes.byref(d)), name
         self.keep += [wp, scale, shift]
         self.x3_launches += 1
-        self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_bf16x3,
-                                     (ctypes.byref(d), xp.shape[1], wp.shape[1], _ptr(yp), yp.shape[1] if yp is not None else 0),
+        self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_bf16x3_ex,
+                                     (ctypes.byref(d), xp.shape[1], wp.shape[1], _ptr(yp), yp.shape[1] if yp is not None else 0,
+                                      _ptr(res_planes), res_planes.shape[1] if res_planes is not None else 0),
                                      keep=(d,)))
 
     def call(self, name, fn, *args):
@@ -378,6 +380,15 @@ class InferencePlan:
 
         # --- residual trunk (BasicBlock: 3x3 - 3x3; Bottleneck: 1x1 - 3x3(s) - 1x1 x4; residual + ReLU in the last epilogue)
         cur, cur_hw, cur_c = p0, R4, 64
+        # fp32 mode, BasicBlock trunks, batches >= 16: the trunk's convolutions run as bf16x3 convolutions too (tile kernel,
+        # csrc/conv_igemm_bf16x3_tile.hip) and hand their activations on as three bf16 planes; the residual is read from
+        # planes as well (summed exactly), only the last block writes the fp32 tensor the up-sampling reads.
+        x3_trunk = self.x3 and not hasattr(bb.layer1[0], "conv3") and B * R4 * R4 >= 65536
+        self.x3_trunk = x3_trunk
+        pcur = None
+        if x3_trunk:
+            pcur = self.buf("pool_planes", 3, p0.numel(), dtype=torch.bfloat16)
+            self.split3("trunk.split_pool", p0, pcur)
         for li in range(4):
             layer = getattr(bb, f"layer{li + 1}")
             for bi, blk in enumerate(layer):
@@ -386,6 +397,30 @@ class InferencePlan:
                 s = (blk.conv2 if bottleneck else blk.conv1).stride
                 cout = (blk.conv3 if bottleneck else blk.conv2).weight.shape[0]
                 ohw = cur_hw // s
+                if x3_trunk:
+                    last = li == 3 and bi == len(layer) - 1
+                    npl = B * ohw * ohw * cout
+                    res_p = pcur
+                    if blk.downsample is not None:
+                        pds = self.buf(f"l{li}_ds_planes", 3, npl, dtype=torch.bfloat16)
+                        wd = pack_conv_weight(blk.downsample[0].weight.detach().float())
+                        scd, shd = fold_bn(blk.downsample[1], npad=wd.shape[0])
+                        self.conv_x3(f"{nm}.downsample", pcur, (cur_hw, cur_hw), wd, scd, shd, None, pds, (ohw, ohw), cin=cur_c,
+                                     in_cs=cur_c, k=1, stride=s, pad=0, N=cout, out_cs=cout, act=0)
+                        res_p = pds
+                    pt = self.buf(f"l{li}_t{bi % 2}_planes", 3, npl, dtype=torch.bfloat16)
+                    w1 = pack_conv_weight(blk.conv1.weight.detach().float())
+                    sc1, sh1 = fold_bn(blk.bn1, npad=w1.shape[0])
+                    self.conv_x3(f"{nm}.conv1", pcur, (cur_hw, cur_hw), w1, sc1, sh1, None, pt, (ohw, ohw), cin=cur_c, in_cs=cur_c,
+                                 k=3, stride=s, pad=1, N=cout, out_cs=cout, act=1)
+                    w2 = pack_conv_weight(blk.conv2.weight.detach().float())
+                    sc2, sh2 = fold_bn(blk.bn2, npad=w2.shape[0])
+                    o = self.buf(f"l{li}_o{bi % 2}", B, ohw, ohw, cout) if last else None
+                    po = None if last else self.buf(f"l{li}_o{bi % 2}_planes", 3, npl, dtype=torch.bfloat16)
+                    self.conv_x3(f"{nm}.conv2", pt, (ohw, ohw), w2, sc2, sh2, o, po, (ohw, ohw), cin=cout, in_cs=cout, k=3,
+                                 stride=1, pad=1, N=cout, out_cs=cout, act=1, res_planes=res_p, res_cs=cout)
+                    cur, pcur, cur_hw, cur_c = o, po, ohw, cout
+                    continue
                 res = cur
                 if blk.downsample is not None:
                     dsb = self.buf(f"l{li}_ds", B, ohw, ohw, cout, dtype=adt)

@@ -79,7 +79,8 @@ def split_bf16x3(x):
     return planes
 
 
-def conv2d_nhwc_x3(x, weight, scale=None, shift=None, stride=1, pad=0, residual=None, act=0, slope=0.0, want_planes=False):
+def conv2d_nhwc_x3(x, weight, scale=None, shift=None, stride=1, pad=0, residual=None, act=0, slope=0.0, want_planes=False,
+                   residual_planes=None):
     """fp32-accurate convolution on the bf16 matrix pipe (rdpn6d_conv2d_bf16x3): x NHWC fp32 [B,H,W,C] or its planes from
     split_bf16x3 / a previous call (tuple (planes, shape)); weight OIHW fp32.  Returns y fp32 NHWC and, with want_planes,
     (planes, shape) of y for the next layer."""
@@ -116,9 +117,14 @@ def conv2d_nhwc_x3(x, weight, scale=None, shift=None, stride=1, pad=0, residual=
     if residual is not None:
         d.res_cs, d.res_co = residual.shape[-1], 0
     d.act, d.slope = act, slope
+    rp = None
+    if residual_planes is not None:  # (planes, shape) of an NHWC tensor with the output's geometry
+        rp = residual_planes[0]
+        d.res_cs, d.res_co = residual_planes[1][-1], 0
     if not lib.rdpn6d_conv_bf16x3_eligible(ctypes.byref(d)):
-        raise ValueError("layer not eligible for the bf16x3 kernel (Cin % 16, N % 256, even K-tile count)")
-    _lib.check(lib.rdpn6d_conv2d_bf16x3(ctypes.byref(d), xp.shape[1], wp.shape[1], _ptr(yp), npe, _stream()), "conv2d_bf16x3")
+        raise ValueError("layer not eligible for the bf16x3 kernels (Cin % 16, N % 8, aligned slices)")
+    _lib.check(lib.rdpn6d_conv2d_bf16x3_ex(ctypes.byref(d), xp.shape[1], wp.shape[1], _ptr(yp), npe, _ptr(rp),
+                                           rp.shape[1] if rp is not None else 0, _stream()), "conv2d_bf16x3")
     return (out, (yp, tuple(out.shape))) if want_planes else out
 
 

@@ -972,6 +972,13 @@ BF16X3_CASES = [
     (2, 32, 32, 512, 1, 1, True, 0),      # 1x1, two K-tiles (prologue + tail only), two column tiles
     (2, 32, 128, 256, 3, 2, False, 1),    # stride 2
     (1, 16, 1024, 256, 3, 1, False, 0),   # K = 9216
+    # the 128x128 .. 64x64 tile kernel (narrow outputs / few rows)
+    (8, 32, 64, 64, 3, 1, True, 1),       # trunk layer1 shape: N = 64 -> 128x64 tiles, 32-channel chunks
+    (4, 32, 128, 128, 3, 1, True, 1),     # layer2 shape -> 128x128 tiles, 16-channel chunks
+    (2, 16, 64, 128, 3, 2, False, 1),     # stride-2 entry conv of a stage, 64-row tiles
+    (2, 16, 64, 128, 1, 2, False, 0),     # 1x1 stride-2 downsample: two K-chunks only
+    (3, 7, 512, 512, 3, 1, True, 1),      # layer4 shape: odd size, ragged rows, K = 4608
+    (2, 16, 48, 128, 3, 1, False, 2),     # Cin % 32 != 0: only the 128x128 tile (16-channel chunks) can take it
 ]
 
 
@@ -1006,6 +1013,10 @@ def test_conv_bf16x3_has_fp32_accuracy(dev, case):
     y32 = ops.conv2d_nhwc(xd, wd, scd, shd, residual=resd, **kw)
     yx3, (planes, shape) = ops.conv2d_nhwc_x3(xd, wd, scd, shd, residual=resd, want_planes=True, **kw)
     torch.cuda.synchronize()
+    if use_res:  # the residual handed over as planes (what chained trunk layers do) must give the same bits
+        yr = ops.conv2d_nhwc_x3(xd, wd, scd, shd, residual_planes=(ops.split_bf16x3(resd), tuple(resd.shape)), **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(yr, yx3)
     e32 = (y32.cpu().double() - y64).abs()
     ex3 = (yx3.cpu().double() - y64).abs()
     scale = y64.abs().max().item()
@@ -1017,7 +1028,7 @@ def test_conv_bf16x3_has_fp32_accuracy(dev, case):
     n = yx3.numel()
     back = planes[:, :n].float().sum(0).reshape(shape)
     assert (back - yx3).abs().max().item() <= 2.0 ** -23 * scale
-    if Cout % 16 == 0 and k == 3 and stride == 1:
+    if Cout % 32 == 0 and k == 3 and stride == 1:
         # chain: y -> next conv, once from the fp32 tensor (split on the fly) and once from the planes the kernel wrote
         w2 = (torch.randn(256, Cout, 3, 3, generator=g) / (Cout * 9) ** 0.5).to(dev)
         a1 = ops.conv2d_nhwc_x3(yx3, w2, pad=1)
@@ -1041,8 +1052,10 @@ def test_fp32_plan_uses_bf16x3_head_only_when_it_pays_and_matches_the_fp32_mfma_
         for x3 in (True, False):
             tcfg.BF16X3 = x3
             model._plans.clear()
-            # six 3x3 layers (the ConvTranspose phases have a quarter of the rows: fp32 MFMA + a split pass at this batch)
-            assert model.plan(16, dev).x3_launches == (6 if x3 else 0)
+            # head: six 3x3 layers (the ConvTranspose phases have a quarter of the rows: fp32 MFMA + a split pass at this
+            # batch); trunk: 32 block convolutions + 3 down-sampling ones
+            plan = model.plan(16, dev)
+            assert plan.x3_launches == (6 + 35 if x3 else 0) and plan.x3_trunk == x3
             o = _run(model, t16)
             outs[x3] = {k: o[k].clone().cpu().double() for k in ("mask", "coor_x", "coor_y", "coor_z", "region", "rot", "trans")}
     finally:
