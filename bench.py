@@ -75,8 +75,9 @@ def roofline(model, t, B, device, reps=3):
     classes = {}  # tile -> launches of the conv kernel instance with that tile (bf16: the 64-channel K-chunk variants)
     lowp_fn = lib.rdpn6d_conv2d_bf16
     for L in plan.launches:
-        if L.keep and L.fn is lib.rdpn6d_conv2d_bf16x3:
-            classes.setdefault("x3", []).append(L)
+        if L.keep and L.fn in (lib.rdpn6d_conv2d_bf16x3, lib.rdpn6d_conv2d_bf16x3_ex):
+            # 256x256 8-phase kernel ("x3") or the 128x128..64x64 tile kernel ("x3tile")
+            classes.setdefault("x3" if lib.rdpn6d_conv_bf16x3_kernel_for(ctypes.byref(L.keep[0])) == 2 else "x3tile", []).append(L)
         elif L.keep and L.fn in (lowp_fn, lib.rdpn6d_conv2d_f32) and (L.fn is lowp_fn) == plan.bf16:
             d = L.keep[0]
             bm, bn = ctypes.c_int(), ctypes.c_int()
@@ -110,9 +111,9 @@ def roofline(model, t, B, device, reps=3):
     avg_ms = total_ms / max(n, 1)
     achieved = flops / len(sel) / (avg_ms * 1e-3) / 1e12 if sel else 0.0
     extra = {}
-    if tile == "x3":
+    if tile in ("x3", "x3tile"):
         # fp32-accurate products as six bf16 partial products: the ceiling for ALGORITHMIC flops is the bf16 pipe / 6
-        kname, peak = "conv_igemm_bf16x3_kernel", round(BF16_MFMA_PEAK_TFLOPS / 6.0, 1)
+        kname, peak = ("conv_igemm_bf16x3_kernel" if tile == "x3" else "conv_x3_tile_kernel"), round(BF16_MFMA_PEAK_TFLOPS / 6.0, 1)
         extra = {"peak_note": "2500 TFLOP/s dense bf16 MFMA / 6 partial products per fp32 product (157.3 on the fp32 MFMA pipe)",
                  "mfma_tflops_issued": round(6.0 * achieved, 1)}
     elif plan.bf16:
