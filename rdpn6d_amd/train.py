@@ -44,6 +44,12 @@ class TrainEngine:
         self.sfx = "bf16" if self.amp else "f32"
         self._casts = {}     # (address, stride, offset, channels) of an fp32 activation slice -> its bf16 copy
         self.mirrors = []    # (bf16 tensor, fp32 packed weight) pairs refreshed with the weights
+        self.mirrors3 = []   # (three bf16 planes, fp32 packed weight) pairs of the bf16x3 layers, re-split after every re-pack
+        self._planes = {}    # fp32 activation -> its three bf16 planes (split once per step, shared by the consumers)
+        # fp32 training: forward and input-gradient convolutions of the wide head layers as fp32-accurate bf16x3 convolutions
+        # (csrc/conv_igemm_bf16x3.hip) when the batch fills the chip; cfg.SOLVER.BF16X3 = False keeps them on the fp32 MFMA
+        self.x3 = (not self.amp) and bool(model.cfg.get("SOLVER", {}).get("BF16X3", True))
+        self.x3_launches = 0
         cfg = model.cfg
         self.R = int(cfg.MODEL.CDPN.BACKBONE.INPUT_RES)
         self.K = int(cfg.MODEL.CDPN.ROT_HEAD.NUM_REGIONS)
@@ -140,6 +146,45 @@ class TrainEngine:
         self.mirrors.append((tb, t))
         return tb
 
+    def _mirror3(self, t):
+        n = t.numel()
+        p3 = torch.zeros(3, _pad_to(n, 8), dtype=torch.bfloat16, device=self.dev)
+        self.mirrors3.append((p3, t))
+        return p3
+
+    def _planes_of(self, launches, src, cache):
+        """three bf16 planes of a contiguous fp32 tensor (input format of the bf16x3 convolution); the split launch is
+        appended to `launches`"""
+        key = src.data_ptr()
+        if cache and key in self._planes:
+            return self._planes[key]
+        n = src.numel()
+        p3 = torch.empty(3, _pad_to(n, 8), dtype=torch.bfloat16, device=self.dev)
+        lib = self.lib
+
+        def run():
+            _lib.check(lib.rdpn6d_split_bf16x3(_ptr(src), n, _ptr(p3), p3.shape[1], self.st()), "split bf16x3")
+
+        run.keep = (src, p3)
+        launches.append(run)
+        if cache:
+            self._planes[key] = p3
+        return p3
+
+    def _x3_wanted(self, d):
+        """the 256x256 bf16x3 kernel would take this convolution and fills the chip with it"""
+        return self.x3 and d.Cin == d.in_cs and d.in_co == 0 and self.lib.rdpn6d_conv_bf16x3_kernel_for(ctypes.byref(d)) == 2
+
+    def _launch_conv_x3(self, name, d, xp3, wp3, keep):
+        lib = self.lib
+        self.x3_launches += 1
+
+        def run():
+            _lib.check(lib.rdpn6d_conv2d_bf16x3(ctypes.byref(d), xp3.shape[1], wp3.shape[1], None, 0, self.st()), name)
+
+        run.keep = (d, keep, xp3, wp3)
+        return run
+
     def _launch_conv(self, name, d, keep, ksplit=False, lowp=False, out_f32=True):
         lib = self.lib
         from .gdrn import pick_ksplit
@@ -228,6 +273,8 @@ class TrainEngine:
         self._repack_table()
         _lib.check(self.lib.rdpn6d_repack_f32(_ptr(self._repack_dev), _ptr(self._repack_bd), _ptr(self._repack_bo),
                                               int(self._repack_bd.numel()), self.st()), "repack")
+        for p3, t in self.mirrors3:
+            _lib.check(self.lib.rdpn6d_split_bf16x3(_ptr(t), t.numel(), _ptr(p3), p3.shape[1], self.st()), "split weights")
 
     # ------------------------------------------------------------------ layer builders
     def conv_unit(self, name, P, x, xhw, in_cs, in_co, cin_real, y, yhw, out_cs, out_co, *, stride=1, perm=None, bias=None,
@@ -262,7 +309,13 @@ class TrainEngine:
         else:
             d = self._conv_desc(x, xhw, in_cs, in_co, cin_pad, wf, y, yhw, out_cs, out_co, cout, taps, stride=stride, shift=bvec,
                                 act=act_out or 0, slope=slope)
-            self.fwd.append(self._launch_conv(name, d, (wf, bvec), ksplit=True))
+            if stride == 1 and perm is None and self._x3_wanted(d):
+                xp3 = self._planes_of(self.fwd, x, cache=True)
+                wf3 = self._mirror3(wf)
+                d.x, d.w = _ptr(xp3), _ptr(wf3)
+                self.fwd.append(self._launch_conv_x3(name, d, xp3, wf3, (wf, bvec, x)))
+            else:
+                self.fwd.append(self._launch_conv(name, d, (wf, bvec), ksplit=True))
         # ---- backward
         dy = self.buf("d:" + name, *y.shape, zero=True, dtype=y.dtype)  # gradient w.r.t. the raw conv output (same layout as y)
         M = B * yhw[0] * yhw[1]
@@ -343,7 +396,13 @@ class TrainEngine:
                                     operm=perm)
                 dd = self._conv_desc(g_src, yhw, g_cs, g_co, n_red, wd, dx, xhw, dx_cs, in_co, cin_real, taps, stride=1,
                                      res=dx_res, res_cs=dx_cs)
-                launches.append(dlaunch("dgrad " + name, dd, wd))
+                if not lowp and perm is None and self._x3_wanted(dd):
+                    g3 = self._planes_of(launches, dy, cache=False)  # split launch first, then the convolution
+                    wd3 = self._mirror3(wd)
+                    dd.x, dd.w = _ptr(g3), _ptr(wd3)
+                    launches.append(self._launch_conv_x3("dgrad " + name, dd, g3, wd3, (wd, dy)))
+                else:
+                    launches.append(dlaunch("dgrad " + name, dd, wd))
             else:
                 assert stride == 2 and perm is None
                 if k == 3:
