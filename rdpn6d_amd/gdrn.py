@@ -301,6 +301,8 @@ class InferencePlan:
         tile-round against the fp32-MFMA kernel) when the last round is not mostly empty."""
         if not self.x3 or N % 256 or cin % 16 or (ntaps * (cin // 16)) % 2:
             return False
+        if 6 * M * max(N, cin) >= (1 << 32) - 64:  # three bf16 planes behind one 32-bit buffer descriptor
+            return False
         tiles = ((M + 255) // 256) * (N // 256)
         rounds = (tiles + 255) // 256
         return tiles >= 160 and tiles / (256.0 * rounds) >= 0.62
@@ -383,7 +385,7 @@ class InferencePlan:
         # fp32 mode, BasicBlock trunks, batches >= 16: the trunk's convolutions run as bf16x3 convolutions too (tile kernel,
         # csrc/conv_igemm_bf16x3_tile.hip) and hand their activations on as three bf16 planes; the residual is read from
         # planes as well (summed exactly), only the last block writes the fp32 tensor the up-sampling reads.
-        x3_trunk = self.x3 and not hasattr(bb.layer1[0], "conv3") and B * R4 * R4 >= 65536
+        x3_trunk = self.x3 and not hasattr(bb.layer1[0], "conv3") and 65536 <= B * R4 * R4 and 6 * B * R4 * R4 * 64 < (1 << 32) - 64
         self.x3_trunk = x3_trunk
         pcur = None
         if x3_trunk:
