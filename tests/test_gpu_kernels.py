@@ -737,11 +737,12 @@ def test_model_pnp_type_net_variants(golden_setup, dev, oracle_lib, pnp_type):
     assert np.abs(o["pnp_pose"].cpu().numpy() - po).max() < 1e-4
 
 
-@pytest.mark.parametrize("layers,R", [(50, 256), (50, 320), (18, 256)])
-def test_other_resnet_trunks_vs_oracle(dev, layers, R):
+@pytest.mark.parametrize("layers,R,B", [(50, 256, 2), (50, 320, 2), (18, 256, 2), (18, 256, 16)])
+def test_other_resnet_trunks_vs_oracle(dev, layers, R, B):
     """resnet_backbone.py:15-21 offers 18 / 34 (BasicBlock) and 50 / 101 / 152 (Bottleneck).  The reference cannot RUN the
     Bottleneck trunks (md_pointnet(512, ...) is hard-coded while layer4 then has 2048 channels) - BASELINE config 5 asks for
-    ResNet-50 at 320x320 - so parity is against the generalised torch-CPU oracle, with the usual fp64 yardstick."""
+    ResNet-50 at 320x320 - so parity is against the generalised torch-CPU oracle, with the usual fp64 yardstick.
+    B = 16 puts the ResNet-18 trunk and the head on the bf16x3 kernels (fp32 accuracy on the bf16 matrix pipe)."""
     from oracle import model_oracle
     from rdpn6d_amd import synth
     from rdpn6d_amd.config import gdrn_base_cfg
@@ -759,7 +760,7 @@ def test_other_resnet_trunks_vs_oracle(dev, layers, R):
         if k.endswith("bn3.weight") or (layers < 50 and k.endswith("bn2.weight")):  # init): keeps round-off growth moderate
             sd[k] *= 0.25
     orc.load_state_dict(sd, strict=True)
-    inp = synth.make_inputs(2, seed=5, res=R)
+    inp = synth.make_inputs(B, seed=5, res=R)
     tc = {k: torch.from_numpy(v) for k, v in inp.items()}
     model_oracle.calibrate_bn(orc, tc["roi_img"])
     model.load_state_dict(orc.state_dict(), strict=True)
@@ -769,17 +770,19 @@ def test_other_resnet_trunks_vs_oracle(dev, layers, R):
         o32 = orc(*args(tc))
         o64 = orc.double()(*args({k: (v.double() if v.dtype.is_floating_point else v) for k, v in tc.items()}))
     o = _run(model, {k: v.to(dev) for k, v in tc.items()})
+    plan = model.plan(B, dev)
+    assert plan.x3_trunk == (B >= 16 and layers < 50) and (plan.x3_launches > 0) == (B >= 16)
     for k in ("mask", "coor_x", "coor_y", "coor_z", "region"):
         self_err = (o32[k].double() - o64[k]).abs().max().item()
         err = (o[k].cpu().double() - o64[k]).abs().max().item()
-        print(f"resnet{layers} R={R} {k}: HIP-vs-fp64 {err:.3e}, oracle fp32-vs-fp64 {self_err:.3e}")
+        print(f"resnet{layers} R={R} B={B} {k}: HIP-vs-fp64 {err:.3e}, oracle fp32-vs-fp64 {self_err:.3e}")
         assert err <= 2.5 * self_err + 1e-6
-    am = model.plan(2, dev).argmax.cpu().numpy().reshape(2, -1)
-    flips = int((am != o64["region_argmax"].numpy().reshape(2, -1)).sum())
+    am = plan.argmax.cpu().numpy().reshape(B, -1)
+    flips = int((am != o64["region_argmax"].numpy().reshape(B, -1)).sum())
     er = _rel(o["rot"].cpu().numpy().astype(np.float64), o64["rot"].numpy())
     et = _rel(o["trans"].cpu().numpy().astype(np.float64), o64["trans"].numpy())
-    print(f"resnet{layers} R={R}: arg-max flips vs fp64 {flips}, pose rel err R {er:.2e} t {et:.2e}")
-    assert flips <= 8 and er < (2e-3 if flips == 0 else 2e-2) and et < (2e-3 if flips == 0 else 2e-2)
+    print(f"resnet{layers} R={R} B={B}: arg-max flips vs fp64 {flips}, pose rel err R {er:.2e} t {et:.2e}")
+    assert flips <= 4 * B and er < (2e-3 if flips == 0 else 2e-2) and et < (2e-3 if flips == 0 else 2e-2)
 
 
 @pytest.mark.parametrize("case", [(2, 8, 512, 512, 3, True, 6), (1, 16, 256, 256, 3, False, 4), (3, 8, 96, 128, 1, False, 2)])
