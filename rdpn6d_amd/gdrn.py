@@ -307,6 +307,11 @@ class InferencePlan:
         rounds = (tiles + 255) // 256
         return tiles >= 160 and tiles / (256.0 * rounds) >= 0.62
 
+    def x3_tile_ok(self, M, N, cin):
+        """the bf16x3 tile kernel (128x128 .. 64x64) for a layer too small for the 256x256 one: 1.35-1.45x the fp32-MFMA
+        kernel from two crops on (head layer: 73 vs 105 us at B=2, 123 vs 190 at B=4, 264 vs 354 at B=8)"""
+        return self.x3 and N % 64 == 0 and cin % 32 == 0 and M >= 8192 and 6 * M * max(N, cin) < (1 << 32) - 64
+
     def split3(self, name, x, planes):
         """launch: fp32 tensor -> its three bf16 planes ([3, plane_elems])"""
         self.launches.append(_Launch(name, self.lib.rdpn6d_split_bf16x3, (_ptr(x), x.numel(), _ptr(planes), planes.shape[1])))
@@ -498,7 +503,8 @@ class InferencePlan:
         wt = head.features[0].weight.detach().float()  # (Cin, Cout, 3, 3)
         sct, sht = fold_bn(head.features[1], npad=_pad_to(F, 64))
         Fp = _pad_to(F, 64)
-        x3_head = F == Fp and len(head.features) > 4 and self.x3_ok(B * R4 * R4, F, F, 9)  # the 3x3 layers of the head
+        x3_head = F == Fp and len(head.features) > 4 and (self.x3_ok(B * R4 * R4, F, F, 9) or
+                                                          self.x3_tile_ok(B * R4 * R4, F, F))  # the 3x3 layers of the head
         x3_ct = x3_head and self.x3_ok(B * R8 * R8, F, 1024, 1)      # ... and the ConvTranspose phases (a quarter of the rows)
         if x3_head:
             pA = self.buf("head_planes_a", 3, B * R4 * R4 * F, dtype=torch.bfloat16)
