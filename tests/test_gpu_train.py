@@ -602,7 +602,7 @@ def test_full_size_training_batch_b32_vs_reference_golden(golden_dir):
     rep = np.tile(np.arange(4), 8)
     batch = {k: torch.from_numpy(np.ascontiguousarray(v[rep] if v.shape[0] == 4 else v)).to(dev) for k, v in {**inp, **gt}.items()}
     eng = TrainEngine(model, 32, dev)
-    assert eng.x3_launches == 12  # forward + input-gradient convolution of the head's six 3x3 layers run as bf16x3
+    assert eng.x3_launches >= 12  # at least forward + input-gradient convolution of the six 3x3 head layers run as bf16x3
     losses = eng.forward_backward(batch)
     torch.cuda.synchronize()
     for k, v in losses.items():
