@@ -1079,3 +1079,28 @@ def test_fp32_plan_uses_bf16x3_head_only_when_it_pays_and_matches_the_fp32_mfma_
         e1 = max(_rel(outs[False][k][i].numpy(), exact[i].numpy()) for i in range(4))
         print(f"{k}: worst rel err vs fp64  bf16x3 path {e3:.3e}  fp32-MFMA path {e1:.3e}")
         assert e3 <= 2.0 * max(e1, 1e-4), k
+
+
+def test_conv_bf16x3_error_bound_under_cancellation(dev):
+    """fp32-class error BOUND, not just typical error: with products that cancel almost completely (inputs and weights
+    built in +/- pairs plus a small signal; magnitudes spread over 2^-10 .. 2^10) the bf16x3 result must stay within
+    c * 2^-24 * sum|a||b| of the fp64 result - the a-priori bound of an fp32 dot product of length K = 2304 (c <= sqrt(K) = 48
+    with random roundings) - and be no worse than the fp32-MFMA kernel's fmaf chain (measured 6.7 vs 11.9)."""
+    from rdpn6d_amd import ops
+
+    g = torch.Generator().manual_seed(99)
+    B, H, C, N = 2, 32, 256, 256
+    mag = torch.exp2(torch.randint(-10, 11, (B, H, H, C // 2), generator=g).float())
+    half = torch.randn(B, H, H, C // 2, generator=g) * mag
+    x = torch.cat([half, half], dim=-1)  # channel c and c + C/2 carry the same value ...
+    wh = torch.randn(N, C // 2, 3, 3, generator=g) / 48.0
+    w = torch.cat([wh, -wh], dim=1) + torch.randn(N, C, 3, 3, generator=g) * 1e-6  # ... and opposite weights (+ a tiny signal)
+    y64 = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double(), padding=1).permute(0, 2, 3, 1)
+    bound = torch.nn.functional.conv2d(x.double().abs().permute(0, 3, 1, 2), w.double().abs(), padding=1).permute(0, 2, 3, 1) * 2.0 ** -24
+    y3 = ops.conv2d_nhwc_x3(x.to(dev), w.to(dev), pad=1).cpu().double()
+    y1 = ops.conv2d_nhwc(x.to(dev), w.to(dev), pad=1).cpu().double()
+    r3 = ((y3 - y64).abs() / bound).max().item()
+    r1 = ((y1 - y64).abs() / bound).max().item()
+    print(f"cancellation test: |err| / (2^-24 sum|a||b|): bf16x3 {r3:.3f}  fp32-MFMA {r1:.3f};  |y|max {y64.abs().max().item():.3e} vs sum|a||b| max {bound.max().item() * 2 ** 24:.3e}")
+    assert r3 <= 1.25 * r1 and r3 <= 48.0 and r1 <= 48.0
+    assert y64.abs().max().item() < 1e-2 * bound.max().item() * 2 ** 24  # the case really cancels (>= 100x)
