@@ -34,5 +34,5 @@ def timeit(fn, n=20):
 t32 = timeit(lambda: _lib.check(lib.rdpn6d_conv2d_f32(ctypes.byref(d32), st)))
 tx3 = timeit(lambda: _lib.check(lib.rdpn6d_conv2d_bf16x3(ctypes.byref(dx3), xp.shape[1], wp.shape[1], None, 0, st)))
 tx3p = timeit(lambda: _lib.check(lib.rdpn6d_conv2d_bf16x3(ctypes.byref(dx3), xp.shape[1], wp.shape[1], _ptr(yp), yp.shape[1], st)))
-print(f"B={B}: fp32-MFMA {t32:8.1f} us ({gf/t32/1e-3/1e3:6.1f} TF/s) | bf16x3 {tx3:8.1f} us ({gf/tx3/1e-3/1e3:6.1f} TF/s fp32-equivalent, "
-      f"{6*gf/tx3/1e-3/1e3:6.1f} TF/s of bf16 MFMA) | bf16x3 + planes out {tx3p:8.1f} us")
+print(f"B={B}: fp32-MFMA {t32:8.1f} us ({gf/t32*1e3:6.1f} TF/s) | bf16x3 {tx3:8.1f} us ({gf/tx3*1e3:6.1f} TF/s fp32-equivalent, "
+      f"{6*gf/tx3*1e3:6.1f} TF/s of bf16 MFMA) | bf16x3 + planes out {tx3p:8.1f} us")

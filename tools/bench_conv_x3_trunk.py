@@ -34,5 +34,5 @@ for name, H, C in (("layer1", 64, 64), ("layer2", 32, 128), ("layer3", 16, 256),
     gf = 2.0 * B * H * H * C * C * 9 / 1e9
     t32 = timeit(lambda: _lib.check(lib.rdpn6d_conv2d_f32(ctypes.byref(d32), st)))
     tx3 = timeit(lambda: _lib.check(lib.rdpn6d_conv2d_bf16x3(ctypes.byref(dx3), xp.shape[1], wp.shape[1], _ptr(yp), yp.shape[1], st)))
-    print(f"{name} ({H}x{H}x{C}, kernel {lib.rdpn6d_conv_bf16x3_kernel_for(ctypes.byref(dx3))}): fp32-MFMA {t32:7.1f} us ({gf/t32*1e-3:6.1f} TF/s) | "
-          f"bf16x3 planes->planes {tx3:7.1f} us ({gf/tx3*1e-3:6.1f} TF/s fp32-equivalent)")
+    print(f"{name} ({H}x{H}x{C}, kernel {lib.rdpn6d_conv_bf16x3_kernel_for(ctypes.byref(dx3))}): fp32-MFMA {t32:7.1f} us ({gf/t32*1e3:6.1f} TF/s) | "
+          f"bf16x3 planes->planes {tx3:7.1f} us ({gf/tx3*1e3:6.1f} TF/s fp32-equivalent)")
