@@ -255,6 +255,12 @@ int rdpn6d_wgrad_bf16_strided(const void* A, int a_cs, int a_co, int Ca, int Ca_
                               int Cb_ld, int Bn, int Ha, int Wa, int Hb, int Wb, int stride, int ntaps, const int* dy,
                               const int* dx, float* out, long long sa, long long st, long long sb, int Ca_out, int Cb_out,
                               float* partial, void* stream);
+/* bf16x3 form (fp32-accurate weight gradient on the bf16 matrix pipe, see rdpn6d_conv2d_bf16x3): A / Bg = plane 0 of the three
+ * bf16 planes [3][a_plane_elems] / [3][b_plane_elems] of the NHWC gradient / activation (rdpn6d_split_bf16x3); Ca, Cb > 64 */
+int rdpn6d_wgrad_bf16x3_strided(const void* A, long long a_plane_elems, int a_cs, int a_co, int Ca, int Ca_ld, const void* Bg,
+                                long long b_plane_elems, int b_cs, int b_co, int Cb, int Cb_ld, int Bn, int Ha, int Wa, int Hb,
+                                int Wb, int stride, int ntaps, const int* dy, const int* dx, float* out, long long sa,
+                                long long st, long long sb, int Ca_out, int Cb_out, float* partial, void* stream);
 int rdpn6d_maxpool3x3s2_backward_f32(const float* x, const float* dy, int B, int H, int W, int C, float* dx, void* stream);
 int rdpn6d_upsample_bilinear_backward_f32(const float* dy, int B, int H, int W, int C, int factor, float* dx, void* stream);
 int rdpn6d_global_max_concat_backward_f32(const float* feat, const float* dfeat, int B, int HW, int C, int cs, float* dl3,

@@ -85,6 +85,8 @@ SIGNATURES = {
                                       _vp, _vp]),
     "rdpn6d_wgrad_bf16_strided": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _ll, _ll, _ll,
                                        _i, _i, _vp, _vp]),
+    "rdpn6d_wgrad_bf16x3_strided": (_i, [_vp, _ll, _i, _i, _i, _i, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp,
+                                         _ll, _ll, _ll, _i, _i, _vp, _vp]),
     "rdpn6d_maxpool3x3s2_backward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "rdpn6d_upsample_bilinear_backward_f32": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "rdpn6d_global_max_concat_backward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),

@@ -218,6 +218,7 @@ struct WgradBArgs {
     int nsplit;
     long long rows_per_split;
     unsigned a_bytes, b_bytes;
+    unsigned a_plane, b_plane;  // bf16x3 form: byte distance between the operand planes (0 otherwise)
 };
 
 typedef short rd_s16x4 __attribute__((ext_vector_type(4)));
@@ -230,15 +231,21 @@ __device__ __forceinline__ rd_s16x4 lds_tr_b64(const void* p)
     return v;
 }
 
-template <int BA, int BB>
-__global__ __launch_bounds__(256, 3) void wgrad_bf16_kernel(const WgradBArgs a)
+// PL = 3: bf16x3 form (fp32-accurate, see conv_igemm_bf16x3.hip): both operands as three bf16 planes (plane strides
+// a_plane / b_plane bytes), six MFMAs per k16 step and tile pair; one k16 step (16 pixels) per chunk so that the three
+// stages x three planes of a 128x128 tile fit 72 KiB (two workgroups per CU).
+template <int BA, int BB, int PL>
+__global__ __launch_bounds__(256, PL == 1 ? 3 : 2) void wgrad_bf16_kernel(const WgradBArgs a)
 {
-    constexpr int KP = 32;                       // pixels per chunk (two k16 MFMA steps)
+    constexpr int KS = PL == 1 ? 2 : 1;          // k16 MFMA steps per chunk
+    constexpr int KP = 16 * KS;                  // pixels per chunk
     constexpr int TA = BA / 64, TB = BB / 64;    // 32x32 tiles per wave (2x2 waves)
     constexpr int NST = 3;
     constexpr int ARB = BA * 2, BRB = BB * 2;    // row bytes
-    __shared__ __attribute__((aligned(1024))) unsigned char As[NST][KP * ARB];
-    __shared__ __attribute__((aligned(1024))) unsigned char Bs[NST][KP * BRB];
+    extern __shared__ __attribute__((aligned(1024))) unsigned char wg_smem[];
+    // As(stage, plane) = wg_smem + (stage*PL + plane) * KP*ARB;  Bs after all A slots
+    auto As = [&](int st, int pl) { return wg_smem + (st * PL + pl) * (KP * ARB); };
+    auto Bs = [&](int st, int pl) { return wg_smem + NST * PL * (KP * ARB) + (st * PL + pl) * (KP * BRB); };
 
     const int ntile = a.atiles * a.btiles * a.ntaps;
     const int nblk = ntile * a.nsplit;
@@ -268,6 +275,7 @@ __global__ __launch_bounds__(256, 3) void wgrad_bf16_kernel(const WgradBArgs a)
     constexpr int ACH = ARB / 16, BCH = BRB / 16;                 // chunks per row (16 | 8)
     constexpr int AROWS = 64 / ACH, BROWS = 64 / BCH;             // rows per piece (4 | 8)
     constexpr int APIECES = KP / AROWS / 4, BPIECES = KP / BROWS / 4;
+    static_assert(APIECES >= 1 && BPIECES >= 1, "chunk / tile layout");
     auto swz = [](int row, int ch) { return ch == 16 ? 4 * (row & 3) : 4 * ((row >> 1) & 1); };
     const int ar = lane / ACH, aq = lane % ACH, br = lane / BCH, bq = lane % BCH;
 
@@ -291,8 +299,10 @@ __global__ __launch_bounds__(256, 3) void wgrad_bf16_kernel(const WgradBArgs a)
             const int lq = aq ^ swz(row, ACH);                      // logical chunk fetched into physical slot aq
             const long long m = ld_m + row;
             const bool ok = m < m_hi && a0 + lq * 8 < a.Ca_ld;
-            const unsigned off = ok ? (unsigned)m * a_row_bytes + (unsigned)(a.a_co + a0 + lq * 8) * 2u : a.a_bytes;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(asrc, (lds_ptr_t)&As[st][row0 * ARB], 16, (int)off, 0, 0, 0);
+            const unsigned off = ok ? (unsigned)m * a_row_bytes + (unsigned)(a.a_co + a0 + lq * 8) * 2u : 0xFFFFFF00u;
+#pragma unroll
+            for (int pl = 0; pl < PL; ++pl)  // the plane offset rides on the scalar offset: an out-of-range lane stays out of range
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(asrc, (lds_ptr_t)(As(st, pl) + row0 * ARB), 16, (int)off, (int)(pl * a.a_plane), 0, 0);
         }
 #pragma unroll
         for (int p = 0; p < BPIECES; ++p) {
@@ -303,8 +313,10 @@ __global__ __launch_bounds__(256, 3) void wgrad_bf16_kernel(const WgradBArgs a)
             const int iy = b_oy[p] * a.stride + dy, ix = b_ox[p] * a.stride + dx;
             const bool ok = m < m_hi && b0 + lq * 8 < a.Cb_ld && (unsigned)iy < (unsigned)a.Hb && (unsigned)ix < (unsigned)a.Wb;
             const unsigned off = ok ? (unsigned)((b_bi[p] * a.Hb + iy) * a.Wb + ix) * b_px_bytes + (unsigned)(a.b_co + b0 + lq * 8) * 2u
-                                    : a.b_bytes;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(bsrc, (lds_ptr_t)&Bs[st][row0 * BRB], 16, (int)off, 0, 0, 0);
+                                    : 0xFFFFFF00u;
+#pragma unroll
+            for (int pl = 0; pl < PL; ++pl)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(bsrc, (lds_ptr_t)(Bs(st, pl) + row0 * BRB), 16, (int)off, (int)(pl * a.b_plane), 0, 0);
             b_ox[p] += KP;
             while (b_ox[p] >= a.Wa) { b_ox[p] -= a.Wa; if (++b_oy[p] == a.Ha) { b_oy[p] = 0; ++b_bi[p]; } }
         }
@@ -330,26 +342,36 @@ __global__ __launch_bounds__(256, 3) void wgrad_bf16_kernel(const WgradBArgs a)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // fragments of one chunk, flat: A piece (tile i, k16 step s, half h) at (i*2+s)*2+h, B pieces after the A pieces
-    constexpr int NF = (TA + TB) * 4;
+    // fragments of one chunk, flat: plane pl, A piece (tile i, k16 step s, half h) at pl*NFP + (i*KS+s)*2+h, B pieces after
+    // the plane's A pieces
+    constexpr int NFP = (TA + TB) * 2 * KS;  // per plane
+    constexpr int NF = NFP * PL;
     auto read_frags = [&](int st, rd_s16x4 (&f)[NF]) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int pl = 0; pl < PL; ++pl)
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int row = s * 16 + trow + h * 4;
+            for (int s = 0; s < KS; ++s)
 #pragma unroll
-                for (int i = 0; i < TA; ++i)
-                    f[(i * 2 + s) * 2 + h] = lds_tr_b64(frag_addr(As[st], ARB, ACH, row, wa * (BA / 2) + i * 32 + tcol));
+                for (int h = 0; h < 2; ++h) {
+                    const int row = s * 16 + trow + h * 4;
 #pragma unroll
-                for (int j = 0; j < TB; ++j)
-                    f[TA * 4 + (j * 2 + s) * 2 + h] = lds_tr_b64(frag_addr(Bs[st], BRB, BCH, row, wb * (BB / 2) + j * 32 + tcol));
-            }
+                    for (int i = 0; i < TA; ++i)
+                        f[pl * NFP + (i * KS + s) * 2 + h] = lds_tr_b64(frag_addr(As(st, pl), ARB, ACH, row, wa * (BA / 2) + i * 32 + tcol));
+#pragma unroll
+                    for (int j = 0; j < TB; ++j)
+                        f[pl * NFP + TA * 2 * KS + (j * KS + s) * 2 + h] =
+                            lds_tr_b64(frag_addr(Bs(st, pl), BRB, BCH, row, wb * (BB / 2) + j * 32 + tcol));
+                }
     };
     // The transpose reads are inline asm, invisible to the compiler's wait-count insertion: one s_waitcnt that formally
     // (re)defines every fragment register, so that no consumer can be scheduled ahead of it.
     auto settle = [&](rd_s16x4 (&f)[NF]) {
-        if constexpr (NF == 16)
+        if constexpr (NF == 24)
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]), "+v"(f[8]),
+                           "+v"(f[9]), "+v"(f[10]), "+v"(f[11]), "+v"(f[12]), "+v"(f[13]), "+v"(f[14]), "+v"(f[15]), "+v"(f[16]),
+                           "+v"(f[17]), "+v"(f[18]), "+v"(f[19]), "+v"(f[20]), "+v"(f[21]), "+v"(f[22]), "+v"(f[23]));
+        else if constexpr (NF == 16)
             asm volatile("s_waitcnt lgkmcnt(0)"
                          : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4]), "+v"(f[5]), "+v"(f[6]), "+v"(f[7]), "+v"(f[8]),
                            "+v"(f[9]), "+v"(f[10]), "+v"(f[11]), "+v"(f[12]), "+v"(f[13]), "+v"(f[14]), "+v"(f[15]));
@@ -363,18 +385,24 @@ __global__ __launch_bounds__(256, 3) void wgrad_bf16_kernel(const WgradBArgs a)
     };
     auto mma = [&](const rd_s16x4 (&f)[NF]) {
         typedef short s16x8 __attribute__((ext_vector_type(8)));
+        constexpr int NPR = PL == 1 ? 1 : 6;
+        constexpr int PA[6] = {PL == 1 ? 0 : 2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};  // plane pairs, smallest terms first
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < KS; ++s)
 #pragma unroll
-            for (int i = 0; i < TA; ++i) {
-                const s16x8 av = __builtin_shufflevector(f[(i * 2 + s) * 2], f[(i * 2 + s) * 2 + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+            for (int pr = 0; pr < NPR; ++pr)
 #pragma unroll
-                for (int j = 0; j < TB; ++j) {
-                    const s16x8 bv = __builtin_shufflevector(f[TA * 4 + (j * 2 + s) * 2], f[TA * 4 + (j * 2 + s) * 2 + 1], 0, 1, 2, 3, 4, 5, 6, 7);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(rd_bf16x8, av),
-                                                                         __builtin_bit_cast(rd_bf16x8, bv), acc[i][j], 0, 0, 0);
+                for (int i = 0; i < TA; ++i) {
+                    const int fa = PA[pr] * NFP + (i * KS + s) * 2;
+                    const s16x8 av = __builtin_shufflevector(f[fa], f[fa + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+                    for (int j = 0; j < TB; ++j) {
+                        const int fb = PB[pr] * NFP + TA * 2 * KS + (j * KS + s) * 2;
+                        const s16x8 bv = __builtin_shufflevector(f[fb], f[fb + 1], 0, 1, 2, 3, 4, 5, 6, 7);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(rd_bf16x8, av),
+                                                                             __builtin_bit_cast(rd_bf16x8, bv), acc[i][j], 0, 0, 0);
+                    }
                 }
-            }
     };
 
     if (nchunks > 0) {
@@ -578,9 +606,27 @@ extern "C" int rdpn6d_wgrad_f32_strided(const float* A, int a_cs, int a_co, int 
 
 // bf16 operands (compact NHWC copies, channel strides/offsets in elements, multiples of 8); Ca_ld / Cb_ld = readable
 // channels of the slices (>= Ca / Cb, zero beyond the real count); out / partial as rdpn6d_wgrad_f32
+template <int BA, int BB, int PL>
+static int wgrad_bf16_launch(const WgradBArgs& a, dim3 grid, hipStream_t s)
+{
+    constexpr int lds = 3 * PL * (PL == 1 ? 32 : 16) * (BA + BB) * 2;
+    auto kern = wgrad_bf16_kernel<BA, BB, PL>;
+    if (lds > 64 * 1024) {
+        static bool configured = false;
+        if (!configured) {
+            RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            configured = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+    return RDPN6D_OK;
+}
+
+// a_plane_elems / b_plane_elems > 0: bf16x3 form - A and Bg are plane 0 of three bf16 planes (128x128 tiles only)
 static int wgrad_bf16_impl(const void* A, int a_cs, int a_co, int Ca, int Ca_ld, const void* Bg, int b_cs, int b_co, int Cb,
                            int Cb_ld, int Bn, int Ha, int Wa, int Hb, int Wb, int stride, int ntaps, const int* dy, const int* dx,
-                           float* out, const WgradOut* so, float* partial, void* stream)
+                           float* out, const WgradOut* so, float* partial, void* stream, long long a_plane_elems = 0,
+                           long long b_plane_elems = 0)
 {
     RD_REQUIRE(A && Bg && out && partial && dy && dx, "null pointer");
     RD_REQUIRE(Bn > 0 && Ha > 0 && Wa > 0 && Hb > 0 && Wb > 0 && stride >= 1, "shape");
@@ -601,9 +647,17 @@ static int wgrad_bf16_impl(const void* A, int a_cs, int a_co, int Ca, int Ca_ld,
         a.dx_pack |= (unsigned long long)(dx[t] + 8) << (4 * t);
     }
     a.Ca = Ca; a.Cb = Cb; a.Ca_ld = Ca_ld; a.Cb_ld = Cb_ld; a.a_cs = a_cs; a.a_co = a_co; a.b_cs = b_cs; a.b_co = b_co;
-    const long long ab = a.M * a_cs * 2, bb_ = (long long)Bn * Hb * Wb * b_cs * 2;
-    RD_REQUIRE(ab < (1LL << 32) - 64 && bb_ < (1LL << 32) - 64, "operands must be smaller than 4 GiB (32-bit buffer offsets)");
+    const bool x3 = a_plane_elems > 0 || b_plane_elems > 0;
+    long long ab = a.M * a_cs * 2, bb_ = (long long)Bn * Hb * Wb * b_cs * 2;
+    if (x3) {
+        RD_REQUIRE(a_plane_elems * 2 >= ab && b_plane_elems * 2 >= bb_ && a_plane_elems % 8 == 0 && b_plane_elems % 8 == 0, "plane sizes");
+        RD_REQUIRE(Ca > 64 && Cb > 64, "the bf16x3 weight gradient has 128x128 tiles only");
+        ab += 4 * a_plane_elems;
+        bb_ += 4 * b_plane_elems;
+    }
+    RD_REQUIRE(ab < (1LL << 32) - 256 && bb_ < (1LL << 32) - 256, "operands must be smaller than 4 GiB (32-bit buffer offsets)");
     a.a_bytes = (unsigned)ab; a.b_bytes = (unsigned)bb_;
+    a.a_plane = (unsigned)(a_plane_elems * 2); a.b_plane = (unsigned)(b_plane_elems * 2);
     const int ba = Ca > 64 ? 128 : 64, bb = Cb > 64 ? 128 : 64;
     a.atiles = (Ca + ba - 1) / ba;
     a.btiles = (Cb + bb - 1) / bb;
@@ -612,11 +666,14 @@ static int wgrad_bf16_impl(const void* A, int a_cs, int a_co, int Ca, int Ca_ld,
     a.rows_per_split = ((a.M + S - 1) / S + 31) / 32 * 32;
     hipStream_t s = (hipStream_t)stream;
     a.nsplit = S;
-    dim3 grid(tiles * S), block(256);
-    if (ba == 128 && bb == 128) hipLaunchKernelGGL((wgrad_bf16_kernel<128, 128>), grid, block, 0, s, a);
-    else if (ba == 128) hipLaunchKernelGGL((wgrad_bf16_kernel<128, 64>), grid, block, 0, s, a);
-    else if (bb == 128) hipLaunchKernelGGL((wgrad_bf16_kernel<64, 128>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((wgrad_bf16_kernel<64, 64>), grid, block, 0, s, a);
+    dim3 grid(tiles * S);
+    int rc;
+    if (x3) rc = wgrad_bf16_launch<128, 128, 3>(a, grid, s);
+    else if (ba == 128 && bb == 128) rc = wgrad_bf16_launch<128, 128, 1>(a, grid, s);
+    else if (ba == 128) rc = wgrad_bf16_launch<128, 64, 1>(a, grid, s);
+    else if (bb == 128) rc = wgrad_bf16_launch<64, 128, 1>(a, grid, s);
+    else rc = wgrad_bf16_launch<64, 64, 1>(a, grid, s);
+    if (rc != RDPN6D_OK) return rc;
     RD_LAUNCH_CHECK();
     wgrad_reduce(partial, S, Ca, ntaps, Cb, out, so, s);
     RD_LAUNCH_CHECK();
@@ -640,4 +697,19 @@ extern "C" int rdpn6d_wgrad_bf16_strided(const void* A, int a_cs, int a_co, int 
     const WgradOut so = {out, sa, st, sb, Ca_out, Cb_out};
     return wgrad_bf16_impl(A, a_cs, a_co, Ca, Ca_ld, Bg, b_cs, b_co, Cb, Cb_ld, Bn, Ha, Wa, Hb, Wb, stride, ntaps, dy, dx, out, &so,
                            partial, stream);
+}
+
+// bf16x3 form (fp32-accurate weight gradient on the bf16 matrix pipe, see conv_igemm_bf16x3.hip): A / Bg = plane 0 of three
+// bf16 planes [3][a_plane_elems] / [3][b_plane_elems] of the NHWC gradient / activation (rdpn6d_split_bf16x3); Ca, Cb > 64
+extern "C" int rdpn6d_wgrad_bf16x3_strided(const void* A, long long a_plane_elems, int a_cs, int a_co, int Ca, int Ca_ld,
+                                           const void* Bg, long long b_plane_elems, int b_cs, int b_co, int Cb, int Cb_ld, int Bn,
+                                           int Ha, int Wa, int Hb, int Wb, int stride, int ntaps, const int* dy, const int* dx,
+                                           float* out, long long sa, long long st, long long sb, int Ca_out, int Cb_out,
+                                           float* partial, void* stream)
+{
+    RD_REQUIRE(Ca_out > 0 && Ca_out <= Ca && Cb_out > 0 && Cb_out <= Cb, "output extents");
+    RD_REQUIRE(a_plane_elems > 0 && b_plane_elems > 0, "plane sizes");
+    const WgradOut so = {out, sa, st, sb, Ca_out, Cb_out};
+    return wgrad_bf16_impl(A, a_cs, a_co, Ca, Ca_ld, Bg, b_cs, b_co, Cb, Cb_ld, Bn, Ha, Wa, Hb, Wb, stride, ntaps, dy, dx, out, &so,
+                           partial, stream, a_plane_elems, b_plane_elems);
 }

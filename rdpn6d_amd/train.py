@@ -286,6 +286,7 @@ class TrainEngine:
         cout, _, k, _ = w.shape
         pad = k // 2
         lowp = self.amp and not name.startswith("pnp_net")  # ConvPnPNet stays fp32 (pose regression)
+        x3_fwd, xp3, g3 = False, None, None  # bf16x3 forward taken; planes of x / of the output gradient
         cin_pad = _pad_to(cin_real, 32 if lowp else 16)
         npad = _pad_to(cout, 64)
         lib, B = self.lib, self.B
@@ -310,6 +311,7 @@ class TrainEngine:
             d = self._conv_desc(x, xhw, in_cs, in_co, cin_pad, wf, y, yhw, out_cs, out_co, cout, taps, stride=stride, shift=bvec,
                                 act=act_out or 0, slope=slope)
             if stride == 1 and perm is None and self._x3_wanted(d):
+                x3_fwd = True
                 xp3 = self._planes_of(self.fwd, x, cache=True)
                 wf3 = self._mirror3(wf)
                 d.x, d.w = _ptr(xp3), _ptr(wf3)
@@ -339,6 +341,12 @@ class TrainEngine:
             else:  # fp32 gradient (the head output's): one compact bf16 copy for the wgrad and the dgrad
                 dyb, dyb_cs, dyb_co = self._bf16_of(launches, dy, out_cs, out_co, cout, M, cache=False)[0], n_red_b, 0
 
+        # bf16x3 weight gradient (fp32-accurate, 1.6x the fp32-MFMA kernel on the head layers): needs the planes of x (from the
+        # forward) and of dy (split here, shared with the input-gradient convolution below)
+        x3_w = x3_fwd and inv_perm is None and cout > 64 and cin_real > 64 and cout % 8 == 0 and cin_real % 8 == 0 and out_co == 0
+        if x3_w:
+            g3 = self._planes_of(launches, dy, cache=False)
+
         def wgrad():
             # the split-K reduce scatters straight into the parameter's own OIHW gradient (element (n, tap, c) at
             # n*Cin*k*k + c*k*k + tap) unless the input channels are permuted in the activation buffer
@@ -352,6 +360,10 @@ class TrainEngine:
                     _lib.check(lib.rdpn6d_wgrad_bf16_strided(*args, *tgt, _ptr(self._wg_partial), self.st()), "wgrad " + name)
                 else:
                     _lib.check(lib.rdpn6d_wgrad_bf16(*args, _ptr(wg_out), _ptr(self._wg_partial), self.st()), "wgrad " + name)
+            elif x3_w:
+                _lib.check(lib.rdpn6d_wgrad_bf16x3_strided(_ptr(g3), g3.shape[1], out_cs, out_co, ca, cout, _ptr(xp3), xp3.shape[1], in_cs,
+                                                           in_co, cb, cin_real, B, yhw[0], yhw[1], xhw[0], xhw[1], stride, k * k, tdy,
+                                                           tdx, *tgt, _ptr(self._wg_partial), self.st()), "wgrad " + name)
             else:
                 args = (_ptr(dy), out_cs, out_co, ca, _ptr(x), in_cs, in_co, cb, B, yhw[0], yhw[1], xhw[0], xhw[1], stride, k * k,
                         tdy, tdx)
@@ -397,7 +409,8 @@ class TrainEngine:
                 dd = self._conv_desc(g_src, yhw, g_cs, g_co, n_red, wd, dx, xhw, dx_cs, in_co, cin_real, taps, stride=1,
                                      res=dx_res, res_cs=dx_cs)
                 if not lowp and perm is None and self._x3_wanted(dd):
-                    g3 = self._planes_of(launches, dy, cache=False)  # split launch first, then the convolution
+                    if g3 is None:
+                        g3 = self._planes_of(launches, dy, cache=False)  # split launch first, then the convolution
                     wd3 = self._mirror3(wd)
                     dd.x, dd.w = _ptr(g3), _ptr(wd3)
                     launches.append(self._launch_conv_x3("dgrad " + name, dd, g3, wd3, (wd, dy)))

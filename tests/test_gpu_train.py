@@ -619,3 +619,66 @@ def test_full_size_training_batch_b32_vs_reference_golden(golden_dir):
     rot = eng.rot.cpu()
     for s in range(32):
         assert torch.equal(rot[s], rot[s % 4]), s
+    # the same step with every convolution / weight gradient on the fp32 MFMA pipe: the bf16x3 kernels (forward, input and
+    # weight gradients of the head's 3x3 layers) must give the same gradients up to fp32 round-off - which this random
+    # 45-layer network amplifies to ~2e-2 of a gradient's norm for ANY fp32 evaluation (test_all_gradients_vs_oracle_autograd)
+    keys = ["rot_head_net.features.3.weight", "rot_head_net.features.9.weight", "rot_head_net.features.18.weight",
+            "backbone.layer1.0.conv1.weight"]
+    gx3 = {k: named[k].grad.clone() for k in keys}
+    del eng
+    torch.cuda.empty_cache()
+    model.cfg.SOLVER.BF16X3 = False
+    try:
+        eng2 = TrainEngine(model, 32, dev)
+        assert eng2.x3_launches == 0
+        eng2.forward_backward(batch)
+        torch.cuda.synchronize()
+    finally:
+        model.cfg.SOLVER.BF16X3 = True
+    for k in keys:
+        a, b = gx3[k].double(), named[k].grad.double()
+        rel = ((a - b).norm() / b.norm()).item()
+        print(f"B=32 grad {k}: bf16x3 path vs fp32-MFMA path rel {rel:.2e}")
+        assert rel < 3e-2, k
+
+
+@pytest.mark.parametrize("case", [(2, 64, 256, 256, 3), (3, 24, 128, 256, 3), (2, 32, 256, 192, 1)])
+def test_wgrad_bf16x3_has_fp32_accuracy(case):
+    """bf16x3 weight-gradient kernel (three bf16 planes per operand, six partial products, transpose LDS reads) against autograd's
+    fp64 weight gradient: no further away than the fp32-MFMA wgrad kernel (x1.5 + noise floor)."""
+    import ctypes
+    from rdpn6d_amd import _lib, ops
+    from rdpn6d_amd.gdrn import _ptr
+
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    Bn, H, Ca, Cb, k = case
+    g = torch.Generator().manual_seed(sum(case) + 17)
+    dy = torch.randn(Bn, H, H, Ca, generator=g).to(dev)
+    x = torch.randn(Bn, H, H, Cb, generator=g).to(dev)
+    dyp, xp = ops.split_bf16x3(dy), ops.split_bf16x3(x)
+    pad = k // 2
+    taps = [(ky - pad, kx - pad) for ky in range(k) for kx in range(k)]
+    tdy = (ctypes.c_int * 9)(*[t[0] for t in taps] + [0] * (9 - len(taps)))
+    tdx = (ctypes.c_int * 9)(*[t[1] for t in taps] + [0] * (9 - len(taps)))
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    scr = torch.empty(int(lib.rdpn6d_wgrad_scratch_floats(Bn, H, H, Ca, Cb, len(taps))), device=dev)
+    o32 = torch.full((Ca, len(taps), Cb), 7.0, device=dev)
+    ox3 = torch.full((Ca, len(taps), Cb), 7.0, device=dev)
+    _lib.check(lib.rdpn6d_wgrad_f32(_ptr(dy), Ca, 0, Ca, _ptr(x), Cb, 0, Cb, Bn, H, H, H, H, 1, len(taps), tdy, tdx, _ptr(o32),
+                                    _ptr(scr), st))
+    nt = len(taps)
+    _lib.check(lib.rdpn6d_wgrad_bf16x3_strided(_ptr(dyp), dyp.shape[1], Ca, 0, Ca, Ca, _ptr(xp), xp.shape[1], Cb, 0, Cb, Cb, Bn, H, H, H,
+                                               H, 1, nt, tdy, tdx, _ptr(ox3), nt * Cb, Cb, 1, Ca, Cb, _ptr(scr), st))
+    torch.cuda.synchronize()
+    xt = x.permute(0, 3, 1, 2).double().cpu()
+    w = torch.zeros(Ca, Cb, k, k, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(xt, w, padding=pad).backward(dy.permute(0, 3, 1, 2).double().cpu())
+    ref = w.grad.permute(0, 2, 3, 1).reshape(Ca, k * k, Cb)
+    scale = ref.abs().max().item()
+    e32 = (o32.cpu().double() - ref).abs()
+    e3 = (ox3.cpu().double() - ref).abs()
+    print(f"{case}: max err / max|dW|: fp32-MFMA wgrad {e32.max().item() / scale:.2e}  bf16x3 {e3.max().item() / scale:.2e}  "
+          f"(rms {e32.pow(2).mean().sqrt().item() / scale:.2e} / {e3.pow(2).mean().sqrt().item() / scale:.2e})")
+    assert e3.max().item() <= 1.5 * e32.max().item() + 1e-7 * scale
+    assert e3.pow(2).mean().sqrt().item() <= 1.5 * e32.pow(2).mean().sqrt().item() + 1e-8 * scale
