@@ -620,6 +620,9 @@ class TrainEngine:
         Mh = B * R4 * R4
         rt0, at0 = self.buf("raw:head0", B, R4, R4, F), self.buf("act:head0", B, R4, R4, F)
         wt = head.features[0].weight
+        # fp32 mode, batches that fill the chip: the ConvTranspose (four phase convolutions, its stride-2 input-gradient convolution
+        # and its weight gradient) on the bf16x3 kernels as well - two split passes (feat, d_rt0) pay for three GEMMs
+        x3_ct = self.x3 and F % 256 == 0 and B * R8 * R8 >= 16384 and 6 * B * R8 * R8 * 1024 < (1 << 32) - 64
         for py in (0, 1):
             for px in (0, 1):
                 ys = [(1, 0)] if py == 0 else [(0, 1), (2, 0)]
@@ -636,7 +639,13 @@ class TrainEngine:
                     self.fwd.append(self._launch_conv(f"convT phase{py}{px}", d, (wp, wpb, featb), lowp=True, out_f32=False))
                 else:
                     d = self._conv_desc(feat, (R8, R8), 1024, 0, 1024, wp, rt0, (R4, R4), F, 0, F, ptaps, phase=(R8, R8, 2, 2, py, px))
-                    self.fwd.append(self._launch_conv(f"convT phase{py}{px}", d, wp))
+                    if x3_ct:  # bf16x3 (tile kernel at this row count): planes of feat, split once for the four phases
+                        featp = self._planes_of(self.fwd, feat, cache=True)
+                        wp3 = self._mirror3(wp)
+                        d.x, d.w = _ptr(featp), _ptr(wp3)
+                        self.fwd.append(self._launch_conv_x3(f"convT phase{py}{px}", d, featp, wp3, (wp, feat)))
+                    else:
+                        self.fwd.append(self._launch_conv(f"convT phase{py}{px}", d, wp))
         d_rt0 = self.buf("d:head0", B, R4, R4, F, zero=True)
         wdT = self._pack_map((1024, 9, F), wt, 1024, 9, F, F * 9, 9, range(9))  # ConvT weight IS the OIHW of its dgrad conv
         convT_bwd = []
@@ -647,6 +656,11 @@ class TrainEngine:
             ddT = self._conv_desc(d_rt0b, (R4, R4), F, 0, F, wdTb, d_feat, (R8, R8), 1024, 0, 1024, _taps(3, 1), stride=2)
         else:
             ddT = self._conv_desc(d_rt0, (R4, R4), F, 0, F, wdT, d_feat, (R8, R8), 1024, 0, 1024, _taps(3, 1), stride=2)
+        d_rt0p = None
+        if x3_ct:
+            x3_ct = bool(lib.rdpn6d_conv_bf16x3_eligible(ctypes.byref(ddT)))
+        if x3_ct:
+            d_rt0p = self._planes_of(convT_bwd, d_rt0, cache=False)  # first launch of the group: split the output gradient
         self._wg_floats = max(self._wg_floats, int(lib.rdpn6d_wgrad_scratch_floats(B, R8, R8, 1024, F, 9)))
         t9y = (ctypes.c_int * 9)(*[t[0] for t in _taps(3, 1)])
         t9x = (ctypes.c_int * 9)(*[t[1] for t in _taps(3, 1)])
@@ -654,14 +668,24 @@ class TrainEngine:
         def convT_wgrad():
             # ConvTranspose weight is (Cin, Cout, 3, 3): element (cin, tap, cout) -> cin*F*9 + cout*9 + tap
             tgt = (_ptr(self._grad(wt)), F * 9, 1, 9, 1024, F)
-            if self.amp:
+            if x3_ct:
+                _lib.check(lib.rdpn6d_wgrad_bf16x3_strided(_ptr(featp), featp.shape[1], 1024, 0, 1024, 1024, _ptr(d_rt0p), d_rt0p.shape[1], F,
+                                                           0, F, F, B, R8, R8, R4, R4, 2, 9, t9y, t9x, *tgt, _ptr(self._wg_partial),
+                                                           self.st()), "wgrad convT")
+            elif self.amp:
                 _lib.check(lib.rdpn6d_wgrad_bf16_strided(_ptr(featb), 1024, 0, 1024, 1024, _ptr(d_rt0b), F, 0, F, F, B, R8, R8, R4, R4, 2,
                                                          9, t9y, t9x, *tgt, _ptr(self._wg_partial), self.st()), "wgrad convT")
             else:
                 _lib.check(lib.rdpn6d_wgrad_f32_strided(_ptr(feat), 1024, 0, 1024, _ptr(d_rt0), F, 0, F, B, R8, R8, R4, R4, 2, 9, t9y,
                                                         t9x, *tgt, _ptr(self._wg_partial), self.st()), "wgrad convT")
 
-        self.bwd.append(convT_bwd + [convT_wgrad, self._launch_conv("dgrad convT", ddT, wdT, lowp=self.amp, out_f32=not self.amp)])
+        if x3_ct:
+            wdT3 = self._mirror3(wdT)
+            ddT.x, ddT.w = _ptr(d_rt0p), _ptr(wdT3)
+            dgradT = self._launch_conv_x3("dgrad convT", ddT, d_rt0p, wdT3, (wdT, d_rt0))
+        else:
+            dgradT = self._launch_conv("dgrad convT", ddT, wdT, lowp=self.amp, out_f32=not self.amp)
+        self.bwd.append(convT_bwd + [convT_wgrad, dgradT])
         d_prev = self.bn_unit("head.bn0", head.features[1], rt0, F, 0, F, Mh, at0, F, 0, True, dx=d_rt0)
         a_prev = at0
         nfeat = len(head.features)
