@@ -173,6 +173,8 @@ class TrainEngine:
 
     def _x3_wanted(self, d):
         """the 256x256 bf16x3 kernel would take this convolution and fills the chip with it"""
+        if 6 * d.B * max(d.H * d.W * d.in_cs, d.OH * d.OW * d.out_cs) >= (1 << 32) - 64:  # three planes behind one descriptor
+            return False
         return self.x3 and d.Cin == d.in_cs and d.in_co == 0 and self.lib.rdpn6d_conv_bf16x3_kernel_for(ctypes.byref(d)) == 2
 
     def _launch_conv_x3(self, name, d, xp3, wp3, keep):
