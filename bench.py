@@ -324,11 +324,11 @@ def main():
     elapsed = float(el.item())
 
     roof, cpu = None, None
-    dtype_label = args.dtype
+    dtype_label, dtype_note = args.dtype, None
     if args.dtype == "f32" and model.plan(B, device).x3_launches:
-        dtype_label = ("f32 (fp32 storage and accumulation; the head's wide convolutions evaluate every fp32 product exactly as six "
-                       "bf16 partial products on the bf16 MFMA pipe - error vs fp64 no larger than the fp32 MFMA kernel's; "
-                       "fp32 MFMA elsewhere)")
+        dtype_note = ("fp32 storage, accumulation and accuracy; the head and the ResNet trunk evaluate every fp32 product exactly as "
+                      "six bf16 partial products on the bf16 MFMA pipe (bf16x3, DESIGN.md section 2: error vs fp64 no larger than the "
+                      "fp32 MFMA kernel's, tested); fp32 MFMA elsewhere; --no-x3 keeps every layer on the fp32 MFMA pipe")
     if rank == 0:
         with torch.no_grad():
             roof = roofline(model, t, B, device)
@@ -351,6 +351,8 @@ def main():
             "achieved_tflops_whole_step": round(44.10e9 * value / 1e12, 2),
             "roofline": roof,
         }
+        if dtype_note:
+            line["dtype_note"] = dtype_note
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line))
