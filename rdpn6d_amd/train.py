@@ -171,11 +171,16 @@ class TrainEngine:
             self._planes[key] = p3
         return p3
 
-    def _x3_wanted(self, d):
-        """the 256x256 bf16x3 kernel would take this convolution and fills the chip with it"""
+    def _x3_wanted(self, d, allow_tile=False):
+        """the 256x256 bf16x3 kernel would take this convolution and fills the chip with it; allow_tile: also the 128x128..64x64
+        tile kernel (trunk layers with >= 128 channels at batches >= 16: forward, input gradient AND the bf16x3 weight gradient
+        share the two split passes - 1.3-1.6x per GEMM against ~12 us per split)"""
         if 6 * d.B * max(d.H * d.W * d.in_cs, d.OH * d.OW * d.out_cs) >= (1 << 32) - 64:  # three planes behind one descriptor
             return False
-        return self.x3 and d.Cin == d.in_cs and d.in_co == 0 and self.lib.rdpn6d_conv_bf16x3_kernel_for(ctypes.byref(d)) == 2
+        if not (self.x3 and d.Cin == d.in_cs and d.in_co == 0):
+            return False
+        which = self.lib.rdpn6d_conv_bf16x3_kernel_for(ctypes.byref(d))
+        return which == 2 or (allow_tile and which == 1 and d.Cin >= 128 and d.N >= 128 and self.B * self.R * self.R >= 16 * 65536)
 
     def _launch_conv_x3(self, name, d, xp3, wp3, keep):
         lib = self.lib
@@ -312,7 +317,8 @@ class TrainEngine:
         else:
             d = self._conv_desc(x, xhw, in_cs, in_co, cin_pad, wf, y, yhw, out_cs, out_co, cout, taps, stride=stride, shift=bvec,
                                 act=act_out or 0, slope=slope)
-            if stride == 1 and perm is None and self._x3_wanted(d):
+            tile_ok = name.startswith("layer")  # residual trunk
+            if stride == 1 and perm is None and self._x3_wanted(d, tile_ok):
                 x3_fwd = True
                 xp3 = self._planes_of(self.fwd, x, cache=True)
                 wf3 = self._mirror3(wf)
@@ -410,7 +416,7 @@ class TrainEngine:
                                     operm=perm)
                 dd = self._conv_desc(g_src, yhw, g_cs, g_co, n_red, wd, dx, xhw, dx_cs, in_co, cin_real, taps, stride=1,
                                      res=dx_res, res_cs=dx_cs)
-                if not lowp and perm is None and self._x3_wanted(dd):
+                if not lowp and perm is None and self._x3_wanted(dd, name.startswith("layer")):
                     if g3 is None:
                         g3 = self._planes_of(launches, dy, cache=False)  # split launch first, then the convolution
                     wd3 = self._mirror3(wd)
