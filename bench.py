@@ -161,6 +161,24 @@ def cpu_baseline(sd, budget_s=20.0):
     from rdpn6d_amd import synth
 
     ncpu = os.cpu_count() or 1
+    # the per-crop RANSAC/Kabsch solve of the step: the C oracle (single thread), when its library is there
+    pnp = None
+    so = os.path.join(ROOT, "oracle", "liboracle.so")
+    if os.path.exists(so):
+        P = ctypes.c_void_p
+        f = ctypes.CDLL(so).oracle_ransac_kabsch
+        f.argtypes = [P, P, P, P, P, P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float, ctypes.c_int,
+                      ctypes.c_float, ctypes.c_uint, P, P, P, P]
+        f.restype = None
+
+        def pnp(o, inp):
+            B, HW, K = 4, 64 * 64, 32
+            arrs = [np.ascontiguousarray(torch.cat([o["mask"], o["coor_x"], o["coor_y"], o["coor_z"], o["region"]], 1).reshape(B, 5 + K, HW).numpy()),
+                    np.ascontiguousarray(inp["roi_coord_2d"].reshape(B, 5, HW).numpy()), np.ascontiguousarray(inp["fps"].numpy()),
+                    np.ascontiguousarray(inp["roi_extent"].numpy()), np.ascontiguousarray(inp["resize_ratio"].numpy()),
+                    np.ascontiguousarray(o["region_argmax"].reshape(B, HW).numpy().astype(np.int32)),
+                    np.zeros((B, 12), np.float32), np.zeros(B, np.int32), np.zeros((B, HW), np.uint8), np.zeros(B, np.int32)]
+            f(*[a.ctypes.data_as(P) for a in arrs[:6]], B, HW, K, 0.5, 0.01, 100, 0.99, 0, *[a.ctypes.data_as(P) for a in arrs[6:]])
     m = model_oracle.GDRNOracle(32, "none")
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
     m.eval()
@@ -179,13 +197,16 @@ def cpu_baseline(sd, budget_s=20.0):
         torch.set_num_threads(best_nt)
         t0, it = time.perf_counter(), 0
         while True:
-            m(*args)
+            o = m(*args)
+            if pnp is not None:
+                pnp(o, inp)
             it += 1
             dt = time.perf_counter() - t0
             if dt > budget_s or it >= 400:
                 break
     return {"value": round(4 * it / dt, 2), "unit": "crops/s", "cores": best_nt, "kind": "port",
-            "sample": f"{it} forward passes of a B=4 batch (256x256, fp32, torch-CPU oracle incl. glue + pose decode) in "
+            "sample": f"{it} passes of a B=4 batch (256x256, fp32, torch-CPU oracle incl. glue + pose decode"
+                      f"{' + the C oracle of the per-crop RANSAC/Kabsch solve, 1 thread' if pnp is not None else ''}) in "
                       f"{dt:.1f} s with {best_nt} threads (best of an 8/16/32/64 sweep; host has {ncpu} logical CPUs)"}
 
 
