@@ -1,0 +1,119 @@
+"""Throughput of the SURVEY 8f "next" rows and of the side kernels of the path, with their HBM roofline and the CPU oracle
+beside them (bounded samples).  Prints one JSON object per row; run on the GPU box:
+    python tools/bench_next_rows.py > gpurun_out/next_rows.jsonl
+"""
+import ctypes, json, os, sys, time
+import numpy as np
+import torch
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+from rdpn6d_amd import _lib, ops, synth          # noqa: E402
+from rdpn6d_amd.crop import build_crops           # noqa: E402
+from rdpn6d_amd.gdrn import _ptr                  # noqa: E402
+
+HBM = 8000.0  # GB/s, MI355X_MICROARCH.md
+dev = torch.device("cuda:0")
+lib = _lib.load()
+
+
+def gpu_time(fn, n=20, warm=3):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e-3
+
+
+def cpu_time(fn, budget=3.0):
+    fn()
+    t0, it = time.perf_counter(), 0
+    while time.perf_counter() - t0 < budget:
+        fn()
+        it += 1
+    return (time.perf_counter() - t0) / max(it, 1)
+
+
+def row(name, units, unit_name, sec, bytes_algo, cpu_sec=None, cpu_units=None, note=""):
+    r = {"row": name, "value": round(units / sec, 1), "unit": unit_name + "/s", "ms": round(sec * 1e3, 4),
+         "roofline": {"bound": "hbm", "achieved": round(bytes_algo / sec / 1e9, 1), "peak": HBM, "unit": "GB/s",
+                      "frac": round(bytes_algo / sec / 1e9 / HBM, 4)}}
+    if cpu_sec is not None:
+        r["cpu_baseline"] = {"value": round((cpu_units or units) / cpu_sec, 2), "unit": unit_name + "/s", "kind": "port"}
+    if note:
+        r["note"] = note
+    print(json.dumps(r), flush=True)
+
+
+# ---- 1. crop builder: 64 crops out of 8 VGA frames (data_loader.py:523-627)
+from oracle import crop_oracle  # noqa: E402  (test infrastructure: CPU baseline only)
+rng = np.random.default_rng(0)
+N, H, W, B = 8, 480, 640, 64
+img = rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8)
+depth = (0.5 + rng.random((N, H, W), dtype=np.float32)).astype(np.float32)
+x0, y0 = rng.uniform(0, 400, B), rng.uniform(0, 280, B)
+wh = rng.uniform(40, 200, (B, 2))
+boxes = np.stack([x0, y0, x0 + wh[:, 0], y0 + wh[:, 1]], 1)
+idx = rng.integers(0, N, B)
+cams = np.stack([synth.LM_K.astype(np.float32)] * B)
+dimg, ddep = torch.from_numpy(img).to(dev), torch.from_numpy(depth).to(dev)
+sec = gpu_time(lambda: build_crops(dimg, ddep, idx, boxes, cams), n=10)
+out_bytes = B * (6 * 256 * 256 + 5 * 64 * 64) * 4
+c = np.array([0.5 * (boxes[0, 0] + boxes[0, 2]), 0.5 * (boxes[0, 1] + boxes[0, 3])])
+sc = min(max(wh[0, 0], wh[0, 1], 1) * 1.5, 640) * 1.0
+cpu = cpu_time(lambda: crop_oracle.build_roi(img[idx[0]], depth[idx[0]], cams[0], c, sc), 3.0)
+row("crop builder (frames + boxes -> roi_img, roi_coord_2d; incl. the host-side affine set-up)", B, "crops", sec,
+    out_bytes + B * 260 * 260 * 7, cpu, 1, "algorithmic bytes: outputs + the source window of every crop (uint8 RGB + fp32 depth)")
+
+# ---- 3. training targets: nearest anchor + residual (data_utils.py:229-244, data_loader.py:881-903)
+from oracle import targets_eval_oracle as teo  # noqa: E402
+Bt, K = 64, 32
+xyz = torch.randn(Bt, 64, 64, 3, device=dev) * 0.05
+fps64 = torch.randn(Bt, K, 3, dtype=torch.float64, device=dev) * 0.05
+rot = torch.eye(3, device=dev).repeat(Bt, 1, 1)
+ext = torch.rand(Bt, 3, device=dev) * 0.2 + 0.05
+sec = gpu_time(lambda: ops.region_targets(xyz, fps64, rot, ext))
+row("training targets (region labels + residual xyz)", Bt, "crops", sec, Bt * 4096 * (12 + 12 + 8))
+
+# ---- 4. ADD / ADI / re / te (lib/pysixd/pose_error.py:297-337,400-436)
+Be, n = 256, 3000
+Re, Rg = torch.eye(3, device=dev).repeat(Be, 1, 1), torch.eye(3, device=dev).repeat(Be, 1, 1)
+te_, tg = torch.rand(Be, 3, device=dev), torch.rand(Be, 3, device=dev)
+pts = torch.randn(n, 3, device=dev) * 0.05
+sec = gpu_time(lambda: ops.pose_errors(Re, te_, Rg, tg, pts), n=5)
+r = {"row": "ADD / ADI / re / te in fp64 (ADI = exact brute-force nearest neighbour over 3000 model points)", "value": round(Be / sec, 1),
+     "unit": "poses/s", "ms": round(sec * 1e3, 3),
+     "roofline": {"bound": "fp64 VALU", "achieved": round(Be * n * n * 9 / sec / 1e12, 2), "peak": 78.6, "unit": "TFLOP/s",
+                  "frac": round(Be * n * n * 9 / sec / 1e12 / 78.6, 4)}}
+print(json.dumps(r), flush=True)
+
+# ---- FPS (A11): 32 anchors of a 50k-point cloud, host-pointer ABI (includes H2D / D2H) and the device-resident batched form
+pts_h = rng.normal(size=(50000, 3)).astype(np.float32)
+t0 = time.perf_counter()
+for _ in range(5):
+    ops.farthest_point_sampling(pts_h, 32, init_center=True)
+sec = (time.perf_counter() - t0) / 5
+so = os.path.join(ROOT, "oracle", "liboracle.so")
+cpu = None
+if os.path.exists(so):
+    ol = ctypes.CDLL(so)
+    idxs = np.zeros(32, np.int32)
+    P = ctypes.c_void_p
+    cpu = cpu_time(lambda: ol.oracle_fps_init_center(pts_h.ctypes.data_as(P), idxs.ctypes.data_as(P), 50000, 32), 2.0)
+row("fps, host ABI (50 000 points, 32 samples, init_center; includes the copies)", 1, "clouds", sec, 50000 * 12, cpu)
+
+# ---- RANSAC / Kabsch: 64 crops, 100 hypotheses each, on synthetic maps
+from tests.ransac_cases import make_case  # noqa: E402
+c = make_case(B=64, outliers=0.3, seed=1)
+t = {k: torch.from_numpy(np.ascontiguousarray(c[k])).to(dev) for k in ("out_nchw", "coord2d", "fps", "extents", "ratios", "argmax")}
+sec = gpu_time(lambda: ops.ransac_kabsch(t["out_nchw"].reshape(64, 37, 64, 64), t["coord2d"], t["fps"], t["extents"], t["ratios"], t["argmax"]))
+cpu = None
+if os.path.exists(so):
+    from tests.test_ransac_oracle import run_oracle  # noqa: E402
+    c4 = make_case(B=4, outliers=0.3, seed=1)
+    cpu = cpu_time(lambda: run_oracle(ol, c4), 3.0)
+row("RANSAC + Kabsch (100 hypotheses per crop, scoring from LDS)", 64, "crops", sec, 64 * 4096 * 20, cpu, 4,
+    "bytes: 20 B per correspondence once (SURVEY 8d); the kernel is latency / ALU bound, not HBM bound")
