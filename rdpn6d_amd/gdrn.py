@@ -387,10 +387,11 @@ class InferencePlan:
 
         # --- residual trunk (BasicBlock: 3x3 - 3x3; Bottleneck: 1x1 - 3x3(s) - 1x1 x4; residual + ReLU in the last epilogue)
         cur, cur_hw, cur_c = p0, R4, 64
-        # fp32 mode, BasicBlock trunks, batches >= 16: the trunk's convolutions run as bf16x3 convolutions too (tile kernel,
+        # fp32 mode, batches >= 16: the trunk's convolutions (BasicBlock and Bottleneck) run as bf16x3 convolutions too (tile kernel,
         # csrc/conv_igemm_bf16x3_tile.hip) and hand their activations on as three bf16 planes; the residual is read from
         # planes as well (summed exactly), only the last block writes the fp32 tensor the up-sampling reads.
-        x3_trunk = self.x3 and not hasattr(bb.layer1[0], "conv3") and 65536 <= B * R4 * R4 and 6 * B * R4 * R4 * 64 < (1 << 32) - 64
+        wide = 256 if hasattr(bb.layer1[0], "conv3") else 64  # channels of the widest (layer1) activation
+        x3_trunk = self.x3 and 65536 <= B * R4 * R4 and 6 * B * R4 * R4 * wide < (1 << 32) - 64
         self.x3_trunk = x3_trunk
         pcur = None
         if x3_trunk:
@@ -415,17 +416,30 @@ class InferencePlan:
                         self.conv_x3(f"{nm}.downsample", pcur, (cur_hw, cur_hw), wd, scd, shd, None, pds, (ohw, ohw), cin=cur_c,
                                      in_cs=cur_c, k=1, stride=s, pad=0, N=cout, out_cs=cout, act=0)
                         res_p = pds
-                    pt = self.buf(f"l{li}_t{bi % 2}_planes", 3, npl, dtype=torch.bfloat16)
-                    w1 = pack_conv_weight(blk.conv1.weight.detach().float())
-                    sc1, sh1 = fold_bn(blk.bn1, npad=w1.shape[0])
-                    self.conv_x3(f"{nm}.conv1", pcur, (cur_hw, cur_hw), w1, sc1, sh1, None, pt, (ohw, ohw), cin=cur_c, in_cs=cur_c,
-                                 k=3, stride=s, pad=1, N=cout, out_cs=cout, act=1)
-                    w2 = pack_conv_weight(blk.conv2.weight.detach().float())
-                    sc2, sh2 = fold_bn(blk.bn2, npad=w2.shape[0])
                     o = self.buf(f"l{li}_o{bi % 2}", B, ohw, ohw, cout) if last else None
                     po = None if last else self.buf(f"l{li}_o{bi % 2}_planes", 3, npl, dtype=torch.bfloat16)
-                    self.conv_x3(f"{nm}.conv2", pt, (ohw, ohw), w2, sc2, sh2, o, po, (ohw, ohw), cin=cout, in_cs=cout, k=3,
-                                 stride=1, pad=1, N=cout, out_cs=cout, act=1, res_planes=res_p, res_cs=cout)
+                    w1 = pack_conv_weight(blk.conv1.weight.detach().float())
+                    sc1, sh1 = fold_bn(blk.bn1, npad=w1.shape[0])
+                    w2 = pack_conv_weight(blk.conv2.weight.detach().float())
+                    sc2, sh2 = fold_bn(blk.bn2, npad=w2.shape[0])
+                    if bottleneck:  # 1x1 - 3x3(s) - 1x1 (x4) + residual
+                        width = blk.conv1.weight.shape[0]
+                        pt1 = self.buf(f"l{li}_ta{bi % 2}_planes", 3, B * cur_hw * cur_hw * width, dtype=torch.bfloat16)
+                        pt2 = self.buf(f"l{li}_tb{bi % 2}_planes", 3, B * ohw * ohw * width, dtype=torch.bfloat16)
+                        self.conv_x3(f"{nm}.conv1", pcur, (cur_hw, cur_hw), w1, sc1, sh1, None, pt1, (cur_hw, cur_hw), cin=cur_c,
+                                     in_cs=cur_c, k=1, N=width, out_cs=width, act=1)
+                        self.conv_x3(f"{nm}.conv2", pt1, (cur_hw, cur_hw), w2, sc2, sh2, None, pt2, (ohw, ohw), cin=width, in_cs=width,
+                                     k=3, stride=s, pad=1, N=width, out_cs=width, act=1)
+                        w3 = pack_conv_weight(blk.conv3.weight.detach().float())
+                        sc3, sh3 = fold_bn(blk.bn3, npad=w3.shape[0])
+                        self.conv_x3(f"{nm}.conv3", pt2, (ohw, ohw), w3, sc3, sh3, o, po, (ohw, ohw), cin=width, in_cs=width, k=1,
+                                     N=cout, out_cs=cout, act=1, res_planes=res_p, res_cs=cout)
+                    else:
+                        pt = self.buf(f"l{li}_t{bi % 2}_planes", 3, npl, dtype=torch.bfloat16)
+                        self.conv_x3(f"{nm}.conv1", pcur, (cur_hw, cur_hw), w1, sc1, sh1, None, pt, (ohw, ohw), cin=cur_c, in_cs=cur_c,
+                                     k=3, stride=s, pad=1, N=cout, out_cs=cout, act=1)
+                        self.conv_x3(f"{nm}.conv2", pt, (ohw, ohw), w2, sc2, sh2, o, po, (ohw, ohw), cin=cout, in_cs=cout, k=3,
+                                     stride=1, pad=1, N=cout, out_cs=cout, act=1, res_planes=res_p, res_cs=cout)
                     cur, pcur, cur_hw, cur_c = o, po, ohw, cout
                     continue
                 res = cur

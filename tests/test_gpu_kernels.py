@@ -737,12 +737,12 @@ def test_model_pnp_type_net_variants(golden_setup, dev, oracle_lib, pnp_type):
     assert np.abs(o["pnp_pose"].cpu().numpy() - po).max() < 1e-4
 
 
-@pytest.mark.parametrize("layers,R,B", [(50, 256, 2), (50, 320, 2), (18, 256, 2), (18, 256, 16)])
+@pytest.mark.parametrize("layers,R,B", [(50, 256, 2), (50, 320, 2), (18, 256, 2), (18, 256, 16), (50, 256, 16)])
 def test_other_resnet_trunks_vs_oracle(dev, layers, R, B):
     """resnet_backbone.py:15-21 offers 18 / 34 (BasicBlock) and 50 / 101 / 152 (Bottleneck).  The reference cannot RUN the
     Bottleneck trunks (md_pointnet(512, ...) is hard-coded while layer4 then has 2048 channels) - BASELINE config 5 asks for
     ResNet-50 at 320x320 - so parity is against the generalised torch-CPU oracle, with the usual fp64 yardstick.
-    B = 16 puts the ResNet-18 trunk and the head on the bf16x3 kernels (fp32 accuracy on the bf16 matrix pipe)."""
+    B = 16 puts the trunk (BasicBlock or Bottleneck) and the head on the bf16x3 kernels (fp32 accuracy on the bf16 matrix pipe)."""
     from oracle import model_oracle
     from rdpn6d_amd import synth
     from rdpn6d_amd.config import gdrn_base_cfg
@@ -771,7 +771,7 @@ def test_other_resnet_trunks_vs_oracle(dev, layers, R, B):
         o64 = orc.double()(*args({k: (v.double() if v.dtype.is_floating_point else v) for k, v in tc.items()}))
     o = _run(model, {k: v.to(dev) for k, v in tc.items()})
     plan = model.plan(B, dev)
-    assert plan.x3_trunk == (B >= 16 and layers < 50) and plan.x3_launches > 0
+    assert plan.x3_trunk == (B >= 16) and plan.x3_launches > 0
     for k in ("mask", "coor_x", "coor_y", "coor_z", "region"):
         self_err = (o32[k].double() - o64[k]).abs().max().item()
         err = (o[k].cpu().double() - o64[k]).abs().max().item()
