@@ -406,34 +406,44 @@ __global__ __launch_bounds__(256, PL == 1 ? 3 : 2) void wgrad_bf16_kernel(const 
     };
 
     if (nchunks > 0) {
+        // The DMA of the chunk staged in a step stays in flight across that step's barrier: the step ends with a counted
+        // s_waitcnt vmcnt(<DMAs of one chunk>) - the chunk staged one step earlier has landed - and a raw s_barrier
+        // (a __syncthreads would drain the queue and expose the L2 -> LDS round trip in every step).
+        constexpr int NDMA = (APIECES + BPIECES) * PL;
+        auto publish = [&]() {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
         stage_chunk(0);
         stage_chunk(1);
-        __syncthreads();
+        publish();  // chunk 0 has landed; chunk 1 may still be in flight
         rd_s16x4 f0[NF], f1[NF];
         read_frags(0, f0);
         settle(f0);
         int st_next = 1, st_stage = 2;
         const int npairs = nchunks >> 1;
         for (int pr = 0; pr < npairs; ++pr) {
-            // step: fragment reads of the next chunk (async), DMA of the chunk after it, MFMAs of the current chunk,
-            // then wait for the reads and for the DMA (the barrier's vmcnt(0))
-            read_frags(st_next, f1);
+            // step: DMA of the chunk after next, wait for the next chunk (staged one step ago) + barrier, fragment reads of
+            // the next chunk (async), MFMAs of the current chunk, settle the reads
             stage_chunk(st_stage);
+            publish();
+            read_frags(st_next, f1);
             mma(f0);
             settle(f1);
-            __syncthreads();
             st_next = st_next == NST - 1 ? 0 : st_next + 1;
             st_stage = st_stage == NST - 1 ? 0 : st_stage + 1;
 
-            read_frags(st_next, f0);
             stage_chunk(st_stage);
+            publish();
+            read_frags(st_next, f0);
             mma(f1);
             settle(f0);
-            __syncthreads();
             st_next = st_next == NST - 1 ? 0 : st_next + 1;
             st_stage = st_stage == NST - 1 ? 0 : st_stage + 1;
         }
         if (nchunks & 1) mma(f0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
 
     const int frow = lane & 31, hi = lane >> 5;
