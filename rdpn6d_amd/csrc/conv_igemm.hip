@@ -205,32 +205,45 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_f32_kernel(const ConvKArgs 
     next_chunk(ld_tap, ld_cc, ld_left, d.ntaps, a.cchunks, a.tap_inner);
     stage_chunk(ld_tap, ld_cc, 1);
     next_chunk(ld_tap, ld_cc, ld_left, d.ntaps, a.cchunks, a.tap_inner);
-    __syncthreads();  // (waits for the LDS-DMA: vmcnt(0) + barrier)
+    // The DMA of the chunk staged in a step stays in flight across that step's barrier: a step waits with a counted
+    // s_waitcnt vmcnt(<DMAs of one chunk>) - the chunk staged one step earlier has landed for this wave - and a raw s_barrier
+    // publishes it (a __syncthreads would drain the queue and expose the L2 -> LDS round trip of the newest chunk every step).
+    constexpr int NDMA = AG + BG;
+    auto publish = [&]() {
+        // lgkmcnt(0): this wave's fragment reads of the previous step have returned, so the stage they came from may be
+        // re-filled by whoever passes the barrier
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NDMA) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    publish();  // chunk 0 has landed (chunk 1 may still be in flight)
     f32x4 fa0[TM][2], fb0[TN][2], fa1[TM][2], fb1[TN][2];
     read_frags(0, fa0, fb0);
 
     // ---- main loop over chunk PAIRS (fragment double buffer statically indexed, body branch-free).
-    // step for chunk kc: (1) start the DMA of chunk kc+2 into its LDS stage, (2) LDS->register fragments of chunk
-    // kc+1, (3) 8 MFMA k-steps of chunk kc, (4) one barrier (which also waits for the DMA issued in (1)).
+    // step for chunk kc: (1) start the DMA of chunk kc+2 into its LDS stage (its last readers finished two steps ago),
+    // (2) counted wait + barrier: chunk kc+1 is in LDS for every wave, (3) LDS->register fragments of chunk kc+1,
+    // (4) 8 MFMA k-steps of chunk kc.
     int st_next = 1, st_stage = 2;  // LDS stage holding chunk kc+1 / receiving chunk kc+2
     const int npairs = nk >> 1;
     for (int pr = 0; pr < npairs; ++pr) {
         stage_chunk(ld_tap, ld_cc, st_stage);
         next_chunk(ld_tap, ld_cc, ld_left, d.ntaps, a.cchunks, a.tap_inner);
+        publish();
         read_frags(st_next, fa1, fb1);
         mma(fa0, fb0);
-        __syncthreads();
         st_next = st_next == NST - 1 ? 0 : st_next + 1;
         st_stage = st_stage == NST - 1 ? 0 : st_stage + 1;
 
         stage_chunk(ld_tap, ld_cc, st_stage);
         next_chunk(ld_tap, ld_cc, ld_left, d.ntaps, a.cchunks, a.tap_inner);
+        publish();
         read_frags(st_next, fa0, fb0);
         mma(fa1, fb1);
-        __syncthreads();
         st_next = st_next == NST - 1 ? 0 : st_next + 1;
         st_stage = st_stage == NST - 1 ? 0 : st_stage + 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant tail DMAs must not land after the workgroup has retired
     if (nk & 1) mma(fa0, fb0);  // odd chunk count: the last chunk's fragments are already in registers
 
     const int hi = lane >> 5;
