@@ -7,6 +7,9 @@
 // structure above its plain-bf16 efficiency.
 #include "conv_x3_args.h"
 
+#include <cstdio>
+#include <cstdlib>
+
 namespace {
 
 template <int BM, int BN, int RB>
@@ -261,9 +264,19 @@ void conv_x3_pick_tile(const rdpn6d_conv_desc* d, long long M, int* pbm, int* pb
     int bm = 128;
     if ((long long)rd_cdiv(M, 128) * (d->Npad / bn) < 512) bm = 64;
     if (bm == 64 && bn == 128 && (long long)rd_cdiv(M, 64) * (d->Npad / 128) < 512) bn = 64;
+    // 32-channel chunks (two k16 steps, 48 MFMAs per barrier) beat the 128x128 tile's 16-channel chunks: 159 vs 138 TFLOP/s on
+    // the 128-channel stage of the trunk - the 128x128 tile is only for reduction widths that are not multiples of 32
+    if (bm == 128 && bn == 128 && d->Cin % 32 == 0) bm = 64;
     if ((bm != 128 || bn != 128) && d->Cin % 32) {
         if (d->Npad % 128) return;
         bm = bn = 128;
+    }
+    if (const char* f = getenv("RDPN6D_X3_TILE")) {  // profiling: "bm,bn"
+        int fbm = 0, fbn = 0;
+        if (sscanf(f, "%d,%d", &fbm, &fbn) == 2 && d->Npad % fbn == 0 && (d->Cin % 32 == 0 || (fbm == 128 && fbn == 128))) {
+            bm = fbm;
+            bn = fbn;
+        }
     }
     *pbm = bm;
     *pbn = bn;
