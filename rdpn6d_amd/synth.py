@@ -181,6 +181,28 @@ def make_state_dict(shapes, seed=1234):
     return out
 
 
+# The second, WELL-CONDITIONED fixture (tests/golden/model_c1w.npz): the same seeded recipe with the last BatchNorm of every
+# residual branch damped (gamma x 0.1), as a trained ResNet has it (zero-gamma initialisation of Goyal et al.; trained
+# residual branches are small corrections to the identity).  The plain random-weight net of make_state_dict() amplifies
+# fp32 round-off ~100x from stem to head, which puts the REFERENCE's own fp32 output 5e-4 away from the exact result;
+# with this recipe the reference is 5e-5 (maps) / 2e-5 (pose) from exact and the north star's bare 1e-4 can be asserted.
+# The input seed of that fixture is chosen so that no pixel's region arg-max is a tie at the tolerance (the reference's
+# smallest top-2 logit gap is 1.1e-4; with seed 0 three pixels sit below 1e-4 and the reference itself flips them
+# between 1 and 8 threads).
+C1W_INPUT_SEED = 36
+C1W_RESIDUAL_GAMMA = 0.1
+
+
+def make_trained_like_state_dict(shapes, seed=1234, residual_gamma=C1W_RESIDUAL_GAMMA):
+    sd = make_state_dict(shapes, seed=seed)
+    for k in sd:
+        if k.startswith("backbone.layer") and k.endswith(("bn2.weight", "bn3.weight")):
+            blk_has_bn3 = k.rsplit(".", 2)[0] + ".bn3.weight" in sd
+            if k.endswith("bn3.weight") or not blk_has_bn3:  # the LAST norm of the branch (bn2 for BasicBlock, bn3 for Bottleneck)
+                sd[k] = (sd[k] * np.float32(residual_gamma)).astype(np.float32)
+    return sd
+
+
 def sha256_of(arrays):
     """SHA-256 over the raw bytes of a list of C-contiguous arrays (order matters)."""
     h = hashlib.sha256()

@@ -1,0 +1,180 @@
+"""GPU parity at the BARE north-star tolerances on the well-conditioned fixture (tests/golden/model_c1w.npz, captured from
+the REAL reference by tools/oracle/gen_model_golden_w.py):
+
+  * dense maps <= 1e-4 max-abs, pose <= 1e-4 worst sample (relative), ZERO region arg-max flips - no fp64-relative slack;
+    at B = 4 (fp32 MFMA kernels) and with the golden crops replicated to B = 64 (the bf16x3 default path bench.py times);
+  * training: nine losses <= 1e-5; every one of the 164 parameter gradients against the reference's own gradient.
+
+model_c1.npz (random-weight, ~100x round-off amplification) stays the stress case in test_gpu_kernels.py / test_gpu_train.py.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+MAPS = ("mask", "coor_x", "coor_y", "coor_z", "region")
+
+
+def _rel(a, b):
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+@pytest.fixture(scope="module")
+def c1w(golden_dir):
+    from rdpn6d_amd import synth
+    from rdpn6d_amd.config import gdrn_base_cfg
+    from rdpn6d_amd.gdrn import build_model_optimizer
+    from tests.c1w_cases import c1w_state_dict
+
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda:0")
+    gold = np.load(os.path.join(golden_dir, "model_c1w.npz"))
+    bn = np.load(os.path.join(golden_dir, "bn_stats_c1w.npz"))
+    inp = synth.make_inputs(4, seed=int(gold["input_seed"]))
+    assert synth.sha256_of([inp[k] for k in sorted(inp)]) == str(gold["sha256_inputs"])
+    models, sd = {}, None
+    for att in ("none", "mul"):
+        model, _ = build_model_optimizer(gdrn_base_cfg(mask_attention=att, device="cuda"))
+        sd = c1w_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, bn)
+        assert synth.sha256_of([sd[k] for k in sorted(sd) if not k.endswith("num_batches_tracked")]) == str(gold["sha256_weights"])
+        sd = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+        model.load_state_dict(sd, strict=True)
+        model.eval()
+        models[att] = model
+    return models, {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}, gold, sd, inp
+
+
+def _run(model, t):
+    with torch.no_grad():
+        o = model(t["roi_img"], roi_classes=t["roi_cls"], roi_coord_2d=t["roi_coord_2d"], roi_cams=t["roi_cam"],
+                  roi_centers=t["roi_center"], roi_whs=t["roi_wh"], roi_extents=t["roi_extent"],
+                  resize_ratios=t["resize_ratio"], do_loss=False, fps=t["fps"])
+    torch.cuda.synchronize()
+    return {k: v.clone() for k, v in o.items() if torch.is_tensor(v)}
+
+
+@pytest.mark.parametrize("B", [4, 64])
+@pytest.mark.parametrize("att", ["none", "mul"])
+def test_c1w_bare_tolerance_end_to_end(c1w, att, B):
+    """tiers (i) + (iii) of SURVEY 8d with the bare numbers.  B = 64: sixteen copies of the four golden crops in a shuffled
+    order, so every batch slot has a reference answer and the large-batch kernel choices (bf16x3 head + trunk, 256x256 tiles)
+    are the ones under test."""
+    models, t, gold, _, _ = c1w
+    model = models[att]
+    dev = t["roi_img"].device
+    order = np.arange(4)
+    if B == 64:
+        order = np.concatenate([np.arange(4), np.random.default_rng(11).permutation(np.repeat(np.arange(4), 15))])
+    idx = torch.from_numpy(order).to(dev)
+    tb = {k: v[idx].contiguous() for k, v in t.items()}
+    o = _run(model, tb)
+    plan = model.plan(B, dev)
+    assert (plan.x3_launches > 0) == (B >= 16), "B=64 must exercise the bf16x3 default path, B=4 the fp32 MFMA kernels"
+    worst = {}
+    for k in MAPS:
+        ref = gold["eval_" + k].astype(np.float64)[order]
+        worst[k] = float(np.abs(o[k].cpu().numpy().astype(np.float64) - ref).max())
+    am = plan.argmax.cpu().numpy().reshape(B, 64, 64)
+    flips = int((am != gold["eval_region_argmax"][order]).sum())
+    R, T = gold[f"eval_{att}_rot"].astype(np.float64)[order], gold[f"eval_{att}_trans"].astype(np.float64)[order]
+    r, tr = o["rot"].cpu().numpy().astype(np.float64), o["trans"].cpu().numpy().astype(np.float64)
+    wr, wt = max(_rel(r[i], R[i]) for i in range(B)), max(_rel(tr[i], T[i]) for i in range(B))
+    print(f"[c1w {att} B={B}] maps max-abs vs reference: " + " ".join(f"{k} {v:.2e}" for k, v in worst.items())
+          + f" | arg-max flips {flips} / {B * 4096} | pose worst sample: R {wr:.2e} t {wt:.2e}"
+          + f" | (reference 1-vs-8 threads: maps {float(gold['ref_noise_region']):.1e}, R {float(gold[f'ref_noise_{att}_rot']):.1e},"
+          f" t {float(gold[f'ref_noise_{att}_trans']):.1e})")
+    if att == "none":  # the maps do not depend on the attention switch; the golden file holds them once
+        for k in MAPS:
+            assert worst[k] <= 1e-4, (k, worst[k])
+    assert flips == 0
+    assert wr <= 1e-4 and wt <= 1e-4, (wr, wt)
+    assert np.allclose(np.linalg.det(r), 1.0, atol=1e-5)
+
+
+@pytest.fixture(scope="module")
+def c1w_train(c1w):
+    """one HIP training step (B = 4) per attention variant + the oracle's autograd on this box's CPU"""
+    from oracle import model_oracle
+    from rdpn6d_amd import synth
+    from rdpn6d_amd.train import TrainEngine
+
+    models, t, gold, sd, inp = c1w
+    dev = t["roi_img"].device
+    gt = synth.make_train_gt(4, inp)
+    assert synth.sha256_of([gt[k] for k in sorted(gt)]) == str(gold["train_sha256_gt"])
+    out = {}
+    for att in ("none", "mul"):
+        model = models[att]
+        model.load_state_dict(sd, strict=True)  # (the running statistics move in train mode: start from the fixture)
+        eng = TrainEngine(model, 4, dev)
+        batch = {k: torch.from_numpy(v).to(dev) for k, v in {**inp, **gt}.items()}
+        losses = {k: v.item() for k, v in eng.forward_backward(batch).items()}
+        torch.cuda.synchronize()
+        grads = {n: p.grad.detach().cpu().double().clone() for n, p in model.named_parameters()}
+        orc = model_oracle.GDRNOracle(32, att)
+        orc.load_state_dict(sd, strict=True)
+        orc.train()
+        tc = {k: torch.from_numpy(v) for k, v in {**inp, **gt}.items()}
+        oo = orc(tc["roi_img"], tc["roi_coord_2d"], tc["fps"], tc["roi_cam"], tc["roi_center"], tc["roi_wh"], tc["resize_ratio"],
+                 train_pose=True)
+        sum(model_oracle.gdrn_losses(oo, tc, tc["roi_extent"]).values()).backward()
+        ograds = {n: p.grad.double() for n, p in orc.named_parameters()}
+        model.load_state_dict(sd, strict=True)
+        model.eval()
+        out[att] = (losses, grads, ograds)
+    return out
+
+
+@pytest.mark.parametrize("att", ["none", "mul"])
+def test_c1w_training_losses_1e5(c1w, c1w_train, att):
+    gold = c1w[2]
+    losses = c1w_train[att][0]
+    assert len(losses) == 9
+    for k, v in losses.items():
+        ref = float(gold[f"train_{att}_{k}"])
+        print(f"[c1w {att}] {k}: HIP {v:.7f} reference {ref:.7f} rel {abs(v - ref) / max(1.0, abs(ref)):.1e} (reference 1-vs-8 threads "
+              f"{float(gold[f'train_{att}_noise_{k}']):.1e})")
+        assert abs(v - ref) <= 1e-5 * max(1.0, abs(ref)), (k, v, ref)
+
+
+@pytest.mark.parametrize("att", ["none", "mul"])
+def test_c1w_all_164_gradients_vs_reference(c1w, c1w_train, att):
+    """Every parameter gradient against the REAL reference's: the golden file holds 256 seeded entries + the norm of each of
+    the 164 tensors, and the reference's own 1-vs-8-thread difference per tensor (`train_*_grad_noise/*`).  A ReLU network's
+    fp32 backward is reproducible only to ~sqrt(fraction of ReLU masks that flip under round-off): the reference differs
+    from ITSELF by 2.5e-3 (median; 4e-3 max) on the trunk / head tensors and by 1e-6..4e-5 on the tensors behind the last
+    ReLU-free stretch (output conv, ConvPnPNet).  Bound per tensor: max(1e-3, 2.5 x its own reference noise) - i.e. the bare
+    1e-3 wherever the reference itself reproduces to better than 4e-4, and the reference's own reproducibility elsewhere.
+    The full tensors are also compared with the oracle's autograd (bit-equal to the reference on one box) at the same bound."""
+    from tests.c1w_cases import grad_sample_index
+
+    gold = c1w[2]
+    _, grads, ograds = c1w_train[att]
+    rows = []
+    for name, g in grads.items():
+        ref_s, ref_n = gold[f"train_{att}_grad_sample/{name}"].astype(np.float64), float(gold[f"train_{att}_grad_norm/{name}"])
+        noise = float(gold[f"train_{att}_grad_noise/{name}"])
+        if ref_n < 1e-4:  # exact gradient is zero up to round-off (a conv bias in front of a BatchNorm)
+            assert g.norm().item() < 1e-4, name
+            continue
+        mine_s = g.reshape(-1)[torch.from_numpy(grad_sample_index(name, g.numel()))].numpy()
+        e_s = np.linalg.norm(mine_s - ref_s) / np.linalg.norm(ref_s)
+        e_n = abs(g.norm().item() - ref_n) / ref_n
+        e_o = ((g - ograds[name]).norm() / ograds[name].norm()).item()
+        rows.append((name, e_s, e_n, e_o, noise))
+    assert len(rows) + sum(1 for n in grads if float(gold[f"train_{att}_grad_norm/{n}"]) < 1e-4) == 164
+    med = lambda i: float(np.median([r[i] for r in rows]))  # noqa: E731
+    print(f"[c1w {att}] relative gradient error, median over {len(rows)} tensors: vs reference samples {med(1):.2e}, norm {med(2):.2e}, "
+          f"full tensor vs oracle autograd {med(3):.2e} | reference 1-vs-8 threads {med(4):.2e}")
+    tight = [r for r in rows if r[4] < 4e-4]
+    print(f"[c1w {att}] {len(tight)} tensors where the reference reproduces itself to < 4e-4: worst HIP error "
+          f"{max(r[3] for r in tight):.2e} (bound 1e-3)")
+    for name, e_s, e_n, e_o, noise in sorted(rows, key=lambda r: -r[3] / max(1e-3, 2.5 * r[4]))[:5]:
+        print(f"    {name}: samples {e_s:.2e} norm {e_n:.2e} full-vs-oracle {e_o:.2e} | reference noise {noise:.2e}")
+    for name, e_s, e_n, e_o, noise in rows:
+        bound = max(1e-3, 2.5 * noise)
+        assert e_o <= bound, (name, e_o, noise)
+        assert e_n <= bound, (name, e_n, noise)
+        assert e_s <= 2.0 * bound, (name, e_s, noise)  # a 256-entry estimate of the same ratio

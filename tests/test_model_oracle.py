@@ -113,3 +113,77 @@ def test_pm_loss_sym_oracle_vs_reference_golden(golden_dir):
         assert abs(L["loss_PM_R"].item() - float(gold[f"loss_PM_R_{name}"])) <= 1e-6 * float(gold[f"loss_PM_R_{name}"])
         (gr,) = torch.autograd.grad(L["loss_PM_R"], pred)
         np.testing.assert_allclose(gr.numpy(), gold[f"grad_pred_rots_{name}"], rtol=1e-5, atol=1e-8)
+
+
+# ------------------------------------------------------------------------- the well-conditioned fixture (model_c1w.npz)
+@pytest.fixture(scope="module")
+def setup_w(golden_dir):
+    from tests.c1w_cases import c1w_state_dict
+
+    gold = np.load(os.path.join(golden_dir, "model_c1w.npz"))
+    bn = np.load(os.path.join(golden_dir, "bn_stats_c1w.npz"))
+    inp = synth.make_inputs(4, seed=int(gold["input_seed"]))
+    assert synth.sha256_of([inp[k] for k in sorted(inp)]) == str(gold["sha256_inputs"])
+    m = model_oracle.GDRNOracle(32, "none")
+    sd = c1w_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, bn)
+    assert synth.sha256_of([sd[k] for k in sorted(sd) if not k.endswith("num_batches_tracked")]) == str(gold["sha256_weights"])
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    return m, {k: torch.from_numpy(v) for k, v in inp.items()}, gold, sd
+
+
+def test_c1w_oracle_meets_the_bare_north_star_tolerance(setup_w):
+    """oracle vs the REAL reference on the well-conditioned fixture: maps <= 1e-4 max-abs, pose <= 1e-4 worst sample, zero
+    arg-max flips - the bare tolerances, no fp64-relative slack (the reference's own 1-vs-8-thread noise, recorded in the
+    fixture from the real code, is 2.6e-5 / 9e-6 / 0 flips)."""
+    m, t, gold, _ = setup_w
+    assert float(gold["eval_region_min_top2_gap"]) > 1e-4 and int(gold["ref_noise_argmax_flips"]) == 0
+    o = _fwd(m, t, "none")
+    for k in ("mask", "coor_x", "coor_y", "coor_z", "region"):
+        assert float(gold["ref_noise_" + k]) < 5e-5
+        assert np.abs(o[k].numpy() - gold["eval_" + k]).max() <= 1e-4, k
+    assert np.array_equal(o["region_argmax"].numpy().reshape(4, 64, 64), gold["eval_region_argmax"])
+    for att in ("none", "mul"):
+        o = _fwd(m, t, att)
+        for k in ("rot", "trans"):
+            ref = gold[f"eval_{att}_{k}"].astype(np.float64)
+            worst = max(np.linalg.norm(o[k][i].numpy() - ref[i]) / np.linalg.norm(ref[i]) for i in range(4))
+            assert worst <= 1e-4, (att, k, worst)
+
+
+@pytest.mark.parametrize("att", ["none", "mul"])
+def test_c1w_oracle_training_losses_and_all_gradients(setup_w, att):
+    """nine losses <= 1e-5 and all 164 parameter gradients against the reference's own (256 seeded entries + norm per tensor).
+    Gradient bound: a ReLU network's fp32 backward is only reproducible to ~sqrt(fraction of ReLU masks that flip): the REAL
+    reference differs from itself by 2.5e-3 (median, max 4e-3) between 1 and 8 threads on this fixture (train_*_grad_noise/*,
+    captured from the real code), so the bound is max(1e-3, 2.5 x that tensor's own reference noise)."""
+    from tests.c1w_cases import grad_sample_index
+
+    _, t, gold, sd = setup_w
+    m = model_oracle.GDRNOracle(32, att)
+    m.load_state_dict(sd, strict=True)
+    m.train()
+    gt = synth.make_train_gt(4, {k: v.numpy() for k, v in t.items()})
+    assert synth.sha256_of([gt[k] for k in sorted(gt)]) == str(gold["train_sha256_gt"])
+    tg = {k: torch.from_numpy(v) for k, v in gt.items()}
+    o = m(t["roi_img"], t["roi_coord_2d"], t["fps"], t["roi_cam"], t["roi_center"], t["roi_wh"], t["resize_ratio"], train_pose=True)
+    L = model_oracle.gdrn_losses(o, tg, t["roi_extent"])
+    for k, v in L.items():
+        ref = float(gold[f"train_{att}_{k}"])
+        assert abs(v.item() - ref) <= 1e-5 * max(1.0, abs(ref)), (k, v.item(), ref)
+    sum(L.values()).backward()
+    n = 0
+    for name, p in m.named_parameters():
+        ref_s, ref_n = gold[f"train_{att}_grad_sample/{name}"].astype(np.float64), float(gold[f"train_{att}_grad_norm/{name}"])
+        noise = float(gold[f"train_{att}_grad_noise/{name}"])
+        g = p.grad.double()
+        mine_s = g.reshape(-1)[torch.from_numpy(grad_sample_index(name, g.numel()))].numpy()
+        n += 1
+        if ref_n < 1e-4:  # exact gradient is zero up to round-off (a conv bias in front of a BatchNorm)
+            assert g.norm().item() < 1e-4, name
+            continue
+        bound = max(1e-3, 2.5 * noise)
+        assert abs(g.norm().item() - ref_n) <= bound * ref_n, (name, g.norm().item(), ref_n)
+        assert np.linalg.norm(mine_s - ref_s) <= 2.0 * bound * np.linalg.norm(ref_s), (name, noise)  # 256-entry estimate of the same ratio
+    assert n == 164
