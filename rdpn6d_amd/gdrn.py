@@ -22,6 +22,16 @@ import torch.nn as nn
 
 from . import _lib
 
+# Weights change under the packed copies an InferencePlan holds in three ways: torch in-place ops (seen through the tensors'
+# ``_version`` counters), and the two raw-pointer writers of this package - the fused Ranger step and the train engine's
+# BatchNorm running-statistics update - which bump this epoch.  GDRN.plan() rebuilds a plan whose stamp is stale.
+_WEIGHTS_EPOCH = [0]
+
+
+def bump_weights_epoch():
+    _WEIGHTS_EPOCH[0] += 1
+
+
 # resnet_backbone.py:15-21: (block expansion, blocks per layer).  Expansion 1 = torchvision BasicBlock, 4 = Bottleneck.
 # The reference cannot run the Bottleneck trunks (md_pointnet(512, ...) is hard-coded at :270 while layer4 then has
 # 2048 channels); here the point-wise fusion takes layer4's real channel count.
@@ -751,21 +761,37 @@ class GDRN(nn.Module):
                  "roi_wh": roi_whs, "resize_ratio": resize_ratios, "roi_extent": roi_extents, "roi_xyz": gt_xyz,
                  "roi_mask_visib": gt_mask_visib, "roi_mask_trunc": gt_mask_trunc, "roi_region": gt_region, "ego_rot": gt_ego_rot,
                  "roi_trans_ratio": gt_trans_ratio, "roi_points": gt_points, "sym_info": sym_infos}
-        losses = eng.forward_losses(batch)
+        losses = eng.forward_losses(batch)  # (bumps the weights epoch: BatchNorm running statistics moved)
         names = list(losses)
         anchor = next(p for p in self.parameters() if p.requires_grad)
         outs = _HipBackward.apply(anchor, eng, *[losses[n] for n in names])
         self.last_train_pose = (eng.rot, eng.trans)
         return {}, dict(zip(names, outs))
 
+    def _weights_stamp(self):
+        """changes whenever a parameter or buffer may have changed since a plan packed its copies (module docstring of
+        _WEIGHTS_EPOCH): eval -> train steps -> eval must not serve the old weights"""
+        v = _WEIGHTS_EPOCH[0]
+        for t in self.parameters():
+            v = v * 1000003 + t._version
+        for t in self.buffers():
+            v = v * 1000003 + t._version
+        return v & 0xFFFFFFFFFFFF
+
     def plan(self, B, device, bf16=None):
         """bf16=None follows cfg.TEST.AMP_TEST (the reference's autocast switch, gdrn_evaluator.py:625)."""
         if bf16 is None:
             bf16 = bool(self.cfg.get("TEST", {}).get("AMP_TEST", False))
         key = (B, str(device), bool(bf16))
-        if key not in self._plans:
-            self._plans[key] = InferencePlan(self, B, device, bf16=bf16)
-        return self._plans[key]
+        stamp = self._weights_stamp()
+        plan = self._plans.get(key)
+        if plan is not None and plan.weights_stamp != stamp:
+            del self._plans[key], plan  # weights moved under the packed copies (optimizer step, BN statistics, in-place edit)
+            plan = None
+        if plan is None:
+            plan = self._plans[key] = InferencePlan(self, B, device, bf16=bf16)
+            plan.weights_stamp = stamp
+        return plan
 
     def forward(self, x, gt_xyz=None, gt_xyz_bin=None, gt_mask_trunc=None, gt_mask_visib=None, gt_mask_obj=None,
                 gt_region=None, gt_allo_quat=None, gt_ego_quat=None, gt_allo_rot6d=None, gt_ego_rot6d=None,
@@ -829,7 +855,7 @@ class GDRN(nn.Module):
             plan.run_graphed(key, launch)
         else:
             launch()
-        o = plan.out_nchw
+        o = plan.out_nchw.clone()  # the plan's buffer is overwritten by the next forward: hand out a private copy
         K = plan.K
         out = {
             "rot": plan.rot.clone(), "trans": plan.trans.clone(),
@@ -853,8 +879,13 @@ class _HipBackward(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gouts):
-        # d(total)/d(loss_i) must be 1 for every loss (the reference sums the dict un-weighted: engine.py:292)
-        ctx.engine.backward()
+        # d(total)/d(loss_i) as autograd hands it over: 1 for the reference's un-weighted sum (engine.py:292), the loss scale
+        # under a GradScaler (engine.py:302-309), 1/accum for gradient accumulation, 0 for a loss left out of the sum.  One
+        # host read of the nine scalars per step (the reference's own loop reads every loss with .item(), engine.py:299-300).
+        eng = ctx.engine
+        w = torch.stack([g.detach().reshape(()).float() if g is not None else torch.zeros((), device=eng.dev) for g in gouts]).tolist()
+        eng.seed_backward(dict(zip(eng.LOSS_NAMES, w)))
+        eng.backward()
         hook = getattr(ctx.engine, "after_backward", None)
         if hook is not None:
             hook()
@@ -932,8 +963,60 @@ def build_model_optimizer(cfg):
                                    "lr": float(cfg.SOLVER.BASE_LR) * mult})
     model = GDRN(cfg, backbone, rot_head, trans_head_net=None, pnp_net=pnp_net)
     optimizer = build_optimizer_with_params(cfg, params_lr_list)
+    if cfg.MODEL.get("WEIGHTS", "") == "":  # GDRN.py:836-851: ImageNet trunk unless a full checkpoint follows
+        load_pretrained_backbone(model.backbone, backbone_cfg.get("PRETRAINED", ""))
     model.to(torch.device(cfg.MODEL.DEVICE))
     return model, optimizer
+
+
+def load_pretrained_backbone(backbone, spec):
+    """``BACKBONE.PRETRAINED`` (GDRN.py:836-851 -> mmcv ``load_checkpoint(model.backbone, spec, strict=False)``).  There is no
+    network here, so ``torchvision://resnetNN`` is looked up in the torch hub cache (``$TORCH_HOME/hub/checkpoints/resnetNN-*.pth``,
+    where torchvision / mmcv leave it) and a plain path is read directly; ``{"state_dict": ...}`` / ``{"model": ...}`` wrappers and a
+    ``backbone.`` / ``module.`` prefix are unwrapped like mmcv does.  Non-strict: the fc layer of the ImageNet file is ignored,
+    the point-wise fusion branch keeps its initialisation.  A spec that cannot be resolved is an ERROR unless
+    RDPN6D_ALLOW_RANDOM_BACKBONE=1 - training from a random trunk by accident is the silent failure this replaces."""
+    import glob
+    import logging
+    import os
+
+    log = logging.getLogger(__name__)
+    if not spec:
+        log.warning("Randomly initialize weights for backbone!")  # the reference's own message (GDRN.py:839)
+        return None
+    path = spec
+    if spec.startswith("torchvision://"):
+        name = spec[len("torchvision://"):]
+        hub = os.path.join(os.environ.get("TORCH_HOME", os.path.join(os.path.expanduser("~"), ".cache", "torch")), "hub", "checkpoints")
+        hits = sorted(glob.glob(os.path.join(hub, name + "-*.pth")) + glob.glob(os.path.join(hub, name + ".pth")))
+        path = hits[0] if hits else None
+    elif spec.startswith(("http://", "https://", "open-mmlab://")):
+        path = None
+    if path is None or not os.path.isfile(path):
+        msg = (f"BACKBONE.PRETRAINED={spec!r} cannot be resolved offline (no file in the torch hub cache / at that path); "
+               "give a local .pth path, set MODEL.WEIGHTS, or PRETRAINED='' for a random trunk")
+        if os.environ.get("RDPN6D_ALLOW_RANDOM_BACKBONE") == "1":
+            log.warning(msg + " - continuing with a RANDOM trunk (RDPN6D_ALLOW_RANDOM_BACKBONE=1)")
+            return None
+        raise FileNotFoundError(msg)
+    sd = torch.load(path, map_location="cpu", weights_only=True)
+    for wrap in ("state_dict", "model"):
+        if isinstance(sd, dict) and wrap in sd and isinstance(sd[wrap], dict):
+            sd = sd[wrap]
+    def strip(k):
+        for pre in ("module.backbone.", "backbone.", "module."):
+            if k.startswith(pre):
+                return k[len(pre):]
+        return k
+
+    sd = {strip(k): v for k, v in sd.items()}
+    own = backbone.state_dict()
+    use = {k: v for k, v in sd.items() if k in own and tuple(v.shape) == tuple(own[k].shape)}
+    res = backbone.load_state_dict(use, strict=False)
+    log.info(f"load backbone weights from: {spec} ({len(use)} tensors; missing {len(res.missing_keys)}, ignored {len(sd) - len(use)})")
+    if not use:
+        raise ValueError(f"{path}: no tensor matches the trunk's state_dict")
+    return res
 
 
 def build_optimizer_with_params(cfg, params):

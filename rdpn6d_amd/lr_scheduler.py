@@ -32,18 +32,18 @@ def flat_and_anneal_lr_scheduler(optimizer, total_iters, warmup_iters=0, warmup_
                 return warmup_factor * (1 - a) + a
             return warmup_factor
         if x >= anneal_start:
-            frac = (float(x) - anneal_start) / (total_iters - anneal_start)
             if anneal_method == "step":
                 return step_gamma ** bisect_right([s * total_iters for s in steps], float(x))
+            if anneal_method == "none":
+                return 1
+            frac = (float(x) - anneal_start) / (total_iters - anneal_start)  # progress through the annealing stretch
             if anneal_method == "cosine":
                 return target_lr_factor + 0.5 * (1 - target_lr_factor) * (1 + cos(pi * frac))
             if anneal_method == "linear":
                 return target_lr_factor + (1 - target_lr_factor) * (1 - frac)
             if anneal_method == "poly":
                 return target_lr_factor + (1 - target_lr_factor) * (1 - frac) ** poly_power
-            if anneal_method == "exp":
-                return max(target_lr_factor, 5e-3) ** frac
-            return 1
+            return max(target_lr_factor, 5e-3) ** frac  # "exp"
         return 1
 
     return torch.optim.lr_scheduler.LambdaLR(optimizer, f)

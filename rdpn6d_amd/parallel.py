@@ -27,28 +27,63 @@ class GradBuckets:
     contiguous buffer; ``reduce(group)`` starts the (asynchronous) all-reduce of that group's slice,
     ``finish()`` waits for all of them and turns sums into means."""
 
-    def __init__(self, model, groups=GROUPS, process_group=None):
+    def __init__(self, model, groups=GROUPS, process_group=None, optimizer=None):
+        """optimizer: the rdpn6d_amd Ranger that will step these parameters.  If it has already built its flat gradient
+        buffer (a step was taken) that buffer is ADOPTED here - each group is a contiguous slice of it in any order - so both
+        sides keep working on the same memory; an un-built Ranger adopts this buffer at its first step by itself."""
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
         params = {g: [p for p in getattr(model, g).parameters() if p.requires_grad] for g in groups}
+        self.params = params
         n = sum(p.numel() for ps in params.values() for p in ps)
         ref = next(p for ps in params.values() for p in ps)
-        self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
-        self.slices, o = {}, 0
-        for g in groups:
-            b = o
-            for p in params[g]:
-                p.grad = self.flat[o:o + p.numel()].view_as(p)
-                o += p.numel()
-            self.slices[g] = (b, o)
+        flat = getattr(optimizer, "_flat", None)
+        flat = flat["g"] if flat else None
+        self.slices = {}
+        if flat is not None:
+            if flat.numel() != n:
+                raise ValueError("GradBuckets: the optimizer's flat gradient buffer does not cover exactly the model's trainable parameters")
+            for g in groups:
+                lo = min((p.grad.data_ptr() - flat.data_ptr()) // 4 for p in params[g])
+                cnt = sum(p.numel() for p in params[g])
+                inside = all(0 <= (p.grad.data_ptr() - flat.data_ptr()) // 4 - lo <= cnt - p.numel() for p in params[g])
+                if not inside:
+                    raise ValueError(f"GradBuckets: group {g!r} is not one contiguous slice of the optimizer's flat gradient buffer")
+                self.slices[g] = (lo, lo + cnt)
+            self.flat = flat
+        else:
+            self.flat = torch.zeros(n, dtype=ref.dtype, device=ref.device)
+            o = 0
+            for g in groups:
+                b = o
+                for p in params[g]:
+                    p.grad = self.flat[o:o + p.numel()].view_as(p)
+                    o += p.numel()
+                self.slices[g] = (b, o)
+        self._home = {id(p): (p.grad.data_ptr() - self.flat.data_ptr()) // 4 for ps in params.values() for p in ps}
         self.handles = []
         # gloo has no AVG: reduce with SUM and scale in finish()
         self.avg_op = self.world > 1 and dist.get_backend(process_group) == "nccl"
+
+    def _rehome(self, group):
+        """a caller may have replaced param.grad since construction (model.zero_grad(set_to_none=True) followed by a
+        backward that allocates fresh tensors): bring such gradients back into the flat buffer BEFORE it is reduced -
+        reducing a buffer the gradients no longer live in would silently leave the ranks un-synchronised."""
+        base = self.flat.data_ptr()
+        for p in self.params[group]:
+            o = self._home[id(p)]
+            if p.grad is None:
+                raise RuntimeError("GradBuckets.reduce: a parameter of group %r has no gradient (backward not run?)" % group)
+            if p.grad.data_ptr() != base + 4 * o:
+                view = self.flat[o:o + p.numel()].view_as(p)
+                view.copy_(p.grad)
+                p.grad = view
 
     def zero_(self):
         self.flat.zero_()
 
     def reduce(self, group):
+        self._rehome(group)
         if self.world == 1:
             return
         b, e = self.slices[group]

@@ -53,17 +53,42 @@ class Ranger(Optimizer):
         n = sum(p.numel() for p in ps)
         f32 = dict(dtype=torch.float32, device=dev)
         fp = torch.empty(n, **f32)
-        # gradients: adopt an existing flat buffer (GradBuckets) when every p.grad already is a view into it, in order
+        # Gradients.  If every p.grad already is a view into ONE foreign flat fp32 buffer that the parameters tile exactly
+        # (parallel.GradBuckets, in whatever group order it chose), that buffer IS adopted and its layout becomes the layout
+        # of all five flat buffers - the all-reduce views stay valid.  The work tables below address parameters by offset,
+        # so no particular order is needed.  Otherwise a fresh buffer in param_groups order is made.
         fg = self._ext_flat_grad
-        offs, o = {}, 0
-        adopt = fg is not None and fg.numel() == n
-        for p in ps:
-            offs[id(p)] = o
-            if adopt and not (p.grad is not None and p.grad.data_ptr() == fg.data_ptr() + 4 * o):
-                adopt = False
-            o += p.numel()
+        if fg is None:
+            bases = {id(p.grad._base) for p in ps if p.grad is not None and p.grad._base is not None}
+            if len(bases) == 1 and all(p.grad is not None and p.grad._base is not None for p in ps):
+                fg = ps[0].grad._base
+        offs, adopt = {}, False
+        if fg is not None:
+            adopt = fg.dim() == 1 and fg.numel() == n and fg.dtype == torch.float32 and fg.is_contiguous() and fg.device == dev
+            spans = []
+            for p in ps:
+                if not adopt:
+                    break
+                byte = (p.grad.data_ptr() - fg.data_ptr()) if p.grad is not None else -1
+                if byte < 0 or byte % 4 or byte // 4 + p.numel() > n or not p.grad.is_contiguous():
+                    adopt = False
+                    break
+                offs[id(p)] = byte // 4
+                spans.append((byte // 4, p.numel()))
+            if adopt:  # exact tiling of [0, n): no overlap, no hole
+                spans.sort()
+                adopt = all(spans[i][0] + spans[i][1] == (spans[i + 1][0] if i + 1 < len(spans) else n) for i in range(len(spans))) \
+                    and spans[0][0] == 0
+            if not adopt and self._ext_flat_grad is not None:
+                raise ValueError("Ranger(flat_grad=...): the parameters' .grad tensors are not views that tile this buffer exactly; "
+                                 "build parallel.GradBuckets(model) first (it points every param.grad into its flat buffer) or "
+                                 "drop the argument")
         if not adopt:
             fg = torch.zeros(n, **f32)
+            offs, o = {}, 0
+            for p in ps:
+                offs[id(p)] = o
+                o += p.numel()
         fm, fv, fs = torch.zeros(n, **f32), torch.zeros(n, **f32), torch.empty(n, **f32)
         for p in ps:
             o, k = offs[id(p)], p.numel()
@@ -117,10 +142,15 @@ class Ranger(Optimizer):
         return self._flat["g"]
 
     def zero_grad(self, set_to_none=False):
-        """keeps param.grad as views of the flat gradient buffer (set_to_none would break the fused step's layout)"""
-        if self._flat is None:
-            return super().zero_grad(set_to_none=set_to_none)
-        self._flat["g"].zero_()
+        """Zeroes IN PLACE, whatever `set_to_none` says (the reference loop calls zero_grad(set_to_none=True), engine.py:304):
+        param.grad tensors are views into a flat buffer - this optimizer's, or parallel.GradBuckets' all-reduce buffer - and
+        dropping them would silently detach the gradients from the buffer that is reduced / stepped."""
+        if self._flat is not None:
+            self._flat["g"].zero_()
+            return
+        grads = [p.grad for g in self.param_groups for p in g["params"] if p.grad is not None]
+        if grads:
+            torch._foreach_zero_(grads)
 
     # ------------------------------------------------------------------ step
     @torch.no_grad()
@@ -137,6 +167,9 @@ class Ranger(Optimizer):
                 p.grad = F["g"][o // 4:o // 4 + p.numel()].view_as(p)
         self._step += 1
         step = self._step
+        from .gdrn import bump_weights_epoch
+
+        bump_weights_epoch()  # the kernel writes the parameters through raw pointers: packed inference copies are stale
         lib = _lib.load()
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         P = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731

@@ -190,6 +190,10 @@ def make_state_dict(shapes, seed=1234):
 # smallest top-2 logit gap is 1.1e-4; with seed 0 three pixels sit below 1e-4 and the reference itself flips them
 # between 1 and 8 threads).
 C1W_INPUT_SEED = 36
+# the TRAINING pass of that fixture runs with batch statistics, i.e. on different maps: its batch is seeded separately, by the
+# same criterion (smallest top-2 gap of the train-mode forward 1.3e-4), because one flipped arg-max pixel changes three
+# ConvPnPNet input channels and with them every ConvPnPNet gradient by ~1e-3
+C1W_TRAIN_INPUT_SEED = 50
 C1W_RESIDUAL_GAMMA = 0.1
 
 

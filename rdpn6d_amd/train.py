@@ -867,20 +867,52 @@ class TrainEngine:
         for fn in self.fwd:
             fn()
         torch._foreach_add_(self._bn_counters, 1)  # BatchNorm2d.num_batches_tracked (one fused launch)
+        from .gdrn import bump_weights_epoch
+
+        bump_weights_epoch()  # running statistics moved under any InferencePlan's folded copies
+        sym = self._pack_sym_infos(batch.get("sym_info")) if self.pm_sym else (None, None, 0)
+        self._loss_ctx = (cams, centers, whs, ratios, extents, gt_xyz, mv, mt, gt_region, gt_rot, gt_ratio, pts, sym)
+        self._run_loss_kernels(self.lw, self.losses9)
+        return {n: self.losses9[i] for i, n in enumerate(self.LOSS_NAMES)}
+
+    def _run_loss_kernels(self, lw, losses9):
+        """the two loss kernels: nine losses into `losses9` and the backward seeds d(sum_i w_i * loss_i)/d(head output) and
+        /d(pose head output) into d_head / d_rt, the weights w being the six entries of `lw`"""
+        lib, B, K = self.lib, self.B, self.K
+        cams, centers, whs, ratios, extents, gt_xyz, mv, mt, gt_region, gt_rot, gt_ratio, pts, (sym_rots, sym_counts, ksym) = self._loss_ctx
         HW = (self.R // 4) ** 2
-        lw = self.lw
         sc = self.buf("pose_scratch", 3 * B)
-        sym_rots, sym_counts, ksym = self._pack_sym_infos(batch.get("sym_info")) if self.pm_sym else (None, None, 0)
         _lib.check(lib.rdpn6d_pose_train_sym_f32(_ptr(self.rt), 16, _ptr(cams), _ptr(centers), _ptr(whs), _ptr(ratios),
                                                  _ptr(extents), _ptr(gt_rot), _ptr(gt_ratio), _ptr(pts), pts.shape[1], B,
                                                  self.is_allo, lw["pm"], lw["pm_norm"], lw["centroid"], lw["z"],
                                                  _ptr(sym_rots) if ksym else None, _ptr(sym_counts) if ksym else None, ksym,
                                                  _ptr(self.gt_rot_used), _ptr(self.rot), _ptr(self.trans), _ptr(self.d_rt),
-                                                 _ptr(self.losses9[6:]), _ptr(sc), self.st()), "pose_train")
+                                                 _ptr(losses9[6:]), _ptr(sc), self.st()), "pose_train")
         _lib.check(lib.rdpn6d_dense_losses_f32(_ptr(self.head_out), self.head_cs, _ptr(gt_xyz), _ptr(mv), _ptr(mt), _ptr(gt_region), B, HW,
-                                               K, lw["xyz"], lw["mask"], lw["region"], _ptr(self.d_head), _ptr(self.losses9),
+                                               K, lw["xyz"], lw["mask"], lw["region"], _ptr(self.d_head), _ptr(losses9),
                                                _ptr(self._scratch_d), self.st()), "dense_losses")
-        return {n: self.losses9[i] for i, n in enumerate(self.LOSS_NAMES)}
+
+    def seed_backward(self, weights):
+        """d(total)/d(loss_i) for the next backward() - what autograd hands to the node the nine losses hang off
+        (gdrn._HipBackward): all 1 for the reference's plain sum, the loss scale under a GradScaler (engine.py:302-309),
+        1/n for gradient accumulation, 0 for a loss left out.  The backward is linear in its two seeds, so a common factor
+        scales them; different factors re-run the two loss kernels with the loss weights multiplied (losses that share a
+        weight in the kernels - coor_x/y/z, region/region_my - must then share their factor)."""
+        w = [float(weights.get(n, 0.0)) for n in self.LOSS_NAMES]
+        if any(x != x or x in (float("inf"), float("-inf")) for x in w):
+            raise FloatingPointError(f"non-finite gradient flowing into the losses: {dict(zip(self.LOSS_NAMES, w))}")
+        if all(x == w[0] for x in w):
+            if w[0] != 1.0:
+                self.d_head.mul_(w[0])
+                self.d_rt.mul_(w[0])
+            return
+        if not (w[0] == w[1] == w[2] and w[4] == w[5]):
+            raise NotImplementedError("different upstream gradients for loss_coor_x/y/z or for loss_region/loss_region_my: the loss "
+                                      f"kernels weight them as one group ({dict(zip(self.LOSS_NAMES, w))})")
+        lw = dict(self.lw)
+        for key, i in (("xyz", 0), ("mask", 3), ("region", 4), ("pm", 6), ("centroid", 7), ("z", 8)):
+            lw[key] = self.lw[key] * w[i]
+        self._run_loss_kernels(lw, self.buf("losses9_scratch", 9))
 
     def backward(self, on_group_done=None):
         """Backward of sum(losses) into param.grad.  on_group_done(name) is called after the gradients of

@@ -1,0 +1,256 @@
+"""GPU tests of the host-side contracts around the kernels (the reference's training / evaluation loop semantics):
+
+  * evaluation after training steps sees the NEW weights (engine.py: TEST.EVAL_PERIOD, sanity eval before training);
+  * Ranger <-> GradBuckets share ONE flat gradient buffer whatever the group order, and survive the reference loop's
+    ``optimizer.zero_grad(set_to_none=True)`` (engine.py:304);
+  * ``backward`` honours the gradient autograd hands to the losses (GradScaler scale, 1/accum, weighted / partial sums);
+  * two data-parallel ranks through the REAL TrainEngine.backward(on_group_done=buckets.reduce) + Ranger: buckets fire in
+    completion order, every gradient is the rank mean, weights stay identical across ranks (engine.py:292-313).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(att="mul", seed=1234):
+    from rdpn6d_amd import synth
+    from rdpn6d_amd.config import gdrn_base_cfg
+    from rdpn6d_amd.gdrn import build_model_optimizer
+
+    model, opt = build_model_optimizer(gdrn_base_cfg(mask_attention=att, device="cuda"))
+    sd = synth.make_trained_like_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=seed)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    return model, opt
+
+
+def _batch(B, seed, dev):
+    from rdpn6d_amd import synth
+
+    inp = synth.make_inputs(B, seed=seed)
+    return {k: torch.from_numpy(v).to(dev) for k, v in {**inp, **synth.make_train_gt(B, inp)}.items()}
+
+
+def _eval(model, b):
+    model.eval()
+    with torch.no_grad():
+        o = model(b["roi_img"], roi_classes=b["roi_cls"], roi_coord_2d=b["roi_coord_2d"], roi_cams=b["roi_cam"], roi_centers=b["roi_center"],
+                  roi_whs=b["roi_wh"], roi_extents=b["roi_extent"], resize_ratios=b["resize_ratio"], do_loss=False, fps=b["fps"])
+    torch.cuda.synchronize()
+    return o
+
+
+def _train_losses(model, b):
+    model.train()
+    od, ld = model(b["roi_img"], gt_xyz=b["roi_xyz"], gt_mask_trunc=b["roi_mask_trunc"], gt_mask_visib=b["roi_mask_visib"],
+                   gt_mask_obj=b["roi_mask_obj"], gt_region=b["roi_region"], gt_ego_rot=b["ego_rot"], gt_points=b["roi_points"],
+                   sym_infos=None, gt_trans=b["trans"], gt_trans_ratio=b["roi_trans_ratio"], roi_classes=b["roi_cls"],
+                   roi_coord_2d=b["roi_coord_2d"], roi_cams=b["roi_cam"], roi_centers=b["roi_center"], roi_whs=b["roi_wh"],
+                   roi_extents=b["roi_extent"], resize_ratios=b["resize_ratio"], do_loss=True, fps=b["fps"])
+    assert od == {}
+    return ld
+
+
+def test_eval_after_training_steps_uses_the_new_weights():
+    """eval -> two optimizer steps -> eval: the second evaluation must come from the stepped weights and the updated
+    BatchNorm statistics (the fused Ranger step and the BN update write through raw pointers, so nothing but the weights
+    epoch tells the cached InferencePlan that its packed copies are stale), and must equal a fresh model loaded from the
+    trained state_dict bit for bit."""
+    dev = torch.device("cuda:0")
+    model, opt = _model()
+    b = _batch(2, 3, dev)
+    o1 = _eval(model, b)
+    maps1, rot1 = o1["region"].clone(), o1["rot"].clone()
+    for g in opt.param_groups:
+        g["lr"] = 1e-2
+    for _ in range(2):
+        ld = _train_losses(model, b)
+        opt.zero_grad(set_to_none=True)
+        sum(ld.values()).backward()
+        opt.step()
+    o2 = _eval(model, b)
+    assert torch.equal(o1["region"], maps1), "outputs of an earlier forward must not be overwritten by a later one"
+    assert (o2["region"] - maps1).abs().max().item() > 1e-3 and (o2["rot"] - rot1).abs().max().item() > 1e-4
+    fresh, _ = _model()
+    fresh.load_state_dict(model.state_dict(), strict=True)
+    o3 = _eval(fresh, b)
+    for k in ("mask", "coor_x", "region", "rot", "trans"):
+        assert torch.equal(o2[k], o3[k]), k
+    # a plain torch in-place edit is seen too (tensor version counters)
+    with torch.no_grad():
+        model.rot_head_net.features[21].bias.add_(1.0)
+    o4 = _eval(model, b)
+    assert abs((o4["region"] - o2["region"]).mean().item() - 1.0) < 1e-4
+
+
+def test_ranger_and_gradbuckets_share_one_buffer_in_any_order():
+    """the factory's optimizer orders its groups backbone | rot_head | pnp_net, GradBuckets lays the gradients out
+    pnp_net | rot_head_net | backbone; zero_grad(set_to_none=True) runs before the first step as in engine.py:304.  The
+    gradients must stay views of the bucket buffer, the fused step must read exactly that buffer, and the result must be
+    bit-identical to a run without buckets."""
+    from rdpn6d_amd.parallel import GradBuckets
+
+    dev = torch.device("cuda:0")
+    b = _batch(2, 4, dev)
+    runs = {}
+    for with_buckets in (False, True):
+        model, opt = _model()
+        buckets = GradBuckets(model, optimizer=opt) if with_buckets else None
+        for it in range(2):
+            ld = _train_losses(model, b)
+            opt.zero_grad(set_to_none=True)
+            sum(ld.values()).backward()
+            if buckets is not None:
+                for g in ("pnp_net", "rot_head_net", "backbone"):
+                    buckets.reduce(g)
+                buckets.finish()
+                lo, hi = buckets.flat.data_ptr(), buckets.flat.data_ptr() + 4 * buckets.flat.numel()
+                assert all(lo <= p.grad.data_ptr() < hi for p in model.parameters())
+            opt.step()
+            if buckets is not None:
+                assert opt._flat["g"].data_ptr() == buckets.flat.data_ptr(), "Ranger must adopt the bucket buffer, not copy out of it"
+        torch.cuda.synchronize()
+        runs[with_buckets] = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    for k in runs[False]:
+        assert torch.equal(runs[False][k], runs[True][k]), k
+    # the other construction order: optimizer already built (one step taken), buckets attached afterwards adopt ITS buffer
+    model, opt = _model()
+    ld = _train_losses(model, b)
+    opt.zero_grad(set_to_none=True)
+    sum(ld.values()).backward()
+    opt.step()
+    buckets = GradBuckets(model, optimizer=opt)
+    assert buckets.flat.data_ptr() == opt._flat["g"].data_ptr()
+    for g, (lo, hi) in buckets.slices.items():
+        assert hi - lo == sum(p.numel() for p in getattr(model, g).parameters())
+    # a caller that drops the gradients (nn.Module.zero_grad defaults to set_to_none=True) is re-homed before the reduce
+    ld = _train_losses(model, b)
+    model.zero_grad(set_to_none=True)
+    sum(ld.values()).backward()
+    want = {n: p.grad.clone() for n, p in model.named_parameters()}
+    for g in ("pnp_net", "rot_head_net", "backbone"):
+        buckets.reduce(g)
+    buckets.finish()
+    lo, hi = buckets.flat.data_ptr(), buckets.flat.data_ptr() + 4 * buckets.flat.numel()
+    for n, p in model.named_parameters():
+        assert lo <= p.grad.data_ptr() < hi and torch.equal(p.grad, want[n]), n
+
+
+def test_backward_honours_the_upstream_gradient():
+    """GradScaler-style scaling (engine.py:302-309), gradient accumulation and weighted / partial sums of the loss dict."""
+    dev = torch.device("cuda:0")
+    model, _ = _model()
+    b = _batch(2, 5, dev)
+
+    def grads(total_of):
+        model.zero_grad(set_to_none=True)
+        total_of(_train_losses(model, b)).backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+
+    g1 = grads(lambda ld: sum(ld.values()))
+    gs = grads(lambda ld: sum(ld.values()) * 65536.0)     # the scale GradScaler starts with
+    ga = grads(lambda ld: sum(ld.values()) / 4.0)         # accumulation over 4 micro-batches
+    for n in g1:
+        assert torch.equal(gs[n], g1[n] * 65536.0) and torch.equal(ga[n], g1[n] * 0.25), n  # powers of two: exact
+    xyz = ("loss_coor_x", "loss_coor_y", "loss_coor_z")
+    gx = grads(lambda ld: sum(ld[k] for k in xyz))                                        # a partial sum
+    gr = grads(lambda ld: sum(v for k, v in ld.items() if k not in xyz))
+    gw = grads(lambda ld: 3.0 * sum(ld[k] for k in xyz) + sum(v for k, v in ld.items() if k not in xyz))
+    worst = 0.0
+    for n in g1:
+        den = g1[n].double().norm().item()
+        if den < 1e-4:
+            continue
+        worst = max(worst, ((gx[n] + gr[n]).double() - g1[n].double()).norm().item() / den,
+                    ((3.0 * gx[n] + gr[n]).double() - gw[n].double()).norm().item() / max(gw[n].double().norm().item(), 1e-30))
+    print(f"linearity of the backward in the loss weights: worst relative deviation {worst:.2e}")
+    assert worst < 1e-4
+    assert gx["pnp_net.fc1.weight"].abs().max().item() == 0.0  # the dense xyz losses do not depend on ConvPnPNet's weights
+    with pytest.raises(NotImplementedError):
+        grads(lambda ld: ld["loss_coor_x"] + 2.0 * ld["loss_coor_y"])
+    with pytest.raises(FloatingPointError):
+        grads(lambda ld: sum(ld.values()) * float("inf"))
+
+
+# ----------------------------------------------------------------------------- two data-parallel ranks on one GPU
+def _dp_worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    from rdpn6d_amd.parallel import GradBuckets, reduce_loss_dict
+
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)  # RCCL cannot put two ranks on one device
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        model, opt = _model()  # factory optimizer: Ranger, groups backbone | rot_head | pnp_net
+        b = _batch(2, 100 + rank, dev)  # every rank its own crops
+        eng = model.train_engine(2, dev)
+        # (1) stand-alone gradients of this rank (no reduction), gathered on the host
+        eng.forward_backward(b)
+        torch.cuda.synchronize()
+        mine = torch.cat([p.grad.detach().reshape(-1).cpu() for p in model.parameters()])
+        both = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(both, mine)
+        mean = sum(both) / world
+        model, opt = _model()  # fresh BatchNorm statistics / weights for the data-parallel run
+        eng = model.train_engine(2, dev)
+        buckets = GradBuckets(model, optimizer=opt)
+        fired = []
+
+        def on_done(g):
+            fired.append(g)
+            buckets.reduce(g)
+
+        ok, msg = True, ""
+        for it in range(3):
+            eng.refresh_weights()
+            losses = eng.forward_losses(b)
+            opt.zero_grad(set_to_none=True)
+            eng.backward(on_group_done=on_done)
+            buckets.finish()
+            if it == 0:
+                torch.cuda.synchronize()
+                got = torch.cat([p.grad.detach().reshape(-1).cpu() for p in model.parameters()])
+                err = ((got - mean).abs().max() / mean.abs().max()).item()
+                if fired != ["pnp_net", "rot_head_net", "backbone"]:
+                    ok, msg = False, f"bucket order {fired}"
+                if err > 1e-6:
+                    ok, msg = False, f"reduced gradient differs from the rank mean: {err:.2e}"
+            red = reduce_loss_dict(losses)
+            opt.step()
+            if opt._flat["g"].data_ptr() != buckets.flat.data_ptr():
+                ok, msg = False, "Ranger steps a different buffer than the one that was reduced"
+        torch.cuda.synchronize()
+        w = torch.cat([p.detach().reshape(-1).cpu() for p in model.parameters()])
+        ws = [torch.empty_like(w) for _ in range(world)]
+        dist.all_gather(ws, w)
+        if not torch.equal(ws[0], ws[1]):
+            ok, msg = False, f"weights diverged across ranks: {(ws[0] - ws[1]).abs().max().item():.3e}"
+        if len(red) != 9 or not all(torch.isfinite(v) for v in red.values()):
+            ok, msg = False, "loss reduction"
+        q.put((rank, ok, msg))
+        dist.destroy_process_group()
+    except Exception as e:  # noqa: BLE001
+        import traceback
+
+        q.put((rank, False, traceback.format_exc()[-1500:] + repr(e)))
+
+
+def test_two_rank_data_parallel_training_through_the_real_engine():
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + os.getpid() % 300
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+    assert [r[:2] for r in res] == [(0, True), (1, True)], res

@@ -115,10 +115,25 @@ def main():
         out[pref + "pred_t_"] = oo["pred_t_"].numpy()
 
     # --- training path, both MASK_ATTENTION variants, 8 threads = the golden values, 1 thread = the reference's own noise
+    inp = synth.make_inputs(B, seed=synth.C1W_TRAIN_INPUT_SEED, res=256, num_regions=32, cam="lm")  # (see synth.py)
+    tin = {k: torch.from_numpy(v) for k, v in inp.items()}
+    out["train_input_seed"] = np.int64(synth.C1W_TRAIN_INPUT_SEED)
+    out["train_sha256_inputs"] = synth.sha256_of([inp[k] for k in sorted(inp)])
     gt = synth.make_train_gt(B, inp)
     tgt = {k: torch.from_numpy(v) for k, v in gt.items()}
     out["train_sha256_gt"] = synth.sha256_of([gt[k] for k in sorted(gt)])
     for att in ("none", "mul"):
+        if att == "none":  # the train-mode maps of the reference: no arg-max tie on this batch either
+            torch.set_num_threads(8)
+            ref, _ = build_reference(att)
+            ref.load_state_dict(full_sd, strict=True)
+            ref.train()
+            with torch.no_grad():
+                reg = ref.rot_head_net(ref.backbone(tin["roi_img"]))[-1]
+            top2 = reg[:, 1:].topk(2, dim=1).values
+            out["train_region_min_top2_gap"] = np.float64((top2[:, 0] - top2[:, 1]).min().item())
+            out["train_region_argmax"] = torch.softmax(reg[:, 1:], 1).reshape(B, 32, -1).argmax(1).reshape(B, 64, 64).numpy().astype(np.int8)
+            print("train-mode smallest top-2 region-logit gap", out["train_region_min_top2_gap"])
         L8, g8 = ref_train(att, full_sd, tin, tgt, 8)
         L1, g1 = ref_train(att, full_sd, tin, tgt, 1)
         torch.set_num_threads(8)
