@@ -90,11 +90,12 @@ class PointFusion(nn.Module):
         self.b1 = nn.BatchNorm2d(ch[1])
         self.b2 = nn.BatchNorm2d(ch[2])
         self.b3 = nn.BatchNorm2d(ch[3])
+        self.relu = nn.ReLU()  # (a module, not F.relu, so that forced_relu_masks() below can reach the three call sites)
 
     def forward(self, feat, xyz):
-        emb = F.relu(self.xb(self.xyz_emb(feat)))
-        l1 = F.relu(self.b1(self.conv1(torch.cat([xyz, emb], 1))))
-        l2 = F.relu(self.b2(self.conv2(l1)))
+        emb = self.relu(self.xb(self.xyz_emb(feat)))
+        l1 = self.relu(self.b1(self.conv1(torch.cat([xyz, emb], 1))))
+        l2 = self.relu(self.b2(self.conv2(l1)))
         l3 = self.b3(self.conv3(l2))  # BN, no ReLU (:49)
         g = l3.amax(dim=(2, 3), keepdim=True).expand_as(l3)  # global max, broadcast (:51-52)
         return torch.cat([l3, g], 1)
@@ -289,6 +290,48 @@ class GDRNOracle(nn.Module):
             rot = torch.from_numpy(np.stack([allo_to_ego_numpy(ra[i], tn[i]) for i in range(ra.shape[0])]))
         return {"rot": rot, "trans": trans, "mask": mask, "coor_x": cx, "coor_y": cy, "coor_z": cz, "region": region,
                 "pred_rot6d": rot6d, "pred_t_": pred_t, "region_argmax": amax}
+
+
+# --------------------------------------------------------------------------------------- forced ReLU decisions
+class forced_relu_masks:
+    """Context manager for gradient parity tests: every ReLU / LeakyReLU call site of `model` takes its on/off decision from
+    `masks[(module name, call index)]` (a 0/1 tensor of the activation's shape) instead of the sign of its own input:
+    out = x * mask (LeakyReLU: x * (mask + slope * (1 - mask))).
+
+    Why: the fp32 backward of a ReLU network is reproducible only up to the units whose pre-activation sits within round-off
+    of zero - one flipped unit of a 1024-wide layer moves every upstream gradient by ~2 % (measured on the real reference,
+    tests/golden/README.md).  With the decisions of the implementation under test forced into the oracle, what remains is
+    the arithmetic of the backward itself, which can then be compared at 1e-4.  The forward values change by at most the
+    magnitude of the near-zero pre-activations concerned (1e-6)."""
+
+    def __init__(self, model, masks):
+        self.model, self.masks, self.saved, self.used = model, masks, [], set()
+
+    def __enter__(self):
+        for name, m in self.model.named_modules():
+            if isinstance(m, (nn.ReLU, nn.LeakyReLU)):
+                slope = m.negative_slope if isinstance(m, nn.LeakyReLU) else 0.0
+                calls = [0]
+
+                def fwd(x, name=name, slope=slope, calls=calls):
+                    key = (name, calls[0])
+                    calls[0] += 1
+                    mask = self.masks[key].to(x.dtype)
+                    assert mask.shape == x.shape, (key, tuple(mask.shape), tuple(x.shape))
+                    self.used.add(key)
+                    return x * (mask + slope * (1 - mask)) if slope else x * mask
+
+                self.saved.append((m, m.__dict__.get("forward")))
+                m.forward = fwd
+        return self
+
+    def __exit__(self, *exc):
+        for m, old in self.saved:
+            if old is None:
+                del m.__dict__["forward"]
+            else:
+                m.forward = old
+        return False
 
 
 # --------------------------------------------------------------------------------------- losses

@@ -125,10 +125,47 @@ def c1w_train(c1w):
                  train_pose=True)
         sum(model_oracle.gdrn_losses(oo, tc, tc["roi_extent"]).values()).backward()
         ograds = {n: p.grad.double() for n, p in orc.named_parameters()}
+        # the same oracle with the ReLU / LeakyReLU decisions of the HIP forward forced in (oracle/model_oracle.py)
+        orc2 = model_oracle.GDRNOracle(32, att)
+        orc2.load_state_dict(sd, strict=True)
+        orc2.train()
+        with model_oracle.forced_relu_masks(orc2, _hip_relu_masks(eng, orc2)) as forced:
+            oo = orc2(tc["roi_img"], tc["roi_coord_2d"], tc["fps"], tc["roi_cam"], tc["roi_center"], tc["roi_wh"], tc["resize_ratio"],
+                      train_pose=True)
+            sum(model_oracle.gdrn_losses(oo, tc, tc["roi_extent"]).values()).backward()
+        assert len(forced.used) == len(forced.masks) == 1 + 2 * 16 + 3 + 7 + 3 + 2
+        fgrads = {n: p.grad.double() for n, p in orc2.named_parameters()}
         model.load_state_dict(sd, strict=True)
         model.eval()
-        out[att] = (losses, grads, ograds)
+        out[att] = (losses, grads, ograds, fgrads)
     return out
+
+
+def _hip_relu_masks(eng, orc):
+    """(oracle ReLU module name, call index) -> 0/1 mask (NCHW) read off the activations the HIP forward stored"""
+    def m(name, sl=None):
+        a = eng.bufs[name]
+        if sl is not None:
+            a = a[..., sl]
+        a = (a > 0).float().cpu()
+        return a.permute(0, 3, 1, 2).contiguous() if a.dim() == 4 else a
+
+    masks = {("backbone.relu", 0): m("act:stem")}
+    for li in range(1, 5):
+        for bi in range(len(getattr(orc.backbone, f"layer{li}"))):
+            masks[(f"backbone.layer{li}.{bi}.relu", 0)] = m(f"act:layer{li}.{bi}.c1")
+            masks[(f"backbone.layer{li}.{bi}.relu", 1)] = m(f"act:layer{li}.{bi}")
+    masks[("backbone.spatial_net.relu", 0)] = m("act:pn_in", slice(0, 64))  # the embedding lives in the first 64 channels
+    masks[("backbone.spatial_net.relu", 1)] = m("act:pn.c1")
+    masks[("backbone.spatial_net.relu", 2)] = m("act:pn.c2")
+    masks[("rot_head_net.features.2", 0)] = m("act:head0")
+    for i in range(3, 21, 3):
+        masks[(f"rot_head_net.features.{i + 2}", 0)] = m(f"act:head{i}")
+    for i in (0, 3, 6):
+        masks[(f"pnp_net.features.{i + 2}", 0)] = m(f"act:pnp{i}")
+    masks[("pnp_net.act", 0)] = m("act:fc1")
+    masks[("pnp_net.act", 1)] = m("act:fc2")
+    return masks
 
 
 @pytest.mark.parametrize("att", ["none", "mul"])
@@ -144,43 +181,60 @@ def test_c1w_training_losses_1e5(c1w, c1w_train, att):
 
 
 @pytest.mark.parametrize("att", ["none", "mul"])
-def test_c1w_all_164_gradients_vs_reference(c1w, c1w_train, att):
-    """Every parameter gradient against the REAL reference's: the golden file holds 256 seeded entries + the norm of each of
-    the 164 tensors, and the reference's own 1-vs-8-thread difference per tensor (`train_*_grad_noise/*`).  A ReLU network's
-    fp32 backward is reproducible only to ~sqrt(fraction of ReLU masks that flip under round-off): the reference differs
-    from ITSELF by 2.5e-3 (median; 4e-3 max) on the trunk / head tensors and by 1e-6..4e-5 on the tensors behind the last
-    ReLU-free stretch (output conv, ConvPnPNet).  Bound per tensor: max(1e-3, 2.5 x its own reference noise) - i.e. the bare
-    1e-3 wherever the reference itself reproduces to better than 4e-4, and the reference's own reproducibility elsewhere.
-    The full tensors are also compared with the oracle's autograd (bit-equal to the reference on one box) at the same bound."""
+def test_c1w_all_164_gradients_at_1e3_with_the_relu_decisions_forced(c1w, c1w_train, att):
+    """THE gradient parity test: every one of the 164 parameter gradients of the HIP backward against the autograd of the
+    reference-pinned oracle, full tensors, at the bare 1e-3 (measured 1e-5 .. 2e-4).  The oracle takes the on/off decision of
+    each of its 48 ReLU / LeakyReLU call sites from the HIP forward (oracle.forced_relu_masks), which removes the one effect
+    that makes fp32 gradients of a ReLU network irreproducible - units whose pre-activation lies within round-off of zero -
+    and leaves exactly what is under test: the arithmetic of dgrad / wgrad / BatchNorm / GroupNorm / pooling / up-sampling /
+    glue / loss / pose backward kernels.  A wrong kernel, a missed term or a mis-scaled tensor shows up at >> 1e-3 here."""
+    _, grads, _, fgrads = c1w_train[att]
+    rows = []
+    for name, g in grads.items():
+        ref = fgrads[name]
+        if ref.norm().item() < 1e-4:  # exact gradient zero up to round-off (a conv bias in front of a BatchNorm)
+            assert g.norm().item() < 1e-4, name
+            continue
+        rows.append(((g - ref).norm().item() / ref.norm().item(), name))
+    rows.sort(reverse=True)
+    print(f"[c1w {att}] HIP vs mask-forced oracle autograd, {len(rows)} tensors: median {np.median([r[0] for r in rows]):.2e}, worst "
+          + ", ".join(f"{n} {e:.2e}" for e, n in rows[:4]))
+    assert len(rows) == 160
+    for e, name in rows:
+        assert e <= 1e-3, (name, e)
+
+
+@pytest.mark.parametrize("att", ["none", "mul"])
+def test_c1w_gradients_vs_reference_golden_within_the_references_own_reproducibility(c1w, c1w_train, att):
+    """The same gradients against the REAL reference's (golden file: 256 seeded entries + the norm of each of the 164 tensors)
+    and against the un-forced oracle on this box's CPU.  Here the ReLU decisions are NOT shared, so the comparison can only be
+    as tight as an fp32 ReLU network reproduces itself: the reference differs from ITSELF by 2.7e-3 (median; 3.5e-3 .. 5.6e-3
+    max) between 1 and 8 threads (`train_*_grad_noise/*`, measured on the real code), and its fp32 gradients on this very
+    batch are 2.4e-2 from its fp64 gradients on the whole pose branch because ONE LeakyReLU unit of fc1 (1 of 4096) and one
+    unit of features.8 flip (tests/golden/README.md).  So this is a distribution-level check: the median error over the
+    tensors within 2.5x the reference's own median noise, and no tensor beyond the worst single-unit flip (5e-2)."""
     from tests.c1w_cases import grad_sample_index
 
     gold = c1w[2]
-    _, grads, ograds = c1w_train[att]
+    _, grads, ograds, _ = c1w_train[att]
     rows = []
     for name, g in grads.items():
         ref_s, ref_n = gold[f"train_{att}_grad_sample/{name}"].astype(np.float64), float(gold[f"train_{att}_grad_norm/{name}"])
         noise = float(gold[f"train_{att}_grad_noise/{name}"])
-        if ref_n < 1e-4:  # exact gradient is zero up to round-off (a conv bias in front of a BatchNorm)
+        if ref_n < 1e-4:
             assert g.norm().item() < 1e-4, name
             continue
-        mine_s = g.reshape(-1)[torch.from_numpy(grad_sample_index(name, g.numel()))].numpy()
-        e_s = np.linalg.norm(mine_s - ref_s) / np.linalg.norm(ref_s)
+        idx = torch.from_numpy(grad_sample_index(name, g.numel()))
+        e_s = np.linalg.norm(g.reshape(-1)[idx].numpy() - ref_s) / np.linalg.norm(ref_s)
+        e_g = np.linalg.norm(ograds[name].reshape(-1)[idx].numpy() - ref_s) / np.linalg.norm(ref_s)  # this box's CPU oracle vs golden
         e_n = abs(g.norm().item() - ref_n) / ref_n
         e_o = ((g - ograds[name]).norm() / ograds[name].norm()).item()
-        rows.append((name, e_s, e_n, e_o, noise))
-    assert len(rows) + sum(1 for n in grads if float(gold[f"train_{att}_grad_norm/{n}"]) < 1e-4) == 164
+        rows.append((name, e_s, e_n, e_o, noise, e_g))
     med = lambda i: float(np.median([r[i] for r in rows]))  # noqa: E731
-    print(f"[c1w {att}] relative gradient error, median over {len(rows)} tensors: vs reference samples {med(1):.2e}, norm {med(2):.2e}, "
-          f"full tensor vs oracle autograd {med(3):.2e} | reference 1-vs-8 threads {med(4):.2e}")
-    tight = [r for r in rows if r[4] < 4e-4]
-    print(f"[c1w {att}] {len(tight)} tensors where the reference reproduces itself to < 4e-4: worst HIP error "
-          f"{max(r[3] for r in tight):.2e} (bound 1e-3)")
-    for name, e_s, e_n, e_o, noise in sorted(rows, key=lambda r: -r[3] / max(1e-3, 2.5 * r[4]))[:5]:
-        print(f"    {name}: samples {e_s:.2e} norm {e_n:.2e} full-vs-oracle {e_o:.2e} | reference noise {noise:.2e}")
-    for name, e_s, e_n, e_o, noise in rows:
-        bound = max(1e-3, 2.5 * noise)
-        assert e_o <= bound, (name, e_o, noise)
-        assert e_n <= bound, (name, e_n, noise)
-        # 256 entries estimate the same ratio only roughly (the differences sit in the few rows behind a flipped ReLU), and
-        # the golden values carry the reference's own noise on top
-        assert e_s <= 4.0 * bound, (name, e_s, noise)
+    print(f"[c1w {att}] relative gradient error, median over {len(rows)} tensors: HIP vs golden samples {med(1):.2e} (norms {med(2):.2e}), "
+          f"HIP vs this box's CPU oracle {med(3):.2e} | this box's CPU oracle vs golden samples {med(5):.2e} | reference 1-vs-8 threads {med(4):.2e}")
+    assert len(rows) == 160
+    assert med(3) <= 2.5 * med(4)                       # HIP vs un-forced oracle: like the reference vs itself
+    assert med(1) <= max(2.5 * med(4), 2.0 * med(5))    # HIP vs golden: no further than this box's own CPU run of the oracle
+    for name, e_s, e_n, e_o, noise, e_g in rows:
+        assert e_o <= 5e-2 and e_n <= 5e-2, (name, e_o, e_n)

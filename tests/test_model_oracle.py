@@ -192,3 +192,50 @@ def test_c1w_oracle_training_losses_and_all_gradients(setup_w, att):
         # 256 entries estimate the same ratio only roughly: the differences sit in the few rows behind a flipped ReLU
         assert np.linalg.norm(mine_s - ref_s) <= 4.0 * bound * np.linalg.norm(ref_s), (name, noise)
     assert n == 164
+
+
+def test_forced_relu_masks_reproduce_the_oracles_own_gradients():
+    """the mechanism behind the GPU gradient-parity test (oracle.forced_relu_masks): forcing the oracle's OWN 48 ReLU /
+    LeakyReLU decisions back in reproduces its gradients bit for bit, flipping one unit of fc1 moves the upstream gradients
+    by percents (the irreproducibility the forcing removes), and the modules are restored on exit."""
+    import torch.nn as nn
+
+    inp = synth.make_inputs(2, seed=50)
+    t = {k: torch.from_numpy(v) for k, v in {**inp, **synth.make_train_gt(2, inp)}.items()}
+
+    def mk():
+        m = model_oracle.GDRNOracle(32, "mul")
+        sd = synth.make_trained_like_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=1234)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        return m.train()
+
+    def run(m):
+        o = m(t["roi_img"], t["roi_coord_2d"], t["fps"], t["roi_cam"], t["roi_center"], t["roi_wh"], t["resize_ratio"], train_pose=True)
+        sum(model_oracle.gdrn_losses(o, t, t["roi_extent"]).values()).backward()
+        return {n: p.grad.clone() for n, p in m.named_parameters()}
+
+    m, masks, calls = mk(), {}, {}
+    for name, mod in m.named_modules():
+        if isinstance(mod, (nn.ReLU, nn.LeakyReLU)):
+            def hook(_m, _i, o, name=name):
+                k = calls.get(name, 0)
+                calls[name] = k + 1
+                masks[(name, k)] = (o.detach() > 0).float()
+            mod.register_forward_hook(hook)
+    g0 = run(m)
+    assert len(masks) == 48
+    m2 = mk()
+    with model_oracle.forced_relu_masks(m2, masks) as f:
+        g1 = run(m2)
+    assert len(f.used) == 48 and all(torch.equal(g0[n], g1[n]) for n in g0)
+    flipped = dict(masks)
+    fm = masks[("pnp_net.act", 0)].clone()
+    fm[0, 0] = 1 - fm[0, 0]
+    flipped[("pnp_net.act", 0)] = fm
+    m3 = mk()
+    with model_oracle.forced_relu_masks(m3, flipped):
+        g2 = run(m3)
+    rel = ((g2["backbone.conv1.weight"] - g0["backbone.conv1.weight"]).norm() / g0["backbone.conv1.weight"].norm()).item()
+    assert rel > 1e-3, rel
+    g3 = run(m3)  # outside the context the module is the plain oracle again
+    assert all(torch.equal(g0[n], g3[n]) for n in g0)
