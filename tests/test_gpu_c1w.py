@@ -181,9 +181,9 @@ def test_c1w_training_losses_1e5(c1w, c1w_train, att):
 
 
 @pytest.mark.parametrize("att", ["none", "mul"])
-def test_c1w_all_164_gradients_at_1e3_with_the_relu_decisions_forced(c1w, c1w_train, att):
+def test_c1w_all_164_gradients_with_the_relu_decisions_forced(c1w, c1w_train, att):
     """THE gradient parity test: every one of the 164 parameter gradients of the HIP backward against the autograd of the
-    reference-pinned oracle, full tensors, at the bare 1e-3 (measured 1e-5 .. 2e-4).  The oracle takes the on/off decision of
+    reference-pinned oracle, full tensors, at 2e-4 - five times tighter than the 1e-3 asked for (measured: median 7.8e-6, worst 4.7e-5).  The oracle takes the on/off decision of
     each of its 48 ReLU / LeakyReLU call sites from the HIP forward (oracle.forced_relu_masks), which removes the one effect
     that makes fp32 gradients of a ReLU network irreproducible - units whose pre-activation lies within round-off of zero -
     and leaves exactly what is under test: the arithmetic of dgrad / wgrad / BatchNorm / GroupNorm / pooling / up-sampling /
@@ -201,7 +201,7 @@ def test_c1w_all_164_gradients_at_1e3_with_the_relu_decisions_forced(c1w, c1w_tr
           + ", ".join(f"{n} {e:.2e}" for e, n in rows[:4]))
     assert len(rows) == 160
     for e, name in rows:
-        assert e <= 1e-3, (name, e)
+        assert e <= 2e-4, (name, e)
 
 
 @pytest.mark.parametrize("att", ["none", "mul"])
