@@ -122,11 +122,17 @@ def roofline(model, t, B, device, reps=3):
         peak = BF16_MFMA_PEAK_TFLOPS
     else:
         kname, peak = f"conv_igemm_f32_kernel<{tile[0]}, {tile[1]}>", FP32_MFMA_PEAK_TFLOPS
-    traffic, traffic_src = pmc_traffic(kname, plan.bf16) if B == 64 else (None, None)
+    traffic, traffic_src, prof_us = pmc_traffic(kname, plan.bf16) if B == 64 else (None, None, None)
+    # the counters come from a committed profile of this command, not from this process: flag the figure when the kernel it was
+    # measured on no longer runs like the one timed here (a changed kernel with a stale profile)
+    stale = None if traffic is None else bool(abs(prof_us - avg_ms * 1e3) > 0.25 * avg_ms * 1e3)
+    if stale:
+        print(f"[bench] roofline.traffic comes from {traffic_src} whose {kname} ran {prof_us:.0f} us/launch, {avg_ms * 1e3:.0f} us here: "
+              "re-run tools/pmc_bench.sh", file=sys.stderr)
     return {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
         "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch (HBM+fabric, PMC)",
-        "traffic_source": traffic_src,
+        "traffic_source": traffic_src, "traffic_stale": stale,
         "kernel": kname.replace(", ", ","), "launches_per_step": len(sel),
         "avg_launch_ms": round(avg_ms, 4), "algorithmic_gflop_per_launch": round(flops / max(len(sel), 1) / 1e9, 2),
         "share_of_step_flops": round(flops / (44.10e9 * B), 3), **extra,
@@ -146,10 +152,10 @@ def pmc_traffic(kernel, bf16=False):
         try:
             d = json.load(open(f))
             e = d[kernel] if kernel in d else next(v for k, v in d.items() if kernel in k)  # (anonymous namespace):: prefix
-            return int((e["fetch_MB_x2"] + e["write_MB"]) * 1e6), os.path.relpath(f, ROOT)
+            return int((e["fetch_MB_x2"] + e["write_MB"]) * 1e6), os.path.relpath(f, ROOT), float(e["avg_us"])
         except (KeyError, ValueError, StopIteration):
             continue
-    return None, None
+    return None, None, None
 
 
 def cpu_baseline(sd, budget_s=20.0):
@@ -276,7 +282,10 @@ def train_bench(args, rank, world, device, dist):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--trace", type=int, default=0, metavar="N",
+                    help="record the stream time of every block of N steps (events, no extra synchronisation) and report it as "
+                         "ms_per_step_trace: shows whether the clock / throughput drifts over a long run (--steps 2000 --trace 100)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="crops per GPU per step (BASELINE configs[1]: 64)")
     ap.add_argument("--mask-attention", default="none", choices=["none", "mul"])
@@ -329,20 +338,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    marks = []
     with torch.no_grad():
         for _ in range(args.warmup):
             step(model, t)
         barrier()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for i in range(args.steps):
+            if args.trace and i % args.trace == 0:
+                marks.append(torch.cuda.Event(enable_timing=True))
+                marks[-1].record()
             step(model, t)
+        if args.trace:
+            marks.append(torch.cuda.Event(enable_timing=True))
+            marks[-1].record()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         barrier()
+    my_elapsed = elapsed
     el = torch.tensor([elapsed], dtype=torch.float64, device=device if dist is None or dist.get_backend() == "nccl" else "cpu")
+    per_rank = [el.clone() for _ in range(world)]
     if dist is not None:
+        dist.all_gather(per_rank, el)  # every rank's own time: a slow / stalled rank is visible in the line, not only in the max
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
+    per_rank_rate = [round(B * args.steps / float(x.item()), 1) for x in per_rank]
+    print(f"[bench] rank {rank}: {B * args.steps / my_elapsed:.1f} crops/s ({my_elapsed / args.steps * 1e3:.3f} ms/step)", file=sys.stderr)
 
     roof, cpu = None, None
     dtype_label, dtype_note = args.dtype, None
@@ -364,14 +385,19 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": dtype_label, "data": "synthetic",
-            "config": {"workload": "LM 13-object inference, batch=64 per GPU, 256x256 RGB-D crops, K=32 regions, "
+            "config": {"workload": f"LM 13-object inference, batch={B} per GPU, 256x256 RGB-D crops, K=32 regions, "
                                    "ResNet-34 trunk + dense head + ConvPnPNet + pose decode + per-crop RANSAC/Kabsch (100 hyp.), all on-device",
                        "batch_per_gpu": B, "global_batch": B * world, "mask_attention": args.mask_attention,
                        "parallelism": f"replicated weights, {world} independent shard(s), no collective",
                        "launch": "hipGraph replay" if args.graph else "eager"},
             "achieved_tflops_whole_step": round(44.10e9 * value / 1e12, 2),
+            "per_rank_crops_per_s": per_rank_rate,
             "roofline": roof,
         }
+        if args.trace:
+            blk = [marks[i].elapsed_time(marks[i + 1]) / min(args.trace, args.steps - i * args.trace) for i in range(len(marks) - 1)]
+            line["ms_per_step_trace"] = {"block_steps": args.trace, "ms_per_step": [round(x, 3) for x in blk],
+                                         "drift_last_vs_first": round(blk[-1] / blk[0], 4), "timed_seconds": round(elapsed, 2)}
         if dtype_note:
             line["dtype_note"] = dtype_note
         if cpu is not None:

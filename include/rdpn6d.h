@@ -351,6 +351,18 @@ int rdpn6d_region_targets_f32(const float* xyz_hwc, const double* fps, const flo
  *   est, gt [B,12] = R row-major | t; pts [n,3] shared (pts_per_pose = 0) or [B,n,3]; out [B,4] = add, adi, re, te */
 int rdpn6d_pose_errors_f64(const double* est, const double* gt, const double* pts, int pts_per_pose, int n, int B,
                            double* scratch, double* out, void* stream);
+/* row A8: 2D-3D correspondence selection in front of the PnP solve, on device (core/gdrn_modeling/engine_utils.py:102-136
+ * get_out_coor / get_out_mask, core/gdrn_modeling/gdrn_evaluator.py:89-126 get_img_model_points_with_coords2d).
+ *   out_nchw [B,C,HW] f32: channel 0 = mask, 1..3 = coor_x/y/z (what GDRN.forward returns); coord2d [B,C2,HW] f32 with the
+ *   normalised u / v coordinates in channels u_ch / v_ch (RDPN's roi_coord_2d: C2 = 5, u_ch = 3, v_ch = 4; the reference call
+ *   site passes channels 0 / 1 "as given"); extents [B,3]; im_hw [B,2] int (H, W) per crop or NULL -> im_H, im_W for all.
+ *   -> image_points [B,HW,2] px, model_points [B,HW,3] m (first counts[b] rows valid, ROW-MAJOR pixel order = numpy's boolean
+ *   gather), counts [B]; optional sel_mask [B,HW] u8 and out_mask [B,HW] (the min-max normalised mask; NaN for a constant
+ *   mask like the reference).  Bit-exact vs the reference functions (tests/golden/select_golden.npz). */
+int rdpn6d_select_correspondences_f32(const float* out_nchw, int C, const float* coord2d, int C2, int u_ch, int v_ch,
+                                      const float* extents, const int* im_hw, int im_H, int im_W, int B, int HW, float mask_thr,
+                                      float* image_points, float* model_points, int* counts, unsigned char* sel_mask,
+                                      float* out_mask, void* stream);
 /* rank 1: GPU crop builder (core/gdrn_modeling/data_loader.py:523-627, core/utils/data_utils.py:81-152; cv2.warpAffine
  * bilinear arithmetic restated, parity with cv2 unpinned).  images [N,H,W,3] u8, depths [N,H,W] f32; per ROI: image index,
  * inverse affine maps for the R and R/4 crops (6 doubles each), fx fy cx cy of (A @ K), resize_ratio ->

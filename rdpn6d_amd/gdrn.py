@@ -312,6 +312,7 @@ class InferencePlan:
         if not self.x3 or N % 256 or cin % 16 or (ntaps * (cin // 16)) % 2:
             return False
         if 6 * M * max(N, cin) >= (1 << 32) - 64:  # three bf16 planes behind one 32-bit buffer descriptor
+            self._x3_limit_warning(M, max(N, cin))
             return False
         tiles = ((M + 255) // 256) * (N // 256)
         rounds = (tiles + 255) // 256
@@ -320,7 +321,21 @@ class InferencePlan:
     def x3_tile_ok(self, M, N, cin):
         """the bf16x3 tile kernel (128x128 .. 64x64) for a layer too small for the 256x256 one: 1.35-1.45x the fp32-MFMA
         kernel from two crops on (head layer: 73 vs 105 us at B=2, 123 vs 190 at B=4, 264 vs 354 at B=8)"""
+        if self.x3 and N % 64 == 0 and cin % 32 == 0 and M >= 8192 and 6 * M * max(N, cin) >= (1 << 32) - 64:
+            self._x3_limit_warning(M, max(N, cin))
         return self.x3 and N % 64 == 0 and cin % 32 == 0 and M >= 8192 and 6 * M * max(N, cin) < (1 << 32) - 64
+
+    def _x3_limit_warning(self, M, C):
+        """a layer that WOULD run as a bf16x3 convolution stays on the fp32 MFMA pipe (~1.5x slower) because its three bf16 planes
+        exceed the 4 GiB a buffer descriptor can address: say so once per plan instead of degrading silently"""
+        if not getattr(self, "_x3_warned", False):
+            self._x3_warned = True
+            import warnings
+
+            warnings.warn(f"rdpn6d_amd: batch {self.B}: an activation of {M} x {C} elements needs {6 * M * C / 2**30:.1f} GiB as three bf16 "
+                          "planes (> 4 GiB buffer-descriptor range): those layers run on the fp32 MFMA kernel instead of bf16x3 "
+                          "(about 1.5x slower per layer); split the batch (<= 256 crops per call at 256x256) to stay on the fast path",
+                          RuntimeWarning, stacklevel=3)
 
     def split3(self, name, x, planes):
         """launch: fp32 tensor -> its three bf16 planes ([3, plane_elems])"""
@@ -401,6 +416,8 @@ class InferencePlan:
         # csrc/conv_igemm_bf16x3_tile.hip) and hand their activations on as three bf16 planes; the residual is read from
         # planes as well (summed exactly), only the last block writes the fp32 tensor the up-sampling reads.
         wide = 256 if hasattr(bb.layer1[0], "conv3") else 64  # channels of the widest (layer1) activation
+        if self.x3 and 65536 <= B * R4 * R4 and 6 * B * R4 * R4 * wide >= (1 << 32) - 64:
+            self._x3_limit_warning(B * R4 * R4, wide)
         x3_trunk = self.x3 and 65536 <= B * R4 * R4 and 6 * B * R4 * R4 * wide < (1 << 32) - 64
         self.x3_trunk = x3_trunk
         pcur = None

@@ -38,7 +38,7 @@ def make_case(B=3, K=32, side=64, noise=0.001, outliers=0.3, holes=0.1, seed=0, 
         d = (rng.random((HW, 3)) - 0.5) * 0.04
         P = (fps[b][am[b]].astype(np.float64) + d) @ R.T + t + rng.standard_normal((HW, 3)) * noise
         delta = d @ R.T + rng.standard_normal((HW, 3)) * noise
-        bad = rng.random(HW) < outliers
+        bad = rng.random(HW) < (outliers[b] if np.ndim(outliers) else outliers)  # per-crop ratio when an array is given
         P[bad] += (rng.random((int(bad.sum()), 3)) - 0.5) * 0.3 + 0.05
         hole = rng.random(HW) < holes
         P[hole] = 0.0

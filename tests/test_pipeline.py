@@ -96,5 +96,6 @@ def test_bench_contract_two_ranks_on_one_gpu():
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["global_batch"] == 16
+    assert "batch=8 per GPU" in out["config"]["workload"] and len(out["per_rank_crops_per_s"]) == 2 and min(out["per_rank_crops_per_s"]) > 0
     assert out["value"] > 0 and abs(out["value"] - 16 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-2 * out["value"]
     assert out["roofline"]["frac"] > 0 and "cpu_baseline" not in out
