@@ -117,6 +117,20 @@ int rdpn6d_conv2d_bf16x3(const rdpn6d_conv_desc* d, long long x_plane_elems, lon
 /* ... with the residual given as three bf16 planes [3][res_plane_elems] (geometry d->res_cs / d->res_co, d->res == NULL) */
 int rdpn6d_conv2d_bf16x3_ex(const rdpn6d_conv_desc* d, long long x_plane_elems, long long w_plane_elems, void* y_planes,
                             long long y_plane_elems, const void* res_planes, long long res_plane_elems, void* stream); /* 256x128 | 128x128 | 128x64 | 64x128 | 64x64 */
+/* fp32-ACCURATE convolution on the fp16 matrix pipe with TWO planes per operand ("h2", csrc/conv_igemm_h2.hip): a * 2^s = hi + lo
+ * in fp16 (22 significand bits), a product = lo*hi + hi*lo + hi*hi (three exact partial products, fp32 accumulation): half the
+ * MFMA work and half the accumulator roundings of bf16x3 - measured error vs fp64 no larger than the fp32-MFMA kernel's.
+ * Same operator and descriptor as rdpn6d_conv2d_f32 with
+ *   d->x = activation as an h2 tensor [pixels][in_cs/32][2][32] fp16 holding a*16 (|a| < 4094),
+ *   d->w = packed weights as an h2 tensor [Npad][ntaps][Cin/32][2][32] fp16 holding w * 2^sw(n) (the caller folds
+ *          2^-(sw(n)+4) into d->scale), d->y = fp32 output (may be NULL), d->res = fp32 residual,
+ *   y_h2 / res_h2 = optional h2 tensors of the result (the next layer's input) / of the residual,
+ *   overflow_flag = device int set to 1 if an output had to be clamped to the fp16 range (never an inf).
+ * Requirements: Cin, in_cs, in_co % 32 == 0; N % 8 == 0; Npad % 64 == 0; 16-byte aligned output slices; tensors < 4 GiB.
+ * rdpn6d_split_h2 converts an fp32 NHWC channel slice to an h2 tensor. */
+int rdpn6d_split_h2(const float* x, int src_cs, int src_co, int C, void* dst, long long npix, int* overflow_flag, void* stream);
+int rdpn6d_conv_h2_kernel_for(const rdpn6d_conv_desc* d); /* 2 = 256x256 eight-phase, 1 = 128x128..64x64 tile kernel, 0 = not eligible */
+int rdpn6d_conv2d_h2(const rdpn6d_conv_desc* d, void* y_h2, const void* res_h2, int* overflow_flag, void* stream);
 void rdpn6d_conv_bf16_force_chunk(int row_bytes); /* profiling: 0 = auto, 64 forces 32-channel K-chunks (measured slower) */
 /* bf16 forms of the kernels between the bf16 convolutions (same argument meaning as the _f32 entry points; activations
  * bf16 NHWC with C % 8 == 0; the stem and the xyz subsample read the fp32 NCHW crop and write bf16) */

@@ -114,6 +114,9 @@ SIGNATURES = {
     "rdpn6d_global_max_concat_backward_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "rdpn6d_stem_im2col_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "rdpn6d_repack_f32": (_i, [_vp, _vp, _vp, _i, _vp]),
+    "rdpn6d_split_h2": (_i, [_vp, _i, _i, _i, _vp, _ll, _vp, _vp]),
+    "rdpn6d_conv_h2_kernel_for": (_i, [_vp]),
+    "rdpn6d_conv2d_h2": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "rdpn6d_select_correspondences_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 

@@ -1,0 +1,746 @@
+// fp32-ACCURATE implicit-GEMM convolution on the fp16 matrix pipe, TWO planes per operand ("h2").
+//
+// Every fp32 operand is held as two fp16 terms of its value scaled by a power of two:
+//     a * 2^s = hi + lo,   hi = fp16(a * 2^s),   lo = fp16(a * 2^s - hi)            (both round-to-nearest-even)
+// |a 2^s - hi - lo| <= 2^-22 |a 2^s| (11 + 11 significand bits; 2^-25 absolute once lo is subnormal - fp16 MFMA inputs keep
+// their subnormals), and a product is evaluated as  lo_a*hi_b + hi_a*lo_b + hi_a*hi_b  - three exact fp32 products (11 x 11
+// bits) accumulated in fp32 by v_mfma_f32_32x32x16_f16.  The dropped lo*lo term is <= 2^-22 relative.  Per product this is
+// 2-4x an fp32 rounding, but a K-long reduction rounds its fp32 ACCUMULATOR at every step, and with HALF the accumulation
+// steps of the three-plane bf16 scheme (conv_igemm_bf16x3.hip: six partial products) the sum ends up CLOSER to the exact
+// result than both that scheme and the fp32-MFMA kernel (tests: error vs an fp64 convolution <= the fp32-MFMA kernel's on
+// every shape, including operands spread over 2^-10..2^10 with >= 100x cancellation).  3 fp16 MFMA flops per algorithmic
+// flop => a ceiling of 2500 / 3 = 833 TFLOP/s for fp32-accurate work (bf16x3: 416.7, fp32 MFMA pipe: 157.3).
+//
+// Range.  fp16 ends at 65504: activations are stored as a * 16 (|a| < 4094; lo stays a normal number down to |a| = 2^-7 and
+// the representation error is <= max(2^-22 |a|, 1.9e-9) below), weights per output channel as w * 2^sw with max |w 2^sw| in
+// [2^13, 2^14); the host folds 2^-(sw+4) into the epilogue's per-channel scale (exact).  An activation beyond the range is
+// CLAMPED and reported through `overflow_flag` (the host then raises / falls back to bf16x3) - never an inf.
+//
+// Layout ("h2 tensor"): per pixel and per group of 32 channels one 128-byte record [hi x 32 | lo x 32] fp16, i.e.
+// [pixels][C / 32][2][32] - the byte size of the fp32 tensor.  A 128-byte LDS row is therefore exactly the 64-"channel" row
+// of the plain bf16 kernels (conv_igemm_bf16.hip / conv_igemm_bf16_8ph.hip): staging, swizzle, DMA stream and both schedules
+// (2x2-wave tile kernel; 256x256 eight-phase ping-pong with the two wave groups one barrier apart) are theirs unchanged.
+// What differs is the inner product: of a row's four 16-byte slot pairs j (j = 0,1: hi of channels 0-15 / 16-31; j = 2,3:
+// lo) a k16 step s takes  A[2+s]*B[s] + A[s]*B[2+s] + A[s]*B[s]  - 6 MFMAs per 32x32 tile pair and row instead of 4, from
+// the same fragment reads - and the epilogue, which writes fp32 and / or the h2 record of the result.
+#include "conv_bf16_common.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+struct ConvH2Args {
+    ConvBArgs b;         // d.x / d.w: h2 tensors; d.y: fp32 output or null; d.res: fp32 residual or null; channel counts REAL
+    void* y_h2;          // optional: the result as an h2 tensor (geometry d.out_cs / d.out_co, multiples of 32)
+    const void* res_h2;  // optional: the residual as an h2 tensor (geometry d.res_cs / d.res_co), used when d.res is null
+    int* overflow_flag;  // set to 1 when an output had to be clamped to the fp16 range (may be null)
+};
+
+namespace {
+
+constexpr float H2_SCALE = 16.f, H2_INV_SCALE = 1.f / 16.f, H2_MAX = 65504.f;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+template <int V>
+using ic = std::integral_constant<int, V>;
+
+// fp32 value (already multiplied by the tensor scale) -> hi, lo; returns true when it had to be clamped
+__device__ __forceinline__ bool h2_split(float s, _Float16& hi, _Float16& lo)
+{
+    const bool over = !(fabsf(s) <= H2_MAX);  // also catches NaN (left to propagate as NaN)
+    s = fminf(fmaxf(s, -H2_MAX), H2_MAX);
+    hi = (_Float16)s;
+    lo = (_Float16)(s - (float)hi);
+    return over;
+}
+
+// Tail of the h2 epilogues for 8 consecutive channels [ch, ch+8) of output pixel `pix`: v = scale*acc + shift on entry;
+// residual (fp32 tensor or h2 record), activation, fp32 store and / or the h2 record of the result.
+__device__ __forceinline__ void h2_finish_row8(const ConvH2Args& ax, float (&v)[8], const long long pix, const int ch)
+{
+    const rdpn6d_conv_desc& d = ax.b.d;
+    if (d.res) {
+        const float* rp = d.res + pix * d.res_cs + d.res_co + ch;
+        const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            v[q] += r0[q];
+            v[4 + q] += r1[q];
+        }
+    } else if (ax.res_h2) {
+        const int c = d.res_co + ch;
+        const _Float16* rp = reinterpret_cast<const _Float16*>(ax.res_h2) + pix * (2 * d.res_cs) + (c >> 5) * 64 + (c & 31);
+        const f16x8 rh = *reinterpret_cast<const f16x8*>(rp), rl = *reinterpret_cast<const f16x8*>(rp + 32);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] += ((float)rh[q] + (float)rl[q]) * H2_INV_SCALE;  // the activation as the h2 tensor holds it (22 significand bits)
+    }
+    conv_bf16_act(v, d.act, d.slope);
+    if (d.y) {
+        float* op = d.y + pix * d.out_cs + d.out_co + ch;
+        const f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+        *reinterpret_cast<f32x4*>(op) = o0;
+        *reinterpret_cast<f32x4*>(op + 4) = o1;
+    }
+    if (ax.y_h2) {
+        f16x8 hi, lo;
+        bool over = false;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            _Float16 h, l;
+            over |= h2_split(v[q] * H2_SCALE, h, l);
+            hi[q] = h;
+            lo[q] = l;
+        }
+        const int c = d.out_co + ch;
+        _Float16* pp = reinterpret_cast<_Float16*>(ax.y_h2) + pix * (2 * d.out_cs) + (c >> 5) * 64 + (c & 31);
+        *reinterpret_cast<f16x8*>(pp) = hi;
+        *reinterpret_cast<f16x8*>(pp + 32) = lo;
+        if (over && ax.overflow_flag) *ax.overflow_flag = 1;
+    }
+}
+
+__device__ __forceinline__ f32x16 h2_mfma(const u32x4 a, const u32x4 b, const f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// the six partial products of a 128-byte row pair, smallest terms first: (slot pair of A, slot pair of B)
+#define H2_PAIRS constexpr int H2_PA[6] = {2, 0, 0, 3, 1, 1}, H2_PB[6] = {0, 2, 0, 1, 3, 1}
+
+__device__ __forceinline__ long long h2_pixel_of(const ConvBArgs& a, const long long m)
+{
+    const rdpn6d_conv_desc& d = a.d;
+    if (a.linear_out) return m;
+    const int mm = (int)m;
+    const int b = mm / a.HoWo;
+    const int rem = mm - b * a.HoWo;
+    const int oy = rem / d.Wo;
+    const int ox = rem - oy * d.Wo;
+    return ((long long)b * d.OH + (oy * d.osy + d.ooy)) * d.OW + (ox * d.osx + d.oox);
+}
+
+// ============================================================================================ 256x256 eight-phase kernel
+constexpr int HT_BYTES = 16384;            // one half-tile slot: 128 rows x 128 B
+constexpr int LDS_8PH = 2 * 4 * HT_BYTES;  // 128 KiB
+
+// Schedule, LDS map, DMA stream and counted waits: see conv_igemm_bf16_8ph.hip (this is that kernel with the h2 inner
+// product - 12 MFMAs per phase instead of 8 - and the h2 epilogue).  A K-tile = one 128-byte row = 32 channels (hi | lo).
+__global__ __launch_bounds__(512) void conv_h2_8ph_kernel(const ConvH2Args ax)
+{
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const ConvBArgs& a = ax.b;
+    const rdpn6d_conv_desc& d = a.d;
+    const int nblk = a.mtiles * a.ntiles;
+    const int bid = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, kk = bid >> 3;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + kk;
+    const int nt = logical % a.ntiles;
+    const int mt = logical / a.ntiles;
+    const long long m0 = (long long)mt * 256;
+    const int n0 = nt * 256;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    // ---- DMA addressing: this wave moves pieces `wave` and `wave + 8` (8 rows x 128 B each) of every half-tile
+    const int prow = lane >> 3;
+    const int lr_lo = wave * 8 + prow;
+    const unsigned lslot16 = (unsigned)((lane & 7) ^ ((lr_lo >> 1) & 7)) * 16u;
+    const unsigned px_bytes = (unsigned)d.in_cs * 4u;  // an h2 pixel is 2 x in_cs halfs
+    unsigned a_base[2][2], a_mask[2][2];
+#pragma unroll
+    for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const long long m = m0 + i * 128 + qm * 64 + lr_lo;
+            const bool ok = m < a.M;
+            const int mm = ok ? (int)m : 0;
+            const int b = mm / a.HoWo;
+            const int rem = mm - b * a.HoWo;
+            const int oy = rem / d.Wo;
+            const int ox = rem - oy * d.Wo;
+            const int iy = oy * d.stride, ix = ox * d.stride;
+            a_base[qm][i] = (unsigned)((b * d.H + iy) * d.W + ix) * px_bytes + (unsigned)d.in_co * 4u + lslot16;
+            unsigned mask = 0;
+            for (int t = 0; t < d.ntaps; ++t) {
+                const int dy = (int)((a.dy_pack >> (4 * t)) & 15ull) - 8, dx = (int)((a.dx_pack >> (4 * t)) & 15ull) - 8;
+                mask |= (ok && (unsigned)(iy + dy) < (unsigned)d.H && (unsigned)(ix + dx) < (unsigned)d.W) ? (1u << t) : 0u;
+            }
+            a_mask[qm][i] = mask;
+        }
+    unsigned w_off[2][2];
+#pragma unroll
+    for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int lr = lr_lo + 64 * i;
+            const int col = (lr >> 5) * 64 + qn * 32 + (lr & 31);
+            w_off[qn][i] = (unsigned)(n0 + col) * (unsigned)a.Ktot * 4u + lslot16;
+        }
+    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.w), 0, a.w_bytes, 0x00020000);
+
+    unsigned st_off[2];
+    auto addr_A = [&](auto qmc, const int tap, const int cc, const bool valid) {
+        constexpr int qm = decltype(qmc)::value;
+        const int dy = (int)((a.dy_pack >> (4 * tap)) & 15ull) - 8, dx = (int)((a.dx_pack >> (4 * tap)) & 15ull) - 8;
+        const unsigned toff = (unsigned)((dy * d.W + dx) * (int)px_bytes + cc * 128);  // wave-uniform
+        const unsigned sel = valid ? 0u : 0xFFFFFFFFu;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const unsigned kill = ((a_mask[qm][i] >> tap) & 1u) - 1u;
+            st_off[i] = (a_base[qm][i] + toff) | kill | sel;
+        }
+    };
+    auto addr_B = [&](auto qnc, const int tap, const int cc, const bool valid) {
+        constexpr int qn = decltype(qnc)::value;
+        const unsigned wk = (unsigned)tap * (unsigned)d.Cin * 4u + (unsigned)cc * 128u;
+        const unsigned sel = valid ? 0u : 0xFFFFFFFFu;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) st_off[i] = (w_off[qn][i] + wk) | sel;
+    };
+    auto issue = [&](auto isBc, auto qc, const int buf, auto ic_) {
+        constexpr int isB = decltype(isBc)::value, q = decltype(qc)::value, i = decltype(ic_)::value;
+        unsigned char* dst = smem + isB * 4 * HT_BYTES + (buf * 2 + q) * HT_BYTES + (wave + 8 * i) * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(isB ? wsrc : xsrc, (lds_ptr_t)dst, 16, (int)st_off[i], 0, 0, 0);
+    };
+    auto stage_A = [&](auto qmc, const int buf, const int tap, const int cc, const bool valid) {
+        addr_A(qmc, tap, cc, valid);
+        issue(ic<0>{}, qmc, buf, ic<0>{});
+        issue(ic<0>{}, qmc, buf, ic<1>{});
+    };
+    auto stage_B = [&](auto qnc, const int buf, const int tap, const int cc, const bool valid) {
+        addr_B(qnc, tap, cc, valid);
+        issue(ic<1>{}, qnc, buf, ic<0>{});
+        issue(ic<1>{}, qnc, buf, ic<1>{});
+    };
+
+    // ---- fragment addressing
+    const int frow = lane & 31;
+    const int half = lane >> 5;
+    unsigned fa_base[2], fa_sw[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int lr = wr * 64 + i * 32 + frow;
+        fa_base[i] = (unsigned)lr * 128u;
+        fa_sw[i] = (unsigned)((lr >> 1) & 7);
+    }
+    const int lrb = wc * 32 + frow;
+    const unsigned fb_base = (unsigned)lrb * 128u, fb_sw = (unsigned)((lrb >> 1) & 7);
+
+    u32x4 fa[2][4], fb0[4], fb1[4];
+    auto read_A = [&](const int qm, const int buf) {
+        const unsigned char* slot = smem + (buf * 2 + qm) * HT_BYTES;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                fa[i][j] = *reinterpret_cast<const u32x4*>(slot + fa_base[i] + ((((unsigned)(2 * j + half)) ^ fa_sw[i]) << 4));
+    };
+    auto read_B = [&](const int qn, const int buf, u32x4 (&fb)[4]) {
+        const unsigned char* slot = smem + 4 * HT_BYTES + (buf * 2 + qn) * HT_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            fb[j] = *reinterpret_cast<const u32x4*>(slot + fb_base + ((((unsigned)(2 * j + half)) ^ fb_sw) << 4));
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    // partial products [p0, p1) of one quadrant, both m-tiles
+    auto mma_part = [&](auto qmc, auto qnc, const u32x4 (&fb)[4], auto p0c, auto p1c) {
+        constexpr int qm = decltype(qmc)::value, qn = decltype(qnc)::value;
+        H2_PAIRS;
+#pragma unroll
+        for (int pr = decltype(p0c)::value; pr < decltype(p1c)::value; ++pr)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[qm * 2 + i][qn] = h2_mfma(fa[i][H2_PA[pr]], fb[H2_PB[pr]], acc[qm * 2 + i][qn]);
+    };
+
+    const int nk = a.nk;
+    int t1_tap = 0, t1_cc = 0, t2_tap = 0, t2_cc = 0;
+    auto advance = [&](int& tap, int& cc) {
+        ++tap;
+        const int wrap = tap == d.ntaps ? 1 : 0;
+        tap = wrap ? 0 : tap;
+        cc += wrap;
+    };
+
+    // ---- prologue: half-tiles 0..6 = all of K-tile 0 and {B-h1, A-h0, B-h0} of K-tile 1
+    stage_B(ic<0>{}, 0, 0, 0, true);
+    stage_A(ic<0>{}, 0, 0, 0, true);
+    stage_B(ic<1>{}, 0, 0, 0, true);
+    stage_A(ic<1>{}, 0, 0, 0, true);
+    advance(t1_tap, t1_cc);
+    stage_B(ic<1>{}, 1, t1_tap, t1_cc, nk > 1);
+    stage_A(ic<0>{}, 1, t1_tap, t1_cc, nk > 1);
+    stage_B(ic<0>{}, 1, t1_tap, t1_cc, nk > 1);
+    t2_tap = t1_tap;
+    t2_cc = t1_cc;
+    advance(t2_tap, t2_cc);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_B(0, 0, fb0);
+    if (wr == 1) __builtin_amdgcn_s_barrier();  // the second wave group runs one barrier behind from here on
+
+    auto phase = [&](auto jc, auto bufc, const int t) {
+        constexpr int j = decltype(jc)::value, buf = decltype(bufc)::value;
+        constexpr int sB = (j == 1 || j == 3) ? 1 : 0;
+        constexpr int sQ = j == 0 ? 1 : (j == 2 ? 0 : (j == 1 ? buf : (buf ^ 1)));
+        constexpr int sBuf = j == 0 ? (buf ^ 1) : buf;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (j == 0) {
+            read_A(0, buf);
+        } else if constexpr (j == 1) {
+            if constexpr (buf == 0) read_B(1, buf, fb1);
+            else read_B(0, buf, fb0);
+        } else if constexpr (j == 2) {
+            read_A(1, buf);
+        } else {
+            if constexpr (buf == 0) read_B(1, buf ^ 1, fb1);
+            else read_B(0, buf ^ 1, fb0);
+        }
+        if constexpr (j == 0) addr_A(ic<1>{}, t1_tap, t1_cc, t + 1 < nk);
+        else if constexpr (j == 2) addr_A(ic<0>{}, t2_tap, t2_cc, t + 2 < nk);
+        else addr_B(ic<sQ>{}, t2_tap, t2_cc, t + 2 < nk);
+        if constexpr (j == 3) {
+            t1_tap = t2_tap;
+            t1_cc = t2_cc;
+            advance(t2_tap, t2_cc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        constexpr int qm = (j >> 1), qn = ((j == 1 || j == 2) ? 1 : 0) ^ buf;
+        const u32x4 (&fb)[4] = qn ? fb1 : fb0;
+        mma_part(ic<qm>{}, ic<qn>{}, fb, ic<0>{}, ic<1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        issue(ic<sB>{}, ic<sQ>{}, sBuf, ic<0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        mma_part(ic<qm>{}, ic<qn>{}, fb, ic<1>{}, ic<2>{});
+        __builtin_amdgcn_sched_barrier(0);
+        issue(ic<sB>{}, ic<sQ>{}, sBuf, ic<1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        mma_part(ic<qm>{}, ic<qn>{}, fb, ic<2>{}, ic<6>{});
+        __builtin_amdgcn_s_setprio(0);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+
+    for (int t = 0; t < nk; t += 2) {
+        phase(ic<0>{}, ic<0>{}, t);
+        phase(ic<1>{}, ic<0>{}, t);
+        phase(ic<2>{}, ic<0>{}, t);
+        phase(ic<3>{}, ic<0>{}, t);
+        phase(ic<0>{}, ic<1>{}, t + 1);
+        phase(ic<1>{}, ic<1>{}, t + 1);
+        phase(ic<2>{}, ic<1>{}, t + 1);
+        phase(ic<3>{}, ic<1>{}, t + 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (wr == 0) __builtin_amdgcn_s_barrier();  // re-align the two groups
+
+    // ---- epilogue: each wave transposes its 128 x 64 tile through its own LDS slice, 8 channels per lane on the way out
+    {
+        const int hi = lane >> 5;
+        constexpr int CS = 64 + 8;
+        __syncthreads();
+        float* cst = reinterpret_cast<float*>(smem) + wave * (32 * CS);
+        const int nb = n0 + wc * 64;
+        float scj[2], shj[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = nb + j * 32 + frow;
+            scj[j] = d.scale ? d.scale[n] : 1.f;
+            shj[j] = d.shift ? d.shift[n] : 0.f;
+        }
+        const int rrow = lane >> 3, c8 = (lane & 7) * 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    cst[((e & 3) + 8 * (e >> 2) + 4 * hi) * CS + j * 32 + frow] = acc[i][j][e] * scj[j] + shj[j];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int row = rr * 8 + rrow;
+                const long long mrow = m0 + wr * 128 + i * 32 + row;
+                if (mrow >= a.M) continue;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(cst + row * CS + c8);
+                const f32x4 hi4 = *reinterpret_cast<const f32x4*>(cst + row * CS + c8 + 4);
+                float v[8] = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+                h2_finish_row8(ax, v, h2_pixel_of(a, mrow), nb + c8);
+            }
+        }
+    }
+}
+
+// ============================================================================================ 128x128 .. 64x64 tile kernel
+// conv_igemm_bf16.hip's two-stage form (2x2 wavefronts, LDS-DMA staging, one barrier per K-chunk, fragment double buffer,
+// two workgroups per CU) on 128-byte h2 rows: 6 MFMAs per 32x32 tile pair and chunk from 4 + 4 fragment reads.
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void conv_h2_tile_kernel(const ConvH2Args ax)
+{
+    constexpr int NW = 4, NST = 2, RB = 128;
+    constexpr int RPP = 1024 / RB;  // 8 rows per 1-KiB DMA piece
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int AG = BM / RPP / NW, BG = BN / RPP / NW;
+    static_assert(TM >= 1 && TN >= 1 && AG >= 1 && BG >= 1, "tile / wave layout");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    unsigned char* As = smem;
+    unsigned char* Bs = smem + NST * BM * RB;
+
+    const ConvBArgs& a = ax.b;
+    const rdpn6d_conv_desc& d = a.d;
+    const int nblk = a.mtiles * a.ntiles;
+    const int bid = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, kk = bid >> 3;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + kk;
+    const int nt = logical % a.ntiles;
+    const int mt = logical / a.ntiles;
+    const long long m0 = (long long)mt * BM;
+    const int n0 = nt * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int prow = lane >> 3, pslot = lane & 7;
+    const unsigned px_bytes = (unsigned)d.in_cs * 4u;
+    unsigned a_base[AG], a_mask[AG];
+#pragma unroll
+    for (int i = 0; i < AG; ++i) {
+        const int row = (wave + NW * i) * RPP + prow;
+        const long long m = m0 + row;
+        const bool ok = m < a.M;
+        const int mm = ok ? (int)m : 0;
+        const int b = mm / a.HoWo;
+        const int rem = mm - b * a.HoWo;
+        const int oy = rem / d.Wo;
+        const int ox = rem - oy * d.Wo;
+        const int iy = oy * d.stride, ix = ox * d.stride;
+        const int lslot = pslot ^ ((row >> 1) & 7);
+        a_base[i] = (unsigned)((b * d.H + iy) * d.W + ix) * px_bytes + (unsigned)d.in_co * 4u + (unsigned)lslot * 16u;
+        unsigned mask = 0;
+        for (int t = 0; t < d.ntaps; ++t) {
+            const int dy = (int)((a.dy_pack >> (4 * t)) & 15ull) - 8, dx = (int)((a.dx_pack >> (4 * t)) & 15ull) - 8;
+            mask |= (ok && (unsigned)(iy + dy) < (unsigned)d.H && (unsigned)(ix + dx) < (unsigned)d.W) ? (1u << t) : 0u;
+        }
+        a_mask[i] = mask;
+    }
+    unsigned w_off[BG];
+#pragma unroll
+    for (int i = 0; i < BG; ++i) {
+        const int row = (wave + NW * i) * RPP + prow;
+        const int lslot = pslot ^ ((row >> 1) & 7);
+        w_off[i] = (unsigned)(n0 + row) * (unsigned)a.Ktot * 4u + (unsigned)lslot * 16u;
+    }
+    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.w), 0, a.w_bytes, 0x00020000);
+
+    auto stage_chunk = [&](const int tap, const int cc, const int st) {
+        const int dy = (int)((a.dy_pack >> (4 * tap)) & 15ull) - 8, dx = (int)((a.dx_pack >> (4 * tap)) & 15ull) - 8;
+        const unsigned toff = (unsigned)((dy * d.W + dx) * (int)px_bytes + cc * RB);  // wave-uniform
+#pragma unroll
+        for (int i = 0; i < AG; ++i) {
+            const unsigned kill = ((a_mask[i] >> tap) & 1u) - 1u;  // all ones outside the image / past M: reads zeros
+            unsigned char* dst = As + ((st * BM) + (wave + NW * i) * RPP) * RB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_ptr_t)dst, 16, (int)((a_base[i] + toff) | kill), 0, 0, 0);
+        }
+        const unsigned wk = (unsigned)tap * (unsigned)d.Cin * 4u + (unsigned)cc * (unsigned)RB;
+#pragma unroll
+        for (int i = 0; i < BG; ++i) {
+            unsigned char* dst = Bs + ((st * BN) + (wave + NW * i) * RPP) * RB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrc, (lds_ptr_t)dst, 16, (int)(w_off[i] + wk), 0, 0, 0);
+        }
+    };
+    const int nk = a.nk;
+    int ld_cc = 0, ld_tap = 0, ld_left = nk - 1;
+    auto next_chunk = [](int& tap, int& cc, int& left, const int ntaps) {
+        const int go = left > 0 ? 1 : 0;
+        left -= go;
+        tap += go;
+        const int wrap = tap == ntaps ? 1 : 0;
+        tap = wrap ? 0 : tap;
+        cc += wrap;
+    };
+
+    const int wm = wave >> 1, wn = wave & 1;
+    const int frow = lane & 31;
+    const int half = lane >> 5;
+
+    auto read_frags = [&](int st, u32x4 (&fa)[TM][4], u32x4 (&fb)[TN][4]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int R = wm * (BM / 2) + i * 32 + frow;
+            const int sw = (R >> 1) & 7;
+            const unsigned char* q = As + ((st * BM) + R) * RB;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fa[i][j] = *reinterpret_cast<const u32x4*>(q + (((2 * j + half) ^ sw) << 4));
+        }
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) {
+            const int R = wn * (BN / 2) + jn * 32 + frow;
+            const int sw = (R >> 1) & 7;
+            const unsigned char* q = Bs + ((st * BN) + R) * RB;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[jn][j] = *reinterpret_cast<const u32x4*>(q + (((2 * j + half) ^ sw) << 4));
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    auto mma = [&](const u32x4 (&fa)[TM][4], const u32x4 (&fb)[TN][4]) {
+        H2_PAIRS;
+#pragma unroll
+        for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int jn = 0; jn < TN; ++jn) acc[i][jn] = h2_mfma(fa[i][H2_PA[pr]], fb[jn][H2_PB[pr]], acc[i][jn]);
+    };
+
+    u32x4 fa0[TM][4], fb0[TN][4], fa1[TM][4], fb1[TN][4];
+    stage_chunk(ld_tap, ld_cc, 0);
+    next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
+    stage_chunk(ld_tap, ld_cc, 1);
+    next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
+    __syncthreads();
+    read_frags(0, fa0, fb0);
+    __syncthreads();  // stage 0 is re-filled by the first loop step: every wave must have its fragments first
+    const int npairs = nk >> 1;
+    for (int pr = 0; pr < npairs; ++pr) {
+        stage_chunk(ld_tap, ld_cc, 0);
+        next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
+        read_frags(1, fa1, fb1);
+        mma(fa0, fb0);
+        __syncthreads();
+
+        stage_chunk(ld_tap, ld_cc, 1);
+        next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
+        read_frags(0, fa0, fb0);
+        mma(fa1, fb1);
+        __syncthreads();
+    }
+    if (nk & 1) mma(fa0, fb0);
+
+    {
+        const int hi = lane >> 5;
+        constexpr int WC = BN / 2, CS = WC + 8, LPR = WC / 8, RPI = 64 / LPR;
+        __syncthreads();
+        float* cst = reinterpret_cast<float*>(smem) + wave * (32 * CS);
+        const int nb = n0 + wn * WC;
+        float scj[TN], shj[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = nb + j * 32 + frow;
+            scj[j] = d.scale ? d.scale[n] : 1.f;
+            shj[j] = d.shift ? d.shift[n] : 0.f;
+        }
+        const int rrow = lane / LPR, c8 = (lane % LPR) * 8;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    cst[((e & 3) + 8 * (e >> 2) + 4 * hi) * CS + j * 32 + frow] = acc[i][j][e] * scj[j] + shj[j];
+#pragma unroll
+            for (int rr = 0; rr < 32 / RPI; ++rr) {
+                const int row = rr * RPI + rrow;
+                const long long mrow = m0 + wm * (BM / 2) + i * 32 + row;
+                if (mrow < a.M && nb + c8 < d.N) {
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(cst + row * CS + c8);
+                    const f32x4 hi4 = *reinterpret_cast<const f32x4*>(cst + row * CS + c8 + 4);
+                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+                    h2_finish_row8(ax, v, h2_pixel_of(a, mrow), nb + c8);
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN>
+int launch_h2_tile(const ConvH2Args& ax, hipStream_t s)
+{
+    constexpr int lds_stage = 2 * (BM + BN) * 128;
+    constexpr int lds_epi = 4 * 32 * (BN / 2 + 8) * 4;
+    constexpr int lds = lds_stage > lds_epi ? lds_stage : lds_epi;
+    static_assert(lds <= 80 * 1024, "two workgroups per CU");
+    auto kern = conv_h2_tile_kernel<BM, BN>;
+    if (lds > 64 * 1024) {
+        static bool configured = false;
+        if (!configured) {
+            RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+            configured = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ax.b.mtiles * ax.b.ntiles)), dim3(256), lds, s, ax);
+    return RDPN6D_OK;
+}
+
+// ============================================================================================ fp32 -> h2
+// x: fp32 NHWC pixels with channel stride src_cs, slice [src_co, src_co + C), C % 32 == 0 -> dst h2 tensor [npix][C/32][2][32]
+__global__ void split_h2_kernel(const float* __restrict__ x, int src_cs, int src_co, int C, _Float16* __restrict__ dst, long long npix,
+                                int* __restrict__ overflow_flag)
+{
+    const int c8n = C >> 3;
+    const long long total = npix * c8n;
+    bool over = false;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long p = i / c8n;
+        const int c = (int)(i - p * c8n) * 8;
+        const float* sp = x + p * src_cs + src_co + c;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
+        const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        f16x8 hi, lo;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            _Float16 h, l;
+            over |= h2_split(v[q] * H2_SCALE, h, l);
+            hi[q] = h;
+            lo[q] = l;
+        }
+        _Float16* pp = dst + p * (2 * (long long)C) + (c >> 5) * 64 + (c & 31);
+        *reinterpret_cast<f16x8*>(pp) = hi;
+        *reinterpret_cast<f16x8*>(pp + 32) = lo;
+    }
+    if (over && overflow_flag) *overflow_flag = 1;
+}
+
+bool h2_common_ok(const rdpn6d_conv_desc* d)
+{
+    return d->Cin % 32 == 0 && d->in_cs % 32 == 0 && d->in_co % 32 == 0 && d->out_cs % 8 == 0 && d->out_co % 8 == 0 && d->N % 8 == 0 &&
+           d->Npad % 64 == 0 && (!d->res || (d->res_cs % 4 == 0 && d->res_co % 4 == 0));
+}
+bool h2_big_ok(const rdpn6d_conv_desc* d)
+{
+    const int nk = d->ntaps * (d->Cin / 32);
+    return h2_common_ok(d) && d->Npad % 256 == 0 && d->N == d->Npad && nk >= 2 && (nk & 1) == 0;
+}
+bool h2_big_pays(const rdpn6d_conv_desc* d, long long M)
+{
+    const long long tiles = (long long)rd_cdiv(M, 256) * (d->Npad / 256);
+    const long long rounds = (tiles + 255) / 256;
+    return tiles >= 160 && (double)tiles >= 0.62 * 256.0 * (double)rounds;
+}
+void h2_pick_tile(const rdpn6d_conv_desc* d, long long M, int* pbm, int* pbn)
+{
+    int bn = (d->Npad % 128 == 0) ? 128 : 64;
+    int bm = 128;
+    if ((long long)rd_cdiv(M, 128) * (d->Npad / bn) < 512) bm = 64;
+    if (bm == 64 && bn == 128 && (long long)rd_cdiv(M, 64) * (d->Npad / 128) < 512) bn = 64;
+    if (const char* f = getenv("RDPN6D_H2_TILE")) {  // profiling: "bm,bn"
+        int fbm = 0, fbn = 0;
+        if (sscanf(f, "%d,%d", &fbm, &fbn) == 2 && (fbm == 64 || fbm == 128) && (fbn == 64 || fbn == 128) && d->Npad % fbn == 0) {
+            bm = fbm;
+            bn = fbn;
+        }
+    }
+    *pbm = bm;
+    *pbn = bn;
+}
+
+}  // namespace
+
+extern "C" int rdpn6d_split_h2(const float* x, int src_cs, int src_co, int C, void* dst, long long npix, int* overflow_flag, void* stream)
+{
+    RD_REQUIRE(x && dst && npix > 0 && C > 0 && C % 32 == 0 && src_cs % 4 == 0 && src_co % 4 == 0 && src_co + C <= src_cs, "h2 split: C % 32, aligned slice");
+    const long long blocks = (npix * (C / 8) + 255) / 256;
+    hipLaunchKernelGGL(split_h2_kernel, dim3((unsigned)(blocks > 16384 ? 16384 : blocks)), dim3(256), 0, (hipStream_t)stream, x, src_cs,
+                       src_co, C, (_Float16*)dst, npix, overflow_flag);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}
+
+// which h2 kernel rdpn6d_conv2d_h2 would use: 2 = 256x256 eight-phase, 1 = 128x128..64x64 tile kernel, 0 = not eligible
+extern "C" int rdpn6d_conv_h2_kernel_for(const rdpn6d_conv_desc* d)
+{
+    if (!d || !h2_common_ok(d)) return 0;
+    const long long M = (long long)d->B * d->Ho * d->Wo;
+    return (h2_big_ok(d) && h2_big_pays(d, M)) ? 2 : 1;
+}
+
+extern "C" int rdpn6d_conv2d_h2(const rdpn6d_conv_desc* d, void* y_h2, const void* res_h2, int* overflow_flag, void* stream)
+{
+    RD_REQUIRE(d && d->x && d->w && (d->y || y_h2), "null pointer");
+    const int which = rdpn6d_conv_h2_kernel_for(d);
+    RD_REQUIRE(which != 0, "h2 needs Cin, in_cs, in_co % 32 == 0, N % 8 == 0, Npad % 64 == 0, 16-byte aligned output slices");
+    RD_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0 && d->ntaps >= 1 && d->ntaps <= 9, "shape");
+    RD_REQUIRE(d->in_co + d->Cin <= d->in_cs && d->out_co + d->N <= d->out_cs, "channel slices");
+    RD_REQUIRE((d->Ho - 1) * d->osy + d->ooy < d->OH && (d->Wo - 1) * d->osx + d->oox < d->OW, "output geometry");
+    RD_REQUIRE(!(d->res && res_h2), "residual either as an fp32 tensor or as an h2 tensor");
+    RD_REQUIRE(!res_h2 || (d->res_cs % 32 == 0 && d->res_co % 8 == 0 && d->res_co + d->N <= d->res_cs), "h2 residual slice");
+    RD_REQUIRE(!y_h2 || (d->out_cs % 32 == 0), "h2 output: channel stride % 32");
+    ConvH2Args ax;
+    ConvBArgs& a = ax.b;
+    a.d = *d;
+    a.M = (long long)d->B * d->Ho * d->Wo;
+    RD_REQUIRE(a.M < (1LL << 31), "B*Ho*Wo must fit 31 bits");
+    a.HoWo = d->Ho * d->Wo;
+    a.cchunks = d->Cin / 32;
+    a.nk = d->ntaps * a.cchunks;
+    a.Ktot = d->ntaps * d->Cin;
+    a.linear_out = (d->osy == 1 && d->osx == 1 && d->ooy == 0 && d->oox == 0 && d->OH == d->Ho && d->OW == d->Wo);
+    a.out_f32 = 1;
+    a.vec_out = 1;
+    const long long x_bytes = (long long)d->B * d->H * d->W * d->in_cs * 4, w_bytes = (long long)d->Npad * d->ntaps * d->Cin * 4;
+    RD_REQUIRE(x_bytes < (1LL << 32) - 64 && w_bytes < (1LL << 32) - 64, "h2 tensors are addressed with 32-bit offsets (< 4 GiB each)");
+    a.x_bytes = (unsigned)x_bytes;
+    a.w_bytes = (unsigned)w_bytes;
+    ax.y_h2 = y_h2;
+    ax.res_h2 = res_h2;
+    ax.overflow_flag = overflow_flag;
+    a.dy_pack = a.dx_pack = 0;
+    for (int t = 0; t < d->ntaps; ++t) {
+        RD_REQUIRE(d->dy[t] >= -8 && d->dy[t] <= 7 && d->dx[t] >= -8 && d->dx[t] <= 7, "tap offsets must be in -8..7");
+        a.dy_pack |= (unsigned long long)(d->dy[t] + 8) << (4 * t);
+        a.dx_pack |= (unsigned long long)(d->dx[t] + 8) << (4 * t);
+    }
+    a.kper = a.nk;
+    a.partial = nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    if (which == 1) {
+        int bm, bn;
+        h2_pick_tile(d, a.M, &bm, &bn);
+        a.mtiles = rd_cdiv(a.M, bm);
+        a.ntiles = d->Npad / bn;
+        int rc;
+        if (bm == 128 && bn == 128) rc = launch_h2_tile<128, 128>(ax, s);
+        else if (bm == 128) rc = launch_h2_tile<128, 64>(ax, s);
+        else if (bn == 128) rc = launch_h2_tile<64, 128>(ax, s);
+        else rc = launch_h2_tile<64, 64>(ax, s);
+        if (rc != RDPN6D_OK) return rc;
+        RD_LAUNCH_CHECK();
+        return RDPN6D_OK;
+    }
+    a.mtiles = rd_cdiv(a.M, 256);
+    a.ntiles = d->Npad / 256;
+    static bool configured = false;
+    if (!configured) {
+        RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2_8ph_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_8PH));
+        configured = true;
+    }
+    hipLaunchKernelGGL(conv_h2_8ph_kernel, dim3((unsigned)(a.mtiles * a.ntiles)), dim3(512), LDS_8PH, s, ax);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}

@@ -196,6 +196,26 @@ def pack_conv_weight(w, cin_pad=None, perm=None):
     return out.contiguous()
 
 
+H2_ACT_SCALE = 16.0  # activations of the two-plane fp16 ("h2") convolutions are stored as a * 16 (csrc/conv_igemm_h2.hip)
+
+
+def pack_h2_weight(w32):
+    """packed fp32 weights [Npad][taps][Cin] (Cin % 32 == 0) -> (h2 tensor [Npad][taps][Cin/32][2][32] fp16 holding
+    w * 2^sw(n) as hi + lo, fp32 vector 2^-sw(n) / 16 to fold into the epilogue scale).  2^sw(n) brings the largest weight of
+    output channel n into [2^13, 2^14): the lo term then stays a normal fp16 number for every weight within 2^-10 of it."""
+    npad, taps, cin = w32.shape
+    assert cin % 32 == 0, cin
+    mx = w32.abs().amax(dim=(1, 2))
+    e = torch.floor(13.0 - torch.log2(mx.clamp_min(1e-30)))
+    sw = torch.where(mx > 0, torch.exp2(e), torch.ones_like(mx))
+    ws = w32 * sw[:, None, None]  # exact: a power of two
+    hi = ws.half()
+    lo = (ws - hi.float()).half()
+    out = torch.stack([hi.view(npad, taps, cin // 32, 32), lo.view(npad, taps, cin // 32, 32)], dim=3).contiguous()
+    assert torch.isfinite(out.float()).all()
+    return out, (1.0 / (sw * H2_ACT_SCALE)).float().contiguous()
+
+
 def fold_bn(bn, conv_bias=None, npad=None):
     """scale = gamma/sqrt(var+eps), shift = beta + (bias - mean)*scale, computed in fp64."""
     g, b = bn.weight.detach().double(), bn.bias.detach().double()

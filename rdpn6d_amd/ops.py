@@ -128,6 +128,72 @@ def conv2d_nhwc_x3(x, weight, scale=None, shift=None, stride=1, pad=0, residual=
     return (out, (yp, tuple(out.shape))) if want_planes else out
 
 
+def split_h2(x):
+    """fp32 NHWC tensor [..., C] (C % 32 == 0) -> its two-plane fp16 form [pixels][C/32][2][32] holding 16*x = hi + lo (input
+    format of conv2d_nhwc_h2); also returns the device overflow flag (1 when a value beyond +-4094 had to be clamped)."""
+    _need_gpu(x)
+    x = x.contiguous()
+    C = x.shape[-1]
+    npix = x.numel() // C
+    h2 = torch.empty(npix, C // 32, 2, 32, dtype=torch.float16, device=x.device)
+    flag = torch.zeros(1, dtype=torch.int32, device=x.device)
+    _lib.check(_lib.load().rdpn6d_split_h2(_ptr(x), C, 0, C, _ptr(h2), npix, _ptr(flag), _stream()), "split_h2")
+    return h2, flag
+
+
+def merge_h2(h2, shape):
+    """inverse of split_h2 (exact): [pixels][C/32][2][32] fp16 -> fp32 tensor of `shape`"""
+    return ((h2[:, :, 0].float() + h2[:, :, 1].float()) / 16.0).reshape(shape)
+
+
+def conv2d_nhwc_h2(x, weight, scale=None, shift=None, stride=1, pad=0, residual=None, act=0, slope=0.0, want_h2=False, residual_h2=None):
+    """fp32-accurate convolution on the fp16 matrix pipe, two planes per operand (rdpn6d_conv2d_h2): x NHWC fp32 [B,H,W,C] or
+    (h2 tensor, shape) from split_h2 / a previous call; weight OIHW fp32 (Cin % 32 == 0).  Returns y fp32 NHWC and, with
+    want_h2, ((h2 tensor, shape) of y, overflow flag)."""
+    from .gdrn import pack_h2_weight
+
+    lib = _lib.load()
+    if isinstance(x, tuple):
+        xh, (B, H, W, cs) = x
+    else:
+        B, H, W, cs = x.shape
+        xh, _ = split_h2(x)
+    _need_gpu(xh, weight, scale, shift, residual)
+    N, wcin, k, _ = weight.shape
+    assert wcin % 32 == 0 and wcin <= cs
+    wp32 = pack_conv_weight(weight.float(), cin_pad=wcin)
+    wh, inv = pack_h2_weight(wp32)
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    out = torch.empty(B, Ho, Wo, N, dtype=torch.float32, device=xh.device)
+    yh = torch.empty(B * Ho * Wo, N // 32, 2, 32, dtype=torch.float16, device=xh.device) if want_h2 else None
+    flag = torch.zeros(1, dtype=torch.int32, device=xh.device)
+    sc = _pad_vec(scale.float(), wp32.shape[0], 1.0) * inv if scale is not None else inv
+    sh = _pad_vec(shift.float(), wp32.shape[0], 0.0) if shift is not None else None
+    d = _lib.ConvDesc()
+    d.x, d.w, d.scale, d.shift, d.res, d.y = _ptr(xh), _ptr(wh), _ptr(sc), _ptr(sh), _ptr(residual), _ptr(out)
+    d.B, d.H, d.W, d.Cin, d.in_cs, d.in_co = B, H, W, wcin, cs, 0
+    d.Ho, d.Wo, d.stride = Ho, Wo, stride
+    taps = [(ky - pad, kx - pad) for ky in range(k) for kx in range(k)]
+    d.ntaps = len(taps)
+    for t, (dy, dx) in enumerate(taps):
+        d.dy[t], d.dx[t] = dy, dx
+    d.N, d.Npad, d.OH, d.OW = N, wp32.shape[0], Ho, Wo
+    d.osy = d.osx = 1
+    d.ooy = d.oox = 0
+    d.out_cs, d.out_co = N, 0
+    if residual is not None:
+        d.res_cs, d.res_co = residual.shape[-1], 0
+    d.act, d.slope = act, slope
+    rh = None
+    if residual_h2 is not None:
+        rh = residual_h2[0]
+        d.res_cs, d.res_co = residual_h2[1][-1], 0
+    if not lib.rdpn6d_conv_h2_kernel_for(ctypes.byref(d)):
+        raise ValueError("layer not eligible for the h2 kernels (Cin % 32, N % 8, aligned slices)")
+    _lib.check(lib.rdpn6d_conv2d_h2(ctypes.byref(d), _ptr(yh), _ptr(rh), _ptr(flag), _stream()), "conv2d_h2")
+    return (out, ((yh, tuple(out.shape)), flag)) if want_h2 else out
+
+
 def stem_conv7x7(x_nchw, weight, scale, shift):
     _need_gpu(x_nchw, weight, scale, shift)
     B, xc, R, _ = x_nchw.shape

@@ -1,0 +1,128 @@
+"""The two-plane fp16 ("h2") convolution kernels - rdpn6d_conv2d_h2, csrc/conv_igemm_h2.hip - are fp32 convolutions: error
+against an fp64 convolution no larger than the fp32-MFMA kernel's own (typical error AND the a-priori bound under
+cancellation), exact hand-over of activations between layers, loud range handling."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+H2_CASES = [
+    # B, H, Cin, Cout, k, stride, res, act
+    (2, 32, 256, 256, 3, 1, True, 1),     # head layer shape (tile kernel at this size)
+    (64, 16, 256, 256, 3, 1, False, 1),   # 64 row tiles x 1 column tile ... M = 16384 rows: tile kernel
+    (3, 30, 64, 256, 3, 1, False, 2),     # ragged M (2700 rows), odd size, leaky
+    (2, 32, 32, 512, 1, 1, True, 0),      # 1x1, a single K-chunk
+    (2, 32, 128, 256, 3, 2, False, 1),    # stride 2
+    (1, 16, 1024, 256, 3, 1, False, 0),   # K = 9216
+    (8, 32, 64, 64, 3, 1, True, 1),       # trunk layer1 shape: N = 64
+    (4, 32, 128, 128, 3, 1, True, 1),     # layer2 shape
+    (2, 16, 64, 128, 3, 2, False, 1),     # stride-2 entry conv of a stage
+    (2, 16, 64, 128, 1, 2, False, 0),     # 1x1 stride-2 downsample
+    (3, 7, 512, 512, 3, 1, True, 1),      # layer4 shape: odd size, ragged rows, K = 4608
+    (12, 64, 256, 256, 3, 1, True, 1),    # 192 tiles of 256 rows: the 256x256 eight-phase kernel
+    (11, 64, 64, 256, 3, 1, False, 2),    # eight-phase kernel, 18 K-tiles, ragged last tile (45056 rows = 176 tiles)
+]
+
+
+def _ref64(x, w, sc, sh, res, k, stride, act):
+    y = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double(), stride=stride, padding=k // 2).permute(0, 2, 3, 1)
+    y = y * sc.double() + sh.double()
+    if res is not None:
+        y = y + res.double()
+    if act == 1:
+        y = y.clamp(min=0)
+    elif act == 2:
+        y = torch.where(y > 0, y, y * 0.1)
+    return y
+
+
+@pytest.mark.parametrize("case", H2_CASES)
+def test_conv_h2_has_fp32_accuracy(case):
+    from rdpn6d_amd import _lib, ops
+    import ctypes
+
+    dev = torch.device("cuda:0")
+    B, H, Cin, Cout, k, stride, use_res, act = case
+    g = torch.Generator().manual_seed(sum(case) * 7 + 1)
+    x = torch.randn(B, H, H, Cin, generator=g)
+    x[0, 0, 0, :8] = torch.tensor([1e-3, 1e-4, 1e-5, 1e-6, 1e-7, 3e-8, 2000.0, -4000.0])  # small magnitudes (lo subnormal) and the top of the range
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    sc, sh = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g)
+    Ho = (H + 2 * (k // 2) - k) // stride + 1
+    res = torch.randn(B, Ho, Ho, Cout, generator=g) if use_res else None
+    y64 = _ref64(x, w, sc, sh, res, k, stride, act)
+    kw = dict(stride=stride, pad=k // 2, act=act, slope=0.1)
+    xd, wd, scd, shd = x.to(dev), w.to(dev), sc.to(dev), sh.to(dev)
+    resd = res.to(dev) if use_res else None
+    y32 = ops.conv2d_nhwc(xd, wd, scd, shd, residual=resd, **kw)
+    yh, ((h2, shape), flag) = ops.conv2d_nhwc_h2(xd, wd, scd, shd, residual=resd, want_h2=Cout % 32 == 0, **kw) if Cout % 32 == 0 else (
+        ops.conv2d_nhwc_h2(xd, wd, scd, shd, residual=resd, **kw), ((None, None), None))
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 0
+    if use_res:  # the residual handed over as an h2 tensor (what chained trunk layers do): the same up to its 22-bit form
+        yr = ops.conv2d_nhwc_h2(xd, wd, scd, shd, residual_h2=(ops.split_h2(resd)[0], tuple(resd.shape)), **kw)
+        torch.cuda.synchronize()
+        assert (yr - yh).abs().max().item() <= 2.0 ** -21 * resd.abs().max().item() + 2.0 ** -22 * y64.abs().max().item()  # (+ one ulp of the sum)
+    e32, eh = (y32.cpu().double() - y64).abs(), (yh.cpu().double() - y64).abs()
+    scale = y64.abs().max().item()
+    print(f"{case}: max err vs fp64  fp32-MFMA {e32.max().item():.3e}  h2 {eh.max().item():.3e}  "
+          f"(rms {e32.pow(2).mean().sqrt().item():.2e} / {eh.pow(2).mean().sqrt().item():.2e}, |y|max {scale:.2f})")
+    assert eh.max().item() <= 1.25 * e32.max().item() + 1e-7 * scale
+    assert eh.pow(2).mean().sqrt().item() <= 1.1 * e32.pow(2).mean().sqrt().item() + 1e-8 * scale
+    # the h2 record of the output re-assembles the fp32 output to 2^-22, and feeding it to the next layer equals feeding the fp32 tensor
+    back = ops.merge_h2(h2, shape)
+    assert (back - yh).abs().max().item() <= 2.0 ** -21 * scale
+    if k == 3 and stride == 1 and B * H * H <= 20000:
+        w2 = (torch.randn(256, Cout, 3, 3, generator=g) / (Cout * 9) ** 0.5).to(dev)
+        a1 = ops.conv2d_nhwc_h2(yh, w2, pad=1)
+        a2 = ops.conv2d_nhwc_h2((h2, shape), w2, pad=1)
+        torch.cuda.synchronize()
+        assert torch.equal(a1, a2)
+    d = _lib.ConvDesc()
+    d.B, d.H, d.W, d.Cin, d.in_cs, d.Ho, d.Wo, d.stride, d.ntaps, d.N, d.Npad, d.out_cs = B, H, H, Cin, Cin, Ho, Ho, stride, k * k, Cout, (Cout + 63) // 64 * 64, Cout
+    which = _lib.load().rdpn6d_conv_h2_kernel_for(ctypes.byref(d))
+    assert which == (2 if B in (11, 12) else 1), which  # the two big cases run on the eight-phase kernel
+
+
+def test_conv_h2_error_bound_under_cancellation():
+    """fp32-class error BOUND: products that cancel almost completely (operands in +/- pairs plus a tiny signal, magnitudes
+    spread over 2^-10 .. 2^9 - the h2 activation range ends at 4094): |err| <= c * 2^-24 * sum|a||b| with c no larger than the
+    fp32-MFMA kernel's fmaf chain, on the eight-phase kernel (B = 40: 160 tiles) and on the tile kernel."""
+    from rdpn6d_amd import ops
+
+    dev = torch.device("cuda:0")
+    for B in (2, 40):
+        g = torch.Generator().manual_seed(99 + B)
+        H, C, N = 32, 256, 256
+        mag = torch.exp2(torch.randint(-10, 10, (B, H, H, C // 2), generator=g).float())
+        half = (torch.randn(B, H, H, C // 2, generator=g) * mag).clamp(-4000, 4000)
+        x = torch.cat([half, half], dim=-1)
+        wh = torch.randn(N, C // 2, 3, 3, generator=g) / 48.0
+        w = torch.cat([wh, -wh], dim=1) + torch.randn(N, C, 3, 3, generator=g) * 1e-6
+        y64 = torch.nn.functional.conv2d(x.double().permute(0, 3, 1, 2), w.double(), padding=1).permute(0, 2, 3, 1)
+        bound = torch.nn.functional.conv2d(x.double().abs().permute(0, 3, 1, 2), w.double().abs(), padding=1).permute(0, 2, 3, 1) * 2.0 ** -24
+        yh = ops.conv2d_nhwc_h2(x.to(dev), w.to(dev), pad=1).cpu().double()
+        y1 = ops.conv2d_nhwc(x.to(dev), w.to(dev), pad=1).cpu().double()
+        rh, r1 = ((yh - y64).abs() / bound).max().item(), ((y1 - y64).abs() / bound).max().item()
+        print(f"cancellation test B={B}: |err| / (2^-24 sum|a||b|): h2 {rh:.3f}  fp32-MFMA {r1:.3f}")
+        assert rh <= 1.25 * r1 and rh <= 48.0
+        assert y64.abs().max().item() < 1e-2 * bound.max().item() * 2 ** 24
+
+
+def test_h2_range_is_guarded_not_silent():
+    """an activation beyond the fp16 range of the h2 format (|a| * 16 > 65504) is clamped and REPORTED, never an inf"""
+    from rdpn6d_amd import ops
+
+    dev = torch.device("cuda:0")
+    x = torch.ones(1, 8, 8, 32, device=dev)
+    x[0, 1, 1, 3] = 5000.0
+    h2, flag = ops.split_h2(x)
+    torch.cuda.synchronize()
+    assert int(flag.item()) == 1 and torch.isfinite(h2.float()).all()
+    w = torch.full((64, 32, 1, 1), 100.0, device=dev)
+    y, ((yh, _), flag2) = ops.conv2d_nhwc_h2(torch.ones(1, 8, 8, 32, device=dev) * 10, w, want_h2=True)  # outputs 32000 > 4094
+    torch.cuda.synchronize()
+    assert int(flag2.item()) == 1 and torch.isfinite(yh.float()).all() and abs(y[0, 0, 0, 0].item() - 32000.0) < 1.0
+    _, f3 = ops.split_h2(torch.randn(2, 4, 4, 64, device=dev) * 100)
+    assert int(f3.item()) == 0
