@@ -36,7 +36,7 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak F
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (same guide; never the 2:1-sparsity figure)
 
 
-def build_model(device, mask_attention="none", bf16=False, graph=False, x3=True):
+def build_model(device, mask_attention="none", bf16=False, graph=False, x3=True, fast="h2"):
     from rdpn6d_amd import synth
     from rdpn6d_amd.config import gdrn_base_cfg
     from rdpn6d_amd.gdrn import build_model_optimizer
@@ -45,7 +45,10 @@ def build_model(device, mask_attention="none", bf16=False, graph=False, x3=True)
     cfg.TEST.USE_PNP = True  # the step includes the per-crop RANSAC/Kabsch solve ("fwd+PnP")
     cfg.TEST.AMP_TEST = bool(bf16)  # secondary mode: trunk + fusion + head on the bf16 matrix pipe
     cfg.TEST.HIP_GRAPH = bool(graph)  # the ~90 launches of a step replay as one hipGraph (same kernels, same order)
-    cfg.TEST.BF16X3 = bool(x3)  # fp32 mode: wide head layers as exact-product bf16x3 convolutions (fp32 accuracy)
+    # fp32 mode: which fp32-ACCURATE form the wide layers take on the 16-bit matrix pipe: "h2" two fp16 planes / 3 partial
+    # products (default), "x3" three bf16 planes / 6 partial products, "none" = every layer on the fp32 MFMA pipe
+    cfg.TEST.BF16X3 = bool(x3) and fast in ("h2", "x3")  # master switch
+    cfg.TEST.FP16X2 = fast == "h2"
     model, _ = build_model_optimizer(cfg)
     sd = synth.make_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=1234)
     bn = np.load(os.path.join(ROOT, "tests", "golden", "bn_stats_c1.npz"))
@@ -75,7 +78,9 @@ def roofline(model, t, B, device, reps=3):
     classes = {}  # tile -> launches of the conv kernel instance with that tile (bf16: the 64-channel K-chunk variants)
     lowp_fn = lib.rdpn6d_conv2d_bf16
     for L in plan.launches:
-        if L.keep and L.fn in (lib.rdpn6d_conv2d_bf16x3, lib.rdpn6d_conv2d_bf16x3_ex):
+        if L.keep and L.fn is lib.rdpn6d_conv2d_h2:
+            classes.setdefault("h2" if lib.rdpn6d_conv_h2_kernel_for(ctypes.byref(L.keep[0])) == 2 else "h2tile", []).append(L)
+        elif L.keep and L.fn in (lib.rdpn6d_conv2d_bf16x3, lib.rdpn6d_conv2d_bf16x3_ex):
             # 256x256 8-phase kernel ("x3") or the 128x128..64x64 tile kernel ("x3tile")
             classes.setdefault("x3" if lib.rdpn6d_conv_bf16x3_kernel_for(ctypes.byref(L.keep[0])) == 2 else "x3tile", []).append(L)
         elif L.keep and L.fn in (lowp_fn, lib.rdpn6d_conv2d_f32) and (L.fn is lowp_fn) == plan.bf16:
@@ -111,7 +116,12 @@ def roofline(model, t, B, device, reps=3):
     avg_ms = total_ms / max(n, 1)
     achieved = flops / len(sel) / (avg_ms * 1e-3) / 1e12 if sel else 0.0
     extra = {}
-    if tile in ("x3", "x3tile"):
+    if tile in ("h2", "h2tile"):
+        # fp32-accurate products as three fp16 partial products: the ceiling for ALGORITHMIC flops is the fp16 pipe / 3
+        kname, peak = ("conv_h2_8ph_kernel" if tile == "h2" else "conv_h2_tile_kernel"), round(BF16_MFMA_PEAK_TFLOPS / 3.0, 1)
+        extra = {"peak_note": "2500 TFLOP/s dense fp16 MFMA / 3 partial products per fp32 product (157.3 on the fp32 MFMA pipe)",
+                 "mfma_tflops_issued": round(3.0 * achieved, 1)}
+    elif tile in ("x3", "x3tile"):
         # fp32-accurate products as six bf16 partial products: the ceiling for ALGORITHMIC flops is the bf16 pipe / 6
         kname, peak = ("conv_igemm_bf16x3_kernel" if tile == "x3" else "conv_x3_tile_kernel"), round(BF16_MFMA_PEAK_TFLOPS / 6.0, 1)
         extra = {"peak_note": "2500 TFLOP/s dense bf16 MFMA / 6 partial products per fp32 product (157.3 on the fp32 MFMA pipe)",
@@ -291,7 +301,10 @@ def main():
     ap.add_argument("--mask-attention", default="none", choices=["none", "mul"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-x3", action="store_true",
-                    help="fp32 mode: keep every convolution on the fp32 MFMA pipe (cfg.TEST.BF16X3 = False)")
+                    help="fp32 mode: keep every convolution on the fp32 MFMA pipe (= --fast none)")
+    ap.add_argument("--fast", default="h2", choices=["h2", "x3", "none"],
+                    help="fp32 mode: fp32-accurate form of the wide layers on the 16-bit matrix pipe: h2 = two fp16 planes, 3 partial "
+                         "products (cfg.TEST.FP16X2, default) | x3 = three bf16 planes, 6 partial products (cfg.TEST.BF16X3) | none")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as one hipGraph instead of launching kernel by kernel (measured: no gain, the "
                          "launch queue already runs ahead of the GPU - 2776 vs 2779 crops/s fp32, 10729 vs 10820 bf16)")
@@ -329,7 +342,7 @@ def main():
 
     if args.train:
         return train_bench(args, rank, world, device, dist)
-    model, sd = build_model(device, args.mask_attention, bf16=args.dtype == "bf16", graph=args.graph, x3=not args.no_x3)
+    model, sd = build_model(device, args.mask_attention, bf16=args.dtype == "bf16", graph=args.graph, x3=not args.no_x3 and args.fast != "none", fast=args.fast)
     B = args.batch
     t = {k: torch.from_numpy(v).to(device) for k, v in synth.make_inputs(B, seed=100 + rank).items()}
 
@@ -368,9 +381,15 @@ def main():
     roof, cpu = None, None
     dtype_label, dtype_note = args.dtype, None
     if args.dtype == "f32" and model.plan(B, device).x3_launches:
-        dtype_note = ("fp32 storage, accumulation and accuracy; the head and the ResNet trunk evaluate every fp32 product exactly as "
-                      "six bf16 partial products on the bf16 MFMA pipe (bf16x3, DESIGN.md section 2: error vs fp64 no larger than the "
-                      "fp32 MFMA kernel's, tested); fp32 MFMA elsewhere; --no-x3 keeps every layer on the fp32 MFMA pipe")
+        if model.plan(B, device).fast == "h2":
+            dtype_note = ("fp32 accumulation and accuracy; the head and the ResNet trunk hold every operand as two fp16 terms (22 bits) and "
+                          "evaluate a product as three exact partial products on the fp16 MFMA pipe (h2, DESIGN.md section 2: error vs fp64 "
+                          "BELOW the fp32 MFMA kernel's on every tested shape, incl. the a-priori bound under cancellation); fp32 MFMA "
+                          "elsewhere; --fast x3 = three bf16 planes / six products, --fast none = every layer on the fp32 MFMA pipe")
+        else:
+            dtype_note = ("fp32 storage, accumulation and accuracy; the head and the ResNet trunk evaluate every fp32 product exactly as "
+                          "six bf16 partial products on the bf16 MFMA pipe (bf16x3, DESIGN.md section 2: error vs fp64 no larger than the "
+                          "fp32 MFMA kernel's, tested); fp32 MFMA elsewhere; --no-x3 keeps every layer on the fp32 MFMA pipe")
     if rank == 0:
         with torch.no_grad():
             roof = roofline(model, t, B, device)

@@ -272,8 +272,16 @@ class InferencePlan:
             raise ValueError(f"MASK_ATTENTION={self.mask_attention!r} is not implemented (none | mul)")
         # fp32 mode: the wide head layers run as exact-product bf16x3 convolutions on the bf16 matrix pipe (fp32 accuracy,
         # csrc/conv_igemm_bf16x3.hip) when the batch fills the chip; cfg.TEST.BF16X3 = False keeps them on the fp32 MFMA.
-        self.x3 = (not self.bf16) and bool(cfg.get("TEST", {}).get("BF16X3", True))
+        # cfg.TEST.FP16X2 (default on) picks the two-plane fp16 form of the same idea (csrc/conv_igemm_h2.hip: three partial
+        # products instead of six, measured error vs fp64 below the fp32-MFMA kernel's); with it off the three-plane bf16 form runs.
+        tcfg = cfg.get("TEST", {})
+        # (cfg.TEST.BF16X3 = False is the master switch: every layer on the fp32 MFMA pipe)
+        self.fast = None if (self.bf16 or not tcfg.get("BF16X3", True)) else ("h2" if tcfg.get("FP16X2", True) else "x3")
+        self.x3 = self.fast is not None  # "the wide layers leave the fp32 MFMA pipe" (name kept from the bf16x3-only days)
         self.x3_launches = 0
+        self.h2_flag = torch.zeros(1, dtype=torch.int32, device=device)  # set by a kernel that had to clamp to the fp16 range
+        self._flag_host = torch.zeros(1, dtype=torch.int32).pin_memory() if self.fast == "h2" else None
+        self._flag_event = None
         self._build(model)
 
     # ---- buffers
@@ -329,9 +337,10 @@ class InferencePlan:
     def x3_ok(self, M, N, cin, ntaps):
         """use the bf16x3 kernel for a conv with M output rows?  One 256x256 tile per CU and round: it pays (1.66x per
         tile-round against the fp32-MFMA kernel) when the last round is not mostly empty."""
-        if not self.x3 or N % 256 or cin % 16 or (ntaps * (cin // 16)) % 2:
+        kc = 32 if self.fast == "h2" else 16  # channels per K-tile of the 256x256 kernel
+        if not self.x3 or N % 256 or cin % kc or (ntaps * (cin // kc)) % 2:
             return False
-        if 6 * M * max(N, cin) >= (1 << 32) - 64:  # three bf16 planes behind one 32-bit buffer descriptor
+        if self._fast_bytes(M, max(N, cin)) >= (1 << 32) - 64:  # the planes sit behind one 32-bit buffer descriptor
             self._x3_limit_warning(M, max(N, cin))
             return False
         tiles = ((M + 255) // 256) * (N // 256)
@@ -341,9 +350,19 @@ class InferencePlan:
     def x3_tile_ok(self, M, N, cin):
         """the bf16x3 tile kernel (128x128 .. 64x64) for a layer too small for the 256x256 one: 1.35-1.45x the fp32-MFMA
         kernel from two crops on (head layer: 73 vs 105 us at B=2, 123 vs 190 at B=4, 264 vs 354 at B=8)"""
-        if self.x3 and N % 64 == 0 and cin % 32 == 0 and M >= 8192 and 6 * M * max(N, cin) >= (1 << 32) - 64:
+        if self.x3 and N % 64 == 0 and cin % 32 == 0 and M >= 8192 and self._fast_bytes(M, max(N, cin)) >= (1 << 32) - 64:
             self._x3_limit_warning(M, max(N, cin))
-        return self.x3 and N % 64 == 0 and cin % 32 == 0 and M >= 8192 and 6 * M * max(N, cin) < (1 << 32) - 64
+        return self.x3 and N % 64 == 0 and cin % 32 == 0 and M >= 8192 and self._fast_bytes(M, max(N, cin)) < (1 << 32) - 64
+
+    def _fast_bytes(self, M, C):
+        """bytes of an M x C activation in the fast path's plane format: 2 x fp16 (h2) or 3 x bf16 (bf16x3)"""
+        return (4 if self.fast == "h2" else 6) * M * C
+
+    def planes_buf(self, name, npix, C):
+        """activation buffer in the plane format of the fast path: h2 tensor [npix][C/32][2][32] fp16 | [3][npix*C] bf16"""
+        if self.fast == "h2":
+            return self.buf(name, npix * C * 2, dtype=torch.float16)
+        return self.buf(name, 3, npix * C, dtype=torch.bfloat16)
 
     def _x3_limit_warning(self, M, C):
         """a layer that WOULD run as a bf16x3 convolution stays on the fp32 MFMA pipe (~1.5x slower) because its three bf16 planes
@@ -352,13 +371,17 @@ class InferencePlan:
             self._x3_warned = True
             import warnings
 
-            warnings.warn(f"rdpn6d_amd: batch {self.B}: an activation of {M} x {C} elements needs {6 * M * C / 2**30:.1f} GiB as three bf16 "
-                          "planes (> 4 GiB buffer-descriptor range): those layers run on the fp32 MFMA kernel instead of bf16x3 "
+            warnings.warn(f"rdpn6d_amd: batch {self.B}: an activation of {M} x {C} elements needs {self._fast_bytes(M, C) / 2**30:.1f} GiB in "
+                          "plane form (> 4 GiB buffer-descriptor range): those layers run on the fp32 MFMA kernel instead "
                           "(about 1.5x slower per layer); split the batch (<= 256 crops per call at 256x256) to stay on the fast path",
                           RuntimeWarning, stacklevel=3)
 
     def split3(self, name, x, planes):
-        """launch: fp32 tensor -> its three bf16 planes ([3, plane_elems])"""
+        """launch: fp32 NHWC tensor -> its plane form (h2 tensor | three bf16 planes [3, plane_elems])"""
+        if self.fast == "h2":
+            C = x.shape[-1]
+            self.launches.append(_Launch(name, self.lib.rdpn6d_split_h2, (_ptr(x), C, 0, C, _ptr(planes), x.numel() // C, _ptr(self.h2_flag))))
+            return
         self.launches.append(_Launch(name, self.lib.rdpn6d_split_bf16x3, (_ptr(x), x.numel(), _ptr(planes), planes.shape[1])))
 
     def weight_planes(self, w32):
@@ -373,7 +396,11 @@ class InferencePlan:
                 slope=0.0, taps=None, phase=None, res_planes=None, res_cs=0):
         """bf16x3 convolution: xp = input planes [3, >= B*H*W*in_cs]; y fp32 output or None; yp output planes or None;
         res_planes = the residual as planes (output geometry, res_cs channels per pixel)."""
-        wp = self.weight_planes(w32)
+        if self.fast == "h2":
+            wp, inv = pack_h2_weight(w32.contiguous())
+            scale = inv if scale is None else (scale * inv).contiguous()  # 2^-(sw+4): exact
+        else:
+            wp = self.weight_planes(w32)
         d = _lib.ConvDesc()
         d.x, d.w, d.scale, d.shift, d.res, d.y = _ptr(xp), _ptr(wp), _ptr(scale), _ptr(shift), None, _ptr(y)
         d.B, d.H, d.W = self.B, xshape[0], xshape[1]
@@ -392,9 +419,14 @@ class InferencePlan:
             d.Ho, d.Wo, d.osy, d.osx, d.ooy, d.oox = phase
         d.out_cs, d.out_co, d.res_cs, d.res_co = out_cs, 0, res_cs, 0
         d.act, d.slope = act, slope
-        assert w32.shape[1] == d.ntaps and w32.shape[2] == cin and self.lib.rdpn6d_conv_bf16x3_eligible(ctypes.byref(d)), name
+        assert w32.shape[1] == d.ntaps and w32.shape[2] == cin, name
         self.keep += [wp, scale, shift]
         self.x3_launches += 1
+        if self.fast == "h2":
+            assert self.lib.rdpn6d_conv_h2_kernel_for(ctypes.byref(d)), name
+            self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_h2, (ctypes.byref(d), _ptr(yp), _ptr(res_planes), _ptr(self.h2_flag)), keep=(d,)))
+            return
+        assert self.lib.rdpn6d_conv_bf16x3_eligible(ctypes.byref(d)), name
         self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_bf16x3_ex,
                                      (ctypes.byref(d), xp.shape[1], wp.shape[1], _ptr(yp), yp.shape[1] if yp is not None else 0,
                                       _ptr(res_planes), res_planes.shape[1] if res_planes is not None else 0),
@@ -436,13 +468,13 @@ class InferencePlan:
         # csrc/conv_igemm_bf16x3_tile.hip) and hand their activations on as three bf16 planes; the residual is read from
         # planes as well (summed exactly), only the last block writes the fp32 tensor the up-sampling reads.
         wide = 256 if hasattr(bb.layer1[0], "conv3") else 64  # channels of the widest (layer1) activation
-        if self.x3 and 65536 <= B * R4 * R4 and 6 * B * R4 * R4 * wide >= (1 << 32) - 64:
+        if self.x3 and 65536 <= B * R4 * R4 and self._fast_bytes(B * R4 * R4, wide) >= (1 << 32) - 64:
             self._x3_limit_warning(B * R4 * R4, wide)
-        x3_trunk = self.x3 and 65536 <= B * R4 * R4 and 6 * B * R4 * R4 * wide < (1 << 32) - 64
+        x3_trunk = self.x3 and 65536 <= B * R4 * R4 and self._fast_bytes(B * R4 * R4, wide) < (1 << 32) - 64
         self.x3_trunk = x3_trunk
         pcur = None
         if x3_trunk:
-            pcur = self.buf("pool_planes", 3, p0.numel(), dtype=torch.bfloat16)
+            pcur = self.planes_buf("pool_planes", p0.numel(), 1)
             self.split3("trunk.split_pool", p0, pcur)
         for li in range(4):
             layer = getattr(bb, f"layer{li + 1}")
@@ -457,22 +489,22 @@ class InferencePlan:
                     npl = B * ohw * ohw * cout
                     res_p = pcur
                     if blk.downsample is not None:
-                        pds = self.buf(f"l{li}_ds_planes", 3, npl, dtype=torch.bfloat16)
+                        pds = self.planes_buf(f"l{li}_ds_planes", npl, 1)
                         wd = pack_conv_weight(blk.downsample[0].weight.detach().float())
                         scd, shd = fold_bn(blk.downsample[1], npad=wd.shape[0])
                         self.conv_x3(f"{nm}.downsample", pcur, (cur_hw, cur_hw), wd, scd, shd, None, pds, (ohw, ohw), cin=cur_c,
                                      in_cs=cur_c, k=1, stride=s, pad=0, N=cout, out_cs=cout, act=0)
                         res_p = pds
                     o = self.buf(f"l{li}_o{bi % 2}", B, ohw, ohw, cout) if last else None
-                    po = None if last else self.buf(f"l{li}_o{bi % 2}_planes", 3, npl, dtype=torch.bfloat16)
+                    po = None if last else self.planes_buf(f"l{li}_o{bi % 2}_planes", npl, 1)
                     w1 = pack_conv_weight(blk.conv1.weight.detach().float())
                     sc1, sh1 = fold_bn(blk.bn1, npad=w1.shape[0])
                     w2 = pack_conv_weight(blk.conv2.weight.detach().float())
                     sc2, sh2 = fold_bn(blk.bn2, npad=w2.shape[0])
                     if bottleneck:  # 1x1 - 3x3(s) - 1x1 (x4) + residual
                         width = blk.conv1.weight.shape[0]
-                        pt1 = self.buf(f"l{li}_ta{bi % 2}_planes", 3, B * cur_hw * cur_hw * width, dtype=torch.bfloat16)
-                        pt2 = self.buf(f"l{li}_tb{bi % 2}_planes", 3, B * ohw * ohw * width, dtype=torch.bfloat16)
+                        pt1 = self.planes_buf(f"l{li}_ta{bi % 2}_planes", B * cur_hw * cur_hw * width, 1)
+                        pt2 = self.planes_buf(f"l{li}_tb{bi % 2}_planes", B * ohw * ohw * width, 1)
                         self.conv_x3(f"{nm}.conv1", pcur, (cur_hw, cur_hw), w1, sc1, sh1, None, pt1, (cur_hw, cur_hw), cin=cur_c,
                                      in_cs=cur_c, k=1, N=width, out_cs=width, act=1)
                         self.conv_x3(f"{nm}.conv2", pt1, (cur_hw, cur_hw), w2, sc2, sh2, None, pt2, (ohw, ohw), cin=width, in_cs=width,
@@ -482,7 +514,7 @@ class InferencePlan:
                         self.conv_x3(f"{nm}.conv3", pt2, (ohw, ohw), w3, sc3, sh3, o, po, (ohw, ohw), cin=width, in_cs=width, k=1,
                                      N=cout, out_cs=cout, act=1, res_planes=res_p, res_cs=cout)
                     else:
-                        pt = self.buf(f"l{li}_t{bi % 2}_planes", 3, npl, dtype=torch.bfloat16)
+                        pt = self.planes_buf(f"l{li}_t{bi % 2}_planes", npl, 1)
                         self.conv_x3(f"{nm}.conv1", pcur, (cur_hw, cur_hw), w1, sc1, sh1, None, pt, (ohw, ohw), cin=cur_c, in_cs=cur_c,
                                      k=3, stride=s, pad=1, N=cout, out_cs=cout, act=1)
                         self.conv_x3(f"{nm}.conv2", pt, (ohw, ohw), w2, sc2, sh2, o, po, (ohw, ohw), cin=cout, in_cs=cout, k=3,
@@ -568,10 +600,10 @@ class InferencePlan:
                                                           self.x3_tile_ok(B * R4 * R4, F, F))  # the 3x3 layers of the head
         x3_ct = x3_head and self.x3_ok(B * R8 * R8, F, 1024, 1)      # ... and the ConvTranspose phases (a quarter of the rows)
         if x3_head:
-            pA = self.buf("head_planes_a", 3, B * R4 * R4 * F, dtype=torch.bfloat16)
-            pB = self.buf("head_planes_b", 3, B * R4 * R4 * F, dtype=torch.bfloat16)
+            pA = self.planes_buf("head_planes_a", B * R4 * R4 * F, 1)
+            pB = self.planes_buf("head_planes_b", B * R4 * R4 * F, 1)
         if x3_ct:
-            pF = self.buf("feat_planes", 3, feat.numel(), dtype=torch.bfloat16)
+            pF = self.planes_buf("feat_planes", feat.numel(), 1)
             self.split3("rot_head.split_feat", feat, pF)
         for py in (0, 1):
             for px in (0, 1):
@@ -696,6 +728,20 @@ class InferencePlan:
         _lib.check(lib.rdpn6d_pose_decode_f32(_ptr(self.rt), 16, _ptr(roi_cams), _ptr(roi_centers), _ptr(roi_whs),
                                               _ptr(resize_ratios), B, 1 if is_allo else 0, 1 if train_pose else 0,
                                               _ptr(self.rot), _ptr(self.trans), st), "pose_decode")
+        if self._flag_host is not None and not torch.cuda.is_current_stream_capturing():
+            # range flag of the h2 kernels -> pinned host memory, without stalling the launch queue; looked at by the next call
+            self._flag_host.copy_(self.h2_flag, non_blocking=True)
+            self._flag_event = torch.cuda.Event()
+            self._flag_event.record()
+
+    def range_exceeded(self, wait=False):
+        """did an h2 kernel of an EARLIER run have to clamp an activation to the fp16 range (|a| >= 4094)?  Non-blocking by
+        default (answers for the runs whose flag copy has completed); wait=True synchronises on the latest run."""
+        if self._flag_event is None:
+            return False
+        if wait:
+            self._flag_event.synchronize()
+        return bool(self._flag_event.query() and int(self._flag_host[0]) != 0)
 
     def run_graphed(self, key, launch):
         """Replay `launch()` (a closure issuing the whole step on the current stream) as one hipGraph.  The graph is
@@ -855,6 +901,17 @@ class GDRN(nn.Module):
                                        gt_mask_trunc, gt_mask_visib, gt_region, gt_ego_rot, gt_points, gt_trans, gt_trans_ratio,
                                        sym_infos)
         plan = self.plan(B, x.device)
+        if plan.range_exceeded():
+            # an activation left the range of the two-plane fp16 format in an earlier forward of this plan (that value was
+            # clamped, never an inf): fall back to the three-plane bf16 form, which has the fp32 exponent range, for good
+            import warnings
+
+            warnings.warn("rdpn6d_amd: an activation exceeded +-4094, the range of the fp16x2 (h2) convolution format; outputs of the "
+                          "previous forward were computed with that value clamped.  Switching this model to the bf16x3 kernels "
+                          "(cfg.TEST.FP16X2 = False).", RuntimeWarning, stacklevel=2)
+            self.cfg.TEST.FP16X2 = False
+            self.invalidate_plans()
+            plan = self.plan(B, x.device)
         if tuple(x.shape[1:]) != (6, plan.R, plan.R):
             raise ValueError(f"expected x of shape (B,6,{plan.R},{plan.R}), got {tuple(x.shape)}")
         if pcfg.TRANS_TYPE != "centroid_z" or pcfg.Z_TYPE != "REL":

@@ -1040,13 +1040,15 @@ def test_conv_bf16x3_has_fp32_accuracy(dev, case):
         assert torch.equal(a1, a2)
 
 
-def test_fp32_plan_uses_bf16x3_head_only_when_it_pays_and_matches_the_fp32_mfma_path(golden_setup, truth, dev):
-    """fp32 mode: from two crops on the head's 3x3 layers run as bf16x3 convolutions (cfg.TEST.BF16X3, default on: tile kernel
-    at small batches, 256x256 kernel when the batch fills the chip), from B = 16 on the ResNet trunk too; a single crop
-    stays on the fp32 MFMA pipe.  Both paths are fp32 evaluations of the same network: against the fp64 oracle the
-    bf16x3 path must be no further away than the fp32-MFMA path (x1.25 + noise floor), and close to it."""
+def test_fp32_plan_fast_forms_match_the_fp32_mfma_path(golden_setup, truth, dev):
+    """fp32 mode: from two crops on the head's 3x3 layers leave the fp32 MFMA pipe for an fp32-ACCURATE form on the 16-bit
+    pipe - h2 (two fp16 planes, cfg.TEST.FP16X2, default) or bf16x3 (three bf16 planes) - tile kernel at small batches,
+    256x256 kernel when the batch fills the chip, from B = 16 on the ResNet trunk too; a single crop stays on the fp32 MFMA
+    pipe, and cfg.TEST.BF16X3 = False keeps everything there.  All three are fp32 evaluations of the same network: against the
+    fp64 oracle each fast form must be no further away than the fp32-MFMA path (x1.25 + noise floor), and close to it."""
     models, t, gold = golden_setup
     model = models["mul"]
+    assert model.plan(4, dev).fast == "h2"
     assert model.plan(4, dev).x3_launches == 6 and not model.plan(4, dev).x3_trunk  # head on the tile kernel from 2 crops on
     assert model.plan(1, dev).x3_launches == 0
     rep = torch.arange(16, device=dev) % 4
@@ -1054,31 +1056,34 @@ def test_fp32_plan_uses_bf16x3_head_only_when_it_pays_and_matches_the_fp32_mfma_
     tcfg = model.cfg.TEST
     outs = {}
     try:
-        for x3 in (True, False):
-            tcfg.BF16X3 = x3
+        for mode in ("h2", "x3", "none"):
+            tcfg.BF16X3, tcfg.FP16X2 = mode != "none", mode == "h2"
             model._plans.clear()
             # head: six 3x3 layers (the ConvTranspose phases have a quarter of the rows: fp32 MFMA + a split pass at this
             # batch); trunk: 32 block convolutions + 3 down-sampling ones
             plan = model.plan(16, dev)
-            assert plan.x3_launches == (6 + 35 if x3 else 0) and plan.x3_trunk == x3
+            assert plan.fast == (None if mode == "none" else mode)
+            assert plan.x3_launches == (6 + 35 if mode != "none" else 0) and plan.x3_trunk == (mode != "none")
             o = _run(model, t16)
-            outs[x3] = {k: o[k].clone().cpu().double() for k in ("mask", "coor_x", "coor_y", "coor_z", "region", "rot", "trans")}
+            assert not plan.range_exceeded(wait=True)
+            outs[mode] = {k: o[k].clone().cpu().double() for k in ("mask", "coor_x", "coor_y", "coor_z", "region", "rot", "trans")}
     finally:
-        tcfg.BF16X3 = True
+        tcfg.BF16X3, tcfg.FP16X2 = True, True
         model._plans.clear()
-    for k in ("mask", "coor_x", "coor_y", "coor_z", "region"):
-        exact = truth["mul"][k].double()
-        e3 = (outs[True][k][:4] - exact).abs().max().item()
-        e1 = (outs[False][k][:4] - exact).abs().max().item()
-        dd = (outs[True][k] - outs[False][k]).abs().max().item()
-        print(f"{k}: vs fp64  bf16x3 path {e3:.3e}  fp32-MFMA path {e1:.3e}   between the two {dd:.3e}")
-        assert e3 <= 1.25 * e1 + 1e-5 and dd <= 2.0 * e1 + 1e-5, k
-    for k in ("rot", "trans"):
-        exact = truth["mul"][k].double()
-        e3 = max(_rel(outs[True][k][i].numpy(), exact[i].numpy()) for i in range(4))
-        e1 = max(_rel(outs[False][k][i].numpy(), exact[i].numpy()) for i in range(4))
-        print(f"{k}: worst rel err vs fp64  bf16x3 path {e3:.3e}  fp32-MFMA path {e1:.3e}")
-        assert e3 <= 2.0 * max(e1, 1e-4), k
+    for mode in ("h2", "x3"):
+        for k in ("mask", "coor_x", "coor_y", "coor_z", "region"):
+            exact = truth["mul"][k].double()
+            e3 = (outs[mode][k][:4] - exact).abs().max().item()
+            e1 = (outs["none"][k][:4] - exact).abs().max().item()
+            dd = (outs[mode][k] - outs["none"][k]).abs().max().item()
+            print(f"{k}: vs fp64  {mode} path {e3:.3e}  fp32-MFMA path {e1:.3e}   between the two {dd:.3e}")
+            assert e3 <= 1.25 * e1 + 1e-5 and dd <= 2.0 * e1 + 1e-5, (mode, k)
+        for k in ("rot", "trans"):
+            exact = truth["mul"][k].double()
+            e3 = max(_rel(outs[mode][k][i].numpy(), exact[i].numpy()) for i in range(4))
+            e1 = max(_rel(outs["none"][k][i].numpy(), exact[i].numpy()) for i in range(4))
+            print(f"{k}: worst rel err vs fp64  {mode} path {e3:.3e}  fp32-MFMA path {e1:.3e}")
+            assert e3 <= 2.0 * max(e1, 1e-4), (mode, k)
 
 
 def test_conv_bf16x3_error_bound_under_cancellation(dev):
