@@ -131,6 +131,13 @@ int rdpn6d_conv2d_bf16x3_ex(const rdpn6d_conv_desc* d, long long x_plane_elems, 
 int rdpn6d_split_h2(const float* x, int src_cs, int src_co, int C, void* dst, long long npix, int* overflow_flag, void* stream);
 int rdpn6d_conv_h2_kernel_for(const rdpn6d_conv_desc* d); /* 2 = 256x256 eight-phase, 1 = 128x128..64x64 tile kernel, 0 = not eligible */
 int rdpn6d_conv2d_h2(const rdpn6d_conv_desc* d, void* y_h2, const void* res_h2, int* overflow_flag, void* stream);
+/* h2 forms of the kernels between the h2 convolutions of the point-wise fusion branch (same argument meaning as the _f32 entry
+ * points; activations are h2 tensors, C / out_cs / out_co multiples of 32; the xyz subsample fills one whole 32-channel group
+ * [x y z 0 ...]; csrc/pointwise_h2.hip) */
+int rdpn6d_upsample_bilinear_h2(const void* x, int B, int H, int W, int C, int factor, void* y, int* overflow_flag, void* stream);
+int rdpn6d_xyz_subsample_h2(const float* x, int B, int xc, int R, int step, void* y, int out_cs, int out_co, int* overflow_flag,
+                            void* stream);
+int rdpn6d_global_max_concat_h2(void* buf, int B, int HW, int C, int cs, void* stream);
 void rdpn6d_conv_bf16_force_chunk(int row_bytes); /* profiling: 0 = auto, 64 forces 32-channel K-chunks (measured slower) */
 /* bf16 forms of the kernels between the bf16 convolutions (same argument meaning as the _f32 entry points; activations
  * bf16 NHWC with C % 8 == 0; the stem and the xyz subsample read the fp32 NCHW crop and write bf16) */

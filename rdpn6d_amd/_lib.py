@@ -117,6 +117,9 @@ SIGNATURES = {
     "rdpn6d_split_h2": (_i, [_vp, _i, _i, _i, _vp, _ll, _vp, _vp]),
     "rdpn6d_conv_h2_kernel_for": (_i, [_vp]),
     "rdpn6d_conv2d_h2": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "rdpn6d_upsample_bilinear_h2": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "rdpn6d_xyz_subsample_h2": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
+    "rdpn6d_global_max_concat_h2": (_i, [_vp, _i, _i, _i, _i, _vp]),
     "rdpn6d_select_correspondences_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 

@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librdpn6d_hip.so")
-SOURCES = ["api.cpp", "conv_igemm.hip", "conv_igemm_bf16.hip", "conv_igemm_bf16_8ph.hip", "conv_igemm_bf16x3.hip", "conv_igemm_bf16x3_tile.hip", "conv_igemm_h2.hip", "pointwise.hip", "pointwise_bf16.hip", "fps.hip", "ransac.hip", "train_norm.hip", "train_wgrad.hip", "train_misc.hip", "ranger.hip", "targets_eval.hip", "crop_builder.hip", "pnp.hip"]
+SOURCES = ["api.cpp", "conv_igemm.hip", "conv_igemm_bf16.hip", "conv_igemm_bf16_8ph.hip", "conv_igemm_bf16x3.hip", "conv_igemm_bf16x3_tile.hip", "conv_igemm_h2.hip", "pointwise.hip", "pointwise_bf16.hip", "pointwise_h2.hip", "fps.hip", "ransac.hip", "train_norm.hip", "train_wgrad.hip", "train_misc.hip", "ranger.hip", "targets_eval.hip", "crop_builder.hip", "pnp.hip"]
 NO_CONTRACT = {"fps.hip", "ransac.hip", "targets_eval.hip", "crop_builder.hip", "pnp.hip"}  # bit-exact integer outputs depend on un-fused fp32 arithmetic
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 if os.environ.get("RDPN6D_PROBE"):  # timing-only ablation variants of the kernels (tools/, never the shipped build)

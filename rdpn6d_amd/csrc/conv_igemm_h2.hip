@@ -391,13 +391,18 @@ __global__ __launch_bounds__(512) void conv_h2_8ph_kernel(const ConvH2Args ax)
 // ============================================================================================ 128x128 .. 64x64 tile kernel
 // conv_igemm_bf16.hip's two-stage form (2x2 wavefronts, LDS-DMA staging, one barrier per K-chunk, fragment double buffer,
 // two workgroups per CU) on 128-byte h2 rows: 6 MFMAs per 32x32 tile pair and chunk from 4 + 4 fragment reads.
-template <int BM, int BN>
+// NST = 3 (tiles up to 72 KiB of LDS, still two workgroups per CU): the DMA runs TWO chunks ahead and is never drained inside
+// the loop - a step ends with s_waitcnt vmcnt(<DMAs of one chunk>) + a raw s_barrier, so the loads of chunk k+3 stay in flight
+// across the barrier that publishes chunk k+2 (the L2 -> LDS round trip, ~1.5 us under load, is what bounds the 2-stage form:
+// a step's 12 - 24 MFMAs take 0.2 - 0.4 us).
+template <int BM, int BN, int NST>
 __global__ __launch_bounds__(256, 2) void conv_h2_tile_kernel(const ConvH2Args ax)
 {
-    constexpr int NW = 4, NST = 2, RB = 128;
+    constexpr int NW = 4, RB = 128;
     constexpr int RPP = 1024 / RB;  // 8 rows per 1-KiB DMA piece
     constexpr int TM = BM / 64, TN = BN / 64;
     constexpr int AG = BM / RPP / NW, BG = BN / RPP / NW;
+    constexpr int NDMA = AG + BG;  // LDS-DMA instructions per wave and chunk
     static_assert(TM >= 1 && TN >= 1 && AG >= 1 && BG >= 1, "tile / wave layout");
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     unsigned char* As = smem;
@@ -520,28 +525,72 @@ __global__ __launch_bounds__(256, 2) void conv_h2_tile_kernel(const ConvH2Args a
     };
 
     u32x4 fa0[TM][4], fb0[TN][4], fa1[TM][4], fb1[TN][4];
-    stage_chunk(ld_tap, ld_cc, 0);
-    next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
-    stage_chunk(ld_tap, ld_cc, 1);
-    next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
-    __syncthreads();
-    read_frags(0, fa0, fb0);
-    __syncthreads();  // stage 0 is re-filled by the first loop step: every wave must have its fragments first
-    const int npairs = nk >> 1;
-    for (int pr = 0; pr < npairs; ++pr) {
+    if constexpr (NST == 2) {
         stage_chunk(ld_tap, ld_cc, 0);
         next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
-        read_frags(1, fa1, fb1);
-        mma(fa0, fb0);
-        __syncthreads();
-
         stage_chunk(ld_tap, ld_cc, 1);
         next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
-        read_frags(0, fa0, fb0);
-        mma(fa1, fb1);
         __syncthreads();
+        read_frags(0, fa0, fb0);
+        __syncthreads();  // stage 0 is re-filled by the first loop step: every wave must have its fragments first
+        const int npairs = nk >> 1;
+        for (int pr = 0; pr < npairs; ++pr) {
+            stage_chunk(ld_tap, ld_cc, 0);
+            next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
+            read_frags(1, fa1, fb1);
+            mma(fa0, fb0);
+            __syncthreads();
+
+            stage_chunk(ld_tap, ld_cc, 1);
+            next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
+            read_frags(0, fa0, fb0);
+            mma(fa1, fb1);
+            __syncthreads();
+        }
+        if (nk & 1) mma(fa0, fb0);
+    } else {
+        // Invariant at the top of step kc: fragments of chunk kc in registers; stage (kc+1)%3 holds chunk kc+1, landed and
+        // published; chunk kc+2 is in flight into stage (kc+2)%3; stage kc%3 is free.  Step: DMA chunk kc+3 -> stage kc%3;
+        // LDS -> registers of chunk kc+1; MFMAs of chunk kc; wait until only this step's NDMA loads are outstanding and the
+        // fragment reads have returned; barrier (publishes chunk kc+2, frees stage (kc+1)%3).
+        auto publish = [&]() {
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NDMA) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        stage_chunk(ld_tap, ld_cc, 0);
+        next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
+        stage_chunk(ld_tap, ld_cc, 1);
+        next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
+        stage_chunk(ld_tap, ld_cc, 2);
+        next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        read_frags(0, fa0, fb0);
+        publish();
+        int st_free = 0, st_next = 1;
+        const int npairs = nk >> 1;
+        for (int pr = 0; pr < npairs; ++pr) {
+            stage_chunk(ld_tap, ld_cc, st_free);
+            next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
+            read_frags(st_next, fa1, fb1);
+            mma(fa0, fb0);
+            publish();
+            st_free = st_next;
+            st_next = st_next == 2 ? 0 : st_next + 1;
+
+            stage_chunk(ld_tap, ld_cc, st_free);
+            next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
+            read_frags(st_next, fa0, fb0);
+            mma(fa1, fb1);
+            publish();
+            st_free = st_next;
+            st_next = st_next == 2 ? 0 : st_next + 1;
+        }
+        if (nk & 1) mma(fa0, fb0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may still be landing in LDS when the epilogue re-uses it
     }
-    if (nk & 1) mma(fa0, fb0);
 
     {
         const int hi = lane >> 5;
@@ -579,14 +628,14 @@ __global__ __launch_bounds__(256, 2) void conv_h2_tile_kernel(const ConvH2Args a
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int NST>
 int launch_h2_tile(const ConvH2Args& ax, hipStream_t s)
 {
-    constexpr int lds_stage = 2 * (BM + BN) * 128;
+    constexpr int lds_stage = NST * (BM + BN) * 128;
     constexpr int lds_epi = 4 * 32 * (BN / 2 + 8) * 4;
     constexpr int lds = lds_stage > lds_epi ? lds_stage : lds_epi;
     static_assert(lds <= 80 * 1024, "two workgroups per CU");
-    auto kern = conv_h2_tile_kernel<BM, BN>;
+    auto kern = conv_h2_tile_kernel<BM, BN, NST>;
     if (lds > 64 * 1024) {
         static bool configured = false;
         if (!configured) {
@@ -725,10 +774,12 @@ extern "C" int rdpn6d_conv2d_h2(const rdpn6d_conv_desc* d, void* y_h2, const voi
         a.mtiles = rd_cdiv(a.M, bm);
         a.ntiles = d->Npad / bn;
         int rc;
-        if (bm == 128 && bn == 128) rc = launch_h2_tile<128, 128>(ax, s);
-        else if (bm == 128) rc = launch_h2_tile<128, 64>(ax, s);
-        else if (bn == 128) rc = launch_h2_tile<64, 128>(ax, s);
-        else rc = launch_h2_tile<64, 64>(ax, s);
+        static const int nst_env = getenv("RDPN6D_H2_NST") ? atoi(getenv("RDPN6D_H2_NST")) : 0;  // profiling: force 2 | 3 stages
+        const bool three = nst_env ? nst_env == 3 : true;  // three stages wherever two workgroups per CU still fit (<= 80 KiB)
+        if (bm == 128 && bn == 128) rc = launch_h2_tile<128, 128, 2>(ax, s);  // (96 KiB with three stages: one workgroup per CU)
+        else if (bm == 128) rc = three ? launch_h2_tile<128, 64, 3>(ax, s) : launch_h2_tile<128, 64, 2>(ax, s);
+        else if (bn == 128) rc = three ? launch_h2_tile<64, 128, 3>(ax, s) : launch_h2_tile<64, 128, 2>(ax, s);
+        else rc = three ? launch_h2_tile<64, 64, 3>(ax, s) : launch_h2_tile<64, 64, 2>(ax, s);
         if (rc != RDPN6D_OK) return rc;
         RD_LAUNCH_CHECK();
         return RDPN6D_OK;

@@ -472,6 +472,12 @@ class InferencePlan:
             self._x3_limit_warning(B * R4 * R4, wide)
         x3_trunk = self.x3 and 65536 <= B * R4 * R4 and self._fast_bytes(B * R4 * R4, wide) < (1 << 32) - 64
         self.x3_trunk = x3_trunk
+        # h2 mode with the trunk on it: the point-wise fusion branch, the ConvTranspose input and the 1x1 output convolution
+        # stay in the h2 format as well (csrc/pointwise_h2.hip) - no fp32 copy of those activations, no split passes
+        F_head = head.features[0].weight.shape[1]
+        h2_pw = (self.fast == "h2" and x3_trunk and len(head.features) > 4 and F_head % 64 == 0
+                 and self.x3_tile_ok(B * R8 * R8, F_head, 1024) and (512 * bb.expansion) % 32 == 0)
+        self.h2_pointwise = h2_pw
         pcur = None
         if x3_trunk:
             pcur = self.planes_buf("pool_planes", p0.numel(), 1)
@@ -485,7 +491,7 @@ class InferencePlan:
                 cout = (blk.conv3 if bottleneck else blk.conv2).weight.shape[0]
                 ohw = cur_hw // s
                 if x3_trunk:
-                    last = li == 3 and bi == len(layer) - 1
+                    last = li == 3 and bi == len(layer) - 1 and not h2_pw
                     npl = B * ohw * ohw * cout
                     res_p = pcur
                     if blk.downsample is not None:
@@ -560,34 +566,59 @@ class InferencePlan:
 
         # --- x4 bilinear up-sampling + point-wise fusion with the depth xyz
         C4 = cur_c  # layer4 channels: 512 (BasicBlock) | 2048 (Bottleneck)
-        up = self.buf("up", B, R8, R8, C4, dtype=adt)
-        self.call("upsample", getattr(lib, f"rdpn6d_upsample_bilinear_{sfx}"), _ptr(cur), B, cur_hw, cur_hw, C4,
-                  R8 // cur_hw, _ptr(up))
         sn = bb.spatial_net
-        pcs = 96 if lp else 80  # [emb(64) | xyz(3) | 0-pad] to the K-chunk granularity of the conv kernel
-        pin = self.buf("pn_in", B, R8, R8, pcs, zero=True, dtype=adt)
-        self.xyz_args = (B, 6, R, 8, _ptr(pin), pcs, 64)
-        we = pw(sn.xyz_emb.weight.detach().float())
-        sce, she = fold_bn(sn.xb, sn.xyz_emb.bias, npad=we.shape[0])
-        self.conv("spatial_net.xyz_emb", up, (R8, R8), we, sce, she, pin, (R8, R8), cin=C4, in_cs=C4, N=64, out_cs=pcs,
-                  act=1, lowp=lp)
         perm = list(range(3, 67)) + [0, 1, 2]  # reference order [xyz | emb] -> buffer order [emb | xyz]
-        wc1 = pw(sn.conv1.weight.detach().float(), cin_pad=pcs, perm=perm)
-        s1, h1 = fold_bn(sn.b1, sn.conv1.bias, npad=wc1.shape[0])
-        l1 = self.buf("pn_l1", B, R8, R8, 128, dtype=adt)
-        self.conv("spatial_net.conv1", pin, (R8, R8), wc1, s1, h1, l1, (R8, R8), cin=pcs, in_cs=pcs, N=128, out_cs=128,
-                  act=1, lowp=lp)
-        wc2 = pw(sn.conv2.weight.detach().float())
-        s2, h2 = fold_bn(sn.b2, sn.conv2.bias, npad=wc2.shape[0])
-        l2 = self.buf("pn_l2", B, R8, R8, 256, dtype=adt)
-        self.conv("spatial_net.conv2", l1, (R8, R8), wc2, s2, h2, l2, (R8, R8), cin=128, in_cs=128, N=256, out_cs=256,
-                  act=1, lowp=lp)
-        wc3 = pw(sn.conv3.weight.detach().float())
-        s3, h3 = fold_bn(sn.b3, sn.conv3.bias, npad=wc3.shape[0])
-        feat = self.buf("feat", B, R8, R8, 1024, dtype=adt)
-        self.conv("spatial_net.conv3", l2, (R8, R8), wc3, s3, h3, feat, (R8, R8), cin=256, in_cs=256, N=512, out_cs=1024,
-                  act=0, lowp=lp)
-        self.call("global_max_concat", getattr(lib, f"rdpn6d_global_max_concat_{sfx}"), _ptr(feat), B, R8 * R8, 512, 1024)
+        npx = B * R8 * R8
+        if h2_pw:
+            up = self.planes_buf("up_planes", npx * C4, 1)
+            self.call("upsample", lib.rdpn6d_upsample_bilinear_h2, _ptr(pcur), B, cur_hw, cur_hw, C4, R8 // cur_hw, _ptr(up), _ptr(self.h2_flag))
+            pcs = 96  # [emb(64) | xyz(3) + 0-pad: one 32-channel group]
+            pin = self.planes_buf("pn_in_planes", npx * pcs, 1)
+            self.xyz_fn = lib.rdpn6d_xyz_subsample_h2
+            self.xyz_args = (B, 6, R, 8, _ptr(pin), pcs, 64, _ptr(self.h2_flag))
+            we = pack_conv_weight(sn.xyz_emb.weight.detach().float())
+            sce, she = fold_bn(sn.xb, sn.xyz_emb.bias, npad=we.shape[0])
+            self.conv_x3("spatial_net.xyz_emb", up, (R8, R8), we, sce, she, None, pin, (R8, R8), cin=C4, in_cs=C4, N=64, out_cs=pcs, act=1)
+            wc1 = pack_conv_weight(sn.conv1.weight.detach().float(), cin_pad=pcs, perm=perm)
+            s1, h1 = fold_bn(sn.b1, sn.conv1.bias, npad=wc1.shape[0])
+            l1 = self.planes_buf("pn_l1_planes", npx * 128, 1)
+            self.conv_x3("spatial_net.conv1", pin, (R8, R8), wc1, s1, h1, None, l1, (R8, R8), cin=pcs, in_cs=pcs, N=128, out_cs=128, act=1)
+            wc2 = pack_conv_weight(sn.conv2.weight.detach().float())
+            s2, h2 = fold_bn(sn.b2, sn.conv2.bias, npad=wc2.shape[0])
+            l2 = self.planes_buf("pn_l2_planes", npx * 256, 1)
+            self.conv_x3("spatial_net.conv2", l1, (R8, R8), wc2, s2, h2, None, l2, (R8, R8), cin=128, in_cs=128, N=256, out_cs=256, act=1)
+            wc3 = pack_conv_weight(sn.conv3.weight.detach().float())
+            s3, h3 = fold_bn(sn.b3, sn.conv3.bias, npad=wc3.shape[0])
+            feat = self.planes_buf("feat_planes", npx * 1024, 1)
+            self.conv_x3("spatial_net.conv3", l2, (R8, R8), wc3, s3, h3, None, feat, (R8, R8), cin=256, in_cs=256, N=512, out_cs=1024, act=0)
+            self.call("global_max_concat", lib.rdpn6d_global_max_concat_h2, _ptr(feat), B, R8 * R8, 512, 1024)
+        else:
+            up = self.buf("up", B, R8, R8, C4, dtype=adt)
+            self.call("upsample", getattr(lib, f"rdpn6d_upsample_bilinear_{sfx}"), _ptr(cur), B, cur_hw, cur_hw, C4,
+                      R8 // cur_hw, _ptr(up))
+            pcs = 96 if lp else 80  # [emb(64) | xyz(3) | 0-pad] to the K-chunk granularity of the conv kernel
+            pin = self.buf("pn_in", B, R8, R8, pcs, zero=True, dtype=adt)
+            self.xyz_args = (B, 6, R, 8, _ptr(pin), pcs, 64)
+            we = pw(sn.xyz_emb.weight.detach().float())
+            sce, she = fold_bn(sn.xb, sn.xyz_emb.bias, npad=we.shape[0])
+            self.conv("spatial_net.xyz_emb", up, (R8, R8), we, sce, she, pin, (R8, R8), cin=C4, in_cs=C4, N=64, out_cs=pcs,
+                      act=1, lowp=lp)
+            wc1 = pw(sn.conv1.weight.detach().float(), cin_pad=pcs, perm=perm)
+            s1, h1 = fold_bn(sn.b1, sn.conv1.bias, npad=wc1.shape[0])
+            l1 = self.buf("pn_l1", B, R8, R8, 128, dtype=adt)
+            self.conv("spatial_net.conv1", pin, (R8, R8), wc1, s1, h1, l1, (R8, R8), cin=pcs, in_cs=pcs, N=128, out_cs=128,
+                      act=1, lowp=lp)
+            wc2 = pw(sn.conv2.weight.detach().float())
+            s2, h2 = fold_bn(sn.b2, sn.conv2.bias, npad=wc2.shape[0])
+            l2 = self.buf("pn_l2", B, R8, R8, 256, dtype=adt)
+            self.conv("spatial_net.conv2", l1, (R8, R8), wc2, s2, h2, l2, (R8, R8), cin=128, in_cs=128, N=256, out_cs=256,
+                      act=1, lowp=lp)
+            wc3 = pw(sn.conv3.weight.detach().float())
+            s3, h3 = fold_bn(sn.b3, sn.conv3.bias, npad=wc3.shape[0])
+            feat = self.buf("feat", B, R8, R8, 1024, dtype=adt)
+            self.conv("spatial_net.conv3", l2, (R8, R8), wc3, s3, h3, feat, (R8, R8), cin=256, in_cs=256, N=512, out_cs=1024,
+                      act=0, lowp=lp)
+            self.call("global_max_concat", getattr(lib, f"rdpn6d_global_max_concat_{sfx}"), _ptr(feat), B, R8 * R8, 512, 1024)
 
         # --- dense head: ConvTranspose(3, s2, p1, op1) as 4 sub-pixel phase convolutions
         F = head.features[0].weight.shape[1]
@@ -598,11 +629,13 @@ class InferencePlan:
         Fp = _pad_to(F, 64)
         x3_head = F == Fp and len(head.features) > 4 and (self.x3_ok(B * R4 * R4, F, F, 9) or
                                                           self.x3_tile_ok(B * R4 * R4, F, F))  # the 3x3 layers of the head
-        x3_ct = x3_head and self.x3_ok(B * R8 * R8, F, 1024, 1)      # ... and the ConvTranspose phases (a quarter of the rows)
+        x3_ct = x3_head and (h2_pw or self.x3_ok(B * R8 * R8, F, 1024, 1))  # ... and the ConvTranspose phases (a quarter of the rows)
         if x3_head:
             pA = self.planes_buf("head_planes_a", B * R4 * R4 * F, 1)
             pB = self.planes_buf("head_planes_b", B * R4 * R4 * F, 1)
-        if x3_ct:
+        if x3_ct and h2_pw:
+            pF = feat  # already an h2 tensor
+        elif x3_ct:
             pF = self.planes_buf("feat_planes", feat.numel(), 1)
             self.split3("rot_head.split_feat", feat, pF)
         for py in (0, 1):
@@ -632,7 +665,7 @@ class InferencePlan:
             if x3_head:  # planes -> planes; the last layer writes the fp32 tensor the 1x1 output convolution reads
                 w32 = pack_conv_weight(head.features[i].weight.detach().float())
                 sch, shh = fold_bn(head.features[i + 1], npad=w32.shape[0])
-                is_last = i == convs[-1]
+                is_last = i == convs[-1] and not h2_pw  # (h2 mode: the 1x1 output convolution reads the h2 tensor too)
                 self.conv_x3(f"rot_head.features.{i}", pa, (R4, R4), w32, sch, shh, b if is_last else None,
                              None if is_last else pb, (R4, R4), cin=F, in_cs=F, k=3, pad=1, N=F, out_cs=F, act=1)
                 pa, pb = pb, pa
@@ -649,8 +682,15 @@ class InferencePlan:
         wl = pw(last.weight.detach().float())
         bl = _pad_vec(last.bias.detach().float(), wl.shape[0], 0.0)
         ho = self.buf("head_out", B, R4 * R4, self.head_cs, zero=True)  # fp32 in both modes
-        self.conv("rot_head.out", a, (R4, R4), wl, None, bl, ho, (R4, R4), cin=F, in_cs=F, N=nout, out_cs=self.head_cs,
-                  lowp=lp, out_f32=True)
+        if h2_pw and x3_head and self.head_cs % 8 == 0:
+            # N = head_cs (the rows past nout have zero weights and bias: the padding channels stay 0)
+            self.conv_x3("rot_head.out", pa, (R4, R4), wl, None, bl, ho, None, (R4, R4), cin=F, in_cs=F, k=1, N=self.head_cs,
+                         out_cs=self.head_cs, act=0)
+        else:
+            if h2_pw:  # the last 3x3 layer wrote planes only
+                raise NotImplementedError("h2 point-wise mode needs a head output width that pads to a multiple of 8")
+            self.conv("rot_head.out", a, (R4, R4), wl, None, bl, ho, (R4, R4), cin=F, in_cs=F, N=nout, out_cs=self.head_cs,
+                      lowp=lp, out_f32=True)
 
         # --- glue -> NCHW API maps + ConvPnPNet input
         HW = R4 * R4
