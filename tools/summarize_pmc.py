@@ -19,14 +19,14 @@ for n in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES"):
 out = {}
 for k, v in agg.items():
     kk = k.replace("void ", "").replace("(anonymous namespace)::", "")
-    if not kk.startswith(("conv_igemm", "conv_x3", "split_bf16x3", "stem_", "maxpool", "global_max", "upsample", "dense_glue", "groupnorm", "ransac")):
+    if not kk.startswith(("conv_igemm", "conv_x3", "conv_h2", "split_h2", "_ZN12_GLOBAL__N_1", "split_bf16x3", "stem_", "maxpool", "global_max", "upsample", "dense_glue", "groupnorm", "ransac")):
         continue
     m = {c: s / n for c, (n, s, t) in v.items()}
     us = v["FETCH_SIZE"][2] / v["FETCH_SIZE"][0] / 1e3
     e = {"launches_profiled": v["FETCH_SIZE"][0], "avg_us": round(us, 1),
          "fetch_MB_raw": round(m["FETCH_SIZE"] * 1024 / 1e6, 1), "fetch_MB_x2": round(2 * m["FETCH_SIZE"] * 1024 / 1e6, 1),
          "write_MB": round(m["WRITE_SIZE"] * 1024 / 1e6, 1)}
-    mops = m.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0) + m.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0)
+    mops = m.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0) + m.get("SQ_INSTS_VALU_MFMA_MOPS_BF16", 0) + m.get("SQ_INSTS_VALU_MFMA_MOPS_F16", 0)
     if mops > 0:
         xcd_cycles = m["GRBM_GUI_ACTIVE"] / 8.0  # the counter is summed over the 8 XCDs
         e["mfma_gflop_issued"] = round(mops * 512 / 1e9, 2)
