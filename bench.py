@@ -43,7 +43,8 @@ def build_model(device, mask_attention="none", bf16=False, graph=False, x3=True,
 
     cfg = gdrn_base_cfg(mask_attention=mask_attention, device=str(device))
     cfg.TEST.USE_PNP = True  # the step includes the per-crop RANSAC/Kabsch solve ("fwd+PnP")
-    cfg.TEST.AMP_TEST = bool(bf16)  # secondary mode: trunk + fusion + head on the bf16 matrix pipe
+    cfg.TEST.AMP_TEST = bool(bf16)  # secondary mode: trunk + fusion + head on the 16-bit matrix pipe (bf16 | fp16)
+    cfg.TEST.AMP_DTYPE = bf16 if bf16 in ("bf16", "fp16") else "bf16"
     cfg.TEST.HIP_GRAPH = bool(graph)  # the ~90 launches of a step replay as one hipGraph (same kernels, same order)
     # fp32 mode: which fp32-ACCURATE form the wide layers take on the 16-bit matrix pipe: "h2" two fp16 planes / 3 partial
     # products (default), "x3" three bf16 planes / 6 partial products, "none" = every layer on the fp32 MFMA pipe
@@ -76,7 +77,7 @@ def roofline(model, t, B, device, reps=3):
     lib = plan.lib
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     classes = {}  # tile -> launches of the conv kernel instance with that tile (bf16: the 64-channel K-chunk variants)
-    lowp_fn = lib.rdpn6d_conv2d_bf16
+    lowp_fn = getattr(lib, f"rdpn6d_conv2d_{plan.lp or 'bf16'}")
     for L in plan.launches:
         if L.keep and L.fn is lib.rdpn6d_conv2d_h2:
             classes.setdefault("h2" if lib.rdpn6d_conv_h2_kernel_for(ctypes.byref(L.keep[0])) == 2 else "h2tile", []).append(L)
@@ -86,7 +87,7 @@ def roofline(model, t, B, device, reps=3):
         elif L.keep and L.fn in (lowp_fn, lib.rdpn6d_conv2d_f32) and (L.fn is lowp_fn) == plan.bf16:
             d = L.keep[0]
             bm, bn = ctypes.c_int(), ctypes.c_int()
-            (lib.rdpn6d_conv_bf16_tile_for if plan.bf16 else lib.rdpn6d_conv_tile_for)(ctypes.byref(d), ctypes.byref(bm), ctypes.byref(bn))
+            (getattr(lib, f"rdpn6d_conv_{plan.lp}_tile_for") if plan.bf16 else lib.rdpn6d_conv_tile_for)(ctypes.byref(d), ctypes.byref(bm), ctypes.byref(bn))
             if not plan.bf16 or d.Cin % 64 == 0:
                 classes.setdefault((bm.value, bn.value), []).append(L)
     # the dominant kernel = the instance that carries most of the step's FLOPs
@@ -236,9 +237,12 @@ def train_bench(args, rank, world, device, dist):
     B = args.batch if args.batch != 64 else 32
     model, _ = build_model(device, "mul")
     model.cfg.TEST.USE_PNP = False
-    amp = args.dtype == "bf16"
-    model.cfg.SOLVER.AMP.ENABLED = amp  # --dtype bf16: mixed precision (bf16 fwd/dgrad convolutions, fp32 everything else)
+    amp = args.dtype in ("bf16", "fp16")
+    model.cfg.SOLVER.AMP.ENABLED = amp  # --dtype bf16 | fp16: mixed precision (16-bit fwd/dgrad/wgrad convolutions, fp32 everything else)
+    model.cfg.SOLVER.AMP.DTYPE = args.dtype if amp else "bf16"
     eng = model.train_engine(B, device)
+    if args.dtype == "fp16":
+        eng.loss_scale = 4096.0  # static loss scale (the reference: GradScaler, engine.py:302-309)
     buckets = GradBuckets(model)
     order = [p for g in ("pnp_net", "rot_head_net", "backbone") for p in getattr(model, g).parameters()]
     opt = Ranger(order, lr=1e-4, flat_grad=buckets.flat)  # fused HIP step over the same flat gradient buffer
@@ -247,8 +251,12 @@ def train_bench(args, rank, world, device, dist):
 
     def one_step():
         losses = eng.forward_losses(batch)
+        if eng.loss_scale != 1.0:
+            eng.seed_backward({n: eng.loss_scale for n in eng.LOSS_NAMES})
         eng.backward(on_group_done=buckets.reduce)
         buckets.finish()
+        if eng.loss_scale != 1.0:
+            buckets.flat.mul_(1.0 / eng.loss_scale)
         opt.step()
         eng.refresh_weights()
         return losses
@@ -277,7 +285,7 @@ def train_bench(args, rank, world, device, dist):
             "metric": "RGB-D crops/sec, TRAINING step (fwd+losses+bwd+allreduce+Ranger) at 256x256", "value": round(value, 1),
             "unit": "crops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16 convolutions (fwd + dgrad + wgrad) and stored activations, fp32 BN math / losses / pose branch / optimizer" if amp else "f32",
+            "dtype": f"{args.dtype} convolutions (fwd + dgrad + wgrad) and stored activations, fp32 BN math / losses / pose branch / optimizer" if amp else "f32",
             "data": "synthetic",
             "config": {"workload": "LM-O style training step, MASK_ATTENTION=mul, K=32, ResNet-34, per-GPU BatchNorm, "
                                    + ("SOLVER.AMP.ENABLED" if amp else "fp32"),
@@ -308,7 +316,7 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as one hipGraph instead of launching kernel by kernel (measured: no gain, the "
                          "launch queue already runs ahead of the GPU - 2776 vs 2779 crops/s fp32, 10729 vs 10820 bf16)")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "fp16"],
                     help="f32 (default, the parity-bearing headline) | bf16: secondary line, cfg.TEST.AMP_TEST mode "
                          "(trunk + fusion + head on the bf16 matrix pipe, fp32 head output / ConvPnPNet / pose / RANSAC)")
     ap.add_argument("--train", action="store_true",
@@ -342,7 +350,7 @@ def main():
 
     if args.train:
         return train_bench(args, rank, world, device, dist)
-    model, sd = build_model(device, args.mask_attention, bf16=args.dtype == "bf16", graph=args.graph, x3=not args.no_x3 and args.fast != "none", fast=args.fast)
+    model, sd = build_model(device, args.mask_attention, bf16=args.dtype if args.dtype != "f32" else False, graph=args.graph, x3=not args.no_x3 and args.fast != "none", fast=args.fast)
     B = args.batch
     t = {k: torch.from_numpy(v).to(device) for k, v in synth.make_inputs(B, seed=100 + rank).items()}
 

@@ -392,6 +392,54 @@ int rdpn6d_crop_builder_f32(const unsigned char* images, const float* depths, in
                             const double* inv_in, const double* inv_out, const double* Knew, const double* ratio, int B, int R,
                             float* roi_img, float* roi_coord_2d, void* stream);
 
+
+/* ================================================================== IEEE fp16 twins of the 16-bit entry points
+ * The reference's mixed precision is torch.cuda.amp.autocast + GradScaler in FLOAT16 (core/gdrn_modeling/engine.py:279-309,
+ * main_gdrn.py:143 precision=16; gdrn_evaluator.py:625 for AMP_TEST).  Every rdpn6d_*_bf16 entry point above exists a second
+ * time as rdpn6d_*_fp16 with identical arguments: the same source compiled with the 16-bit storage format = IEEE half and
+ * v_mfma_f32_32x32x16_f16 (csrc/common.h, rdpn6d_amd/build.py).  rdpn6d_repack_fp16 = rdpn6d_repack_f32 writing fp16 mirrors.
+ * Selected by cfg.SOLVER.AMP.DTYPE / cfg.TEST.AMP_DTYPE = "fp16" (default "bf16"). */
+int rdpn6d_conv2d_fp16(const rdpn6d_conv_desc* d, int out_f32, void* stream);
+int rdpn6d_conv2d_splitk_fp16(const rdpn6d_conv_desc* d, int out_f32, int ksplit, float* workspace, void* stream);
+void rdpn6d_conv_fp16_force_tile(int bm, int bn);
+int rdpn6d_conv_fp16_tile_for(const rdpn6d_conv_desc* d, int* bm, int* bn);
+void rdpn6d_conv_fp16_force_chunk(int row_bytes);
+int rdpn6d_stem_conv7x7_fp16(const float* x, int B, int xc, int R, const float* w, const float* scale,
+                             const float* shift, void* y, void* stream);
+int rdpn6d_maxpool3x3s2_fp16(const void* x, int B, int H, int W, int C, void* y, void* stream);
+int rdpn6d_upsample_bilinear_fp16(const void* x, int B, int H, int W, int C, int factor, void* y, void* stream);
+int rdpn6d_xyz_subsample_fp16(const float* x, int B, int xc, int R, int step, void* y, int out_cs, int out_co,
+                              void* stream);
+int rdpn6d_global_max_concat_fp16(void* buf, int B, int HW, int C, int cs, void* stream);
+int rdpn6d_cast_f32_fp16(const float* src, int src_cs, int src_co, int C, void* dst, int dst_cs, long long npix,
+                         void* stream);
+int rdpn6d_wgrad_fp16(const void* A, int a_cs, int a_co, int Ca, int Ca_ld, const void* Bg, int b_cs, int b_co, int Cb,
+                      int Cb_ld, int Bn, int Ha, int Wa, int Hb, int Wb, int stride, int ntaps, const int* dy, const int* dx,
+                      float* out, float* partial, void* stream);
+int rdpn6d_wgrad_fp16_strided(const void* A, int a_cs, int a_co, int Ca, int Ca_ld, const void* Bg, int b_cs, int b_co, int Cb,
+                              int Cb_ld, int Bn, int Ha, int Wa, int Hb, int Wb, int stride, int ntaps, const int* dy,
+                              const int* dx, float* out, long long sa, long long st, long long sb, int Ca_out, int Cb_out,
+                              float* partial, void* stream);
+int rdpn6d_bn_train_stats_fp16(const void* x, long long M, int C, int cs, int co, float eps, float momentum, float* mean,
+                               float* invstd, float* running_mean, float* running_var, double* scratch, void* stream);
+int rdpn6d_bn_apply_fp16(const void* x, int xcs, int xco, const float* mean, const float* invstd, const float* gamma,
+                         const float* beta, const void* res, int rcs, int rco, void* y, int ycs, int yco, long long M, int C,
+                         int relu, void* stream);
+int rdpn6d_bn_backward_fp16(const void* x, int xcs, int xco, const void* dy, int dcs, int dco, const void* y, int ycs, int yco,
+                            const float* mean, const float* invstd, const float* gamma, float* dgamma, float* dbeta, void* dx,
+                            int xgcs, int xgco, void* dres, int rcs, int rco, long long M, int C, int relu, double* scratch,
+                            void* stream);
+int rdpn6d_channel_sum_fp16(const void* x, long long M, int C, int cs, int co, float* out, int accumulate, double* scratch,
+                            void* stream);
+int rdpn6d_maxpool3x3s2_backward_fp16(const void* x, const void* dy, int B, int H, int W, int C, void* dx, void* stream);
+int rdpn6d_upsample_bilinear_backward_fp16(const void* dy, int B, int H, int W, int C, int factor, void* dx, void* stream);
+int rdpn6d_global_max_concat_backward_fp16(const void* feat, const void* dfeat, int B, int HW, int C, int cs, void* dl3,
+                                           void* stream);
+int rdpn6d_stem_im2col_fp16(const float* x, int B, int xc, int R, void* out, void* stream);
+int rdpn6d_stem_conv7x7_raw_fp16(const float* x, int B, int xc, int R, const float* w, void* y, void* stream);
+int rdpn6d_repack_fp16(const rdpn6d_repack_desc* table_dev, const int* blk_desc_dev, const long long* blk_off_dev, int nblocks,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -123,6 +123,10 @@ SIGNATURES = {
     "rdpn6d_select_correspondences_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
+for _k in [k for k in list(SIGNATURES) if "_bf16" in k and "bf16x3" not in k]:  # the fp16 twins (include/rdpn6d.h, last section)
+    SIGNATURES[_k.replace("_bf16", "_fp16")] = SIGNATURES[_k]
+SIGNATURES["rdpn6d_repack_fp16"] = SIGNATURES["rdpn6d_repack_f32"]
+
 _lib = None
 
 

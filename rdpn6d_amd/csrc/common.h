@@ -38,13 +38,43 @@ static inline int rd_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// bf16 storage helpers (bf16 = the upper 16 bits of an fp32; conversion rounds to nearest even)
+// 16-bit storage helpers.  The "low-precision" kernels (conv_igemm_bf16*.hip, pointwise_bf16.hip, the 16-bit forms in
+// pointwise.hip / train_*.hip) are written once against these helpers and compiled TWICE (rdpn6d_amd/build.py):
+//   default            bf16 (the upper 16 bits of an fp32, round to nearest even)   -> entry points  rdpn6d_*_bf16
+//   -DRDPN6D_LP_FP16   IEEE fp16 (the reference's AMP dtype: torch.cuda.amp.autocast + GradScaler, engine.py:279-309)
+//                                                                                   -> entry points  rdpn6d_*_fp16
+// (the second set of objects is merged with `ld -r`, its rdpn6d_*_bf16 symbols are renamed and everything else is made local
+// with llvm-objcopy, so that the two builds of the same source never meet at link time).  The type name rd_bf16_t and the
+// helper names keep their bf16 spelling in both builds: they mean "the 16-bit storage format of this translation unit".
 typedef unsigned short rd_bf16_t;
 typedef unsigned rd_u32x4 __attribute__((ext_vector_type(4)));
+typedef float rd_f32x2 __attribute__((ext_vector_type(2)));
+#ifdef RDPN6D_LP_FP16
+typedef _Float16 rd_lp_hw __attribute__((ext_vector_type(1)));
+typedef _Float16 rd_lp_x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 rd_lp_x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned rd_f2bf_pk(float lo, float hi)
+{
+    const rd_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, rd_lp_x2));  // v_cvt_f16_f32 x2: round to nearest even
+}
+__device__ __forceinline__ rd_bf16_t rd_f2bf(float f) { return __builtin_bit_cast(rd_bf16_t, (_Float16)f); }
+__device__ __forceinline__ float rd_bf2f(rd_bf16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ void rd_unpack8(const rd_u32x4 p, float (&v)[8])
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const rd_f32x2 t = __builtin_convertvector(__builtin_bit_cast(rd_lp_x2, p[i]), rd_f32x2);
+        v[2 * i] = t[0];
+        v[2 * i + 1] = t[1];
+    }
+}
+#define RD_LP_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(rd_lp_x8, a), __builtin_bit_cast(rd_lp_x8, b), c, 0, 0, 0)
+#else
 // gfx950 converts in hardware (v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN) - one instruction per PAIR
 // instead of the ~7-instruction integer sequence per value
 typedef __bf16 rd_bf16x2_hw __attribute__((ext_vector_type(2)));
-typedef float rd_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 rd_lp_x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ unsigned rd_f2bf_pk(float lo, float hi)
 {
     const rd_f32x2 v = {lo, hi};
@@ -61,6 +91,8 @@ __device__ __forceinline__ void rd_unpack8(const rd_u32x4 p, float (&v)[8])
         v[2 * i + 1] = __uint_as_float(p[i] & 0xffff0000u);
     }
 }
+#define RD_LP_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(rd_lp_x8, a), __builtin_bit_cast(rd_lp_x8, b), c, 0, 0, 0)
+#endif
 __device__ __forceinline__ rd_u32x4 rd_pack8(const float (&v)[8])
 {
     rd_u32x4 p;
@@ -76,10 +108,16 @@ template <> __device__ __forceinline__ f32x4 rd_ld4<rd_bf16_t>(const rd_bf16_t* 
 {
     const uint2 u = *reinterpret_cast<const uint2*>(p);
     f32x4 v;
+#ifdef RDPN6D_LP_FP16
+    const rd_f32x2 a = __builtin_convertvector(__builtin_bit_cast(rd_lp_x2, u.x), rd_f32x2);
+    const rd_f32x2 b = __builtin_convertvector(__builtin_bit_cast(rd_lp_x2, u.y), rd_f32x2);
+    v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];
+#else
     v[0] = __uint_as_float(u.x << 16);
     v[1] = __uint_as_float(u.x & 0xffff0000u);
     v[2] = __uint_as_float(u.y << 16);
     v[3] = __uint_as_float(u.y & 0xffff0000u);
+#endif
     return v;
 }
 template <typename T> __device__ __forceinline__ void rd_st4(T* p, const f32x4 v);

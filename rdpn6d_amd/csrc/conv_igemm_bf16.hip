@@ -152,9 +152,7 @@ __global__ __launch_bounds__(64 * WM * WN, NST == 2 ? 2 : 1) void conv_igemm_bf1
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int jn = 0; jn < TN; ++jn)
-                    acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i][j]),
-                                                                         __builtin_bit_cast(bf16x8, fb[jn][j]),
-                                                                         acc[i][jn], 0, 0, 0);
+                    acc[i][jn] = RD_LP_MFMA_32x32x16(fa[i][j], fb[jn][j], acc[i][jn]);
     };
 
     u32x4 fa0[TM][NJ], fb0[TN][NJ], fa1[TM][NJ], fb1[TN][NJ];

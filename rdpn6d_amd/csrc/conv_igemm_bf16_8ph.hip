@@ -188,9 +188,7 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_8ph_kernel(const ConvBArg
         for (int j = decltype(j0c)::value; j < decltype(j1c)::value; ++j)
 #pragma unroll
             for (int i = 0; i < 2; ++i)
-                acc[qm * 2 + i][qn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i][j]),
-                                                                              __builtin_bit_cast(bf16x8, fb[j]),
-                                                                              acc[qm * 2 + i][qn], 0, 0, 0);
+                acc[qm * 2 + i][qn] = RD_LP_MFMA_32x32x16(fa[i][j], fb[j], acc[qm * 2 + i][qn]);
     };
 
     // K order: channel-chunk major, taps innermost (as conv_igemm_bf16.hip)

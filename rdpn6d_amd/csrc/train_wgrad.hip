@@ -399,8 +399,7 @@ __global__ __launch_bounds__(256, PL == 1 ? 3 : 2) void wgrad_bf16_kernel(const 
                     for (int j = 0; j < TB; ++j) {
                         const int fb = PB[pr] * NFP + TA * 2 * KS + (j * KS + s) * 2;
                         const s16x8 bv = __builtin_shufflevector(f[fb], f[fb + 1], 0, 1, 2, 3, 4, 5, 6, 7);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(rd_bf16x8, av),
-                                                                             __builtin_bit_cast(rd_bf16x8, bv), acc[i][j], 0, 0, 0);
+                        acc[i][j] = RD_LP_MFMA_32x32x16(av, bv, acc[i][j]);
                     }
                 }
     };

@@ -259,7 +259,13 @@ class InferencePlan:
         pipe with bf16 activations (the reference's autocast mode, gdrn_evaluator.py:625); the head output, the
         glue, ConvPnPNet, the pose decode and RANSAC stay fp32."""
         self.lib = _lib.load()
-        self.B, self.device, self.bf16 = B, device, bool(bf16)
+        # bf16: False | True / "bf16" | "fp16" - the 16-bit format of the reduced-precision mode (cfg.TEST.AMP_DTYPE; the
+        # reference's autocast is fp16: gdrn_evaluator.py:625).  self.bf16 keeps meaning "reduced-precision mode on".
+        self.lp = None if not bf16 else ("bf16" if bf16 is True else str(bf16))
+        if self.lp not in (None, "bf16", "fp16"):
+            raise ValueError(f"16-bit format {self.lp!r}: bf16 | fp16")
+        self.lp_dtype = torch.float16 if self.lp == "fp16" else torch.bfloat16
+        self.B, self.device, self.bf16 = B, device, self.lp is not None
         self.launches = []
         self._graphs = {}
         self.bufs = {}
@@ -323,13 +329,13 @@ class InferencePlan:
         if ks > 1:
             ws = self.buf("splitk_ws:" + name, int(self.lib.rdpn6d_conv_splitk_ws_floats(ctypes.byref(d), ks)))
             if lowp:
-                self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_splitk_bf16, (ctypes.byref(d), 1 if out_f32 else 0, ks, _ptr(ws)),
+                self.launches.append(_Launch(name, getattr(self.lib, f"rdpn6d_conv2d_splitk_{self.lp}"), (ctypes.byref(d), 1 if out_f32 else 0, ks, _ptr(ws)),
                                              keep=(d,)))
             else:
                 self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_splitk_f32, (ctypes.byref(d), ks, _ptr(ws)), keep=(d,)))
         elif lowp:
-            assert w.dtype == torch.bfloat16, name
-            self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_bf16, (ctypes.byref(d), 1 if out_f32 else 0), keep=(d,)))
+            assert w.dtype == self.lp_dtype, name
+            self.launches.append(_Launch(name, getattr(self.lib, f"rdpn6d_conv2d_{self.lp}"), (ctypes.byref(d), 1 if out_f32 else 0), keep=(d,)))
         else:
             assert w.dtype == torch.float32, name
             self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_f32, (ctypes.byref(d),), keep=(d,)))
@@ -441,12 +447,12 @@ class InferencePlan:
         bb, head, pnp = model.backbone, model.rot_head_net, model.pnp_net
         f32 = dict(dtype=torch.float32, device=self.device)
         lp = self.bf16
-        adt = torch.bfloat16 if lp else torch.float32  # activation dtype up to the head output
-        sfx = "bf16" if lp else "f32"
+        adt = self.lp_dtype if lp else torch.float32  # activation dtype up to the head output
+        sfx = self.lp if lp else "f32"
 
         def pw(w, **kw):
             t = pack_conv_weight(w, **kw)
-            return t.to(torch.bfloat16) if lp else t
+            return t.to(self.lp_dtype) if lp else t
 
         self.x_in = None  # bound per call
         R2, R4, R8, R16, R32 = R // 2, R // 4, R // 8, R // 16, R // 32
@@ -865,7 +871,8 @@ class GDRN(nn.Module):
     def train_engine(self, B, device):
         from .train import TrainEngine
 
-        amp = bool(self.cfg.get("SOLVER", {}).get("AMP", {}).get("ENABLED", False))  # common_base.py:130, engine.py:279
+        acfg = self.cfg.get("SOLVER", {}).get("AMP", {})
+        amp = bool(acfg.get("ENABLED", False)) and str(acfg.get("DTYPE", "bf16"))  # common_base.py:130, engine.py:279; False | "bf16" | "fp16"
         key = ("train", B, str(device), amp)
         if key not in self._plans:
             self._plans[key] = TrainEngine(self, B, device, amp=amp)
@@ -902,10 +909,14 @@ class GDRN(nn.Module):
         return v & 0xFFFFFFFFFFFF
 
     def plan(self, B, device, bf16=None):
-        """bf16=None follows cfg.TEST.AMP_TEST (the reference's autocast switch, gdrn_evaluator.py:625)."""
+        """bf16=None follows cfg.TEST.AMP_TEST (the reference's autocast switch, gdrn_evaluator.py:625) with the 16-bit format
+        cfg.TEST.AMP_DTYPE ("bf16" default | "fp16" = what torch.cuda.amp.autocast uses in the reference); or False | True |
+        "bf16" | "fp16" explicitly."""
         if bf16 is None:
             bf16 = bool(self.cfg.get("TEST", {}).get("AMP_TEST", False))
-        key = (B, str(device), bool(bf16))
+        if bf16 is True:
+            bf16 = str(self.cfg.get("TEST", {}).get("AMP_DTYPE", "bf16"))
+        key = (B, str(device), bf16 or False)
         stamp = self._weights_stamp()
         plan = self._plans.get(key)
         if plan is not None and plan.weights_stamp != stamp:

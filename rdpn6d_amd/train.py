@@ -39,9 +39,14 @@ class TrainEngine:
         makes.  bf16 keeps the fp32 exponent range, so no loss scaling is needed."""
         self.lib = _lib.load()
         self.model, self.B, self.dev = model, B, device
+        # amp: False | True / "bf16" | "fp16" (cfg.SOLVER.AMP.DTYPE; the reference's autocast + GradScaler run in fp16: loss
+        # scaling then comes from torch's GradScaler through the autograd node of GDRN.forward, or from `loss_scale` below)
         self.amp = bool(amp)
-        self.adt = torch.bfloat16 if self.amp else torch.float32  # storage type of trunk / head activations and gradients
-        self.sfx = "bf16" if self.amp else "f32"
+        self.lp = "fp16" if amp == "fp16" else "bf16"   # 16-bit storage format of the mixed-precision step
+        self.lp_dtype = torch.float16 if self.lp == "fp16" else torch.bfloat16
+        self.loss_scale = 1.0  # forward_backward() multiplies the backward seeds by it and divides the parameter gradients again
+        self.adt = self.lp_dtype if self.amp else torch.float32  # storage type of trunk / head activations and gradients
+        self.sfx = self.lp if self.amp else "f32"
         self._casts = {}     # (address, stride, offset, channels) of an fp32 activation slice -> its bf16 copy
         self.mirrors = []    # (bf16 tensor, fp32 packed weight) pairs refreshed with the weights
         self.mirrors3 = []   # (three bf16 planes, fp32 packed weight) pairs of the bf16x3 layers, re-split after every re-pack
@@ -96,6 +101,10 @@ class TrainEngine:
     def st(self):
         return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
+    def lpf(self, bf16_name):
+        """the entry point of the step's 16-bit format: rdpn6d_*_bf16 -> rdpn6d_*_fp16 under cfg.SOLVER.AMP.DTYPE = "fp16"""
+        return getattr(self.lib, bf16_name.replace("bf16", self.lp))
+
     def _grad(self, p):
         if p.grad is None:
             p.grad = torch.zeros_like(p)
@@ -129,11 +138,11 @@ class TrainEngine:
         key = (src.data_ptr(), src_cs, src_co, C)
         if cache and key in self._casts:
             return self._casts[key], Cp
-        t = torch.zeros(npix, Cp, dtype=torch.bfloat16, device=self.dev)
+        t = torch.zeros(npix, Cp, dtype=self.lp_dtype, device=self.dev)
         lib = self.lib
 
         def run():
-            _lib.check(lib.rdpn6d_cast_f32_bf16(_ptr(src), src_cs, src_co, C, _ptr(t), Cp, npix, self.st()), "cast bf16")
+            _lib.check(self.lpf("rdpn6d_cast_f32_bf16")(_ptr(src), src_cs, src_co, C, _ptr(t), Cp, npix, self.st()), "cast bf16")
 
         run.keep = (src, t)
         launches.append(run)
@@ -142,7 +151,7 @@ class TrainEngine:
         return t, Cp
 
     def _mirror(self, t):
-        tb = torch.zeros(*t.shape, dtype=torch.bfloat16, device=self.dev)
+        tb = torch.zeros(*t.shape, dtype=self.lp_dtype, device=self.dev)
         self.mirrors.append((tb, t))
         return tb
 
@@ -204,10 +213,10 @@ class TrainEngine:
                 wsb = self.buf("splitk_ws:" + name, int(lib.rdpn6d_conv_splitk_ws_floats(ctypes.byref(d), ksb)))
 
                 def run():
-                    _lib.check(lib.rdpn6d_conv2d_splitk_bf16(ctypes.byref(d), of, ksb, _ptr(wsb), self.st()), name)
+                    _lib.check(self.lpf("rdpn6d_conv2d_splitk_bf16")(ctypes.byref(d), of, ksb, _ptr(wsb), self.st()), name)
             else:
                 def run():
-                    _lib.check(lib.rdpn6d_conv2d_bf16(ctypes.byref(d), of, self.st()), name)
+                    _lib.check(self.lpf("rdpn6d_conv2d_bf16")(ctypes.byref(d), of, self.st()), name)
 
             run.keep = (d, keep)
             return run
@@ -278,7 +287,8 @@ class TrainEngine:
         every optimizer step.  The table is rebuilt only when a parameter's storage moved (e.g. an optimizer that re-homes
         the parameters into a flat buffer)."""
         self._repack_table()
-        _lib.check(self.lib.rdpn6d_repack_f32(_ptr(self._repack_dev), _ptr(self._repack_bd), _ptr(self._repack_bo),
+        repack = self.lib.rdpn6d_repack_fp16 if (self.amp and self.lp == "fp16") else self.lib.rdpn6d_repack_f32  # 16-bit mirrors
+        _lib.check(repack(_ptr(self._repack_dev), _ptr(self._repack_bd), _ptr(self._repack_bo),
                                               int(self._repack_bd.numel()), self.st()), "repack")
         for p3, t in self.mirrors3:
             _lib.check(self.lib.rdpn6d_split_bf16x3(_ptr(t), t.numel(), _ptr(p3), p3.shape[1], self.st()), "split weights")
@@ -305,7 +315,7 @@ class TrainEngine:
             bvec = self._pack_map((npad,), bias, 1, 1, cout, 0, 1, [0])
         taps = _taps(k, pad)
         if lowp:
-            if x.dtype == torch.bfloat16:  # stored in bf16: read in place (channels beyond cin_real inside the slice are zero)
+            if x.dtype == self.lp_dtype:  # stored in 16 bits: read in place (channels beyond cin_real inside the slice are zero)
                 assert in_cs % 8 == 0 and in_co % 8 == 0 and in_co + cin_pad <= in_cs, (name, in_cs, in_co, cin_pad)
                 xb, xb_cs, xb_co = x, in_cs, in_co
             else:
@@ -344,7 +354,7 @@ class TrainEngine:
         launches = []
         if lowp:
             n_red_b = _pad_to(cout, 32)
-            if dy.dtype == torch.bfloat16 and out_cs % 8 == 0 and out_co % 8 == 0 and out_co + n_red_b <= out_cs:
+            if dy.dtype == self.lp_dtype and out_cs % 8 == 0 and out_co % 8 == 0 and out_co + n_red_b <= out_cs:
                 dyb, dyb_cs, dyb_co = dy, out_cs, out_co      # stored in bf16: read in place
             else:  # fp32 gradient (the head output's): one compact bf16 copy for the wgrad and the dgrad
                 dyb, dyb_cs, dyb_co = self._bf16_of(launches, dy, out_cs, out_co, cout, M, cache=False)[0], n_red_b, 0
@@ -365,9 +375,9 @@ class TrainEngine:
                 args = (_ptr(dyb), dyb_cs, dyb_co, ca, min(_pad_to(cout, 8), dyb_cs - dyb_co), _ptr(xb), xb_cs, xb_co, cb,
                         min(_pad_to(cin_real, 8), xb_cs - xb_co), B, yhw[0], yhw[1], xhw[0], xhw[1], stride, k * k, tdy, tdx)
                 if direct:
-                    _lib.check(lib.rdpn6d_wgrad_bf16_strided(*args, *tgt, _ptr(self._wg_partial), self.st()), "wgrad " + name)
+                    _lib.check(self.lpf("rdpn6d_wgrad_bf16_strided")(*args, *tgt, _ptr(self._wg_partial), self.st()), "wgrad " + name)
                 else:
-                    _lib.check(lib.rdpn6d_wgrad_bf16(*args, _ptr(wg_out), _ptr(self._wg_partial), self.st()), "wgrad " + name)
+                    _lib.check(self.lpf("rdpn6d_wgrad_bf16")(*args, _ptr(wg_out), _ptr(self._wg_partial), self.st()), "wgrad " + name)
             elif x3_w:
                 _lib.check(lib.rdpn6d_wgrad_bf16x3_strided(_ptr(g3), g3.shape[1], out_cs, out_co, ca, cout, _ptr(xp3), xp3.shape[1], in_cs,
                                                            in_co, cb, cin_real, B, yhw[0], yhw[1], xhw[0], xhw[1], stride, k * k, tdy,
@@ -383,7 +393,7 @@ class TrainEngine:
                 g = wg_out[:cout, :, :cin_real].view(cout, k, k, cin_real).permute(0, 3, 1, 2)
                 gw.copy_(g[:, inv_perm])
             if bias is not None:
-                csum = lib.rdpn6d_channel_sum_bf16 if dy.dtype == torch.bfloat16 else lib.rdpn6d_channel_sum_f32
+                csum = self.lpf("rdpn6d_channel_sum_bf16") if dy.dtype == self.lp_dtype else lib.rdpn6d_channel_sum_f32
                 if cout % 4 == 0:
                     _lib.check(csum(_ptr(dy), M, ca, out_cs, out_co, _ptr(self._grad(bias)), 0, _ptr(self._scratch_d), self.st()),
                                "bias grad " + name)
@@ -456,7 +466,7 @@ class TrainEngine:
         mean, invstd = self.buf("mean:" + name, _pad_to(C, 4)), self.buf("istd:" + name, _pad_to(C, 4))
         ga, be = bn.weight, bn.bias  # read in place (C % 4 == 0); pointers are taken at launch time
 
-        t = "bf16" if x_raw.dtype == torch.bfloat16 else "f32"   # storage type of x_raw / y / res / dy / dx / dres alike
+        t = self.lp if x_raw.dtype == self.lp_dtype else "f32"   # storage type of x_raw / y / res / dy / dx / dres alike
         assert y.dtype == x_raw.dtype and (res is None or res.dtype == x_raw.dtype), name
         f_stats, f_apply, f_bwd = (getattr(lib, f"rdpn6d_bn_{n}_{t}") for n in ("train_stats", "apply", "backward"))
 
@@ -509,7 +519,7 @@ class TrainEngine:
             # dW(conv1)[n][ky][kx][c] = sum over output pixels of dY[p][n] * patch[p][(ky,kx,c)]: one pixel-reduction GEMM
             _lib.check(getattr(lib, f"rdpn6d_stem_im2col_{sfx}")(_ptr(self.x), B, 6, R, _ptr(xcol), self.st()), "stem im2col")
             if self.amp:
-                _lib.check(lib.rdpn6d_wgrad_bf16(_ptr(d_raw0), 64, 0, 64, 64, _ptr(xcol), 160, 0, 160, 160, B, R2, R2, R2, R2, 1, 1, z9, z9,
+                _lib.check(self.lpf("rdpn6d_wgrad_bf16")(_ptr(d_raw0), 64, 0, 64, 64, _ptr(xcol), 160, 0, 160, 160, B, R2, R2, R2, R2, 1, 1, z9, z9,
                                                  _ptr(wg_stem), _ptr(self._wg_partial), self.st()), "wgrad stem")
             else:
                 _lib.check(lib.rdpn6d_wgrad_f32(_ptr(d_raw0), 64, 0, 64, _ptr(xcol), 160, 0, 160, B, R2, R2, R2, R2, 1, 1, z9, z9,
@@ -681,7 +691,7 @@ class TrainEngine:
                                                            0, F, F, B, R8, R8, R4, R4, 2, 9, t9y, t9x, *tgt, _ptr(self._wg_partial),
                                                            self.st()), "wgrad convT")
             elif self.amp:
-                _lib.check(lib.rdpn6d_wgrad_bf16_strided(_ptr(featb), 1024, 0, 1024, 1024, _ptr(d_rt0b), F, 0, F, F, B, R8, R8, R4, R4, 2,
+                _lib.check(self.lpf("rdpn6d_wgrad_bf16_strided")(_ptr(featb), 1024, 0, 1024, 1024, _ptr(d_rt0b), F, 0, F, F, B, R8, R8, R4, R4, 2,
                                                          9, t9y, t9x, *tgt, _ptr(self._wg_partial), self.st()), "wgrad convT")
             else:
                 _lib.check(lib.rdpn6d_wgrad_f32_strided(_ptr(feat), 1024, 0, 1024, _ptr(d_rt0), F, 0, F, B, R8, R8, R4, R4, 2, 9, t9y,
@@ -925,6 +935,20 @@ class TrainEngine:
                 on_group_done(marks[idx])
 
     def forward_backward(self, batch):
+        """forward + losses + backward.  With `loss_scale` != 1 (fp16 storage of the activation gradients: the un-scaled seeds
+        1 / (B * HW) ~ 4e-6 are fp16 subnormals) the seeds are multiplied by it and the parameter gradients divided again -
+        what torch's GradScaler does around the reference's step (engine.py:302-309); non-finite gradients are left for the
+        caller's overflow check, as GradScaler.step would see them."""
         losses = self.forward_losses(batch)
+        S = float(self.loss_scale)
+        if S != 1.0:
+            self.seed_backward({n: S for n in self.LOSS_NAMES})
         self.backward()
+        if S != 1.0:
+            grads = [p.grad for p in self.model.parameters() if p.grad is not None]
+            base = {id(g._base) for g in grads if g._base is not None}
+            if len(base) == 1 and all(g._base is not None for g in grads):
+                grads[0]._base.mul_(1.0 / S)  # one flat buffer (GradBuckets / Ranger)
+            else:
+                torch._foreach_mul_(grads, 1.0 / S)
         return losses

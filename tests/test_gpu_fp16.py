@@ -1,0 +1,232 @@
+"""The IEEE fp16 form of the reduced-precision mode - the dtype of the reference's own mixed precision (torch.cuda.amp.autocast
++ GradScaler: core/gdrn_modeling/engine.py:279-309, main_gdrn.py:143 precision=16; gdrn_evaluator.py:625 AMP_TEST) and of
+BASELINE configuration C5 (MP6D, ResNet-50, 320x320, "fp16 MFMA").  Selected with cfg.TEST.AMP_DTYPE / cfg.SOLVER.AMP.DTYPE
+= "fp16"; every 16-bit kernel exists as rdpn6d_*_fp16 (same source as the bf16 build, v_mfma_f32_32x32x16_f16)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+def _run(model, t):
+    with torch.no_grad():
+        o = model(t["roi_img"], roi_classes=t["roi_cls"], roi_coord_2d=t["roi_coord_2d"], roi_cams=t["roi_cam"], roi_centers=t["roi_center"],
+                  roi_whs=t["roi_wh"], roi_extents=t["roi_extent"], resize_ratios=t["resize_ratio"], do_loss=False, fps=t["fps"])
+    torch.cuda.synchronize()
+    return {k: v.clone() for k, v in o.items() if torch.is_tensor(v)}
+
+
+@pytest.mark.parametrize("case", [(2, 16, 64, 128, 3, 1, True, 1), (1, 64, 256, 256, 3, 1, False, 1), (3, 16, 64, 128, 1, 2, False, 0)])
+def test_conv_fp16_layer_vs_fp32_kernel_on_fp16_operands(case):
+    """rdpn6d_conv2d_fp16: products of fp16 numbers are exact in fp32, so against the fp32 kernel on the same (fp16-valued)
+    operands only the summation order differs; the fp16 output is that result rounded once."""
+    import ctypes
+
+    from rdpn6d_amd import _lib
+    from rdpn6d_amd.gdrn import _pad_to, _pad_vec, _ptr, pack_conv_weight
+
+    lib, dev = _lib.load(), torch.device("cuda:0")
+    B, H, Cin, Cout, k, stride, use_res, act = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, H, H, Cin, generator=g).half().to(dev)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).half().float()
+    wp = pack_conv_weight(w.to(dev), cin_pad=_pad_to(Cin, 32))
+    sc, sh = _pad_vec((torch.rand(Cout, generator=g) + 0.5).to(dev), wp.shape[0], 1.0), _pad_vec(torch.randn(Cout, generator=g).to(dev), wp.shape[0], 0.0)
+    Ho = (H + 2 * (k // 2) - k) // stride + 1
+    res = torch.randn(B, Ho, Ho, Cout, generator=g).half().to(dev) if use_res else None
+
+    def desc(xt, wt, yt, rt):
+        d = _lib.ConvDesc()
+        d.x, d.w, d.scale, d.shift, d.res, d.y = _ptr(xt), _ptr(wt), _ptr(sc), _ptr(sh), _ptr(rt), _ptr(yt)
+        d.B, d.H, d.W, d.Cin, d.in_cs, d.Ho, d.Wo, d.stride = B, H, H, Cin, Cin, Ho, Ho, stride
+        taps = [(ky - k // 2, kx - k // 2) for ky in range(k) for kx in range(k)]
+        d.ntaps = len(taps)
+        for t, (dy, dx) in enumerate(taps):
+            d.dy[t], d.dx[t] = dy, dx
+        d.N, d.Npad, d.OH, d.OW, d.osy, d.osx, d.out_cs, d.res_cs, d.act = Cout, wp.shape[0], Ho, Ho, 1, 1, Cout, Cout, act
+        return d
+
+    y16 = torch.empty(B, Ho, Ho, Cout, dtype=torch.float16, device=dev)
+    y32 = torch.empty(B, Ho, Ho, Cout, dtype=torch.float32, device=dev)
+    d16 = desc(x, wp.half(), y16, res)
+    _lib.check(lib.rdpn6d_conv2d_fp16(ctypes.byref(d16), 0, None))
+    d32 = desc(x.float(), wp, y32, res.float() if use_res else None)
+    _lib.check(lib.rdpn6d_conv2d_f32(ctypes.byref(d32), None))
+    torch.cuda.synchronize()
+    err = (y16.float() - y32).abs().max().item()
+    scale = y32.abs().max().item()
+    print(f"{case}: fp16 kernel vs fp32 kernel on fp16-valued operands: {err:.3e} (|y|max {scale:.2f})")
+    assert err <= 2.0 ** -10 * scale  # one fp16 rounding of the output (2^-11 relative) + summation order
+
+
+def test_fp16_inference_mode_vs_autocast_fp16_yardstick():
+    """cfg.TEST.AMP_TEST with cfg.TEST.AMP_DTYPE = "fp16": the HIP fp16 maps are at least as close to the fp64 answer as the
+    torch-CPU oracle under torch.autocast(float16) - what the reference's own AMP_TEST path computes - and, with 11 instead of
+    8 significand bits, several times closer than the bf16 mode."""
+    from oracle import model_oracle
+    from rdpn6d_amd import synth
+    from rdpn6d_amd.config import gdrn_base_cfg
+    from rdpn6d_amd.gdrn import build_model_optimizer
+
+    dev = torch.device("cuda:0")
+    orc = model_oracle.GDRNOracle(32, "none")
+    sd = synth.make_trained_like_state_dict({k: tuple(v.shape) for k, v in orc.state_dict().items()}, seed=1234)
+    orc.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    inp = synth.make_inputs(4, seed=0)
+    tc = {k: torch.from_numpy(v) for k, v in inp.items()}
+    model_oracle.calibrate_bn(orc, tc["roi_img"])
+    orc.eval()
+    model, _ = build_model_optimizer(gdrn_base_cfg(mask_attention="none", device="cuda"))
+    model.load_state_dict(orc.state_dict(), strict=True)
+    model.eval()
+    args = lambda d: (d["roi_img"], d["roi_coord_2d"], d["fps"], d["roi_cam"], d["roi_center"], d["roi_wh"], d["resize_ratio"])  # noqa: E731
+    with torch.no_grad():
+        with torch.autocast("cpu", dtype=torch.float16):
+            oac = orc(*args(tc))
+        o64 = orc.double()(*args({k: (v.double() if v.dtype.is_floating_point else v) for k, v in tc.items()}))
+    t = {k: v.to(dev) for k, v in tc.items()}
+    outs = {}
+    try:
+        for dt in ("bf16", "fp16"):
+            model.cfg.TEST.AMP_TEST, model.cfg.TEST.AMP_DTYPE = True, dt
+            outs[dt] = _run(model, t)
+            plan = model.plan(4, dev)
+            assert plan.lp == dt and plan.bufs["head_a"].dtype == (torch.float16 if dt == "fp16" else torch.bfloat16)
+    finally:
+        model.cfg.TEST.AMP_TEST, model.cfg.TEST.AMP_DTYPE = False, "bf16"
+    for k in ("mask", "coor_x", "coor_y", "coor_z", "region"):
+        exact = o64[k]
+        f = {dt: (torch.linalg.norm(outs[dt][k].cpu().double() - exact) / torch.linalg.norm(exact)).item() for dt in outs}
+        fac = (torch.linalg.norm(oac[k].double() - exact) / torch.linalg.norm(exact)).item()
+        print(f"{k}: rel-Frobenius vs fp64: HIP-fp16 {f['fp16']:.3e} | autocast(fp16) oracle {fac:.3e} | HIP-bf16 {f['bf16']:.3e}")
+        assert f["fp16"] <= 1.1 * fac and f["fp16"] <= 0.5 * f["bf16"], k
+    assert torch.isfinite(outs["fp16"]["rot"]).all() and torch.isfinite(outs["fp16"]["trans"]).all()
+
+
+def test_fp16_training_through_the_reference_loop_with_gradscaler():
+    """the reference's AMP step, literally (engine.py:279-309): forward under the model's AMP switch, GradScaler.scale(loss).backward(),
+    scaler.step(optimizer), scaler.update() - on the fp16 kernels (cfg.SOLVER.AMP.DTYPE = "fp16").  The scaled upstream gradient
+    reaches the HIP backward through the autograd node, the activation gradients are stored in fp16, GradScaler unscales the
+    fp32 parameter gradients and steps the fused Ranger; the loss must go down and no step may be skipped for overflow after the
+    scale has settled."""
+    from rdpn6d_amd import synth
+    from rdpn6d_amd.config import gdrn_base_cfg
+    from rdpn6d_amd.gdrn import build_model_optimizer
+
+    dev = torch.device("cuda:0")
+    cfg = gdrn_base_cfg(mask_attention="mul", device="cuda")
+    cfg.SOLVER.AMP.ENABLED, cfg.SOLVER.AMP.DTYPE = True, "fp16"
+    cfg.SOLVER.OPTIMIZER_CFG = dict(type="Ranger", lr=2e-3, weight_decay=0)
+    model, opt = build_model_optimizer(cfg)
+    sd = synth.make_trained_like_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=1234)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    inp = synth.make_inputs(4, seed=0)
+    b = {k: torch.from_numpy(v).to(dev) for k, v in {**inp, **synth.make_train_gt(4, inp)}.items()}
+    scaler = torch.amp.GradScaler("cuda", init_scale=65536.0)
+    hist, scales = [], []
+    for it in range(8):
+        _, ld = model(b["roi_img"], gt_xyz=b["roi_xyz"], gt_mask_trunc=b["roi_mask_trunc"], gt_mask_visib=b["roi_mask_visib"],
+                      gt_mask_obj=b["roi_mask_obj"], gt_region=b["roi_region"], gt_ego_rot=b["ego_rot"], gt_points=b["roi_points"],
+                      sym_infos=None, gt_trans=b["trans"], gt_trans_ratio=b["roi_trans_ratio"], roi_classes=b["roi_cls"],
+                      roi_coord_2d=b["roi_coord_2d"], roi_cams=b["roi_cam"], roi_centers=b["roi_center"], roi_whs=b["roi_wh"],
+                      roi_extents=b["roi_extent"], resize_ratios=b["resize_ratio"], do_loss=True, fps=b["fps"])
+        losses = sum(ld.values())
+        opt.zero_grad(set_to_none=True)
+        scaler.scale(losses).backward()
+        scaler.step(opt)
+        scaler.update()
+        hist.append(losses.item())
+        scales.append(scaler.get_scale())
+    eng = model.train_engine(4, dev)
+    assert eng.amp and eng.lp == "fp16" and eng.bufs["act:head3"].dtype == torch.float16 and eng.bufs["d:head3"].dtype == torch.float16
+    print("fp16 AMP + GradScaler: total loss", [round(h, 4) for h in hist], "scale", scales)
+    assert np.isfinite(hist).all() and hist[-1] < hist[0]
+    assert scales[-1] == scales[-3], "the loss scale must have settled (no overflow in the last steps)"
+
+
+def test_fp16_step_vs_autocast_fp16_yardstick_and_c5_resnet50_320():
+    """(a) one fp16 training step against fp64 with the torch.autocast(float16) oracle as yardstick (static loss scale 4096 on both
+    sides' terms: the HIP engine's `loss_scale`); (b) BASELINE configuration C5's shape - ResNet-50 trunk, 320x320 crops - at
+    B = 16 in fp16: finite losses / gradients and a Ranger step that lowers the loss."""
+    from oracle import model_oracle
+    from rdpn6d_amd import synth
+    from rdpn6d_amd.config import gdrn_base_cfg
+    from rdpn6d_amd.gdrn import build_model_optimizer
+    from rdpn6d_amd.ranger import Ranger
+
+    dev = torch.device("cuda:0")
+    inp = synth.make_inputs(4, seed=0)
+    gt = synth.make_train_gt(4, inp)
+    cfg = gdrn_base_cfg(mask_attention="mul", device="cuda")
+    cfg.SOLVER.AMP.ENABLED, cfg.SOLVER.AMP.DTYPE = True, "fp16"
+    model, _ = build_model_optimizer(cfg)
+    sd = synth.make_trained_like_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=1234)
+    sd = {k: torch.from_numpy(np.asarray(v)).clone() for k, v in sd.items()}
+    model.load_state_dict(sd, strict=True)
+    eng = model.train_engine(4, dev)
+    eng.loss_scale = 4096.0
+    batch = {k: torch.from_numpy(v).to(dev) for k, v in {**inp, **gt}.items()}
+    losses = eng.forward_backward(batch)
+    torch.cuda.synchronize()
+    t = {k: torch.from_numpy(v) for k, v in {**inp, **gt}.items()}
+
+    def run_oracle(dtype, autocast):
+        o = model_oracle.GDRNOracle(32, "mul")
+        o.load_state_dict(sd, strict=True)
+        o = o.to(dtype).train()
+        tt = {k: (v.to(dtype) if v.dtype.is_floating_point else v) for k, v in t.items()}
+        with torch.autocast("cpu", dtype=torch.float16, enabled=autocast):
+            out = o(tt["roi_img"], tt["roi_coord_2d"], tt["fps"], tt["roi_cam"], tt["roi_center"], tt["roi_wh"], tt["resize_ratio"], train_pose=True)
+            L = model_oracle.gdrn_losses({k: (v.float() if autocast and torch.is_tensor(v) and v.is_floating_point() else v) for k, v in out.items()},
+                                         tt, tt["roi_extent"])
+        (sum(L.values()) * (4096.0 if autocast else 1.0)).backward()
+        return o, L
+
+    o64, L64 = run_oracle(torch.float64, False)
+    oac, Lac = run_oracle(torch.float32, True)
+    tot64 = sum(v.item() for v in L64.values())
+    e_hip, e_ac = abs(sum(v.item() for v in losses.values()) - tot64), abs(sum(v.item() for v in Lac.values()) - tot64)
+    r64, rac = dict(o64.named_parameters()), dict(oac.named_parameters())
+    eh, ea = [], []
+    for name, p in model.named_parameters():
+        g64 = r64[name].grad
+        n = g64.norm().item()
+        if n < 1e-4:
+            continue
+        assert torch.isfinite(p.grad).all(), name
+        eh.append((p.grad.cpu().double() - g64).norm().item() / n)
+        ea.append((rac[name].grad.double() / 4096.0 - g64).norm().item() / n)
+    print(f"fp16 step: total loss off by HIP {e_hip:.2e} | autocast(fp16) oracle {e_ac:.2e} (fp64 total {tot64:.4f}); median relative gradient "
+          f"error vs fp64: HIP {np.median(eh):.3e} | autocast oracle {np.median(ea):.3e}; worst {max(eh):.3e} | {max(ea):.3e}")
+    assert np.median(eh) <= 1.1 * np.median(ea) and max(eh) <= 1.5 * max(ea) and e_hip <= 1e-2 * tot64
+    del eng, model
+    torch.cuda.empty_cache()
+
+    # (b) C5 shape
+    B, R = 16, 320
+    cfg = gdrn_base_cfg(mask_attention="mul", device="cuda")
+    cfg.MODEL.CDPN.BACKBONE.NUM_LAYERS, cfg.MODEL.CDPN.BACKBONE.INPUT_RES, cfg.MODEL.CDPN.BACKBONE.OUTPUT_RES = 50, R, R // 4
+    cfg.SOLVER.AMP.ENABLED, cfg.SOLVER.AMP.DTYPE = True, "fp16"
+    model, _ = build_model_optimizer(cfg)
+    sd = synth.make_trained_like_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=7)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    inp = synth.make_inputs(B, seed=3, res=R)
+    batch = {k: torch.from_numpy(v).to(dev) for k, v in {**inp, **synth.make_train_gt(B, inp)}.items()}
+    eng = model.train_engine(B, dev)
+    eng.loss_scale = 4096.0
+    opt = Ranger([p for p in model.parameters()], lr=1e-3)
+    hist = []
+    for it in range(4):
+        eng.refresh_weights()
+        L = eng.forward_backward(batch)
+        assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+        opt.step()
+        hist.append(sum(v.item() for v in L.values()))
+    print("C5 shape (ResNet-50, 320x320, B=16, fp16): total loss over 4 Ranger steps", [round(h, 4) for h in hist])
+    assert np.isfinite(hist).all() and hist[-1] < hist[0]
+    assert eng.lp == "fp16" and eng.adt == torch.float16
