@@ -64,7 +64,9 @@ def _fp16_object(lp_objs):
     llvm = os.environ.get("LLVM_BIN", "/opt/rocm/lib/llvm/bin")
     merged = os.path.join(HERE, "build", "lp_fp16_merged.o")
     final = os.path.join(HERE, "build", "lp_fp16.o")
-    subprocess.run(["ld", "-r", "-o", merged] + lp_objs, check=True)
+    # --force-group-allocation: template instantiations (kernel host stubs, their handles) sit in COMDAT groups that the final
+    # link would otherwise de-duplicate BY NAME against the bf16 objects' copies - and launch the bf16 kernel for the fp16 entry
+    subprocess.run(["ld", "-r", "--force-group-allocation", "-o", merged] + lp_objs, check=True)
     nm = subprocess.run(["nm", "--defined-only", "--extern-only", merged], check=True, capture_output=True, text=True).stdout  # (binutils)
     renames = dict(LP_EXTRA_RENAMES)
     for line in nm.splitlines():

@@ -64,7 +64,8 @@ __device__ __forceinline__ void rd_unpack8(const rd_u32x4 p, float (&v)[8])
 {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const rd_f32x2 t = __builtin_convertvector(__builtin_bit_cast(rd_lp_x2, p[i]), rd_f32x2);
+        const unsigned u = p[i];  // (a scalar copy first: bit-casting the vector ELEMENT expression reads element 0 every time - clang 22)
+        const rd_f32x2 t = __builtin_convertvector(__builtin_bit_cast(rd_lp_x2, u), rd_f32x2);
         v[2 * i] = t[0];
         v[2 * i + 1] = t[1];
     }
@@ -109,8 +110,9 @@ template <> __device__ __forceinline__ f32x4 rd_ld4<rd_bf16_t>(const rd_bf16_t* 
     const uint2 u = *reinterpret_cast<const uint2*>(p);
     f32x4 v;
 #ifdef RDPN6D_LP_FP16
-    const rd_f32x2 a = __builtin_convertvector(__builtin_bit_cast(rd_lp_x2, u.x), rd_f32x2);
-    const rd_f32x2 b = __builtin_convertvector(__builtin_bit_cast(rd_lp_x2, u.y), rd_f32x2);
+    const unsigned ux = u.x, uy = u.y;  // (scalar copies first, see rd_unpack8)
+    const rd_f32x2 a = __builtin_convertvector(__builtin_bit_cast(rd_lp_x2, ux), rd_f32x2);
+    const rd_f32x2 b = __builtin_convertvector(__builtin_bit_cast(rd_lp_x2, uy), rd_f32x2);
     v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1];
 #else
     v[0] = __uint_as_float(u.x << 16);
