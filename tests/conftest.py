@@ -19,7 +19,7 @@ def oracle_lib():
     import ctypes
 
     so = os.path.join(ROOT, "oracle", "liboracle.so")
-    srcs = [os.path.join(ROOT, "oracle", f) for f in ("fps_oracle.c", "ransac_oracle.c")]
+    srcs = [os.path.join(ROOT, "oracle", f) for f in ("fps_oracle.c", "ransac_oracle.c", "pnp_oracle.c")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"], check=True, capture_output=True)
     return ctypes.CDLL(so)
