@@ -43,6 +43,7 @@ def build_model(device, mask_attention="none", bf16=False, graph=False, x3=True,
 
     cfg = gdrn_base_cfg(mask_attention=mask_attention, device=str(device))
     cfg.TEST.USE_PNP = True  # the step includes the per-crop RANSAC/Kabsch solve ("fwd+PnP")
+    cfg.TEST.PNP_TYPE = "ransac_kabsch"  # the north star's solver (3D-3D on the RGB-D residual geometry); "ransac_pnp" = the 2D-3D one
     cfg.TEST.AMP_TEST = bool(bf16)  # secondary mode: trunk + fusion + head on the 16-bit matrix pipe (bf16 | fp16)
     cfg.TEST.AMP_DTYPE = bf16 if bf16 in ("bf16", "fp16") else "bf16"
     cfg.TEST.HIP_GRAPH = bool(graph)  # the ~90 launches of a step replay as one hipGraph (same kernels, same order)

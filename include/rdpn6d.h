@@ -384,6 +384,20 @@ int rdpn6d_select_correspondences_f32(const float* out_nchw, int C, const float*
                                       const float* extents, const int* im_hw, int im_H, int im_W, int B, int HW, float mask_thr,
                                       float* image_points, float* model_points, int* counts, unsigned char* sel_mask,
                                       float* out_mask, void* stream);
+/* rows A9 / A10: 2D-3D RANSAC-PnP on device, the role of lib/pysixd/misc.py:145-194 pnp_v2 -> cv2.solvePnPRansac(EPnP, 3 px, 100 it.)
+ * at gdrn_evaluator.py:316-435 and of process_net_and_pnp (:187-314).  image_points [B,HW,2] px / model_points [B,HW,3] m / counts [B]
+ * = the output of rdpn6d_select_correspondences_f32; cams [B,9] K row-major; net_pose [B,12] (R row-major | t) or NULL.
+ *   mode 0  RANSAC: one hypothesis per wavefront (Lambda-Twist P3P on 3 + 1 correspondences, fp64), inliers by reprojection
+ *           error < reproj_thr from LDS, confidence-driven stop, Gauss-Newton refit on the winner's inliers; < 4
+ *           correspondences or no model = the -100 sentinel pose;
+ *   mode 1  net_pose is hypothesis 0 (useExtrinsicGuess; the reference runs 20 iterations);  mode 2  Gauss-Newton from net_pose
+ *           over all correspondences (SOLVEPNP_ITERATIVE); both keep net_pose below 4 correspondences and its translation
+ *           when the solved one moved by more than max_t_diff.
+ * -> pose_out [B,12], n_inliers [B], inlier_mask [B,HW] (indexed like the lists), best_hyp [B].  Masks / counts / winner are
+ * bit-exact vs oracle/pnp_oracle.c under a fixed seed; parity with cv2 is unpinned (cv2 absent). */
+int rdpn6d_ransac_pnp_f32(const float* image_points, const float* model_points, const int* counts, const float* cams,
+                          const float* net_pose, int B, int HW, float reproj_thr, int iters, float confidence, unsigned seed, int mode,
+                          float max_t_diff, float* pose_out, int* n_inliers, unsigned char* inlier_mask, int* best_hyp, void* stream);
 /* rank 1: GPU crop builder (core/gdrn_modeling/data_loader.py:523-627, core/utils/data_utils.py:81-152; cv2.warpAffine
  * bilinear arithmetic restated, parity with cv2 unpinned).  images [N,H,W,3] u8, depths [N,H,W] f32; per ROI: image index,
  * inverse affine maps for the R and R/4 crops (6 doubles each), fx fy cx cy of (A @ K), resize_ratio ->

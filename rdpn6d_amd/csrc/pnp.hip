@@ -92,3 +92,599 @@ extern "C" int rdpn6d_select_correspondences_f32(const float* out_nchw, int C, c
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
 }
+
+// =====================================================================================================================
+// 2D-3D RANSAC-PnP (rows A9 / A10): the on-device counterpart of lib/pysixd/misc.py:145-194 pnp_v2 -> cv2.solvePnPRansac as
+// called from gdrn_evaluator.py:316-435 (process_pnp_ransac: reprojection threshold 3 px, 100 iterations) and :187-314
+// (process_net_and_pnp: the network pose as extrinsic guess with 20 iterations, or SOLVEPNP_ITERATIVE from it).
+//
+// One 512-thread workgroup (8 wavefronts) per crop; the crop's correspondences (uv, xyz: 20 bytes each, n <= HW) live in LDS.
+//   phase 1  correspondences HBM -> LDS
+//   phase 2  ONE HYPOTHESIS PER WAVEFRONT: every lane draws the same 4 distinct correspondences (counter-based integer hash),
+//            solves the Lambda-Twist P3P on three of them in fp64 and keeps the solution that reprojects the fourth best; then the
+//            64 lanes sweep the LDS-resident correspondences, score them by REPROJECTION error < thr and the wave's inlier count
+//            lands on the LDS scoreboard next to its pose
+//   phase 3  sequential scan of the scoreboard with the confidence-driven stop (minimal set of 4)
+//   phase 4  inlier mask of the winner, then PNP_REFIT_ITERS Gauss-Newton steps on the reprojection error of its inliers
+//            (6 parameters, normal equations reduced over the workgroup in a fixed tree, Cayley-transform rotation update)
+// The executable specification is oracle/pnp_oracle.c: fp64 arithmetic of + - * / sqrt only, written operation by operation in
+// the same order (this file is compiled with contraction off), so masks, counts and the winning hypothesis are bit-exact under
+// a fixed seed; the refit differs by summation order (~1e-9).  Parity with cv2 itself is UNPINNED (cv2 is not installed).
+#define PNP_THREADS 512
+#define PNP_WAVES (PNP_THREADS / 64)
+#define PNP_MAX_ITERS 256
+#define PNP_REFIT_ITERS 10
+#define PNP_HUGE (__builtin_huge_val())
+
+namespace {
+__device__ static unsigned pnp_hash(unsigned seed, unsigned b, unsigned h, unsigned t, unsigned j)
+{
+    unsigned x = seed;
+    x ^= b * 0x9E3779B1u;
+    x ^= h * 0x85EBCA77u;
+    x ^= t * 0xC2B2AE3Du;
+    x ^= j * 0x27D4EB2Fu;
+    x ^= x >> 16;
+    x *= 0x85EBCA6Bu;
+    x ^= x >> 13;
+    x *= 0xC2B2AE35u;
+    x ^= x >> 16;
+    return x;
+}
+
+__device__ static void cross3(const double* a, const double* b, double* c)
+{
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ static double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+/* one real root of x^3 + b x^2 + c x + d by Newton-Raphson from a start on the correct side of the stationary points */
+__device__ static double cubic_one_root(double b, double c, double d)
+{
+    double r0;
+    if (b * b >= 3.0 * c) {
+        const double v = sqrt(b * b - 3.0 * c);
+        const double t1 = (-b - v) / 3.0;
+        double k = ((t1 + b) * t1 + c) * t1 + d;
+        if (k > 0.0) {
+            r0 = t1 - sqrt(-k / (3.0 * t1 + b));
+        } else {
+            const double t2 = (-b + v) / 3.0;
+            k = ((t2 + b) * t2 + c) * t2 + d;
+            r0 = t2 + sqrt(-k / (3.0 * t2 + b));
+        }
+    } else {
+        r0 = -b / 3.0;
+        if (fabs((3.0 * r0 + 2.0 * b) * r0 + c) < 1e-4) r0 += 1.0;
+    }
+    for (int it = 0; it < 50; it++) {
+        const double fx = ((r0 + b) * r0 + c) * r0 + d;
+        if (it >= 7 && fabs(fx) < 1e-13) break;
+        const double fpx = (3.0 * r0 + 2.0 * b) * r0 + c;
+        if (fpx == 0.0) break;
+        r0 -= fx / fpx;
+    }
+    return r0;
+}
+
+/* real roots of x^2 + b x + c; returns their number (0 or 2) */
+__device__ static int quad_roots(double b, double c, double* r1, double* r2)
+{
+    const double disc = b * b - 4.0 * c;
+    if (!(disc >= 0.0)) return 0;
+    const double y = sqrt(disc);
+    const double q = b < 0.0 ? 0.5 * (-b + y) : 0.5 * (-b - y);
+    *r1 = q;
+    *r2 = q != 0.0 ? c / q : 0.0;
+    return 2;
+}
+
+__device__ static double det3(const double* m)
+{
+    return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+}
+/* trace(adj(A) B) for 3x3 */
+__device__ static double tr_adj_mul(const double* A, const double* B)
+{
+    double adj[9];
+    adj[0] = A[4] * A[8] - A[5] * A[7];
+    adj[1] = A[2] * A[7] - A[1] * A[8];
+    adj[2] = A[1] * A[5] - A[2] * A[4];
+    adj[3] = A[5] * A[6] - A[3] * A[8];
+    adj[4] = A[0] * A[8] - A[2] * A[6];
+    adj[5] = A[2] * A[3] - A[0] * A[5];
+    adj[6] = A[3] * A[7] - A[4] * A[6];
+    adj[7] = A[1] * A[6] - A[0] * A[7];
+    adj[8] = A[0] * A[4] - A[1] * A[3];
+    double t = 0.0;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) t += adj[i * 3 + j] * B[j * 3 + i];
+    return t;
+}
+
+/* unit eigenvector of the symmetric 3x3 matrix A for the eigenvalue e: the largest cross product of two rows of A - e I */
+__device__ static int eigvec_sym3(const double* A, double e, double* v)
+{
+    double M[9];
+    for (int i = 0; i < 9; i++) M[i] = A[i];
+    M[0] -= e; M[4] -= e; M[8] -= e;
+    double c01[3], c02[3], c12[3];
+    cross3(M, M + 3, c01);
+    cross3(M, M + 6, c02);
+    cross3(M + 3, M + 6, c12);
+    const double n01 = dot3(c01, c01), n02 = dot3(c02, c02), n12 = dot3(c12, c12);
+    const double* best = c01;
+    double nb = n01;
+    if (n02 > nb) { best = c02; nb = n02; }
+    if (n12 > nb) { best = c12; nb = n12; }
+    if (!(nb > 0.0)) return 0;
+    const double s = 1.0 / sqrt(nb);
+    v[0] = best[0] * s; v[1] = best[1] * s; v[2] = best[2] * s;
+    return 1;
+}
+
+/* P3P: bearings y[3][3] (unit), model points x[3][3] -> up to 4 poses (R row-major, t); returns their number */
+__device__ static int p3p_lambdatwist(const double y[3][3], const double x[3][3], double R[4][9], double t[4][3])
+{
+    const double b12 = -2.0 * dot3(y[0], y[1]), b13 = -2.0 * dot3(y[0], y[2]), b23 = -2.0 * dot3(y[1], y[2]);
+    double d12[3], d13[3], d23[3], d12xd13[3];
+    for (int c = 0; c < 3; c++) { d12[c] = x[0][c] - x[1][c]; d13[c] = x[0][c] - x[2][c]; d23[c] = x[1][c] - x[2][c]; }
+    cross3(d12, d13, d12xd13);
+    const double a12 = dot3(d12, d12), a13 = dot3(d13, d13), a23 = dot3(d23, d23);
+    if (!(a12 > 0.0 && a13 > 0.0 && a23 > 0.0) || !(dot3(d12xd13, d12xd13) > 1e-24 * a12 * a13)) return 0;
+    /* D1 = a23 M12 - a12 M23,  D2 = a23 M13 - a13 M23  (symmetric, row-major) */
+    const double D1[9] = {a23, 0.5 * a23 * b12, 0.0, 0.5 * a23 * b12, a23 - a12, -0.5 * a12 * b23, 0.0, -0.5 * a12 * b23, -a12};
+    const double D2[9] = {a23, 0.0, 0.5 * a23 * b13, 0.0, -a13, -0.5 * a13 * b23, 0.5 * a23 * b13, -0.5 * a13 * b23, a23 - a13};
+    /* det(D1 + g D2) = c0 + c1 g + c2 g^2 + c3 g^3 */
+    const double c3 = det3(D2), c0 = det3(D1), c1 = tr_adj_mul(D1, D2), c2 = tr_adj_mul(D2, D1);
+    if (c3 == 0.0) return 0;
+    const double pb = c2 / c3, pc = c1 / c3, pd = c0 / c3;
+    double roots[3];
+    int nroots = 1;
+    roots[0] = cubic_one_root(pb, pc, pd);
+    {   /* deflate: x^2 + (pb + r) x + (pc + (pb + r) r) */
+        const double qb = pb + roots[0], qc = pc + qb * roots[0];
+        double r1, r2;
+        if (quad_roots(qb, qc, &r1, &r2)) { roots[1] = r1; roots[2] = r2; nroots = 3; }
+    }
+    double Ls[4][3];
+    int valid = 0;
+    for (int ri = 0; ri < nroots && valid == 0; ri++) {
+        const double g = roots[ri];
+        double A[9];
+        for (int i = 0; i < 9; i++) A[i] = D1[i] + g * D2[i];
+        /* the two non-zero eigenvalues: roots of e^2 - tr e + (sum of principal 2x2 minors) */
+        const double tr = A[0] + A[4] + A[8];
+        const double mn = (A[0] * A[4] - A[1] * A[3]) + (A[0] * A[8] - A[2] * A[6]) + (A[4] * A[8] - A[5] * A[7]);
+        double e1, e2;
+        if (!quad_roots(-tr, mn, &e1, &e2)) continue;
+        if (fabs(e1) < fabs(e2)) { const double tmp = e1; e1 = e2; e2 = tmp; }
+        if (!(e1 * e2 < 0.0)) continue;  /* not a pair of real planes for this root */
+        double v1[3], v2[3];
+        if (!eigvec_sym3(A, e1, v1) || !eigvec_sym3(A, e2, v2)) continue;
+        const double v = sqrt(-e2 / e1);
+        for (int sgn = 0; sgn < 2 && valid < 4; sgn++) {
+            const double s = sgn == 0 ? v : -v;
+            /* plane n . L = 0 with n = v1 + s v2  ->  l1 = w0 l2 + w1 l3 */
+            const double n0 = v1[0] + s * v2[0], n1 = v1[1] + s * v2[1], n2 = v1[2] + s * v2[2];
+            if (n0 == 0.0) continue;
+            const double w0 = -n1 / n0, w1 = -n2 / n0;
+            const double qa = (a13 - a12) * w1 * w1 - a12 * b13 * w1 - a12;
+            if (qa == 0.0) continue;
+            const double qb = (a13 * b12 * w1 - a12 * b13 * w0 - 2.0 * w0 * w1 * (a12 - a13)) / qa;
+            const double qc = ((a13 - a12) * w0 * w0 + a13 * b12 * w0 + a13) / qa;
+            double taus[2];
+            if (!quad_roots(qb, qc, &taus[0], &taus[1])) continue;
+            for (int ti = 0; ti < 2 && valid < 4; ti++) {
+                const double tau = taus[ti];
+                if (!(tau > 0.0)) continue;
+                const double den = tau * (b23 + tau) + 1.0;
+                if (!(den > 0.0)) continue;
+                const double l2 = sqrt(a23 / den), l3 = tau * l2, l1 = w0 * l2 + w1 * l3;
+                if (!(l1 >= 0.0)) continue;
+                Ls[valid][0] = l1; Ls[valid][1] = l2; Ls[valid][2] = l3;
+                valid++;
+            }
+        }
+    }
+    int nsol = 0;
+    for (int k = 0; k < valid; k++) {
+        double l1 = Ls[k][0], l2 = Ls[k][1], l3 = Ls[k][2];
+        for (int it = 0; it < 5; it++) {  /* Newton on the three quadrics */
+            const double r1 = l1 * l1 + l2 * l2 + b12 * l1 * l2 - a12;
+            const double r2 = l1 * l1 + l3 * l3 + b13 * l1 * l3 - a13;
+            const double r3 = l2 * l2 + l3 * l3 + b23 * l2 * l3 - a23;
+            if (fabs(r1) + fabs(r2) + fabs(r3) < 1e-10 * (a12 + a13 + a23)) break;
+            const double j11 = 2.0 * l1 + b12 * l2, j12 = 2.0 * l2 + b12 * l1;
+            const double j21 = 2.0 * l1 + b13 * l3, j23 = 2.0 * l3 + b13 * l1;
+            const double j32 = 2.0 * l2 + b23 * l3, j33 = 2.0 * l3 + b23 * l2;
+            const double det = -j11 * j23 * j32 - j12 * j21 * j33;
+            if (det == 0.0) break;
+            const double id = 1.0 / det;
+            const double dl1 = id * (-j23 * j32 * r1 - j12 * j33 * r2 + j12 * j23 * r3);
+            const double dl2 = id * (-j21 * j33 * r1 + j11 * j33 * r2 - j11 * j23 * r3);
+            const double dl3 = id * (j21 * j32 * r1 - j11 * j32 * r2 - j12 * j21 * r3);
+            l1 -= dl1; l2 -= dl2; l3 -= dl3;
+        }
+        if (!(l1 > 0.0 && l2 > 0.0 && l3 > 0.0)) continue;
+        /* R maps (d12, d13, d12 x d13) onto (l1 y1 - l2 y2, l1 y1 - l3 y3, their cross product); t = l1 y1 - R x1 */
+        double yd1[3], yd2[3], yx[3], ry1[3];
+        for (int c = 0; c < 3; c++) { ry1[c] = l1 * y[0][c]; yd1[c] = ry1[c] - l2 * y[1][c]; yd2[c] = ry1[c] - l3 * y[2][c]; }
+        cross3(yd1, yd2, yx);
+        const double X[9] = {d12[0], d13[0], d12xd13[0], d12[1], d13[1], d12xd13[1], d12[2], d13[2], d12xd13[2]};
+        const double dX = det3(X);
+        if (dX == 0.0) continue;
+        const double iX = 1.0 / dX;
+        double Xi[9];
+        Xi[0] = (X[4] * X[8] - X[5] * X[7]) * iX; Xi[1] = (X[2] * X[7] - X[1] * X[8]) * iX; Xi[2] = (X[1] * X[5] - X[2] * X[4]) * iX;
+        Xi[3] = (X[5] * X[6] - X[3] * X[8]) * iX; Xi[4] = (X[0] * X[8] - X[2] * X[6]) * iX; Xi[5] = (X[2] * X[3] - X[0] * X[5]) * iX;
+        Xi[6] = (X[3] * X[7] - X[4] * X[6]) * iX; Xi[7] = (X[1] * X[6] - X[0] * X[7]) * iX; Xi[8] = (X[0] * X[4] - X[1] * X[3]) * iX;
+        const double Y[9] = {yd1[0], yd2[0], yx[0], yd1[1], yd2[1], yx[1], yd1[2], yd2[2], yx[2]};
+        double* Rk = R[nsol];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) Rk[i * 3 + j] = Y[i * 3 + 0] * Xi[0 * 3 + j] + Y[i * 3 + 1] * Xi[1 * 3 + j] + Y[i * 3 + 2] * Xi[2 * 3 + j];
+        for (int i = 0; i < 3; i++) t[nsol][i] = ry1[i] - (Rk[i * 3] * x[0][0] + Rk[i * 3 + 1] * x[0][1] + Rk[i * 3 + 2] * x[0][2]);
+        nsol++;
+    }
+    return nsol;
+}
+
+/* squared reprojection error (pixels) of model point p under pose (R, t) and intrinsics; +inf behind the camera */
+__device__ static double reproj_err2(const double* R, const double* t, const double* K4 /* fx fy cx cy */, const float* p, const float* uv)
+{
+    const double X = R[0] * p[0] + R[1] * p[1] + R[2] * p[2] + t[0];
+    const double Y = R[3] * p[0] + R[4] * p[1] + R[5] * p[2] + t[1];
+    const double Z = R[6] * p[0] + R[7] * p[1] + R[8] * p[2] + t[2];
+    if (!(Z > 0.0)) return PNP_HUGE;
+    const double du = K4[0] * X / Z + K4[2] - (double)uv[0];
+    const double dv = K4[1] * Y / Z + K4[3] - (double)uv[1];
+    return du * du + dv * dv;
+}
+
+/* hypothesis h of crop b: sample 4 distinct correspondences, P3P on the first three, keep the solution with the smallest
+ * reprojection error of the fourth.  Returns 0 if no pose came out. */
+__device__ static int pnp_hypothesis(unsigned seed, unsigned b, unsigned h, int n, const float* ip, const float* mp, const double* K4, double* R, double* t)
+{
+    for (unsigned tr = 0; tr < 8; tr++) {
+        int idx[4];
+        for (int j = 0; j < 4; j++) idx[j] = (int)(pnp_hash(seed, b, h, tr, (unsigned)j) % (unsigned)n);
+        if (idx[0] == idx[1] || idx[0] == idx[2] || idx[0] == idx[3] || idx[1] == idx[2] || idx[1] == idx[3] || idx[2] == idx[3]) continue;
+        double y[3][3], x[3][3];
+        for (int j = 0; j < 3; j++) {
+            const double bx = ((double)ip[2 * idx[j]] - K4[2]) / K4[0], by = ((double)ip[2 * idx[j] + 1] - K4[3]) / K4[1];
+            const double inv = 1.0 / sqrt(bx * bx + by * by + 1.0);
+            y[j][0] = bx * inv; y[j][1] = by * inv; y[j][2] = inv;
+            for (int c = 0; c < 3; c++) x[j][c] = (double)mp[3 * idx[j] + c];
+        }
+        double Rs[4][9], ts[4][3];
+        const int ns = p3p_lambdatwist(y, x, Rs, ts);
+        int bestk = -1;
+        double beste = PNP_HUGE;
+        for (int k = 0; k < ns; k++) {
+            const double e = reproj_err2(Rs[k], ts[k], K4, mp + 3 * idx[3], ip + 2 * idx[3]);
+            if (e < beste) { beste = e; bestk = k; }
+        }
+        if (bestk < 0) continue;
+        for (int i = 0; i < 9; i++) R[i] = Rs[bestk][i];
+        for (int i = 0; i < 3; i++) t[i] = ts[bestk][i];
+        return 1;
+    }
+    return 0;
+}
+
+/* solve the symmetric positive definite 6x6 system H d = g in place (Gaussian elimination with partial pivoting); 0 if singular */
+__device__ static int solve6(double H[6][6], double g[6])
+{
+    for (int c = 0; c < 6; c++) {
+        int p = c;
+        for (int r = c + 1; r < 6; r++)
+            if (fabs(H[r][c]) > fabs(H[p][c])) p = r;
+        if (H[p][c] == 0.0) return 0;
+        if (p != c) {
+            for (int k = 0; k < 6; k++) { const double tmp = H[c][k]; H[c][k] = H[p][k]; H[p][k] = tmp; }
+            const double tg = g[c]; g[c] = g[p]; g[p] = tg;
+        }
+        for (int r = c + 1; r < 6; r++) {
+            const double f = H[r][c] / H[c][c];
+            for (int k = c; k < 6; k++) H[r][k] -= f * H[c][k];
+            g[r] -= f * g[c];
+        }
+    }
+    for (int c = 5; c >= 0; c--) {
+        double s = g[c];
+        for (int k = c + 1; k < 6; k++) s -= H[c][k] * g[k];
+        g[c] = s / H[c][c];
+    }
+    return 1;
+}
+
+
+// deterministic block-wide sum of NV doubles (fixed butterfly + fixed wave order); result to all threads
+template <int NV>
+__device__ __forceinline__ void pnp_block_sum(double* v, double* s_buf /* [PNP_WAVES * NV] */)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; k++)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o);
+    __syncthreads();
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < NV; k++) s_buf[wave * NV + k] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        double t = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < PNP_WAVES; wv++) t += s_buf[wv * NV + k];
+        v[k] = t;
+    }
+}
+
+// solve H d = g (6x6, Gaussian elimination with partial pivoting) - as oracle solve6
+__device__ static int pnp_solve6(double (&H)[6][6], double (&g)[6])
+{
+    for (int c = 0; c < 6; c++) {
+        int p = c;
+        for (int r = c + 1; r < 6; r++)
+            if (fabs(H[r][c]) > fabs(H[p][c])) p = r;
+        if (H[p][c] == 0.0) return 0;
+        if (p != c) {
+            for (int k = 0; k < 6; k++) { const double tmp = H[c][k]; H[c][k] = H[p][k]; H[p][k] = tmp; }
+            const double tg = g[c]; g[c] = g[p]; g[p] = tg;
+        }
+        for (int r = c + 1; r < 6; r++) {
+            const double f = H[r][c] / H[c][c];
+            for (int k = c; k < 6; k++) H[r][k] -= f * H[c][k];
+            g[r] -= f * g[c];
+        }
+    }
+    for (int c = 5; c >= 0; c--) {
+        double s = g[c];
+        for (int k = c + 1; k < 6; k++) s -= H[c][k] * g[k];
+        g[c] = s / H[c][c];
+    }
+    return 1;
+}
+
+__global__ __launch_bounds__(PNP_THREADS) void ransac_pnp_kernel(
+    const float* __restrict__ image_points, const float* __restrict__ model_points, const int* __restrict__ counts,
+    const float* __restrict__ cams, const float* __restrict__ net_pose, int HW, float reproj_thr, int iters, float confidence,
+    unsigned seed, int mode, float max_t_diff, float* __restrict__ pose_out, int* __restrict__ n_inliers,
+    unsigned char* __restrict__ inlier_mask, int* __restrict__ best_hyp)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char pnp_smem[];
+    double* s_red = reinterpret_cast<double*>(pnp_smem);               // PNP_WAVES * 27
+    double* s_pose = s_red + PNP_WAVES * 27;                           // 12 * PNP_MAX_ITERS (R | t per hypothesis)
+    double* s_cur = s_pose + 12 * PNP_MAX_ITERS;                       // 12: the pose being refined
+    int* s_cnt = reinterpret_cast<int*>(s_cur + 12);                   // PNP_MAX_ITERS
+    int* s_misc = s_cnt + PNP_MAX_ITERS;                               // 4
+    float* s_ip = reinterpret_cast<float*>(s_misc + 4);                // 2 * HW
+    float* s_mp = s_ip + 2 * (size_t)HW;                               // 3 * HW
+
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = counts[b];
+    const double K4[4] = {(double)cams[b * 9 + 0], (double)cams[b * 9 + 4], (double)cams[b * 9 + 2], (double)cams[b * 9 + 5]};
+    const double thr2 = (double)reproj_thr * (double)reproj_thr;
+    float* po = pose_out + b * 12;
+    unsigned char* msk = inlier_mask + (size_t)b * HW;
+    for (int p = tid; p < HW; p += PNP_THREADS) msk[p] = 0;
+    if (n < 4) {  // gdrn_evaluator.py:391-392 (sentinel) / :297-300 (keep the network pose)
+        if (tid < 12) po[tid] = net_pose ? net_pose[b * 12 + tid] : -100.f;
+        if (tid == 0) { n_inliers[b] = 0; best_hyp[b] = -1; }
+        return;
+    }
+    // ---- phase 1
+    {
+        const float* gi = image_points + (size_t)b * HW * 2;
+        const float* gm = model_points + (size_t)b * HW * 3;
+        for (int i = tid; i < 2 * n; i += PNP_THREADS) s_ip[i] = gi[i];
+        for (int i = tid; i < 3 * n; i += PNP_THREADS) s_mp[i] = gm[i];
+    }
+    for (int h = tid; h < iters; h += PNP_THREADS) s_cnt[h] = -1;
+    __syncthreads();
+
+    int best = -1, best_cnt = 0;
+    if (mode != 2) {
+        // ---- phase 2: one hypothesis per wavefront
+        for (int h = wave; h < iters; h += PNP_WAVES) {
+            double R[9], t[3];
+            int ok = 0;
+            if (mode == 1 && h == 0) {
+#pragma unroll
+                for (int i = 0; i < 9; i++) R[i] = (double)net_pose[b * 12 + i];
+#pragma unroll
+                for (int i = 0; i < 3; i++) t[i] = (double)net_pose[b * 12 + 9 + i];
+                ok = 1;
+            } else {
+                ok = pnp_hypothesis(seed, (unsigned)b, (unsigned)h, n, s_ip, s_mp, K4, R, t);
+            }
+            if (!ok) continue;  // wave-uniform
+            int cnt = 0;
+            for (int i = lane; i < n; i += 64) cnt += reproj_err2(R, t, K4, s_mp + 3 * i, s_ip + 2 * i) < thr2 ? 1 : 0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+            if (lane == 0) {
+                s_cnt[h] = cnt;  // the LDS inlier scoreboard
+#pragma unroll
+                for (int i = 0; i < 9; i++) s_pose[12 * h + i] = R[i];
+#pragma unroll
+                for (int i = 0; i < 3; i++) s_pose[12 * h + 9 + i] = t[i];
+            }
+        }
+        __syncthreads();
+        // ---- phase 3: scoreboard scan with the confidence-driven stop
+        if (tid == 0) {
+            int niters = iters;
+            for (int h = 0; h < iters && h < niters; h++) {
+                const int cnt = s_cnt[h];
+                if (cnt > best_cnt && cnt >= 4) {
+                    best = h;
+                    best_cnt = cnt;
+                    const double w = (double)cnt / (double)n;
+                    const double miss = 1.0 - w * w * w * w, target = 1.0 - (double)confidence;
+                    double prod = 1.0;
+                    int k = 0;
+                    while (prod > target && k < iters) { prod *= miss; k++; }
+                    if (k < niters) niters = k;
+                }
+            }
+            s_misc[0] = best;
+            s_misc[1] = best_cnt;
+        }
+        __syncthreads();
+        best = s_misc[0];
+        best_cnt = s_misc[1];
+        if (best < 0) {
+            if (tid < 12) po[tid] = net_pose ? net_pose[b * 12 + tid] : -100.f;
+            if (tid == 0) { n_inliers[b] = 0; best_hyp[b] = -1; }
+            return;
+        }
+        if (tid < 12) s_cur[tid] = s_pose[12 * best + tid];
+    } else {
+        if (tid < 12) s_cur[tid] = (double)net_pose[b * 12 + tid];
+    }
+    __syncthreads();
+
+    // ---- phase 4: inlier mask of the winner (mode 2: every correspondence takes part), Gauss-Newton refit
+    unsigned use_bits[(16384 / PNP_THREADS + 31) / 32 + 1];  // this thread's points (i = tid + k * PNP_THREADS): inlier flags
+#pragma unroll
+    for (int q = 0; q < (int)(sizeof(use_bits) / 4); q++) use_bits[q] = 0u;
+    {
+        double R[9], t[3];
+#pragma unroll
+        for (int i = 0; i < 9; i++) R[i] = s_cur[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) t[i] = s_cur[9 + i];
+        int k = 0;
+        for (int i = tid; i < n; i += PNP_THREADS, k++) {
+            const bool in = mode == 2 ? true : reproj_err2(R, t, K4, s_mp + 3 * i, s_ip + 2 * i) < thr2;
+            if (in) use_bits[k >> 5] |= 1u << (k & 31);
+            if (mode != 2 && in) msk[i] = 1;
+        }
+    }
+    for (int it = 0; it < PNP_REFIT_ITERS; it++) {
+        double R[9], t[3];
+#pragma unroll
+        for (int i = 0; i < 9; i++) R[i] = s_cur[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) t[i] = s_cur[9 + i];
+        double acc[27];  // 21 upper entries of H (row-major over r <= c) + 6 of g
+#pragma unroll
+        for (int q = 0; q < 27; q++) acc[q] = 0.0;
+        int k = 0;
+        for (int i = tid; i < n; i += PNP_THREADS, k++) {
+            if (!((use_bits[k >> 5] >> (k & 31)) & 1u)) continue;
+            const float* p = s_mp + 3 * i;
+            const double rp[3] = {R[0] * p[0] + R[1] * p[1] + R[2] * p[2], R[3] * p[0] + R[4] * p[1] + R[5] * p[2], R[6] * p[0] + R[7] * p[1] + R[8] * p[2]};
+            const double X = rp[0] + t[0], Y = rp[1] + t[1], Z = rp[2] + t[2];
+            if (!(Z > 0.0)) continue;
+            const double iz = 1.0 / Z;
+            const double ru = K4[0] * X * iz + K4[2] - (double)s_ip[2 * i], rv = K4[1] * Y * iz + K4[3] - (double)s_ip[2 * i + 1];
+            const double a0 = K4[0] * iz, a2 = -K4[0] * X * iz * iz, b1 = K4[1] * iz, b2 = -K4[1] * Y * iz * iz;
+            double Ju[6], Jv[6];
+            Ju[0] = a2 * rp[1];               Ju[1] = a0 * rp[2] - a2 * rp[0];  Ju[2] = -a0 * rp[1];
+            Jv[0] = -b1 * rp[2] + b2 * rp[1]; Jv[1] = -b2 * rp[0];              Jv[2] = b1 * rp[0];
+            Ju[3] = a0; Ju[4] = 0.0; Ju[5] = a2;
+            Jv[3] = 0.0; Jv[4] = b1; Jv[5] = b2;
+            int q = 0;
+#pragma unroll
+            for (int r = 0; r < 6; r++) {
+#pragma unroll
+                for (int c = r; c < 6; c++) acc[q++] += Ju[r] * Ju[c] + Jv[r] * Jv[c];
+                acc[21 + r] += Ju[r] * ru + Jv[r] * rv;
+            }
+        }
+        pnp_block_sum<27>(acc, s_red);
+        if (tid == 0) {
+            double H[6][6], g[6];
+            int q = 0;
+            for (int r = 0; r < 6; r++)
+                for (int c = r; c < 6; c++) H[r][c] = acc[q++];
+            double trc = 0.0;
+            for (int r = 0; r < 6; r++) { trc += H[r][r]; g[r] = acc[21 + r]; }
+            for (int r = 0; r < 6; r++) {
+                H[r][r] += 1e-12 * trc;
+                for (int c = 0; c < r; c++) H[r][c] = H[c][r];
+            }
+            if (pnp_solve6(H, g)) {
+                const double a[3] = {-0.5 * g[0], -0.5 * g[1], -0.5 * g[2]};
+                const double aa = dot3(a, a), inv = 1.0 / (1.0 + aa);
+                const double C[9] = {(1.0 - aa + 2.0 * a[0] * a[0]) * inv, (2.0 * a[0] * a[1] - 2.0 * a[2]) * inv, (2.0 * a[0] * a[2] + 2.0 * a[1]) * inv,
+                                     (2.0 * a[1] * a[0] + 2.0 * a[2]) * inv, (1.0 - aa + 2.0 * a[1] * a[1]) * inv, (2.0 * a[1] * a[2] - 2.0 * a[0]) * inv,
+                                     (2.0 * a[2] * a[0] - 2.0 * a[1]) * inv, (2.0 * a[2] * a[1] + 2.0 * a[0]) * inv, (1.0 - aa + 2.0 * a[2] * a[2]) * inv};
+                for (int i = 0; i < 3; i++)
+                    for (int j = 0; j < 3; j++) s_cur[i * 3 + j] = C[i * 3] * R[j] + C[i * 3 + 1] * R[3 + j] + C[i * 3 + 2] * R[6 + j];
+                s_cur[9] = t[0] - g[3]; s_cur[10] = t[1] - g[4]; s_cur[11] = t[2] - g[5];
+                s_misc[2] = 1;
+            } else {
+                s_misc[2] = 0;
+            }
+        }
+        __syncthreads();
+        if (!s_misc[2]) break;  // uniform
+    }
+    if (mode == 2) {  // inliers of the refined pose
+        double R[9], t[3];
+#pragma unroll
+        for (int i = 0; i < 9; i++) R[i] = s_cur[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) t[i] = s_cur[9 + i];
+        double c[1] = {0.0};
+        for (int i = tid; i < n; i += PNP_THREADS)
+            if (reproj_err2(R, t, K4, s_mp + 3 * i, s_ip + 2 * i) < thr2) { msk[i] = 1; c[0] += 1.0; }
+        pnp_block_sum<1>(c, s_red);
+        best_cnt = (int)c[0];
+        best = 0;
+    }
+    if (tid == 0) {
+        n_inliers[b] = best_cnt;
+        best_hyp[b] = best;
+        for (int i = 0; i < 12; i++) po[i] = (float)s_cur[i];
+        if (net_pose) {  // "translation error too large" guard (gdrn_evaluator.py:293-296): keep the network's t
+            double d2 = 0.0;
+            for (int i = 0; i < 3; i++) { const double dt = (double)po[9 + i] - (double)net_pose[b * 12 + 9 + i]; d2 += dt * dt; }
+            if (sqrt(d2) > (double)max_t_diff)
+                for (int i = 0; i < 3; i++) po[9 + i] = net_pose[b * 12 + 9 + i];
+        }
+    }
+}
+
+size_t pnp_smem_bytes(int HW)
+{
+    size_t s = sizeof(double) * (PNP_WAVES * 27 + 12 * PNP_MAX_ITERS + 12) + sizeof(int) * (PNP_MAX_ITERS + 4) + sizeof(float) * 5 * (size_t)HW;
+    return (s + 15) & ~(size_t)15;
+}
+
+}  // namespace
+
+// image_points [B,HW,2] / model_points [B,HW,3] / counts [B]: the output of rdpn6d_select_correspondences_f32; cams [B,9];
+// net_pose [B,12] or NULL.  mode 0: RANSAC (TEST.PNP_TYPE = "ransac_pnp"); 1: the network pose is hypothesis 0
+// ("net_ransac_pnp", 20 iterations in the reference); 2: Gauss-Newton from the network pose over all correspondences
+// ("net_iter_pnp").  inlier_mask [B,HW] is indexed like the correspondence lists.
+extern "C" int rdpn6d_ransac_pnp_f32(const float* image_points, const float* model_points, const int* counts, const float* cams,
+                                     const float* net_pose, int B, int HW, float reproj_thr, int iters, float confidence, unsigned seed,
+                                     int mode, float max_t_diff, float* pose_out, int* n_inliers, unsigned char* inlier_mask,
+                                     int* best_hyp, void* stream)
+{
+    RD_REQUIRE(image_points && model_points && counts && cams && pose_out && n_inliers && inlier_mask && best_hyp, "null pointer");
+    RD_REQUIRE(B > 0 && HW > 0 && HW <= 6400, "HW must be in 1..6400 (LDS-resident correspondences)");
+    RD_REQUIRE(mode >= 0 && mode <= 2 && (mode == 0 || net_pose), "mode 0 | 1 | 2 (1 and 2 need the network pose)");
+    RD_REQUIRE(iters >= 1 && iters <= PNP_MAX_ITERS && reproj_thr > 0.f && confidence > 0.f && confidence < 1.f, "iterations / thresholds");
+    RD_REQUIRE(mode == 0 || max_t_diff > 0.f, "max_t_diff");
+    RD_REQUIRE(pose_out != net_pose, "pose_out must not alias net_pose");
+    const size_t smem = pnp_smem_bytes(HW);
+    RD_REQUIRE(smem <= 160 * 1024, "correspondences do not fit the 160 KiB LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ransac_pnp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(ransac_pnp_kernel, dim3(B), dim3(PNP_THREADS), smem, (hipStream_t)stream, image_points, model_points, counts, cams,
+                       net_pose, HW, reproj_thr, iters, confidence, seed, mode, max_t_diff, pose_out, n_inliers, inlier_mask, best_hyp);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}

@@ -810,6 +810,29 @@ class InferencePlan:
             self._graphs[key] = g
         g.replay()
 
+    def run_pnp2d(self, roi_coord_2d, roi_extents, roi_cams, im_hw, uv_channels, mask_thr=0.5, reproj_thr=3.0, iters=100, confidence=0.99,
+                  seed=0, net_mode=0, max_t_diff=1.0):
+        """the reference's classical solve on the maps the last run() left in out_nchw: correspondence selection exactly as
+        get_img_model_points_with_coords2d (row A8, bit-exact) + per-crop 2D-3D RANSAC-PnP (rows A9 / A10)"""
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        B, C = self.B, self.out_nchw.shape[1]
+        HW = self.out_nchw.shape[2] * self.out_nchw.shape[3]
+        ip, mp = self.buf("pnp2d_ip", B, HW, 2), self.buf("pnp2d_mp", B, HW, 3)
+        cnt = self.buf("pnp2d_cnt", B, dtype=torch.int32)
+        _lib.check(self.lib.rdpn6d_select_correspondences_f32(
+            _ptr(self.out_nchw), C, _ptr(roi_coord_2d), roi_coord_2d.shape[1], uv_channels[0], uv_channels[1], _ptr(roi_extents), None,
+            int(im_hw[0]), int(im_hw[1]), B, HW, mask_thr, _ptr(ip), _ptr(mp), _ptr(cnt), None, None, st), "select_correspondences")
+        netp = None
+        if net_mode:
+            netp = self.buf("net_pose", B, 12)
+            netp[:, :9].copy_(self.rot.view(B, 9))
+            netp[:, 9:].copy_(self.trans)
+        cams = roi_cams.reshape(B, 9)
+        _lib.check(self.lib.rdpn6d_ransac_pnp_f32(_ptr(ip), _ptr(mp), _ptr(cnt), _ptr(cams), _ptr(netp), B, HW, reproj_thr, iters, confidence,
+                                                  seed, net_mode, max_t_diff, _ptr(self.pnp_pose), _ptr(self.pnp_ninl), _ptr(self.pnp_mask),
+                                                  _ptr(self.pnp_best), st), "ransac_pnp")
+        self.pnp_counts = cnt
+
     def run_ransac(self, roi_coord_2d, fps, roi_extents, resize_ratios, mask_thr=0.5, inlier_thr=0.01, iters=100,
                    confidence=0.99, seed=0, net_mode=0, max_t_diff=1.0):
         """per-crop RANSAC + Kabsch on the maps the last run() left in out_nchw / argmax.  net_mode 1 / 2 = the
@@ -970,18 +993,31 @@ class GDRN(nn.Module):
         tcfg = self.cfg.get("TEST", {})
         use_pnp = bool(tcfg.get("USE_PNP", False))
         if use_pnp:
-            pnp_type = str(tcfg.get("PNP_TYPE", "ransac_pnp")).lower()  # the three choices of gdrn_evaluator.py:136-145
-            if pnp_type not in ("ransac_pnp", "net_ransac_pnp", "net_iter_pnp"):
-                raise NotImplementedError(f"TEST.PNP_TYPE={pnp_type!r}: ransac_pnp | net_ransac_pnp | net_iter_pnp")
-            net_mode = {"ransac_pnp": 0, "net_ransac_pnp": 1, "net_iter_pnp": 2}[pnp_type]
+            # the three choices of gdrn_evaluator.py:136-145 = the reference's 2D-3D solve (reprojection error, P3P / Gauss-Newton:
+            # rdpn6d_ransac_pnp_f32), and the same three on the RGB-D residual geometry P - delta = R anchor + t (3D-3D Kabsch,
+            # rdpn6d_ransac_kabsch_*: what the north star names; no reference counterpart)
+            pnp_type = str(tcfg.get("PNP_TYPE", "ransac_pnp")).lower()
+            modes = {"ransac_pnp": 0, "net_ransac_pnp": 1, "net_iter_pnp": 2, "ransac_kabsch": 0, "net_ransac_kabsch": 1, "net_iter_kabsch": 2}
+            if pnp_type not in modes:
+                raise NotImplementedError(f"TEST.PNP_TYPE={pnp_type!r}: one of {sorted(modes)}")
+            net_mode, kabsch = modes[pnp_type], pnp_type.endswith("kabsch")
             assert roi_extents is not None, "USE_PNP needs roi_extents"
             roi_extents = f32c(roi_extents)
         is_allo = "allo" in pcfg.ROT_TYPE
 
         def launch():
             plan.run(x, roi_coord_2d, fps, roi_cams, roi_centers, roi_whs, resize_ratios, is_allo=is_allo)
-            if use_pnp:
-                # the reference leaves "TODO: move the pnp/ransac inside forward" (GDRN.py:294); here it is inside:
+            if use_pnp and not kabsch:
+                # the reference leaves "TODO: move the pnp/ransac inside forward" (GDRN.py:294); here it is inside: selection +
+                # 2D-3D RANSAC-PnP with the call sites' parameters (3 px, 100 | 20 iterations: gdrn_evaluator.py:275,386-389)
+                c2 = roi_coord_2d.shape[1]
+                plan.run_pnp2d(roi_coord_2d, roi_extents, roi_cams, (int(tcfg.get("IM_H", 480)), int(tcfg.get("IM_W", 640))),
+                               tuple(tcfg.get("PNP_COORD2D_CHANNELS", (c2 - 2, c2 - 1))),  # RDPN: [depth xyz | u v]; the call site's "as given" = (0, 1)
+                               mask_thr=float(self.cfg.MODEL.CDPN.ROT_HEAD.MASK_THR_TEST),
+                               reproj_thr=float(tcfg.get("PNP_REPROJ_THR", 3.0)), iters=int(tcfg.get("PNP_ITERS", 20 if net_mode == 1 else 100)),
+                               confidence=float(tcfg.get("PNP_CONFIDENCE", 0.99)), seed=int(tcfg.get("PNP_SEED", 0)), net_mode=net_mode,
+                               max_t_diff=float(tcfg.get("PNP_MAX_T_DIFF", 1.0)))
+            elif use_pnp:
                 # per-crop RANSAC + Kabsch on the residual correspondences, result next to the learned pose
                 plan.run_ransac(roi_coord_2d, fps, roi_extents, resize_ratios,
                                 mask_thr=float(self.cfg.MODEL.CDPN.ROT_HEAD.MASK_THR_TEST),
@@ -1010,6 +1046,8 @@ class GDRN(nn.Module):
         if use_pnp:
             out.update({"pnp_pose": plan.pnp_pose.clone(),
                         "pnp_num_inliers": plan.pnp_ninl.clone(), "pnp_inlier_mask": plan.pnp_mask.clone()})
+            if not kabsch:  # the 2D-3D solve's mask is indexed like the selected correspondence list (gdrn_evaluator.py:119-120)
+                out["pnp_num_points"] = plan.pnp_counts.clone()
         return out
 
 

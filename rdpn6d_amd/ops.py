@@ -284,6 +284,30 @@ def ransac_kabsch(out_nchw, coord2d, fps, extents, resize_ratios, region_argmax,
     return pose, nin, mask, best
 
 
+def ransac_pnp(image_points, model_points, counts, cams, reproj_thr=3.0, iters=100, confidence=0.99, seed=0, net_pose=None,
+               net_mode="ransac", max_t_diff=1.0):
+    """2D-3D RANSAC-PnP per crop (rdpn6d_ransac_pnp_f32; the role of misc.pnp_v2 -> cv2.solvePnPRansac(EPnP, 3 px, 100 iterations) at
+    gdrn_evaluator.py:316-435).  image_points [B,HW,2] px, model_points [B,HW,3] m, counts [B] int32 from
+    select_correspondences; cams [B,3,3].  With net_pose [B,12]: net_mode "ransac" = the learned pose is hypothesis 0, "iter" =
+    Gauss-Newton from it over all correspondences (process_net_and_pnp).  Returns pose [B,12] (R row-major | t; -100 when fewer
+    than 4 correspondences), n_inliers [B], inlier_mask [B,HW] (indexed like the lists), best_hyp [B]."""
+    _need_gpu(image_points, model_points, counts, cams)
+    B, HW = image_points.shape[0], image_points.shape[1]
+    dev = image_points.device
+    pose = torch.empty(B, 12, dtype=torch.float32, device=dev)
+    nin = torch.empty(B, dtype=torch.int32, device=dev)
+    mask = torch.empty(B, HW, dtype=torch.uint8, device=dev)
+    best = torch.empty(B, dtype=torch.int32, device=dev)
+    args = [image_points.float().contiguous(), model_points.float().contiguous(), counts.contiguous(), cams.float().reshape(B, 9).contiguous()]
+    assert args[2].dtype == torch.int32
+    npz = net_pose.float().contiguous() if net_pose is not None else None
+    mode = 0 if net_pose is None else {"ransac": 1, "iter": 2}[net_mode]
+    _lib.check(_lib.load().rdpn6d_ransac_pnp_f32(*[_ptr(t) for t in args], _ptr(npz), B, HW, float(reproj_thr), int(iters), float(confidence),
+                                                 int(seed), mode, float(max_t_diff), _ptr(pose), _ptr(nin), _ptr(mask), _ptr(best), _stream()),
+               "ransac_pnp")
+    return pose, nin, mask, best
+
+
 def region_targets(xyz_hwc, fps64, rot, extent):
     """Training targets on device (data_utils.xyz_to_region + data_loader.py:881-903): xyz_hwc [B,H,W,3] f32 model-space
     crop, fps64 [B,K,3] float64 anchors, rot [B,3,3], extent [B,3] -> roi_xyz [B,3,H,W] f32, roi_region [B,H,W] int64."""

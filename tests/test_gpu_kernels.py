@@ -397,12 +397,12 @@ def test_model_use_pnp_matches_oracle_on_model_maps(golden_setup, dev, oracle_li
 
     models, t, _ = golden_setup
     model = models["none"]
-    model.cfg.TEST.USE_PNP = True
+    model.cfg.TEST.USE_PNP, model.cfg.TEST.PNP_TYPE = True, "ransac_kabsch"
     model.cfg.TEST.PNP_INLIER_THR = 0.05
     try:
         o = _run(model, t)
     finally:
-        model.cfg.TEST.USE_PNP = False
+        model.cfg.TEST.USE_PNP, model.cfg.TEST.PNP_TYPE = False, "ransac_pnp"
     plan = model.plan(4, dev)
     c = dict(out_nchw=plan.out_nchw.cpu().numpy().reshape(4, 37, 4096), coord2d=t["roi_coord_2d"].cpu().numpy().reshape(4, 5, 4096),
              fps=t["fps"].cpu().numpy(), extents=t["roi_extent"].cpu().numpy(), ratios=t["resize_ratio"].cpu().numpy(),
@@ -714,7 +714,7 @@ def test_ransac_net_initialised_bit_exact_vs_oracle(dev, oracle_lib, mode, iters
     assert np.array_equal(pose[3].cpu().numpy(), net[3]) and np.array_equal(pose[2, 9:].cpu().numpy(), net[2, 9:])
 
 
-@pytest.mark.parametrize("pnp_type", ["net_ransac_pnp", "net_iter_pnp"])
+@pytest.mark.parametrize("pnp_type", ["net_ransac_kabsch", "net_iter_kabsch"])
 def test_model_pnp_type_net_variants(golden_setup, dev, oracle_lib, pnp_type):
     """cfg.TEST.PNP_TYPE (gdrn_evaluator.py:136-145) inside GDRN.forward: equals the C oracle run on the model's own maps and
     its own decoded pose."""
@@ -732,7 +732,7 @@ def test_model_pnp_type_net_variants(golden_setup, dev, oracle_lib, pnp_type):
              fps=t["fps"].cpu().numpy(), extents=t["roi_extent"].cpu().numpy(), ratios=t["resize_ratio"].cpu().numpy(),
              argmax=plan.argmax.cpu().numpy(), B=4, HW=4096, K=32)
     net = np.concatenate([o["rot"].cpu().numpy().reshape(4, 9), o["trans"].cpu().numpy()], 1)
-    po, ni, mo, bo = run_oracle_net(oracle_lib, c, net, mode=1 if pnp_type == "net_ransac_pnp" else 2, inlier_thr=0.05, iters=20, seed=0)
+    po, ni, mo, bo = run_oracle_net(oracle_lib, c, net, mode=1 if pnp_type == "net_ransac_kabsch" else 2, inlier_thr=0.05, iters=20, seed=0)
     assert np.array_equal(o["pnp_num_inliers"].cpu().numpy(), ni) and np.array_equal(o["pnp_inlier_mask"].cpu().numpy(), mo)
     assert np.abs(o["pnp_pose"].cpu().numpy() - po).max() < 1e-4
 

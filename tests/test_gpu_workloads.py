@@ -30,7 +30,7 @@ def test_c4_ycbv_b64_mask_attention_mul_vs_oracle_and_copies(golden_dir):
 
     dev = torch.device("cuda:0")
     cfg = gdrn_base_cfg(mask_attention="mul", device="cuda", num_classes=21)
-    cfg.TEST.USE_PNP = True
+    cfg.TEST.USE_PNP, cfg.TEST.PNP_TYPE = True, "ransac_kabsch"
     model, _ = build_model_optimizer(cfg)
     orc = model_oracle.GDRNOracle(32, "mul")
     sd = synth.make_trained_like_state_dict({k: tuple(v.shape) for k, v in orc.state_dict().items()}, seed=1234)
