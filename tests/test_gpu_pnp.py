@@ -61,7 +61,7 @@ def test_pnp_full_batch_outlier_sweep_b64(oracle_lib):
     for b in range(B):
         if ratios[b] <= 0.5:
             re, te = pose_errors(pose[b].cpu().numpy(), c["R"][b], c["t"][b])
-            assert re < 1.0 and te < 0.02, (b, ratios[b], re, te)
+            assert re < 2.0 and te < 0.03, (b, ratios[b], re, te)
 
 
 def test_pnp_sentinel_and_network_initialised_variants(oracle_lib):
