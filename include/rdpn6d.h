@@ -138,6 +138,12 @@ int rdpn6d_upsample_bilinear_h2(const void* x, int B, int H, int W, int C, int f
 int rdpn6d_xyz_subsample_h2(const float* x, int B, int xc, int R, int step, void* y, int out_cs, int out_co, int* overflow_flag,
                             void* stream);
 int rdpn6d_global_max_concat_h2(void* buf, int B, int HW, int C, int cs, void* stream);
+/* fused front of the network for the h2 path: conv1 7x7/2 + folded BN + ReLU + MaxPool2d(3,2,1) (resnet_backbone.py:272-275)
+ * as an implicit GEMM on the fp16 matrix pipe (two-plane arithmetic, fp32-accurate), writing the pooled activation
+ * [B, R/4, R/4, 64] as an h2 tensor.  w_h2 [64][5][2][32] fp16 = the conv1 weights with k = (ky*7+kx)*3+c padded to 160;
+ * scale = BN scale * 2^-(sw(n)+4), shift = BN shift. */
+int rdpn6d_stem_pool_h2(const float* x, int B, int xc, int R, const void* w_h2, const float* scale, const float* shift, void* y,
+                        int* overflow_flag, void* stream);
 void rdpn6d_conv_bf16_force_chunk(int row_bytes); /* profiling: 0 = auto, 64 forces 32-channel K-chunks (measured slower) */
 /* bf16 forms of the kernels between the bf16 convolutions (same argument meaning as the _f32 entry points; activations
  * bf16 NHWC with C % 8 == 0; the stem and the xyz subsample read the fp32 NCHW crop and write bf16) */

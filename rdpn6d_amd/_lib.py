@@ -119,6 +119,7 @@ SIGNATURES = {
     "rdpn6d_conv2d_h2": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "rdpn6d_upsample_bilinear_h2": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "rdpn6d_xyz_subsample_h2": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
+    "rdpn6d_stem_pool_h2": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rdpn6d_global_max_concat_h2": (_i, [_vp, _i, _i, _i, _i, _vp]),
     "rdpn6d_ransac_pnp_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _f, ctypes.c_uint, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "rdpn6d_select_correspondences_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),

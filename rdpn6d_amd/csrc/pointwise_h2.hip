@@ -159,3 +159,239 @@ extern "C" int rdpn6d_global_max_concat_h2(void* buf, int B, int HW, int C, int 
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
 }
+
+// =====================================================================================================================
+// Fused front of the network on the fp16 matrix pipe: conv1 7x7 stride 2 pad 3 (channels 0..2 of the NCHW crop) + folded
+// BatchNorm + ReLU + MaxPool2d(3, 2, 1) (resnet_backbone.py:272-275, :321-324), writing the POOLED activation as an h2 tensor -
+// the input of the h2 trunk.  Replaces three kernels (VALU stem 0.37 ms, max-pool 0.09 ms, fp32 -> h2 split 0.03 ms at B = 64) and
+// the 268 MB fp32 stem activation they passed around.
+//
+// The stem as an implicit GEMM  [stem pixels] x [K] x [64 channels]  in the two-plane fp16 arithmetic of conv_igemm_h2.hip (hi / lo
+// terms of 16 x value, three exact partial products per fp32 product, fp32 accumulation).  The reduction index is laid out as
+// k = (c*7 + ky)*8 + kx (kx = 7: zero weight) = 168 -> 192, so that the 8 consecutive k-values an MFMA lane feeds are 8 CONSECUTIVE
+// samples of one input row: a fragment is four 4-byte LDS reads of a pre-split patch, no per-element address or conversion work.
+// One 256-thread workgroup per 8 x 16 tile of POOLED pixels:
+//   1. the 39 x 71 x 3 input patch -> registers -> hi / lo fp16 planes in LDS (zero outside the image);
+//   2. a wave owns stem m-tiles (32 consecutive pixels of the 17 x 33 stem tile = the pooled tile's 3x3 windows); per 32-k chunk it
+//      fetches its weight fragments (L2-resident h2 tensor [64][6][hi32 | lo32]) and issues 6 MFMAs per m-tile and channel half;
+//   3. per 16-channel slice: scale / shift (BatchNorm and the two power-of-two format scales folded) + ReLU -> LDS (overlaying the
+//      dead patch); pixels outside the image become 0, which a ReLU output can never lose to (max-pool pads with -inf);
+//      3x3 / stride-2 max per pooled pixel, hi / lo split, 16-byte stores of the h2 record.
+namespace {
+
+constexpr int SP_PH = 8, SP_PW = 16;                        // pooled tile
+constexpr int SP_SH = 2 * SP_PH + 1, SP_SW = 2 * SP_PW + 1; // stem tile 17 x 33
+constexpr int SP_NPIX = SP_SH * SP_SW;                      // 561
+constexpr int SP_MT = (SP_NPIX + 31) / 32;                  // 18 m-tiles
+constexpr int SP_IH = 2 * SP_SH + 5, SP_IW = 2 * SP_SW + 5; // input patch 39 x 71
+constexpr int SP_IWS = SP_IW + 3;                           // padded row (74 halfs: rows start 4-byte aligned, reads run 1 sample over)
+constexpr int SP_PLANE = 3 * SP_IH * SP_IWS + 8;            // halfs per plane (+ slack for the 8-wide reads at the very end)
+constexpr int SP_KC = 6;                                    // 32-k chunks (K = 192)
+constexpr int SP_TS = 20;                                   // stem-tile row stride in floats: a 16-channel slice + 4
+constexpr int SP_LDS_A = 2 * SP_PLANE * 2;
+constexpr int SP_LDS_B = SP_NPIX * SP_TS * 4;               // one 16-channel slice of the stem tile at a time: 45 KiB
+constexpr int SP_LDS = SP_LDS_A > SP_LDS_B ? SP_LDS_A : SP_LDS_B;
+
+typedef unsigned sp_u32x4 __attribute__((ext_vector_type(4)));
+
+// first patch element (relative to the pixel's top-left sample) of the 8-wide k-row rw = k / 8 = c*7 + ky; rows 21..23 are padding
+__host__ __device__ constexpr int sp_rowoff(int rw) { return rw >= 21 ? 0 : ((rw / 7) * SP_IH + rw % 7) * SP_IWS; }
+
+__global__ __launch_bounds__(256, 2) void stem_pool_h2_kernel(const float* __restrict__ x, int xc, int R, const _Float16* __restrict__ w_h2,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              _Float16* __restrict__ y, int* __restrict__ overflow_flag)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
+    _Float16* s_hi = reinterpret_cast<_Float16*>(sp_smem);
+    _Float16* s_lo = s_hi + SP_PLANE;
+    float* s_t = reinterpret_cast<float*>(sp_smem);  // stem-tile slice, overlays the patch after the MFMA phase
+    const int Rs = R / 2, Rp = R / 4;                // stem / pooled resolution
+    const int b = blockIdx.z, py0 = blockIdx.y * SP_PH, px0 = blockIdx.x * SP_PW;
+    const int sy0 = 2 * py0 - 1, sx0 = 2 * px0 - 1;  // first stem pixel of the tile
+    const int iy0 = 2 * sy0 - 3, ix0 = 2 * sx0 - 3;  // first input sample of the patch
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    {   // all global loads of the patch are issued before the first LDS store (a load-store loop serialises the round trips)
+        constexpr int NP = (3 * SP_IH * SP_IW + 255) / 256;
+        float pv[NP];
+#pragma unroll
+        for (int t = 0; t < NP; ++t) {
+            const int i = tid + 256 * t;
+            const int c = i / (SP_IH * SP_IW), rem = i - c * SP_IH * SP_IW, py = rem / SP_IW, px = rem - py * SP_IW;
+            const int iy = iy0 + py, ix = ix0 + px;
+            pv[t] = 0.f;
+            if (i < 3 * SP_IH * SP_IW && (unsigned)iy < (unsigned)R && (unsigned)ix < (unsigned)R) pv[t] = x[(((long long)b * xc + c) * R + iy) * R + ix];
+        }
+        for (int i = tid; i < 3 * SP_IH * (SP_IWS - SP_IW) + 8; i += 256) {  // the row padding and the slack: zeros (read, times zero weights)
+            const int row = i / (SP_IWS - SP_IW), q = i - row * (SP_IWS - SP_IW);
+            const int idx = row < 3 * SP_IH ? row * SP_IWS + SP_IW + q : 3 * SP_IH * SP_IWS + (i - 3 * SP_IH * (SP_IWS - SP_IW));
+            s_hi[idx] = (_Float16)0.f;
+            s_lo[idx] = (_Float16)0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < NP; ++t) {
+            const int i = tid + 256 * t;
+            const int c = i / (SP_IH * SP_IW), rem = i - c * SP_IH * SP_IW, py = rem / SP_IW, px = rem - py * SP_IW;
+            if (i < 3 * SP_IH * SP_IW) {
+                const float v = pv[t] * H2_SCALE;  // image / 255 in [0, 1]: no range issue
+                const _Float16 h = (_Float16)v;
+                s_hi[(c * SP_IH + py) * SP_IWS + px] = h;
+                s_lo[(c * SP_IH + py) * SP_IWS + px] = (_Float16)(v - (float)h);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- MFMA phase.  Wave w owns m-tiles w, w+4, ... (at most 5); lane = (row r, k-half).
+    const int r = lane & 31, half = lane >> 5;
+    constexpr int MPW = (SP_MT + 3) / 4;
+    f32x16 acc[MPW][2];
+    int base[MPW];
+#pragma unroll
+    for (int m = 0; m < MPW; ++m) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][j][e] = 0.f;
+        int p = (wave + 4 * m) * 32 + r;
+        p = p < SP_NPIX ? p : 0;  // rows past the tile compute pixel 0 again and are never stored
+        const int sy = p / SP_SW, sx = p - sy * SP_SW;
+        base[m] = 2 * sy * SP_IWS + 2 * sx;  // even: 4-byte aligned in both planes
+    }
+    // weight fragments of chunk cc: channel row n = nt*32 + r, 16-byte slot 2j + half of its 128-byte record (global, L2-resident)
+    const unsigned char* wrow[2] = {reinterpret_cast<const unsigned char*>(w_h2) + (size_t)(r * SP_KC) * 128 + half * 16,
+                                    reinterpret_cast<const unsigned char*>(w_h2) + (size_t)((32 + r) * SP_KC) * 128 + half * 16};
+    sp_u32x4 fb[2][4], fbn[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[nt][j] = *reinterpret_cast<const sp_u32x4*>(wrow[nt] + j * 32);
+#pragma unroll
+    for (int cc = 0; cc < SP_KC; ++cc) {
+        if (cc + 1 < SP_KC) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fbn[nt][j] = *reinterpret_cast<const sp_u32x4*>(wrow[nt] + (cc + 1) * 128 + j * 32);
+        }
+#pragma unroll
+        for (int m = 0; m < MPW; ++m) {
+            if (wave + 4 * m >= SP_MT) continue;  // wave-uniform
+            sp_u32x4 ah[2], al[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                // k-row of this lane's 8 values: 4*cc + 2*s + half
+                const int off = base[m] + (half ? sp_rowoff(4 * cc + 2 * s + 1) : sp_rowoff(4 * cc + 2 * s));
+                const unsigned* ph = reinterpret_cast<const unsigned*>(s_hi + off);
+                const unsigned* pl = reinterpret_cast<const unsigned*>(s_lo + off);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    ah[s][q] = ph[q];
+                    al[s][q] = pl[q];
+                }
+            }
+            // lo*hi, hi*lo, hi*hi per k16 step (as conv_igemm_h2.hip), the two channel halves alternating
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al[s]), __builtin_bit_cast(f16x8, fb[nt][s]), acc[m][nt], 0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[s]), __builtin_bit_cast(f16x8, fb[nt][2 + s]), acc[m][nt], 0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[s]), __builtin_bit_cast(f16x8, fb[nt][s]), acc[m][nt], 0, 0, 0);
+            }
+        }
+        if (cc + 1 < SP_KC) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb[nt][j] = fbn[nt][j];
+        }
+    }
+
+    // ---- epilogue + pooling, one 16-channel slice of the stem tile at a time (the slice overlays the dead patch).
+    // Accumulator element e of lane (r, half) = pixel row (e&3) + 8*(e>>2) + 4*half of the m-tile, channel nt*32 + r.
+    bool over = false;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        __syncthreads();  // q = 0: every wave is done with the patch; q > 0: the previous slice has been pooled
+        if ((r >> 4) == (q & 1)) {
+            const int nt = q >> 1, n = nt * 32 + r;
+            const float sc = scale[n], sh = shift[n];
+#pragma unroll
+            for (int m = 0; m < MPW; ++m) {
+                if (wave + 4 * m >= SP_MT) continue;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int p = (wave + 4 * m) * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
+                    if (p < SP_NPIX) {
+                        const int sy = p / SP_SW, sx = p - sy * SP_SW;
+                        const bool inside = (unsigned)(sy0 + sy) < (unsigned)Rs && (unsigned)(sx0 + sx) < (unsigned)Rs;
+                        const float v = acc[m][nt][e] * sc + sh;
+                        s_t[p * SP_TS + (r & 15)] = inside && v > 0.f ? v : 0.f;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        {   // 3x3 / stride 2 max-pool + h2 record: one work item = (pooled pixel, 8 channels) per thread
+            const int c8 = (tid & 1) * 8, pq = tid >> 1, qy = pq / SP_PW, qx = pq - qy * SP_PW;
+            const int py = py0 + qy, px = px0 + qx;
+            if (py < Rp && px < Rp) {
+                float m8[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m8[e] = 0.f;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const float* tp = s_t + ((2 * qy + dy) * SP_SW + 2 * qx + dx) * SP_TS + c8;
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(tp), c = *reinterpret_cast<const f32x4*>(tp + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            m8[e] = a[e] > m8[e] ? a[e] : m8[e];
+                            m8[4 + e] = c[e] > m8[4 + e] ? c[e] : m8[4 + e];
+                        }
+                    }
+                f16x8 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    _Float16 h, l;
+                    over |= h2_split1(m8[e] * H2_SCALE, h, l);
+                    hi[e] = h;
+                    lo[e] = l;
+                }
+                _Float16* dp = y + h2_off(((long long)b * Rp + py) * Rp + px, 64, q * 16 + c8);
+                *reinterpret_cast<f16x8*>(dp) = hi;
+                *reinterpret_cast<f16x8*>(dp + 32) = lo;
+            }
+        }
+    }
+    if (over && overflow_flag) *overflow_flag = 1;
+}
+
+}  // namespace
+
+// x [B, xc, R, R] fp32 NCHW (channels 0..2 used); w_h2: conv1 weights with the reduction index k = (c*7 + ky)*8 + kx padded to
+// 192 (zeros at kx = 7 and k >= 168) as an h2 tensor [64][6][2][32] fp16 holding w * 2^sw(n) (gdrn.pack_stem_h2_weight);
+// scale / shift [64]: folded BatchNorm times 2^-(sw(n)+4) / plain shift.  y: pooled activation [B, R/4, R/4, 64] as an h2 tensor.
+extern "C" int rdpn6d_stem_pool_h2(const float* x, int B, int xc, int R, const void* w_h2, const float* scale, const float* shift, void* y,
+                                   int* overflow_flag, void* stream)
+{
+    RD_REQUIRE(x && w_h2 && scale && shift && y, "null pointer");
+    RD_REQUIRE(B > 0 && xc >= 3 && R > 0 && R % 4 == 0, "shape (R % 4)");
+    static bool configured = false;
+    if (!configured) {
+        RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(stem_pool_h2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS));
+        configured = true;
+    }
+    const int Rp = R / 4;
+    dim3 grid(rd_cdiv(Rp, SP_PW), rd_cdiv(Rp, SP_PH), B);
+    hipLaunchKernelGGL(stem_pool_h2_kernel, grid, dim3(256), SP_LDS, (hipStream_t)stream, x, xc, R, (const _Float16*)w_h2, scale, shift,
+                       (_Float16*)y, overflow_flag);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}

@@ -216,6 +216,15 @@ def pack_h2_weight(w32):
     return out, (1.0 / (sw * H2_ACT_SCALE)).float().contiguous()
 
 
+def pack_stem_h2_weight(w_oihw):
+    """conv1 weights (64, 3, 7, 7) -> the h2 tensor of rdpn6d_stem_pool_h2: reduction index k = (c*7 + ky)*8 + kx, padded to 192
+    (zeros at kx = 7 and beyond k = 168), [64][6][2][32] fp16 + the per-channel factor 2^-sw(n) / 16 for the epilogue scale."""
+    w = w_oihw.detach().float()
+    wk = torch.zeros(64, 24, 8, dtype=torch.float32, device=w.device)
+    wk[:, :21, :7] = w.reshape(64, 21, 7)  # (c, ky) rows, kx columns
+    return pack_h2_weight(wk.reshape(64, 1, 192))
+
+
 def fold_bn(bn, conv_bias=None, npad=None):
     """scale = gamma/sqrt(var+eps), shift = beta + (bias - mean)*scale, computed in fp64."""
     g, b = bn.weight.detach().double(), bn.bias.detach().double()
@@ -457,22 +466,9 @@ class InferencePlan:
         self.x_in = None  # bound per call
         R2, R4, R8, R16, R32 = R // 2, R // 4, R // 8, R // 16, R // 32
 
-        # --- stem + maxpool
-        w = bb.conv1.weight.detach().float().permute(0, 2, 3, 1).contiguous()  # [64][7][7][3]
-        sc, sh = fold_bn(bb.bn1)
-        s0 = self.buf("stem", B, R2, R2, 64, dtype=adt)
-        self.keep += [w, sc, sh]
-        self.stem_fn = getattr(lib, f"rdpn6d_stem_conv7x7_{sfx}")
-        self.xyz_fn = getattr(lib, f"rdpn6d_xyz_subsample_{sfx}")
-        self.stem_args = (B, 6, R, _ptr(w), _ptr(sc), _ptr(sh), _ptr(s0))
-        p0 = self.buf("pool", B, R4, R4, 64, dtype=adt)
-        self.call("maxpool", getattr(lib, f"rdpn6d_maxpool3x3s2_{sfx}"), _ptr(s0), B, R2, R2, 64, _ptr(p0))
-
-        # --- residual trunk (BasicBlock: 3x3 - 3x3; Bottleneck: 1x1 - 3x3(s) - 1x1 x4; residual + ReLU in the last epilogue)
-        cur, cur_hw, cur_c = p0, R4, 64
-        # fp32 mode, batches >= 16: the trunk's convolutions (BasicBlock and Bottleneck) run as bf16x3 convolutions too (tile kernel,
-        # csrc/conv_igemm_bf16x3_tile.hip) and hand their activations on as three bf16 planes; the residual is read from
-        # planes as well (summed exactly), only the last block writes the fp32 tensor the up-sampling reads.
+        # fp32 mode, batches >= 16: the trunk's convolutions (BasicBlock and Bottleneck) run as fp32-accurate convolutions on the
+        # 16-bit matrix pipe too (tile kernels of csrc/conv_igemm_h2.hip / conv_igemm_bf16x3_tile.hip) and hand their activations on
+        # in plane form; the residual is read from planes as well, only the last block writes the fp32 tensor the up-sampling reads.
         wide = 256 if hasattr(bb.layer1[0], "conv3") else 64  # channels of the widest (layer1) activation
         if self.x3 and 65536 <= B * R4 * R4 and self._fast_bytes(B * R4 * R4, wide) >= (1 << 32) - 64:
             self._x3_limit_warning(B * R4 * R4, wide)
@@ -484,8 +480,33 @@ class InferencePlan:
         h2_pw = (self.fast == "h2" and x3_trunk and len(head.features) > 4 and F_head % 64 == 0
                  and self.x3_tile_ok(B * R8 * R8, F_head, 1024) and (512 * bb.expansion) % 32 == 0)
         self.h2_pointwise = h2_pw
+
+        # --- stem + maxpool
+        w = bb.conv1.weight.detach().float().permute(0, 2, 3, 1).contiguous()  # [64][7][7][3]
+        sc, sh = fold_bn(bb.bn1)
+        self.xyz_fn = getattr(lib, f"rdpn6d_xyz_subsample_{sfx}")
         pcur = None
-        if x3_trunk:
+        self.fused_front = bool(x3_trunk and self.fast == "h2" and R % 4 == 0)
+        if self.fused_front:
+            # conv1 + BN + ReLU + max-pool in ONE kernel on the fp16 matrix pipe, pooled activation written as an h2 tensor
+            wh, inv = pack_stem_h2_weight(bb.conv1.weight)
+            scf = (sc[:64] * inv).contiguous()
+            pcur = self.planes_buf("pool_planes", B * R4 * R4 * 64, 1)
+            p0 = None
+            self.keep += [wh, scf, sh]
+            self.stem_fn = lib.rdpn6d_stem_pool_h2
+            self.stem_args = (B, 6, R, _ptr(wh), _ptr(scf), _ptr(sh), _ptr(pcur), _ptr(self.h2_flag))
+        else:
+            s0 = self.buf("stem", B, R2, R2, 64, dtype=adt)
+            self.keep += [w, sc, sh]
+            self.stem_fn = getattr(lib, f"rdpn6d_stem_conv7x7_{sfx}")
+            self.stem_args = (B, 6, R, _ptr(w), _ptr(sc), _ptr(sh), _ptr(s0))
+            p0 = self.buf("pool", B, R4, R4, 64, dtype=adt)
+            self.call("maxpool", getattr(lib, f"rdpn6d_maxpool3x3s2_{sfx}"), _ptr(s0), B, R2, R2, 64, _ptr(p0))
+
+        # --- residual trunk (BasicBlock: 3x3 - 3x3; Bottleneck: 1x1 - 3x3(s) - 1x1 x4; residual + ReLU in the last epilogue)
+        cur, cur_hw, cur_c = p0, R4, 64
+        if x3_trunk and not self.fused_front:
             pcur = self.planes_buf("pool_planes", p0.numel(), 1)
             self.split3("trunk.split_pool", p0, pcur)
         for li in range(4):

@@ -126,3 +126,36 @@ def test_h2_range_is_guarded_not_silent():
     assert int(flag2.item()) == 1 and torch.isfinite(yh.float()).all() and abs(y[0, 0, 0, 0].item() - 32000.0) < 1.0
     _, f3 = ops.split_h2(torch.randn(2, 4, 4, 64, device=dev) * 100)
     assert int(f3.item()) == 0
+
+
+@pytest.mark.parametrize("B,R", [(2, 256), (3, 64), (1, 320), (2, 72)])
+def test_fused_stem_pool_h2_vs_fp64(B, R):
+    """rdpn6d_stem_pool_h2: conv1 7x7/2 + folded BN + ReLU + MaxPool2d(3,2,1) in one kernel on the fp16 matrix pipe, pooled output as
+    an h2 tensor - against an fp64 evaluation, with the fp32 VALU stem + fp32 max-pool kernels as the yardstick."""
+    import ctypes
+
+    from rdpn6d_amd import _lib, ops
+    from rdpn6d_amd.gdrn import _ptr, pack_stem_h2_weight
+
+    lib, dev = _lib.load(), torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B * 1000 + R)
+    x = torch.rand(B, 6, R, R, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) / 12
+    sc, sh = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.3
+    y64 = torch.nn.functional.conv2d(x[:, :3].double(), w.double(), stride=2, padding=3) * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]
+    y64 = torch.nn.functional.max_pool2d(y64.clamp(min=0), 3, 2, 1).permute(0, 2, 3, 1)
+    xd = x.to(dev)
+    wh, inv = pack_stem_h2_weight(w.to(dev))
+    scf = (sc.to(dev) * inv).contiguous()
+    Rp = R // 4
+    yh = torch.empty(B * Rp * Rp, 2, 2, 32, dtype=torch.float16, device=dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(lib.rdpn6d_stem_pool_h2(_ptr(xd), B, 6, R, _ptr(wh), _ptr(scf), _ptr(sh.to(dev)), _ptr(yh), _ptr(flag), None))
+    s32 = ops.stem_conv7x7(xd, w.to(dev), sc.to(dev), sh.to(dev))
+    p32 = ops.maxpool3x3s2(s32)
+    torch.cuda.synchronize()
+    mine = ops.merge_h2(yh, (B, Rp, Rp, 64)).cpu().double()
+    e_h2, e_32 = (mine - y64).abs().max().item(), (p32.cpu().double() - y64).abs().max().item()
+    scale = y64.abs().max().item()
+    print(f"B={B} R={R}: fused h2 stem+pool vs fp64 {e_h2:.3e} | fp32 VALU stem + pool vs fp64 {e_32:.3e} (|y|max {scale:.2f})")
+    assert int(flag.item()) == 0 and e_h2 <= 1.25 * e_32 + 2.0 ** -21 * scale  # (+ the 22-bit h2 record of the output itself)
