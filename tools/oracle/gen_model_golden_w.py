@@ -92,6 +92,17 @@ def main():
         out[f"ref_noise_{att}_rot"] = np.float64(max(rel(o1["rot"][i].numpy(), o["rot"][i].numpy()) for i in range(B)))
         out[f"ref_noise_{att}_trans"] = np.float64(max(rel(o1["trans"][i].numpy(), o["trans"][i].numpy()) for i in range(B)))
         print(f"[{att}] reference 1-vs-8 threads: worst-sample pose rel diff R {out[f'ref_noise_{att}_rot']:.2e} t {out[f'ref_noise_{att}_trans']:.2e}")
+        # the REAL reference evaluated in float64 (same weights, same inputs): how far its own fp32 pose is from the exact one.
+        # With MASK_ATTENTION = "mul" the pose is markedly more sensitive to the dense maps (every ConvPnPNet input is scaled by the
+        # min-max normalised mask): the reference's fp32 rotation is itself > 1e-4 from exact on this batch.
+        ref64, _ = build_reference(att)
+        ref64.load_state_dict(full_sd, strict=True)
+        ref64.double().eval()
+        t64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in tin.items()}
+        o64 = ref_eval(ref64, t64)
+        out[f"ref_fp64err_{att}_rot"] = np.float64(max(rel(o["rot"][i].numpy().astype(np.float64), o64["rot"][i].numpy().astype(np.float64)) for i in range(B)))
+        out[f"ref_fp64err_{att}_trans"] = np.float64(max(rel(o["trans"][i].numpy().astype(np.float64), o64["trans"][i].numpy().astype(np.float64)) for i in range(B)))
+        print(f"[{att}] reference fp32 vs the reference in fp64: worst-sample pose rel diff R {out[f'ref_fp64err_{att}_rot']:.2e} t {out[f'ref_fp64err_{att}_trans']:.2e}")
         if att == "none":
             for k in ("mask", "coor_x", "coor_y", "coor_z", "region"):
                 out["eval_" + k] = o[k].numpy()
