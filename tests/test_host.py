@@ -123,12 +123,15 @@ def test_unsupported_switches_fail_loudly(path, value):
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/configs/gdrn"), reason="needs the reference checkout (build container only)")
-def test_every_shipped_rgbd_config_builds_through_the_factory():
+def test_every_shipped_rgbd_config_builds_through_the_factory(monkeypatch):
     """all model configs under configs/gdrn (138: K = 32 / 64, MASK_ATTENTION mul / none, 30 with SOLVER.AMP) load unchanged and
     build: same 305 state_dict keys, Ranger with three parameter groups.  BASE_LR is derived from OPTIMIZER_CFG the way
     main_gdrn.py:63-74 does before it calls the factory."""
     import glob
 
+    # the shipped configs name BACKBONE.PRETRAINED = "torchvision://resnet34", which cannot be resolved offline: the factory then
+    # raises unless told that a random trunk is acceptable (test_pretrained_backbone_loading covers the loading itself)
+    monkeypatch.setenv("RDPN6D_ALLOW_RANDOM_BACKBONE", "1")
     n = amp = k64 = 0
     for f in sorted(glob.glob("/root/reference/configs/gdrn/**/*.py", recursive=True)):
         try:
@@ -145,3 +148,51 @@ def test_every_shipped_rgbd_config_builds_through_the_factory():
         amp += bool(cfg.SOLVER.AMP.ENABLED)
         k64 += int(cfg.MODEL.CDPN.ROT_HEAD.NUM_REGIONS) == 64
     assert n == 138 and amp == 30 and k64 == 10
+
+
+def test_pretrained_backbone_loading(tmp_path, monkeypatch):
+    """BACKBONE.PRETRAINED (GDRN.py:836-851 -> mmcv load_checkpoint(model.backbone, spec, strict=False)): a local .pth path and a
+    torchvision:// name found in the torch hub cache load non-strictly into the trunk (fc ignored, fusion branch untouched);
+    a spec that cannot be resolved offline RAISES instead of training from a random trunk unnoticed; MODEL.WEIGHTS != "" skips it."""
+    import torch
+
+    from rdpn6d_amd.gdrn import BackboneP
+
+    donor = BackboneP(34)
+    sd = {k: torch.randn_like(v) if v.is_floating_point() else v for k, v in donor.state_dict().items() if not k.startswith("spatial_net")}
+    sd["fc.weight"], sd["fc.bias"] = torch.randn(1000, 512), torch.randn(1000)  # what an ImageNet file carries besides
+    path = tmp_path / "resnet34-abc123.pth"
+    torch.save({"state_dict": {"module." + k: v for k, v in sd.items()}}, path)
+    cfg = gdrn_base_cfg(device="cpu")
+    cfg.MODEL.CDPN.BACKBONE.PRETRAINED = str(path)
+    model, _ = build_model_optimizer(cfg)
+    got = model.backbone.state_dict()
+    assert all(torch.equal(got[k], v) for k, v in sd.items() if k in got) and "fc.weight" not in got
+    hub = tmp_path / "hub" / "checkpoints"
+    hub.mkdir(parents=True)
+    torch.save(sd, hub / "resnet34-b627a593.pth")
+    monkeypatch.setenv("TORCH_HOME", str(tmp_path))
+    cfg = gdrn_base_cfg(device="cpu")
+    cfg.MODEL.CDPN.BACKBONE.PRETRAINED = "torchvision://resnet34"
+    model, _ = build_model_optimizer(cfg)
+    assert torch.equal(model.backbone.state_dict()["layer3.2.conv1.weight"], sd["layer3.2.conv1.weight"])
+    monkeypatch.setenv("TORCH_HOME", str(tmp_path / "nowhere"))
+    cfg = gdrn_base_cfg(device="cpu")
+    cfg.MODEL.CDPN.BACKBONE.PRETRAINED = "torchvision://resnet34"
+    with pytest.raises(FileNotFoundError):
+        build_model_optimizer(cfg)
+    cfg = gdrn_base_cfg(device="cpu")
+    cfg.MODEL.CDPN.BACKBONE.PRETRAINED, cfg.MODEL.WEIGHTS = "torchvision://resnet34", "output/some_checkpoint.pth"
+    build_model_optimizer(cfg)  # a full checkpoint follows: the trunk initialisation is skipped like in the reference
+
+
+def test_lr_schedule_none_and_step_when_annealing_starts_at_the_end():
+    """anneal_point = 1 (anneal_start == total_iters) must not divide by zero for the methods that never use the fraction"""
+    import torch
+
+    from rdpn6d_amd.lr_scheduler import flat_and_anneal_lr_scheduler
+
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+    for method, kw in (("none", dict(anneal_point=1.0)), ("step", dict(steps=(1.0,)))):
+        f = flat_and_anneal_lr_scheduler(opt, 100, anneal_method=method, **kw).lr_lambdas[0]
+        assert f(100) in (1, 1.0, 0.1) and f(50) == 1
