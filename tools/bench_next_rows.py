@@ -117,3 +117,28 @@ if os.path.exists(so):
     cpu = cpu_time(lambda: run_oracle(ol, c4), 3.0)
 row("RANSAC + Kabsch (100 hypotheses per crop, scoring from LDS)", 64, "crops", sec, 64 * 4096 * 20, cpu, 4,
     "bytes: 20 B per correspondence once (SURVEY 8d); the kernel is latency / ALU bound, not HBM bound")
+
+# ---- A8: correspondence selection (gdrn_evaluator.py:89-126) on 64 crops of model-shaped maps
+from oracle import select_oracle  # noqa: E402
+maps_h = rng.standard_normal((64, 37, 64, 64)).astype(np.float32)
+maps_h[:, 1:4] = rng.random((64, 3, 64, 64), dtype=np.float32)
+c5_h = rng.random((64, 5, 64, 64), dtype=np.float32)
+ext_h = (rng.random((64, 3), dtype=np.float32) * 0.2 + 0.05).astype(np.float32)
+maps_d, c5_d, ext_d = torch.from_numpy(maps_h).to(dev), torch.from_numpy(c5_h).to(dev), torch.from_numpy(ext_h).to(dev)
+sec = gpu_time(lambda: ops.select_correspondences(maps_d, c5_d, ext_d, 480, 640))
+nm0 = select_oracle.out_mask_l1(maps_h[:1, :1])
+cpu = cpu_time(lambda: select_oracle.select_correspondences(nm0[0, 0], maps_h[0, 1:4].transpose(1, 2, 0), c5_h[0, 3:5].transpose(1, 2, 0), 480, 640, ext_h[0]), 2.0)
+row("correspondence selection A8 (mask / coordinate filter + ordered compaction)", 64, "crops", sec, 64 * 4096 * (6 * 4 + 20), cpu, 1)
+
+# ---- A9: 2D-3D RANSAC-PnP, 64 crops x 100 hypotheses (P3P per wavefront, reprojection scoring from LDS, Gauss-Newton refit)
+from tests.pnp_cases import make_pnp_case  # noqa: E402
+cp = make_pnp_case(B=64, n=1600, outliers=0.3, seed=2)
+tp = {k: torch.from_numpy(np.ascontiguousarray(cp[k])).to(dev) for k in ("image_points", "model_points", "counts", "cams")}
+sec = gpu_time(lambda: ops.ransac_pnp(tp["image_points"], tp["model_points"], tp["counts"], tp["cams"].reshape(64, 3, 3)))
+cpu = None
+if os.path.exists(so):
+    from tests.test_pnp_oracle import run_pnp_oracle  # noqa: E402
+    cp4 = make_pnp_case(B=4, n=1600, outliers=0.3, seed=2)
+    cpu = cpu_time(lambda: run_pnp_oracle(ol, cp4), 3.0)
+row("2D-3D RANSAC-PnP (100 P3P hypotheses per crop in fp64, 3 px reprojection scoring from LDS, Gauss-Newton refit)", 64, "crops", sec,
+    64 * 1600 * 20, cpu, 4, "latency / fp64-ALU bound; bytes: 20 B per correspondence once")
