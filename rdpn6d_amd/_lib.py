@@ -141,6 +141,13 @@ def load():
                 f"{LIB_PATH} is missing: build the HIP extension first (python -m rdpn6d_amd.build). "
                 "rdpn6d_amd has no CPU fallback."
             )
+        # torch first: it brings its own libamdhip64 and this library must bind to THAT copy (one HIP runtime per process).  Loaded
+        # the other way round - this .so first, e.g. build() followed by smoke() in one process - the system runtime gets in,
+        # torch then initialises a second one and one of the two sees no device.
+        import torch  # noqa: F401
+
+        if torch.cuda.device_count() > 0:
+            torch.cuda.init()
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
