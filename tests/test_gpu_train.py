@@ -110,6 +110,40 @@ def test_all_gradients_vs_oracle_autograd(train_setup, att):
     assert med_h <= max(2.0 * med_c, 1e-3)
 
 
+@pytest.mark.parametrize("att", ["none", "mul"])
+def test_all_gradients_on_the_stress_fixture_with_the_relu_decisions_forced(train_setup, att):
+    """the same 164 gradients with the HIP forward's ReLU / LeakyReLU decisions forced into the oracle (oracle.forced_relu_masks, see
+    tests/test_gpu_c1w.py): even on this ill-conditioned random-weight network - where un-forced fp32 gradients are only good to
+    ~3e-2 - the backward ARITHMETIC then agrees to 1.5e-4 (median) / 6e-4 (worst): bound 1e-3."""
+    from oracle import model_oracle
+    from rdpn6d_amd import synth
+    from tests.test_gpu_c1w import _hip_relu_masks
+
+    out, _ = train_setup
+    model, eng, _, orc, _, _ = out[att]
+    inp = synth.make_inputs(4, seed=0)
+    gt = synth.make_train_gt(4, inp)
+    t = {k: torch.from_numpy(v) for k, v in {**inp, **gt}.items()}
+    orc2 = model_oracle.GDRNOracle(32, att)
+    orc2.load_state_dict({k: v.clone() for k, v in orc.state_dict().items()}, strict=True)  # (running statistics do not enter a train-mode forward)
+    orc2.train()
+    with model_oracle.forced_relu_masks(orc2, _hip_relu_masks(eng, orc2)) as forced:
+        o = orc2(t["roi_img"], t["roi_coord_2d"], t["fps"], t["roi_cam"], t["roi_center"], t["roi_wh"], t["resize_ratio"], train_pose=True)
+        sum(model_oracle.gdrn_losses(o, t, t["roi_extent"]).values()).backward()
+    assert len(forced.used) == 48
+    ref = dict(orc2.named_parameters())
+    rows = []
+    for name, p in model.named_parameters():
+        r = ref[name].grad.double()
+        if r.norm().item() < 1e-4:
+            continue
+        rows.append(((p.grad.cpu().double() - r).norm().item() / r.norm().item(), name))
+    rows.sort(reverse=True)
+    print(f"[stress fixture, {att}] HIP vs mask-forced oracle autograd: median {np.median([e for e, _ in rows]):.2e}, worst "
+          + ", ".join(f"{n} {e:.2e}" for e, n in rows[:3]))
+    assert all(e <= 1e-3 for e, _ in rows), rows[:3]
+
+
 def test_bn_running_stats_updated_like_torch(train_setup):
     out, _ = train_setup
     model, orc = out["none"][0], out["none"][3]
