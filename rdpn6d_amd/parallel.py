@@ -27,12 +27,15 @@ class GradBuckets:
     contiguous buffer; ``reduce(group)`` starts the (asynchronous) all-reduce of that group's slice,
     ``finish()`` waits for all of them and turns sums into means."""
 
-    def __init__(self, model, groups=GROUPS, process_group=None, optimizer=None):
-        """optimizer: the rdpn6d_amd Ranger that will step these parameters.  If it has already built its flat gradient
+    def __init__(self, model, groups=GROUPS, process_group=None, optimizer=None, always_reduce=False):
+        """always_reduce: issue the all-reduces even in a one-rank group (a no-op on the values; the single-GPU RCCL test uses it to
+        put real RCCL kernels between the backward and the optimizer).
+        optimizer: the rdpn6d_amd Ranger that will step these parameters.  If it has already built its flat gradient
         buffer (a step was taken) that buffer is ADOPTED here - each group is a contiguous slice of it in any order - so both
         sides keep working on the same memory; an un-built Ranger adopts this buffer at its first step by itself."""
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.active = self.world > 1 or (always_reduce and dist.is_available() and dist.is_initialized())
         params = {g: [p for p in getattr(model, g).parameters() if p.requires_grad] for g in groups}
         self.params = params
         n = sum(p.numel() for ps in params.values() for p in ps)
@@ -63,7 +66,7 @@ class GradBuckets:
         self._home = {id(p): (p.grad.data_ptr() - self.flat.data_ptr()) // 4 for ps in params.values() for p in ps}
         self.handles = []
         # gloo has no AVG: reduce with SUM and scale in finish()
-        self.avg_op = self.world > 1 and dist.get_backend(process_group) == "nccl"
+        self.avg_op = self.active and dist.get_backend(process_group) == "nccl"
 
     def _rehome(self, group):
         """a caller may have replaced param.grad since construction (model.zero_grad(set_to_none=True) followed by a
@@ -84,7 +87,7 @@ class GradBuckets:
 
     def reduce(self, group):
         self._rehome(group)
-        if self.world == 1:
+        if not self.active:
             return
         b, e = self.slices[group]
         op = dist.ReduceOp.AVG if self.avg_op else dist.ReduceOp.SUM
@@ -94,7 +97,7 @@ class GradBuckets:
         for h in self.handles:
             h.wait()
         self.handles = []
-        if self.world > 1 and not self.avg_op:
+        if self.active and not self.avg_op:
             self.flat.div_(self.world)
 
 

@@ -177,16 +177,17 @@ def test_backward_honours_the_upstream_gradient():
 
 
 # ----------------------------------------------------------------------------- two data-parallel ranks on one GPU
-def _dp_worker(rank, world, port, q):
+def _dp_worker(rank, world, port, q, backend="gloo"):
     import torch.distributed as dist
 
     from rdpn6d_amd.parallel import GradBuckets, reduce_loss_dict
 
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        dist.init_process_group("gloo", rank=rank, world_size=world)  # RCCL cannot put two ranks on one device
         dev = torch.device("cuda:0")
         torch.cuda.set_device(dev)
+        # RCCL cannot put two ranks on one device: two ranks rendezvous over gloo, the RCCL run has one rank
+        dist.init_process_group(backend, rank=rank, world_size=world, **({"device_id": dev} if backend == "nccl" else {}))
         model, opt = _model()  # factory optimizer: Ranger, groups backbone | rot_head | pnp_net
         b = _batch(2, 100 + rank, dev)  # every rank its own crops
         eng = model.train_engine(2, dev)
@@ -194,12 +195,15 @@ def _dp_worker(rank, world, port, q):
         eng.forward_backward(b)
         torch.cuda.synchronize()
         mine = torch.cat([p.grad.detach().reshape(-1).cpu() for p in model.parameters()])
-        both = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(both, mine)
-        mean = sum(both) / world
+        if backend == "nccl":
+            mean = mine
+        else:
+            both = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(both, mine)
+            mean = sum(both) / world
         model, opt = _model()  # fresh BatchNorm statistics / weights for the data-parallel run
         eng = model.train_engine(2, dev)
-        buckets = GradBuckets(model, optimizer=opt)
+        buckets = GradBuckets(model, optimizer=opt, always_reduce=backend == "nccl")
         fired = []
 
         def on_done(g):
@@ -227,8 +231,24 @@ def _dp_worker(rank, world, port, q):
                 ok, msg = False, "Ranger steps a different buffer than the one that was reduced"
         torch.cuda.synchronize()
         w = torch.cat([p.detach().reshape(-1).cpu() for p in model.parameters()])
-        ws = [torch.empty_like(w) for _ in range(world)]
-        dist.all_gather(ws, w)
+        if backend == "nccl":
+            # the same three steps without any process group: the RCCL all-reduce of one rank (its own stream, async handles waited on
+            # before Ranger) must leave every bit of the trajectory alone - a missing stream dependency shows up here
+            model, opt = _model()
+            eng = model.train_engine(2, dev)
+            for it in range(3):
+                eng.refresh_weights()
+                eng.forward_losses(b)
+                opt.zero_grad(set_to_none=True)
+                eng.backward()
+                opt.step()
+            torch.cuda.synchronize()
+            ws = [w, torch.cat([p.detach().reshape(-1).cpu() for p in model.parameters()])]
+            if dist.get_backend() != "nccl" or not buckets.active:
+                ok, msg = False, "the reduction did not go through RCCL"
+        else:
+            ws = [torch.empty_like(w) for _ in range(world)]
+            dist.all_gather(ws, w)
         if not torch.equal(ws[0], ws[1]):
             ok, msg = False, f"weights diverged across ranks: {(ws[0] - ws[1]).abs().max().item():.3e}"
         if len(red) != 9 or not all(torch.isfinite(v) for v in red.values()):
@@ -254,3 +274,20 @@ def test_two_rank_data_parallel_training_through_the_real_engine():
     for p in procs:
         p.join(timeout=120)
     assert [r[:2] for r in res] == [(0, True), (1, True)], res
+
+
+def test_rccl_backed_gradient_reduction_through_the_real_engine():
+    """The same loop over RCCL (backend "nccl"): one rank - RCCL refuses two ranks on one device and this box has one GPU - so the
+    all-reduces really run as RCCL kernels on RCCL's stream against the flat gradient buffer, between the backward kernels and the
+    fused Ranger step: bucket order, reduced == stand-alone gradients, and a three-step trajectory bit-identical to the run without
+    a process group (what a missing stream dependency or a reduction of the wrong buffer would break)."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29950 + os.getpid() % 40
+    p = ctx.Process(target=_dp_worker, args=(0, 1, port, q, "nccl"))
+    p.start()
+    res = q.get(timeout=600)
+    p.join(timeout=120)
+    assert res[:2] == (0, True), res
