@@ -244,7 +244,7 @@ def train_bench(args, rank, world, device, dist):
     eng = model.train_engine(B, device)
     if args.dtype == "fp16":
         eng.loss_scale = 4096.0  # static loss scale (the reference: GradScaler, engine.py:302-309)
-    buckets = GradBuckets(model)
+    buckets = GradBuckets(model, always_reduce=bool(os.environ.get("RDPN6D_BENCH_FORCE_DIST")))
     order = [p for g in ("pnp_net", "rot_head_net", "backbone") for p in getattr(model, g).parameters()]
     opt = Ranger(order, lr=1e-4, flat_grad=buckets.flat)  # fused HIP step over the same flat gradient buffer
     inp = synth.make_inputs(B, seed=200 + rank)
@@ -335,7 +335,7 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("RDPN6D_BENCH_FORCE_DIST"):  # (forced at world 1: the one-GPU test of the RCCL code path)
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -332,8 +332,9 @@ int rdpn6d_stem_im2col_f32(const float* x, int B, int xc, int R, float* out, voi
 
 /* Weight re-packing of the training step in one launch.  Entry: dst[(o*dT + t)*dIpad + i] = src[operm(o)*so +
  * iperm(i)*si + toff[t]] for o < O, t < T, i < I (operm / iperm may be NULL = identity; dst and/or dst_bf16 are written;
- * padding entries of dst are never touched).  Workgroup b handles the 2048 elements of entry blk_desc[b] that start at
- * element blk_off[b]; table and maps live in device memory (`start` is unused by the kernel, kept for bookkeeping). */
+ * padding entries of dst are never touched).  Workgroup b handles 256 (o, i) pairs - all T taps of each - of entry blk_desc[b],
+ * starting at pair blk_off[b] (pair = o*I + i); table and maps live in device memory (`start` is unused by the kernel, kept
+ * for bookkeeping). */
 typedef struct {
     const float* src;
     float* dst;

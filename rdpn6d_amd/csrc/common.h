@@ -137,3 +137,22 @@ template <> __device__ __forceinline__ float rd_ld1<rd_bf16_t>(const rd_bf16_t* 
 template <typename T> __device__ __forceinline__ void rd_st1(T* p, float v);
 template <> __device__ __forceinline__ void rd_st1<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void rd_st1<rd_bf16_t>(rd_bf16_t* p, float v) { *p = rd_f2bf(v); }
+// V = 4 (16-byte fp32 or 8-byte 16-bit accesses) or 8 (16-byte accesses of a 16-bit tensor) consecutive channels as floats
+template <typename T, int V> __device__ __forceinline__ void rd_ldv(const T* p, float (&v)[V])
+{
+    if constexpr (V == 4) {
+        const f32x4 t = rd_ld4<T>(p);
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+    } else {
+        static_assert(sizeof(T) == 2 && V == 8, "8 channels per thread is the bf16 form");
+        rd_unpack8(*reinterpret_cast<const rd_u32x4*>(p), v);
+    }
+}
+
+template <typename T, int V> __device__ __forceinline__ void rd_stv(T* p, const float (&v)[V])
+{
+    if constexpr (V == 4) rd_st4<T>(p, f32x4{v[0], v[1], v[2], v[3]});
+    else *reinterpret_cast<rd_u32x4*>(p) = rd_pack8(v);
+}
+
+

@@ -12,50 +12,76 @@
 // ------------------------------------------------------------------------------------------------
 // MaxPool2d(3,2,1) backward, gather form (deterministic): an input element receives the gradient of every
 // window in which it is the FIRST maximum in scan order (torch's CPU/GPU kernels keep the first max).
-// One thread = one input pixel x 4 channels (16-byte loads; the <= 4 windows x 9 taps it inspects are L1/L2 hits).
-template <typename T>
-__global__ void maxpool3x3s2_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, int B, int H, int W, int C,
-                                        T* __restrict__ dx)
+// A workgroup owns 16 x 16 input pixels x <= 64 channels: phase 1 finds the arg-max tap of the 9 x 9 windows that touch them
+// (one thread = one window x V channels, 9 vector loads) and parks (tap, dy) in LDS; phase 2 gives every pixel the gradient of the
+// <= 4 windows whose arg-max it is.  ~1.3 reads of x per element instead of the 36 of a per-pixel window scan.
+template <typename T, int V>
+__global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, int B, int H, int W, int C,
+                                                               T* __restrict__ dx)
 {
-    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1, C4 = C / 4;
-    const long long total = (long long)B * H * W * C4;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C4) * 4;
-        long long p = i / C4;
-        const int ix = (int)(p % W);
-        p /= W;
-        const int iy = (int)(p % H);
-        const int b = (int)(p / H);
-        const T* xb = x + (long long)b * H * W * C + c;
-        const f32x4 v = rd_ld4<T>(xb + ((long long)iy * W + ix) * C);
-        f32x4 g = {0.f, 0.f, 0.f, 0.f};
-        // windows (oy,ox) covering (iy,ix): oy*2-1 <= iy <= oy*2+1
-        for (int oy = iy / 2; oy <= (iy + 1) / 2; ++oy) {
-            if (oy >= Ho) continue;
-            for (int ox = ix / 2; ox <= (ix + 1) / 2; ++ox) {
-                if (ox >= Wo) continue;
-                // per channel: is (iy,ix) the first max of this window?
-                bool first[4] = {true, true, true, true};
+    constexpr int TP = 16, TW = TP / 2 + 1, CH = 64;
+    __shared__ unsigned char s_tap[TW * TW][CH];
+    __shared__ float s_dy[TW * TW][CH];
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const int tiles_x = (W + TP - 1) / TP, tiles_y = (H + TP - 1) / TP;
+    int bid = blockIdx.x;
+    const int tx = (bid % tiles_x) * TP;
+    bid /= tiles_x;
+    const int ty = (bid % tiles_y) * TP;
+    const int b = bid / tiles_y;
+    const int c0 = blockIdx.y * CH;
+    const int nch = C - c0 < CH ? C - c0 : CH;  // channels of this chunk (multiple of V)
+    const int ng = nch / V;
+    const int oy0 = ty / 2, ox0 = tx / 2;
+    const T* xb = x + (long long)b * H * W * C + c0;
+    for (int task = threadIdx.x; task < TW * TW * ng; task += 256) {
+        const int g = task % ng, w = task / ng;
+        const int oy = oy0 + w / TW, ox = ox0 + w % TW;
+        float best[V], d[V];
+        int tap[V];
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    const int yy = oy * 2 - 1 + ky;
-                    if ((unsigned)yy >= (unsigned)H) continue;
+        for (int e = 0; e < V; ++e) { best[e] = 0.f; d[e] = 0.f; tap[e] = 255; }
+        if (oy < Ho && ox < Wo) {
+            bool have = false;
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const int xx = ox * 2 - 1 + kx;
-                        if ((unsigned)xx >= (unsigned)W) continue;
-                        const f32x4 u = rd_ld4<T>(xb + ((long long)yy * W + xx) * C);
-                        const bool before = yy < iy || (yy == iy && xx < ix);
+            for (int ky = 0; ky < 3; ++ky) {
+                const int yy = oy * 2 - 1 + ky;
+                if ((unsigned)yy >= (unsigned)H) continue;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) first[e] = first[e] && !(u[e] > v[e] || (before && u[e] == v[e]));
-                    }
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int xx = ox * 2 - 1 + kx;
+                    if ((unsigned)xx >= (unsigned)W) continue;
+                    float u[V];
+                    rd_ldv<T, V>(xb + ((long long)yy * W + xx) * C + g * V, u);
+#pragma unroll
+                    for (int e = 0; e < V; ++e)
+                        if (!have || u[e] > best[e]) { best[e] = u[e]; tap[e] = ky * 3 + kx; }
+                    have = true;
                 }
-                const f32x4 d = rd_ld4<T>(dy + (((long long)b * Ho + oy) * Wo + ox) * C + c);
+            }
+            rd_ldv<T, V>(dy + (((long long)b * Ho + oy) * Wo + ox) * C + c0 + g * V, d);
+        }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) g[e] += first[e] ? d[e] : 0.f;
+        for (int e = 0; e < V; ++e) { s_tap[w][g * V + e] = (unsigned char)tap[e]; s_dy[w][g * V + e] = d[e]; }
+    }
+    __syncthreads();
+    for (int task = threadIdx.x; task < TP * TP * ng; task += 256) {
+        const int g = task % ng, p = task / ng;
+        const int iy = ty + p / TP, ix = tx + p % TP;
+        if (iy >= H || ix >= W) continue;
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = 0.f;
+        for (int oy = iy / 2; oy <= (iy + 1) / 2; ++oy) {
+            const int ky = iy - (oy * 2 - 1);
+            for (int ox = ix / 2; ox <= (ix + 1) / 2; ++ox) {
+                const int k = ky * 3 + (ix - (ox * 2 - 1));
+                const int w = (oy - oy0) * TW + (ox - ox0);
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc[e] += s_tap[w][g * V + e] == k ? s_dy[w][g * V + e] : 0.f;
             }
         }
-        rd_st4<T>(dx + (((long long)b * H + iy) * W + ix) * C + c, g);
+        rd_stv<T, V>(dx + (((long long)b * H + iy) * W + ix) * C + c0 + g * V, acc);
     }
 }
 
@@ -63,9 +89,17 @@ template <typename T>
 static int maxpool_bwd_impl(const T* x, const T* dy, int B, int H, int W, int C, T* dx, void* stream)
 {
     RD_REQUIRE(x && dy && dx && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "shape");
-    const long long total = (long long)B * H * W * (C / 4);
-    const int blocks = (int)((total + 255) / 256 < 32768 ? (total + 255) / 256 : 32768);
-    hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, dy, B, H, W, C, dx);
+    const long long tiles = (long long)B * ((H + 15) / 16) * ((W + 15) / 16);
+    RD_REQUIRE(tiles < (1LL << 31), "grid");
+    const dim3 grid((unsigned)tiles, (unsigned)((C + 63) / 64));
+    if constexpr (sizeof(T) == 2) {
+        if (C % 8 == 0) {
+            hipLaunchKernelGGL((maxpool3x3s2_bwd_kernel<T, 8>), grid, dim3(256), 0, (hipStream_t)stream, x, dy, B, H, W, C, dx);
+            RD_LAUNCH_CHECK();
+            return RDPN6D_OK;
+        }
+    }
+    hipLaunchKernelGGL((maxpool3x3s2_bwd_kernel<T, 4>), grid, dim3(256), 0, (hipStream_t)stream, x, dy, B, H, W, C, dx);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
 }
@@ -299,10 +333,20 @@ __global__ void dense_loss_finalize_kernel(const double* __restrict__ partial, i
                                            long long n, float xyz_lw, float mask_lw, float region_lw,
                                            float* __restrict__ losses)
 {
+    // 384 threads = 64 lanes x 6 sums: a lane adds every 64th partial, thread k < 6 then adds the 64 lane sums in lane order
+    __shared__ double s_p[64][6];
+    {
+        const int kk = threadIdx.x % 6, lane = threadIdx.x / 6;
+        double t = 0.0;
+        for (int i = lane; i < nblk; i += 64) t += partial[(long long)i * 6 + kk];
+        s_p[lane][kk] = t;
+    }
+    __syncthreads();
     const int k = threadIdx.x;
     if (k >= 6) return;
     double a = 0.0;
-    for (int i = 0; i < nblk; ++i) a += partial[(long long)i * 6 + k];
+#pragma unroll 8
+    for (int i = 0; i < 64; ++i) a += s_p[i][k];
     const double denom = sums[0] > 1.0 ? sums[0] : 1.0;
     double v;
     if (k < 3) v = xyz_lw * a / denom;
@@ -331,7 +375,7 @@ extern "C" int rdpn6d_dense_losses_f32(const float* head, int head_cs, const flo
         hipLaunchKernelGGL(dense_loss_kernel<64>, dim3(nblk), dim3(256), 0, s, head, head_cs, gt_xyz, mask_visib, mask_trunc, gt_region,
                            B, HW, K, scratch, xyz_lw, mask_lw, region_lw, dhead, scratch + 8);
     RD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(dense_loss_finalize_kernel, dim3(1), dim3(64), 0, s, scratch + 8, nblk, scratch, n, xyz_lw, mask_lw, region_lw, losses);
+    hipLaunchKernelGGL(dense_loss_finalize_kernel, dim3(1), dim3(384), 0, s, scratch + 8, nblk, scratch, n, xyz_lw, mask_lw, region_lw, losses);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
 }
@@ -785,23 +829,25 @@ extern "C" int rdpn6d_rgb_to_nhwc4_f32(const float* x, int B, int xc, int R, flo
 __global__ __launch_bounds__(256) void repack_kernel(const rdpn6d_repack_desc* __restrict__ tab, const int* __restrict__ blk_desc,
                                                      const long long* __restrict__ blk_off)
 {
-    // workgroup -> (table entry, first element) comes from a host-built map: no per-element search
+    // workgroup -> (table entry, first (o, i) pair) comes from a host-built map: no per-element search.  One thread = one (o, i)
+    // pair and its T taps: the taps of a pair are adjacent in the source (a 3x3 filter = 36 contiguous bytes, read once per
+    // cache line instead of once per tap), and for each tap consecutive lanes write consecutive i of the packed slab.
     const rdpn6d_repack_desc& D = tab[blk_desc[blockIdx.x]];
-    const long long n = (long long)D.O * D.T * D.I;
-    const long long base = blk_off[blockIdx.x];
+    const long long pair = blk_off[blockIdx.x] + threadIdx.x;
+    if (pair >= (long long)D.O * D.I) return;
+    const int i = (int)(pair % D.I);
+    const int o = (int)(pair / D.I);
+    const int oo = D.operm ? D.operm[o] : o, ii = D.iperm ? D.iperm[i] : i;
+    const float* sp = D.src + oo * D.so + ii * D.si;
+    float v[9];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        long long r = base + k * 256 + threadIdx.x;
-        if (r >= n) break;
-        const int i = (int)(r % D.I);
-        r /= D.I;
-        const int t = (int)(r % D.T);
-        const int o = (int)(r / D.T);
-        const int oo = D.operm ? D.operm[o] : o, ii = D.iperm ? D.iperm[i] : i;
-        const float v = D.src[oo * D.so + ii * D.si + D.toff[t]];
+    for (int t = 0; t < 9; ++t) v[t] = t < D.T ? sp[D.toff[t]] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        if (t >= D.T) break;
         const long long idx = ((long long)o * D.dT + t) * D.dIpad + i;
-        if (D.dst) D.dst[idx] = v;
-        if (D.dst_bf16) reinterpret_cast<unsigned short*>(D.dst_bf16)[idx] = rd_f2bf(v);
+        if (D.dst) D.dst[idx] = v[t];
+        if (D.dst_bf16) reinterpret_cast<unsigned short*>(D.dst_bf16)[idx] = rd_f2bf(v[t]);
     }
 }
 

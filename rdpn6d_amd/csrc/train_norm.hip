@@ -18,28 +18,19 @@
 // grid = (C/64, S); block = 256 = 16 row lanes x 16 channel quads (16-byte loads)
 // V = channels per thread: 4 (16-byte fp32 loads, 64 channels per workgroup) or 8 (16-byte bf16 loads, 128 channels per
 // workgroup - the bf16-stored activations of the mixed-precision step, so that a wavefront still reads 256-byte rows)
-template <typename T, int V> __device__ __forceinline__ void rd_ldv(const T* p, float (&v)[V])
-{
-    if constexpr (V == 4) {
-        const f32x4 t = rd_ld4<T>(p);
-        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
-    } else {
-        static_assert(sizeof(T) == 2 && V == 8, "8 channels per thread is the bf16 form");
-        rd_unpack8(*reinterpret_cast<const rd_u32x4*>(p), v);
-    }
-}
-
-template <int MODE, typename T, int V>
+template <int MODE, typename T, int V, int CG>
 __global__ __launch_bounds__(256) void chan_partial_kernel(const T* __restrict__ x, int xcs, int xco,
                                                            const T* __restrict__ dy, int dcs, int dco,
                                                            const T* __restrict__ y, int ycs, int yco,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            long long M, int C, int relu, double* __restrict__ partial)
 {
-    // block = 16 row lanes x 16 channel groups of V: every thread streams 16-byte loads, a wavefront covers 4 rows x 256 B
-    constexpr int CB = 16 * V;  // channels per workgroup
-    __shared__ double s_a[16][CB], s_b[16][CB];
-    const int q = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    // block = RL row lanes x CG channel groups of V: every thread streams 16-byte loads, a wavefront covers 64 / CG rows x CG * 16 B
+    // (CG = 16: 256-byte rows; CG = 8 when the tensor has only 8 groups - 64 channels of a 16-bit tensor - so no lane idles)
+    constexpr int CB = CG * V;  // channels per workgroup
+    constexpr int RL = 256 / CG;
+    __shared__ double s_a[RL][CB], s_b[RL][CB];
+    const int q = threadIdx.x % CG, rl = threadIdx.x / CG;
     const int c = blockIdx.x * CB + q * V;
     const int S = gridDim.y;
     const long long rows_per = (M + S - 1) / S;
@@ -53,12 +44,12 @@ __global__ __launch_bounds__(256) void chan_partial_kernel(const T* __restrict__
         for (int e = 0; e < V; ++e) { mu[e] = MODE == 1 ? mean[c + e] : 0.f; is[e] = MODE == 1 ? invstd[c + e] : 0.f; }
         // four rows per iteration: all loads of the group are issued before the first dependent use (memory-level
         // parallelism - the kernel is latency-bound otherwise); rows past the end are clamped and contribute zero
-        for (long long m0 = m_lo + rl; m0 < m_hi; m0 += 64) {
+        for (long long m0 = m_lo + rl; m0 < m_hi; m0 += 4 * RL) {
             float xv[4][V], g[4][V], yv[4][V];
             bool ok[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const long long mr = m0 + 16 * u;
+                const long long mr = m0 + RL * u;
                 ok[u] = mr < m_hi;
                 const long long m = ok[u] ? mr : m0;
                 rd_ldv<T, V>(x + m * xcs + xco + c, xv[u]);
@@ -95,7 +86,7 @@ __global__ __launch_bounds__(256) void chan_partial_kernel(const T* __restrict__
     if (threadIdx.x < CB && blockIdx.x * CB + threadIdx.x < C) {
         double ta = 0.0, tb = 0.0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { ta += s_a[r][threadIdx.x]; tb += s_b[r][threadIdx.x]; }
+        for (int r = 0; r < RL; ++r) { ta += s_a[r][threadIdx.x]; tb += s_b[r][threadIdx.x]; }
         const int cc = blockIdx.x * CB + threadIdx.x;
         partial[((long long)blockIdx.y * C + cc) * 2 + 0] = ta;
         partial[((long long)blockIdx.y * C + cc) * 2 + 1] = tb;
@@ -104,37 +95,73 @@ __global__ __launch_bounds__(256) void chan_partial_kernel(const T* __restrict__
 
 template <int MODE, typename T>
 static void chan_partial_launch(const T* x, int xcs, int xco, const T* dy, int dcs, int dco, const T* y, int ycs, int yco,
-                                const float* mean, const float* invstd, long long M, int C, int relu, double* partial, int S,
+                                const float* mean, const float* invstd, long long M, int C, int relu, double* scratch, int S,
                                 hipStream_t s)
 {
     // 8 channels per thread when every operand slice allows 16-byte bf16 accesses
     const bool wide = sizeof(T) == 2 && C % 8 == 0 && xcs % 8 == 0 && xco % 8 == 0 &&
                       (MODE == 0 || (dcs % 8 == 0 && dco % 8 == 0 && (!relu || (ycs % 8 == 0 && yco % 8 == 0))));
     if constexpr (sizeof(T) == 2) {
+        if (wide && C <= 64) {
+            hipLaunchKernelGGL((chan_partial_kernel<MODE, T, 8, 8>), dim3((C + 63) / 64, S), dim3(256), 0, s, x, xcs, xco, dy, dcs, dco, y,
+                               ycs, yco, mean, invstd, M, C, relu, scratch);
+            return;
+        }
         if (wide) {
-            hipLaunchKernelGGL((chan_partial_kernel<MODE, T, 8>), dim3((C + 127) / 128, S), dim3(256), 0, s, x, xcs, xco, dy, dcs, dco, y,
-                               ycs, yco, mean, invstd, M, C, relu, partial);
+            hipLaunchKernelGGL((chan_partial_kernel<MODE, T, 8, 16>), dim3((C + 127) / 128, S), dim3(256), 0, s, x, xcs, xco, dy, dcs, dco, y,
+                               ycs, yco, mean, invstd, M, C, relu, scratch);
             return;
         }
     }
-    hipLaunchKernelGGL((chan_partial_kernel<MODE, T, 4>), dim3((C + 63) / 64, S), dim3(256), 0, s, x, xcs, xco, dy, dcs, dco, y, ycs,
-                       yco, mean, invstd, M, C, relu, partial);
+    if (C <= 32) {
+        hipLaunchKernelGGL((chan_partial_kernel<MODE, T, 4, 8>), dim3((C + 31) / 32, S), dim3(256), 0, s, x, xcs, xco, dy, dcs, dco, y, ycs,
+                           yco, mean, invstd, M, C, relu, scratch);
+        return;
+    }
+    hipLaunchKernelGGL((chan_partial_kernel<MODE, T, 4, 16>), dim3((C + 63) / 64, S), dim3(256), 0, s, x, xcs, xco, dy, dcs, dco, y, ycs,
+                       yco, mean, invstd, M, C, relu, scratch);
 }
 
-// Stage 2 helpers: block = 256 threads = 4 split lanes x 64 channels; the S partials of a channel are summed by 4
-// lanes (fixed order) and combined through LDS.
+// channels per workgroup of the variant chan_partial_launch picks (for the split count)
+template <typename T> static int chan_cb(int C)
+{
+    if (sizeof(T) == 2 && C % 8 == 0) return C <= 64 ? 64 : 128;
+    return C <= 32 ? 32 : 64;
+}
+
+// Stage 2 helpers: block = 256 threads = 16 split lanes x 16 channels (C / 16 workgroups: a 64-channel layer gets four, not one);
+// every lane adds its S / 16 partials with the loads of four splits in flight, the lanes are combined through LDS in a fixed tree.
+#define FIN_CH 16
 __device__ __forceinline__ void combine_partials(const double* __restrict__ partial, int S, int C, int c, bool ok, double& a,
                                                  double& b)
 {
-    __shared__ double s_a[4][64], s_b[4][64];
-    const int sl = threadIdx.x >> 6, cl = threadIdx.x & 63;
+    __shared__ double s_a[16][FIN_CH], s_b[16][FIN_CH];
+    const int sl = threadIdx.x >> 4, cl = threadIdx.x & 15;
     a = 0.0; b = 0.0;
-    if (ok)
-        for (int s = sl; s < S; s += 4) { a += partial[((long long)s * C + c) * 2]; b += partial[((long long)s * C + c) * 2 + 1]; }
+    if (ok) {
+        const double* p = partial + (long long)c * 2;
+        const long long st = (long long)C * 2;
+        int k = sl;
+        for (; k + 48 < S; k += 64) {
+            const double a0 = p[k * st], b0 = p[k * st + 1], a1 = p[(k + 16) * st], b1 = p[(k + 16) * st + 1];
+            const double a2 = p[(k + 32) * st], b2 = p[(k + 32) * st + 1], a3 = p[(k + 48) * st], b3 = p[(k + 48) * st + 1];
+            a += (a0 + a1) + (a2 + a3);
+            b += (b0 + b1) + (b2 + b3);
+        }
+        for (; k < S; k += 16) { a += p[k * st]; b += p[k * st + 1]; }
+    }
     s_a[sl][cl] = a; s_b[sl][cl] = b;
     __syncthreads();
-    a = (s_a[0][cl] + s_a[1][cl]) + (s_a[2][cl] + s_a[3][cl]);
-    b = (s_b[0][cl] + s_b[1][cl]) + (s_b[2][cl] + s_b[3][cl]);
+    if (sl == 0) {
+        double ta[4], tb[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            ta[g] = (s_a[4 * g][cl] + s_a[4 * g + 1][cl]) + (s_a[4 * g + 2][cl] + s_a[4 * g + 3][cl]);
+            tb[g] = (s_b[4 * g][cl] + s_b[4 * g + 1][cl]) + (s_b[4 * g + 2][cl] + s_b[4 * g + 3][cl]);
+        }
+        a = (ta[0] + ta[1]) + (ta[2] + ta[3]);
+        b = (tb[0] + tb[1]) + (tb[2] + tb[3]);
+    }
 }
 
 // Stage 2 for BN statistics: mean, invstd, running-stat update.
@@ -143,11 +170,11 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double* __
                                                                 float* __restrict__ invstd, float* __restrict__ running_mean,
                                                                 float* __restrict__ running_var)
 {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1));
     const bool ok = c < C;
     double a, b;
     combine_partials(partial, S, C, c, ok, a, b);
-    if (!ok || threadIdx.x >= 64) return;
+    if (!ok || threadIdx.x >= FIN_CH) return;
     const double mu = a / (double)M;
     double var = b / (double)M - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -165,11 +192,11 @@ __global__ __launch_bounds__(256) void chan_sum_finalize_kernel(const double* __
                                                                 float* __restrict__ out_a, float* __restrict__ out_b,
                                                                 int accumulate)
 {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1));
     const bool ok = c < C;
     double a, b;
     combine_partials(partial, S, C, c, ok, a, b);
-    if (!ok || threadIdx.x >= 64) return;
+    if (!ok || threadIdx.x >= FIN_CH) return;
     if (out_a) out_a[c] = (accumulate ? out_a[c] : 0.f) + (float)a;
     if (out_b) out_b[c] = (accumulate ? out_b[c] : 0.f) + (float)b;
 }
@@ -190,11 +217,11 @@ static int bn_train_stats_impl(const T* x, long long M, int C, int cs, int co, f
 {
     RD_REQUIRE(x && mean && invstd && scratch, "null pointer");
     RD_REQUIRE(M > 0 && C > 0 && co + C <= cs && C % 4 == 0 && cs % 4 == 0 && co % 4 == 0, "shape / 16-byte alignment");
-    const int S = pick_splits(M, C, sizeof(T) == 2 && C % 8 == 0 ? 128 : 64);
+    const int S = pick_splits(M, C, chan_cb<T>(C));
     hipStream_t s = (hipStream_t)stream;
     chan_partial_launch<0, T>(x, cs, co, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, M, C, 0, scratch, S, s);
     RD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, s, scratch, S, C, M, eps, momentum, mean,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, s, scratch, S, C, M, eps, momentum, mean,
                        invstd, running_mean, running_var);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
@@ -220,11 +247,11 @@ template <typename T>
 static int channel_sum_impl(const T* x, long long M, int C, int cs, int co, float* out, int accumulate, double* scratch, void* stream)
 {
     RD_REQUIRE(x && out && scratch && M > 0 && C > 0 && co + C <= cs && C % 4 == 0 && cs % 4 == 0 && co % 4 == 0, "shape / alignment");
-    const int S = pick_splits(M, C, sizeof(T) == 2 && C % 8 == 0 ? 128 : 64);
+    const int S = pick_splits(M, C, chan_cb<T>(C));
     hipStream_t s = (hipStream_t)stream;
     chan_partial_launch<0, T>(x, cs, co, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, M, C, 0, scratch, S, s);
     RD_LAUNCH_CHECK();
-    hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, s, scratch, S, C, out, nullptr, accumulate);
+    hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, s, scratch, S, C, out, nullptr, accumulate);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
 }
@@ -241,12 +268,6 @@ extern "C" int rdpn6d_channel_sum_bf16(const void* x, long long M, int C, int cs
 
 // ---------------------------------------------------------------------------------------------
 // y = act(((x - mean) * invstd) * gamma + beta (+ res)), 4 channels per thread
-template <typename T, int V> __device__ __forceinline__ void rd_stv(T* p, const float (&v)[V])
-{
-    if constexpr (V == 4) rd_st4<T>(p, f32x4{v[0], v[1], v[2], v[3]});
-    else *reinterpret_cast<rd_u32x4*>(p) = rd_pack8(v);
-}
-
 template <typename T, int V>
 __global__ void bn_apply_kernel(const T* __restrict__ x, int xcs, int xco, const float* __restrict__ mean,
                                 const float* __restrict__ invstd, const float* __restrict__ gamma,
@@ -358,12 +379,12 @@ static int bn_backward_impl(const T* x, int xcs, int xco, const T* dy, int dcs, 
     RD_REQUIRE(x && dy && mean && invstd && gamma && dgamma && dbeta && dx && scratch, "null pointer");
     RD_REQUIRE(!relu || y, "ReLU mask needs the forward output");
     RD_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "shape");
-    const int S = pick_splits(M, C, sizeof(T) == 2 && C % 8 == 0 ? 128 : 64);
+    const int S = pick_splits(M, C, chan_cb<T>(C));
     hipStream_t s = (hipStream_t)stream;
     chan_partial_launch<1, T>(x, xcs, xco, dy, dcs, dco, y, ycs, yco, mean, invstd, M, C, relu, scratch, S, s);
     RD_LAUNCH_CHECK();
     // partial = (sum g, sum g*xhat) -> dbeta, dgamma
-    hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, s, scratch, S, C, dbeta, dgamma, 0);
+    hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, s, scratch, S, C, dbeta, dgamma, 0);
     RD_LAUNCH_CHECK();
     if constexpr (sizeof(T) == 2) {
         if (C % 8 == 0 && xcs % 8 == 0 && xco % 8 == 0 && dcs % 8 == 0 && dco % 8 == 0 && xgcs % 8 == 0 && xgco % 8 == 0 &&

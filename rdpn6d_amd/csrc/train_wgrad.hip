@@ -508,8 +508,51 @@ __global__ void splitk_reduce_strided_kernel(const float* __restrict__ partial, 
     }
 }
 
+// The OIHW case of the scatter (st == 1, sb == ntaps > 1: row a of the gradient is one contiguous run of Cb_out * ntaps floats, element
+// (t, b) at b * ntaps + t): a workgroup sums a [ntaps][BC] panel of row a with the same 16-byte loads and the same fixed order, turns
+// it through LDS and writes the run with consecutive lanes on consecutive addresses (the strided form writes 4-byte pieces 36 bytes apart).
+template <int BC>
+__global__ __launch_bounds__(256) void splitk_reduce_oihw_kernel(const float* __restrict__ partial, int S, int Ca, int ntaps, int Cb, WgradOut o)
+{
+    __shared__ float s_v[9][BC + 1];
+    const int a = blockIdx.y, b0 = blockIdx.x * BC;
+    const long long n = (long long)Ca * ntaps * Cb;
+    const int nb = Cb - b0 < BC ? Cb - b0 : BC;  // multiple of 4
+    const int nb4 = nb >> 2;
+    for (int task = threadIdx.x; task < ntaps * nb4; task += 256) {
+        const int t = task / nb4, b = (task - t * nb4) * 4;
+        const float* p = partial + ((long long)a * ntaps + t) * Cb + b0 + b;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        int k = 0;
+        for (; k + 4 <= S; k += 4) {
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(p + (long long)k * n);
+            const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (long long)(k + 1) * n);
+            const f32x4 v2 = *reinterpret_cast<const f32x4*>(p + (long long)(k + 2) * n);
+            const f32x4 v3 = *reinterpret_cast<const f32x4*>(p + (long long)(k + 3) * n);
+            s = (((s + v0) + v1) + v2) + v3;
+        }
+        for (; k < S; ++k) s = s + *reinterpret_cast<const f32x4*>(p + (long long)k * n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s_v[t][b + e] = s[e];
+    }
+    __syncthreads();
+    const int nout = (o.Cb_out - b0 < nb ? o.Cb_out - b0 : nb) * ntaps;  // real input channels of this panel
+    float* q = o.out + a * o.sa + (long long)b0 * ntaps;
+    for (int j = threadIdx.x; j < nout; j += 256) {
+        const int b = j / ntaps, t = j - b * ntaps;
+        q[j] = s_v[t][b];
+    }
+}
+
 static void wgrad_reduce(const float* partial, int S, int Ca, int ntaps, int Cb, float* out, const WgradOut* o, hipStream_t s)
 {
+    if (o && o->st == 1 && o->sb == ntaps && ntaps > 1 && ntaps <= 9 && Cb % 4 == 0 && o->Ca_out <= Ca) {
+        if (Cb >= 128)
+            hipLaunchKernelGGL(splitk_reduce_oihw_kernel<128>, dim3((Cb + 127) / 128, o->Ca_out), dim3(256), 0, s, partial, S, Ca, ntaps, Cb, *o);
+        else
+            hipLaunchKernelGGL(splitk_reduce_oihw_kernel<64>, dim3((Cb + 63) / 64, o->Ca_out), dim3(256), 0, s, partial, S, Ca, ntaps, Cb, *o);
+        return;
+    }
     const long long n = (long long)Ca * ntaps * Cb;
     const int rblocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     const int rblocks4 = (int)((n / 4 + 255) / 256 < 4096 ? (n / 4 + 255) / 256 : 4096);

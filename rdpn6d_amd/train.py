@@ -270,11 +270,11 @@ class TrainEngine:
             r["O"], r["T"], r["I"], r["dT"], r["dIpad"] = e["O"], e["T"], e["I"], e["dT"], e["dIpad"]
             r["toff"][: e["T"]] = e["toff"]
             start += e["O"] * e["T"] * e["I"]
-        # workgroup map: 2048 elements per workgroup, never straddling two entries
+        # workgroup map: 256 (o, i) pairs (x T taps) per workgroup, never straddling two entries
         bd, bo = [], []
         for di, e in enumerate(self.repack):
-            n = e["O"] * e["T"] * e["I"]
-            offs = np.arange(0, n, 2048, dtype=np.int64)
+            n = e["O"] * e["I"]
+            offs = np.arange(0, n, 256, dtype=np.int64)
             bo.append(offs)
             bd.append(np.full(len(offs), di, dtype=np.int32))
         self._repack_dev = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(self.dev)

@@ -99,3 +99,27 @@ def test_bench_contract_two_ranks_on_one_gpu():
     assert "batch=8 per GPU" in out["config"]["workload"] and len(out["per_rank_crops_per_s"]) == 2 and min(out["per_rank_crops_per_s"]) > 0
     assert out["value"] > 0 and abs(out["value"] - 16 * 3 / (out["ms_per_step"] * 3e-3)) < 1e-2 * out["value"]
     assert out["roofline"]["frac"] > 0 and "cpu_baseline" not in out
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_bench_contract_over_rccl_one_rank(train):
+    """the same launch line with the backend of a real run - RCCL ("nccl") - on the one GPU this box has: process-group creation
+    bound to the device, the barriers around the timed region, the all_gather / all_reduce(MAX) of the per-rank times on device
+    tensors and (--train) the bucketed gradient all-reduces all go through RCCL."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RDPN6D_BENCH_FORCE_DIST="1")
+    env.pop("RDPN6D_BENCH_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--batch", "8",
+           "--no-cpu-baseline"] + (["--train"] if train else [])
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["global_batch"] == 8

@@ -1,0 +1,15 @@
+# kernel stats of the AMP training step: bash tools/debug/run_train_prof.sh <dtype> <outdir-under-gpurun_out>
+R=$(pwd); DT=${1:-bf16}; OUT=$R/gpurun_out/${2:-train_prof}; mkdir -p $OUT
+cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/kt
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 $R/bench.py --train --dtype $DT --no-cpu-baseline --steps 10 --warmup 2 > $OUT/bench.json 2>$OUT/err.log
+f=$(ls /tmp/kt/*/*kernel_stats.csv | head -1); cp $f $OUT/kernel_stats.csv
+python3 - "$OUT/kernel_stats.csv" <<'PY'
+import csv, sys
+rows=list(csv.DictReader(open(sys.argv[1])))
+tot=sum(int(r["TotalDurationNs"]) for r in rows)
+print("total kernel ms per step", tot/1e6/12)
+for r in rows[:40]:
+    n=r["Name"].replace("(anonymous namespace)::","").replace("void ","")[:70]
+    print(f'{int(r["TotalDurationNs"])/1e6/12:7.3f} ms/step {r["Percentage"]:>6}%  calls/step {int(r["Calls"])/12:6.1f} avg {float(r["AverageNs"])/1e3:8.1f} us  {n}')
+PY
+tail -c 400 $OUT/bench.json
