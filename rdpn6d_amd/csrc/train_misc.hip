@@ -180,42 +180,76 @@ extern "C" int rdpn6d_upsample_bilinear_backward_bf16(const void* dy, int B, int
 // ------------------------------------------------------------------------------------------------
 // Backward of [l3 | broadcast(global max l3)]: dl3[p,c] = dfeat[p,c] + (p == first arg-max pixel of channel c) * sum_p' dfeat[p', C+c]
 // feat / dfeat NHWC [B,HW,cs] with cs >= 2C; dl3 [B,HW,C].  grid = (C/64, B), block 256 = 4 pixel lanes x 64 channels.
-template <typename T>
+template <typename T, int V>
 __global__ __launch_bounds__(256) void global_max_concat_bwd_kernel(const T* __restrict__ feat, const T* __restrict__ dfeat,
                                                                    int HW, int C, int cs, T* __restrict__ dl3)
 {
-    __shared__ float s_m[4][64], s_s[4][64];
-    __shared__ int s_i[4][64];
-    const int b = blockIdx.y, cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, pl = threadIdx.x >> 6;
+    // 256 threads = PL pixel lanes x CG groups of V channels (64 channels per workgroup): 16-byte loads, HW / PL steps per thread
+    constexpr int CG = 64 / V, PL = 256 / CG;
+    __shared__ float s_m[PL][64], s_s[PL][64];
+    __shared__ int s_i[PL][64];
+    __shared__ float s_tot[64];
+    __shared__ int s_best[64];
+    const int b = blockIdx.y, q = threadIdx.x % CG, pl = threadIdx.x / CG, c = blockIdx.x * 64 + q * V;
     const T* f = feat + (long long)b * HW * cs;
     const T* g = dfeat + (long long)b * HW * cs;
-    float m = -FLT_MAX, s = 0.f;
-    int mi = 0x7fffffff;
-    for (int p = pl; p < HW; p += 4) {
-        const float v = rd_ld1<T>(f + (long long)p * cs + c);
-        if (v > m) { m = v; mi = p; }
-        s += rd_ld1<T>(g + (long long)p * cs + C + c);
-    }
-    s_m[pl][cl] = m; s_i[pl][cl] = mi; s_s[pl][cl] = s;
-    __syncthreads();
-    float bm = s_m[0][cl], tot = s_s[0][cl];
-    int bi = s_i[0][cl];
+    float m[V], s[V];
+    int mi[V];
 #pragma unroll
-    for (int k = 1; k < 4; ++k) {
-        const float om = s_m[k][cl];
-        const int oi = s_i[k][cl];
-        if (om > bm || (om == bm && oi < bi)) { bm = om; bi = oi; }
-        tot += s_s[k][cl];
+    for (int e = 0; e < V; ++e) { m[e] = -FLT_MAX; s[e] = 0.f; mi[e] = 0x7fffffff; }
+    for (int p = pl; p < HW; p += PL) {
+        float v[V], d[V];
+        rd_ldv<T, V>(f + (long long)p * cs + c, v);
+        rd_ldv<T, V>(g + (long long)p * cs + C + c, d);
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            if (v[e] > m[e]) { m[e] = v[e]; mi[e] = p; }
+            s[e] += d[e];
+        }
     }
+#pragma unroll
+    for (int e = 0; e < V; ++e) { s_m[pl][q * V + e] = m[e]; s_i[pl][q * V + e] = mi[e]; s_s[pl][q * V + e] = s[e]; }
+    __syncthreads();
+    if (threadIdx.x < 64) {  // lanes in order: the first arg-max pixel wins ties, the sum has a fixed order
+        const int cl = threadIdx.x;
+        float bm = s_m[0][cl], tot = s_s[0][cl];
+        int bi = s_i[0][cl];
+        for (int k = 1; k < PL; ++k) {
+            const float om = s_m[k][cl];
+            const int oi = s_i[k][cl];
+            if (om > bm || (om == bm && oi < bi)) { bm = om; bi = oi; }
+            tot += s_s[k][cl];
+        }
+        s_tot[cl] = tot;
+        s_best[cl] = bi;
+    }
+    __syncthreads();
+    float tot[V];
+    int bi[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) { tot[e] = s_tot[q * V + e]; bi[e] = s_best[q * V + e]; }
     T* o = dl3 + (long long)b * HW * C;
-    for (int p = pl; p < HW; p += 4) rd_st1<T>(o + (long long)p * C + c, rd_ld1<T>(g + (long long)p * cs + c) + (p == bi ? tot : 0.f));
+    for (int p = pl; p < HW; p += PL) {
+        float d[V];
+        rd_ldv<T, V>(g + (long long)p * cs + c, d);
+#pragma unroll
+        for (int e = 0; e < V; ++e) d[e] += p == bi[e] ? tot[e] : 0.f;
+        rd_stv<T, V>(o + (long long)p * C + c, d);
+    }
 }
 
 template <typename T>
 static int gmax_bwd_impl(const T* feat, const T* dfeat, int B, int HW, int C, int cs, T* dl3, void* stream)
 {
-    RD_REQUIRE(feat && dfeat && dl3 && B > 0 && HW > 0 && C > 0 && C % 64 == 0 && 2 * C <= cs, "shape");
-    hipLaunchKernelGGL(global_max_concat_bwd_kernel<T>, dim3(C / 64, B), dim3(256), 0, (hipStream_t)stream, feat, dfeat, HW, C, cs, dl3);
+    RD_REQUIRE(feat && dfeat && dl3 && B > 0 && HW > 0 && C > 0 && C % 64 == 0 && 2 * C <= cs && cs % 4 == 0, "shape");
+    if constexpr (sizeof(T) == 2) {
+        if (cs % 8 == 0) {
+            hipLaunchKernelGGL((global_max_concat_bwd_kernel<T, 8>), dim3(C / 64, B), dim3(256), 0, (hipStream_t)stream, feat, dfeat, HW, C, cs, dl3);
+            RD_LAUNCH_CHECK();
+            return RDPN6D_OK;
+        }
+    }
+    hipLaunchKernelGGL((global_max_concat_bwd_kernel<T, 4>), dim3(C / 64, B), dim3(256), 0, (hipStream_t)stream, feat, dfeat, HW, C, cs, dl3);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
 }
@@ -385,19 +419,29 @@ extern "C" int rdpn6d_dense_losses_f32(const float* head, int head_cs, const flo
 //   pnp_in = att * [x y z | coord2d(5) | anchor(3) | softmax(region[1:])],  att = 1 or (mask-mn)/(mx-mn)
 // datt_out [B,HW] (only with mask attention) feeds the per-sample min/max terms handled by the second kernel.
 template <int KMAX>
-__global__ __launch_bounds__(256) void dense_glue_bwd_kernel(const float* __restrict__ head, int head_cs,
+__global__ __launch_bounds__(128) void dense_glue_bwd_kernel(const float* __restrict__ head, int head_cs,
                                                              const float* __restrict__ coord2d, const float* __restrict__ fps,
                                                              const int* __restrict__ argmax, const float* __restrict__ dpnp,
                                                              int pnp_cs, int B, int HW, int K, int mask_attention,
                                                              const float* __restrict__ minmax, float* __restrict__ dhead,
                                                              float* __restrict__ datt_out)
 {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long long)B * HW) return;
+    // the head and dpnp rows of the workgroup's pixels go through LDS (coalesced copies; a thread then walks its own row, odd row
+    // strides = no bank conflicts); the head row is overwritten with the gradient contributions and added to dhead the same way
+    extern __shared__ float s_rows[];
+    const int NT = blockDim.x, sh = head_cs | 1, sg = pnp_cs | 1;
+    float* s_h = s_rows;
+    float* s_g = s_rows + NT * sh;
+    const long long i0 = (long long)blockIdx.x * NT, total = (long long)B * HW;
+    const int npx = (int)(total - i0 < NT ? total - i0 : NT);
+    for (int j = threadIdx.x; j < npx * head_cs; j += NT) s_h[(j / head_cs) * sh + j % head_cs] = head[i0 * head_cs + j];
+    for (int j = threadIdx.x; j < npx * pnp_cs; j += NT) s_g[(j / pnp_cs) * sg + j % pnp_cs] = dpnp[i0 * pnp_cs + j];
+    __syncthreads();
+    const long long i = i0 + threadIdx.x;
+    if (threadIdx.x < npx) {
     const int b = (int)(i / HW), p = (int)(i - (long long)b * HW);
-    const float* h = head + i * head_cs;
-    const float* g = dpnp + i * pnp_cs;
-    float* dh = dhead + i * head_cs;
+    float* h = s_h + threadIdx.x * sh;
+    const float* g = s_g + threadIdx.x * sg;
     float att = 1.f, range = 1.f;
     if (mask_attention) {
         range = minmax[b * 2 + 1] - minmax[b * 2];
@@ -415,11 +459,7 @@ __global__ __launch_bounds__(256) void dense_glue_bwd_kernel(const float* __rest
 #pragma unroll
     for (int k = 0; k < KMAX; ++k)
         if (k < K) { e[k] = e[k] / se; dot += e[k] * g[11 + k] * att; }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) dh[1 + c] += g[c] * att;
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k)
-        if (k < K) dh[5 + k] += e[k] * (g[11 + k] * att - dot);
+    float d0 = 0.f;
     if (mask_attention) {
         // datt = sum_c dpnp[c] * (un-attenuated input c)
         float da = 0.f;
@@ -433,9 +473,20 @@ __global__ __launch_bounds__(256) void dense_glue_bwd_kernel(const float* __rest
 #pragma unroll
         for (int k = 0; k < KMAX; ++k)
             if (k < K) da += g[11 + k] * e[k];
-        dh[0] += da / range;
+        d0 = da / range;
         datt_out[i] = da;
     }
+    // the row now becomes the contribution to dhead (every read of h is done)
+    for (int c = 0; c < head_cs; ++c) h[c] = 0.f;
+    h[0] = d0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) h[1 + c] = g[c] * att;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+        if (k < K) h[5 + k] = e[k] * (g[11 + k] * att - dot);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < npx * head_cs; j += NT) dhead[i0 * head_cs + j] += s_h[(j / head_cs) * sh + j % head_cs];
 }
 
 // per-sample min/max terms of att = (m - mn)/(mx - mn): d/dmn = sum datt*(m - mx)/range^2 -> first arg-min pixel,
@@ -493,12 +544,16 @@ extern "C" int rdpn6d_dense_glue_backward_f32(const float* head, int head_cs, co
     RD_REQUIRE(B > 0 && HW > 0 && K >= 2 && K <= 64, "K in 2..64");
     RD_REQUIRE(!mask_attention || (minmax && datt_scratch), "mask attention needs minmax and a [B,HW] scratch");
     hipStream_t s = (hipStream_t)stream;
-    const unsigned blocks = (unsigned)(((long long)B * HW + 255) / 256);
+    RD_REQUIRE(head_cs >= 5 + K && pnp_cs >= 11 + K && head_cs <= 128 && pnp_cs <= 128, "row strides");
+    const int rowf = (head_cs | 1) + (pnp_cs | 1);          // floats of LDS per pixel
+    const int nt = rowf * 128 * 4 <= 64 * 1024 ? 128 : 64;  // pixels (= threads) per workgroup
+    const unsigned blocks = (unsigned)(((long long)B * HW + nt - 1) / nt);
+    const size_t lds = (size_t)rowf * nt * 4;
     if (K <= 32)
-        hipLaunchKernelGGL(dense_glue_bwd_kernel<32>, dim3(blocks), dim3(256), 0, s, head, head_cs, coord2d, fps, argmax, dpnp, pnp_cs, B,
+        hipLaunchKernelGGL(dense_glue_bwd_kernel<32>, dim3(blocks), dim3(nt), lds, s, head, head_cs, coord2d, fps, argmax, dpnp, pnp_cs, B,
                            HW, K, mask_attention, minmax, dhead, datt_scratch);
     else
-        hipLaunchKernelGGL(dense_glue_bwd_kernel<64>, dim3(blocks), dim3(256), 0, s, head, head_cs, coord2d, fps, argmax, dpnp, pnp_cs, B,
+        hipLaunchKernelGGL(dense_glue_bwd_kernel<64>, dim3(blocks), dim3(nt), lds, s, head, head_cs, coord2d, fps, argmax, dpnp, pnp_cs, B,
                            HW, K, mask_attention, minmax, dhead, datt_scratch);
     RD_LAUNCH_CHECK();
     if (mask_attention) {
