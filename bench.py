@@ -80,7 +80,7 @@ def roofline(model, t, B, device, reps=3):
     classes = {}  # tile -> launches of the conv kernel instance with that tile (bf16: the 64-channel K-chunk variants)
     lowp_fn = getattr(lib, f"rdpn6d_conv2d_{plan.lp or 'bf16'}")
     for L in plan.launches:
-        if L.keep and L.fn is lib.rdpn6d_conv2d_h2:
+        if L.keep and L.fn in (lib.rdpn6d_conv2d_h2, lib.rdpn6d_conv2d_h2_cb):
             classes.setdefault("h2" if lib.rdpn6d_conv_h2_kernel_for(ctypes.byref(L.keep[0])) == 2 else "h2tile", []).append(L)
         elif L.keep and L.fn in (lib.rdpn6d_conv2d_bf16x3, lib.rdpn6d_conv2d_bf16x3_ex):
             # 256x256 8-phase kernel ("x3") or the 128x128..64x64 tile kernel ("x3tile")
@@ -419,6 +419,10 @@ def main():
                        "parallelism": f"replicated weights, {world} independent shard(s), no collective",
                        "launch": "hipGraph replay" if args.graph else "eager"},
             "achieved_tflops_whole_step": round(44.10e9 * value / 1e12, 2),
+            "flops_note": ("44.10 GFLOP per crop = the reference network's multiply-adds" +
+                           ("; the h2 plan evaluates the spatially constant (broadcast global max) half of the ConvTranspose input as a "
+                            "per-crop bias (cfg.TEST.FOLD_GLOBAL_MAX, DESIGN.md section 4), 2.42 GFLOP per crop it does not execute"
+                            if getattr(model.plan(B, device), "fold_gmax", False) else "")),
             "per_rank_crops_per_s": per_rank_rate,
             "roofline": roof,
         }

@@ -131,6 +131,11 @@ int rdpn6d_conv2d_bf16x3_ex(const rdpn6d_conv_desc* d, long long x_plane_elems, 
 int rdpn6d_split_h2(const float* x, int src_cs, int src_co, int C, void* dst, long long npix, int* overflow_flag, void* stream);
 int rdpn6d_conv_h2_kernel_for(const rdpn6d_conv_desc* d); /* 2 = 256x256 eight-phase, 1 = 128x128..64x64 tile kernel, 0 = not eligible */
 int rdpn6d_conv2d_h2(const rdpn6d_conv_desc* d, void* y_h2, const void* res_h2, int* overflow_flag, void* stream);
+/* the same with a per-crop bias [B][4][Npad] fp32 added after scale / shift (before residual and activation): row (b, v) with
+ * v = (output row == OH-1) * 2 + (output column == OW-1); NULL = rdpn6d_conv2d_h2.  Used by the ConvTranspose phases of the head for
+ * the spatially constant half of their input (below). */
+int rdpn6d_conv2d_h2_cb(const rdpn6d_conv_desc* d, void* y_h2, const void* res_h2, int* overflow_flag, const float* crop_bias,
+                        void* stream);
 /* h2 forms of the kernels between the h2 convolutions of the point-wise fusion branch (same argument meaning as the _f32 entry
  * points; activations are h2 tensors, C / out_cs / out_co multiples of 32; the xyz subsample fills one whole 32-channel group
  * [x y z 0 ...]; csrc/pointwise_h2.hip) */
@@ -138,6 +143,14 @@ int rdpn6d_upsample_bilinear_h2(const void* x, int B, int H, int W, int C, int f
 int rdpn6d_xyz_subsample_h2(const float* x, int B, int xc, int R, int step, void* y, int out_cs, int out_co, int* overflow_flag,
                             void* stream);
 int rdpn6d_global_max_concat_h2(void* buf, int B, int HW, int C, int cs, void* stream);
+/* md_pointnet's concat [l3 | broadcast(global max l3)] (resnet_backbone.py:51-52) feeds a ConvTranspose2d(3, 2, 1, output_padding 1)
+ * (cdpn_rot_head_region.py): a spatially constant input contributes a per-crop constant per output parity and border position, so
+ * the broadcast half need not exist.  rdpn6d_global_max_h2: the max over the pixels of channels [0, C) of an h2 tensor as an h2
+ * record per crop, gmax_h2 [B][C/32][2][32].  A one-pixel h2 convolution of it with the weights of the constant half gives
+ * V [B][9*F] fp32, V[b][(ky*3+kx)*F + n] = sum_c W[C+c][n][ky][kx] * g[b][c]; rdpn6d_convt3x3s2_const_bias_f32 adds the valid taps:
+ * out[py*2+px][b][v][n] = scale[n] * sum (v as in rdpn6d_conv2d_h2_cb: the last output row / column lack the ky / kx = 0 tap). */
+int rdpn6d_global_max_h2(const void* x_h2, int B, int HW, int C, int cs, void* gmax_h2, void* stream);
+int rdpn6d_convt3x3s2_const_bias_f32(const float* V, const float* scale, int B, int F, float* out /* [4][B][4][F] */, void* stream);
 /* fused front of the network for the h2 path: conv1 7x7/2 + folded BN + ReLU + MaxPool2d(3,2,1) (resnet_backbone.py:272-275)
  * as an implicit GEMM on the fp16 matrix pipe (two-plane arithmetic, fp32-accurate), writing the pooled activation
  * [B, R/4, R/4, 64] as an h2 tensor.  w_h2 [64][5][2][32] fp16 = the conv1 weights with k = (ky*7+kx)*3+c padded to 160;

@@ -34,6 +34,9 @@ struct ConvH2Args {
     void* y_h2;          // optional: the result as an h2 tensor (geometry d.out_cs / d.out_co, multiples of 32)
     const void* res_h2;  // optional: the residual as an h2 tensor (geometry d.res_cs / d.res_co), used when d.res is null
     int* overflow_flag;  // set to 1 when an output had to be clamped to the fp16 range (may be null)
+    // per-crop bias [B][4][Npad] added after scale / shift: row (b, variant) with variant = (last output row) * 2 + (last output column)
+    // - the contribution of a spatially constant input slice to a ConvTranspose phase (pointwise_h2.hip); null = none
+    const float* crop_bias;
 };
 
 namespace {
@@ -60,6 +63,19 @@ __device__ __forceinline__ bool h2_split(float s, _Float16& hi, _Float16& lo)
 __device__ __forceinline__ void h2_finish_row8(const ConvH2Args& ax, float (&v)[8], const long long pix, const int ch)
 {
     const rdpn6d_conv_desc& d = ax.b.d;
+    if (ax.crop_bias) {
+        const int ohw = d.OH * d.OW;
+        const int b = (int)(pix / ohw);
+        const int r = (int)(pix - (long long)b * ohw);
+        const int oy = r / d.OW, ox = r - oy * d.OW;
+        const float* cb = ax.crop_bias + (long long)(b * 4 + (oy == d.OH - 1 ? 2 : 0) + (ox == d.OW - 1 ? 1 : 0)) * d.Npad + ch;
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(cb), c1 = *reinterpret_cast<const f32x4*>(cb + 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            v[q] += c0[q];
+            v[4 + q] += c1[q];
+        }
+    }
     if (d.res) {
         const float* rp = d.res + pix * d.res_cs + d.res_co + ch;
         const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
@@ -729,7 +745,15 @@ extern "C" int rdpn6d_conv_h2_kernel_for(const rdpn6d_conv_desc* d)
     return (h2_big_ok(d) && h2_big_pays(d, M)) ? 2 : 1;
 }
 
+extern "C" int rdpn6d_conv2d_h2_cb(const rdpn6d_conv_desc* d, void* y_h2, const void* res_h2, int* overflow_flag, const float* crop_bias,
+                                   void* stream);
 extern "C" int rdpn6d_conv2d_h2(const rdpn6d_conv_desc* d, void* y_h2, const void* res_h2, int* overflow_flag, void* stream)
+{
+    return rdpn6d_conv2d_h2_cb(d, y_h2, res_h2, overflow_flag, nullptr, stream);
+}
+
+extern "C" int rdpn6d_conv2d_h2_cb(const rdpn6d_conv_desc* d, void* y_h2, const void* res_h2, int* overflow_flag, const float* crop_bias,
+                                   void* stream)
 {
     RD_REQUIRE(d && d->x && d->w && (d->y || y_h2), "null pointer");
     const int which = rdpn6d_conv_h2_kernel_for(d);
@@ -759,6 +783,7 @@ extern "C" int rdpn6d_conv2d_h2(const rdpn6d_conv_desc* d, void* y_h2, const voi
     ax.y_h2 = y_h2;
     ax.res_h2 = res_h2;
     ax.overflow_flag = overflow_flag;
+    ax.crop_bias = crop_bias;
     a.dy_pack = a.dx_pack = 0;
     for (int t = 0; t < d->ntaps; ++t) {
         RD_REQUIRE(d->dy[t] >= -8 && d->dy[t] <= 7 && d->dx[t] >= -8 && d->dx[t] <= 7, "tap offsets must be in -8..7");

@@ -127,7 +127,92 @@ __global__ __launch_bounds__(1024) void global_max_concat_h2_kernel(_Float16* __
     }
 }
 
+// The max alone, as an h2 record per crop and channel ([B][C/32][hi32 | lo32]): what the ConvTranspose of the head needs from the
+// broadcast half of md_pointnet's concat (:51-52) - a spatially constant input contributes a per-crop constant (rdpn6d_convt3x3s2_
+// const_bias_f32), so the [pixels][2C] tensor is never written.  grid = (C/64, B); block 256 = 32 pixel lanes x 8 groups of 8 channels.
+__global__ __launch_bounds__(256) void global_max_h2_kernel(const _Float16* __restrict__ buf, int HW, int C, int cs, _Float16* __restrict__ out)
+{
+    __shared__ float s_m[32][64];
+    __shared__ _Float16 s_h[32][64], s_l[32][64];
+    const int b = blockIdx.y, q = threadIdx.x & 7, pl = threadIdx.x >> 3, c = blockIdx.x * 64 + q * 8;
+    const long long p0 = (long long)b * HW;
+    float m[8];
+    f16x8 mh, ml;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { m[e] = -FLT_MAX; mh[e] = (_Float16)0.f; ml[e] = (_Float16)0.f; }
+    for (int p = pl; p < HW; p += 32) {
+        const _Float16* sp = buf + h2_off(p0 + p, cs, c);
+        const f16x8 h = *reinterpret_cast<const f16x8*>(sp), l = *reinterpret_cast<const f16x8*>(sp + 32);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = (float)h[e] + (float)l[e];
+            if (v > m[e]) { m[e] = v; mh[e] = h[e]; ml[e] = l[e]; }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s_m[pl][q * 8 + e] = m[e]; s_h[pl][q * 8 + e] = mh[e]; s_l[pl][q * 8 + e] = ml[e]; }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int cl = threadIdx.x;
+        float bm = s_m[0][cl];
+        _Float16 bh = s_h[0][cl], bl = s_l[0][cl];
+        for (int k = 1; k < 32; ++k)
+            if (s_m[k][cl] > bm) { bm = s_m[k][cl]; bh = s_h[k][cl]; bl = s_l[k][cl]; }
+        _Float16* dp = out + h2_off(b, C, blockIdx.x * 64 + cl);
+        dp[0] = bh;
+        dp[32] = bl;
+    }
+}
+
+// ConvTranspose2d(k 3, stride 2, pad 1, output_padding 1) over a spatially CONSTANT input g: output pixel (oy, ox) receives
+// sum over its valid taps of W[ky][kx] . g.  Even rows use ky = 1; odd rows ky = 2 (input row i) and ky = 0 (input row i + 1, missing
+// for the last output row); the same for columns.  V[b][(ky*3+kx)*F + n] = W[ky][kx][n] . g_b comes from a one-pixel convolution;
+// out[phase = py*2+px][b][variant = last_row*2 + last_col][n] = scale[n] * sum of the valid taps - the per-crop bias the four phase
+// convolutions add in their epilogues (rdpn6d_conv2d_h2_cb).
+__global__ void convt_const_bias_kernel(const float* __restrict__ V, const float* __restrict__ scale, int B, int F, float* __restrict__ out)
+{
+    const long long total = (long long)16 * B * F;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i % F);
+        long long r = i / F;
+        const int var = (int)(r % 4);
+        r /= 4;
+        const int b = (int)(r % B);
+        const int ph = (int)(r / B);
+        const int py = ph >> 1, px = ph & 1, lr = var >> 1, lc = var & 1;
+        const float* v = V + (long long)b * 9 * F + n;
+        float acc = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const bool yok = py == 0 ? ky == 1 : (ky == 2 || (ky == 0 && !lr));
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const bool xok = px == 0 ? kx == 1 : (kx == 2 || (kx == 0 && !lc));
+                if (yok && xok) acc += v[(ky * 3 + kx) * F];
+            }
+        }
+        out[i] = (scale ? scale[n] : 1.f) * acc;
+    }
+}
+
 }  // namespace
+
+extern "C" int rdpn6d_global_max_h2(const void* x_h2, int B, int HW, int C, int cs, void* gmax_h2, void* stream)
+{
+    RD_REQUIRE(x_h2 && gmax_h2 && B > 0 && HW > 0 && C > 0 && C % 64 == 0 && C <= cs && cs % 32 == 0, "shape");
+    hipLaunchKernelGGL(global_max_h2_kernel, dim3(C / 64, B), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x_h2, HW, C, cs, (_Float16*)gmax_h2);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}
+
+extern "C" int rdpn6d_convt3x3s2_const_bias_f32(const float* V, const float* scale, int B, int F, float* out, void* stream)
+{
+    RD_REQUIRE(V && out && B > 0 && F > 0, "shape");
+    const long long total = (long long)16 * B * F;
+    hipLaunchKernelGGL(convt_const_bias_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, V, scale, B, F, out);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}
 
 extern "C" int rdpn6d_upsample_bilinear_h2(const void* x, int B, int H, int W, int C, int factor, void* y, int* overflow_flag, void* stream)
 {

@@ -408,7 +408,7 @@ class InferencePlan:
         return wp
 
     def conv_x3(self, name, xp, xshape, w32, scale, shift, y, yp, yshape, *, cin, in_cs, k=1, stride=1, pad=0, N, out_cs, act=0,
-                slope=0.0, taps=None, phase=None, res_planes=None, res_cs=0):
+                slope=0.0, taps=None, phase=None, res_planes=None, res_cs=0, crop_bias=None):
         """bf16x3 convolution: xp = input planes [3, >= B*H*W*in_cs]; y fp32 output or None; yp output planes or None;
         res_planes = the residual as planes (output geometry, res_cs channels per pixel)."""
         if self.fast == "h2":
@@ -439,6 +439,10 @@ class InferencePlan:
         self.x3_launches += 1
         if self.fast == "h2":
             assert self.lib.rdpn6d_conv_h2_kernel_for(ctypes.byref(d)), name
+            if crop_bias is not None:  # per-crop bias rows [B][4][Npad] (the folded global-max half of the ConvTranspose input)
+                self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_h2_cb, (ctypes.byref(d), _ptr(yp), _ptr(res_planes), _ptr(self.h2_flag),
+                                                                                   _ptr(crop_bias)), keep=(d, crop_bias)))
+                return
             self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_h2, (ctypes.byref(d), _ptr(yp), _ptr(res_planes), _ptr(self.h2_flag)), keep=(d,)))
             return
         assert self.lib.rdpn6d_conv_bf16x3_eligible(ctypes.byref(d)), name
@@ -616,9 +620,17 @@ class InferencePlan:
             self.conv_x3("spatial_net.conv2", l1, (R8, R8), wc2, s2, h2, None, l2, (R8, R8), cin=128, in_cs=128, N=256, out_cs=256, act=1)
             wc3 = pack_conv_weight(sn.conv3.weight.detach().float())
             s3, h3 = fold_bn(sn.b3, sn.conv3.bias, npad=wc3.shape[0])
-            feat = self.planes_buf("feat_planes", npx * 1024, 1)
-            self.conv_x3("spatial_net.conv3", l2, (R8, R8), wc3, s3, h3, None, feat, (R8, R8), cin=256, in_cs=256, N=512, out_cs=1024, act=0)
-            self.call("global_max_concat", lib.rdpn6d_global_max_concat_h2, _ptr(feat), B, R8 * R8, 512, 1024)
+            # cfg.TEST.FOLD_GLOBAL_MAX: the broadcast half of [l3 | max(l3)] is spatially constant, so its share of the ConvTranspose
+            # is a per-crop constant (see the head below) - feat keeps the 512 l3 channels only and the max stays a [B, 512] record
+            self.fold_gmax = bool(model.cfg.get("TEST", {}).get("FOLD_GLOBAL_MAX", True))
+            fcs = 512 if self.fold_gmax else 1024
+            feat = self.planes_buf("feat_planes", npx * fcs, 1)
+            self.conv_x3("spatial_net.conv3", l2, (R8, R8), wc3, s3, h3, None, feat, (R8, R8), cin=256, in_cs=256, N=512, out_cs=fcs, act=0)
+            if self.fold_gmax:
+                gmax = self.planes_buf("gmax_planes", B * 512, 1)
+                self.call("global_max", lib.rdpn6d_global_max_h2, _ptr(feat), B, R8 * R8, 512, 512, _ptr(gmax))
+            else:
+                self.call("global_max_concat", lib.rdpn6d_global_max_concat_h2, _ptr(feat), B, R8 * R8, 512, 1024)
         else:
             up = self.buf("up", B, R8, R8, C4, dtype=adt)
             self.call("upsample", getattr(lib, f"rdpn6d_upsample_bilinear_{sfx}"), _ptr(cur), B, cur_hw, cur_hw, C4,
@@ -665,6 +677,19 @@ class InferencePlan:
         elif x3_ct:
             pF = self.planes_buf("feat_planes", feat.numel(), 1)
             self.split3("rot_head.split_feat", feat, pF)
+        fold = x3_ct and h2_pw and getattr(self, "fold_gmax", False)
+        ct_cin, cbias = 1024, None
+        if fold:
+            # V[b][(ky*3+kx)*F + n] = W[512+c][n][ky][kx] . max_b[c] (a one-pixel h2 convolution), then the valid taps per output parity /
+            # border position, times the BatchNorm scale: the per-crop bias rows of the four phase convolutions
+            ct_cin = 512
+            wconst = wt[512:].permute(2, 3, 1, 0).reshape(9 * F, 1, 512).contiguous()
+            V = self.buf("convT_const", B, 9 * F)
+            self.conv_x3("rot_head.convT.const", gmax, (1, 1), wconst, None, None, V, None, (1, 1), cin=512, in_cs=512, N=9 * F,
+                         out_cs=9 * F, act=0)
+            cbias = self.buf("convT_crop_bias", 4, B, 4, Fp)
+            self.call("convT_const_bias", lib.rdpn6d_convt3x3s2_const_bias_f32, _ptr(V), _ptr(sct), B, F, _ptr(cbias))
+            self.keep += [sct]
         for py in (0, 1):
             for px in (0, 1):
                 ys = [(1, 0)] if py == 0 else [(0, 1), (2, 0)]  # (kernel index, input offset)
@@ -677,8 +702,9 @@ class InferencePlan:
                 wp = torch.zeros(Fp, len(taps), 1024, **f32)
                 wp[:F] = torch.stack(slabs, dim=1)
                 if x3_ct:  # planes in, planes out (the fp32 tensor is never materialised)
-                    self.conv_x3(f"rot_head.convT.phase{py}{px}", pF, (R8, R8), wp.contiguous(), sct, sht, None, pA, (R4, R4),
-                                 cin=1024, in_cs=1024, N=F, out_cs=F, act=1, taps=taps, phase=(R8, R8, 2, 2, py, px))
+                    self.conv_x3(f"rot_head.convT.phase{py}{px}", pF, (R8, R8), wp[:, :, :ct_cin].contiguous(), sct, sht, None, pA, (R4, R4),
+                                 cin=ct_cin, in_cs=ct_cin, N=F, out_cs=F, act=1, taps=taps, phase=(R8, R8, 2, 2, py, px),
+                                 crop_bias=cbias[py * 2 + px] if fold else None)
                 else:
                     self.conv(f"rot_head.convT.phase{py}{px}", feat, (R8, R8), wp.contiguous().to(adt), sct, sht, hA, (R4, R4),
                               cin=1024, in_cs=1024, N=F, out_cs=F, act=1, taps=taps, phase=(R8, R8, 2, 2, py, px), lowp=lp)
@@ -960,7 +986,8 @@ class GDRN(nn.Module):
             bf16 = bool(self.cfg.get("TEST", {}).get("AMP_TEST", False))
         if bf16 is True:
             bf16 = str(self.cfg.get("TEST", {}).get("AMP_DTYPE", "bf16"))
-        key = (B, str(device), bf16 or False)
+        tc = self.cfg.get("TEST", {})
+        key = (B, str(device), bf16 or False, bool(tc.get("BF16X3", True)), bool(tc.get("FP16X2", True)), bool(tc.get("FOLD_GLOBAL_MAX", True)))
         stamp = self._weights_stamp()
         plan = self._plans.get(key)
         if plan is not None and plan.weights_stamp != stamp:

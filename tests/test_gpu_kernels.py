@@ -1064,8 +1064,9 @@ def test_fp32_plan_fast_forms_match_the_fp32_mfma_path(golden_setup, truth, dev)
             plan = model.plan(16, dev)
             assert plan.fast == (None if mode == "none" else mode)
             # h2 additionally keeps the point-wise fusion branch (4 convolutions), the ConvTranspose phases (4, tile kernel) and the 1x1
-            # output convolution in its format: no fp32 copies / split passes in between
-            assert plan.x3_launches == {"h2": 6 + 35 + 4 + 4 + 1, "x3": 6 + 35, "none": 0}[mode] and plan.x3_trunk == (mode != "none")
+            # output convolution in its format: no fp32 copies / split passes in between; + the one-pixel convolution of the folded
+            # global-max half of the ConvTranspose input (cfg.TEST.FOLD_GLOBAL_MAX)
+            assert plan.x3_launches == {"h2": 6 + 35 + 4 + 4 + 1 + 1, "x3": 6 + 35, "none": 0}[mode] and plan.x3_trunk == (mode != "none")
             assert plan.h2_pointwise == (mode == "h2")
             o = _run(model, t16)
             assert not plan.range_exceeded(wait=True)
