@@ -314,6 +314,9 @@ def main():
     ap.add_argument("--fast", default="h2", choices=["h2", "x3", "none"],
                     help="fp32 mode: fp32-accurate form of the wide layers on the 16-bit matrix pipe: h2 = two fp16 planes, 3 partial "
                          "products (cfg.TEST.FP16X2, default) | x3 = three bf16 planes, 6 partial products (cfg.TEST.BF16X3) | none")
+    ap.add_argument("--test-cfg", default="", metavar="KEY=0|1[,...]",
+                    help="override boolean cfg.TEST switches for A/B runs, e.g. FOLD_GLOBAL_MAX=0,CONV_BEFORE_UPSAMPLE=0 "
+                         "(the reference's evaluation order of the two algebraic rewrites of the h2 plan)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as one hipGraph instead of launching kernel by kernel (measured: no gain, the "
                          "launch queue already runs ahead of the GPU - 2776 vs 2779 crops/s fp32, 10729 vs 10820 bf16)")
@@ -352,6 +355,9 @@ def main():
     if args.train:
         return train_bench(args, rank, world, device, dist)
     model, sd = build_model(device, args.mask_attention, bf16=args.dtype if args.dtype != "f32" else False, graph=args.graph, x3=not args.no_x3 and args.fast != "none", fast=args.fast)
+    for kv in filter(None, args.test_cfg.split(",")):
+        k, v = kv.split("=")
+        model.cfg.TEST[k.strip()] = bool(int(v))
     B = args.batch
     t = {k: torch.from_numpy(v).to(device) for k, v in synth.make_inputs(B, seed=100 + rank).items()}
 

@@ -140,6 +140,11 @@ int rdpn6d_conv2d_h2_cb(const rdpn6d_conv_desc* d, void* y_h2, const void* res_h
  * points; activations are h2 tensors, C / out_cs / out_co multiples of 32; the xyz subsample fills one whole 32-channel group
  * [x y z 0 ...]; csrc/pointwise_h2.hip) */
 int rdpn6d_upsample_bilinear_h2(const void* x, int B, int H, int W, int C, int factor, void* y, int* overflow_flag, void* stream);
+/* ... into the channel slice [out_co, out_co + C) of an h2 tensor with out_cs channels per pixel, ReLU optional: the second half of
+ * "1x1 convolution + BatchNorm at the low resolution, then up-sample + ReLU" (= up-sample, convolution, BatchNorm, ReLU of
+ * resnet_backbone.py:280 / :46: the interpolation weights sum to 1, so the affine map commutes with it) */
+int rdpn6d_upsample_bilinear_h2_ex(const void* x, int B, int H, int W, int C, int factor, void* y, int out_cs, int out_co, int relu,
+                                   int* overflow_flag, void* stream);
 int rdpn6d_xyz_subsample_h2(const float* x, int B, int xc, int R, int step, void* y, int out_cs, int out_co, int* overflow_flag,
                             void* stream);
 int rdpn6d_global_max_concat_h2(void* buf, int B, int HW, int C, int cs, void* stream);

@@ -121,6 +121,7 @@ SIGNATURES = {
     "rdpn6d_xyz_subsample_h2": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
     "rdpn6d_stem_pool_h2": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rdpn6d_global_max_concat_h2": (_i, [_vp, _i, _i, _i, _i, _vp]),
+    "rdpn6d_upsample_bilinear_h2_ex": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
     "rdpn6d_global_max_h2": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "rdpn6d_convt3x3s2_const_bias_f32": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "rdpn6d_conv2d_h2_cb": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),

@@ -23,7 +23,7 @@ __device__ __forceinline__ bool h2_split1(float s, _Float16& hi, _Float16& lo)
 __device__ __forceinline__ long long h2_off(long long pix, int cs, int c) { return pix * (2 * (long long)cs) + (c >> 5) * 64 + (c & 31); }
 
 __global__ void upsample_bilinear_h2_kernel(const _Float16* __restrict__ x, int B, int H, int W, int C, int f, _Float16* __restrict__ y,
-                                            int* __restrict__ overflow_flag)
+                                            int out_cs, int out_co, int relu, int* __restrict__ overflow_flag)
 {
     const int Ho = H * f, Wo = W * f, C8 = C / 8;
     const float sy = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
@@ -54,13 +54,14 @@ __global__ void upsample_bilinear_h2_kernel(const _Float16* __restrict__ x, int 
         f16x8 oh, ol;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float o = hy * (hx * v[0][e] + lx * v[1][e]) + ly * (hx * v[2][e] + lx * v[3][e]);  // as upsample_bilinear_kernel
+            float o = hy * (hx * v[0][e] + lx * v[1][e]) + ly * (hx * v[2][e] + lx * v[3][e]);  // as upsample_bilinear_kernel
+            if (relu) o = fmaxf(o, 0.f);
             _Float16 h, l;
             over |= h2_split1(o * H2_SCALE, h, l);
             oh[e] = h;
             ol[e] = l;
         }
-        _Float16* dp = y + h2_off(((long long)b * Ho + oy) * Wo + ox, C, c);
+        _Float16* dp = y + h2_off(((long long)b * Ho + oy) * Wo + ox, out_cs, out_co + c);
         *reinterpret_cast<f16x8*>(dp) = oh;
         *reinterpret_cast<f16x8*>(dp + 32) = ol;
     }
@@ -214,13 +215,25 @@ extern "C" int rdpn6d_convt3x3s2_const_bias_f32(const float* V, const float* sca
     return RDPN6D_OK;
 }
 
+extern "C" int rdpn6d_upsample_bilinear_h2_ex(const void* x, int B, int H, int W, int C, int factor, void* y, int out_cs, int out_co, int relu,
+                                              int* overflow_flag, void* stream);
 extern "C" int rdpn6d_upsample_bilinear_h2(const void* x, int B, int H, int W, int C, int factor, void* y, int* overflow_flag, void* stream)
 {
+    return rdpn6d_upsample_bilinear_h2_ex(x, B, H, W, C, factor, y, C, 0, 0, overflow_flag, stream);
+}
+
+// the same into the channel slice [out_co, out_co + C) of an h2 tensor with out_cs channels per pixel, optionally followed by ReLU
+// (a 1x1 convolution + BatchNorm commute with the interpolation - its weights sum to 1 - so "conv at the low resolution, then
+// up-sample + ReLU" replaces "up-sample, then conv + ReLU" at 1/16 of the convolution's rows)
+extern "C" int rdpn6d_upsample_bilinear_h2_ex(const void* x, int B, int H, int W, int C, int factor, void* y, int out_cs, int out_co, int relu,
+                                              int* overflow_flag, void* stream)
+{
     RD_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && C > 0 && C % 32 == 0 && factor >= 1, "shape (C % 32)");
+    RD_REQUIRE(out_cs % 32 == 0 && out_co % 32 == 0 && out_co + C <= out_cs, "output slice: whole 32-channel groups");
     const long long total = (long long)B * H * factor * W * factor * (C / 8);
     const int blocks = (int)((total + 255) / 256 < 32768 ? (total + 255) / 256 : 32768);
     hipLaunchKernelGGL(upsample_bilinear_h2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, B, H, W, C, factor,
-                       (_Float16*)y, overflow_flag);
+                       (_Float16*)y, out_cs, out_co, relu, overflow_flag);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
 }

@@ -601,15 +601,25 @@ class InferencePlan:
         perm = list(range(3, 67)) + [0, 1, 2]  # reference order [xyz | emb] -> buffer order [emb | xyz]
         npx = B * R8 * R8
         if h2_pw:
-            up = self.planes_buf("up_planes", npx * C4, 1)
-            self.call("upsample", lib.rdpn6d_upsample_bilinear_h2, _ptr(pcur), B, cur_hw, cur_hw, C4, R8 // cur_hw, _ptr(up), _ptr(self.h2_flag))
             pcs = 96  # [emb(64) | xyz(3) + 0-pad: one 32-channel group]
             pin = self.planes_buf("pn_in_planes", npx * pcs, 1)
             self.xyz_fn = lib.rdpn6d_xyz_subsample_h2
             self.xyz_args = (B, 6, R, 8, _ptr(pin), pcs, 64, _ptr(self.h2_flag))
             we = pack_conv_weight(sn.xyz_emb.weight.detach().float())
             sce, she = fold_bn(sn.xb, sn.xyz_emb.bias, npad=we.shape[0])
-            self.conv_x3("spatial_net.xyz_emb", up, (R8, R8), we, sce, she, None, pin, (R8, R8), cin=C4, in_cs=C4, N=64, out_cs=pcs, act=1)
+            self.conv_first = bool(model.cfg.get("TEST", {}).get("CONV_BEFORE_UPSAMPLE", True))
+            if self.conv_first:
+                # xyz_emb is a 1x1 convolution + BatchNorm: an affine map per pixel, which commutes with the bilinear interpolation
+                # (weights sum to 1) - evaluate it on layer4's 8x8 map and up-sample its 64 channels instead of all 512 (ReLU after)
+                emb = self.planes_buf("emb_lowres_planes", B * cur_hw * cur_hw * 64, 1)
+                self.conv_x3("spatial_net.xyz_emb", pcur, (cur_hw, cur_hw), we, sce, she, None, emb, (cur_hw, cur_hw), cin=C4, in_cs=C4,
+                             N=64, out_cs=64, act=0)
+                self.call("upsample", lib.rdpn6d_upsample_bilinear_h2_ex, _ptr(emb), B, cur_hw, cur_hw, 64, R8 // cur_hw, _ptr(pin), pcs, 0, 1,
+                          _ptr(self.h2_flag))
+            else:
+                up = self.planes_buf("up_planes", npx * C4, 1)
+                self.call("upsample", lib.rdpn6d_upsample_bilinear_h2, _ptr(pcur), B, cur_hw, cur_hw, C4, R8 // cur_hw, _ptr(up), _ptr(self.h2_flag))
+                self.conv_x3("spatial_net.xyz_emb", up, (R8, R8), we, sce, she, None, pin, (R8, R8), cin=C4, in_cs=C4, N=64, out_cs=pcs, act=1)
             wc1 = pack_conv_weight(sn.conv1.weight.detach().float(), cin_pad=pcs, perm=perm)
             s1, h1 = fold_bn(sn.b1, sn.conv1.bias, npad=wc1.shape[0])
             l1 = self.planes_buf("pn_l1_planes", npx * 128, 1)
@@ -987,7 +997,8 @@ class GDRN(nn.Module):
         if bf16 is True:
             bf16 = str(self.cfg.get("TEST", {}).get("AMP_DTYPE", "bf16"))
         tc = self.cfg.get("TEST", {})
-        key = (B, str(device), bf16 or False, bool(tc.get("BF16X3", True)), bool(tc.get("FP16X2", True)), bool(tc.get("FOLD_GLOBAL_MAX", True)))
+        key = (B, str(device), bf16 or False, bool(tc.get("BF16X3", True)), bool(tc.get("FP16X2", True)), bool(tc.get("FOLD_GLOBAL_MAX", True)),
+               bool(tc.get("CONV_BEFORE_UPSAMPLE", True)))
         stamp = self._weights_stamp()
         plan = self._plans.get(key)
         if plan is not None and plan.weights_stamp != stamp:

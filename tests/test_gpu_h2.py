@@ -208,7 +208,9 @@ def test_global_max_record_and_constant_input_bias_of_the_conv_transpose():
 
 def test_folded_global_max_plan_equals_the_concat_plan():
     """the two forms of the same network: [l3 | broadcast max] through a 1024-channel ConvTranspose, and l3 through a 512-channel one
-    plus the per-crop bias of the constant half - outputs equal up to fp32 summation order (on the ill-conditioned stress weights
+    plus the per-crop bias of the constant half (cfg.TEST.FOLD_GLOBAL_MAX); and xyz_emb (1x1 convolution + BatchNorm) evaluated on
+    layer4's 8x8 map before the bilinear up-sampling instead of after it (cfg.TEST.CONV_BEFORE_UPSAMPLE) - outputs equal up to fp32
+    summation order (on the ill-conditioned stress weights
     of the bench, where the reference's own fp32 evaluation is 4e-4 from the exact one - DESIGN.md section 2 - the two orders may
     differ by a fraction of that; the well-conditioned c1w parity tests run on the folded plan)"""
     import bench
@@ -222,12 +224,14 @@ def test_folded_global_max_plan_equals_the_concat_plan():
         model, _ = bench.build_model(dev, "none")
         model.cfg.TEST.USE_PNP = False
         model.cfg.TEST.FOLD_GLOBAL_MAX = fold
+        model.cfg.TEST.CONV_BEFORE_UPSAMPLE = fold
         with torch.no_grad():
             o = bench.step(model, t)
         plan = model.plan(B, dev)
         assert plan.fast == "h2" and bool(getattr(plan, "fold_gmax", False)) == fold
         names = [L.name for L in plan.launches]
         assert ("global_max" in names) == fold and ("global_max_concat" in names) != fold
+        assert (names.index("spatial_net.xyz_emb") < names.index("upsample")) == fold
         outs[fold] = {k: v.float().clone() for k, v in o.items() if torch.is_tensor(v)}
     assert {"rot", "trans"} <= set(outs[True]) and len(outs[True]) >= 3  # poses + the dense maps
     for k in sorted(outs[True]):
