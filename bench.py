@@ -427,7 +427,9 @@ def main():
             "achieved_tflops_whole_step": round(44.10e9 * value / 1e12, 2),
             "flops_note": ("44.10 GFLOP per crop = the reference network's multiply-adds" +
                            ("; the h2 plan evaluates the spatially constant (broadcast global max) half of the ConvTranspose input as a "
-                            "per-crop bias (cfg.TEST.FOLD_GLOBAL_MAX, DESIGN.md section 4), 2.42 GFLOP per crop it does not execute"
+                            "per-crop bias and composes conv3 + BatchNorm (no activation in between) into the ConvTranspose weights "
+                            "(cfg.TEST.FOLD_GLOBAL_MAX / COMPOSE_CONV3_CONVT, DESIGN.md section 4): identical function, "
+                            f"{3.62 if getattr(model.plan(B, device), 'compose_ct', False) else 2.42} GFLOP per crop it does not execute"
                             if getattr(model.plan(B, device), "fold_gmax", False) else "")),
             "per_rank_crops_per_s": per_rank_rate,
             "roofline": roof,

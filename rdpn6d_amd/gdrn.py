@@ -694,8 +694,20 @@ class InferencePlan:
             # border position, times the BatchNorm scale: the per-crop bias rows of the four phase convolutions
             ct_cin = 512
             wconst = wt[512:].permute(2, 3, 1, 0).reshape(9 * F, 1, 512).contiguous()
+            vconst = None
+            self.compose_ct = bool(model.cfg.get("TEST", {}).get("COMPOSE_CONV3_CONVT", True))
+            if self.compose_ct:
+                # l3 = s3 * (W3 l2) + h3 (conv3 + BatchNorm, no activation) feeds the max and the ConvTranspose only, and the latter is
+                # linear: ConvT_W(l3) = ConvT_{W A}(l2) + ConvT_W(h3), A = diag(s3) W3 - the 512 -> F transposed convolution over l3
+                # becomes a 256 -> F one over l2 (weights composed in fp64 here) plus one more constant-input term in the bias rows
+                W3 = sn.conv3.weight.detach().double().reshape(512, 256)
+                A = s3[:512].double()[:, None] * W3
+                Wl = wt[:512].double()
+                wt_ct = torch.einsum("cnyx,ck->knyx", Wl, A).float()  # (256, F, 3, 3)
+                vconst = torch.einsum("cnyx,c->yxn", Wl, h3[:512].double()).reshape(9 * F).float().contiguous()
+                pF, ct_cin = l2, 256
             V = self.buf("convT_const", B, 9 * F)
-            self.conv_x3("rot_head.convT.const", gmax, (1, 1), wconst, None, None, V, None, (1, 1), cin=512, in_cs=512, N=9 * F,
+            self.conv_x3("rot_head.convT.const", gmax, (1, 1), wconst, None, vconst, V, None, (1, 1), cin=512, in_cs=512, N=9 * F,
                          out_cs=9 * F, act=0)
             cbias = self.buf("convT_crop_bias", 4, B, 4, Fp)
             self.call("convT_const_bias", lib.rdpn6d_convt3x3s2_const_bias_f32, _ptr(V), _ptr(sct), B, F, _ptr(cbias))
@@ -708,8 +720,8 @@ class InferencePlan:
                 for ky, dy in ys:
                     for kx, dx in xs:
                         taps.append((dy, dx))
-                        slabs.append(wt[:, :, ky, kx].t())  # (Cout, Cin)
-                wp = torch.zeros(Fp, len(taps), 1024, **f32)
+                        slabs.append((wt_ct if fold and self.compose_ct else wt)[:, :, ky, kx].t())  # (Cout, Cin)
+                wp = torch.zeros(Fp, len(taps), slabs[0].shape[1], **f32)
                 wp[:F] = torch.stack(slabs, dim=1)
                 if x3_ct:  # planes in, planes out (the fp32 tensor is never materialised)
                     self.conv_x3(f"rot_head.convT.phase{py}{px}", pF, (R8, R8), wp[:, :, :ct_cin].contiguous(), sct, sht, None, pA, (R4, R4),
@@ -998,7 +1010,7 @@ class GDRN(nn.Module):
             bf16 = str(self.cfg.get("TEST", {}).get("AMP_DTYPE", "bf16"))
         tc = self.cfg.get("TEST", {})
         key = (B, str(device), bf16 or False, bool(tc.get("BF16X3", True)), bool(tc.get("FP16X2", True)), bool(tc.get("FOLD_GLOBAL_MAX", True)),
-               bool(tc.get("CONV_BEFORE_UPSAMPLE", True)))
+               bool(tc.get("CONV_BEFORE_UPSAMPLE", True)), bool(tc.get("COMPOSE_CONV3_CONVT", True)))
         stamp = self._weights_stamp()
         plan = self._plans.get(key)
         if plan is not None and plan.weights_stamp != stamp:

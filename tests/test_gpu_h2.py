@@ -209,8 +209,9 @@ def test_global_max_record_and_constant_input_bias_of_the_conv_transpose():
 def test_folded_global_max_plan_equals_the_concat_plan():
     """the two forms of the same network: [l3 | broadcast max] through a 1024-channel ConvTranspose, and l3 through a 512-channel one
     plus the per-crop bias of the constant half (cfg.TEST.FOLD_GLOBAL_MAX); and xyz_emb (1x1 convolution + BatchNorm) evaluated on
-    layer4's 8x8 map before the bilinear up-sampling instead of after it (cfg.TEST.CONV_BEFORE_UPSAMPLE) - outputs equal up to fp32
-    summation order (on the ill-conditioned stress weights
+    layer4's 8x8 map before the bilinear up-sampling instead of after it (cfg.TEST.CONV_BEFORE_UPSAMPLE); and conv3 + BatchNorm
+    (no activation) composed into the ConvTranspose weights (cfg.TEST.COMPOSE_CONV3_CONVT) - outputs equal up to fp32 summation
+    order (on the ill-conditioned stress weights
     of the bench, where the reference's own fp32 evaluation is 4e-4 from the exact one - DESIGN.md section 2 - the two orders may
     differ by a fraction of that; the well-conditioned c1w parity tests run on the folded plan)"""
     import bench
@@ -225,6 +226,7 @@ def test_folded_global_max_plan_equals_the_concat_plan():
         model.cfg.TEST.USE_PNP = False
         model.cfg.TEST.FOLD_GLOBAL_MAX = fold
         model.cfg.TEST.CONV_BEFORE_UPSAMPLE = fold
+        model.cfg.TEST.COMPOSE_CONV3_CONVT = fold
         with torch.no_grad():
             o = bench.step(model, t)
         plan = model.plan(B, dev)
