@@ -800,7 +800,9 @@ extern "C" int rdpn6d_conv2d_h2_cb(const rdpn6d_conv_desc* d, void* y_h2, const 
         a.ntiles = d->Npad / bn;
         int rc;
         static const int nst_env = getenv("RDPN6D_H2_NST") ? atoi(getenv("RDPN6D_H2_NST")) : 0;  // profiling: force 2 | 3 stages
-        const bool three = nst_env ? nst_env == 3 : true;  // three stages wherever two workgroups per CU still fit (<= 80 KiB)
+        // three stages (where two workgroups per CU still fit, <= 80 KiB) pay on long K loops only: layer4's 144 chunks 97 -> 70 us, but
+        // layer1's 18 chunks run 92 us against 84 with two stages (a third workgroup per CU fits and the longer prologue is not amortised)
+        const bool three = nst_env ? nst_env == 3 : a.nk >= 32;
         if (bm == 128 && bn == 128) rc = launch_h2_tile<128, 128, 2>(ax, s);  // (96 KiB with three stages: one workgroup per CU)
         else if (bm == 128) rc = three ? launch_h2_tile<128, 64, 3>(ax, s) : launch_h2_tile<128, 64, 2>(ax, s);
         else if (bn == 128) rc = three ? launch_h2_tile<64, 128, 3>(ax, s) : launch_h2_tile<64, 128, 2>(ax, s);
