@@ -24,7 +24,7 @@
 
 #pragma clang fp contract(off)
 
-#define RS_THREADS 512
+#define RS_THREADS 1024
 #define RS_WAVES (RS_THREADS / 64)
 #define RS_MAX_ITERS 256
 
@@ -194,8 +194,8 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_kabsch_kernel(
     float* s_pose = reinterpret_cast<float*>(s_dbl + RS_WAVES * 9 + 16);        // 12 * RS_MAX_ITERS
     int* s_cnt = reinterpret_cast<int*>(s_pose + 12 * RS_MAX_ITERS);            // RS_MAX_ITERS
     float* s_anchor = reinterpret_cast<float*>(s_cnt + RS_MAX_ITERS);           // 3 * 64
-    int* s_misc = reinterpret_cast<int*>(s_anchor + 3 * 64);                    // 32 ints
-    float* s_q = reinterpret_cast<float*>(s_misc + 32);                         // 3 * HW
+    int* s_misc = reinterpret_cast<int*>(s_anchor + 3 * 64);                    // 64 ints
+    float* s_q = reinterpret_cast<float*>(s_misc + 64);                         // 3 * HW
     unsigned short* s_pix = reinterpret_cast<unsigned short*>(s_q + 3 * (size_t)HW);  // HW
     unsigned char* s_ai = reinterpret_cast<unsigned char*>(s_pix + HW);         // HW
 
@@ -214,13 +214,13 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_kabsch_kernel(
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
     float* s_f = reinterpret_cast<float*>(s_misc);
-    if (lane == 0) { s_f[wave] = mn; s_f[8 + wave] = mx; }
+    if (lane == 0) { s_f[wave] = mn; s_f[RS_WAVES + wave] = mx; }
     for (int i = tid; i < 3 * K; i += RS_THREADS) s_anchor[i] = A[i];
     if (inlier_mask) for (int p = tid; p < HW; p += RS_THREADS) inlier_mask[(size_t)b * HW + p] = 0;
     __syncthreads();
-    mn = s_f[0]; mx = s_f[8];
+    mn = s_f[0]; mx = s_f[RS_WAVES];
 #pragma unroll
-    for (int wv = 1; wv < RS_WAVES; wv++) { mn = fminf(mn, s_f[wv]); mx = fmaxf(mx, s_f[8 + wv]); }
+    for (int wv = 1; wv < RS_WAVES; wv++) { mn = fminf(mn, s_f[wv]); mx = fmaxf(mx, s_f[RS_WAVES + wv]); }
     const float range = mx - mn;
     __syncthreads();
 
@@ -242,11 +242,11 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_kabsch_kernel(
         }
         const unsigned long long bal = __ballot(sel);
         const int before = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) s_misc[16 + wave] = __popcll(bal);
+        if (lane == 0) s_misc[2 * RS_WAVES + wave] = __popcll(bal);
         __syncthreads();
         int woff = 0, tot = 0;
 #pragma unroll
-        for (int wv = 0; wv < RS_WAVES; wv++) { const int c = s_misc[16 + wv]; woff += wv < wave ? c : 0; tot += c; }
+        for (int wv = 0; wv < RS_WAVES; wv++) { const int c = s_misc[2 * RS_WAVES + wv]; woff += wv < wave ? c : 0; tot += c; }
         if (sel) {
             const int pos = n + woff + before;
             s_q[3 * pos] = qx; s_q[3 * pos + 1] = qy; s_q[3 * pos + 2] = qz;
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_kabsch_kernel(
 static size_t rs_smem_bytes(int HW)
 {
     size_t s = sizeof(double) * (RS_WAVES * 9 + 16) + sizeof(float) * 12 * RS_MAX_ITERS + sizeof(int) * RS_MAX_ITERS +
-               sizeof(float) * 3 * 64 + sizeof(int) * 32;
+               sizeof(float) * 3 * 64 + sizeof(int) * 64;
     s += sizeof(float) * 3 * (size_t)HW + sizeof(unsigned short) * (size_t)HW + (size_t)HW;
     return (s + 15) & ~(size_t)15;
 }
