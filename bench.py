@@ -36,12 +36,14 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak F
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (same guide; never the 2:1-sparsity figure)
 
 
-def build_model(device, mask_attention="none", bf16=False, graph=False, x3=True, fast="h2"):
+def build_model(device, mask_attention="none", bf16=False, graph=False, x3=True, fast="h2", backbone=34, res=256):
     from rdpn6d_amd import synth
     from rdpn6d_amd.config import gdrn_base_cfg
     from rdpn6d_amd.gdrn import build_model_optimizer
 
     cfg = gdrn_base_cfg(mask_attention=mask_attention, device=str(device))
+    if (backbone, res) != (34, 256):  # BASELINE configuration C5: ResNet-50 trunk, 320x320 crops (training line only)
+        cfg.MODEL.CDPN.BACKBONE.NUM_LAYERS, cfg.MODEL.CDPN.BACKBONE.INPUT_RES, cfg.MODEL.CDPN.BACKBONE.OUTPUT_RES = backbone, res, res // 4
     cfg.TEST.USE_PNP = True  # the step includes the per-crop RANSAC/Kabsch solve ("fwd+PnP")
     cfg.TEST.PNP_TYPE = "ransac_kabsch"  # the north star's solver (3D-3D on the RGB-D residual geometry); "ransac_pnp" = the 2D-3D one
     cfg.TEST.AMP_TEST = bool(bf16)  # secondary mode: trunk + fusion + head on the 16-bit matrix pipe (bf16 | fp16)
@@ -52,9 +54,12 @@ def build_model(device, mask_attention="none", bf16=False, graph=False, x3=True,
     cfg.TEST.BF16X3 = bool(x3) and fast in ("h2", "x3")  # master switch
     cfg.TEST.FP16X2 = fast == "h2"
     model, _ = build_model_optimizer(cfg)
-    sd = synth.make_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=1234)
-    bn = np.load(os.path.join(ROOT, "tests", "golden", "bn_stats_c1.npz"))
-    sd.update({k: bn[k] for k in bn.files})
+    if (backbone, res) != (34, 256):
+        sd = synth.make_trained_like_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=7)
+    else:
+        sd = synth.make_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=1234)
+        bn = np.load(os.path.join(ROOT, "tests", "golden", "bn_stats_c1.npz"))
+        sd.update({k: bn[k] for k in bn.files})
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
     model.eval()
     return model, sd
@@ -236,7 +241,7 @@ def train_bench(args, rank, world, device, dist):
     from rdpn6d_amd.ranger import Ranger
 
     B = args.batch if args.batch != 64 else 32
-    model, _ = build_model(device, "mul")
+    model, _ = build_model(device, "mul", backbone=args.backbone, res=args.res)
     model.cfg.TEST.USE_PNP = False
     amp = args.dtype in ("bf16", "fp16")
     model.cfg.SOLVER.AMP.ENABLED = amp  # --dtype bf16 | fp16: mixed precision (16-bit fwd/dgrad/wgrad convolutions, fp32 everything else)
@@ -247,7 +252,7 @@ def train_bench(args, rank, world, device, dist):
     buckets = GradBuckets(model, always_reduce=bool(os.environ.get("RDPN6D_BENCH_FORCE_DIST")))
     order = [p for g in ("pnp_net", "rot_head_net", "backbone") for p in getattr(model, g).parameters()]
     opt = Ranger(order, lr=1e-4, flat_grad=buckets.flat)  # fused HIP step over the same flat gradient buffer
-    inp = synth.make_inputs(B, seed=200 + rank)
+    inp = synth.make_inputs(B, seed=200 + rank, res=args.res)
     batch = {k: torch.from_numpy(v).to(device) for k, v in {**inp, **synth.make_train_gt(B, inp)}.items()}
 
     def one_step():
@@ -283,16 +288,17 @@ def train_bench(args, rank, world, device, dist):
     if rank == 0:
         value = world * B * args.steps / elapsed
         print(json.dumps({
-            "metric": "RGB-D crops/sec, TRAINING step (fwd+losses+bwd+allreduce+Ranger) at 256x256", "value": round(value, 1),
+            "metric": f"RGB-D crops/sec, TRAINING step (fwd+losses+bwd+allreduce+Ranger) at {args.res}x{args.res}", "value": round(value, 1),
             "unit": "crops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": f"{args.dtype} convolutions (fwd + dgrad + wgrad) and stored activations, fp32 BN math / losses / pose branch / optimizer" if amp else "f32",
             "data": "synthetic",
-            "config": {"workload": "LM-O style training step, MASK_ATTENTION=mul, K=32, ResNet-34, per-GPU BatchNorm, "
+            "config": {"workload": ("LM-O style" if (args.backbone, args.res) == (34, 256) else "MP6D style (BASELINE C5 shape)")
+                                   + f" training step, MASK_ATTENTION=mul, K=32, ResNet-{args.backbone}, {args.res}x{args.res} crops, per-GPU BatchNorm, "
                                    + ("SOLVER.AMP.ENABLED" if amp else "fp32"),
                        "batch_per_gpu": B, "global_batch": B * world,
                        "parallelism": f"dp{world}: flat gradient buffer, 3 bucketed RCCL all-reduces overlapped with backward, fused HIP Ranger"},
-            "achieved_tflops_whole_step": round(132.3e9 * value / 1e12, 2),
+            "achieved_tflops_whole_step": round(132.3e9 * value / 1e12, 2) if (args.backbone, args.res) == (34, 256) else None,
             "loss_total": round(float(sum(v.item() for v in losses.values())), 4)}))
     if dist is not None:
         dist.destroy_process_group()
@@ -314,6 +320,9 @@ def main():
     ap.add_argument("--fast", default="h2", choices=["h2", "x3", "none"],
                     help="fp32 mode: fp32-accurate form of the wide layers on the 16-bit matrix pipe: h2 = two fp16 planes, 3 partial "
                          "products (cfg.TEST.FP16X2, default) | x3 = three bf16 planes, 6 partial products (cfg.TEST.BF16X3) | none")
+    ap.add_argument("--backbone", type=int, default=34, choices=[18, 34, 50, 101],
+                    help="--train only: ResNet depth (BASELINE C5 = 50 with --res 320 --dtype fp16)")
+    ap.add_argument("--res", type=int, default=256, help="--train only: crop size (C5: 320)")
     ap.add_argument("--test-cfg", default="", metavar="KEY=0|1[,...]",
                     help="override boolean cfg.TEST switches for A/B runs, e.g. FOLD_GLOBAL_MAX=0,CONV_BEFORE_UPSAMPLE=0 "
                          "(the reference's evaluation order of the two algebraic rewrites of the h2 plan)")

@@ -13,11 +13,12 @@ python bench.py --train --dtype bf16 --steps 30 > $O/bench_train_bf16.json 2>> $
 python bench.py --train --steps 30 > $O/bench_train_f32.json 2>> $O/bench.err
 python bench.py --dtype fp16 --no-cpu-baseline > $O/bench_fp16.json 2>> $O/bench.err
 python bench.py --train --dtype fp16 --steps 30 > $O/bench_train_fp16.json 2>> $O/bench.err
+python bench.py --train --dtype fp16 --backbone 50 --res 320 --steps 30 > $O/bench_train_c5_fp16.json 2>> $O/bench.err
 python tools/bench_next_rows.py > $O/next_rows.jsonl 2>> $O/bench.err
 python bench.py --steps 4000 --trace 200 --no-cpu-baseline > $O/bench_sustained.json 2>> $O/bench.err
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --no-cpu-baseline --steps 20 > /dev/null 2>&1
 cd $R; f=$(ls $O/prof/*/*kernel_stats.csv | head -1); cp $f $O/kernel_stats.csv; rm -rf $O/prof
 bash tools/pmc_bench.sh $TAG > $O/pmc.log 2>&1; cp gpurun_out/pmc_$TAG/summary.json $O/pmc_summary.json; cp gpurun_out/pmc_$TAG/summary.md $O/pmc_summary.md; rm -rf gpurun_out/pmc_$TAG/raw_*
-for f in bench_mul bench_x3 bench_fp32mfma bench_bf16 bench_fp16 bench_train_bf16 bench_train_fp16 bench_train_f32 bench_sustained; do python3 -c "
+for f in bench_mul bench_x3 bench_fp32mfma bench_bf16 bench_fp16 bench_train_bf16 bench_train_fp16 bench_train_f32 bench_train_c5_fp16 bench_sustained; do python3 -c "
 import json; d=json.load(open('$O/$f.json')); print('$f', d['value'], d['ms_per_step'], d.get('ms_per_step_trace', {}).get('drift_last_vs_first'))"; done
