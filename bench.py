@@ -320,6 +320,7 @@ def main():
     ap.add_argument("--fast", default="h2", choices=["h2", "x3", "none"],
                     help="fp32 mode: fp32-accurate form of the wide layers on the 16-bit matrix pipe: h2 = two fp16 planes, 3 partial "
                          "products (cfg.TEST.FP16X2, default) | x3 = three bf16 planes, 6 partial products (cfg.TEST.BF16X3) | none")
+    ap.add_argument("--cam", default="lm", choices=["lm", "ycbv"], help="camera intrinsics / object set of the synthetic crops (C4: ycbv)")
     ap.add_argument("--backbone", type=int, default=34, choices=[18, 34, 50, 101],
                     help="--train only: ResNet depth (BASELINE C5 = 50 with --res 320 --dtype fp16)")
     ap.add_argument("--res", type=int, default=256, help="--train only: crop size (C5: 320)")
@@ -368,7 +369,7 @@ def main():
         k, v = kv.split("=")
         model.cfg.TEST[k.strip()] = bool(int(v))
     B = args.batch
-    t = {k: torch.from_numpy(v).to(device) for k, v in synth.make_inputs(B, seed=100 + rank).items()}
+    t = {k: torch.from_numpy(v).to(device) for k, v in synth.make_inputs(B, seed=100 + rank, cam=args.cam).items()}
 
     def barrier():
         if dist is not None:
@@ -428,7 +429,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": dtype_label, "data": "synthetic",
-            "config": {"workload": f"LM 13-object inference, batch={B} per GPU, 256x256 RGB-D crops, K=32 regions, "
+            "config": {"workload": ("LM 13-object" if args.cam == "lm" else "YCB-V 21-object (BASELINE C4 shape: YCB-V intrinsics)")
+                                   + f" inference, batch={B} per GPU, 256x256 RGB-D crops, K=32 regions, "
                                    "ResNet-34 trunk + dense head + ConvPnPNet + pose decode + per-crop RANSAC/Kabsch (100 hyp.), all on-device",
                        "batch_per_gpu": B, "global_batch": B * world, "mask_attention": args.mask_attention,
                        "parallelism": f"replicated weights, {world} independent shard(s), no collective",
