@@ -123,3 +123,25 @@ def test_bench_contract_over_rccl_one_rank(train):
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["value"] > 0 and out["config"]["global_batch"] == 8
+
+
+@pytest.mark.parametrize("extra,check", [
+    (["--cam", "ycbv", "--mask-attention", "mul", "--batch", "16", "--test-cfg", "FOLD_GLOBAL_MAX=0,COMPOSE_CONV3_CONVT=0"], "YCB-V"),
+    (["--train", "--dtype", "fp16", "--backbone", "50", "--res", "320", "--batch", "4"], "ResNet-50"),
+])
+def test_bench_secondary_lines(extra, check):
+    """the BASELINE-shaped secondary lines of bench.py (C4: YCB-V intrinsics; C5: ResNet-50 / 320x320 / fp16 training) and the
+    --test-cfg switch run and label themselves"""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu-baseline"] + extra,
+                       cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["value"] > 0 and check in out["config"]["workload"]
+    if "--train" not in extra:
+        assert "flops_note" in out and "does not execute" not in out["flops_note"]  # the rewrites were switched off
