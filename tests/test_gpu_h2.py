@@ -206,7 +206,8 @@ def test_global_max_record_and_constant_input_bias_of_the_conv_transpose():
     assert checked == 9
 
 
-def test_folded_global_max_plan_equals_the_concat_plan():
+@pytest.mark.parametrize("backbone,res", [(34, 256), (50, 320)])
+def test_folded_global_max_plan_equals_the_concat_plan(backbone, res):
     """the two forms of the same network: [l3 | broadcast max] through a 1024-channel ConvTranspose, and l3 through a 512-channel one
     plus the per-crop bias of the constant half (cfg.TEST.FOLD_GLOBAL_MAX); and xyz_emb (1x1 convolution + BatchNorm) evaluated on
     layer4's 8x8 map before the bilinear up-sampling instead of after it (cfg.TEST.CONV_BEFORE_UPSAMPLE); and conv3 + BatchNorm
@@ -218,11 +219,11 @@ def test_folded_global_max_plan_equals_the_concat_plan():
     from rdpn6d_amd import synth
 
     dev = torch.device("cuda:0")
-    B = 16  # >= 16: the h2 plan
-    t = {k: torch.from_numpy(v).to(dev) for k, v in synth.make_inputs(B, seed=11).items()}
+    B = 16  # >= 16: the h2 plan.  (50, 320): Bottleneck trunk, 40x40 -> 80x80 ConvTranspose (other border rows, other tile counts)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in synth.make_inputs(B, seed=11, res=res).items()}
     outs = {}
     for fold in (True, False):
-        model, _ = bench.build_model(dev, "none")
+        model, _ = bench.build_model(dev, "none", backbone=backbone, res=res)
         model.cfg.TEST.USE_PNP = False
         model.cfg.TEST.FOLD_GLOBAL_MAX = fold
         model.cfg.TEST.CONV_BEFORE_UPSAMPLE = fold
