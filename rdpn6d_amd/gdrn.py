@@ -297,6 +297,7 @@ class InferencePlan:
         self.h2_flag = torch.zeros(1, dtype=torch.int32, device=device)  # set by a kernel that had to clamp to the fp16 range
         self._flag_host = torch.zeros(1, dtype=torch.int32).pin_memory() if self.fast == "h2" else None
         self._flag_event = None
+        self._side_stream = None  # second HIP stream for work that only depends on the glue kernel (plain RANSAC), created on first use
         self._build(model)
 
     # ---- buffers
@@ -829,7 +830,10 @@ class InferencePlan:
                   slope=0.1, ksplit=True)
 
     # ---- run
-    def run(self, x, roi_coord_2d, fps, roi_cams, roi_centers, roi_whs, resize_ratios, is_allo=True, train_pose=False):
+    def run(self, x, roi_coord_2d, fps, roi_cams, roi_centers, roi_whs, resize_ratios, is_allo=True, train_pose=False, after_glue=None):
+        """after_glue: optional callable launched on a SIDE stream right after the glue kernel (it may read out_nchw / argmax / pnp_in,
+        the glue's outputs): work that does not depend on ConvPnPNet - the plain RANSAC solve - then overlaps its small launches;
+        the main stream re-joins it before run() returns."""
         lib = self.lib
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         B = self.B
@@ -838,11 +842,21 @@ class InferencePlan:
         for L in self.launches:
             _lib.check(L.fn(*L.args, st), L.name)
         _lib.check(lib.rdpn6d_dense_glue_f32(*self.glue_args(roi_coord_2d, fps), st), "dense_glue")
+        side = None
+        if after_glue is not None:
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=self.device)
+            side = self._side_stream
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                after_glue()
         for L in self.post:
             _lib.check(L.fn(*L.args, st), L.name)
         _lib.check(lib.rdpn6d_pose_decode_f32(_ptr(self.rt), 16, _ptr(roi_cams), _ptr(roi_centers), _ptr(roi_whs),
                                               _ptr(resize_ratios), B, 1 if is_allo else 0, 1 if train_pose else 0,
                                               _ptr(self.rot), _ptr(self.trans), st), "pose_decode")
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
         if self._flag_host is not None and not torch.cuda.is_current_stream_capturing():
             # range flag of the h2 kernels -> pinned host memory, without stalling the launch queue; looked at by the next call
             self._flag_host.copy_(self.h2_flag, non_blocking=True)
@@ -1076,8 +1090,24 @@ class GDRN(nn.Module):
             roi_extents = f32c(roi_extents)
         is_allo = "allo" in pcfg.ROT_TYPE
 
+        def kabsch_solve():
+            # per-crop RANSAC + Kabsch on the residual correspondences, result next to the learned pose
+            plan.run_ransac(roi_coord_2d, fps, roi_extents, resize_ratios,
+                            mask_thr=float(self.cfg.MODEL.CDPN.ROT_HEAD.MASK_THR_TEST),
+                            inlier_thr=float(tcfg.get("PNP_INLIER_THR", 0.01)),
+                            iters=int(tcfg.get("PNP_ITERS", 20 if net_mode == 1 else 100)),  # 20: gdrn_evaluator.py:275
+                            confidence=float(tcfg.get("PNP_CONFIDENCE", 0.99)), seed=int(tcfg.get("PNP_SEED", 0)),
+                            net_mode=net_mode, max_t_diff=float(tcfg.get("PNP_MAX_T_DIFF", 1.0)))
+
+        # the plain solve (no network pose involved) needs only the glue kernel's outputs: it runs on a second stream next to
+        # ConvPnPNet's small launches (cfg.TEST.PNP_SIDE_STREAM, default on) and is joined before the outputs are handed out
+        overlap = use_pnp and kabsch and net_mode == 0 and bool(tcfg.get("PNP_SIDE_STREAM", True))
+
         def launch():
-            plan.run(x, roi_coord_2d, fps, roi_cams, roi_centers, roi_whs, resize_ratios, is_allo=is_allo)
+            plan.run(x, roi_coord_2d, fps, roi_cams, roi_centers, roi_whs, resize_ratios, is_allo=is_allo,
+                     after_glue=kabsch_solve if overlap else None)
+            if overlap:
+                return
             if use_pnp and not kabsch:
                 # the reference leaves "TODO: move the pnp/ransac inside forward" (GDRN.py:294); here it is inside: selection +
                 # 2D-3D RANSAC-PnP with the call sites' parameters (3 px, 100 | 20 iterations: gdrn_evaluator.py:275,386-389)
@@ -1089,13 +1119,7 @@ class GDRN(nn.Module):
                                confidence=float(tcfg.get("PNP_CONFIDENCE", 0.99)), seed=int(tcfg.get("PNP_SEED", 0)), net_mode=net_mode,
                                max_t_diff=float(tcfg.get("PNP_MAX_T_DIFF", 1.0)))
             elif use_pnp:
-                # per-crop RANSAC + Kabsch on the residual correspondences, result next to the learned pose
-                plan.run_ransac(roi_coord_2d, fps, roi_extents, resize_ratios,
-                                mask_thr=float(self.cfg.MODEL.CDPN.ROT_HEAD.MASK_THR_TEST),
-                                inlier_thr=float(tcfg.get("PNP_INLIER_THR", 0.01)),
-                                iters=int(tcfg.get("PNP_ITERS", 20 if net_mode == 1 else 100)),  # 20: gdrn_evaluator.py:275
-                                confidence=float(tcfg.get("PNP_CONFIDENCE", 0.99)), seed=int(tcfg.get("PNP_SEED", 0)),
-                                net_mode=net_mode, max_t_diff=float(tcfg.get("PNP_MAX_T_DIFF", 1.0)))
+                kabsch_solve()
 
         if tcfg.get("HIP_GRAPH", False):
             # one hipGraph per set of input buffers: a serving loop that re-fills the same device buffers replays ~90
@@ -1103,7 +1127,7 @@ class GDRN(nn.Module):
             key = tuple(t.data_ptr() for t in (x, roi_coord_2d, fps, roi_cams, roi_centers, roi_whs, resize_ratios)) + (
                 roi_extents.data_ptr() if use_pnp else 0, is_allo, use_pnp, float(tcfg.get("PNP_INLIER_THR", 0.01)),
                 int(tcfg.get("PNP_ITERS", 100)), int(tcfg.get("PNP_SEED", 0)), tcfg.get("PNP_TYPE", "ransac_pnp"),
-                torch.cuda.current_stream().cuda_stream)
+                bool(tcfg.get("PNP_SIDE_STREAM", True)), torch.cuda.current_stream().cuda_stream)
             plan.run_graphed(key, launch)
         else:
             launch()

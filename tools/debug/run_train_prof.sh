@@ -1,7 +1,7 @@
 # kernel stats of the AMP training step: bash tools/debug/run_train_prof.sh <dtype> <outdir-under-gpurun_out>
 R=$(pwd); DT=${1:-bf16}; OUT=$R/gpurun_out/${2:-train_prof}; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/kt
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 $R/bench.py --train --dtype $DT --no-cpu-baseline --steps 10 --warmup 2 > $OUT/bench.json 2>$OUT/err.log
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 $R/bench.py --train $( [ "$DT" = f32 ] || echo --dtype $DT ) --no-cpu-baseline --steps 10 --warmup 2 > $OUT/bench.json 2>$OUT/err.log
 f=$(ls /tmp/kt/*/*kernel_stats.csv | head -1); cp $f $OUT/kernel_stats.csv
 python3 - "$OUT/kernel_stats.csv" <<'PY'
 import csv, sys
