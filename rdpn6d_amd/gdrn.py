@@ -16,6 +16,7 @@ Generalisation over the reference's hard-coded geometry: ``nIn =
 xyz resize = ``INPUT_RES/8``, out = ``INPUT_RES/4``, ``fc1`` in = ``128*(OUT_RES/8)**2``.
 """
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -475,9 +476,13 @@ class InferencePlan:
         # 16-bit matrix pipe too (tile kernels of csrc/conv_igemm_h2.hip / conv_igemm_bf16x3_tile.hip) and hand their activations on
         # in plane form; the residual is read from planes as well, only the last block writes the fp32 tensor the up-sampling reads.
         wide = 256 if hasattr(bb.layer1[0], "conv3") else 64  # channels of the widest (layer1) activation
-        if self.x3 and 65536 <= B * R4 * R4 and self._fast_bytes(B * R4 * R4, wide) >= (1 << 32) - 64:
+        # rows of the layer1 activation from which the trunk leaves the fp32 MFMA: bf16x3 pays from 16 crops of 256x256 on; the h2 tile
+        # kernels from 6 (per-image batches of the reference's test loop: B = 8 2.42 -> 2.00 ms, B = 12 3.19 -> 2.29, B = 15 3.76 -> 2.48;
+        # B = 4 would lose 9 %).  RDPN6D_TRUNK_MIN_ROWS overrides (profiling)
+        trunk_min = int(os.environ.get("RDPN6D_TRUNK_MIN_ROWS", 24576 if self.fast == "h2" else 65536))
+        if self.x3 and trunk_min <= B * R4 * R4 and self._fast_bytes(B * R4 * R4, wide) >= (1 << 32) - 64:
             self._x3_limit_warning(B * R4 * R4, wide)
-        x3_trunk = self.x3 and 65536 <= B * R4 * R4 and self._fast_bytes(B * R4 * R4, wide) < (1 << 32) - 64
+        x3_trunk = self.x3 and trunk_min <= B * R4 * R4 and self._fast_bytes(B * R4 * R4, wide) < (1 << 32) - 64
         self.x3_trunk = x3_trunk
         # h2 mode with the trunk on it: the point-wise fusion branch, the ConvTranspose input and the 1x1 output convolution
         # stay in the h2 format as well (csrc/pointwise_h2.hip) - no fp32 copy of those activations, no split passes
