@@ -298,6 +298,10 @@ class InferencePlan:
         self.h2_flag = torch.zeros(1, dtype=torch.int32, device=device)  # set by a kernel that had to clamp to the fp16 range
         self._flag_host = torch.zeros(1, dtype=torch.int32).pin_memory() if self.fast == "h2" else None
         self._flag_event = None
+        # rows from which a layer takes the fast path's tile kernel: bf16x3 pays from 8192 (two crops' head); with h2 the WHOLE network
+        # stays in the h2 format from one crop on (B = 1 1.48 -> 1.24 ms, B = 4 1.83 -> 1.71, B = 7 2.40 -> 2.05: no fp32 <-> plane
+        # conversions, the rewrites of DESIGN.md section 4 apply at every batch size).  RDPN6D_TILE_MIN_ROWS overrides (profiling)
+        self._tile_min_rows = int(os.environ.get("RDPN6D_TILE_MIN_ROWS", 1024 if self.fast == "h2" else 8192))
         self._side_stream = None  # second HIP stream for work that only depends on the glue kernel (plain RANSAC), created on first use
         self._build(model)
 
@@ -367,9 +371,9 @@ class InferencePlan:
     def x3_tile_ok(self, M, N, cin):
         """the bf16x3 tile kernel (128x128 .. 64x64) for a layer too small for the 256x256 one: 1.35-1.45x the fp32-MFMA
         kernel from two crops on (head layer: 73 vs 105 us at B=2, 123 vs 190 at B=4, 264 vs 354 at B=8)"""
-        if self.x3 and N % 64 == 0 and cin % 32 == 0 and M >= 8192 and self._fast_bytes(M, max(N, cin)) >= (1 << 32) - 64:
+        if self.x3 and N % 64 == 0 and cin % 32 == 0 and M >= self._tile_min_rows and self._fast_bytes(M, max(N, cin)) >= (1 << 32) - 64:
             self._x3_limit_warning(M, max(N, cin))
-        return self.x3 and N % 64 == 0 and cin % 32 == 0 and M >= 8192 and self._fast_bytes(M, max(N, cin)) < (1 << 32) - 64
+        return self.x3 and N % 64 == 0 and cin % 32 == 0 and M >= self._tile_min_rows and self._fast_bytes(M, max(N, cin)) < (1 << 32) - 64
 
     def _fast_bytes(self, M, C):
         """bytes of an M x C activation in the fast path's plane format: 2 x fp16 (h2) or 3 x bf16 (bf16x3)"""
@@ -477,9 +481,9 @@ class InferencePlan:
         # in plane form; the residual is read from planes as well, only the last block writes the fp32 tensor the up-sampling reads.
         wide = 256 if hasattr(bb.layer1[0], "conv3") else 64  # channels of the widest (layer1) activation
         # rows of the layer1 activation from which the trunk leaves the fp32 MFMA: bf16x3 pays from 16 crops of 256x256 on; the h2 tile
-        # kernels from 6 (per-image batches of the reference's test loop: B = 8 2.42 -> 2.00 ms, B = 12 3.19 -> 2.29, B = 15 3.76 -> 2.48;
-        # B = 4 would lose 9 %).  RDPN6D_TRUNK_MIN_ROWS overrides (profiling)
-        trunk_min = int(os.environ.get("RDPN6D_TRUNK_MIN_ROWS", 24576 if self.fast == "h2" else 65536))
+        # kernels from the first (per-image batches of the reference's test loop: B = 8 2.42 -> 2.05 ms, B = 15 3.76 -> 2.55, and with the
+        # point-wise branch in h2 as well B = 1 1.48 -> 1.24).  RDPN6D_TRUNK_MIN_ROWS overrides (profiling)
+        trunk_min = int(os.environ.get("RDPN6D_TRUNK_MIN_ROWS", 4096 if self.fast == "h2" else 65536))
         if self.x3 and trunk_min <= B * R4 * R4 and self._fast_bytes(B * R4 * R4, wide) >= (1 << 32) - 64:
             self._x3_limit_warning(B * R4 * R4, wide)
         x3_trunk = self.x3 and trunk_min <= B * R4 * R4 and self._fast_bytes(B * R4 * R4, wide) < (1 << 32) - 64
