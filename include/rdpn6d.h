@@ -136,6 +136,13 @@ int rdpn6d_conv2d_h2(const rdpn6d_conv_desc* d, void* y_h2, const void* res_h2, 
  * the spatially constant half of their input (below). */
 int rdpn6d_conv2d_h2_cb(const rdpn6d_conv_desc* d, void* y_h2, const void* res_h2, int* overflow_flag, const float* crop_bias,
                         void* stream);
+/* ... and a workspace: a launch too small to fill the chip (per-image batches: one crop's layer4 is 64 rows x 4608 reductions) cuts
+ * K into slices that write fp32 partial tiles; a second launch adds them in slice order (deterministic) and runs the epilogue.
+ * rdpn6d_conv_h2_workspace_bytes = what the layer wants (0: it does not split); launches of one stream can share a buffer; without
+ * a (large enough) workspace the call is rdpn6d_conv2d_h2_cb. */
+long long rdpn6d_conv_h2_workspace_bytes(const rdpn6d_conv_desc* d);
+int rdpn6d_conv2d_h2_ws(const rdpn6d_conv_desc* d, void* y_h2, const void* res_h2, int* overflow_flag, const float* crop_bias,
+                        void* workspace, long long workspace_bytes, void* stream);
 /* h2 forms of the kernels between the h2 convolutions of the point-wise fusion branch (same argument meaning as the _f32 entry
  * points; activations are h2 tensors, C / out_cs / out_co multiples of 32; the xyz subsample fills one whole 32-channel group
  * [x y z 0 ...]; csrc/pointwise_h2.hip) */

@@ -37,6 +37,11 @@ struct ConvH2Args {
     // per-crop bias [B][4][Npad] added after scale / shift: row (b, variant) with variant = (last output row) * 2 + (last output column)
     // - the contribution of a spatially constant input slice to a ConvTranspose phase (pointwise_h2.hip); null = none
     const float* crop_bias;
+    // split-K of the tile kernel (per-image batches: layer3 / layer4 of one crop are 256 / 64 rows x 2304 / 4608 reductions on a
+    // handful of workgroups): gridDim.y K-slices of b.kper chunks each write raw fp32 partial tiles to `partial`
+    // ([slice][mtiles*BM][Npad]); h2_splitk_reduce_kernel adds the slices in slice order (deterministic) and runs the epilogue
+    float* partial;
+    int nsplit, mpad;
 };
 
 namespace {
@@ -488,8 +493,9 @@ __global__ __launch_bounds__(256, 2) void conv_h2_tile_kernel(const ConvH2Args a
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrc, (lds_ptr_t)dst, 16, (int)(w_off[i] + wk), 0, 0, 0);
         }
     };
-    const int nk = a.nk;
-    int ld_cc = 0, ld_tap = 0, ld_left = nk - 1;
+    const int nk = a.kper;  // all chunks, or K-slice blockIdx.y (chunk order: channel-chunk major, taps innermost)
+    const int kt0 = (int)blockIdx.y * a.kper;
+    int ld_cc = kt0 / d.ntaps, ld_tap = kt0 - (kt0 / d.ntaps) * d.ntaps, ld_left = nk - 1;
     auto next_chunk = [](int& tap, int& cc, int& left, const int ntaps) {
         const int go = left > 0 ? 1 : 0;
         left -= go;
@@ -622,6 +628,24 @@ __global__ __launch_bounds__(256, 2) void conv_h2_tile_kernel(const ConvH2Args a
             shj[j] = d.shift ? d.shift[n] : 0.f;
         }
         const int rrow = lane / LPR, c8 = (lane % LPR) * 8;
+        if (ax.partial) {  // split-K: the raw partial tile of this K-slice (rows past M included: the workspace is tile-padded)
+            float* part = ax.partial + ((size_t)blockIdx.y * ax.mpad + (size_t)m0 + wm * (BM / 2)) * d.Npad + nb + c8;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) cst[((e & 3) + 8 * (e >> 2) + 4 * hi) * CS + j * 32 + frow] = acc[i][j][e];
+#pragma unroll
+                for (int rr = 0; rr < 32 / RPI; ++rr) {
+                    const int row = rr * RPI + rrow;
+                    float* pp = part + (size_t)(i * 32 + row) * d.Npad;
+                    *reinterpret_cast<f32x4*>(pp) = *reinterpret_cast<const f32x4*>(cst + row * CS + c8);
+                    *reinterpret_cast<f32x4*>(pp + 4) = *reinterpret_cast<const f32x4*>(cst + row * CS + c8 + 4);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -644,6 +668,45 @@ __global__ __launch_bounds__(256, 2) void conv_h2_tile_kernel(const ConvH2Args a
     }
 }
 
+// Second pass of the split-K form: one thread = 8 consecutive channels of one output row; the K-slices are added in slice order
+// (three loads in flight per step), then scale / shift and the common tail (residual, activation, fp32 and / or h2 stores).
+__global__ __launch_bounds__(256) void h2_splitk_reduce_kernel(const ConvH2Args ax)
+{
+    const ConvBArgs& a = ax.b;
+    const rdpn6d_conv_desc& d = a.d;
+    const int n8 = d.Npad >> 3;
+    const long long total = a.M * n8;
+    const size_t sstride = (size_t)ax.mpad * d.Npad;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long m = i / n8;
+        const int ch = (int)(i - m * n8) * 8;
+        if (ch >= d.N) continue;
+        const float* pp = ax.partial + (size_t)m * d.Npad + ch;
+        f32x4 s0 = *reinterpret_cast<const f32x4*>(pp), s1 = *reinterpret_cast<const f32x4*>(pp + 4);
+        int sl = 1;
+        for (; sl + 3 <= ax.nsplit; sl += 3) {
+            const float* q = pp + sl * sstride;
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(q), t1 = *reinterpret_cast<const f32x4*>(q + 4);
+            const f32x4 u0 = *reinterpret_cast<const f32x4*>(q + sstride), u1 = *reinterpret_cast<const f32x4*>(q + sstride + 4);
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(q + 2 * sstride), w1 = *reinterpret_cast<const f32x4*>(q + 2 * sstride + 4);
+            s0 = ((s0 + t0) + u0) + w0;
+            s1 = ((s1 + t1) + u1) + w1;
+        }
+        for (; sl < ax.nsplit; ++sl) {
+            const float* q = pp + sl * sstride;
+            s0 += *reinterpret_cast<const f32x4*>(q);
+            s1 += *reinterpret_cast<const f32x4*>(q + 4);
+        }
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            v[q] = s0[q] * (d.scale ? d.scale[ch + q] : 1.f) + (d.shift ? d.shift[ch + q] : 0.f);
+            v[4 + q] = s1[q] * (d.scale ? d.scale[ch + 4 + q] : 1.f) + (d.shift ? d.shift[ch + 4 + q] : 0.f);
+        }
+        h2_finish_row8(ax, v, h2_pixel_of(a, m), ch);
+    }
+}
+
 template <int BM, int BN, int NST>
 int launch_h2_tile(const ConvH2Args& ax, hipStream_t s)
 {
@@ -659,7 +722,7 @@ int launch_h2_tile(const ConvH2Args& ax, hipStream_t s)
             configured = true;
         }
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(ax.b.mtiles * ax.b.ntiles)), dim3(256), lds, s, ax);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ax.b.mtiles * ax.b.ntiles), (unsigned)ax.nsplit), dim3(256), lds, s, ax);
     return RDPN6D_OK;
 }
 
@@ -737,6 +800,20 @@ extern "C" int rdpn6d_split_h2(const float* x, int src_cs, int src_co, int C, vo
     return RDPN6D_OK;
 }
 
+// K-slices of the tile kernel for a launch too small to fill the chip (0 = do not split): the largest power of two that keeps
+// tiles * slices <= 512 workgroups with >= 4 whole chunks per slice
+static int h2_tile_ksplit(const rdpn6d_conv_desc* d, long long M, int bm, int bn)
+{
+    static const int off = getenv("RDPN6D_H2_NO_SPLITK") ? 1 : 0;  // profiling
+    const long long tiles = (long long)rd_cdiv(M, bm) * (d->Npad / bn);
+    if (off || tiles >= 128) return 0;
+    const int nk = d->ntaps * (d->Cin / 32);
+    int best = 0;
+    for (int sl = 2; sl <= 32; sl *= 2)
+        if (tiles * sl <= 512 && nk % sl == 0 && nk / sl >= 4) best = sl;
+    return best;
+}
+
 // which h2 kernel rdpn6d_conv2d_h2 would use: 2 = 256x256 eight-phase, 1 = 128x128..64x64 tile kernel, 0 = not eligible
 extern "C" int rdpn6d_conv_h2_kernel_for(const rdpn6d_conv_desc* d)
 {
@@ -752,8 +829,26 @@ extern "C" int rdpn6d_conv2d_h2(const rdpn6d_conv_desc* d, void* y_h2, const voi
     return rdpn6d_conv2d_h2_cb(d, y_h2, res_h2, overflow_flag, nullptr, stream);
 }
 
+// bytes of workspace rdpn6d_conv2d_h2_ws wants for this layer (0: the launch does not split K)
+extern "C" long long rdpn6d_conv_h2_workspace_bytes(const rdpn6d_conv_desc* d)
+{
+    if (!d || rdpn6d_conv_h2_kernel_for(d) != 1) return 0;
+    const long long M = (long long)d->B * d->Ho * d->Wo;
+    int bm, bn;
+    h2_pick_tile(d, M, &bm, &bn);
+    return (long long)h2_tile_ksplit(d, M, bm, bn) * rd_cdiv(M, bm) * bm * d->Npad * 4;
+}
+
+extern "C" int rdpn6d_conv2d_h2_ws(const rdpn6d_conv_desc* d, void* y_h2, const void* res_h2, int* overflow_flag, const float* crop_bias,
+                                   void* workspace, long long workspace_bytes, void* stream);
 extern "C" int rdpn6d_conv2d_h2_cb(const rdpn6d_conv_desc* d, void* y_h2, const void* res_h2, int* overflow_flag, const float* crop_bias,
                                    void* stream)
+{
+    return rdpn6d_conv2d_h2_ws(d, y_h2, res_h2, overflow_flag, crop_bias, nullptr, 0, stream);
+}
+
+extern "C" int rdpn6d_conv2d_h2_ws(const rdpn6d_conv_desc* d, void* y_h2, const void* res_h2, int* overflow_flag, const float* crop_bias,
+                                   void* workspace, long long workspace_bytes, void* stream)
 {
     RD_REQUIRE(d && d->x && d->w && (d->y || y_h2), "null pointer");
     const int which = rdpn6d_conv_h2_kernel_for(d);
@@ -784,6 +879,9 @@ extern "C" int rdpn6d_conv2d_h2_cb(const rdpn6d_conv_desc* d, void* y_h2, const 
     ax.res_h2 = res_h2;
     ax.overflow_flag = overflow_flag;
     ax.crop_bias = crop_bias;
+    ax.partial = nullptr;
+    ax.nsplit = 1;
+    ax.mpad = 0;
     a.dy_pack = a.dx_pack = 0;
     for (int t = 0; t < d->ntaps; ++t) {
         RD_REQUIRE(d->dy[t] >= -8 && d->dy[t] <= 7 && d->dx[t] >= -8 && d->dx[t] <= 7, "tap offsets must be in -8..7");
@@ -798,17 +896,29 @@ extern "C" int rdpn6d_conv2d_h2_cb(const rdpn6d_conv_desc* d, void* y_h2, const 
         h2_pick_tile(d, a.M, &bm, &bn);
         a.mtiles = rd_cdiv(a.M, bm);
         a.ntiles = d->Npad / bn;
+        const int ks = h2_tile_ksplit(d, a.M, bm, bn);
+        if (ks && workspace && workspace_bytes >= (long long)ks * a.mtiles * bm * d->Npad * 4) {
+            ax.nsplit = ks;
+            ax.mpad = a.mtiles * bm;
+            ax.partial = reinterpret_cast<float*>(workspace);
+            a.kper = a.nk / ks;
+        }
         int rc;
         static const int nst_env = getenv("RDPN6D_H2_NST") ? atoi(getenv("RDPN6D_H2_NST")) : 0;  // profiling: force 2 | 3 stages
         // three stages (where two workgroups per CU still fit, <= 80 KiB) pay on long K loops only: layer4's 144 chunks 97 -> 70 us, but
         // layer1's 18 chunks run 92 us against 84 with two stages (a third workgroup per CU fits and the longer prologue is not amortised)
-        const bool three = nst_env ? nst_env == 3 : a.nk >= 32;
+        const bool three = nst_env ? nst_env == 3 : a.kper >= 32;
         if (bm == 128 && bn == 128) rc = launch_h2_tile<128, 128, 2>(ax, s);  // (96 KiB with three stages: one workgroup per CU)
         else if (bm == 128) rc = three ? launch_h2_tile<128, 64, 3>(ax, s) : launch_h2_tile<128, 64, 2>(ax, s);
         else if (bn == 128) rc = three ? launch_h2_tile<64, 128, 3>(ax, s) : launch_h2_tile<64, 128, 2>(ax, s);
         else rc = three ? launch_h2_tile<64, 64, 3>(ax, s) : launch_h2_tile<64, 64, 2>(ax, s);
         if (rc != RDPN6D_OK) return rc;
         RD_LAUNCH_CHECK();
+        if (ax.partial) {
+            const long long items = a.M * (d->Npad / 8);
+            hipLaunchKernelGGL(h2_splitk_reduce_kernel, dim3((unsigned)((items + 255) / 256 < 4096 ? (items + 255) / 256 : 4096)), dim3(256), 0, s, ax);
+            RD_LAUNCH_CHECK();
+        }
         return RDPN6D_OK;
     }
     a.mtiles = rd_cdiv(a.M, 256);
@@ -818,7 +928,7 @@ extern "C" int rdpn6d_conv2d_h2_cb(const rdpn6d_conv_desc* d, void* y_h2, const 
         RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2_8ph_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_8PH));
         configured = true;
     }
-    hipLaunchKernelGGL(conv_h2_8ph_kernel, dim3((unsigned)(a.mtiles * a.ntiles)), dim3(512), LDS_8PH, s, ax);
+    hipLaunchKernelGGL(conv_h2_8ph_kernel, dim3((unsigned)(a.mtiles * a.ntiles)), dim3(512), LDS_8PH, s, ax);  // (never split: ax.partial stays null)
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
 }

@@ -413,6 +413,16 @@ class InferencePlan:
         torch.cuda.synchronize(self.device)
         return wp
 
+    def h2_workspace(self, nbytes):
+        """one fp32 partial-tile workspace for every split-K launch of this plan, grown to the largest request while the plan is built"""
+        cur = self.bufs.get("h2_workspace")
+        if cur is None or cur.numel() < nbytes:
+            self.bufs["h2_workspace"] = cur = torch.empty(max(nbytes, 8 << 20), dtype=torch.uint8, device=self.device)
+            for L in self.launches:  # launches built against a smaller buffer: point them at the new one
+                if L.fn is self.lib.rdpn6d_conv2d_h2_ws:
+                    L.args = L.args[:5] + (_ptr(cur), cur.numel())
+        return cur
+
     def conv_x3(self, name, xp, xshape, w32, scale, shift, y, yp, yshape, *, cin, in_cs, k=1, stride=1, pad=0, N, out_cs, act=0,
                 slope=0.0, taps=None, phase=None, res_planes=None, res_cs=0, crop_bias=None):
         """bf16x3 convolution: xp = input planes [3, >= B*H*W*in_cs]; y fp32 output or None; yp output planes or None;
@@ -445,6 +455,12 @@ class InferencePlan:
         self.x3_launches += 1
         if self.fast == "h2":
             assert self.lib.rdpn6d_conv_h2_kernel_for(ctypes.byref(d)), name
+            ws_bytes = int(self.lib.rdpn6d_conv_h2_workspace_bytes(ctypes.byref(d)))
+            if ws_bytes:  # a launch too small to fill the chip: split-K through the plan's shared workspace (launches are stream-ordered)
+                ws = self.h2_workspace(ws_bytes)
+                self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_h2_ws, (ctypes.byref(d), _ptr(yp), _ptr(res_planes), _ptr(self.h2_flag),
+                                                                                   _ptr(crop_bias), _ptr(ws), ws.numel()), keep=(d, crop_bias)))
+                return
             if crop_bias is not None:  # per-crop bias rows [B][4][Npad] (the folded global-max half of the ConvTranspose input)
                 self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_h2_cb, (ctypes.byref(d), _ptr(yp), _ptr(res_planes), _ptr(self.h2_flag),
                                                                                    _ptr(crop_bias)), keep=(d, crop_bias)))

@@ -22,6 +22,9 @@ H2_CASES = [
     (3, 7, 512, 512, 3, 1, True, 1),      # layer4 shape: odd size, ragged rows, K = 4608
     (12, 64, 256, 256, 3, 1, True, 1),    # 192 tiles of 256 rows: the 256x256 eight-phase kernel
     (11, 64, 64, 256, 3, 1, False, 2),    # eight-phase kernel, 18 K-tiles, ragged last tile (45056 rows = 176 tiles)
+    (1, 8, 512, 512, 3, 1, True, 1),      # layer4 of ONE crop: 64 rows, 144 chunks -> tile kernel with K cut into 16 slices
+    (1, 15, 256, 256, 3, 1, False, 2),    # split-K with ragged rows (225), no residual, LeakyReLU
+    (1, 16, 128, 256, 3, 2, False, 1),    # stride-2 entry convolution of one crop, split-K
 ]
 
 
@@ -83,6 +86,14 @@ def test_conv_h2_has_fp32_accuracy(case):
     d.B, d.H, d.W, d.Cin, d.in_cs, d.Ho, d.Wo, d.stride, d.ntaps, d.N, d.Npad, d.out_cs = B, H, H, Cin, Cin, Ho, Ho, stride, k * k, Cout, (Cout + 63) // 64 * 64, Cout
     which = _lib.load().rdpn6d_conv_h2_kernel_for(ctypes.byref(d))
     assert which == (2 if B in (11, 12) else 1), which  # the two big cases run on the eight-phase kernel
+    wsb = _lib.load().rdpn6d_conv_h2_workspace_bytes(ctypes.byref(d))
+    assert wsb > 0 if B == 1 else (wsb == 0 if which == 2 else True), (case, wsb)  # one crop's layers cut K into slices ...
+    if wsb:  # ... with the same bits on every run (slices are added in slice order), fp32 rounding away from the un-split launch
+        again = ops.conv2d_nhwc_h2(xd, wd, scd, shd, residual=resd, **kw)
+        whole = ops.conv2d_nhwc_h2(xd, wd, scd, shd, residual=resd, split_k=False, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(again, yh)
+        assert not torch.equal(whole, yh) and (whole - yh).abs().max().item() <= 4e-6 * scale
 
 
 def test_conv_h2_error_bound_under_cancellation():
