@@ -806,7 +806,8 @@ static int h2_tile_ksplit(const rdpn6d_conv_desc* d, long long M, int bm, int bn
 {
     static const int off = getenv("RDPN6D_H2_NO_SPLITK") ? 1 : 0;  // profiling
     const long long tiles = (long long)rd_cdiv(M, bm) * (d->Npad / bn);
-    if (off || tiles >= 128) return 0;
+    static const int tmax = getenv("RDPN6D_H2_SPLIT_TILES") ? atoi(getenv("RDPN6D_H2_SPLIT_TILES")) : 128;  // profiling
+    if (off || tiles >= tmax) return 0;
     const int nk = d->ntaps * (d->Cin / 32);
     int best = 0;
     for (int sl = 2; sl <= 32; sl *= 2)
