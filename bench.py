@@ -327,6 +327,10 @@ def main():
     ap.add_argument("--test-cfg", default="", metavar="KEY=0|1[,...]",
                     help="override boolean cfg.TEST switches for A/B runs, e.g. FOLD_GLOBAL_MAX=0,CONV_BEFORE_UPSAMPLE=0 "
                          "(the reference's evaluation order of the two algebraic rewrites of the h2 plan)")
+    ap.add_argument("--range-check", default="sync", choices=["sync", "deferred"],
+                    help="cfg.TEST.H2_RANGE_CHECK: sync (the model's default: every forward reads the fp16-range flag of the h2 kernels for "
+                         "itself before handing out its outputs - one host wait per step) | deferred (pipelined serving: the flag is "
+                         "looked at by the next forward and once more here after the timed loop)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as one hipGraph instead of launching kernel by kernel (measured: no gain, the "
                          "launch queue already runs ahead of the GPU - 2776 vs 2779 crops/s fp32, 10729 vs 10820 bf16)")
@@ -368,6 +372,7 @@ def main():
     for kv in filter(None, args.test_cfg.split(",")):
         k, v = kv.split("=")
         model.cfg.TEST[k.strip()] = bool(int(v))
+    model.cfg.TEST.H2_RANGE_CHECK = args.range_check
     B = args.batch
     t = {k: torch.from_numpy(v).to(device) for k, v in synth.make_inputs(B, seed=100 + rank, cam=args.cam).items()}
 
@@ -434,7 +439,10 @@ def main():
                                    "ResNet-34 trunk + dense head + ConvPnPNet + pose decode + per-crop RANSAC/Kabsch (100 hyp.), all on-device",
                        "batch_per_gpu": B, "global_batch": B * world, "mask_attention": args.mask_attention,
                        "parallelism": f"replicated weights, {world} independent shard(s), no collective",
-                       "launch": "hipGraph replay" if args.graph else "eager"},
+                       "launch": "hipGraph replay" if args.graph else "eager",
+                       "h2_range_check": args.range_check},
+            # no activation left the fp16 range of the h2 kernels in any step (otherwise the model would have warned and switched to bf16x3)
+            "h2_range_exceeded": bool(model.h2_range_exceeded(device, wait=True)) or model.plan(B, device).fast != ("h2" if (args.dtype == "f32" and args.fast == "h2" and not args.no_x3) else model.plan(B, device).fast),
             "achieved_tflops_whole_step": round(44.10e9 * value / 1e12, 2),
             "flops_note": ("44.10 GFLOP per crop = the reference network's multiply-adds" +
                            ("; the h2 plan evaluates the spatially constant (broadcast global max) half of the ConvTranspose input as a "

@@ -35,6 +35,31 @@ extern "C" void rdpn6d_set_error(const char* fmt, ...);
 
 static inline int rd_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Opt-in to more than 64 KiB of dynamic LDS for `kern`.  hipFuncSetAttribute acts on the CURRENT device's copy of the function, so the
+// "done" state is kept per device (one bit each, set after the call succeeded): a process that drives several GPUs configures
+// every one of them, and two host threads building plans at once can at worst both make the (idempotent) call.
+#include <atomic>
+struct RdLdsOptIn {
+    std::atomic<unsigned long long> done[4];  // devices 0..255
+};
+static inline hipError_t rd_lds_opt_in(RdLdsOptIn& st, const void* kern, int bytes)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::atomic<unsigned long long>& word = st.done[(dev >> 6) & 3];
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (word.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess) word.fetch_or(bit, std::memory_order_release);
+    return e;
+}
+#define RD_LDS_OPT_IN(kern, bytes)                                                           \
+    do {                                                                                     \
+        static RdLdsOptIn _st;                                                               \
+        RD_CHECK_HIP(rd_lds_opt_in(_st, reinterpret_cast<const void*>(kern), (int)(bytes))); \
+    } while (0)
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

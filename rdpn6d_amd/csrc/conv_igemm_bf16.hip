@@ -291,11 +291,7 @@ static int conv_bf16_launch_one(const ConvBArgs& a, int nsplit, hipStream_t s)
     constexpr int lds = lds_stage > lds_epi ? lds_stage : lds_epi;
     auto kern = conv_igemm_bf16_kernel<BM, BN, RB, WM, WN, NST>;
     if (lds > 64 * 1024) {
-        static bool configured = false;  // one-time opt-in to > 64 KiB of dynamic LDS
-        if (!configured) {
-            RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            configured = true;
-        }
+        RD_LDS_OPT_IN(kern, lds);
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)(a.mtiles * a.ntiles), (unsigned)nsplit), dim3(64 * WM * WN), lds, s, a);
     return RDPN6D_OK;

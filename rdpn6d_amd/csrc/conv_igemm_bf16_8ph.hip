@@ -318,12 +318,8 @@ bool conv_bf16_8ph_eligible(const ConvBArgs& a, int rb)
 template <int ABL>
 static int launch_8ph(const ConvBArgs& a, hipStream_t s)
 {
-    static bool configured = false;
     auto kern = conv_igemm_bf16_8ph_kernel<ABL>;
-    if (!configured) {
-        RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_8PH));
-        configured = true;
-    }
+    RD_LDS_OPT_IN(kern, LDS_8PH);
     hipLaunchKernelGGL(kern, dim3((unsigned)(a.mtiles * a.ntiles)), dim3(512), LDS_8PH, s, a);
     return RDPN6D_OK;
 }

@@ -426,12 +426,7 @@ extern "C" int rdpn6d_conv2d_bf16x3_ex(const rdpn6d_conv_desc* d, long long x_pl
     a.mtiles = rd_cdiv(a.M, 256);
     a.ntiles = d->Npad / 256;
     a.kper = a.nk;
-    static bool configured = false;
-    if (!configured) {
-        RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_bf16x3_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS));
-        configured = true;
-    }
+    RD_LDS_OPT_IN(conv_igemm_bf16x3_kernel, X3_LDS);
     hipLaunchKernelGGL(conv_igemm_bf16x3_kernel, dim3((unsigned)(a.mtiles * a.ntiles)), dim3(512), X3_LDS, s, ax);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;

@@ -242,11 +242,7 @@ int launch_tile(const ConvX3Args& ax, hipStream_t s)
     static_assert(lds <= 80 * 1024, "two workgroups per CU");
     auto kern = conv_x3_tile_kernel<BM, BN, RB>;
     if (lds > 64 * 1024) {
-        static bool configured = false;
-        if (!configured) {
-            RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            configured = true;
-        }
+        RD_LDS_OPT_IN(kern, lds);
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)(ax.b.mtiles * ax.b.ntiles)), dim3(256), lds, s, ax);
     return RDPN6D_OK;

@@ -44,6 +44,17 @@ struct ConvH2Args {
     int nsplit, mpad;
 };
 
+#ifdef RDPN6D_PROBE
+// probe build only (RDPN6D_PROBE=1 python -m rdpn6d_amd.build; tools/probe_h2_tile.py): per-wave cycle sums of the phases of a
+// tile-kernel step, written by the SCHED = 9 variant (RDPN6D_H2_SCHED=9)
+__device__ unsigned long long* g_h2_probe = nullptr;
+extern "C" int rdpn6d_debug_h2_probe(void* buf)
+{
+    RD_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_h2_probe), &buf, sizeof(buf)));
+    return RDPN6D_OK;
+}
+#endif
+
 namespace {
 
 constexpr float H2_SCALE = 16.f, H2_INV_SCALE = 1.f / 16.f, H2_MAX = 65504.f;
@@ -416,7 +427,7 @@ __global__ __launch_bounds__(512) void conv_h2_8ph_kernel(const ConvH2Args ax)
 // the loop - a step ends with s_waitcnt vmcnt(<DMAs of one chunk>) + a raw s_barrier, so the loads of chunk k+3 stay in flight
 // across the barrier that publishes chunk k+2 (the L2 -> LDS round trip, ~1.5 us under load, is what bounds the 2-stage form:
 // a step's 12 - 24 MFMAs take 0.2 - 0.4 us).
-template <int BM, int BN, int NST>
+template <int BM, int BN, int NST, int SCHED = 0>
 __global__ __launch_bounds__(256, 2) void conv_h2_tile_kernel(const ConvH2Args ax)
 {
     constexpr int NW = 4, RB = 128;
@@ -493,6 +504,27 @@ __global__ __launch_bounds__(256, 2) void conv_h2_tile_kernel(const ConvH2Args a
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrc, (lds_ptr_t)dst, 16, (int)(w_off[i] + wk), 0, 0, 0);
         }
     };
+    // the same chunk in two parts, for schedules that spread the DMA pieces between the MFMAs: offsets first, then piece by piece
+    unsigned dma_off[NDMA];
+    auto stage_addr = [&](const int tap, const int cc) {
+        const int dy = (int)((a.dy_pack >> (4 * tap)) & 15ull) - 8, dx = (int)((a.dx_pack >> (4 * tap)) & 15ull) - 8;
+        const unsigned toff = (unsigned)((dy * d.W + dx) * (int)px_bytes + cc * RB);
+#pragma unroll
+        for (int i = 0; i < AG; ++i) dma_off[i] = (a_base[i] + toff) | (((a_mask[i] >> tap) & 1u) - 1u);
+        const unsigned wk = (unsigned)tap * (unsigned)d.Cin * 4u + (unsigned)cc * (unsigned)RB;
+#pragma unroll
+        for (int i = 0; i < BG; ++i) dma_off[AG + i] = w_off[i] + wk;
+    };
+    auto stage_piece = [&](auto ic_, const int st) {
+        constexpr int i = decltype(ic_)::value;
+        if constexpr (i < AG) {
+            unsigned char* dst = As + ((st * BM) + (wave + NW * i) * RPP) * RB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_ptr_t)dst, 16, (int)dma_off[i], 0, 0, 0);
+        } else {
+            unsigned char* dst = Bs + ((st * BN) + (wave + NW * (i - AG)) * RPP) * RB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrc, (lds_ptr_t)dst, 16, (int)dma_off[i], 0, 0, 0);
+        }
+    };
     const int nk = a.kper;  // all chunks, or K-slice blockIdx.y (chunk order: channel-chunk major, taps innermost)
     const int kt0 = (int)blockIdx.y * a.kper;
     int ld_cc = kt0 / d.ntaps, ld_tap = kt0 - (kt0 / d.ntaps) * d.ntaps, ld_left = nk - 1;
@@ -547,6 +579,9 @@ __global__ __launch_bounds__(256, 2) void conv_h2_tile_kernel(const ConvH2Args a
     };
 
     u32x4 fa0[TM][4], fb0[TN][4], fa1[TM][4], fb1[TN][4];
+    [[maybe_unused]] unsigned long long pr_sum[5] = {0, 0, 0, 0, 0};
+    [[maybe_unused]] const unsigned long long pr_start = SCHED == 9 ? __builtin_readcyclecounter() : 0ull;
+    [[maybe_unused]] const unsigned long long pr_rt0 = SCHED == 9 ? (__builtin_amdgcn_s_memrealtime() & 0xffffffffull) : 0ull;
     if constexpr (NST == 2) {
         stage_chunk(ld_tap, ld_cc, 0);
         next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
@@ -557,17 +592,39 @@ __global__ __launch_bounds__(256, 2) void conv_h2_tile_kernel(const ConvH2Args a
         __syncthreads();  // stage 0 is re-filled by the first loop step: every wave must have its fragments first
         const int npairs = nk >> 1;
         for (int pr = 0; pr < npairs; ++pr) {
-            stage_chunk(ld_tap, ld_cc, 0);
-            next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
-            read_frags(1, fa1, fb1);
-            mma(fa0, fb0);
-            __syncthreads();
+            if constexpr (SCHED == 0) {
+                stage_chunk(ld_tap, ld_cc, 0);
+                next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
+                read_frags(1, fa1, fb1);
+                mma(fa0, fb0);
+                __syncthreads();
 
-            stage_chunk(ld_tap, ld_cc, 1);
-            next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
-            read_frags(0, fa0, fb0);
-            mma(fa1, fb1);
-            __syncthreads();
+                stage_chunk(ld_tap, ld_cc, 1);
+                next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
+                read_frags(0, fa0, fb0);
+                mma(fa1, fb1);
+                __syncthreads();
+            } else {
+                __builtin_amdgcn_sched_barrier(0);
+                read_frags(1, fa1, fb1);
+                __builtin_amdgcn_sched_barrier(0);
+                stage_chunk(ld_tap, ld_cc, 0);
+                next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(fa0, fb0);
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();
+
+                __builtin_amdgcn_sched_barrier(0);
+                read_frags(0, fa0, fb0);
+                __builtin_amdgcn_sched_barrier(0);
+                stage_chunk(ld_tap, ld_cc, 1);
+                next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(fa1, fb1);
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();
+            }
         }
         if (nk & 1) mma(fa0, fb0);
     } else {
@@ -593,26 +650,103 @@ __global__ __launch_bounds__(256, 2) void conv_h2_tile_kernel(const ConvH2Args a
         publish();
         int st_free = 0, st_next = 1;
         const int npairs = nk >> 1;
+        auto step = [&](const int stf, const int stn, u32x4 (&fcur_a)[TM][4], u32x4 (&fcur_b)[TN][4], u32x4 (&fnxt_a)[TM][4], u32x4 (&fnxt_b)[TN][4]) {
+            if constexpr (SCHED == 0) {
+                stage_chunk(ld_tap, ld_cc, stf);
+                next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
+                read_frags(stn, fnxt_a, fnxt_b);
+                mma(fcur_a, fcur_b);
+                publish();
+            } else if constexpr (SCHED == 3) {
+                // reads of the next chunk first; then the six partial-product groups of this chunk's MFMAs with the chunk-(+3) DMA pieces
+                // spread between them: a 1-KiB LDS-DMA piece costs its wave ~60 cycles of issue (measured with the probe build:
+                // a block of 6 pieces = 400 cycles, as long as the step's 12 MFMAs), which the matrix pipe covers when it has work queued
+                H2_PAIRS;
+                __builtin_amdgcn_sched_barrier(0);
+                read_frags(stn, fnxt_a, fnxt_b);
+                stage_addr(ld_tap, ld_cc);
+                next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
+                __builtin_amdgcn_sched_barrier(0);
+                auto group = [&](auto prc) {
+                    constexpr int pr = decltype(prc)::value;
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int jn = 0; jn < TN; ++jn) acc[i][jn] = h2_mfma(fcur_a[i][H2_PA[pr]], fcur_b[jn][H2_PB[pr]], acc[i][jn]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    // pieces [pr * NDMA / 6, (pr + 1) * NDMA / 6)
+                    constexpr int p0 = pr * NDMA / 6, p1 = (pr + 1) * NDMA / 6;
+                    if constexpr (p1 > p0) stage_piece(ic<p0>{}, stf);
+                    if constexpr (p1 > p0 + 1) stage_piece(ic<p0 + 1>{}, stf);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                group(ic<0>{});
+                group(ic<1>{});
+                group(ic<2>{});
+                group(ic<3>{});
+                group(ic<4>{});
+                group(ic<5>{});
+                publish();
+            } else if constexpr (SCHED == 9) {
+#ifdef RDPN6D_PROBE
+                const unsigned long long t0 = __builtin_readcyclecounter();
+                __builtin_amdgcn_sched_barrier(0);
+                read_frags(stn, fnxt_a, fnxt_b);
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned long long t1 = __builtin_readcyclecounter();
+                __builtin_amdgcn_sched_barrier(0);
+                stage_chunk(ld_tap, ld_cc, stf);
+                next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned long long t2 = __builtin_readcyclecounter();
+                __builtin_amdgcn_sched_barrier(0);
+                mma(fcur_a, fcur_b);
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned long long t3 = __builtin_readcyclecounter();
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NDMA) : "memory");
+                const unsigned long long t4 = __builtin_readcyclecounter();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                const unsigned long long t5 = __builtin_readcyclecounter();
+                pr_sum[0] += t1 - t0;
+                pr_sum[1] += t2 - t1;
+                pr_sum[2] += t3 - t2;
+                pr_sum[3] += t4 - t3;
+                pr_sum[4] += t5 - t4;
+#endif
+            } else {
+                // pinned issue order: the fragment reads of the NEXT chunk go out first, the DMA of chunk +3 next, and this chunk's
+                // MFMAs run behind them - left to itself hipcc sinks the ds_reads to the end of the step, right in front of the
+                // lgkmcnt(0) + barrier, where their whole latency is exposed
+                __builtin_amdgcn_sched_barrier(0);
+                read_frags(stn, fnxt_a, fnxt_b);
+                __builtin_amdgcn_sched_barrier(0);
+                stage_chunk(ld_tap, ld_cc, stf);
+                next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (SCHED == 2) __builtin_amdgcn_s_setprio(1);
+                mma(fcur_a, fcur_b);
+                if constexpr (SCHED == 2) __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                publish();
+            }
+        };
         for (int pr = 0; pr < npairs; ++pr) {
-            stage_chunk(ld_tap, ld_cc, st_free);
-            next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
-            read_frags(st_next, fa1, fb1);
-            mma(fa0, fb0);
-            publish();
+            step(st_free, st_next, fa0, fb0, fa1, fb1);
             st_free = st_next;
             st_next = st_next == 2 ? 0 : st_next + 1;
-
-            stage_chunk(ld_tap, ld_cc, st_free);
-            next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
-            read_frags(st_next, fa0, fb0);
-            mma(fa1, fb1);
-            publish();
+            step(st_free, st_next, fa1, fb1, fa0, fb0);
             st_free = st_next;
             st_next = st_next == 2 ? 0 : st_next + 1;
         }
         if (nk & 1) mma(fa0, fb0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may still be landing in LDS when the epilogue re-uses it
     }
+#ifdef RDPN6D_PROBE
+    [[maybe_unused]] const unsigned long long pr_loop_end = SCHED == 9 ? __builtin_readcyclecounter() : 0ull;
+#endif
 
     {
         const int hi = lane >> 5;
@@ -666,6 +800,18 @@ __global__ __launch_bounds__(256, 2) void conv_h2_tile_kernel(const ConvH2Args a
             }
         }
     }
+#ifdef RDPN6D_PROBE
+    if constexpr (SCHED == 9) {
+        if (g_h2_probe && lane == 0) {
+            const unsigned long long t_end = __builtin_readcyclecounter();
+            unsigned long long* o = g_h2_probe + ((size_t)blockIdx.x * 4 + wave) * 8;
+            for (int i = 0; i < 5; ++i) o[i] = pr_sum[i];
+            o[5] = pr_loop_end - pr_start;  // prologue + loop
+            o[6] = t_end - pr_loop_end;     // epilogue
+            o[7] = pr_rt0 | (__builtin_amdgcn_s_memrealtime() << 32);  // start | end on the constant 100 MHz clock (low 32 bits each)
+        }
+    }
+#endif
 }
 
 // Second pass of the split-K form: one thread = 8 consecutive channels of one output row; the K-slices are added in slice order
@@ -707,20 +853,30 @@ __global__ __launch_bounds__(256) void h2_splitk_reduce_kernel(const ConvH2Args 
     }
 }
 
+template <int BM, int BN, int NST, int SCHED = 0>
+int launch_h2_tile_s(const ConvH2Args& ax, hipStream_t s);
 template <int BM, int BN, int NST>
 int launch_h2_tile(const ConvH2Args& ax, hipStream_t s)
+{
+    static const int sched = getenv("RDPN6D_H2_SCHED") ? atoi(getenv("RDPN6D_H2_SCHED")) : 0;  // profiling
+    if (sched == 1) return launch_h2_tile_s<BM, BN, NST, 1>(ax, s);
+    if (sched == 2) return launch_h2_tile_s<BM, BN, NST, 2>(ax, s);
+    if (sched == 3 && NST == 3) return launch_h2_tile_s<BM, BN, NST, 3>(ax, s);
+#ifdef RDPN6D_PROBE
+    if (sched == 9) return launch_h2_tile_s<BM, BN, NST, 9>(ax, s);
+#endif
+    return launch_h2_tile_s<BM, BN, NST, 0>(ax, s);
+}
+template <int BM, int BN, int NST, int SCHED>
+int launch_h2_tile_s(const ConvH2Args& ax, hipStream_t s)
 {
     constexpr int lds_stage = NST * (BM + BN) * 128;
     constexpr int lds_epi = 4 * 32 * (BN / 2 + 8) * 4;
     constexpr int lds = lds_stage > lds_epi ? lds_stage : lds_epi;
-    static_assert(lds <= 80 * 1024, "two workgroups per CU");
-    auto kern = conv_h2_tile_kernel<BM, BN, NST>;
+    static_assert(lds <= 80 * 1024 || (BM == 128 && BN == 128 && NST == 3), "two workgroups per CU (128x128 with three stages: one)");
+    auto kern = conv_h2_tile_kernel<BM, BN, NST, SCHED>;
     if (lds > 64 * 1024) {
-        static bool configured = false;
-        if (!configured) {
-            RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            configured = true;
-        }
+        RD_LDS_OPT_IN(kern, lds);
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)(ax.b.mtiles * ax.b.ntiles), (unsigned)ax.nsplit), dim3(256), lds, s, ax);
     return RDPN6D_OK;
@@ -909,7 +1065,7 @@ extern "C" int rdpn6d_conv2d_h2_ws(const rdpn6d_conv_desc* d, void* y_h2, const 
         // three stages (where two workgroups per CU still fit, <= 80 KiB) pay on long K loops only: layer4's 144 chunks 97 -> 70 us, but
         // layer1's 18 chunks run 92 us against 84 with two stages (a third workgroup per CU fits and the longer prologue is not amortised)
         const bool three = nst_env ? nst_env == 3 : a.kper >= 32;
-        if (bm == 128 && bn == 128) rc = launch_h2_tile<128, 128, 2>(ax, s);  // (96 KiB with three stages: one workgroup per CU)
+        if (bm == 128 && bn == 128) rc = (nst_env == 3) ? launch_h2_tile<128, 128, 3>(ax, s) : launch_h2_tile<128, 128, 2>(ax, s);  // (96 KiB with three stages: one workgroup per CU)
         else if (bm == 128) rc = three ? launch_h2_tile<128, 64, 3>(ax, s) : launch_h2_tile<128, 64, 2>(ax, s);
         else if (bn == 128) rc = three ? launch_h2_tile<64, 128, 3>(ax, s) : launch_h2_tile<64, 128, 2>(ax, s);
         else rc = three ? launch_h2_tile<64, 64, 3>(ax, s) : launch_h2_tile<64, 64, 2>(ax, s);
@@ -924,11 +1080,7 @@ extern "C" int rdpn6d_conv2d_h2_ws(const rdpn6d_conv_desc* d, void* y_h2, const 
     }
     a.mtiles = rd_cdiv(a.M, 256);
     a.ntiles = d->Npad / 256;
-    static bool configured = false;
-    if (!configured) {
-        RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_h2_8ph_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_8PH));
-        configured = true;
-    }
+    RD_LDS_OPT_IN(conv_h2_8ph_kernel, LDS_8PH);
     hipLaunchKernelGGL(conv_h2_8ph_kernel, dim3((unsigned)(a.mtiles * a.ntiles)), dim3(512), LDS_8PH, s, ax);  // (never split: ax.partial stays null)
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;

@@ -678,11 +678,7 @@ extern "C" int rdpn6d_ransac_pnp_f32(const float* image_points, const float* mod
     RD_REQUIRE(pose_out != net_pose, "pose_out must not alias net_pose");
     const size_t smem = pnp_smem_bytes(HW);
     RD_REQUIRE(smem <= 160 * 1024, "correspondences do not fit the 160 KiB LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
-        RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ransac_pnp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    RD_LDS_OPT_IN(ransac_pnp_kernel, 160 * 1024);
     hipLaunchKernelGGL(ransac_pnp_kernel, dim3(B), dim3(PNP_THREADS), smem, (hipStream_t)stream, image_points, model_points, counts, cams,
                        net_pose, HW, reproj_thr, iters, confidence, seed, mode, max_t_diff, pose_out, n_inliers, inlier_mask, best_hyp);
     RD_LAUNCH_CHECK();

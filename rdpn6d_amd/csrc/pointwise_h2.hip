@@ -481,11 +481,7 @@ extern "C" int rdpn6d_stem_pool_h2(const float* x, int B, int xc, int R, const v
 {
     RD_REQUIRE(x && w_h2 && scale && shift && y, "null pointer");
     RD_REQUIRE(B > 0 && xc >= 3 && R > 0 && R % 4 == 0, "shape (R % 4)");
-    static bool configured = false;
-    if (!configured) {
-        RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(stem_pool_h2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS));
-        configured = true;
-    }
+    RD_LDS_OPT_IN(stem_pool_h2_kernel, SP_LDS);
     const int Rp = R / 4;
     dim3 grid(rd_cdiv(Rp, SP_PW), rd_cdiv(Rp, SP_PH), B);
     hipLaunchKernelGGL(stem_pool_h2_kernel, grid, dim3(256), SP_LDS, (hipStream_t)stream, x, xc, R, (const _Float16*)w_h2, scale, shift,

@@ -429,12 +429,7 @@ static int rs_launch(const float* out_nchw, const float* coord2d, const float* f
     RD_REQUIRE(pose_out != net_pose, "pose_out must not alias net_pose");
     const size_t smem = rs_smem_bytes(HW);
     RD_REQUIRE(smem <= 160 * 1024, "correspondences do not fit the 160 KiB LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
-        RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ransac_kabsch_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    RD_LDS_OPT_IN(ransac_kabsch_kernel, 160 * 1024);
     hipLaunchKernelGGL(ransac_kabsch_kernel, dim3(B), dim3(RS_THREADS), smem, (hipStream_t)stream, out_nchw, coord2d, fps,
                        extents, resize_ratios, region_argmax, HW, K, mask_thr, inlier_thr, iters, confidence, seed,
                        pose_out, n_inliers, inlier_mask, best_hyp, net_pose, max_t_diff);

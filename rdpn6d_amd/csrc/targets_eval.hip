@@ -134,12 +134,7 @@ extern "C" int rdpn6d_pose_errors_f64(const double* est, const double* gt, const
     const int use_lds = lds <= 150 * 1024;
     RD_REQUIRE(use_lds || scratch, "more than 6400 model points need a [B,n,3] double scratch");
     if (use_lds) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(pose_errors_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             150 * 1024));
-            attr_set = true;
-        }
+        RD_LDS_OPT_IN(pose_errors_kernel, 150 * 1024);
     }
     hipLaunchKernelGGL(pose_errors_kernel, dim3(B), dim3(256), use_lds ? lds : 0, (hipStream_t)stream, est, gt, pts,
                        pts_per_pose ? (long long)n * 3 : 0LL, n, scratch, use_lds, out);

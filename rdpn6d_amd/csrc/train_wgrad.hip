@@ -664,11 +664,7 @@ static int wgrad_bf16_launch(const WgradBArgs& a, dim3 grid, hipStream_t s)
     constexpr int lds = 3 * PL * (PL == 1 ? 32 : 16) * (BA + BB) * 2;
     auto kern = wgrad_bf16_kernel<BA, BB, PL>;
     if (lds > 64 * 1024) {
-        static bool configured = false;
-        if (!configured) {
-            RD_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-            configured = true;
-        }
+        RD_LDS_OPT_IN(kern, lds);
     }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
     return RDPN6D_OK;

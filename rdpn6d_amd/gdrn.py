@@ -25,12 +25,24 @@ from . import _lib
 
 # Weights change under the packed copies an InferencePlan holds in three ways: torch in-place ops (seen through the tensors'
 # ``_version`` counters), and the two raw-pointer writers of this package - the fused Ranger step and the train engine's
-# BatchNorm running-statistics update - which bump this epoch.  GDRN.plan() rebuilds a plan whose stamp is stale.
-_WEIGHTS_EPOCH = [0]
+# BatchNorm running-statistics update - which bump the epoch OF THE MODEL THEY WRITE (a teacher / EMA copy used for evaluation
+# next to the model being trained keeps its plans).  GDRN.plan() rebuilds a plan whose stamp is stale.  Edits that bypass both
+# (``p.data.add_(...)``: ``.data`` does not bump ``_version``) need ``model.invalidate_plans()``.
+import weakref
+
+_MODELS = weakref.WeakSet()
 
 
-def bump_weights_epoch():
-    _WEIGHTS_EPOCH[0] += 1
+def bump_weights_epoch(tensors=None):
+    """the caller has written parameters / buffers through raw pointers.  tensors: the tensors written (any iterable of
+    parameters / buffers; the models owning one of them are bumped) or a GDRN model; None = every live model (conservative)."""
+    if isinstance(tensors, nn.Module):
+        tensors._weights_epoch += 1
+        return
+    ids = None if tensors is None else {id(t) for t in tensors}
+    for m in list(_MODELS):
+        if ids is None or not ids.isdisjoint(m._tensor_ids()):
+            m._weights_epoch += 1
 
 
 # resnet_backbone.py:15-21: (block expansion, blocks per layer).  Expansion 1 = torchvision BasicBlock, 4 = Bottleneck.
@@ -286,6 +298,10 @@ class InferencePlan:
         self.mask_attention = cfg.MODEL.CDPN.PNP_NET.MASK_ATTENTION
         if self.mask_attention not in ("none", "mul"):
             raise ValueError(f"MASK_ATTENTION={self.mask_attention!r} is not implemented (none | mul)")
+        if self.mask_attention != "none" and cfg.MODEL.CDPN.ROT_HEAD.MASK_LOSS_TYPE != "L1":
+            # get_mask_prob (models/model_utils.py:24-42): L1 = per-crop min-max (what the glue kernel does), BCE = sigmoid, CE = softmax
+            raise NotImplementedError(f"MASK_ATTENTION={self.mask_attention!r} with ROT_HEAD.MASK_LOSS_TYPE="
+                                      f"{cfg.MODEL.CDPN.ROT_HEAD.MASK_LOSS_TYPE!r}: only the 'L1' (min-max) mask probability is implemented")
         # fp32 mode: the wide head layers run as exact-product bf16x3 convolutions on the bf16 matrix pipe (fp32 accuracy,
         # csrc/conv_igemm_bf16x3.hip) when the batch fills the chip; cfg.TEST.BF16X3 = False keeps them on the fp32 MFMA.
         # cfg.TEST.FP16X2 (default on) picks the two-plane fp16 form of the same idea (csrc/conv_igemm_h2.hip: three partial
@@ -295,9 +311,9 @@ class InferencePlan:
         self.fast = None if (self.bf16 or not tcfg.get("BF16X3", True)) else ("h2" if tcfg.get("FP16X2", True) else "x3")
         self.x3 = self.fast is not None  # "the wide layers leave the fp32 MFMA pipe" (name kept from the bf16x3-only days)
         self.x3_launches = 0
-        self.h2_flag = torch.zeros(1, dtype=torch.int32, device=device)  # set by a kernel that had to clamp to the fp16 range
-        self._flag_host = torch.zeros(1, dtype=torch.int32).pin_memory() if self.fast == "h2" else None
-        self._flag_event = None
+        # set by a kernel that had to clamp to the fp16 range.  ONE flag per (model, device), shared by every plan of the model and
+        # never reset by a plan: it survives plan rebuilds (new weights, another batch size) - GDRN.forward reads it (below)
+        self.h2_flag = model.h2_range_flag(device)
         # rows from which a layer takes the fast path's tile kernel: bf16x3 pays from 8192 (two crops' head); with h2 the WHOLE network
         # stays in the h2 format from one crop on (B = 1 1.48 -> 1.24 ms, B = 4 1.83 -> 1.71, B = 7 2.40 -> 2.05: no fp32 <-> plane
         # conversions, the rewrites of DESIGN.md section 4 apply at every batch size).  RDPN6D_TILE_MIN_ROWS overrides (profiling)
@@ -882,20 +898,16 @@ class InferencePlan:
                                               _ptr(self.rot), _ptr(self.trans), st), "pose_decode")
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
-        if self._flag_host is not None and not torch.cuda.is_current_stream_capturing():
-            # range flag of the h2 kernels -> pinned host memory, without stalling the launch queue; looked at by the next call
-            self._flag_host.copy_(self.h2_flag, non_blocking=True)
-            self._flag_event = torch.cuda.Event()
-            self._flag_event.record()
 
-    def range_exceeded(self, wait=False):
-        """did an h2 kernel of an EARLIER run have to clamp an activation to the fp16 range (|a| >= 4094)?  Non-blocking by
-        default (answers for the runs whose flag copy has completed); wait=True synchronises on the latest run."""
-        if self._flag_event is None:
+    def range_exceeded(self, wait=True):
+        """did an h2 kernel launched so far (any plan of the model on this device) have to clamp an activation to the fp16 range
+        (|a| >= 4094)?  Synchronises on the work queued so far (wait=True) - for callers that drive run() themselves;
+        GDRN.forward does its own check for every forward (GDRN._range_check)."""
+        if self.fast != "h2":
             return False
         if wait:
-            self._flag_event.synchronize()
-        return bool(self._flag_event.query() and int(self._flag_host[0]) != 0)
+            torch.cuda.current_stream().synchronize()
+        return bool(int(self.h2_flag.item()) != 0)
 
     def run_graphed(self, key, launch):
         """Replay `launch()` (a closure issuing the whole step on the current stream) as one hipGraph.  The graph is
@@ -921,15 +933,17 @@ class InferencePlan:
     def run_pnp2d(self, roi_coord_2d, roi_extents, roi_cams, im_hw, uv_channels, mask_thr=0.5, reproj_thr=3.0, iters=100, confidence=0.99,
                   seed=0, net_mode=0, max_t_diff=1.0):
         """the reference's classical solve on the maps the last run() left in out_nchw: correspondence selection exactly as
-        get_img_model_points_with_coords2d (row A8, bit-exact) + per-crop 2D-3D RANSAC-PnP (rows A9 / A10)"""
+        get_img_model_points_with_coords2d (row A8, bit-exact) + per-crop 2D-3D RANSAC-PnP (rows A9 / A10).
+        im_hw: (B, 2) int32 device tensor, [H, W] of the image each crop comes from."""
+        assert im_hw.dtype == torch.int32 and tuple(im_hw.shape) == (self.B, 2) and im_hw.is_cuda and im_hw.is_contiguous()
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         B, C = self.B, self.out_nchw.shape[1]
         HW = self.out_nchw.shape[2] * self.out_nchw.shape[3]
         ip, mp = self.buf("pnp2d_ip", B, HW, 2), self.buf("pnp2d_mp", B, HW, 3)
         cnt = self.buf("pnp2d_cnt", B, dtype=torch.int32)
         _lib.check(self.lib.rdpn6d_select_correspondences_f32(
-            _ptr(self.out_nchw), C, _ptr(roi_coord_2d), roi_coord_2d.shape[1], uv_channels[0], uv_channels[1], _ptr(roi_extents), None,
-            int(im_hw[0]), int(im_hw[1]), B, HW, mask_thr, _ptr(ip), _ptr(mp), _ptr(cnt), None, None, st), "select_correspondences")
+            _ptr(self.out_nchw), C, _ptr(roi_coord_2d), roi_coord_2d.shape[1], uv_channels[0], uv_channels[1], _ptr(roi_extents), _ptr(im_hw),
+            0, 0, B, HW, mask_thr, _ptr(ip), _ptr(mp), _ptr(cnt), None, None, st), "select_correspondences")
         netp = None
         if net_mode:
             netp = self.buf("net_pose", B, 12)
@@ -985,10 +999,58 @@ class GDRN(nn.Module):
         self.trans_head_net = trans_head_net
         self.cfg = cfg
         self._plans = {}
+        self._weights_epoch = 0
+        self._stamp_tensors = None  # cached [parameters + buffers] of the stamp (rebuilt when the module tree changes)
+        _MODELS.add(self)
+        self._h2_flags = {}  # device -> (device int32 flag written by the h2 kernels, pinned host copy, [event of the last copy])
+
+    # ---- range guard of the two-plane fp16 ("h2") format, DESIGN.md section 2
+    def h2_range_flag(self, device):
+        """the device flag every h2 kernel of this model's plans on `device` sets when it had to clamp an activation"""
+        key = str(device)
+        if key not in self._h2_flags:
+            self._h2_flags[key] = [torch.zeros(1, dtype=torch.int32, device=device), torch.zeros(1, dtype=torch.int32).pin_memory(), None]
+        return self._h2_flags[key][0]
+
+    def _range_flag_fetch(self, device):
+        """queue flag -> pinned host memory behind the forward just issued (outside any hipGraph: a replayed graph is followed by
+        this copy like an eager run) and record an event; nothing waits here"""
+        ent = self._h2_flags.get(str(device))
+        if ent is None:
+            return
+        ent[1].copy_(ent[0], non_blocking=True)
+        ent[2] = torch.cuda.Event()
+        ent[2].record()
+
+    def h2_range_exceeded(self, device=None, wait=True):
+        """has any h2 kernel of this model clamped an activation (|a| >= 4094) in a forward whose flag copy has completed
+        (wait=True: in any forward issued so far)?  The flag is sticky until the model has switched to the bf16x3 kernels."""
+        hit = False
+        for key, ent in self._h2_flags.items():
+            if (device is not None and key != str(device)) or ent[2] is None:
+                continue
+            if wait:
+                ent[2].synchronize()
+            hit |= bool(ent[2].query() and int(ent[1][0]) != 0)
+        return hit
+
+    def _leave_h2(self, device, when):
+        import warnings
+
+        warnings.warn(f"rdpn6d_amd: an activation exceeded +-4094, the range of the fp16x2 (h2) convolution format, in {when} (the value "
+                      "was clamped, never an inf).  Switching this model to the bf16x3 kernels (cfg.TEST.FP16X2 = False), which have "
+                      "the fp32 exponent range.", RuntimeWarning, stacklevel=3)
+        self.cfg.TEST.FP16X2 = False
+        self.invalidate_plans()
+        for ent in self._h2_flags.values():  # (no h2 kernel runs from here on; a model switched back by hand starts clean)
+            ent[0].zero_()
+            ent[1].zero_()
+            ent[2] = None
 
     # weights changed -> packed copies are stale
     def invalidate_plans(self):
         self._plans.clear()
+        self._stamp_tensors = None
 
     def load_state_dict(self, *a, **k):
         r = super().load_state_dict(*a, **k)
@@ -997,6 +1059,7 @@ class GDRN(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self._plans = {}
+        self._stamp_tensors = None  # (.to() / .half() may replace the tensor objects)
         return super()._apply(fn, *a, **k)
 
     def train_engine(self, B, device):
@@ -1029,15 +1092,22 @@ class GDRN(nn.Module):
         self.last_train_pose = (eng.rot, eng.trans)
         return {}, dict(zip(names, outs))
 
+    def _stamp_list(self):
+        ts = self._stamp_tensors
+        if ts is None:
+            ts = self._stamp_tensors = list(self.parameters()) + list(self.buffers())
+            self._stamp_ids = frozenset(id(t) for t in ts)
+        return ts
+
+    def _tensor_ids(self):
+        self._stamp_list()
+        return self._stamp_ids
+
     def _weights_stamp(self):
-        """changes whenever a parameter or buffer may have changed since a plan packed its copies (module docstring of
-        _WEIGHTS_EPOCH): eval -> train steps -> eval must not serve the old weights"""
-        v = _WEIGHTS_EPOCH[0]
-        for t in self.parameters():
-            v = v * 1000003 + t._version
-        for t in self.buffers():
-            v = v * 1000003 + t._version
-        return v & 0xFFFFFFFFFFFF
+        """changes whenever a parameter or buffer may have changed since a plan packed its copies (comment above
+        bump_weights_epoch): eval -> train steps -> eval must not serve the old weights.  (epoch of this model, sum of the
+        tensors' in-place version counters - they only grow - over a cached tensor list: ~20 us per forward)"""
+        return (self._weights_epoch, sum(t._version for t in self._stamp_list()))
 
     def plan(self, B, device, bf16=None):
         """bf16=None follows cfg.TEST.AMP_TEST (the reference's autocast switch, gdrn_evaluator.py:625) with the 16-bit format
@@ -1064,7 +1134,10 @@ class GDRN(nn.Module):
                 gt_region=None, gt_allo_quat=None, gt_ego_quat=None, gt_allo_rot6d=None, gt_ego_rot6d=None,
                 gt_ego_rot=None, gt_points=None, sym_infos=None, gt_trans=None, gt_trans_ratio=None, roi_classes=None,
                 roi_coord_2d=None, roi_cams=None, roi_centers=None, roi_whs=None, roi_extents=None, resize_ratios=None,
-                do_loss=False, fps=None):
+                do_loss=False, fps=None, im_H=None, im_W=None):
+        """The reference's signature (GDRN.py:107-134) + im_H / im_W: the batch's per-crop image sizes (engine_utils.py:71), which
+        the reference's evaluator - not its model - consumes; they are needed here because the 2D-3D PnP (TEST.USE_PNP) runs inside
+        forward."""
         if not x.is_cuda:
             raise RuntimeError("rdpn6d_amd.GDRN runs on the MI355X HIP kernels only; got a CPU tensor (no CPU fallback)")
         pcfg = self.cfg.MODEL.CDPN.PNP_NET
@@ -1084,24 +1157,21 @@ class GDRN(nn.Module):
             return self._forward_train(x, roi_coord_2d, fps, roi_cams, roi_centers, roi_whs, roi_extents, resize_ratios, gt_xyz,
                                        gt_mask_trunc, gt_mask_visib, gt_region, gt_ego_rot, gt_points, gt_trans, gt_trans_ratio,
                                        sym_infos)
-        plan = self.plan(B, x.device)
-        if plan.range_exceeded():
-            # an activation left the range of the two-plane fp16 format in an earlier forward of this plan (that value was
-            # clamped, never an inf): fall back to the three-plane bf16 form, which has the fp32 exponent range, for good
-            import warnings
-
-            warnings.warn("rdpn6d_amd: an activation exceeded +-4094, the range of the fp16x2 (h2) convolution format; outputs of the "
-                          "previous forward were computed with that value clamped.  Switching this model to the bf16x3 kernels "
-                          "(cfg.TEST.FP16X2 = False).", RuntimeWarning, stacklevel=2)
-            self.cfg.TEST.FP16X2 = False
-            self.invalidate_plans()
-            plan = self.plan(B, x.device)
-        if tuple(x.shape[1:]) != (6, plan.R, plan.R):
-            raise ValueError(f"expected x of shape (B,6,{plan.R},{plan.R}), got {tuple(x.shape)}")
+        tcfg = self.cfg.get("TEST", {})
+        # cfg.TEST.H2_RANGE_CHECK: "sync" (default) - the range flag of the h2 kernels is read for THIS forward before its outputs
+        # are handed out (one host wait per forward, as the reference's own test-time forward has: pose_from_pred_centroid_z.py:128
+        # copies the pose to the host) and an overflowing batch is re-run on the bf16x3 kernels; "deferred" - for a pipelined
+        # serving loop: the flag travels to pinned memory behind every forward without a wait, is looked at by the NEXT forward
+        # (whatever its batch size or plan) and by h2_range_exceeded(); the forward that overflowed has then returned clamped values
+        range_check = str(tcfg.get("H2_RANGE_CHECK", "sync")).lower()
+        if range_check not in ("sync", "deferred"):
+            raise ValueError(f"TEST.H2_RANGE_CHECK={range_check!r}: sync | deferred")
+        if range_check == "deferred" and self.h2_range_exceeded(x.device, wait=False):
+            self._leave_h2(x.device, "an earlier forward, whose outputs were computed with that value clamped")
         if pcfg.TRANS_TYPE != "centroid_z" or pcfg.Z_TYPE != "REL":
             raise ValueError("only TRANS_TYPE='centroid_z' with Z_TYPE='REL' is implemented")
-        tcfg = self.cfg.get("TEST", {})
         use_pnp = bool(tcfg.get("USE_PNP", False))
+        net_mode, kabsch, im_hw = 0, False, None
         if use_pnp:
             # the three choices of gdrn_evaluator.py:136-145 = the reference's 2D-3D solve (reprojection error, P3P / Gauss-Newton:
             # rdpn6d_ransac_pnp_f32), and the same three on the RGB-D residual geometry P - delta = R anchor + t (3D-3D Kabsch,
@@ -1111,64 +1181,101 @@ class GDRN(nn.Module):
             if pnp_type not in modes:
                 raise NotImplementedError(f"TEST.PNP_TYPE={pnp_type!r}: one of {sorted(modes)}")
             net_mode, kabsch = modes[pnp_type], pnp_type.endswith("kabsch")
+            if self.cfg.MODEL.CDPN.ROT_HEAD.MASK_LOSS_TYPE != "L1":
+                # both solves normalise the mask like get_out_mask's L1 branch (engine_utils.py:124-129: per-crop min-max); its
+                # BCE / CE branches (sigmoid / arg-max, :130-134) are not built - no shipped config selects them
+                raise NotImplementedError(f"TEST.USE_PNP with ROT_HEAD.MASK_LOSS_TYPE={self.cfg.MODEL.CDPN.ROT_HEAD.MASK_LOSS_TYPE!r}: the "
+                                          "on-device correspondence selection implements the 'L1' (min-max) mask normalisation only")
             assert roi_extents is not None, "USE_PNP needs roi_extents"
             roi_extents = f32c(roi_extents)
+            if not kabsch:
+                im_hw = self._image_sizes(im_H, im_W, B, x.device, tcfg)
         is_allo = "allo" in pcfg.ROT_TYPE
 
-        def kabsch_solve():
-            # per-crop RANSAC + Kabsch on the residual correspondences, result next to the learned pose
-            plan.run_ransac(roi_coord_2d, fps, roi_extents, resize_ratios,
-                            mask_thr=float(self.cfg.MODEL.CDPN.ROT_HEAD.MASK_THR_TEST),
-                            inlier_thr=float(tcfg.get("PNP_INLIER_THR", 0.01)),
-                            iters=int(tcfg.get("PNP_ITERS", 20 if net_mode == 1 else 100)),  # 20: gdrn_evaluator.py:275
-                            confidence=float(tcfg.get("PNP_CONFIDENCE", 0.99)), seed=int(tcfg.get("PNP_SEED", 0)),
-                            net_mode=net_mode, max_t_diff=float(tcfg.get("PNP_MAX_T_DIFF", 1.0)))
+        def infer():
+            plan = self.plan(B, x.device)
+            if tuple(x.shape[1:]) != (6, plan.R, plan.R):
+                raise ValueError(f"expected x of shape (B,6,{plan.R},{plan.R}), got {tuple(x.shape)}")
 
-        # the plain solve (no network pose involved) needs only the glue kernel's outputs: it runs on a second stream next to
-        # ConvPnPNet's small launches (cfg.TEST.PNP_SIDE_STREAM, default on) and is joined before the outputs are handed out
-        overlap = use_pnp and kabsch and net_mode == 0 and bool(tcfg.get("PNP_SIDE_STREAM", True))
+            def kabsch_solve():
+                # per-crop RANSAC + Kabsch on the residual correspondences, result next to the learned pose
+                plan.run_ransac(roi_coord_2d, fps, roi_extents, resize_ratios,
+                                mask_thr=float(self.cfg.MODEL.CDPN.ROT_HEAD.MASK_THR_TEST),
+                                inlier_thr=float(tcfg.get("PNP_INLIER_THR", 0.01)),
+                                iters=int(tcfg.get("PNP_ITERS", 20 if net_mode == 1 else 100)),  # 20: gdrn_evaluator.py:275
+                                confidence=float(tcfg.get("PNP_CONFIDENCE", 0.99)), seed=int(tcfg.get("PNP_SEED", 0)),
+                                net_mode=net_mode, max_t_diff=float(tcfg.get("PNP_MAX_T_DIFF", 1.0)))
 
-        def launch():
-            plan.run(x, roi_coord_2d, fps, roi_cams, roi_centers, roi_whs, resize_ratios, is_allo=is_allo,
-                     after_glue=kabsch_solve if overlap else None)
-            if overlap:
-                return
-            if use_pnp and not kabsch:
-                # the reference leaves "TODO: move the pnp/ransac inside forward" (GDRN.py:294); here it is inside: selection +
-                # 2D-3D RANSAC-PnP with the call sites' parameters (3 px, 100 | 20 iterations: gdrn_evaluator.py:275,386-389)
-                c2 = roi_coord_2d.shape[1]
-                plan.run_pnp2d(roi_coord_2d, roi_extents, roi_cams, (int(tcfg.get("IM_H", 480)), int(tcfg.get("IM_W", 640))),
-                               tuple(tcfg.get("PNP_COORD2D_CHANNELS", (c2 - 2, c2 - 1))),  # RDPN: [depth xyz | u v]; the call site's "as given" = (0, 1)
-                               mask_thr=float(self.cfg.MODEL.CDPN.ROT_HEAD.MASK_THR_TEST),
-                               reproj_thr=float(tcfg.get("PNP_REPROJ_THR", 3.0)), iters=int(tcfg.get("PNP_ITERS", 20 if net_mode == 1 else 100)),
-                               confidence=float(tcfg.get("PNP_CONFIDENCE", 0.99)), seed=int(tcfg.get("PNP_SEED", 0)), net_mode=net_mode,
-                               max_t_diff=float(tcfg.get("PNP_MAX_T_DIFF", 1.0)))
-            elif use_pnp:
-                kabsch_solve()
+            # the plain solve (no network pose involved) needs only the glue kernel's outputs: it runs on a second stream next to
+            # ConvPnPNet's small launches (cfg.TEST.PNP_SIDE_STREAM, default on) and is joined before the outputs are handed out
+            overlap = use_pnp and kabsch and net_mode == 0 and bool(tcfg.get("PNP_SIDE_STREAM", True))
 
-        if tcfg.get("HIP_GRAPH", False):
-            # one hipGraph per set of input buffers: a serving loop that re-fills the same device buffers replays ~90
-            # kernel launches with one call (extension over the reference's config surface, off by default)
-            key = tuple(t.data_ptr() for t in (x, roi_coord_2d, fps, roi_cams, roi_centers, roi_whs, resize_ratios)) + (
-                roi_extents.data_ptr() if use_pnp else 0, is_allo, use_pnp, float(tcfg.get("PNP_INLIER_THR", 0.01)),
-                int(tcfg.get("PNP_ITERS", 100)), int(tcfg.get("PNP_SEED", 0)), tcfg.get("PNP_TYPE", "ransac_pnp"),
-                bool(tcfg.get("PNP_SIDE_STREAM", True)), torch.cuda.current_stream().cuda_stream)
-            plan.run_graphed(key, launch)
-        else:
-            launch()
-        o = plan.out_nchw.clone()  # the plan's buffer is overwritten by the next forward: hand out a private copy
-        K = plan.K
-        out = {
-            "rot": plan.rot.clone(), "trans": plan.trans.clone(),
-            "mask": o[:, 0:1], "coor_x": o[:, 1:2], "coor_y": o[:, 2:3], "coor_z": o[:, 3:4], "region": o[:, 4:5 + K],
-            "consistent_map": None,
-        }
-        if use_pnp:
-            out.update({"pnp_pose": plan.pnp_pose.clone(),
-                        "pnp_num_inliers": plan.pnp_ninl.clone(), "pnp_inlier_mask": plan.pnp_mask.clone()})
-            if not kabsch:  # the 2D-3D solve's mask is indexed like the selected correspondence list (gdrn_evaluator.py:119-120)
-                out["pnp_num_points"] = plan.pnp_counts.clone()
+            def launch():
+                plan.run(x, roi_coord_2d, fps, roi_cams, roi_centers, roi_whs, resize_ratios, is_allo=is_allo,
+                         after_glue=kabsch_solve if overlap else None)
+                if overlap:
+                    return
+                if use_pnp and not kabsch:
+                    # the reference leaves "TODO: move the pnp/ransac inside forward" (GDRN.py:294); here it is inside: selection +
+                    # 2D-3D RANSAC-PnP with the call sites' parameters (3 px, 100 | 20 iterations: gdrn_evaluator.py:275,386-389)
+                    c2 = roi_coord_2d.shape[1]
+                    plan.run_pnp2d(roi_coord_2d, roi_extents, roi_cams, im_hw,
+                                   tuple(tcfg.get("PNP_COORD2D_CHANNELS", (c2 - 2, c2 - 1))),  # RDPN: [depth xyz | u v]; the call site's "as given" = (0, 1)
+                                   mask_thr=float(self.cfg.MODEL.CDPN.ROT_HEAD.MASK_THR_TEST),
+                                   reproj_thr=float(tcfg.get("PNP_REPROJ_THR", 3.0)), iters=int(tcfg.get("PNP_ITERS", 20 if net_mode == 1 else 100)),
+                                   confidence=float(tcfg.get("PNP_CONFIDENCE", 0.99)), seed=int(tcfg.get("PNP_SEED", 0)), net_mode=net_mode,
+                                   max_t_diff=float(tcfg.get("PNP_MAX_T_DIFF", 1.0)))
+                elif use_pnp:
+                    kabsch_solve()
+
+            if tcfg.get("HIP_GRAPH", False):
+                # one hipGraph per set of input buffers: a serving loop that re-fills the same device buffers replays ~90
+                # kernel launches with one call (extension over the reference's config surface, off by default)
+                key = tuple(t.data_ptr() for t in (x, roi_coord_2d, fps, roi_cams, roi_centers, roi_whs, resize_ratios)) + (
+                    roi_extents.data_ptr() if use_pnp else 0, im_hw.data_ptr() if im_hw is not None else 0, is_allo, use_pnp,
+                    float(tcfg.get("PNP_INLIER_THR", 0.01)), int(tcfg.get("PNP_ITERS", 100)), int(tcfg.get("PNP_SEED", 0)),
+                    tcfg.get("PNP_TYPE", "ransac_pnp"), bool(tcfg.get("PNP_SIDE_STREAM", True)), torch.cuda.current_stream().cuda_stream)
+                plan.run_graphed(key, launch)
+            else:
+                launch()
+            o = plan.out_nchw.clone()  # the plan's buffer is overwritten by the next forward: hand out a private copy
+            K = plan.K
+            out = {
+                "rot": plan.rot.clone(), "trans": plan.trans.clone(),
+                "mask": o[:, 0:1], "coor_x": o[:, 1:2], "coor_y": o[:, 2:3], "coor_z": o[:, 3:4], "region": o[:, 4:5 + K],
+                "consistent_map": None,
+            }
+            if use_pnp:
+                out.update({"pnp_pose": plan.pnp_pose.clone(),
+                            "pnp_num_inliers": plan.pnp_ninl.clone(), "pnp_inlier_mask": plan.pnp_mask.clone()})
+                if not kabsch:  # the 2D-3D solve's mask is indexed like the selected correspondence list (gdrn_evaluator.py:119-120)
+                    out["pnp_num_points"] = plan.pnp_counts.clone()
+            return plan, out
+
+        plan, out = infer()
+        if plan.fast == "h2":
+            # after the replayed graph / the eager launches AND the clones above: the flag read below answers for THIS forward
+            self._range_flag_fetch(x.device)
+            if range_check == "sync" and self.h2_range_exceeded(x.device, wait=True):
+                self._leave_h2(x.device, "this forward; the batch is re-run on the bf16x3 kernels")
+                plan, out = infer()
         return out
+
+    @staticmethod
+    def _image_sizes(im_H, im_W, B, device, tcfg):
+        """(B, 2) int32 [H, W] of the image every crop was cut from: the reference scales coord2d by each input's own im_H / im_W
+        (gdrn_evaluator.py:346-347,107-108; batch keys "im_H", "im_W" of engine_utils.batch_data_test).  Taken from the forward's
+        im_H / im_W arguments (scalar, list or tensor of B), else from cfg.TEST.IM_H / IM_W when BOTH are set; there is no default -
+        a silently assumed 480 x 640 mis-scales the 2D points of every other camera (T-LESS 540 x 720, ITODD, ...)."""
+        if im_H is None and im_W is None and "IM_H" in tcfg and "IM_W" in tcfg:
+            im_H, im_W = tcfg.get("IM_H"), tcfg.get("IM_W")
+        if im_H is None or im_W is None:
+            raise ValueError("TEST.USE_PNP with a 2D-3D PNP_TYPE needs the image size of every crop: pass im_H / im_W to forward "
+                             "(batch['im_H'], batch['im_W']) or set cfg.TEST.IM_H and cfg.TEST.IM_W")
+        hw = torch.stack([torch.as_tensor(v).reshape(-1).to(torch.float64).round().to(torch.int32).cpu().expand(B) for v in (im_H, im_W)], dim=1)
+        if int(hw.min()) <= 0:
+            raise ValueError(f"im_H / im_W must be positive, got {hw.tolist()}")
+        return hw.contiguous().to(device)
 
 
 class _HipBackward(torch.autograd.Function):

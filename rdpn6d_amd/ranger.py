@@ -169,7 +169,7 @@ class Ranger(Optimizer):
         step = self._step
         from .gdrn import bump_weights_epoch
 
-        bump_weights_epoch()  # the kernel writes the parameters through raw pointers: packed inference copies are stale
+        bump_weights_epoch(self._params)  # the kernel writes THESE parameters through raw pointers: their model's packed inference copies are stale
         lib = _lib.load()
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         P = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731

@@ -45,6 +45,9 @@ class TrainEngine:
         self.lp = "fp16" if amp == "fp16" else "bf16"   # 16-bit storage format of the mixed-precision step
         self.lp_dtype = torch.float16 if self.lp == "fp16" else torch.bfloat16
         self.loss_scale = 1.0  # forward_backward() multiplies the backward seeds by it and divides the parameter gradients again
+        self.accumulate_grad = False  # backward() WRITES param.grad; True = add to what is there (see backward)
+        self._seed_factor = 1.0  # factor currently applied to the backward seeds d_head / d_rt (seed_backward)
+        self._consumed = True  # backward() has used up the last forward's buffers (nothing to differentiate before the first forward)
         self.adt = self.lp_dtype if self.amp else torch.float32  # storage type of trunk / head activations and gradients
         self.sfx = self.lp if self.amp else "f32"
         self._casts = {}     # (address, stride, offset, channels) of an fp32 activation slice -> its bf16 copy
@@ -879,10 +882,12 @@ class TrainEngine:
         torch._foreach_add_(self._bn_counters, 1)  # BatchNorm2d.num_batches_tracked (one fused launch)
         from .gdrn import bump_weights_epoch
 
-        bump_weights_epoch()  # running statistics moved under any InferencePlan's folded copies
+        bump_weights_epoch(self.model)  # running statistics moved under this model's InferencePlans' folded copies
         sym = self._pack_sym_infos(batch.get("sym_info")) if self.pm_sym else (None, None, 0)
         self._loss_ctx = (cams, centers, whs, ratios, extents, gt_xyz, mv, mt, gt_region, gt_rot, gt_ratio, pts, sym)
         self._run_loss_kernels(self.lw, self.losses9)
+        self._seed_factor = 1.0  # fresh seeds
+        self._consumed = False
         return {n: self.losses9[i] for i, n in enumerate(self.LOSS_NAMES)}
 
     def _run_loss_kernels(self, lw, losses9):
@@ -907,14 +912,21 @@ class TrainEngine:
         (gdrn._HipBackward): all 1 for the reference's plain sum, the loss scale under a GradScaler (engine.py:302-309),
         1/n for gradient accumulation, 0 for a loss left out.  The backward is linear in its two seeds, so a common factor
         scales them; different factors re-run the two loss kernels with the loss weights multiplied (losses that share a
-        weight in the kernels - coor_x/y/z, region/region_my - must then share their factor)."""
+        weight in the kernels - coor_x/y/z, region/region_my - must then share their factor).
+        ABSOLUTE, not cumulative: the factor applied to d_head / d_rt since the last forward_losses() is remembered, so calling
+        this again (a second backward through the same node with retain_graph, a caller that seeds and then runs
+        forward_backward) re-scales by new / old instead of compounding."""
+        if self._consumed:
+            raise RuntimeError("seed_backward: no forward to differentiate (backward already ran for it; retain_graph is not supported)")
         w = [float(weights.get(n, 0.0)) for n in self.LOSS_NAMES]
         if any(x != x or x in (float("inf"), float("-inf")) for x in w):
             raise FloatingPointError(f"non-finite gradient flowing into the losses: {dict(zip(self.LOSS_NAMES, w))}")
-        if all(x == w[0] for x in w):
-            if w[0] != 1.0:
-                self.d_head.mul_(w[0])
-                self.d_rt.mul_(w[0])
+        cur = self._seed_factor  # a float (common factor in place) or None (per-loss factors / zeroed: seeds must be recomputed)
+        if all(x == w[0] for x in w) and cur is not None and cur != 0.0:
+            if w[0] != cur:
+                self.d_head.mul_(w[0] / cur)
+                self.d_rt.mul_(w[0] / cur)
+                self._seed_factor = w[0]
             return
         if not (w[0] == w[1] == w[2] and w[4] == w[5]):
             raise NotImplementedError("different upstream gradients for loss_coor_x/y/z or for loss_region/loss_region_my: the loss "
@@ -923,32 +935,64 @@ class TrainEngine:
         for key, i in (("xyz", 0), ("mask", 3), ("region", 4), ("pm", 6), ("centroid", 7), ("z", 8)):
             lw[key] = self.lw[key] * w[i]
         self._run_loss_kernels(lw, self.buf("losses9_scratch", 9))
+        self._seed_factor = w[0] if all(x == w[0] for x in w) else None
 
-    def backward(self, on_group_done=None):
-        """Backward of sum(losses) into param.grad.  on_group_done(name) is called after the gradients of
-        'pnp_net', 'rot_head_net' and 'backbone' are complete (gradient-bucket all-reduce hook)."""
+    def _flat_or_list(self):
+        """(the one flat buffer all parameter gradients are views of - GradBuckets / Ranger layout - or None, the gradient list)"""
+        grads = [p.grad for p in self.model.parameters() if p.grad is not None]
+        bases = {id(g._base) for g in grads if g._base is not None}
+        flat = grads[0]._base if grads and len(bases) == 1 and all(g._base is not None for g in grads) else None
+        return flat, grads
+
+    def backward(self, on_group_done=None, unscale=1.0):
+        """Backward of sum(seed_i * loss_i) into param.grad.  on_group_done(name) is called after the gradients of
+        'pnp_net', 'rot_head_net' and 'backbone' are complete (gradient-bucket all-reduce hook).
+        The kernels WRITE param.grad (split-K reduces, BatchNorm / bias sums store, they do not add): that equals autograd's
+        accumulate after the zero_grad the reference loop issues before every backward (engine.py:304-308).  For gradient
+        accumulation over micro-batches - not part of the reference loop - set `accumulate_grad = True`: the gradients already
+        in param.grad are saved and added back after this backward (one extra pass over the 146 MB; not with bucket hooks, whose
+        all-reduce would average the running sum again).
+        unscale: divide THIS backward's gradients by it (the loss scale the seeds carried) - before anything accumulated
+        earlier is added back, so earlier micro-batches are never divided twice."""
+        if self._consumed:
+            # the backward kernels work in place on the gradient buffers the loss kernels seeded (and on saved activations): a second
+            # pass over the same forward would start from overwritten data - autograd's "backward through the graph a second time"
+            raise RuntimeError("TrainEngine.backward was already run for this forward; the HIP backward consumes the forward's buffers "
+                               "(retain_graph is not supported) - call forward_losses / the model's forward again")
+        self._consumed = True
         marks = getattr(self, "_group_marks", None)
+        prev = None
+        if self.accumulate_grad:
+            if on_group_done is not None:
+                raise NotImplementedError("accumulate_grad with gradient-bucket hooks: reduce once, after the last micro-batch")
+            flat, grads = self._flat_or_list()
+            prev = flat.clone() if flat is not None else [g.clone() for g in grads]
         for idx in range(len(self.bwd) - 1, -1, -1):
             for fn in self.bwd[idx]:
                 fn()
             if on_group_done is not None and marks and idx in marks:
                 on_group_done(marks[idx])
+        if unscale != 1.0 or prev is not None:
+            flat, grads = self._flat_or_list()
+            if unscale != 1.0:
+                if on_group_done is not None:
+                    raise NotImplementedError("unscale with gradient-bucket hooks: un-scale the flat buffer after buckets.finish()")
+                flat.mul_(1.0 / unscale) if flat is not None else torch._foreach_mul_(grads, 1.0 / unscale)
+            if prev is not None:
+                if flat is not None and torch.is_tensor(prev):
+                    flat.add_(prev)
+                else:  # (param.grad tensors were created by this very backward: nothing had accumulated for them)
+                    prev_l = [prev] if torch.is_tensor(prev) else prev
+                    if len(prev_l) == len(grads) and all(a.shape == b.shape for a, b in zip(grads, prev_l)):
+                        torch._foreach_add_(grads, prev_l)
 
     def forward_backward(self, batch):
         """forward + losses + backward.  With `loss_scale` != 1 (fp16 storage of the activation gradients: the un-scaled seeds
-        1 / (B * HW) ~ 4e-6 are fp16 subnormals) the seeds are multiplied by it and the parameter gradients divided again -
-        what torch's GradScaler does around the reference's step (engine.py:302-309); non-finite gradients are left for the
-        caller's overflow check, as GradScaler.step would see them."""
+        1 / (B * HW) ~ 4e-6 are fp16 subnormals) the seeds are multiplied by it and the parameter gradients of THIS backward divided
+        again - what torch's GradScaler does around the reference's step (engine.py:302-309); non-finite gradients are left for
+        the caller's overflow check, as GradScaler.step would see them."""
         losses = self.forward_losses(batch)
         S = float(self.loss_scale)
-        if S != 1.0:
-            self.seed_backward({n: S for n in self.LOSS_NAMES})
-        self.backward()
-        if S != 1.0:
-            grads = [p.grad for p in self.model.parameters() if p.grad is not None]
-            base = {id(g._base) for g in grads if g._base is not None}
-            if len(base) == 1 and all(g._base is not None for g in grads):
-                grads[0]._base.mul_(1.0 / S)  # one flat buffer (GradBuckets / Ranger)
-            else:
-                torch._foreach_mul_(grads, 1.0 / S)
+        self.seed_backward({n: S for n in self.LOSS_NAMES})
+        self.backward(unscale=S)
         return losses

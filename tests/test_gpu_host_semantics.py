@@ -176,6 +176,72 @@ def test_backward_honours_the_upstream_gradient():
         grads(lambda ld: sum(ld.values()) * float("inf"))
 
 
+def test_loss_scale_and_micro_batch_accumulation_do_not_compound():
+    """(a) seed_backward is absolute - seeding twice does not compound the factor, and a second backward through the same
+    node (retain_graph) raises; (b) forward_backward with a loss scale un-scales only what THIS backward produced, so with
+    `accumulate_grad` the gradients of earlier micro-batches are not divided again; (c) without accumulate_grad a backward WRITES
+    param.grad (the documented contract: the reference loop zeroes before every backward, engine.py:304-308)."""
+    dev = torch.device("cuda:0")
+    model, opt = _model("none")
+    b1, b2 = _batch(2, 11, dev), _batch(2, 12, dev)
+    eng = model.train_engine(2, dev)
+
+    def grads_of(batch, scale=1.0):
+        eng.loss_scale = scale
+        eng.forward_backward(batch)
+        torch.cuda.synchronize()
+        return torch.cat([p.grad.detach().reshape(-1) for p in model.parameters()]).clone()
+
+    opt.zero_grad(set_to_none=True)
+    g1 = grads_of(b1)
+    g2 = grads_of(b2)                     # (c) overwrites: equals b2's own gradients, not g1 + g2
+    model2, _ = _model("none")
+    eng2 = model2.train_engine(2, dev)
+    eng2.forward_backward(b1)             # same BatchNorm-statistics history as `model` had when it saw b2
+    eng2.forward_backward(b2)
+    torch.cuda.synchronize()
+    assert torch.equal(g2, torch.cat([p.grad.detach().reshape(-1) for p in model2.parameters()]))
+    # (a) absolute seeds: scale 4096 via seed_backward called twice + forward_backward's own call
+    eng.loss_scale = 1.0
+    eng.forward_losses(b2)
+    eng.seed_backward({n: 4096.0 for n in eng.LOSS_NAMES})
+    eng.seed_backward({n: 4096.0 for n in eng.LOSS_NAMES})
+    eng.backward(unscale=4096.0)
+    torch.cuda.synchronize()
+    g2s = torch.cat([p.grad.detach().reshape(-1) for p in model.parameters()]).clone()
+    assert torch.equal(g2s, g2)  # same weights, same batch (training-mode BatchNorm uses batch statistics): 4096 drops out exactly
+    ld = _train_losses(model, b2)
+    tot = sum(ld.values())
+    opt.zero_grad(set_to_none=True)
+    tot.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="retain_graph is not supported"):  # the HIP backward works in place: a second pass is refused, not silently wrong
+        (tot * 8.0).backward()
+    # (b) two micro-batches with a loss scale, accumulated: g(b1) + g(b2) of the SAME weights / statistics sequence without a scale
+    def two_micro(scale, m):
+        e = m.train_engine(2, dev)
+        e.accumulate_grad, e.loss_scale = True, scale
+        torch._foreach_zero_([p.grad for p in m.parameters()])  # (in place: the engine's launches hold the gradients' addresses)
+        e.forward_backward(b1)
+        e.forward_backward(b2)
+        torch.cuda.synchronize()
+        e.accumulate_grad = False
+        return torch.cat([p.grad.detach().reshape(-1) for p in m.parameters()]).clone()
+
+    ma, _ = _model("none")
+    mb, _ = _model("none")
+    acc1, acc_s = two_micro(1.0, ma), two_micro(1024.0, mb)
+    assert torch.equal(acc1, acc_s), "power-of-two loss scale must drop out exactly, also for the first micro-batch"
+    mc, _ = _model("none")
+    ec = mc.train_engine(2, dev)
+    ec.forward_backward(b1)
+    torch.cuda.synchronize()
+    first = torch.cat([p.grad.detach().reshape(-1) for p in mc.parameters()]).clone()
+    ec.forward_backward(b2)
+    torch.cuda.synchronize()
+    second = torch.cat([p.grad.detach().reshape(-1) for p in mc.parameters()])
+    assert torch.equal(acc1, first + second)
+
+
 # ----------------------------------------------------------------------------- two data-parallel ranks on one GPU
 def _dp_worker(rank, world, port, q, backend="gloo"):
     import torch.distributed as dist
@@ -291,3 +357,80 @@ def test_rccl_backed_gradient_reduction_through_the_real_engine():
     res = q.get(timeout=600)
     p.join(timeout=120)
     assert res[:2] == (0, True), res
+
+
+def _overflowing(b):
+    """the batch with its image 10^5 times too bright: the stem's activations leave the +-4094 of the h2 format"""
+    o = dict(b)
+    o["roi_img"] = b["roi_img"] * 1.0e5
+    return o
+
+
+def _want_bf16x3(b):
+    ref, _ = _model("none")
+    ref.cfg.TEST.FP16X2 = False
+    return _eval(ref, b)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_h2_range_overflow_is_caught_in_the_forward_that_overflowed(graph):
+    """an activation beyond the fp16 range of the h2 kernels must not reach the caller as a clamped result.  Default
+    (cfg.TEST.H2_RANGE_CHECK = "sync"): the forward reads the device flag for ITSELF, warns, switches the model to the bf16x3
+    kernels and re-runs the batch - also when the forward is a replayed hipGraph captured on an input that did not overflow,
+    also when the overflow happens on a plan (batch size) that is used only once, and the switch survives a plan rebuild."""
+    dev = torch.device("cuda:0")
+    b, b3 = _batch(2, 3, dev), _batch(3, 5, dev)
+    hot = _overflowing(b)
+    want = _want_bf16x3(hot)
+    model, _ = _model("none")
+    model.cfg.TEST.HIP_GRAPH = graph
+    with warnings_none():
+        for _ in range(3):  # (graph: eager, capture, replay) on data that stays in range
+            o_ok = _eval(model, b)
+    assert model.cfg.TEST.FP16X2 is True and not model.h2_range_exceeded(dev) and model.plan(2, dev).fast == "h2"
+    if graph:
+        assert any(not isinstance(g, str) for g in model.plan(2, dev)._graphs.values()), "the graph was not captured"
+        keep = b["roi_img"].clone()
+        b["roi_img"].copy_(hot["roi_img"])  # same buffers -> the captured graph replays on data that now overflows
+        hot = b
+    with pytest.warns(RuntimeWarning, match="exceeded"):
+        o = _eval(model, hot)
+    assert model.cfg.TEST.FP16X2 is False
+    for k in ("mask", "coor_x", "region", "rot", "trans"):
+        assert torch.isfinite(o[k]).all() and torch.equal(o[k], want[k]), k
+    with warnings_none():
+        o3 = _eval(model, b3)  # another batch size, new plan: stays on bf16x3, no second warning
+        assert model.plan(3, dev).fast == "x3" and torch.isfinite(o3["rot"]).all()
+    assert torch.isfinite(o_ok["rot"]).all()
+
+
+def test_h2_range_overflow_deferred_mode_is_reported_by_the_next_forward_of_any_plan():
+    """cfg.TEST.H2_RANGE_CHECK = "deferred" (pipelined serving: no host wait per forward): the flag is model-level, so the NEXT
+    forward sees it whatever its batch size, and h2_range_exceeded() answers at any sync point."""
+    dev = torch.device("cuda:0")
+    b, b3 = _batch(2, 3, dev), _batch(3, 5, dev)
+    model, _ = _model("none")
+    model.cfg.TEST.H2_RANGE_CHECK = "deferred"
+    with warnings_none():
+        o = _eval(model, _overflowing(b))  # clamped values, no wait, no warning yet
+    assert model.cfg.TEST.FP16X2 is True and torch.isfinite(o["rot"]).all()
+    assert model.h2_range_exceeded(dev, wait=True)
+    with pytest.warns(RuntimeWarning, match="earlier forward"):
+        o3 = _eval(model, b3)
+    assert model.cfg.TEST.FP16X2 is False and model.plan(3, dev).fast == "x3"
+    want3 = _want_bf16x3(b3)
+    assert torch.equal(o3["rot"], want3["rot"]) and torch.equal(o3["region"], want3["region"])
+
+
+class warnings_none:
+    """context: any RuntimeWarning inside is an error"""
+
+    def __enter__(self):
+        import warnings
+
+        self._cm = warnings.catch_warnings()
+        self._cm.__enter__()
+        warnings.simplefilter("error", RuntimeWarning)
+
+    def __exit__(self, *a):
+        return self._cm.__exit__(*a)

@@ -117,16 +117,22 @@ def test_model_pnp_type_2d3d_inside_forward(oracle_lib, golden_dir, pnp_type):
     model.eval()
     inp = synth.make_inputs(4, seed=36)
     t = {k: torch.from_numpy(v).to(dev) for k, v in inp.items()}
+    # per-crop image sizes as the reference's batch carries them (engine_utils.py:71 "im_H", "im_W"; gdrn_evaluator.py:346-347): crop 1
+    # comes from a 540 x 720 image (T-LESS), the others from 480 x 640
+    im_H, im_W = torch.tensor([480.0, 540.0, 480.0, 480.0]), torch.tensor([640.0, 720.0, 640.0, 640.0])
+    kw = dict(roi_classes=t["roi_cls"], roi_coord_2d=t["roi_coord_2d"], roi_cams=t["roi_cam"], roi_centers=t["roi_center"],
+              roi_whs=t["roi_wh"], roi_extents=t["roi_extent"], resize_ratios=t["resize_ratio"], do_loss=False, fps=t["fps"])
     with torch.no_grad():
-        o = model(t["roi_img"], roi_classes=t["roi_cls"], roi_coord_2d=t["roi_coord_2d"], roi_cams=t["roi_cam"], roi_centers=t["roi_center"],
-                  roi_whs=t["roi_wh"], roi_extents=t["roi_extent"], resize_ratios=t["resize_ratio"], do_loss=False, fps=t["fps"])
+        with pytest.raises(ValueError, match="im_H"):  # no silent 480 x 640
+            model(t["roi_img"], **kw)
+        o = model(t["roi_img"], im_H=im_H.to(dev), im_W=im_W, **kw)
     torch.cuda.synchronize()
     maps = torch.cat([o["mask"], o["coor_x"], o["coor_y"], o["coor_z"]], 1).cpu().numpy()
     nm = select_oracle.out_mask_l1(maps[:, :1])
     ip, mp, cnt = np.zeros((4, 4096, 2), np.float32), np.zeros((4, 4096, 3), np.float32), np.zeros(4, np.int32)
     for b in range(4):
         a, m, _ = select_oracle.select_correspondences(nm[b, 0], maps[b, 1:4].transpose(1, 2, 0), inp["roi_coord_2d"][b, 3:5].transpose(1, 2, 0),
-                                                       480, 640, inp["roi_extent"][b], 0.5)
+                                                       int(im_H[b]), int(im_W[b]), inp["roi_extent"][b], 0.5)
         cnt[b] = len(a)
         ip[b, :len(a)], mp[b, :len(a)] = a, m
     assert np.array_equal(o["pnp_num_points"].cpu().numpy(), cnt) and cnt.min() >= 4
@@ -137,3 +143,16 @@ def test_model_pnp_type_2d3d_inside_forward(oracle_lib, golden_dir, pnp_type):
     assert np.array_equal(o["pnp_num_inliers"].cpu().numpy(), ni) and np.array_equal(o["pnp_inlier_mask"].cpu().numpy(), mo)
     assert np.abs(o["pnp_pose"].cpu().numpy() - po).max() < 1e-4
     assert o["pnp_pose"].shape == (4, 12)
+    if pnp_type == "ransac_pnp":
+        # cfg.TEST.IM_H / IM_W (both set) serve a loop whose images all have one size; a mask type whose normalisation the
+        # selection kernel does not implement (get_out_mask's sigmoid branch, engine_utils.py:130-132) raises instead of using min-max
+        cfg.TEST.IM_H, cfg.TEST.IM_W = 480, 640
+        with torch.no_grad():
+            o2 = model(t["roi_img"], **kw)
+            o3 = model(t["roi_img"], im_H=480, im_W=[640] * 4, **kw)
+        for k in ("pnp_pose", "pnp_num_points", "pnp_inlier_mask"):
+            assert torch.equal(o2[k], o3[k])
+        assert not torch.equal(o2["pnp_pose"][1], o["pnp_pose"][1]) and torch.equal(o2["pnp_num_points"], o["pnp_num_points"])
+        cfg.MODEL.CDPN.ROT_HEAD.MASK_LOSS_TYPE = "BCE"
+        with torch.no_grad(), pytest.raises(NotImplementedError, match="MASK_LOSS_TYPE"):
+            model(t["roi_img"], **kw)
