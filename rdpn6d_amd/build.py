@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librdpn6d_hip.so")
-SOURCES = ["api.cpp", "conv_igemm.hip", "conv_igemm_bf16.hip", "conv_igemm_bf16_8ph.hip", "conv_igemm_bf16x3.hip", "conv_igemm_bf16x3_tile.hip", "conv_igemm_h2.hip", "pointwise.hip", "pointwise_bf16.hip", "pointwise_h2.hip", "fps.hip", "ransac.hip", "train_norm.hip", "train_wgrad.hip", "train_misc.hip", "ranger.hip", "targets_eval.hip", "crop_builder.hip", "pnp.hip"]
+SOURCES = ["api.cpp", "conv_igemm.hip", "conv_igemm_bf16.hip", "conv_igemm_bf16_8ph.hip", "conv_igemm_bf16x3.hip", "conv_igemm_bf16x3_tile.hip", "conv_igemm_h2.hip", "conv_igemm_h2_pp.hip", "pointwise.hip", "pointwise_bf16.hip", "pointwise_h2.hip", "fps.hip", "ransac.hip", "train_norm.hip", "train_wgrad.hip", "train_misc.hip", "ranger.hip", "targets_eval.hip", "crop_builder.hip", "pnp.hip"]
 NO_CONTRACT = {"fps.hip", "ransac.hip", "targets_eval.hip", "crop_builder.hip", "pnp.hip"}  # bit-exact integer outputs depend on un-fused fp32 arithmetic
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # The 16-bit kernels are written once and built twice (csrc/common.h): bf16 with the sources above, IEEE fp16 - the reference's

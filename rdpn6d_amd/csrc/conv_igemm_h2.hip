@@ -23,26 +23,10 @@
 // What differs is the inner product: of a row's four 16-byte slot pairs j (j = 0,1: hi of channels 0-15 / 16-31; j = 2,3:
 // lo) a k16 step s takes  A[2+s]*B[s] + A[s]*B[2+s] + A[s]*B[s]  - 6 MFMAs per 32x32 tile pair and row instead of 4, from
 // the same fragment reads - and the epilogue, which writes fp32 and / or the h2 record of the result.
-#include "conv_bf16_common.h"
+#include "conv_h2_common.h"
 
 #include <cstdio>
 #include <cstdlib>
-#include <type_traits>
-
-struct ConvH2Args {
-    ConvBArgs b;         // d.x / d.w: h2 tensors; d.y: fp32 output or null; d.res: fp32 residual or null; channel counts REAL
-    void* y_h2;          // optional: the result as an h2 tensor (geometry d.out_cs / d.out_co, multiples of 32)
-    const void* res_h2;  // optional: the residual as an h2 tensor (geometry d.res_cs / d.res_co), used when d.res is null
-    int* overflow_flag;  // set to 1 when an output had to be clamped to the fp16 range (may be null)
-    // per-crop bias [B][4][Npad] added after scale / shift: row (b, variant) with variant = (last output row) * 2 + (last output column)
-    // - the contribution of a spatially constant input slice to a ConvTranspose phase (pointwise_h2.hip); null = none
-    const float* crop_bias;
-    // split-K of the tile kernel (per-image batches: layer3 / layer4 of one crop are 256 / 64 rows x 2304 / 4608 reductions on a
-    // handful of workgroups): gridDim.y K-slices of b.kper chunks each write raw fp32 partial tiles to `partial`
-    // ([slice][mtiles*BM][Npad]); h2_splitk_reduce_kernel adds the slices in slice order (deterministic) and runs the epilogue
-    float* partial;
-    int nsplit, mpad;
-};
 
 #ifdef RDPN6D_PROBE
 // probe build only (RDPN6D_PROBE=1 python -m rdpn6d_amd.build; tools/probe_h2_tile.py): per-wave cycle sums of the phases of a
@@ -56,100 +40,6 @@ extern "C" int rdpn6d_debug_h2_probe(void* buf)
 #endif
 
 namespace {
-
-constexpr float H2_SCALE = 16.f, H2_INV_SCALE = 1.f / 16.f, H2_MAX = 65504.f;
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-
-template <int V>
-using ic = std::integral_constant<int, V>;
-
-// fp32 value (already multiplied by the tensor scale) -> hi, lo; returns true when it had to be clamped
-__device__ __forceinline__ bool h2_split(float s, _Float16& hi, _Float16& lo)
-{
-    const bool over = !(fabsf(s) <= H2_MAX);  // also catches NaN (left to propagate as NaN)
-    s = fminf(fmaxf(s, -H2_MAX), H2_MAX);
-    hi = (_Float16)s;
-    lo = (_Float16)(s - (float)hi);
-    return over;
-}
-
-// Tail of the h2 epilogues for 8 consecutive channels [ch, ch+8) of output pixel `pix`: v = scale*acc + shift on entry;
-// residual (fp32 tensor or h2 record), activation, fp32 store and / or the h2 record of the result.
-__device__ __forceinline__ void h2_finish_row8(const ConvH2Args& ax, float (&v)[8], const long long pix, const int ch)
-{
-    const rdpn6d_conv_desc& d = ax.b.d;
-    if (ax.crop_bias) {
-        const int ohw = d.OH * d.OW;
-        const int b = (int)(pix / ohw);
-        const int r = (int)(pix - (long long)b * ohw);
-        const int oy = r / d.OW, ox = r - oy * d.OW;
-        const float* cb = ax.crop_bias + (long long)(b * 4 + (oy == d.OH - 1 ? 2 : 0) + (ox == d.OW - 1 ? 1 : 0)) * d.Npad + ch;
-        const f32x4 c0 = *reinterpret_cast<const f32x4*>(cb), c1 = *reinterpret_cast<const f32x4*>(cb + 4);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            v[q] += c0[q];
-            v[4 + q] += c1[q];
-        }
-    }
-    if (d.res) {
-        const float* rp = d.res + pix * d.res_cs + d.res_co + ch;
-        const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            v[q] += r0[q];
-            v[4 + q] += r1[q];
-        }
-    } else if (ax.res_h2) {
-        const int c = d.res_co + ch;
-        const _Float16* rp = reinterpret_cast<const _Float16*>(ax.res_h2) + pix * (2 * d.res_cs) + (c >> 5) * 64 + (c & 31);
-        const f16x8 rh = *reinterpret_cast<const f16x8*>(rp), rl = *reinterpret_cast<const f16x8*>(rp + 32);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] += ((float)rh[q] + (float)rl[q]) * H2_INV_SCALE;  // the activation as the h2 tensor holds it (22 significand bits)
-    }
-    conv_bf16_act(v, d.act, d.slope);
-    if (d.y) {
-        float* op = d.y + pix * d.out_cs + d.out_co + ch;
-        const f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-        *reinterpret_cast<f32x4*>(op) = o0;
-        *reinterpret_cast<f32x4*>(op + 4) = o1;
-    }
-    if (ax.y_h2) {
-        f16x8 hi, lo;
-        bool over = false;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            _Float16 h, l;
-            over |= h2_split(v[q] * H2_SCALE, h, l);
-            hi[q] = h;
-            lo[q] = l;
-        }
-        const int c = d.out_co + ch;
-        _Float16* pp = reinterpret_cast<_Float16*>(ax.y_h2) + pix * (2 * d.out_cs) + (c >> 5) * 64 + (c & 31);
-        *reinterpret_cast<f16x8*>(pp) = hi;
-        *reinterpret_cast<f16x8*>(pp + 32) = lo;
-        if (over && ax.overflow_flag) *ax.overflow_flag = 1;
-    }
-}
-
-__device__ __forceinline__ f32x16 h2_mfma(const u32x4 a, const u32x4 b, const f32x16 c)
-{
-    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
-}
-// the six partial products of a 128-byte row pair, smallest terms first: (slot pair of A, slot pair of B)
-#define H2_PAIRS constexpr int H2_PA[6] = {2, 0, 0, 3, 1, 1}, H2_PB[6] = {0, 2, 0, 1, 3, 1}
-
-__device__ __forceinline__ long long h2_pixel_of(const ConvBArgs& a, const long long m)
-{
-    const rdpn6d_conv_desc& d = a.d;
-    if (a.linear_out) return m;
-    const int mm = (int)m;
-    const int b = mm / a.HoWo;
-    const int rem = mm - b * a.HoWo;
-    const int oy = rem / d.Wo;
-    const int ox = rem - oy * d.Wo;
-    return ((long long)b * d.OH + (oy * d.osy + d.ooy)) * d.OW + (ox * d.osx + d.oox);
-}
 
 // ============================================================================================ 256x256 eight-phase kernel
 constexpr int HT_BYTES = 16384;            // one half-tile slot: 128 rows x 128 B
@@ -432,7 +322,8 @@ __global__ __launch_bounds__(256, 2) void conv_h2_tile_kernel(const ConvH2Args a
 {
     constexpr int NW = 4, RB = 128;
     constexpr int RPP = 1024 / RB;  // 8 rows per 1-KiB DMA piece
-    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int WGN = 2, WTM = BM / 2, WTN = BN / 2;  // 2 x 2 wavefronts (a 4 x 1 grid with 256x64 tiles for N = 64 was slower: layer1 90 vs 85 us)
+    constexpr int TM = WTM / 32, TN = WTN / 32;
     constexpr int AG = BM / RPP / NW, BG = BN / RPP / NW;
     constexpr int NDMA = AG + BG;  // LDS-DMA instructions per wave and chunk
     static_assert(TM >= 1 && TN >= 1 && AG >= 1 && BG >= 1, "tile / wave layout");
@@ -504,27 +395,6 @@ __global__ __launch_bounds__(256, 2) void conv_h2_tile_kernel(const ConvH2Args a
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrc, (lds_ptr_t)dst, 16, (int)(w_off[i] + wk), 0, 0, 0);
         }
     };
-    // the same chunk in two parts, for schedules that spread the DMA pieces between the MFMAs: offsets first, then piece by piece
-    unsigned dma_off[NDMA];
-    auto stage_addr = [&](const int tap, const int cc) {
-        const int dy = (int)((a.dy_pack >> (4 * tap)) & 15ull) - 8, dx = (int)((a.dx_pack >> (4 * tap)) & 15ull) - 8;
-        const unsigned toff = (unsigned)((dy * d.W + dx) * (int)px_bytes + cc * RB);
-#pragma unroll
-        for (int i = 0; i < AG; ++i) dma_off[i] = (a_base[i] + toff) | (((a_mask[i] >> tap) & 1u) - 1u);
-        const unsigned wk = (unsigned)tap * (unsigned)d.Cin * 4u + (unsigned)cc * (unsigned)RB;
-#pragma unroll
-        for (int i = 0; i < BG; ++i) dma_off[AG + i] = w_off[i] + wk;
-    };
-    auto stage_piece = [&](auto ic_, const int st) {
-        constexpr int i = decltype(ic_)::value;
-        if constexpr (i < AG) {
-            unsigned char* dst = As + ((st * BM) + (wave + NW * i) * RPP) * RB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_ptr_t)dst, 16, (int)dma_off[i], 0, 0, 0);
-        } else {
-            unsigned char* dst = Bs + ((st * BN) + (wave + NW * (i - AG)) * RPP) * RB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrc, (lds_ptr_t)dst, 16, (int)dma_off[i], 0, 0, 0);
-        }
-    };
     const int nk = a.kper;  // all chunks, or K-slice blockIdx.y (chunk order: channel-chunk major, taps innermost)
     const int kt0 = (int)blockIdx.y * a.kper;
     int ld_cc = kt0 / d.ntaps, ld_tap = kt0 - (kt0 / d.ntaps) * d.ntaps, ld_left = nk - 1;
@@ -537,14 +407,14 @@ __global__ __launch_bounds__(256, 2) void conv_h2_tile_kernel(const ConvH2Args a
         cc += wrap;
     };
 
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
     const int frow = lane & 31;
     const int half = lane >> 5;
 
     auto read_frags = [&](int st, u32x4 (&fa)[TM][4], u32x4 (&fb)[TN][4]) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int R = wm * (BM / 2) + i * 32 + frow;
+            const int R = wm * WTM + i * 32 + frow;
             const int sw = (R >> 1) & 7;
             const unsigned char* q = As + ((st * BM) + R) * RB;
 #pragma unroll
@@ -552,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_tile_kernel(const ConvH2Args a
         }
 #pragma unroll
         for (int jn = 0; jn < TN; ++jn) {
-            const int R = wn * (BN / 2) + jn * 32 + frow;
+            const int R = wn * WTN + jn * 32 + frow;
             const int sw = (R >> 1) & 7;
             const unsigned char* q = Bs + ((st * BN) + R) * RB;
 #pragma unroll
@@ -592,39 +462,17 @@ __global__ __launch_bounds__(256, 2) void conv_h2_tile_kernel(const ConvH2Args a
         __syncthreads();  // stage 0 is re-filled by the first loop step: every wave must have its fragments first
         const int npairs = nk >> 1;
         for (int pr = 0; pr < npairs; ++pr) {
-            if constexpr (SCHED == 0) {
-                stage_chunk(ld_tap, ld_cc, 0);
-                next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
-                read_frags(1, fa1, fb1);
-                mma(fa0, fb0);
-                __syncthreads();
+            stage_chunk(ld_tap, ld_cc, 0);
+            next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
+            read_frags(1, fa1, fb1);
+            mma(fa0, fb0);
+            __syncthreads();
 
-                stage_chunk(ld_tap, ld_cc, 1);
-                next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
-                read_frags(0, fa0, fb0);
-                mma(fa1, fb1);
-                __syncthreads();
-            } else {
-                __builtin_amdgcn_sched_barrier(0);
-                read_frags(1, fa1, fb1);
-                __builtin_amdgcn_sched_barrier(0);
-                stage_chunk(ld_tap, ld_cc, 0);
-                next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(fa0, fb0);
-                __builtin_amdgcn_sched_barrier(0);
-                __syncthreads();
-
-                __builtin_amdgcn_sched_barrier(0);
-                read_frags(0, fa0, fb0);
-                __builtin_amdgcn_sched_barrier(0);
-                stage_chunk(ld_tap, ld_cc, 1);
-                next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(fa1, fb1);
-                __builtin_amdgcn_sched_barrier(0);
-                __syncthreads();
-            }
+            stage_chunk(ld_tap, ld_cc, 1);
+            next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
+            read_frags(0, fa0, fb0);
+            mma(fa1, fb1);
+            __syncthreads();
         }
         if (nk & 1) mma(fa0, fb0);
     } else {
@@ -657,36 +505,6 @@ __global__ __launch_bounds__(256, 2) void conv_h2_tile_kernel(const ConvH2Args a
                 read_frags(stn, fnxt_a, fnxt_b);
                 mma(fcur_a, fcur_b);
                 publish();
-            } else if constexpr (SCHED == 3) {
-                // reads of the next chunk first; then the six partial-product groups of this chunk's MFMAs with the chunk-(+3) DMA pieces
-                // spread between them: a 1-KiB LDS-DMA piece costs its wave ~60 cycles of issue (measured with the probe build:
-                // a block of 6 pieces = 400 cycles, as long as the step's 12 MFMAs), which the matrix pipe covers when it has work queued
-                H2_PAIRS;
-                __builtin_amdgcn_sched_barrier(0);
-                read_frags(stn, fnxt_a, fnxt_b);
-                stage_addr(ld_tap, ld_cc);
-                next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
-                __builtin_amdgcn_sched_barrier(0);
-                auto group = [&](auto prc) {
-                    constexpr int pr = decltype(prc)::value;
-#pragma unroll
-                    for (int i = 0; i < TM; ++i)
-#pragma unroll
-                        for (int jn = 0; jn < TN; ++jn) acc[i][jn] = h2_mfma(fcur_a[i][H2_PA[pr]], fcur_b[jn][H2_PB[pr]], acc[i][jn]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    // pieces [pr * NDMA / 6, (pr + 1) * NDMA / 6)
-                    constexpr int p0 = pr * NDMA / 6, p1 = (pr + 1) * NDMA / 6;
-                    if constexpr (p1 > p0) stage_piece(ic<p0>{}, stf);
-                    if constexpr (p1 > p0 + 1) stage_piece(ic<p0 + 1>{}, stf);
-                    __builtin_amdgcn_sched_barrier(0);
-                };
-                group(ic<0>{});
-                group(ic<1>{});
-                group(ic<2>{});
-                group(ic<3>{});
-                group(ic<4>{});
-                group(ic<5>{});
-                publish();
             } else if constexpr (SCHED == 9) {
 #ifdef RDPN6D_PROBE
                 const unsigned long long t0 = __builtin_readcyclecounter();
@@ -716,21 +534,6 @@ __global__ __launch_bounds__(256, 2) void conv_h2_tile_kernel(const ConvH2Args a
                 pr_sum[3] += t4 - t3;
                 pr_sum[4] += t5 - t4;
 #endif
-            } else {
-                // pinned issue order: the fragment reads of the NEXT chunk go out first, the DMA of chunk +3 next, and this chunk's
-                // MFMAs run behind them - left to itself hipcc sinks the ds_reads to the end of the step, right in front of the
-                // lgkmcnt(0) + barrier, where their whole latency is exposed
-                __builtin_amdgcn_sched_barrier(0);
-                read_frags(stn, fnxt_a, fnxt_b);
-                __builtin_amdgcn_sched_barrier(0);
-                stage_chunk(ld_tap, ld_cc, stf);
-                next_chunk(ld_tap, ld_cc, ld_left, d.ntaps);
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (SCHED == 2) __builtin_amdgcn_s_setprio(1);
-                mma(fcur_a, fcur_b);
-                if constexpr (SCHED == 2) __builtin_amdgcn_s_setprio(0);
-                __builtin_amdgcn_sched_barrier(0);
-                publish();
             }
         };
         for (int pr = 0; pr < npairs; ++pr) {
@@ -750,7 +553,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_tile_kernel(const ConvH2Args a
 
     {
         const int hi = lane >> 5;
-        constexpr int WC = BN / 2, CS = WC + 8, LPR = WC / 8, RPI = 64 / LPR;
+        constexpr int WC = WTN, CS = WC + 8, LPR = WC / 8, RPI = 64 / LPR;
         __syncthreads();
         float* cst = reinterpret_cast<float*>(smem) + wave * (32 * CS);
         const int nb = n0 + wn * WC;
@@ -763,7 +566,7 @@ __global__ __launch_bounds__(256, 2) void conv_h2_tile_kernel(const ConvH2Args a
         }
         const int rrow = lane / LPR, c8 = (lane % LPR) * 8;
         if (ax.partial) {  // split-K: the raw partial tile of this K-slice (rows past M included: the workspace is tile-padded)
-            float* part = ax.partial + ((size_t)blockIdx.y * ax.mpad + (size_t)m0 + wm * (BM / 2)) * d.Npad + nb + c8;
+            float* part = ax.partial + ((size_t)blockIdx.y * ax.mpad + (size_t)m0 + wm * WTM) * d.Npad + nb + c8;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -780,6 +583,29 @@ __global__ __launch_bounds__(256, 2) void conv_h2_tile_kernel(const ConvH2Args a
             }
             return;
         }
+        // every residual record of this lane's rows first (TM * 32 / RPI independent 2 x 16-byte loads in flight during the transposes):
+        // one dependent load per row group cost the workgroup ~9 000 cycles, 8-34 % of its life (profiles/r3_probe_tile_kernel.md)
+        constexpr int NRR = 32 / RPI;
+        f16x8 rh[TM][NRR], rl[TM][NRR];
+        long long pixs[TM][NRR];
+        const bool res_pre = ax.res_h2 != nullptr && d.res == nullptr;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int rr = 0; rr < NRR; ++rr) {
+                const long long mrow = m0 + wm * WTM + i * 32 + rr * RPI + rrow;
+                const bool ok = mrow < a.M && nb + c8 < d.N;
+                pixs[i][rr] = ok ? h2_pixel_of(a, mrow) : -1;
+                if (res_pre && ok) {
+                    const int c = d.res_co + nb + c8;
+                    const _Float16* rp = reinterpret_cast<const _Float16*>(ax.res_h2) + pixs[i][rr] * (2 * d.res_cs) + (c >> 5) * 64 + (c & 31);
+                    rh[i][rr] = *reinterpret_cast<const f16x8*>(rp);
+                    rl[i][rr] = *reinterpret_cast<const f16x8*>(rp + 32);
+                } else {
+                    rh[i][rr] = f16x8{};
+                    rl[i][rr] = f16x8{};
+                }
+            }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -788,14 +614,14 @@ __global__ __launch_bounds__(256, 2) void conv_h2_tile_kernel(const ConvH2Args a
                 for (int e = 0; e < 16; ++e)
                     cst[((e & 3) + 8 * (e >> 2) + 4 * hi) * CS + j * 32 + frow] = acc[i][j][e] * scj[j] + shj[j];
 #pragma unroll
-            for (int rr = 0; rr < 32 / RPI; ++rr) {
+            for (int rr = 0; rr < NRR; ++rr) {
                 const int row = rr * RPI + rrow;
-                const long long mrow = m0 + wm * (BM / 2) + i * 32 + row;
-                if (mrow < a.M && nb + c8 < d.N) {
+                if (pixs[i][rr] >= 0) {
                     const f32x4 lo = *reinterpret_cast<const f32x4*>(cst + row * CS + c8);
                     const f32x4 hi4 = *reinterpret_cast<const f32x4*>(cst + row * CS + c8 + 4);
                     float v[8] = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
-                    h2_finish_row8(ax, v, h2_pixel_of(a, mrow), nb + c8);
+                    if (res_pre) h2_finish_row8_t<true>(ax, v, pixs[i][rr], nb + c8, rh[i][rr], rl[i][rr]);
+                    else h2_finish_row8_t<false>(ax, v, pixs[i][rr], nb + c8, rh[i][rr], rl[i][rr]);
                 }
             }
         }
@@ -858,11 +684,8 @@ int launch_h2_tile_s(const ConvH2Args& ax, hipStream_t s);
 template <int BM, int BN, int NST>
 int launch_h2_tile(const ConvH2Args& ax, hipStream_t s)
 {
-    static const int sched = getenv("RDPN6D_H2_SCHED") ? atoi(getenv("RDPN6D_H2_SCHED")) : 0;  // profiling
-    if (sched == 1) return launch_h2_tile_s<BM, BN, NST, 1>(ax, s);
-    if (sched == 2) return launch_h2_tile_s<BM, BN, NST, 2>(ax, s);
-    if (sched == 3 && NST == 3) return launch_h2_tile_s<BM, BN, NST, 3>(ax, s);
 #ifdef RDPN6D_PROBE
+    static const int sched = getenv("RDPN6D_H2_SCHED") ? atoi(getenv("RDPN6D_H2_SCHED")) : 0;  // 9 = the step cut into timed parts (tools/probe_h2_tile.py)
     if (sched == 9) return launch_h2_tile_s<BM, BN, NST, 9>(ax, s);
 #endif
     return launch_h2_tile_s<BM, BN, NST, 0>(ax, s);
@@ -956,6 +779,28 @@ extern "C" int rdpn6d_split_h2(const float* x, int src_cs, int src_co, int C, vo
     return RDPN6D_OK;
 }
 
+int conv_h2_launch_pp(ConvH2Args& ax, int shape, hipStream_t s);  // conv_igemm_h2_pp.hip
+
+// Does the 8-wave ping-pong kernel (conv_igemm_h2_pp.hip) take this launch, and with which tile (0 = 128x128, 2 = 256x128)?  One
+// workgroup per CU: it wants >= 224 tiles and a K loop long enough to amortise its prologue.  Measured at B = 64 (gpurun_out/r3_h):
+// layer3 65.1 -> 58.3 us (128x128), layer2 65.2 -> 61.8 us (256x128: one round instead of two of 128x128, 67.7 us).  Two forms that
+// were built and dropped: a 256x64 tile for N = 64 (layer1: 95-100 us against the tile kernel's 83) and K cut into 2 / 4 slices for
+// launches with 56 .. 223 tiles (layer4: 70-71 us against 72).  RDPN6D_H2_PP = 0 switches the kernel off (profiling).
+static int h2_pp_plan(const rdpn6d_conv_desc* d, long long M, int* pbm, int* pbn)
+{
+    static const int on = getenv("RDPN6D_H2_PP") ? atoi(getenv("RDPN6D_H2_PP")) : 1;
+    static const int force = getenv("RDPN6D_H2_PP_SHAPE") ? atoi(getenv("RDPN6D_H2_PP_SHAPE")) : -1;  // profiling: 0 | 2
+    if (!on || d->Npad % 128 != 0 || d->ntaps * (d->Cin / 32) < 8) return -1;
+    int shape = 0;
+    if ((long long)rd_cdiv(M, 256) * (d->Npad / 128) >= 224 && (long long)rd_cdiv(M, 128) * (d->Npad / 128) > 288) shape = 2;
+    if (force == 0 || force == 2) shape = force;
+    const int bm = shape == 0 ? 128 : 256;
+    if ((long long)rd_cdiv(M, bm) * (d->Npad / 128) < 224) return -1;
+    *pbm = bm;
+    *pbn = 128;
+    return shape;
+}
+
 // K-slices of the tile kernel for a launch too small to fill the chip (0 = do not split): the largest power of two that keeps
 // tiles * slices <= 512 workgroups with >= 4 whole chunks per slice
 static int h2_tile_ksplit(const rdpn6d_conv_desc* d, long long M, int bm, int bn)
@@ -992,6 +837,7 @@ extern "C" long long rdpn6d_conv_h2_workspace_bytes(const rdpn6d_conv_desc* d)
     if (!d || rdpn6d_conv_h2_kernel_for(d) != 1) return 0;
     const long long M = (long long)d->B * d->Ho * d->Wo;
     int bm, bn;
+    if (h2_pp_plan(d, M, &bm, &bn) >= 0) return 0;
     h2_pick_tile(d, M, &bm, &bn);
     return (long long)h2_tile_ksplit(d, M, bm, bn) * rd_cdiv(M, bm) * bm * d->Npad * 4;
 }
@@ -1050,6 +896,15 @@ extern "C" int rdpn6d_conv2d_h2_ws(const rdpn6d_conv_desc* d, void* y_h2, const 
     hipStream_t s = (hipStream_t)stream;
     if (which == 1) {
         int bm, bn;
+        const int shape = h2_pp_plan(d, a.M, &bm, &bn);
+        if (shape >= 0) {
+            a.mtiles = rd_cdiv(a.M, bm);
+            a.ntiles = d->Npad / bn;
+            const int rc = conv_h2_launch_pp(ax, shape, s);
+            if (rc != RDPN6D_OK) return rc;
+            RD_LAUNCH_CHECK();
+            return RDPN6D_OK;
+        }
         h2_pick_tile(d, a.M, &bm, &bn);
         a.mtiles = rd_cdiv(a.M, bm);
         a.ntiles = d->Npad / bn;

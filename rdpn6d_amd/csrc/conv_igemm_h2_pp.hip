@@ -1,0 +1,311 @@
+// fp32-accurate (h2: two fp16 planes per operand, three partial products - see conv_igemm_h2.hip) implicit-GEMM convolution for the
+// layers that are too narrow / too short for the 256x256 eight-phase kernel: the ResNet trunk (N = 64 .. 512, 4 096 .. 262 144 rows at
+// B = 64).  Round 3: the 2x2-wave tile kernel of conv_igemm_h2.hip runs these layers at MfmaUtil 37-41 %; its probe build
+// (profiles/r3_probe_tile_kernel.md) shows why: a K-chunk step is a SEQUENCE inside each wavefront - fragment reads (~250 cycles until
+// they are back), the chunk's 1-KiB LDS-DMA pieces (~65 cycles of issue EACH, not covered by the wave's own MFMAs: 6 pieces = 410
+// cycles), the 12 MFMAs (400), s_waitcnt + s_barrier (180) - and the second workgroup on the CU overlaps it only by chance.
+//
+// This kernel makes the overlap structural, the way the eight-phase kernel does: ONE workgroup of EIGHT wavefronts per CU in two
+// groups of four (waves i and i + 4 share a SIMD) that run ONE BARRIER APART.  A wavefront alternates
+//     L(k): ds_read the fragments of chunk k (single-buffered) + issue its share of the LDS-DMA pieces of chunk k + D   | s_barrier
+//     M(k): the MFMAs of chunk k (the last PM pieces between them)                                                      | s_barrier
+// and while group 0 is in M(k), group 1 is in L(k) (it executes one extra barrier before the loop, group 0 one after it): every
+// SIMD always has one wave feeding the matrix pipe and one wave issuing reads / DMA.  The DMA runs D = NST - 1 chunks ahead through
+// a ring of NST stages and is never drained inside the loop: counted s_waitcnt vmcnt at the end of both parts (below) guarantee
+// that chunk k + 1 has landed - for BOTH groups' pieces - before the barrier that lets the other group read it.
+//
+// Tile BM x BN on a WM x WN grid of wavefronts (group = upper half of the row blocks), wave tile (BM / WM) x (BN / WN) of 32x32 MFMA
+// tiles; 128-byte h2 rows, XOR-swizzled 16-byte slots and DMA addressing exactly as in the tile kernel.  The epilogue issues every
+// residual load of the wave's tile BEFORE the LDS transposes (the tile kernel's one-dependent-load-per-row-group epilogue cost
+// 9 000 cycles per workgroup, 8-34 % of its life).
+#include "conv_h2_common.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+namespace {
+
+template <int BM, int BN, int WM, int WN, int NST, int PM>
+__global__ __launch_bounds__(512) void conv_h2_pp_kernel(const ConvH2Args ax)
+{
+    constexpr int RB = 128, RPP = 8, NW = 8;
+    constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+    constexpr int AG = BM / RPP / NW, BG = BN / RPP / NW;  // LDS-DMA pieces per wave and chunk
+    constexpr int P = AG + BG, PL = P - PM, D = NST - 1;
+    static_assert(WM * WN == NW && WM == 2 && TM >= 1 && TN >= 1 && AG >= 1 && BG >= 1, "wave grid / tile");
+    static_assert(PM >= 0 && PM <= 2 && PL >= 1 && D >= 2, "pieces in the MFMA part; at least three stages");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    unsigned char* As = smem;
+    unsigned char* Bs = smem + NST * BM * RB;
+
+    const ConvBArgs& a = ax.b;
+    const rdpn6d_conv_desc& d = a.d;
+    const int nblk = a.mtiles * a.ntiles;
+    const int bid = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, kk = bid >> 3;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + kk;
+    const int nt = logical % a.ntiles;
+    const int mt = logical / a.ntiles;
+    const long long m0 = (long long)mt * BM;
+    const int n0 = nt * BN;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wq = wave & 3;
+    const int wm = grp, wn = wq;
+
+    // ---- DMA addressing: this wave moves pieces wave, wave + 8, ... (8 rows x 128 B each) of the A rows and of the B rows of a chunk
+    const int prow = lane >> 3, pslot = lane & 7;
+    const unsigned px_bytes = (unsigned)d.in_cs * 4u;  // an h2 pixel is 2 x in_cs halfs
+    unsigned a_base[AG], a_mask[AG];
+#pragma unroll
+    for (int i = 0; i < AG; ++i) {
+        const int row = (wave + NW * i) * RPP + prow;
+        const long long m = m0 + row;
+        const bool ok = m < a.M;
+        const int mm = ok ? (int)m : 0;
+        const int b = mm / a.HoWo;
+        const int rem = mm - b * a.HoWo;
+        const int oy = rem / d.Wo;
+        const int ox = rem - oy * d.Wo;
+        const int iy = oy * d.stride, ix = ox * d.stride;
+        const int lslot = pslot ^ ((row >> 1) & 7);
+        a_base[i] = (unsigned)((b * d.H + iy) * d.W + ix) * px_bytes + (unsigned)d.in_co * 4u + (unsigned)lslot * 16u;
+        unsigned mask = 0;
+        for (int t = 0; t < d.ntaps; ++t) {
+            const int dy = (int)((a.dy_pack >> (4 * t)) & 15ull) - 8, dx = (int)((a.dx_pack >> (4 * t)) & 15ull) - 8;
+            mask |= (ok && (unsigned)(iy + dy) < (unsigned)d.H && (unsigned)(ix + dx) < (unsigned)d.W) ? (1u << t) : 0u;
+        }
+        a_mask[i] = mask;
+    }
+    unsigned w_off[BG];
+#pragma unroll
+    for (int i = 0; i < BG; ++i) {
+        const int row = (wave + NW * i) * RPP + prow;
+        const int lslot = pslot ^ ((row >> 1) & 7);
+        w_off[i] = (unsigned)(n0 + row) * (unsigned)a.Ktot * 4u + (unsigned)lslot * 16u;
+    }
+    const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.w), 0, a.w_bytes, 0x00020000);
+
+    unsigned dma_off[P];
+    auto stage_addr = [&](const int tap, const int cc, const bool valid) {
+        const int dy = (int)((a.dy_pack >> (4 * tap)) & 15ull) - 8, dx = (int)((a.dx_pack >> (4 * tap)) & 15ull) - 8;
+        const unsigned toff = (unsigned)((dy * d.W + dx) * (int)px_bytes + cc * RB);  // wave-uniform
+        const unsigned sel = valid ? 0u : 0xFFFFFFFFu;                                 // past the last chunk: out of range, zeros land
+#pragma unroll
+        for (int i = 0; i < AG; ++i) dma_off[i] = (a_base[i] + toff) | (((a_mask[i] >> tap) & 1u) - 1u) | sel;
+        const unsigned wk = (unsigned)tap * (unsigned)d.Cin * 4u + (unsigned)cc * (unsigned)RB;
+#pragma unroll
+        for (int i = 0; i < BG; ++i) dma_off[AG + i] = (w_off[i] + wk) | sel;
+    };
+    auto stage_piece = [&](auto ic_, const int st) {
+        constexpr int i = decltype(ic_)::value;
+        if constexpr (i < AG) {
+            unsigned char* dst = As + ((st * BM) + (wave + NW * i) * RPP) * RB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xsrc, (lds_ptr_t)dst, 16, (int)dma_off[i], 0, 0, 0);
+        } else {
+            unsigned char* dst = Bs + ((st * BN) + (wave + NW * (i - AG)) * RPP) * RB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wsrc, (lds_ptr_t)dst, 16, (int)dma_off[i], 0, 0, 0);
+        }
+    };
+    auto stage_pieces = [&](auto firstc, auto lastc, const int st) {  // pieces [first, last)
+        constexpr int first = decltype(firstc)::value, last = decltype(lastc)::value;
+        if constexpr (first + 0 < last) stage_piece(ic<first + 0>{}, st);
+        if constexpr (first + 1 < last) stage_piece(ic<first + 1>{}, st);
+        if constexpr (first + 2 < last) stage_piece(ic<first + 2>{}, st);
+        if constexpr (first + 3 < last) stage_piece(ic<first + 3>{}, st);
+        if constexpr (first + 4 < last) stage_piece(ic<first + 4>{}, st);
+        if constexpr (first + 5 < last) stage_piece(ic<first + 5>{}, st);
+        if constexpr (first + 6 < last) stage_piece(ic<first + 6>{}, st);
+        if constexpr (first + 7 < last) stage_piece(ic<first + 7>{}, st);
+        static_assert(last - first <= 8, "pieces per wave and chunk");
+    };
+
+    const int nk = a.nk;                       // chunk order: channel-chunk major, taps innermost
+    int ld_cc = 0, ld_tap = 0, ld_idx = 0;  // the chunk the DMA stream is at
+    auto next_chunk = [&]() {
+        ++ld_idx;
+        ++ld_tap;
+        const int wrap = ld_tap == d.ntaps ? 1 : 0;
+        ld_tap = wrap ? 0 : ld_tap;
+        ld_cc += wrap;
+    };
+
+    // ---- fragment addressing
+    const int frow = lane & 31;
+    const int half = lane >> 5;
+    u32x4 fa[TM][4], fb[TN][4];
+    auto read_frags = [&](const int st) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int R = wm * WTM + i * 32 + frow;
+            const int sw = (R >> 1) & 7;
+            const unsigned char* q = As + ((st * BM) + R) * RB;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fa[i][j] = *reinterpret_cast<const u32x4*>(q + (((2 * j + half) ^ sw) << 4));
+        }
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) {
+            const int R = wn * WTN + jn * 32 + frow;
+            const int sw = (R >> 1) & 7;
+            const unsigned char* q = Bs + ((st * BN) + R) * RB;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[jn][j] = *reinterpret_cast<const u32x4*>(q + (((2 * j + half) ^ sw) << 4));
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    auto mma_group = [&](auto prc) {
+        constexpr int pr = decltype(prc)::value;
+        H2_PAIRS;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) acc[i][jn] = h2_mfma(fa[i][H2_PA[pr]], fb[jn][H2_PB[pr]], acc[i][jn]);
+    };
+
+    // ---- prologue: chunks 0 .. D-1 into stages 0 .. D-1
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        stage_addr(ld_tap, ld_cc, ld_idx < nk);
+        stage_pieces(ic<0>{}, ic<P>{}, c);
+        next_chunk();
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * P) : "memory");  // chunk 0 has landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();                                        // ... and everybody's
+    asm volatile("" ::: "memory");
+    if (grp == 1) __builtin_amdgcn_s_barrier();  // the second wave group runs one barrier behind from here on
+
+    int st_rd = 0, st_wr = D;  // stage of chunk k, stage of chunk k + D
+    for (int k = 0; k < nk; ++k) {
+        // ---- L(k): fragments of chunk k; this wave's first PL pieces of chunk k + D
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(st_rd);
+        stage_addr(ld_tap, ld_cc, ld_idx < nk);
+        __builtin_amdgcn_sched_barrier(0);
+        stage_pieces(ic<0>{}, ic<PL>{}, st_wr);
+        __builtin_amdgcn_sched_barrier(0);
+        // outstanding and newer than chunk k + 1: chunks k + 2 .. k + D - 1 (P each) + the PL pieces just issued -> chunk k + 1 has
+        // landed; the fragment reads are back (nobody may still be reading a stage the other group is about to re-fill)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((D - 2) * P + PL) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        // ---- M(k): the MFMAs of chunk k, the remaining PM pieces between them
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        mma_group(ic<0>{});
+        mma_group(ic<1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PM >= 1) stage_piece(ic<PL>{}, st_wr);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_group(ic<2>{});
+        mma_group(ic<3>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PM >= 2) stage_piece(ic<PL + 1>{}, st_wr);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_group(ic<4>{});
+        mma_group(ic<5>{});
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        next_chunk();
+        st_rd = st_rd == NST - 1 ? 0 : st_rd + 1;
+        st_wr = st_wr == NST - 1 ? 0 : st_wr + 1;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * P) : "memory");  // newer than chunk k + 1: chunks k + 2 .. k + D
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the out-of-range pieces of the last D steps: nothing may still be landing in LDS)
+    if (grp == 0) __builtin_amdgcn_s_barrier();       // re-align the two groups
+
+    // ---- epilogue
+    {
+        const int hi = lane >> 5;
+        constexpr int CS = WTN + 8, LPR = WTN / 8, RPI = 64 / LPR, NRR = 32 / RPI;
+        const int nb = n0 + wn * WTN;
+        const int rrow = lane / LPR, c8 = (lane % LPR) * 8;
+        const long long mbase = m0 + wm * WTM;
+        // every residual record of this lane's rows first: TM * NRR independent 2 x 16-byte loads in flight during the transposes
+        f16x8 rh[TM][NRR], rl[TM][NRR];
+        long long pixs[TM][NRR];
+        const bool res_pre = ax.res_h2 != nullptr && d.res == nullptr;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int rr = 0; rr < NRR; ++rr) {
+                const long long mrow = mbase + i * 32 + rr * RPI + rrow;
+                const bool ok = mrow < a.M && nb + c8 < d.N;
+                pixs[i][rr] = ok ? h2_pixel_of(a, mrow) : -1;
+                if (res_pre && ok) {
+                    const int c = d.res_co + nb + c8;
+                    const _Float16* rp = reinterpret_cast<const _Float16*>(ax.res_h2) + pixs[i][rr] * (2 * d.res_cs) + (c >> 5) * 64 + (c & 31);
+                    rh[i][rr] = *reinterpret_cast<const f16x8*>(rp);
+                    rl[i][rr] = *reinterpret_cast<const f16x8*>(rp + 32);
+                } else {
+                    rh[i][rr] = f16x8{};
+                    rl[i][rr] = f16x8{};
+                }
+            }
+        __syncthreads();
+        float* cst = reinterpret_cast<float*>(smem) + wave * (32 * CS);
+        float scj[TN], shj[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = nb + j * 32 + frow;
+            scj[j] = d.scale ? d.scale[n] : 1.f;
+            shj[j] = d.shift ? d.shift[n] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    cst[((e & 3) + 8 * (e >> 2) + 4 * hi) * CS + j * 32 + frow] = acc[i][j][e] * scj[j] + shj[j];
+#pragma unroll
+            for (int rr = 0; rr < NRR; ++rr) {
+                const int row = rr * RPI + rrow;
+                if (pixs[i][rr] >= 0) {
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(cst + row * CS + c8);
+                    const f32x4 hi4 = *reinterpret_cast<const f32x4*>(cst + row * CS + c8 + 4);
+                    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+                    if (res_pre) h2_finish_row8_t<true>(ax, v, pixs[i][rr], nb + c8, rh[i][rr], rl[i][rr]);
+                    else h2_finish_row8_t<false>(ax, v, pixs[i][rr], nb + c8, rh[i][rr], rl[i][rr]);
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int NST, int PM>
+int launch_pp(const ConvH2Args& ax, hipStream_t s)
+{
+    constexpr int lds_stage = NST * (BM + BN) * 128;
+    constexpr int lds_epi = 8 * 32 * (BN / WN + 8) * 4;
+    constexpr int lds = lds_stage > lds_epi ? lds_stage : lds_epi;
+    static_assert(lds <= 160 * 1024, "LDS");
+    auto kern = conv_h2_pp_kernel<BM, BN, WM, WN, NST, PM>;
+    RD_LDS_OPT_IN(kern, lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ax.b.mtiles * ax.b.ntiles)), dim3(512), lds, s, ax);
+    return RDPN6D_OK;
+}
+
+}  // namespace
+
+// shape: 0 = 128x128 tile (2 x 4 waves of 64x32, four LDS stages), 2 = 256x128 (2 x 4 waves of 128x32, three stages)
+int conv_h2_launch_pp(ConvH2Args& ax, int shape, hipStream_t s)
+{
+    static const int pm = getenv("RDPN6D_H2_PP_PM") ? atoi(getenv("RDPN6D_H2_PP_PM")) : 2;  // profiling: DMA pieces inside the MFMA part
+    if (shape == 0) return pm == 0 ? launch_pp<128, 128, 2, 4, 4, 0>(ax, s) : pm == 1 ? launch_pp<128, 128, 2, 4, 4, 1>(ax, s) : launch_pp<128, 128, 2, 4, 4, 2>(ax, s);
+    if (shape == 2) return pm == 0 ? launch_pp<256, 128, 2, 4, 3, 0>(ax, s) : pm == 1 ? launch_pp<256, 128, 2, 4, 3, 1>(ax, s) : launch_pp<256, 128, 2, 4, 3, 2>(ax, s);
+    rdpn6d_set_error("conv_h2_launch_pp: unknown tile shape %d", shape);
+    return RDPN6D_EINVAL;
+}

@@ -965,8 +965,8 @@ class TrainEngine:
         if self.accumulate_grad:
             if on_group_done is not None:
                 raise NotImplementedError("accumulate_grad with gradient-bucket hooks: reduce once, after the last micro-batch")
-            flat, grads = self._flat_or_list()
-            prev = flat.clone() if flat is not None else [g.clone() for g in grads]
+            flat, _ = self._flat_or_list()
+            prev = flat.clone() if flat is not None else {id(p): p.grad.clone() for p in self.model.parameters() if p.grad is not None}
         for idx in range(len(self.bwd) - 1, -1, -1):
             for fn in self.bwd[idx]:
                 fn()
@@ -979,12 +979,12 @@ class TrainEngine:
                     raise NotImplementedError("unscale with gradient-bucket hooks: un-scale the flat buffer after buckets.finish()")
                 flat.mul_(1.0 / unscale) if flat is not None else torch._foreach_mul_(grads, 1.0 / unscale)
             if prev is not None:
-                if flat is not None and torch.is_tensor(prev):
+                if torch.is_tensor(prev):  # (the flat buffer of GradBuckets / Ranger: same layout before and after)
                     flat.add_(prev)
-                else:  # (param.grad tensors were created by this very backward: nothing had accumulated for them)
-                    prev_l = [prev] if torch.is_tensor(prev) else prev
-                    if len(prev_l) == len(grads) and all(a.shape == b.shape for a, b in zip(grads, prev_l)):
-                        torch._foreach_add_(grads, prev_l)
+                else:  # (a gradient this backward created had nothing accumulated before)
+                    ps = [p for p in self.model.parameters() if p.grad is not None and id(p) in prev]
+                    if ps:
+                        torch._foreach_add_([p.grad for p in ps], [prev[id(p)] for p in ps])
 
     def forward_backward(self, batch):
         """forward + losses + backward.  With `loss_scale` != 1 (fp16 storage of the activation gradients: the un-scaled seeds

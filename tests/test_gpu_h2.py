@@ -25,6 +25,15 @@ H2_CASES = [
     (1, 8, 512, 512, 3, 1, True, 1),      # layer4 of ONE crop: 64 rows, 144 chunks -> tile kernel with K cut into 16 slices
     (1, 15, 256, 256, 3, 1, False, 2),    # split-K with ragged rows (225), no residual, LeakyReLU
     (1, 16, 128, 256, 3, 2, False, 1),    # stride-2 entry convolution of one crop, split-K
+    # ---- the 8-wave ping-pong kernel (conv_igemm_h2_pp.hip: N % 128 == 0 and >= 224 tiles) and its neighbours
+    (64, 16, 256, 256, 3, 1, True, 1),    # layer3 at B = 64: 256 tiles of 128x128, four LDS stages, h2 residual
+    (64, 32, 128, 128, 3, 1, True, 1),    # layer2 at B = 64: 256 tiles of 256x128
+    (37, 32, 128, 128, 3, 1, True, 2),    # 296 tiles of 128x128, two rounds, the second one ragged
+    (29, 62, 64, 64, 3, 1, True, 1),      # layer1-like, odd size, ragged last tile (111 476 rows): tile kernel (N = 64)
+    (64, 8, 512, 512, 3, 1, True, 1),     # layer4 at B = 64: 128 tiles of 128x128 would not fill the chip -> tile kernel
+    (28, 16, 256, 256, 3, 1, False, 2),   # 112 x 2 = 224 tiles of 128x128: the smallest launch the ping-pong kernel takes
+    (64, 32, 128, 256, 3, 2, False, 1),   # stride-2 entry convolution of layer3 at B = 64
+    (64, 32, 256, 128, 1, 1, False, 0),   # 1x1: 8 chunks, the shortest loop the kernel takes
 ]
 
 

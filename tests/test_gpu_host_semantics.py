@@ -220,7 +220,9 @@ def test_loss_scale_and_micro_batch_accumulation_do_not_compound():
     def two_micro(scale, m):
         e = m.train_engine(2, dev)
         e.accumulate_grad, e.loss_scale = True, scale
-        torch._foreach_zero_([p.grad for p in m.parameters()])  # (in place: the engine's launches hold the gradients' addresses)
+        have = [p.grad for p in m.parameters() if p.grad is not None]
+        if have:
+            torch._foreach_zero_(have)  # (in place: the engine's launches hold the gradients' addresses)
         e.forward_backward(b1)
         e.forward_backward(b2)
         torch.cuda.synchronize()
