@@ -441,8 +441,8 @@ def main():
                        "parallelism": f"replicated weights, {world} independent shard(s), no collective",
                        "launch": "hipGraph replay" if args.graph else "eager",
                        "h2_range_check": args.range_check},
-            # no activation left the fp16 range of the h2 kernels in any step (otherwise the model would have warned and switched to bf16x3)
-            "h2_range_exceeded": bool(model.h2_range_exceeded(device, wait=True)) or model.plan(B, device).fast != ("h2" if (args.dtype == "f32" and args.fast == "h2" and not args.no_x3) else model.plan(B, device).fast),
+            # the fp32-accurate form the plan ended on ("h2" unless an activation left the fp16 range and the model switched to "x3")
+            "fast_path": model.plan(B, device).fast, "h2_range_exceeded": bool(model.h2_range_exceeded(device, wait=True)),
             "achieved_tflops_whole_step": round(44.10e9 * value / 1e12, 2),
             "flops_note": ("44.10 GFLOP per crop = the reference network's multiply-adds" +
                            ("; the h2 plan evaluates the spatially constant (broadcast global max) half of the ConvTranspose input as a "

@@ -108,8 +108,20 @@ __global__ __launch_bounds__(512) void conv_h2_8ph_kernel(const ConvH2Args ax)
     auto addr_A = [&](auto qmc, const int tap, const int cc, const bool valid) {
         constexpr int qm = decltype(qmc)::value;
         const int dy = (int)((a.dy_pack >> (4 * tap)) & 15ull) - 8, dx = (int)((a.dx_pack >> (4 * tap)) & 15ull) - 8;
+#ifdef RDPN6D_PROBE
+        // nsplit = 102: every tap but the first re-reads the tile's first chunk (centre rows, channels 0..31): real, non-zero data from
+        // the CU's own L1 instead of L2 - separates the L2 traffic from the zero-operand effect of mode 101 on the matrix pipe's power
+        const unsigned toff = (ax.nsplit == 102 && tap != 0) ? 0u : (unsigned)((dy * d.W + dx) * (int)px_bytes + cc * 128);
+#else
         const unsigned toff = (unsigned)((dy * d.W + dx) * (int)px_bytes + cc * 128);  // wave-uniform
+#endif
+#ifdef RDPN6D_PROBE
+        // timing-only ablation (wrong results): nsplit = 101 -> the activation half-tiles of every tap but the first read out of range
+        // (the DMA instruction is still issued, no L2 traffic): what a halo-resident patch (A staged once per 32 channels) could save
+        const unsigned sel = (valid && !(ax.nsplit == 101 && tap != 0)) ? 0u : 0xFFFFFFFFu;
+#else
         const unsigned sel = valid ? 0u : 0xFFFFFFFFu;
+#endif
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const unsigned kill = ((a_mask[qm][i] >> tap) & 1u) - 1u;
@@ -936,6 +948,9 @@ extern "C" int rdpn6d_conv2d_h2_ws(const rdpn6d_conv_desc* d, void* y_h2, const 
     a.mtiles = rd_cdiv(a.M, 256);
     a.ntiles = d->Npad / 256;
     RD_LDS_OPT_IN(conv_h2_8ph_kernel, LDS_8PH);
+#ifdef RDPN6D_PROBE
+    if (const char* e = getenv("RDPN6D_H2_ABL_A")) ax.nsplit = 100 + atoi(e);
+#endif
     hipLaunchKernelGGL(conv_h2_8ph_kernel, dim3((unsigned)(a.mtiles * a.ntiles)), dim3(512), LDS_8PH, s, ax);  // (never split: ax.partial stays null)
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;

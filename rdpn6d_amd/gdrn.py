@@ -1040,6 +1040,8 @@ class GDRN(nn.Module):
         warnings.warn(f"rdpn6d_amd: an activation exceeded +-4094, the range of the fp16x2 (h2) convolution format, in {when} (the value "
                       "was clamped, never an inf).  Switching this model to the bf16x3 kernels (cfg.TEST.FP16X2 = False), which have "
                       "the fp32 exponent range.", RuntimeWarning, stacklevel=3)
+        if "TEST" not in self.cfg:  # (a hand-made config without the section: plan() reads it with .get)
+            self.cfg["TEST"] = {}
         self.cfg.TEST.FP16X2 = False
         self.invalidate_plans()
         for ent in self._h2_flags.values():  # (no h2 kernel runs from here on; a model switched back by hand starts clean)

@@ -207,7 +207,7 @@ def _run(model, t):
     with torch.no_grad():
         o = model(t["roi_img"], roi_classes=t["roi_cls"], roi_coord_2d=t["roi_coord_2d"], roi_cams=t["roi_cam"],
                   roi_centers=t["roi_center"], roi_whs=t["roi_wh"], roi_extents=t["roi_extent"],
-                  resize_ratios=t["resize_ratio"], do_loss=False, fps=t["fps"])
+                  resize_ratios=t["resize_ratio"], do_loss=False, fps=t["fps"], im_H=480, im_W=640)  # (synth.IM_H, IM_W: the 2D-3D PnP scales coord2d by them)
     torch.cuda.synchronize()
     return o
 

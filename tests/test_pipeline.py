@@ -43,7 +43,8 @@ def test_frames_to_pose_errors_on_device(golden_dir):
     with torch.no_grad():
         out = model(crops["roi_img"], roi_classes=torch.zeros(B, dtype=torch.long, device=dev), roi_coord_2d=crops["roi_coord_2d"],
                     roi_cams=t_cams, roi_centers=crops["bbox_center"], roi_whs=crops["roi_wh"], roi_extents=torch.from_numpy(extents).to(dev),
-                    resize_ratios=crops["resize_ratio"], do_loss=False, fps=torch.from_numpy(fps).to(dev))
+                    resize_ratios=crops["resize_ratio"], do_loss=False, fps=torch.from_numpy(fps).to(dev),
+                    im_H=img.shape[1], im_W=img.shape[2])  # the frames' own size (the batch's im_H / im_W, engine_utils.py:71)
     torch.cuda.synchronize()
     assert all(out[k].is_cuda for k in ("rot", "trans", "mask", "region", "pnp_pose"))
 
