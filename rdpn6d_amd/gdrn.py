@@ -871,10 +871,15 @@ class InferencePlan:
                   slope=0.1, ksplit=True)
 
     # ---- run
-    def run(self, x, roi_coord_2d, fps, roi_cams, roi_centers, roi_whs, resize_ratios, is_allo=True, train_pose=False, after_glue=None):
+    def run(self, x, roi_coord_2d, fps, roi_cams, roi_centers, roi_whs, resize_ratios, is_allo=True, train_pose=False, after_glue=None,
+            after_h2=None):
         """after_glue: optional callable launched on a SIDE stream right after the glue kernel (it may read out_nchw / argmax / pnp_in,
         the glue's outputs): work that does not depend on ConvPnPNet - the plain RANSAC solve - then overlaps its small launches;
-        the main stream re-joins it before run() returns."""
+        the main stream re-joins it before run() returns.
+        after_h2: optional callable invoked right after the last kernel that can raise the fp16-range flag (the head's output
+        convolution; glue, ConvPnPNet, pose decode and RANSAC are plain fp32) - GDRN.forward queues its flag read there, so the host
+        wait of the "sync" range check ends ~0.3 ms before the step does and the next forward's launches overlap this one's tail.
+        Not called while a hipGraph is being captured (the caller then reads the flag after the replay)."""
         lib = self.lib
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         B = self.B
@@ -882,6 +887,10 @@ class InferencePlan:
         _lib.check(self.xyz_fn(_ptr(x), self.xyz_args[0], x.shape[1], *self.xyz_args[2:], st), "xyz")
         for L in self.launches:
             _lib.check(L.fn(*L.args, st), L.name)
+        self.flag_read_queued = False
+        if after_h2 is not None and not torch.cuda.is_current_stream_capturing():
+            after_h2()
+            self.flag_read_queued = True
         _lib.check(lib.rdpn6d_dense_glue_f32(*self.glue_args(roi_coord_2d, fps), st), "dense_glue")
         side = None
         if after_glue is not None:
@@ -1214,7 +1223,8 @@ class GDRN(nn.Module):
 
             def launch():
                 plan.run(x, roi_coord_2d, fps, roi_cams, roi_centers, roi_whs, resize_ratios, is_allo=is_allo,
-                         after_glue=kabsch_solve if overlap else None)
+                         after_glue=kabsch_solve if overlap else None,
+                         after_h2=(lambda: self._range_flag_fetch(x.device)) if plan.fast == "h2" else None)
                 if overlap:
                     return
                 if use_pnp and not kabsch:
@@ -1256,8 +1266,10 @@ class GDRN(nn.Module):
 
         plan, out = infer()
         if plan.fast == "h2":
-            # after the replayed graph / the eager launches AND the clones above: the flag read below answers for THIS forward
-            self._range_flag_fetch(x.device)
+            # the flag read answers for THIS forward: queued by run() behind the last h2 kernel (eager launches), or here - behind the
+            # replayed graph, or the first, eager run of a graph key, whose run() is not told to queue it
+            if not (getattr(plan, "flag_read_queued", False) and not tcfg.get("HIP_GRAPH", False)):
+                self._range_flag_fetch(x.device)
             if range_check == "sync" and self.h2_range_exceeded(x.device, wait=True):
                 self._leave_h2(x.device, "this forward; the batch is re-run on the bf16x3 kernels")
                 plan, out = infer()
