@@ -50,6 +50,10 @@ constexpr int LDS_8PH = 2 * 4 * HT_BYTES;  // 128 KiB
 __global__ __launch_bounds__(512) void conv_h2_8ph_kernel(const ConvH2Args ax)
 {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+#ifdef RDPN6D_PROBE
+    const unsigned long long pq_start = __builtin_readcyclecounter();
+    const unsigned long long pq_rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const ConvBArgs& a = ax.b;
     const rdpn6d_conv_desc& d = a.d;
     const int nblk = a.mtiles * a.ntiles;
@@ -273,6 +277,9 @@ __global__ __launch_bounds__(512) void conv_h2_8ph_kernel(const ConvH2Args ax)
         asm volatile("" ::: "memory");
     };
 
+#ifdef RDPN6D_PROBE
+    const unsigned long long pq_loop0 = __builtin_readcyclecounter();
+#endif
     for (int t = 0; t < nk; t += 2) {
         phase(ic<0>{}, ic<0>{}, t);
         phase(ic<1>{}, ic<0>{}, t);
@@ -283,6 +290,9 @@ __global__ __launch_bounds__(512) void conv_h2_8ph_kernel(const ConvH2Args ax)
         phase(ic<2>{}, ic<1>{}, t + 1);
         phase(ic<3>{}, ic<1>{}, t + 1);
     }
+#ifdef RDPN6D_PROBE
+    const unsigned long long pq_loop1 = __builtin_readcyclecounter();
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (wr == 0) __builtin_amdgcn_s_barrier();  // re-align the two groups
 
@@ -320,6 +330,23 @@ __global__ __launch_bounds__(512) void conv_h2_8ph_kernel(const ConvH2Args ax)
             }
         }
     }
+#ifdef RDPN6D_PROBE
+    {
+        const unsigned long long t_issued = __builtin_readcyclecounter();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t_done = __builtin_readcyclecounter();
+        if (g_h2_probe && lane == 0) {
+            unsigned long long* o = g_h2_probe + ((size_t)blockIdx.x * 8 + wave) * 8;
+            o[0] = pq_loop0 - pq_start;   // set-up + prologue
+            o[1] = pq_loop1 - pq_loop0;   // K loop
+            o[2] = t_issued - pq_loop1;   // epilogue until the last store is issued
+            o[3] = t_done - t_issued;     // ... until the stores are done
+            o[4] = pq_rt0;                // start on the 100 MHz clock
+            o[5] = __builtin_amdgcn_s_memrealtime();
+            o[6] = (unsigned long long)nk;
+        }
+    }
+#endif
 }
 
 // ============================================================================================ 128x128 .. 64x64 tile kernel
@@ -441,6 +468,41 @@ __global__ __launch_bounds__(256, 2) void conv_h2_tile_kernel(const ConvH2Args a
             for (int j = 0; j < 4; ++j) fb[jn][j] = *reinterpret_cast<const u32x4*>(q + (((2 * j + half) ^ sw) << 4));
         }
     };
+
+    // ---- epilogue operands, requested FIRST (the oldest entries of the vmcnt queue: the first wait of the K loop covers them): the h2
+    // residual records of this lane's output rows and the folded BatchNorm scale / shift of its channels.  Requested in the epilogue -
+    // which every workgroup of a one-round launch reaches at the same time - they were 4 000 - 9 000 cycles of exposed HBM latency per
+    // workgroup (probe builds: tools/probe_h2_tile.py, tools/probe_h2_pp.py)
+    constexpr int WC = WTN, CS = WC + 8, LPR = WC / 8, RPI = 64 / LPR, NRR = 32 / RPI;
+    const int nb = n0 + wn * WC;
+    const int rrow = lane / LPR, c8 = (lane % LPR) * 8;
+    f16x8 rh[TM][NRR], rl[TM][NRR];
+    long long pixs[TM][NRR];
+    const bool res_pre = ax.res_h2 != nullptr && d.res == nullptr && ax.partial == nullptr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int rr = 0; rr < NRR; ++rr) {
+            const long long mrow = m0 + wm * WTM + i * 32 + rr * RPI + rrow;
+            const bool ok = mrow < a.M && nb + c8 < d.N;
+            pixs[i][rr] = ok ? h2_pixel_of(a, mrow) : -1;
+            if (res_pre && ok) {
+                const int c = d.res_co + nb + c8;
+                const _Float16* rp = reinterpret_cast<const _Float16*>(ax.res_h2) + pixs[i][rr] * (2 * d.res_cs) + (c >> 5) * 64 + (c & 31);
+                rh[i][rr] = *reinterpret_cast<const f16x8*>(rp);
+                rl[i][rr] = *reinterpret_cast<const f16x8*>(rp + 32);
+            } else {
+                rh[i][rr] = f16x8{};
+                rl[i][rr] = f16x8{};
+            }
+        }
+    float scj[TN], shj[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = nb + j * 32 + frow;
+        scj[j] = (d.scale && !ax.partial) ? d.scale[n] : 1.f;
+        shj[j] = (d.shift && !ax.partial) ? d.shift[n] : 0.f;
+    }
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -565,18 +627,12 @@ __global__ __launch_bounds__(256, 2) void conv_h2_tile_kernel(const ConvH2Args a
 
     {
         const int hi = lane >> 5;
-        constexpr int WC = WTN, CS = WC + 8, LPR = WC / 8, RPI = 64 / LPR;
-        __syncthreads();
+        // every wave is past its last fragment read; nothing may still be landing in LDS - then a bare barrier (not __syncthreads(), whose
+        // fence would wait for every outstanding global access as well)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         float* cst = reinterpret_cast<float*>(smem) + wave * (32 * CS);
-        const int nb = n0 + wn * WC;
-        float scj[TN], shj[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = nb + j * 32 + frow;
-            scj[j] = d.scale ? d.scale[n] : 1.f;
-            shj[j] = d.shift ? d.shift[n] : 0.f;
-        }
-        const int rrow = lane / LPR, c8 = (lane % LPR) * 8;
         if (ax.partial) {  // split-K: the raw partial tile of this K-slice (rows past M included: the workspace is tile-padded)
             float* part = ax.partial + ((size_t)blockIdx.y * ax.mpad + (size_t)m0 + wm * WTM) * d.Npad + nb + c8;
 #pragma unroll
@@ -595,29 +651,6 @@ __global__ __launch_bounds__(256, 2) void conv_h2_tile_kernel(const ConvH2Args a
             }
             return;
         }
-        // every residual record of this lane's rows first (TM * 32 / RPI independent 2 x 16-byte loads in flight during the transposes):
-        // one dependent load per row group cost the workgroup ~9 000 cycles, 8-34 % of its life (profiles/r3_probe_tile_kernel.md)
-        constexpr int NRR = 32 / RPI;
-        f16x8 rh[TM][NRR], rl[TM][NRR];
-        long long pixs[TM][NRR];
-        const bool res_pre = ax.res_h2 != nullptr && d.res == nullptr;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int rr = 0; rr < NRR; ++rr) {
-                const long long mrow = m0 + wm * WTM + i * 32 + rr * RPI + rrow;
-                const bool ok = mrow < a.M && nb + c8 < d.N;
-                pixs[i][rr] = ok ? h2_pixel_of(a, mrow) : -1;
-                if (res_pre && ok) {
-                    const int c = d.res_co + nb + c8;
-                    const _Float16* rp = reinterpret_cast<const _Float16*>(ax.res_h2) + pixs[i][rr] * (2 * d.res_cs) + (c >> 5) * 64 + (c & 31);
-                    rh[i][rr] = *reinterpret_cast<const f16x8*>(rp);
-                    rl[i][rr] = *reinterpret_cast<const f16x8*>(rp + 32);
-                } else {
-                    rh[i][rr] = f16x8{};
-                    rl[i][rr] = f16x8{};
-                }
-            }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll

@@ -23,6 +23,21 @@
 #include <cstdio>
 #include <cstdlib>
 
+#ifdef RDPN6D_PROBE
+// probe build only (tools/probe_h2_tile.py): per-wave cycle sums of the parts of a ping-pong step
+__device__ unsigned long long* g_h2pp_probe = nullptr;
+extern "C" int rdpn6d_debug_h2pp_probe(void* buf)
+{
+    RD_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_h2pp_probe), &buf, sizeof(buf)));
+    return RDPN6D_OK;
+}
+#define PP_T(i) const unsigned long long pt##i = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0)
+#define PP_ACC(j, a, b) pp_sum[j] += pt##b - pt##a
+#else
+#define PP_T(i)
+#define PP_ACC(j, a, b)
+#endif
+
 namespace {
 
 template <int BM, int BN, int WM, int WN, int NST, int PM>
@@ -37,6 +52,10 @@ __global__ __launch_bounds__(512) void conv_h2_pp_kernel(const ConvH2Args ax)
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     unsigned char* As = smem;
     unsigned char* Bs = smem + NST * BM * RB;
+#ifdef RDPN6D_PROBE
+    const unsigned long long pp_start = __builtin_readcyclecounter();
+    unsigned long long pp_e[6] = {0, 0, 0, 0, 0, 0};
+#endif
 
     const ConvBArgs& a = ax.b;
     const rdpn6d_conv_desc& d = a.d;
@@ -123,6 +142,43 @@ __global__ __launch_bounds__(512) void conv_h2_pp_kernel(const ConvH2Args ax)
         static_assert(last - first <= 8, "pieces per wave and chunk");
     };
 
+    // ---- epilogue operands, requested FIRST (they are the oldest entries of the vmcnt queue, so the prologue's wait for chunk 0 covers
+    // them): the h2 residual records of this lane's output rows (TM * NRR independent 2 x 16-byte loads) and the folded BatchNorm
+    // scale / shift of its channels.  Requested in the epilogue they cost the workgroup 4 000 - 9 000 cycles of exposed HBM latency
+    // (probe build, tools/probe_h2_pp.py: every workgroup of the launch reaches its epilogue at the same time).
+    constexpr int CS = WTN + 8, LPR = WTN / 8, RPI = 64 / LPR, NRR = 32 / RPI;
+    const int frow = lane & 31;
+    const int nb = n0 + wn * WTN;
+    const int rrow = lane / LPR, c8 = (lane % LPR) * 8;
+    const long long mbase = m0 + wm * WTM;
+    f16x8 rh[TM][NRR], rl[TM][NRR];
+    long long pixs[TM][NRR];
+    const bool res_pre = ax.res_h2 != nullptr && d.res == nullptr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int rr = 0; rr < NRR; ++rr) {
+            const long long mrow = mbase + i * 32 + rr * RPI + rrow;
+            const bool ok = mrow < a.M && nb + c8 < d.N;
+            pixs[i][rr] = ok ? h2_pixel_of(a, mrow) : -1;
+            if (res_pre && ok) {
+                const int c = d.res_co + nb + c8;
+                const _Float16* rp = reinterpret_cast<const _Float16*>(ax.res_h2) + pixs[i][rr] * (2 * d.res_cs) + (c >> 5) * 64 + (c & 31);
+                rh[i][rr] = *reinterpret_cast<const f16x8*>(rp);
+                rl[i][rr] = *reinterpret_cast<const f16x8*>(rp + 32);
+            } else {
+                rh[i][rr] = f16x8{};
+                rl[i][rr] = f16x8{};
+            }
+        }
+    float scj[TN], shj[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = nb + j * 32 + frow;
+        scj[j] = d.scale ? d.scale[n] : 1.f;
+        shj[j] = d.shift ? d.shift[n] : 0.f;
+    }
+
     const int nk = a.nk;                       // chunk order: channel-chunk major, taps innermost
     int ld_cc = 0, ld_tap = 0, ld_idx = 0;  // the chunk the DMA stream is at
     auto next_chunk = [&]() {
@@ -134,7 +190,6 @@ __global__ __launch_bounds__(512) void conv_h2_pp_kernel(const ConvH2Args ax)
     };
 
     // ---- fragment addressing
-    const int frow = lane & 31;
     const int half = lane >> 5;
     u32x4 fa[TM][4], fb[TN][4];
     auto read_frags = [&](const int st) {
@@ -186,21 +241,29 @@ __global__ __launch_bounds__(512) void conv_h2_pp_kernel(const ConvH2Args ax)
     if (grp == 1) __builtin_amdgcn_s_barrier();  // the second wave group runs one barrier behind from here on
 
     int st_rd = 0, st_wr = D;  // stage of chunk k, stage of chunk k + D
+#ifdef RDPN6D_PROBE
+    unsigned long long pp_sum[6] = {0, 0, 0, 0, 0, 0};
+    const unsigned long long pp_t0 = __builtin_readcyclecounter();
+#endif
     for (int k = 0; k < nk; ++k) {
         // ---- L(k): fragments of chunk k; this wave's first PL pieces of chunk k + D
         __builtin_amdgcn_sched_barrier(0);
+        PP_T(0);
         read_frags(st_rd);
         stage_addr(ld_tap, ld_cc, ld_idx < nk);
         __builtin_amdgcn_sched_barrier(0);
         stage_pieces(ic<0>{}, ic<PL>{}, st_wr);
         __builtin_amdgcn_sched_barrier(0);
+        PP_T(1);
         // outstanding and newer than chunk k + 1: chunks k + 2 .. k + D - 1 (P each) + the PL pieces just issued -> chunk k + 1 has
         // landed; the fragment reads are back (nobody may still be reading a stage the other group is about to re-fill)
         asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((D - 2) * P + PL) : "memory");
+        PP_T(2);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         // ---- M(k): the MFMAs of chunk k, the remaining PM pieces between them
         __builtin_amdgcn_sched_barrier(0);
+        PP_T(3);
         __builtin_amdgcn_s_setprio(1);
         mma_group(ic<0>{});
         mma_group(ic<1>{});
@@ -216,53 +279,42 @@ __global__ __launch_bounds__(512) void conv_h2_pp_kernel(const ConvH2Args ax)
         mma_group(ic<5>{});
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
+        PP_T(4);
         next_chunk();
         st_rd = st_rd == NST - 1 ? 0 : st_rd + 1;
         st_wr = st_wr == NST - 1 ? 0 : st_wr + 1;
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * P) : "memory");  // newer than chunk k + 1: chunks k + 2 .. k + D
+        PP_T(5);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        PP_T(6);
+        PP_ACC(0, 0, 1);  // reads + addresses + PL pieces issued
+        PP_ACC(1, 1, 2);  // s_waitcnt vmcnt + lgkmcnt
+        PP_ACC(2, 2, 3);  // barrier after L
+        PP_ACC(3, 3, 4);  // MFMAs + PM pieces
+        PP_ACC(4, 4, 5);  // s_waitcnt vmcnt
+        PP_ACC(5, 5, 6);  // barrier after M
     }
+#ifdef RDPN6D_PROBE
+    const unsigned long long pp_loop_end = __builtin_readcyclecounter();
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the out-of-range pieces of the last D steps: nothing may still be landing in LDS)
     if (grp == 0) __builtin_amdgcn_s_barrier();       // re-align the two groups
+#ifdef RDPN6D_PROBE
+    pp_e[0] = __builtin_readcyclecounter();
+#endif
 
     // ---- epilogue
     {
         const int hi = lane >> 5;
-        constexpr int CS = WTN + 8, LPR = WTN / 8, RPI = 64 / LPR, NRR = 32 / RPI;
-        const int nb = n0 + wn * WTN;
-        const int rrow = lane / LPR, c8 = (lane % LPR) * 8;
-        const long long mbase = m0 + wm * WTM;
-        // every residual record of this lane's rows first: TM * NRR independent 2 x 16-byte loads in flight during the transposes
-        f16x8 rh[TM][NRR], rl[TM][NRR];
-        long long pixs[TM][NRR];
-        const bool res_pre = ax.res_h2 != nullptr && d.res == nullptr;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int rr = 0; rr < NRR; ++rr) {
-                const long long mrow = mbase + i * 32 + rr * RPI + rrow;
-                const bool ok = mrow < a.M && nb + c8 < d.N;
-                pixs[i][rr] = ok ? h2_pixel_of(a, mrow) : -1;
-                if (res_pre && ok) {
-                    const int c = d.res_co + nb + c8;
-                    const _Float16* rp = reinterpret_cast<const _Float16*>(ax.res_h2) + pixs[i][rr] * (2 * d.res_cs) + (c >> 5) * 64 + (c & 31);
-                    rh[i][rr] = *reinterpret_cast<const f16x8*>(rp);
-                    rl[i][rr] = *reinterpret_cast<const f16x8*>(rp + 32);
-                } else {
-                    rh[i][rr] = f16x8{};
-                    rl[i][rr] = f16x8{};
-                }
-            }
-        __syncthreads();
+        // every wave is past its last fragment read (lgkmcnt(0) in its last L part) and no DMA is in flight (vmcnt(0) above): a bare
+        // barrier, not __syncthreads() - whose fence would also wait for anything a kernel variant still has in flight to global memory
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#ifdef RDPN6D_PROBE
+        pp_e[1] = __builtin_readcyclecounter();
+#endif
         float* cst = reinterpret_cast<float*>(smem) + wave * (32 * CS);
-        float scj[TN], shj[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = nb + j * 32 + frow;
-            scj[j] = d.scale ? d.scale[n] : 1.f;
-            shj[j] = d.shift ? d.shift[n] : 0.f;
-        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -283,6 +335,22 @@ __global__ __launch_bounds__(512) void conv_h2_pp_kernel(const ConvH2Args ax)
             }
         }
     }
+#ifdef RDPN6D_PROBE
+    pp_e[2] = __builtin_readcyclecounter();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    pp_e[3] = __builtin_readcyclecounter();
+    if (g_h2pp_probe && lane == 0) {
+        unsigned long long* o = g_h2pp_probe + ((size_t)blockIdx.x * 8 + wave) * 16;
+        for (int i = 0; i < 6; ++i) o[i] = pp_sum[i];
+        o[6] = pp_loop_end - pp_t0;
+        o[7] = (unsigned long long)nk;
+        o[8] = pp_t0 - pp_start;        // set-up + prologue (first chunks landed, first barrier)
+        o[9] = pp_e[0] - pp_loop_end;   // drain + re-align
+        o[10] = pp_e[1] - pp_e[0];      // residual loads issued + __syncthreads
+        o[11] = pp_e[2] - pp_e[1];      // scale / shift, transposes, finish, stores issued
+        o[12] = pp_e[3] - pp_e[2];      // stores done
+    }
+#endif
 }
 
 template <int BM, int BN, int WM, int WN, int NST, int PM>
