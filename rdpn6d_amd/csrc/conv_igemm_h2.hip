@@ -765,13 +765,10 @@ __global__ void split_h2_kernel(const float* __restrict__ x, int src_cs, int src
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(sp), v1 = *reinterpret_cast<const f32x4*>(sp + 4);
         const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         f16x8 hi, lo;
+        float sv[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            _Float16 h, l;
-            over |= h2_split(v[q] * H2_SCALE, h, l);
-            hi[q] = h;
-            lo[q] = l;
-        }
+        for (int q = 0; q < 8; ++q) sv[q] = v[q] * H2_SCALE;
+        over |= h2_split8(sv, hi, lo);
         _Float16* pp = dst + p * (2 * (long long)C) + (c >> 5) * 64 + (c & 31);
         *reinterpret_cast<f16x8*>(pp) = hi;
         *reinterpret_cast<f16x8*>(pp + 32) = lo;
