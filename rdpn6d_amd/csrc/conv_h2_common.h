@@ -2,6 +2,7 @@
 // tile kernel) and conv_igemm_h2_pp.hip (8-wave ping-pong tile kernel).  Format, range and error analysis: header of conv_igemm_h2.hip.
 #pragma once
 #include "conv_bf16_common.h"
+#include "h2_format.h"
 
 #include <type_traits>
 
@@ -39,26 +40,8 @@ __device__ __forceinline__ bool h2_split(float s, _Float16& hi, _Float16& lo)
     lo = (_Float16)(s - (float)hi);
     return over;
 }
-// eight values at once (the epilogues' unit).  The range check is ONE unsigned compare of the largest |bits| (|s| > 65504, inf and NaN all
-// order above 0x477fe000) instead of a float compare + mask arithmetic per element: the split is the epilogues' VALU load (probe:
-// 19 300 cycles of epilogue per 256x256 tile of the eight-phase kernel)
-__device__ __forceinline__ bool h2_split8(const float (&s)[8], f16x8& hi, f16x8& lo)
-{
-    unsigned m = 0;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const unsigned u = __float_as_uint(s[q]) & 0x7fffffffu;
-        m = u > m ? u : m;
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const float c = fminf(fmaxf(s[q], -H2_MAX), H2_MAX);
-        const _Float16 h = (_Float16)c;
-        hi[q] = h;
-        lo[q] = (_Float16)(c - (float)h);
-    }
-    return m > 0x477fe000u;  // bits of 65504.f
-}
+// eight values at once (the epilogues' unit): h2_format.h
+__device__ __forceinline__ bool h2_split8(const float (&s)[8], f16x8& hi, f16x8& lo) { return rd_h2_split8(s, hi, lo); }
 
 // Tail of the h2 epilogues for 8 consecutive channels [ch, ch+8) of output pixel `pix`: v = scale*acc + shift on entry;
 // residual (fp32 tensor or h2 record), activation, fp32 store and / or the h2 record of the result.

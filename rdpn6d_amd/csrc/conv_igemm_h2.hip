@@ -184,6 +184,16 @@ __global__ __launch_bounds__(512) void conv_h2_8ph_kernel(const ConvH2Args ax)
             fb[j] = *reinterpret_cast<const u32x4*>(slot + fb_base + ((((unsigned)(2 * j + half)) ^ fb_sw) << 4));
     };
 
+    // folded BatchNorm scale / shift of this lane's two channels, requested before the K loop (in the epilogue their L2 round trip was exposed)
+    const int nb = n0 + wc * 64;
+    float scj[2], shj[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = nb + j * 32 + frow;
+        scj[j] = d.scale ? d.scale[n] : 1.f;
+        shj[j] = d.shift ? d.shift[n] : 0.f;
+    }
+
     f32x16 acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -300,16 +310,10 @@ __global__ __launch_bounds__(512) void conv_h2_8ph_kernel(const ConvH2Args ax)
     {
         const int hi = lane >> 5;
         constexpr int CS = 64 + 8;
-        __syncthreads();
+        // (every wave is past its last fragment read, no DMA is in flight: a bare barrier; __syncthreads() would add a fence)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         float* cst = reinterpret_cast<float*>(smem) + wave * (32 * CS);
-        const int nb = n0 + wc * 64;
-        float scj[2], shj[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int n = nb + j * 32 + frow;
-            scj[j] = d.scale ? d.scale[n] : 1.f;
-            shj[j] = d.shift ? d.shift[n] : 0.f;
-        }
         const int rrow = lane >> 3, c8 = (lane & 7) * 8;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {

@@ -5,6 +5,7 @@
 //   xyz_subsample_h2       nearest 1/step subsample of the crop's depth-xyz channels into one 32-channel group [x y z 0 ...]
 //   global_max_concat_h2   max over the pixels of channels [0,C), broadcast into channels [C,2C) (:51-52)
 #include "common.h"
+#include "h2_format.h"
 #include <float.h>
 
 namespace {
@@ -52,15 +53,14 @@ __global__ void upsample_bilinear_h2_kernel(const _Float16* __restrict__ x, int 
             for (int e = 0; e < 8; ++e) v[k][e] = ((float)h[e] + (float)l[e]) * H2_INV_SCALE;
         }
         f16x8 oh, ol;
+        float os[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float o = hy * (hx * v[0][e] + lx * v[1][e]) + ly * (hx * v[2][e] + lx * v[3][e]);  // as upsample_bilinear_kernel
             if (relu) o = fmaxf(o, 0.f);
-            _Float16 h, l;
-            over |= h2_split1(o * H2_SCALE, h, l);
-            oh[e] = h;
-            ol[e] = l;
+            os[e] = o * H2_SCALE;
         }
+        over |= rd_h2_split8(os, oh, ol);
         _Float16* dp = y + h2_off(((long long)b * Ho + oy) * Wo + ox, out_cs, out_co + c);
         *reinterpret_cast<f16x8*>(dp) = oh;
         *reinterpret_cast<f16x8*>(dp + 32) = ol;
@@ -456,12 +456,8 @@ __global__ __launch_bounds__(256, 2) void stem_pool_h2_kernel(const float* __res
                     }
                 f16x8 hi, lo;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    _Float16 h, l;
-                    over |= h2_split1(m8[e] * H2_SCALE, h, l);
-                    hi[e] = h;
-                    lo[e] = l;
-                }
+                for (int e = 0; e < 8; ++e) m8[e] *= H2_SCALE;
+                over |= rd_h2_split8(m8, hi, lo);
                 _Float16* dp = y + h2_off(((long long)b * Rp + py) * Rp + px, 64, q * 16 + c8);
                 *reinterpret_cast<f16x8*>(dp) = hi;
                 *reinterpret_cast<f16x8*>(dp + 32) = lo;

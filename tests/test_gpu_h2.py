@@ -130,6 +130,35 @@ def test_conv_h2_error_bound_under_cancellation():
         assert y64.abs().max().item() < 1e-2 * bound.max().item() * 2 ** 24
 
 
+def test_split_h2_is_the_exact_two_term_split():
+    """csrc/h2_format.h writes the fp32 -> (hi, lo) split instruction by instruction (v_cvt_pk_f16_f32 for hi, v_fma_mixlo/hi_f16 for
+    lo = fp16(s - hi) in one instruction, one unsigned compare for the range check): it must be BIT-identical to the plain definition
+    hi = fp16(s), lo = fp16(s - fp32(hi)), s = clamp(16 x), on values from fp16-subnormal lo terms to the top of the range, and the
+    flag must fire exactly for |16 x| > 65504, inf and NaN."""
+    from rdpn6d_amd import ops
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    mags = torch.tensor([1e-9, 1e-7, 3e-6, 1e-4, 0.01, 0.3, 1.0, 17.0, 333.0, 600.0])  # (|randn| < 6: all inside +-4094)
+    x = torch.randn(4096, 64, generator=g) * mags[torch.randint(0, 10, (4096, 64), generator=g)]
+    x[0, :8] = torch.tensor([0.0, -0.0, 4094.0, -4094.0, 2.0 ** -24, 65504.0 / 16, 1.0 + 2.0 ** -11, -(1.0 + 2.0 ** -12)])
+    h2, flag = ops.split_h2(x.to(dev))
+    torch.cuda.synchronize()
+    s = (x * 16.0).clamp(-65504.0, 65504.0)
+    hi = s.half()
+    lo = (s - hi.float()).half()
+    got = h2.cpu().reshape(4096, 2, 2, 32)  # [pixel][group of 32 channels][hi | lo][32]
+    assert torch.equal(got[:, :, 0].reshape(4096, 64).view(torch.int16), hi.view(torch.int16))
+    assert torch.equal(got[:, :, 1].reshape(4096, 64).view(torch.int16), lo.view(torch.int16))
+    assert int(flag.item()) == 0
+    assert (lo != 0).float().mean().item() > 0.5 and ((lo.float().abs() < 6.2e-5) & (lo != 0)).any()  # subnormal lo terms are in the sample
+    for bad, want in ((4094.001, 1), (-1e9, 1), (float("inf"), 1), (float("nan"), 1), (4093.9, 0)):
+        y = x.clone()
+        y[7, 3] = bad
+        _, f = ops.split_h2(y.to(dev))
+        assert int(f.item()) == want, bad
+
+
 def test_h2_range_is_guarded_not_silent():
     """an activation beyond the fp16 range of the h2 format (|a| * 16 > 65504) is clamped and REPORTED, never an inf"""
     from rdpn6d_amd import ops
