@@ -828,7 +828,7 @@ extern "C" int rdpn6d_split_h2(const float* x, int src_cs, int src_co, int C, vo
 int conv_h2_launch_pp(ConvH2Args& ax, int shape, hipStream_t s);  // conv_igemm_h2_pp.hip
 
 // Does the 8-wave ping-pong kernel (conv_igemm_h2_pp.hip) take this launch, and with which tile (0 = 128x128, 2 = 256x128)?  One
-// workgroup per CU: it wants >= 224 tiles and a K loop long enough to amortise its prologue.  Measured at B = 64 (gpurun_out/r3_h):
+// workgroup per CU: it wants >= 224 tiles and a K loop long enough to amortise its prologue.  Measured at B = 64 (profiles/r3_logs/r3_h_conv.log):
 // layer3 65.1 -> 58.3 us (128x128), layer2 65.2 -> 61.8 us (256x128: one round instead of two of 128x128, 67.7 us).  Two forms that
 // were built and dropped: a 256x64 tile for N = 64 (layer1: 95-100 us against the tile kernel's 83) and K cut into 2 / 4 slices for
 // launches with 56 .. 223 tiles (layer4: 70-71 us against 72).  RDPN6D_H2_PP = 0 switches the kernel off (profiling).
