@@ -1014,9 +1014,17 @@ class GDRN(nn.Module):
         self._h2_flags = {}  # device -> (device int32 flag written by the h2 kernels, pinned host copy, [event of the last copy])
 
     # ---- range guard of the two-plane fp16 ("h2") format, DESIGN.md section 2
+    @staticmethod
+    def _dev_key(device):
+        """'cuda' and 'cuda:0' (current device 0) are the same GPU: one flag, one key"""
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        return str(device)
+
     def h2_range_flag(self, device):
         """the device flag every h2 kernel of this model's plans on `device` sets when it had to clamp an activation"""
-        key = str(device)
+        key = self._dev_key(device)
         if key not in self._h2_flags:
             self._h2_flags[key] = [torch.zeros(1, dtype=torch.int32, device=device), torch.zeros(1, dtype=torch.int32).pin_memory(), None]
         return self._h2_flags[key][0]
@@ -1024,7 +1032,7 @@ class GDRN(nn.Module):
     def _range_flag_fetch(self, device):
         """queue flag -> pinned host memory behind the forward just issued (outside any hipGraph: a replayed graph is followed by
         this copy like an eager run) and record an event; nothing waits here"""
-        ent = self._h2_flags.get(str(device))
+        ent = self._h2_flags.get(self._dev_key(device))
         if ent is None:
             return
         ent[1].copy_(ent[0], non_blocking=True)
@@ -1036,7 +1044,7 @@ class GDRN(nn.Module):
         (wait=True: in any forward issued so far)?  The flag is sticky until the model has switched to the bf16x3 kernels."""
         hit = False
         for key, ent in self._h2_flags.items():
-            if (device is not None and key != str(device)) or ent[2] is None:
+            if (device is not None and key != self._dev_key(device)) or ent[2] is None:
                 continue
             if wait:
                 ent[2].synchronize()

@@ -196,3 +196,41 @@ def test_lr_schedule_none_and_step_when_annealing_starts_at_the_end():
     for method, kw in (("none", dict(anneal_point=1.0)), ("step", dict(steps=(1.0,)))):
         f = flat_and_anneal_lr_scheduler(opt, 100, anneal_method=method, **kw).lr_lambdas[0]
         assert f(100) in (1, 1.0, 0.1) and f(50) == 1
+
+
+def test_image_sizes_of_the_2d3d_pnp_and_per_model_weight_epochs():
+    """host logic of round 3 that needs no GPU: (a) the per-crop [H, W] table of the 2D-3D PnP (gdrn_evaluator.py:346-347: the batch's
+    im_H / im_W) from scalars, lists or tensors, cfg.TEST.IM_H / IM_W only when BOTH are set, an error otherwise - never a silent
+    480 x 640; (b) raw-pointer writers bump the epoch of the models that own the tensors they wrote, not every model's."""
+    import torch
+
+    from rdpn6d_amd import gdrn
+    from rdpn6d_amd.config import ConfigDict, gdrn_base_cfg
+    from rdpn6d_amd.gdrn import GDRN, build_model_optimizer
+
+    dev = torch.device("cpu")
+    hw = GDRN._image_sizes(480, 640, 3, dev, ConfigDict())
+    assert hw.dtype == torch.int32 and hw.tolist() == [[480, 640]] * 3
+    hw = GDRN._image_sizes(torch.tensor([480.0, 540.0]), [640, 720], 2, dev, ConfigDict())
+    assert hw.tolist() == [[480, 640], [540, 720]] and hw.is_contiguous()
+    assert GDRN._image_sizes(None, None, 2, dev, ConfigDict(IM_H=540, IM_W=720)).tolist() == [[540, 720]] * 2
+    for bad in (dict(), dict(IM_H=480)):
+        with pytest.raises(ValueError, match="im_H"):
+            GDRN._image_sizes(None, None, 2, dev, ConfigDict(bad))
+    with pytest.raises(ValueError):
+        GDRN._image_sizes(0, 640, 2, dev, ConfigDict())
+
+    a, _ = build_model_optimizer(gdrn_base_cfg(device="cpu"))
+    b, _ = build_model_optimizer(gdrn_base_cfg(device="cpu"))
+    sa, sb = a._weights_stamp(), b._weights_stamp()
+    gdrn.bump_weights_epoch(list(a.pnp_net.parameters())[:2])  # what Ranger.step reports: the parameters it wrote
+    assert a._weights_stamp() != sa and b._weights_stamp() == sb
+    gdrn.bump_weights_epoch(b)                                  # what the train engine reports: its model
+    assert b._weights_stamp() != sb
+    sa = a._weights_stamp()
+    with torch.no_grad():
+        next(a.parameters()).add_(1.0)                          # torch in-place ops are seen through the version counters
+    assert a._weights_stamp() != sa
+    sa, sb = a._weights_stamp(), b._weights_stamp()
+    gdrn.bump_weights_epoch()                                   # unknown writer: every live model
+    assert a._weights_stamp() != sa and b._weights_stamp() != sb
