@@ -275,6 +275,18 @@ extern "C" int rdpn6d_global_max_concat_h2(void* buf, int B, int HW, int C, int 
 //   3. per 16-channel slice: scale / shift (BatchNorm and the two power-of-two format scales folded) + ReLU -> LDS (overlaying the
 //      dead patch); pixels outside the image become 0, which a ReLU output can never lose to (max-pool pads with -inf);
 //      3x3 / stride-2 max per pooled pixel, hi / lo split, 16-byte stores of the h2 record.
+#ifdef RDPN6D_PROBE
+__device__ unsigned long long* g_stem_probe = nullptr;  // probe builds: tools/probe_stem.py
+extern "C" int rdpn6d_debug_stem_probe(void* buf)
+{
+    RD_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_stem_probe), &buf, sizeof(buf)));
+    return RDPN6D_OK;
+}
+#define SPT(i) const unsigned long long spt##i = __builtin_readcyclecounter()
+#else
+#define SPT(i)
+#endif
+
 namespace {
 
 constexpr int SP_PH = 8, SP_PW = 16;                        // pooled tile
@@ -287,7 +299,7 @@ constexpr int SP_PLANE = 3 * SP_IH * SP_IWS + 8;            // halfs per plane (
 constexpr int SP_KC = 6;                                    // 32-k chunks (K = 192)
 constexpr int SP_TS = 20;                                   // stem-tile row stride in floats: a 16-channel slice + 4
 constexpr int SP_LDS_A = 2 * SP_PLANE * 2;
-constexpr int SP_LDS_B = SP_NPIX * SP_TS * 4;               // one 16-channel slice of the stem tile at a time: 45 KiB
+constexpr int SP_LDS_B = SP_MT * 32 * SP_TS * 4;            // one 16-channel slice of the stem tile at a time (all 576 m-tile rows): 45 KiB
 constexpr int SP_LDS = SP_LDS_A > SP_LDS_B ? SP_LDS_A : SP_LDS_B;
 
 typedef unsigned sp_u32x4 __attribute__((ext_vector_type(4)));
@@ -303,22 +315,29 @@ __global__ __launch_bounds__(256, 2) void stem_pool_h2_kernel(const float* __res
     _Float16* s_hi = reinterpret_cast<_Float16*>(sp_smem);
     _Float16* s_lo = s_hi + SP_PLANE;
     float* s_t = reinterpret_cast<float*>(sp_smem);  // stem-tile slice, overlays the patch after the MFMA phase
-    const int Rs = R / 2, Rp = R / 4;                // stem / pooled resolution
+    const int Rp = R / 4;                            // pooled resolution (stem: R / 2)
     const int b = blockIdx.z, py0 = blockIdx.y * SP_PH, px0 = blockIdx.x * SP_PW;
     const int sy0 = 2 * py0 - 1, sx0 = 2 * px0 - 1;  // first stem pixel of the tile
     const int iy0 = 2 * sy0 - 3, ix0 = 2 * sx0 - 3;  // first input sample of the patch
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    SPT(0);
 
-    {   // all global loads of the patch are issued before the first LDS store (a load-store loop serialises the round trips)
-        constexpr int NP = (3 * SP_IH * SP_IW + 255) / 256;
-        float pv[NP];
+    {   // The patch, as ALIGNED 16-byte loads: ix0 = 4*px0 - 5, so columns ix0 - 3 + 4j (j = 0 .. 18) are 16-byte aligned in the crop's
+        // rows (R % 4 == 0) and cover patch columns -3 .. 72 - the 71 real ones, two of the three padding columns (read times zero
+        // weights only: any finite value does) and three in front that are dropped.  9 loads per thread instead of 33 scalar ones; all
+        // of them are issued before the first LDS store (a load-store loop serialises the round trips).
+        typedef float sp_f4 __attribute__((ext_vector_type(4)));
+        constexpr int F4R = 19, NF4 = 3 * SP_IH * F4R, NP4 = (NF4 + 255) / 256;
+        static_assert(4 * F4R - 3 >= SP_IW && 4 * F4R - 3 <= SP_IWS, "19 aligned float4 cover a patch row and stay inside its padding");
+        sp_f4 pv[NP4];
 #pragma unroll
-        for (int t = 0; t < NP; ++t) {
+        for (int t = 0; t < NP4; ++t) {
             const int i = tid + 256 * t;
-            const int c = i / (SP_IH * SP_IW), rem = i - c * SP_IH * SP_IW, py = rem / SP_IW, px = rem - py * SP_IW;
-            const int iy = iy0 + py, ix = ix0 + px;
-            pv[t] = 0.f;
-            if (i < 3 * SP_IH * SP_IW && (unsigned)iy < (unsigned)R && (unsigned)ix < (unsigned)R) pv[t] = x[(((long long)b * xc + c) * R + iy) * R + ix];
+            const int row = i / F4R, j = i - row * F4R, c = row / SP_IH, py = row - c * SP_IH;
+            const int iy = iy0 + py, col = ix0 - 3 + 4 * j;
+            pv[t] = sp_f4{0.f, 0.f, 0.f, 0.f};
+            if (i < NF4 && (unsigned)iy < (unsigned)R && (unsigned)col < (unsigned)R)
+                pv[t] = *reinterpret_cast<const sp_f4*>(x + (((long long)b * xc + c) * R + iy) * R + col);
         }
         for (int i = tid; i < 3 * SP_IH * (SP_IWS - SP_IW) + 8; i += 256) {  // the row padding and the slack: zeros (read, times zero weights)
             const int row = i / (SP_IWS - SP_IW), q = i - row * (SP_IWS - SP_IW);
@@ -326,19 +345,34 @@ __global__ __launch_bounds__(256, 2) void stem_pool_h2_kernel(const float* __res
             s_hi[idx] = (_Float16)0.f;
             s_lo[idx] = (_Float16)0.f;
         }
+        __syncthreads();  // (the padding zeros first: the stores below put real samples into two of the three padding columns)
 #pragma unroll
-        for (int t = 0; t < NP; ++t) {
+        for (int t = 0; t < NP4; ++t) {
             const int i = tid + 256 * t;
-            const int c = i / (SP_IH * SP_IW), rem = i - c * SP_IH * SP_IW, py = rem / SP_IW, px = rem - py * SP_IW;
-            if (i < 3 * SP_IH * SP_IW) {
-                const float v = pv[t] * H2_SCALE;  // image / 255 in [0, 1]: no range issue
-                const _Float16 h = (_Float16)v;
-                s_hi[(c * SP_IH + py) * SP_IWS + px] = h;
-                s_lo[(c * SP_IH + py) * SP_IWS + px] = (_Float16)(v - (float)h);
+            const int row = i / F4R, j = i - row * F4R;
+            if (i < NF4) {
+                _Float16 h[4], l[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = pv[t][e] * H2_SCALE;  // image / 255 in [0, 1]: no range issue
+                    h[e] = (_Float16)v;
+                    l[e] = (_Float16)(v - (float)h[e]);
+                }
+                const int o = row * SP_IWS + 4 * j - 3;  // patch column 4j - 3 + e; o is odd: (o + 1, o + 2) is a 4-byte aligned pair
+                if (j > 0) {
+                    s_hi[o] = h[0];
+                    s_lo[o] = l[0];
+                    typedef _Float16 sp_h2 __attribute__((ext_vector_type(2)));
+                    *reinterpret_cast<sp_h2*>(s_hi + o + 1) = sp_h2{h[1], h[2]};
+                    *reinterpret_cast<sp_h2*>(s_lo + o + 1) = sp_h2{l[1], l[2]};
+                }
+                s_hi[o + 3] = h[3];
+                s_lo[o + 3] = l[3];
             }
         }
     }
     __syncthreads();
+    SPT(1);
 
     // ---- MFMA phase.  Wave w owns m-tiles w, w+4, ... (at most 5); lane = (row r, k-half).
     const int r = lane & 31, half = lane >> 5;
@@ -410,6 +444,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool_h2_kernel(const float* __res
         }
     }
 
+    SPT(2);
     // ---- epilogue + pooling, one 16-channel slice of the stem tile at a time (the slice overlays the dead patch).
     // Accumulator element e of lane (r, half) = pixel row (e&3) + 8*(e>>2) + 4*half of the m-tile, channel nt*32 + r.
     bool over = false;
@@ -417,21 +452,17 @@ __global__ __launch_bounds__(256, 2) void stem_pool_h2_kernel(const float* __res
     for (int q = 0; q < 4; ++q) {
         __syncthreads();  // q = 0: every wave is done with the patch; q > 0: the previous slice has been pooled
         if ((r >> 4) == (q & 1)) {
+            // 3 instructions per value (fma, max, ds_write with an immediate offset): the row of accumulator element e is
+            // (wave + 4m)*32 + 4*half + (e&3) + 8*(e>>2), so only the first term needs an address.  Pixels outside the image (the tile's
+            // first row / column at the top / left edge of the crop) are left as they are and SKIPPED by the pooling below.
             const int nt = q >> 1, n = nt * 32 + r;
             const float sc = scale[n], sh = shift[n];
 #pragma unroll
             for (int m = 0; m < MPW; ++m) {
                 if (wave + 4 * m >= SP_MT) continue;
+                float* tp = s_t + ((wave + 4 * m) * 32 + 4 * half) * SP_TS + (r & 15);
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int p = (wave + 4 * m) * 32 + (e & 3) + 8 * (e >> 2) + 4 * half;
-                    if (p < SP_NPIX) {
-                        const int sy = p / SP_SW, sx = p - sy * SP_SW;
-                        const bool inside = (unsigned)(sy0 + sy) < (unsigned)Rs && (unsigned)(sx0 + sx) < (unsigned)Rs;
-                        const float v = acc[m][nt][e] * sc + sh;
-                        s_t[p * SP_TS + (r & 15)] = inside && v > 0.f ? v : 0.f;
-                    }
-                }
+                for (int e = 0; e < 16; ++e) tp[((e & 3) + 8 * (e >> 2)) * SP_TS] = fmaxf(acc[m][nt][e] * sc + sh, 0.f);
             }
         }
         __syncthreads();
@@ -446,12 +477,15 @@ __global__ __launch_bounds__(256, 2) void stem_pool_h2_kernel(const float* __res
                 for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                     for (int dx = 0; dx < 3; ++dx) {
+                        // stem pixel (sy0 + 2qy + dy, sx0 + 2qx + dx): only row / column -1 can lie outside (MaxPool pads with -inf;
+                        // leaving the tap out = the 0 a ReLU output can never lose to)
+                        if ((dy == 0 && sy0 + 2 * qy < 0) || (dx == 0 && sx0 + 2 * qx < 0)) continue;
                         const float* tp = s_t + ((2 * qy + dy) * SP_SW + 2 * qx + dx) * SP_TS + c8;
                         const f32x4 a = *reinterpret_cast<const f32x4*>(tp), c = *reinterpret_cast<const f32x4*>(tp + 4);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            m8[e] = a[e] > m8[e] ? a[e] : m8[e];
-                            m8[4 + e] = c[e] > m8[4 + e] ? c[e] : m8[4 + e];
+                        for (int e = 0; e < 4; ++e) {  // (ReLU outputs: no NaN ordering question, one v_max_f32 each)
+                            m8[e] = __builtin_fmaxf(m8[e], a[e]);
+                            m8[4 + e] = __builtin_fmaxf(m8[4 + e], c[e]);
                         }
                     }
                 f16x8 hi, lo;
@@ -465,6 +499,18 @@ __global__ __launch_bounds__(256, 2) void stem_pool_h2_kernel(const float* __res
         }
     }
     if (over && overflow_flag) *overflow_flag = 1;
+#ifdef RDPN6D_PROBE
+    {
+        const unsigned long long spt3 = __builtin_readcyclecounter();
+        if (g_stem_probe && lane == 0) {
+            unsigned long long* o = g_stem_probe + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 * 4 + wave * 4;
+            o[0] = spt1 - spt0;
+            o[1] = spt2 - spt1;
+            o[2] = spt3 - spt2;
+            o[3] = 1;
+        }
+    }
+#endif
 }
 
 }  // namespace
@@ -477,6 +523,7 @@ extern "C" int rdpn6d_stem_pool_h2(const float* x, int B, int xc, int R, const v
 {
     RD_REQUIRE(x && w_h2 && scale && shift && y, "null pointer");
     RD_REQUIRE(B > 0 && xc >= 3 && R > 0 && R % 4 == 0, "shape (R % 4)");
+    RD_REQUIRE((reinterpret_cast<size_t>(x) & 15) == 0, "x must be 16-byte aligned (the patch is read with aligned 16-byte loads)");
     RD_LDS_OPT_IN(stem_pool_h2_kernel, SP_LDS);
     const int Rp = R / 4;
     dim3 grid(rd_cdiv(Rp, SP_PW), rd_cdiv(Rp, SP_PH), B);
