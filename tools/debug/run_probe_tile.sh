@@ -1,4 +1,4 @@
 #!/bin/bash
-O=gpurun_out/r3_e; mkdir -p $O
+O=gpurun_out/probe; mkdir -p $O
 RDPN6D_PROBE=1 python rdpn6d_amd/build.py --force > $O/build.log 2>&1; tail -1 $O/build.log
 RDPN6D_H2_SCHED=9 RDPN6D_H2_NST=3 python tools/probe_h2_tile.py 2>&1 | grep -v amdgpu | tee $O/probe.log
