@@ -3,6 +3,7 @@
 Per wave the kernel sums shader cycles of: fragment-read issue | DMA issue (addresses + 1 KiB LDS-DMA pieces) | MFMA issue |
 s_waitcnt vmcnt + lgkmcnt | s_barrier, plus prologue + loop and epilogue time (s_memtime; ~10 % intrusive)."""
 import ctypes, os, sys
+os.environ.setdefault("RDPN6D_H2_PP", "0")  # every layer on the tile kernel (the ping-pong kernel has its own probe: tools/probe_h2_pp.py)
 import numpy as np
 import torch
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
