@@ -165,8 +165,10 @@ int rdpn6d_global_max_h2(const void* x_h2, int B, int HW, int C, int cs, void* g
 int rdpn6d_convt3x3s2_const_bias_f32(const float* V, const float* scale, int B, int F, float* out /* [4][B][4][F] */, void* stream);
 /* fused front of the network for the h2 path: conv1 7x7/2 + folded BN + ReLU + MaxPool2d(3,2,1) (resnet_backbone.py:272-275)
  * as an implicit GEMM on the fp16 matrix pipe (two-plane arithmetic, fp32-accurate), writing the pooled activation
- * [B, R/4, R/4, 64] as an h2 tensor.  w_h2 [64][5][2][32] fp16 = the conv1 weights with k = (ky*7+kx)*3+c padded to 160;
- * scale = BN scale * 2^-(sw(n)+4), shift = BN shift. */
+ * [B, R/4, R/4, 64] as an h2 tensor.  x [B, xc, R, R] fp32 NCHW (channels 0..2 used), 16-byte aligned, R % 4 == 0 (the input
+ * patch is read with aligned 16-byte loads); w_h2 [64][6][2][32] fp16 = the conv1 weights with the reduction index
+ * k = (c*7+ky)*8+kx padded to 192 (zeros at kx = 7 and k >= 168; gdrn.pack_stem_h2_weight); scale = BN scale * 2^-(sw(n)+4),
+ * shift = BN shift. */
 int rdpn6d_stem_pool_h2(const float* x, int B, int xc, int R, const void* w_h2, const float* scale, const float* shift, void* y,
                         int* overflow_flag, void* stream);
 void rdpn6d_conv_bf16_force_chunk(int row_bytes); /* profiling: 0 = auto, 64 forces 32-channel K-chunks (measured slower) */
