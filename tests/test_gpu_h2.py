@@ -34,6 +34,8 @@ H2_CASES = [
     (28, 16, 256, 256, 3, 1, False, 2),   # 112 x 2 = 224 tiles of 128x128: the smallest launch the ping-pong kernel takes
     (64, 32, 128, 256, 3, 2, False, 1),   # stride-2 entry convolution of layer3 at B = 64
     (64, 32, 256, 128, 1, 1, False, 0),   # 1x1: 8 chunks, the shortest loop the kernel takes
+    (40, 16, 256, 384, 3, 1, True, 1),    # three column tiles (N = 384): 80 x 3 = 240 tiles of 128x128
+    (64, 32, 256, 512, 1, 2, False, 0),   # Bottleneck-style 1x1 stride-2 downsample: 64 x 4 = 256 tiles of 256x128, 8 chunks
 ]
 
 
