@@ -235,6 +235,7 @@ __global__ __launch_bounds__(512) void conv_h2_pp_kernel(const ConvH2Args ax)
         stage_pieces(ic<0>{}, ic<P>{}, c);
         next_chunk();
     }
+    stage_addr(ld_tap, ld_cc, ld_idx < nk);                              // addresses of chunk D, issued in step 0
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * P) : "memory");  // chunk 0 has landed (this wave's pieces)
     __builtin_amdgcn_s_barrier();                                        // ... and everybody's
     asm volatile("" ::: "memory");
@@ -250,9 +251,8 @@ __global__ __launch_bounds__(512) void conv_h2_pp_kernel(const ConvH2Args ax)
         __builtin_amdgcn_sched_barrier(0);
         PP_T(0);
         read_frags(st_rd);
-        stage_addr(ld_tap, ld_cc, ld_idx < nk);
         __builtin_amdgcn_sched_barrier(0);
-        stage_pieces(ic<0>{}, ic<PL>{}, st_wr);
+        stage_pieces(ic<0>{}, ic<PL>{}, st_wr);  // (addresses of chunk k + D: computed between the MFMAs of the previous step)
         __builtin_amdgcn_sched_barrier(0);
         PP_T(1);
         // outstanding and newer than chunk k + 1: chunks k + 2 .. k + D - 1 (P each) + the PL pieces just issued -> chunk k + 1 has
@@ -275,12 +275,15 @@ __global__ __launch_bounds__(512) void conv_h2_pp_kernel(const ConvH2Args ax)
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (PM >= 2) stage_piece(ic<PL + 1>{}, st_wr);
         __builtin_amdgcn_sched_barrier(0);
+        // the DMA addresses of the NEXT step's chunk (k + 1 + D), here, where their ~50 scalar / vector instructions run under the
+        // MFMAs instead of lengthening the L part (probe: per chunk 1 105 -> 987 cycles on layer3)
+        next_chunk();
+        stage_addr(ld_tap, ld_cc, ld_idx < nk);
         mma_group(ic<4>{});
         mma_group(ic<5>{});
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         PP_T(4);
-        next_chunk();
         st_rd = st_rd == NST - 1 ? 0 : st_rd + 1;
         st_wr = st_wr == NST - 1 ? 0 : st_wr + 1;
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * P) : "memory");  // newer than chunk k + 1: chunks k + 2 .. k + D
