@@ -171,6 +171,10 @@ int rdpn6d_convt3x3s2_const_bias_f32(const float* V, const float* scale, int B, 
  * shift = BN shift. */
 int rdpn6d_stem_pool_h2(const float* x, int B, int xc, int R, const void* w_h2, const float* scale, const float* shift, void* y,
                         int* overflow_flag, void* stream);
+/* the same kernel with the pooled activation stored as out_fmt: 0 = h2 tensor (above), 1 = bf16, 2 = fp16 NHWC [B, R/4, R/4, 64] - the
+ * front of the 16-bit inference mode (cfg.TEST.AMP_TEST; gdrn_evaluator.py:625): fp32-accurate arithmetic, one rounding on the store */
+int rdpn6d_stem_pool_h2_ex(const float* x, int B, int xc, int R, const void* w_h2, const float* scale, const float* shift, void* y,
+                           int out_fmt, int* overflow_flag, void* stream);
 void rdpn6d_conv_bf16_force_chunk(int row_bytes); /* profiling: 0 = auto, 64 forces 32-channel K-chunks (measured slower) */
 /* bf16 forms of the kernels between the bf16 convolutions (same argument meaning as the _f32 entry points; activations
  * bf16 NHWC with C % 8 == 0; the stem and the xyz subsample read the fp32 NCHW crop and write bf16) */

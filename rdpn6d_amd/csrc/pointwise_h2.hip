@@ -307,6 +307,9 @@ typedef unsigned sp_u32x4 __attribute__((ext_vector_type(4)));
 // first patch element (relative to the pixel's top-left sample) of the 8-wide k-row rw = k / 8 = c*7 + ky; rows 21..23 are padding
 __host__ __device__ constexpr int sp_rowoff(int rw) { return rw >= 21 ? 0 : ((rw / 7) * SP_IH + rw % 7) * SP_IWS; }
 
+// OUT: 0 = the pooled activation as an h2 tensor; 1 / 2 = as a plain bf16 / fp16 NHWC tensor [B, R/4, R/4, 64] (the 16-bit inference
+// mode, cfg.TEST.AMP_TEST: the arithmetic stays the fp32-accurate h2 one, only the stored result is rounded)
+template <int OUT>
 __global__ __launch_bounds__(256, 2) void stem_pool_h2_kernel(const float* __restrict__ x, int xc, int R, const _Float16* __restrict__ w_h2,
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
                                                               _Float16* __restrict__ y, int* __restrict__ overflow_flag)
@@ -488,13 +491,31 @@ __global__ __launch_bounds__(256, 2) void stem_pool_h2_kernel(const float* __res
                             m8[4 + e] = __builtin_fmaxf(m8[4 + e], c[e]);
                         }
                     }
-                f16x8 hi, lo;
+                if constexpr (OUT == 0) {
+                    f16x8 hi, lo;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) m8[e] *= H2_SCALE;
-                over |= rd_h2_split8(m8, hi, lo);
-                _Float16* dp = y + h2_off(((long long)b * Rp + py) * Rp + px, 64, q * 16 + c8);
-                *reinterpret_cast<f16x8*>(dp) = hi;
-                *reinterpret_cast<f16x8*>(dp + 32) = lo;
+                    for (int e = 0; e < 8; ++e) m8[e] *= H2_SCALE;
+                    over |= rd_h2_split8(m8, hi, lo);
+                    _Float16* dp = y + h2_off(((long long)b * Rp + py) * Rp + px, 64, q * 16 + c8);
+                    *reinterpret_cast<f16x8*>(dp) = hi;
+                    *reinterpret_cast<f16x8*>(dp + 32) = lo;
+                } else {
+                    sp_u32x4 pk;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if constexpr (OUT == 1) {
+                            typedef __bf16 sp_b2 __attribute__((ext_vector_type(2)));
+                            typedef float sp_f2 __attribute__((ext_vector_type(2)));
+                            pk[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(sp_f2{m8[2 * e], m8[2 * e + 1]}, sp_b2));
+                        } else {
+                            typedef _Float16 sp_h2v __attribute__((ext_vector_type(2)));
+                            typedef float sp_f2 __attribute__((ext_vector_type(2)));
+                            pk[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(sp_f2{m8[2 * e], m8[2 * e + 1]}, sp_h2v));
+                        }
+                    }
+                    unsigned short* dp = reinterpret_cast<unsigned short*>(y) + (((long long)b * Rp + py) * Rp + px) * 64 + q * 16 + c8;
+                    *reinterpret_cast<sp_u32x4*>(dp) = pk;
+                }
             }
         }
     }
@@ -518,17 +539,32 @@ __global__ __launch_bounds__(256, 2) void stem_pool_h2_kernel(const float* __res
 // x [B, xc, R, R] fp32 NCHW (channels 0..2 used); w_h2: conv1 weights with the reduction index k = (c*7 + ky)*8 + kx padded to
 // 192 (zeros at kx = 7 and k >= 168) as an h2 tensor [64][6][2][32] fp16 holding w * 2^sw(n) (gdrn.pack_stem_h2_weight);
 // scale / shift [64]: folded BatchNorm times 2^-(sw(n)+4) / plain shift.  y: pooled activation [B, R/4, R/4, 64] as an h2 tensor.
-extern "C" int rdpn6d_stem_pool_h2(const float* x, int B, int xc, int R, const void* w_h2, const float* scale, const float* shift, void* y,
-                                   int* overflow_flag, void* stream)
+extern "C" int rdpn6d_stem_pool_h2_ex(const float* x, int B, int xc, int R, const void* w_h2, const float* scale, const float* shift, void* y,
+                                      int out_fmt, int* overflow_flag, void* stream)
 {
     RD_REQUIRE(x && w_h2 && scale && shift && y, "null pointer");
     RD_REQUIRE(B > 0 && xc >= 3 && R > 0 && R % 4 == 0, "shape (R % 4)");
+    RD_REQUIRE(out_fmt >= 0 && out_fmt <= 2, "out_fmt: 0 = h2 tensor, 1 = bf16 NHWC, 2 = fp16 NHWC");
     RD_REQUIRE((reinterpret_cast<size_t>(x) & 15) == 0, "x must be 16-byte aligned (the patch is read with aligned 16-byte loads)");
-    RD_LDS_OPT_IN(stem_pool_h2_kernel, SP_LDS);
     const int Rp = R / 4;
     dim3 grid(rd_cdiv(Rp, SP_PW), rd_cdiv(Rp, SP_PH), B);
-    hipLaunchKernelGGL(stem_pool_h2_kernel, grid, dim3(256), SP_LDS, (hipStream_t)stream, x, xc, R, (const _Float16*)w_h2, scale, shift,
-                       (_Float16*)y, overflow_flag);
+    hipStream_t s = (hipStream_t)stream;
+    if (out_fmt == 0) {
+        RD_LDS_OPT_IN(stem_pool_h2_kernel<0>, SP_LDS);
+        hipLaunchKernelGGL(stem_pool_h2_kernel<0>, grid, dim3(256), SP_LDS, s, x, xc, R, (const _Float16*)w_h2, scale, shift, (_Float16*)y, overflow_flag);
+    } else if (out_fmt == 1) {
+        RD_LDS_OPT_IN(stem_pool_h2_kernel<1>, SP_LDS);
+        hipLaunchKernelGGL(stem_pool_h2_kernel<1>, grid, dim3(256), SP_LDS, s, x, xc, R, (const _Float16*)w_h2, scale, shift, (_Float16*)y, overflow_flag);
+    } else {
+        RD_LDS_OPT_IN(stem_pool_h2_kernel<2>, SP_LDS);
+        hipLaunchKernelGGL(stem_pool_h2_kernel<2>, grid, dim3(256), SP_LDS, s, x, xc, R, (const _Float16*)w_h2, scale, shift, (_Float16*)y, overflow_flag);
+    }
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
+}
+
+extern "C" int rdpn6d_stem_pool_h2(const float* x, int B, int xc, int R, const void* w_h2, const float* scale, const float* shift, void* y,
+                                   int* overflow_flag, void* stream)
+{
+    return rdpn6d_stem_pool_h2_ex(x, B, xc, R, w_h2, scale, shift, y, 0, overflow_flag, stream);
 }

@@ -542,6 +542,15 @@ class InferencePlan:
             self.keep += [wh, scf, sh]
             self.stem_fn = lib.rdpn6d_stem_pool_h2
             self.stem_args = (B, 6, R, _ptr(wh), _ptr(scf), _ptr(sh), _ptr(pcur), _ptr(self.h2_flag))
+        elif self.bf16 and R % 4 == 0 and model.cfg.get("TEST", {}).get("FUSED_FRONT_LP", True):
+            # 16-bit mode: the same fused kernel (fp32-accurate h2 arithmetic on the fp16 matrix pipe), the pooled activation rounded once
+            # into the mode's NHWC bf16 / fp16 tensor - instead of the VALU stem + max-pool pair and the [B,128,128,64] tensor between them
+            wh, inv = pack_stem_h2_weight(bb.conv1.weight)
+            scf = (sc[:64] * inv).contiguous()
+            p0 = self.buf("pool", B, R4, R4, 64, dtype=adt)
+            self.keep += [wh, scf, sh]
+            self.stem_fn = lib.rdpn6d_stem_pool_h2_ex
+            self.stem_args = (B, 6, R, _ptr(wh), _ptr(scf), _ptr(sh), _ptr(p0), 1 if self.lp == "bf16" else 2, None)
         else:
             s0 = self.buf("stem", B, R2, R2, 64, dtype=adt)
             self.keep += [w, sc, sh]
@@ -1138,6 +1147,7 @@ class GDRN(nn.Module):
             bf16 = str(self.cfg.get("TEST", {}).get("AMP_DTYPE", "bf16"))
         tc = self.cfg.get("TEST", {})
         key = (B, str(device), bf16 or False, bool(tc.get("BF16X3", True)), bool(tc.get("FP16X2", True)), bool(tc.get("FOLD_GLOBAL_MAX", True)),
+               bool(tc.get("FUSED_FRONT_LP", True)),
                bool(tc.get("CONV_BEFORE_UPSAMPLE", True)), bool(tc.get("COMPOSE_CONV3_CONVT", True)))
         stamp = self._weights_stamp()
         plan = self._plans.get(key)

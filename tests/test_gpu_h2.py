@@ -210,6 +210,14 @@ def test_fused_stem_pool_h2_vs_fp64(B, R):
     scale = y64.abs().max().item()
     print(f"B={B} R={R}: fused h2 stem+pool vs fp64 {e_h2:.3e} | fp32 VALU stem + pool vs fp64 {e_32:.3e} (|y|max {scale:.2f})")
     assert int(flag.item()) == 0 and e_h2 <= 1.25 * e_32 + 2.0 ** -21 * scale  # (+ the 22-bit h2 record of the output itself)
+    # the same kernel storing bf16 / fp16 NHWC (front of the 16-bit inference mode): one rounding of the same values
+    for fmt, dt, ulp in ((1, torch.bfloat16, 2.0 ** -8), (2, torch.float16, 2.0 ** -11)):
+        y16 = torch.empty(B, Rp, Rp, 64, dtype=dt, device=dev)
+        _lib.check(lib.rdpn6d_stem_pool_h2_ex(_ptr(xd), B, 6, R, _ptr(wh), _ptr(scf), _ptr(sh.to(dev)), _ptr(y16), fmt, None, None))
+        torch.cuda.synchronize()
+        err = (y16.cpu().double() - y64).abs()
+        assert (err <= ulp * y64.abs() * 1.01 + e_h2 + 1e-7).all(), (fmt, err.max().item())  # (unit roundoff 2^-8 | 2^-11)
+        assert torch.equal(y16.cpu(), mine.to(dt)) or (y16.cpu().double() - mine).abs().max().item() <= ulp * scale  # = the h2 result rounded once (up to double rounding)
 
 
 def test_global_max_record_and_constant_input_bias_of_the_conv_transpose():
