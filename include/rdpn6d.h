@@ -98,6 +98,8 @@ int rdpn6d_conv2d_bf16(const rdpn6d_conv_desc* d, int out_f32, void* stream);
 /* split-K form, as rdpn6d_conv2d_splitk_f32 (same workspace size, linear output geometry) */
 int rdpn6d_conv2d_splitk_bf16(const rdpn6d_conv_desc* d, int out_f32, int ksplit, float* workspace, void* stream);
 void rdpn6d_conv_bf16_force_tile(int bm, int bn);
+/* profiling: LDS stages of the 4-wave tiles (0 = the heuristic: 3 for 64x64 tiles with >= 64 K-chunks, else 2) */
+void rdpn6d_conv_bf16_force_stages(int nst);
 int rdpn6d_conv_bf16_tile_for(const rdpn6d_conv_desc* d, int* bm, int* bn);
 /* fp32-ACCURATE convolution on the bf16 matrix pipe ("bf16x3", csrc/conv_igemm_bf16x3.hip): every fp32 operand is held as
  * three bf16 planes (a = a1 + a2 + a3, 24 significand bits) and a product is the six partial products a_i*b_j, i+j <= 4,
@@ -284,6 +286,11 @@ int rdpn6d_bn_backward_f32(const float* x, int xcs, int xco, const float* dy, in
                            int yco, const float* mean, const float* invstd, const float* gamma, float* dgamma, float* dbeta,
                            float* dx, int xgcs, int xgco, float* dres, int rcs, int rco, long long M, int C, int relu,
                            double* scratch, void* stream);
+/* BN + ReLU backward (no residual between them) WITHOUT the stored activation: the mask y > 0 is re-derived from x with the forward's
+ * own expression and rounding - one tensor read less in both passes */
+int rdpn6d_bn_relu_backward_f32(const float* x, int xcs, int xco, const float* dy, int dcs, int dco, const float* mean,
+                                const float* invstd, const float* gamma, const float* beta, float* dgamma, float* dbeta, float* dx,
+                                int xgcs, int xgco, long long M, int C, double* scratch, void* stream);
 /* out[c] (+)= sum over rows of x[m, co+c]  (bias gradients) */
 int rdpn6d_channel_sum_f32(const float* x, long long M, int C, int cs, int co, float* out, int accumulate, double* scratch,
                            void* stream);
@@ -391,6 +398,9 @@ int rdpn6d_bn_backward_bf16(const void* x, int xcs, int xco, const void* dy, int
                             const float* mean, const float* invstd, const float* gamma, float* dgamma, float* dbeta, void* dx,
                             int xgcs, int xgco, void* dres, int rcs, int rco, long long M, int C, int relu, double* scratch,
                             void* stream);
+int rdpn6d_bn_relu_backward_bf16(const void* x, int xcs, int xco, const void* dy, int dcs, int dco, const float* mean,
+                                 const float* invstd, const float* gamma, const float* beta, float* dgamma, float* dbeta, void* dx,
+                                 int xgcs, int xgco, long long M, int C, double* scratch, void* stream);
 int rdpn6d_channel_sum_bf16(const void* x, long long M, int C, int cs, int co, float* out, int accumulate, double* scratch,
                             void* stream);
 int rdpn6d_maxpool3x3s2_backward_bf16(const void* x, const void* dy, int B, int H, int W, int C, void* dx, void* stream);
@@ -454,6 +464,7 @@ int rdpn6d_crop_builder_f32(const unsigned char* images, const float* depths, in
 int rdpn6d_conv2d_fp16(const rdpn6d_conv_desc* d, int out_f32, void* stream);
 int rdpn6d_conv2d_splitk_fp16(const rdpn6d_conv_desc* d, int out_f32, int ksplit, float* workspace, void* stream);
 void rdpn6d_conv_fp16_force_tile(int bm, int bn);
+void rdpn6d_conv_fp16_force_stages(int nst);
 int rdpn6d_conv_fp16_tile_for(const rdpn6d_conv_desc* d, int* bm, int* bn);
 void rdpn6d_conv_fp16_force_chunk(int row_bytes);
 int rdpn6d_stem_conv7x7_fp16(const float* x, int B, int xc, int R, const float* w, const float* scale,
@@ -477,6 +488,9 @@ int rdpn6d_bn_train_stats_fp16(const void* x, long long M, int C, int cs, int co
 int rdpn6d_bn_apply_fp16(const void* x, int xcs, int xco, const float* mean, const float* invstd, const float* gamma,
                          const float* beta, const void* res, int rcs, int rco, void* y, int ycs, int yco, long long M, int C,
                          int relu, void* stream);
+int rdpn6d_bn_relu_backward_fp16(const void* x, int xcs, int xco, const void* dy, int dcs, int dco, const float* mean,
+                                 const float* invstd, const float* gamma, const float* beta, float* dgamma, float* dbeta, void* dx,
+                                 int xgcs, int xgco, long long M, int C, double* scratch, void* stream);
 int rdpn6d_bn_backward_fp16(const void* x, int xcs, int xco, const void* dy, int dcs, int dco, const void* y, int ycs, int yco,
                             const float* mean, const float* invstd, const float* gamma, float* dgamma, float* dbeta, void* dx,
                             int xgcs, int xgco, void* dres, int rcs, int rco, long long M, int C, int relu, double* scratch,

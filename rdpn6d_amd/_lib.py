@@ -52,6 +52,7 @@ SIGNATURES = {
     "rdpn6d_conv_bf16x3_kernel_for": (_i, [ctypes.POINTER(ConvDesc)]),
     "rdpn6d_conv2d_bf16x3_ex": (_i, [ctypes.POINTER(ConvDesc), _ll, _ll, _vp, _ll, _vp, _ll, _vp]),
     "rdpn6d_conv_bf16_force_chunk": (None, [_i]),
+    "rdpn6d_conv_bf16_force_stages": (None, [_i]),
     "rdpn6d_stem_conv7x7_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "rdpn6d_maxpool3x3s2_bf16": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "rdpn6d_upsample_bilinear_bf16": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
@@ -75,6 +76,7 @@ SIGNATURES = {
     "rdpn6d_bn_apply_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _ll, _i, _i, _vp]),
     "rdpn6d_bn_backward_f32": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i,
                                     _ll, _i, _i, _vp, _vp]),
+    "rdpn6d_bn_relu_backward_f32": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _ll, _i, _vp, _vp]),
     "rdpn6d_channel_sum_f32": (_i, [_vp, _ll, _i, _i, _i, _vp, _i, _vp, _vp]),
     "rdpn6d_groupnorm_relu_train_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "rdpn6d_groupnorm_relu_backward_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
@@ -108,6 +110,7 @@ SIGNATURES = {
     "rdpn6d_bn_apply_bf16": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _ll, _i, _i, _vp]),
     "rdpn6d_bn_backward_bf16": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i,
                                      _ll, _i, _i, _vp, _vp]),
+    "rdpn6d_bn_relu_backward_bf16": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _ll, _i, _vp, _vp]),
     "rdpn6d_channel_sum_bf16": (_i, [_vp, _ll, _i, _i, _i, _vp, _i, _vp, _vp]),
     "rdpn6d_maxpool3x3s2_backward_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "rdpn6d_upsample_bilinear_backward_bf16": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -21,7 +21,7 @@
 #include "conv_bf16_common.h"
 
 template <int BM, int BN, int RB, int WM, int WN, int NST>
-__global__ __launch_bounds__(64 * WM * WN, NST == 2 ? 2 : 1) void conv_igemm_bf16_kernel(const ConvBArgs a)
+__global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_igemm_bf16_kernel(const ConvBArgs a)
 {
     constexpr int NW = WM * WN;      // wavefronts per workgroup
     constexpr int SL = RB / 16;      // 16-byte slots per LDS row
@@ -253,7 +253,8 @@ __global__ void conv_bf16_splitk_epilogue_kernel(const float* __restrict__ parti
 bool conv_bf16_8ph_eligible(const ConvBArgs& a, int rb);
 int conv_bf16_launch_8ph(const ConvBArgs& a, hipStream_t s);
 
-static int g_bforce_bm = 0, g_bforce_bn = 0, g_bforce_rb = 0;
+static int g_bforce_bm = 0, g_bforce_bn = 0, g_bforce_rb = 0, g_bforce_nst = 0;
+extern "C" void rdpn6d_conv_bf16_force_stages(int nst) { g_bforce_nst = nst; }  // 0 = auto, 2 | 3 (profiling: LDS stages of the 4-wave tiles)
 extern "C" void rdpn6d_conv_bf16_force_chunk(int row_bytes) { g_bforce_rb = row_bytes; }  // 0 = auto, 64 | 128 (profiling)
 extern "C" void rdpn6d_conv_bf16_force_tile(int bm, int bn) { g_bforce_bm = bm; g_bforce_bn = bn; }
 
@@ -302,6 +303,16 @@ static int conv_bf16_launch(const ConvBArgs& a, int bm, int bn, int nsplit, hipS
 {
     if constexpr (RB == 128) {
         if (bm == 256) return conv_bf16_launch_one<256, 128, RB, 4, 2, 3>(a, nsplit, s);
+    }
+    // Three LDS stages (the DMA two chunks ahead, never drained inside the loop) for the 4-wave tiles: pays where the K loop is
+    // long and the tile small - 64x64 tiles of the 512-channel layers (layer4: 72 chunks; 38 -> 25 us at B = 32, 40 -> 32 at B = 64) -
+    // and loses occupancy (96 KiB for a 128x128 tile: one workgroup per CU instead of two) everywhere else (measured, B = 32 / 64)
+    const int nst = g_bforce_nst ? g_bforce_nst : ((bm == 64 && bn == 64 && a.kper >= 64) ? 3 : 2);
+    if (nst == 3) {
+        if (bm == 128 && bn == 128) return conv_bf16_launch_one<128, 128, RB, 2, 2, 3>(a, nsplit, s);
+        if (bm == 128 && bn == 64) return conv_bf16_launch_one<128, 64, RB, 2, 2, 3>(a, nsplit, s);
+        if (bm == 64 && bn == 128) return conv_bf16_launch_one<64, 128, RB, 2, 2, 3>(a, nsplit, s);
+        return conv_bf16_launch_one<64, 64, RB, 2, 2, 3>(a, nsplit, s);
     }
     if (bm == 128 && bn == 128) return conv_bf16_launch_one<128, 128, RB, 2, 2, 2>(a, nsplit, s);
     if (bm == 128 && bn == 64) return conv_bf16_launch_one<128, 64, RB, 2, 2, 2>(a, nsplit, s);

@@ -12,6 +12,19 @@
 
 #define NS_MAX 128  // row splits of the partial reductions
 
+// The normalised value of the forward pass, ONE expression for bn_apply_kernel and for the backward kernels that re-derive the ReLU
+// mask from x instead of reading the stored activation (relu == 2): the same operations in the same order, so the same sign.
+__device__ __forceinline__ float bn_fwd_value(float x, float mean, float invstd, float gamma, float beta)
+{
+    return __builtin_fmaf((x - mean) * invstd, gamma, beta);
+}
+// y > 0 for the activation as it was STORED (type T): a positive fp32 value that rounds to zero in 16 bits has a zero mask
+template <typename T> __device__ __forceinline__ bool bn_stored_positive(float v)
+{
+    if constexpr (sizeof(T) == 2) return rd_bf2f(rd_f2bf(v)) > 0.f;
+    else return v > 0.f;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Stage 1 of every per-channel reduction.  MODE 0: (sum x, sum x^2)         [BN statistics, bias grads]
 //                                            MODE 1: (sum g, sum g*xhat)       [BN backward], g = dy*(y>0) if relu
@@ -23,6 +36,7 @@ __global__ __launch_bounds__(256) void chan_partial_kernel(const T* __restrict__
                                                            const T* __restrict__ dy, int dcs, int dco,
                                                            const T* __restrict__ y, int ycs, int yco,
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            long long M, int C, int relu, double* __restrict__ partial)
 {
     // block = RL row lanes x CG channel groups of V: every thread streams 16-byte loads, a wavefront covers 64 / CG rows x CG * 16 B
@@ -39,9 +53,14 @@ __global__ __launch_bounds__(256) void chan_partial_kernel(const T* __restrict__
 #pragma unroll
     for (int e = 0; e < V; ++e) { a[e] = 0.0; b[e] = 0.0; }
     if (c < C) {  // C % V == 0 is required by the callers
-        float mu[V], is[V];
+        float mu[V], is[V], ga[V], be[V];
 #pragma unroll
-        for (int e = 0; e < V; ++e) { mu[e] = MODE == 1 ? mean[c + e] : 0.f; is[e] = MODE == 1 ? invstd[c + e] : 0.f; }
+        for (int e = 0; e < V; ++e) {
+            mu[e] = MODE == 1 ? mean[c + e] : 0.f;
+            is[e] = MODE == 1 ? invstd[c + e] : 0.f;
+            ga[e] = (MODE == 1 && relu == 2) ? gamma[c + e] : 0.f;
+            be[e] = (MODE == 1 && relu == 2) ? beta[c + e] : 0.f;
+        }
         // four rows per iteration: all loads of the group are issued before the first dependent use (memory-level
         // parallelism - the kernel is latency-bound otherwise); rows past the end are clamped and contribute zero
         for (long long m0 = m_lo + rl; m0 < m_hi; m0 += 4 * RL) {
@@ -55,7 +74,7 @@ __global__ __launch_bounds__(256) void chan_partial_kernel(const T* __restrict__
                 rd_ldv<T, V>(x + m * xcs + xco + c, xv[u]);
                 if (MODE == 1) {
                     rd_ldv<T, V>(dy + m * dcs + dco + c, g[u]);
-                    if (relu) rd_ldv<T, V>(y + m * ycs + yco + c, yv[u]);
+                    if (relu == 1) rd_ldv<T, V>(y + m * ycs + yco + c, yv[u]);
                 }
             }
 #pragma unroll
@@ -71,7 +90,8 @@ __global__ __launch_bounds__(256) void chan_partial_kernel(const T* __restrict__
 #pragma unroll
                     for (int e = 0; e < V; ++e) {
                         float ge = ok[u] ? g[u][e] : 0.f;
-                        if (relu) ge = yv[u][e] > 0.f ? ge : 0.f;
+                        if (relu == 1) ge = yv[u][e] > 0.f ? ge : 0.f;
+                        else if (relu == 2) ge = bn_stored_positive<T>(bn_fwd_value(xv[u][e], mu[e], is[e], ga[e], be[e])) ? ge : 0.f;
                         const float xh = (xv[u][e] - mu[e]) * is[e];
                         a[e] += (double)ge;
                         b[e] += (double)ge * (double)xh;
@@ -96,30 +116,30 @@ __global__ __launch_bounds__(256) void chan_partial_kernel(const T* __restrict__
 template <int MODE, typename T>
 static void chan_partial_launch(const T* x, int xcs, int xco, const T* dy, int dcs, int dco, const T* y, int ycs, int yco,
                                 const float* mean, const float* invstd, long long M, int C, int relu, double* scratch, int S,
-                                hipStream_t s)
+                                hipStream_t s, const float* gamma = nullptr, const float* beta = nullptr)
 {
     // 8 channels per thread when every operand slice allows 16-byte bf16 accesses
     const bool wide = sizeof(T) == 2 && C % 8 == 0 && xcs % 8 == 0 && xco % 8 == 0 &&
-                      (MODE == 0 || (dcs % 8 == 0 && dco % 8 == 0 && (!relu || (ycs % 8 == 0 && yco % 8 == 0))));
+                      (MODE == 0 || (dcs % 8 == 0 && dco % 8 == 0 && (relu != 1 || (ycs % 8 == 0 && yco % 8 == 0))));
     if constexpr (sizeof(T) == 2) {
         if (wide && C <= 64) {
             hipLaunchKernelGGL((chan_partial_kernel<MODE, T, 8, 8>), dim3((C + 63) / 64, S), dim3(256), 0, s, x, xcs, xco, dy, dcs, dco, y,
-                               ycs, yco, mean, invstd, M, C, relu, scratch);
+                               ycs, yco, mean, invstd, gamma, beta, M, C, relu, scratch);
             return;
         }
         if (wide) {
             hipLaunchKernelGGL((chan_partial_kernel<MODE, T, 8, 16>), dim3((C + 127) / 128, S), dim3(256), 0, s, x, xcs, xco, dy, dcs, dco, y,
-                               ycs, yco, mean, invstd, M, C, relu, scratch);
+                               ycs, yco, mean, invstd, gamma, beta, M, C, relu, scratch);
             return;
         }
     }
     if (C <= 32) {
         hipLaunchKernelGGL((chan_partial_kernel<MODE, T, 4, 8>), dim3((C + 31) / 32, S), dim3(256), 0, s, x, xcs, xco, dy, dcs, dco, y, ycs,
-                           yco, mean, invstd, M, C, relu, scratch);
+                           yco, mean, invstd, gamma, beta, M, C, relu, scratch);
         return;
     }
     hipLaunchKernelGGL((chan_partial_kernel<MODE, T, 4, 16>), dim3((C + 63) / 64, S), dim3(256), 0, s, x, xcs, xco, dy, dcs, dco, y, ycs,
-                       yco, mean, invstd, M, C, relu, scratch);
+                       yco, mean, invstd, gamma, beta, M, C, relu, scratch);
 }
 
 // channels per workgroup of the variant chan_partial_launch picks (for the split count)
@@ -282,7 +302,7 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, int xcs, int xco, const
         float v[V], o[V];
         rd_ldv<T, V>(x + m * xcs + xco + c, v);
 #pragma unroll
-        for (int e = 0; e < V; ++e) o[e] = (v[e] - mean[c + e]) * invstd[c + e] * gamma[c + e] + beta[c + e];
+        for (int e = 0; e < V; ++e) o[e] = bn_fwd_value(v[e], mean[c + e], invstd[c + e], gamma[c + e], beta[c + e]);
         if (res) {
             float r[V];
             rd_ldv<T, V>(res + m * rcs + rco + c, r);
@@ -335,16 +355,18 @@ extern "C" int rdpn6d_bn_apply_bf16(const void* x, int xcs, int xco, const float
 }
 
 // ---------------------------------------------------------------------------------------------
-// BN backward.  g = dy * (y > 0) when the BN was followed by ReLU.
+// BN backward.  g = dy * (y > 0) when the BN was followed by ReLU: relu == 1 reads the stored activation y; relu == 2 (no residual
+// between the BN and its ReLU) re-derives the mask from x - bn_fwd_value, rounded as it was stored - and never touches y: one
+// tensor read less in the reduction pass and in the apply pass (the head's seven 67-MB activations and the stem's, at B = 32).
 //   dgamma = sum g*xhat, dbeta = sum g
 //   dx = gamma*invstd * (g - dbeta/M - xhat*dgamma/M);   dres (optional) = g  (identity branch of a residual block)
 template <typename T, int V>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ x, int xcs, int xco, const T* __restrict__ dy, int dcs, int dco,
                                     const T* __restrict__ y, int ycs, int yco, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                    const float* __restrict__ dgamma, const float* __restrict__ dbeta,
-                                    T* __restrict__ dx, int xgcs, int xgco, T* __restrict__ dres, int rcs, int rco,
-                                    long long M, int C, int relu)
+                                    const float* __restrict__ beta, const float* __restrict__ dgamma,
+                                    const float* __restrict__ dbeta, T* __restrict__ dx, int xgcs, int xgco,
+                                    T* __restrict__ dres, int rcs, int rco, long long M, int C, int relu)
 {
     const int CV = C / V;
     const long long total = M * CV;
@@ -355,11 +377,15 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ x, int xcs, int xco, c
         float xv[V], g[V], o[V];
         rd_ldv<T, V>(x + m * xcs + xco + c, xv);
         rd_ldv<T, V>(dy + m * dcs + dco + c, g);
-        if (relu) {
+        if (relu == 1) {
             float yv[V];
             rd_ldv<T, V>(y + m * ycs + yco + c, yv);
 #pragma unroll
             for (int e = 0; e < V; ++e) g[e] = yv[e] > 0.f ? g[e] : 0.f;
+        } else if (relu == 2) {
+#pragma unroll
+            for (int e = 0; e < V; ++e)
+                g[e] = bn_stored_positive<T>(bn_fwd_value(xv[e], mean[c + e], invstd[c + e], gamma[c + e], beta[c + e])) ? g[e] : 0.f;
         }
 #pragma unroll
         for (int e = 0; e < V; ++e) {
@@ -374,25 +400,28 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ x, int xcs, int xco, c
 template <typename T>
 static int bn_backward_impl(const T* x, int xcs, int xco, const T* dy, int dcs, int dco, const T* y, int ycs, int yco,
                             const float* mean, const float* invstd, const float* gamma, float* dgamma, float* dbeta, T* dx, int xgcs,
-                            int xgco, T* dres, int rcs, int rco, long long M, int C, int relu, double* scratch, void* stream)
+                            int xgco, T* dres, int rcs, int rco, long long M, int C, int relu, double* scratch, void* stream,
+                            const float* beta = nullptr)
 {
     RD_REQUIRE(x && dy && mean && invstd && gamma && dgamma && dbeta && dx && scratch, "null pointer");
-    RD_REQUIRE(!relu || y, "ReLU mask needs the forward output");
+    RD_REQUIRE(relu >= 0 && relu <= 2, "relu: 0 none, 1 mask from y, 2 mask re-derived from x");
+    RD_REQUIRE(relu != 1 || y, "ReLU mask needs the forward output");
+    RD_REQUIRE(relu != 2 || beta, "re-deriving the ReLU mask needs beta");
     RD_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "shape");
     const int S = pick_splits(M, C, chan_cb<T>(C));
     hipStream_t s = (hipStream_t)stream;
-    chan_partial_launch<1, T>(x, xcs, xco, dy, dcs, dco, y, ycs, yco, mean, invstd, M, C, relu, scratch, S, s);
+    chan_partial_launch<1, T>(x, xcs, xco, dy, dcs, dco, y, ycs, yco, mean, invstd, M, C, relu, scratch, S, s, gamma, beta);
     RD_LAUNCH_CHECK();
     // partial = (sum g, sum g*xhat) -> dbeta, dgamma
     hipLaunchKernelGGL(chan_sum_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, s, scratch, S, C, dbeta, dgamma, 0);
     RD_LAUNCH_CHECK();
     if constexpr (sizeof(T) == 2) {
         if (C % 8 == 0 && xcs % 8 == 0 && xco % 8 == 0 && dcs % 8 == 0 && dco % 8 == 0 && xgcs % 8 == 0 && xgco % 8 == 0 &&
-            (!relu || (ycs % 8 == 0 && yco % 8 == 0)) && (!dres || (rcs % 8 == 0 && rco % 8 == 0))) {
+            (relu != 1 || (ycs % 8 == 0 && yco % 8 == 0)) && (!dres || (rcs % 8 == 0 && rco % 8 == 0))) {
             const long long total8 = M * (C / 8);
             const int blocks8 = (int)((total8 + 255) / 256 < 16384 ? (total8 + 255) / 256 : 16384);
             hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 8>), dim3(blocks8), dim3(256), 0, s, x, xcs, xco, dy, dcs, dco, y, ycs, yco, mean,
-                               invstd, gamma, dgamma, dbeta, dx, xgcs, xgco, dres, rcs, rco, M, C, relu);
+                               invstd, gamma, beta, dgamma, dbeta, dx, xgcs, xgco, dres, rcs, rco, M, C, relu);
             RD_LAUNCH_CHECK();
             return RDPN6D_OK;
         }
@@ -400,7 +429,7 @@ static int bn_backward_impl(const T* x, int xcs, int xco, const T* dy, int dcs, 
     const long long total = M * (C / 4);
     const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 4>), dim3(blocks), dim3(256), 0, s, x, xcs, xco, dy, dcs, dco, y, ycs, yco, mean, invstd,
-                       gamma, dgamma, dbeta, dx, xgcs, xgco, dres, rcs, rco, M, C, relu);
+                       gamma, beta, dgamma, dbeta, dx, xgcs, xgco, dres, rcs, rco, M, C, relu);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
 }
@@ -420,6 +449,22 @@ extern "C" int rdpn6d_bn_backward_bf16(const void* x, int xcs, int xco, const vo
     return bn_backward_impl<rd_bf16_t>((const rd_bf16_t*)x, xcs, xco, (const rd_bf16_t*)dy, dcs, dco, (const rd_bf16_t*)y, ycs, yco, mean,
                                        invstd, gamma, dgamma, dbeta, (rd_bf16_t*)dx, xgcs, xgco, (rd_bf16_t*)dres, rcs, rco, M, C, relu,
                                        scratch, stream);
+}
+
+// BN + ReLU backward without the stored activation (relu == 2 above): the mask is sign(bn_fwd_value(x)) as the forward stored it
+extern "C" int rdpn6d_bn_relu_backward_f32(const float* x, int xcs, int xco, const float* dy, int dcs, int dco, const float* mean,
+                                           const float* invstd, const float* gamma, const float* beta, float* dgamma, float* dbeta,
+                                           float* dx, int xgcs, int xgco, long long M, int C, double* scratch, void* stream)
+{
+    return bn_backward_impl<float>(x, xcs, xco, dy, dcs, dco, nullptr, 0, 0, mean, invstd, gamma, dgamma, dbeta, dx, xgcs, xgco, nullptr, 0,
+                                   0, M, C, 2, scratch, stream, beta);
+}
+extern "C" int rdpn6d_bn_relu_backward_bf16(const void* x, int xcs, int xco, const void* dy, int dcs, int dco, const float* mean,
+                                            const float* invstd, const float* gamma, const float* beta, float* dgamma, float* dbeta,
+                                            void* dx, int xgcs, int xgco, long long M, int C, double* scratch, void* stream)
+{
+    return bn_backward_impl<rd_bf16_t>((const rd_bf16_t*)x, xcs, xco, (const rd_bf16_t*)dy, dcs, dco, nullptr, 0, 0, mean, invstd, gamma,
+                                       dgamma, dbeta, (rd_bf16_t*)dx, xgcs, xgco, nullptr, 0, 0, M, C, 2, scratch, stream, beta);
 }
 
 // ---------------------------------------------------------------------------------------------

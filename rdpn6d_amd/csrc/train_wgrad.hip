@@ -12,6 +12,7 @@
 //   order (deterministic, no atomics).
 // Backward of nn.Conv2d / nn.ConvTranspose2d / nn.Linear weights in core/gdrn_modeling/models/*.py.
 #include "common.h"
+#include <cstdlib>
 
 struct WgradKArgs {
     const float* A;
@@ -234,10 +235,9 @@ __device__ __forceinline__ rd_s16x4 lds_tr_b64(const void* p)
 // PL = 3: bf16x3 form (fp32-accurate, see conv_igemm_bf16x3.hip): both operands as three bf16 planes (plane strides
 // a_plane / b_plane bytes), six MFMAs per k16 step and tile pair; one k16 step (16 pixels) per chunk so that the three
 // stages x three planes of a 128x128 tile fit 72 KiB (two workgroups per CU).
-template <int BA, int BB, int PL>
-__global__ __launch_bounds__(256, PL == 1 ? 3 : 2) void wgrad_bf16_kernel(const WgradBArgs a)
+template <int BA, int BB, int PL, int KS = (PL == 1 ? 2 : 1)>  // KS: k16 MFMA steps per chunk
+__global__ __launch_bounds__(256, (PL == 1 && BA <= 128) ? 3 : 2) void wgrad_bf16_kernel(const WgradBArgs a)
 {
-    constexpr int KS = PL == 1 ? 2 : 1;          // k16 MFMA steps per chunk
     constexpr int KP = 16 * KS;                  // pixels per chunk
     constexpr int TA = BA / 64, TB = BB / 64;    // 32x32 tiles per wave (2x2 waves)
     constexpr int NST = 3;
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256, PL == 1 ? 3 : 2) void wgrad_bf16_kernel(const 
     constexpr int AROWS = 64 / ACH, BROWS = 64 / BCH;             // rows per piece (4 | 8)
     constexpr int APIECES = KP / AROWS / 4, BPIECES = KP / BROWS / 4;
     static_assert(APIECES >= 1 && BPIECES >= 1, "chunk / tile layout");
-    auto swz = [](int row, int ch) { return ch == 16 ? 4 * (row & 3) : 4 * ((row >> 1) & 1); };
+    auto swz = [](int row, int ch) { return ch >= 16 ? 4 * (row & 3) : 4 * ((row >> 1) & 1); };  // (512-byte rows alias like 256-byte ones)
     const int ar = lane / ACH, aq = lane % ACH, br = lane / BCH, bq = lane % BCH;
 
     int b_ox[BPIECES], b_oy[BPIECES], b_bi[BPIECES];
@@ -658,11 +658,11 @@ extern "C" int rdpn6d_wgrad_f32_strided(const float* A, int a_cs, int a_co, int 
 
 // bf16 operands (compact NHWC copies, channel strides/offsets in elements, multiples of 8); Ca_ld / Cb_ld = readable
 // channels of the slices (>= Ca / Cb, zero beyond the real count); out / partial as rdpn6d_wgrad_f32
-template <int BA, int BB, int PL>
+template <int BA, int BB, int PL, int KS = (PL == 1 ? 2 : 1)>
 static int wgrad_bf16_launch(const WgradBArgs& a, dim3 grid, hipStream_t s)
 {
-    constexpr int lds = 3 * PL * (PL == 1 ? 32 : 16) * (BA + BB) * 2;
-    auto kern = wgrad_bf16_kernel<BA, BB, PL>;
+    constexpr int lds = 3 * PL * (16 * KS) * (BA + BB) * 2;
+    auto kern = wgrad_bf16_kernel<BA, BB, PL, KS>;
     if (lds > 64 * 1024) {
         RD_LDS_OPT_IN(kern, lds);
     }
@@ -706,17 +706,43 @@ static int wgrad_bf16_impl(const void* A, int a_cs, int a_co, int Ca, int Ca_ld,
     RD_REQUIRE(ab < (1LL << 32) - 256 && bb_ < (1LL << 32) - 256, "operands must be smaller than 4 GiB (32-bit buffer offsets)");
     a.a_bytes = (unsigned)ab; a.b_bytes = (unsigned)bb_;
     a.a_plane = (unsigned)(a_plane_elems * 2); a.b_plane = (unsigned)(b_plane_elems * 2);
-    const int ba = Ca > 64 ? 128 : 64, bb = Cb > 64 ? 128 : 64;
+    int ba = Ca > 64 ? 128 : 64;
+    const int bb = Cb > 64 ? 128 : 64;
     a.atiles = (Ca + ba - 1) / ba;
     a.btiles = (Cb + bb - 1) / bb;
-    const int tiles = a.atiles * a.btiles * ntaps;
-    const int S = wgrad_pick_splits(a.M, tiles, ba, bb);  // same split count (and scratch size) as the fp32 form
+    int tiles = a.atiles * a.btiles * ntaps;
+    int S = wgrad_pick_splits(a.M, tiles, ba, bb);  // same split count (and scratch size) as the fp32 form
+    // 256 x 128 tile (2x2 waves of 128 x 64, one k16 step per chunk) for the wide layers with many pixels - the head's 256 -> 256 and
+    // the ConvTranspose: a quarter fewer bytes through LDS-DMA per FLOP (the launch moves ~2.4 GB L2 -> LDS, > 10 TB/s), 12 transpose
+    // reads per 8 MFMAs instead of 8 per 4, half the partial tiles: head layer at B = 32 247 -> 228 us, 1x1 512 -> 256 at 32^2 46 -> 42;
+    // with few pixels (layer3 / layer4: 8 192 / 2 048) the halved workgroup count costs more (43 -> 47 us).  Never more splits than
+    // the scratch was sized for.
+    static const bool wide_off = getenv("RDPN6D_WGRAD_WIDE") && atoi(getenv("RDPN6D_WGRAD_WIDE")) == 0;  // profiling
+    if (!x3 && !wide_off && Ca % 256 == 0 && bb == 128 && a.M >= 32768) {
+        const int t2 = (Ca / 256) * a.btiles * ntaps;
+        // the FEWEST splits that fill whole rounds of the 512 resident workgroups to >= 97 % (every split costs one partial tile
+        // written and read again by the reduce: 2.4 MB for a head layer), else the best fill
+        int best = 1;
+        double best_util = 0.0;
+        for (int sp = 1; sp <= S; ++sp) {
+            if ((a.M + sp - 1) / sp < 512) break;  // >= 32 chunks of 16 pixels per split
+            const long long blocks = (long long)sp * t2, rounds = (blocks + 511) / 512;
+            const double util = (double)blocks / (double)(rounds * 512);
+            if (util > best_util + 1e-9) { best_util = util; best = sp; }
+            if (util >= 0.97) break;
+        }
+        ba = 256;
+        a.atiles = Ca / 256;
+        tiles = t2;
+        S = best;
+    }
     a.rows_per_split = ((a.M + S - 1) / S + 31) / 32 * 32;
     hipStream_t s = (hipStream_t)stream;
     a.nsplit = S;
     dim3 grid(tiles * S);
     int rc;
     if (x3) rc = wgrad_bf16_launch<128, 128, 3>(a, grid, s);
+    else if (ba == 256) rc = wgrad_bf16_launch<256, 128, 1, 1>(a, grid, s);  // (two k16 steps per chunk spill: 269 vs 228 us)
     else if (ba == 128 && bb == 128) rc = wgrad_bf16_launch<128, 128, 1>(a, grid, s);
     else if (ba == 128) rc = wgrad_bf16_launch<128, 64, 1>(a, grid, s);
     else if (bb == 128) rc = wgrad_bf16_launch<64, 128, 1>(a, grid, s);

@@ -17,6 +17,7 @@ PyTorch is used for memory, for the (tiny, once per step) weight re-packing and 
 gradient tiles into ``param.grad`` layout.  Gradients of all 164 parameter tensors are produced.
 """
 import ctypes
+import os
 
 import torch
 
@@ -57,6 +58,9 @@ class TrainEngine:
         # fp32 training: forward and input-gradient convolutions of the wide head layers as fp32-accurate bf16x3 convolutions
         # (csrc/conv_igemm_bf16x3.hip) when the batch fills the chip; cfg.SOLVER.BF16X3 = False keeps them on the fp32 MFMA
         self.x3 = (not self.amp) and bool(model.cfg.get("SOLVER", {}).get("BF16X3", True))
+        # BatchNorm + ReLU backward without the stored activation (the mask is re-derived from the BN input: csrc/train_norm.hip,
+        # rdpn6d_bn_relu_backward_*): one tensor read less in both backward passes of every BN that has no residual before its ReLU
+        self.bn_remask = bool(model.cfg.get("SOLVER", {}).get("BN_REMASK", os.environ.get("RDPN6D_BN_REMASK", "1") != "0"))
         self.x3_launches = 0
         cfg = model.cfg
         self.R = int(cfg.MODEL.CDPN.BACKBONE.INPUT_RES)
@@ -487,8 +491,16 @@ class TrainEngine:
             dy_co = 0
         assert C % 4 == 0
 
+        remask = relu and res is None and dres is None and self.bn_remask
+        f_bwd_remask = getattr(lib, f"rdpn6d_bn_relu_backward_{t}")
+
         def bwd():
             # dgamma / dbeta land directly in the parameters' gradients (C entries each, also read back by the dx pass)
+            if remask:
+                _lib.check(f_bwd_remask(_ptr(x_raw), cs, co, _ptr(dy), dy_cs, dy_co, _ptr(mean), _ptr(invstd), _ptr(ga), _ptr(be),
+                                        _ptr(self._grad(bn.weight)), _ptr(self._grad(bn.bias)), _ptr(dx), cs, co, M, C,
+                                        _ptr(self._scratch_d), self.st()), "bn+relu bwd " + name)
+                return
             _lib.check(f_bwd(_ptr(x_raw), cs, co, _ptr(dy), dy_cs, dy_co, _ptr(y), ycs, yco, _ptr(mean), _ptr(invstd), _ptr(ga),
                              _ptr(self._grad(bn.weight)), _ptr(self._grad(bn.bias)), _ptr(dx), cs, co, _ptr(dres),
                              (dres.shape[-1] if dres is not None else 0), 0, M, C, 1 if relu else 0, _ptr(self._scratch_d), self.st()),

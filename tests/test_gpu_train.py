@@ -291,6 +291,60 @@ def test_amp_reference_loop_loss_goes_down(golden_dir):
     assert hist[-1] < hist[0]
 
 
+@pytest.mark.parametrize("t", ["f32", "bf16", "fp16"])
+@pytest.mark.parametrize("M,C", [(5000, 64), (4099, 128), (777, 36)])
+def test_bn_relu_backward_without_the_stored_activation_is_bit_identical(t, M, C):
+    """rdpn6d_bn_relu_backward_* re-derives the ReLU mask from the BN input (same expression and rounding as the forward's store)
+    instead of reading the stored activation: dgamma, dbeta and dx must equal rdpn6d_bn_backward_*(relu=1) bit for bit, and agree
+    with autograd."""
+    import ctypes
+    from rdpn6d_amd import _lib
+    from rdpn6d_amd.gdrn import _ptr
+
+    if t != "f32" and C % 8:
+        pytest.skip("16-bit slices are multiples of 8 channels")
+    lib, dev = _lib.load(), torch.device("cuda:0")
+    dt = {"f32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[t]
+    g = torch.Generator().manual_seed(M + C)
+    x = torch.randn(M, C, generator=g).to(dev).to(dt)
+    dy = torch.randn(M, C, generator=g).to(dev).to(dt)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(dev)
+    gamma[::7] *= -1.0  # negative scales flip which side of the mean survives the ReLU
+    beta = (0.3 * torch.randn(C, generator=g)).to(dev)
+    beta[:4] = 0.0
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    mean, istd, rm, rv = (torch.zeros(C, device=dev) for _ in range(4))
+    scr = torch.empty(512 * 1024 * 2 + 4096, dtype=torch.float64, device=dev)
+    _lib.check(getattr(lib, f"rdpn6d_bn_train_stats_{t}")(_ptr(x), M, C, C, 0, 1e-5, 0.1, _ptr(mean), _ptr(istd), _ptr(rm), _ptr(rv), _ptr(scr), st))
+    y = torch.empty_like(x)
+    _lib.check(getattr(lib, f"rdpn6d_bn_apply_{t}")(_ptr(x), C, 0, _ptr(mean), _ptr(istd), _ptr(gamma), _ptr(beta), None, 0, 0, _ptr(y), C, 0, M, C, 1, st))
+    outs = []
+    for remask in (False, True):
+        dg, db = torch.full((C,), 3.0, device=dev), torch.full((C,), 3.0, device=dev)
+        dx = torch.empty_like(x)
+        if remask:
+            _lib.check(getattr(lib, f"rdpn6d_bn_relu_backward_{t}")(_ptr(x), C, 0, _ptr(dy), C, 0, _ptr(mean), _ptr(istd), _ptr(gamma), _ptr(beta),
+                                                                    _ptr(dg), _ptr(db), _ptr(dx), C, 0, M, C, _ptr(scr), st))
+        else:
+            _lib.check(getattr(lib, f"rdpn6d_bn_backward_{t}")(_ptr(x), C, 0, _ptr(dy), C, 0, _ptr(y), C, 0, _ptr(mean), _ptr(istd), _ptr(gamma),
+                                                               _ptr(dg), _ptr(db), _ptr(dx), C, 0, None, 0, 0, M, C, 1, _ptr(scr), st))
+        torch.cuda.synchronize()
+        outs.append((dg.clone(), db.clone(), dx.clone()))
+    assert (y == 0).float().mean().item() > 0.2  # the mask matters
+    for a, b, n in zip(outs[0], outs[1], ("dgamma", "dbeta", "dx")):
+        assert torch.equal(a, b), n
+    # autograd (fp64) on the same stored operands
+    xd = x.double().cpu().requires_grad_(True)
+    gd, bd = gamma.double().cpu().requires_grad_(True), beta.double().cpu().requires_grad_(True)
+    yr = torch.relu(torch.nn.functional.batch_norm(xd, None, None, gd, bd, training=True, eps=1e-5))
+    yr.backward(dy.double().cpu())
+    tol = 2e-5 if t == "f32" else 2e-2
+    for a, ref, n in zip(outs[1], (gd.grad, bd.grad, xd.grad), ("dgamma", "dbeta", "dx")):
+        err = (a.double().cpu() - ref).abs() / (ref.abs().max().item() + 1e-30)
+        # (a pre-activation within round-off of zero may take the other ReLU branch in fp64: a handful of elements at most)
+        assert (err > tol).double().mean().item() < 1e-5 and err.median().item() < tol / 10, (n, err.max().item())
+
+
 @pytest.mark.parametrize("case", [
     # Bn, Ha, Hb, stride, Ca, Cb, k
     (2, 16, 16, 1, 128, 128, 3),
@@ -298,6 +352,8 @@ def test_amp_reference_loop_loss_goes_down(golden_dir):
     (2, 16, 16, 1, 64, 96, 1),     # Cb not a multiple of the tile, 1x1
     (1, 64, 64, 1, 256, 256, 3),   # several tiles, several splits
     (5, 7, 7, 1, 36, 68, 3),       # ragged everything (channels multiples of 4 only)
+    (8, 64, 64, 1, 256, 96, 3),    # >= 32 768 pixels, 256 gradient channels: the 256 x 128 tile (ragged Cb)
+    (8, 64, 128, 2, 512, 128, 1),  # the same tile, two A tiles, stride 2
 ])
 def test_wgrad_bf16_vs_fp32_kernel(case):
     """bf16 weight-gradient kernel (transpose LDS reads) vs the fp32 kernel on the same bf16-valued operands: products are exact

@@ -67,6 +67,7 @@ def bench(name, H, Cin, Cout, k, stride, tiles=None, reps=20):
     fl = 2.0 * B * Ho * Ho * Cout * k * k * Cin
     lib.rdpn6d_conv_bf16_force_tile(0, 0)
     print(f"{name:34s} tile {bm.value:3d}x{bn.value:3d} {ms*1e3:9.1f} us  {fl/ms/1e9:7.1f} TF/s  ({fl/ms/1e9/2500*100:5.1f}% of bf16 MFMA peak)")
+if os.environ.get("NST"): lib.rdpn6d_conv_bf16_force_stages(int(os.environ["NST"]))  # profiling: LDS stages of the 4-wave tiles
 for s in SHAPES: check(*s)
 for s in SHAPES: bench(*s)
 if os.environ.get("SWEEP"):
