@@ -97,6 +97,11 @@ void rdpn6d_conv_set_tap_inner(int v);
 int rdpn6d_conv2d_bf16(const rdpn6d_conv_desc* d, int out_f32, void* stream);
 /* split-K form, as rdpn6d_conv2d_splitk_f32 (same workspace size, linear output geometry) */
 int rdpn6d_conv2d_splitk_bf16(const rdpn6d_conv_desc* d, int out_f32, int ksplit, float* workspace, void* stream);
+/* Training forward of a conv + BatchNorm pair: the convolution (16-bit output, no split-K) whose epilogue also writes the BatchNorm
+ * statistics' partial sums - per channel (sum, sum of squares) of the values AS STORED, rows stats_row0 .. stats_row0 + *stats_rows - 1
+ * of a [rows][N][2] double array.  *stats_rows = 0: the geometry does not allow it (ragged tiles, unaligned slices), the convolution ran
+ * normally and the caller uses rdpn6d_bn_train_stats_bf16.  rdpn6d_bn_stats_finalize (below) finishes the statistics. */
+int rdpn6d_conv2d_bf16_bnstats(const rdpn6d_conv_desc* d, double* stats, int stats_row0, int* stats_rows, void* stream);
 void rdpn6d_conv_bf16_force_tile(int bm, int bn);
 /* profiling: LDS stages of the 4-wave tiles (0 = the heuristic: 3 for 64x64 tiles with >= 64 K-chunks, else 2) */
 void rdpn6d_conv_bf16_force_stages(int nst);
@@ -277,6 +282,10 @@ int rdpn6d_stem_conv7x7_raw_f32(const float* x, int B, int xc, int R, const floa
  * running stats updated with `momentum` (unbiased var) when given.  scratch >= 512*C*2 doubles. */
 int rdpn6d_bn_train_stats_f32(const float* x, long long M, int C, int cs, int co, float eps, float momentum, float* mean,
                               float* invstd, float* running_mean, float* running_var, double* scratch, void* stream);
+/* the second half of rdpn6d_bn_train_stats_*: mean / invstd / running statistics from S rows [S][C][2] of per-channel (sum, sum of
+ * squares) partials over M values per channel */
+int rdpn6d_bn_stats_finalize(const double* partial, int S, int C, long long M, float eps, float momentum, float* mean, float* invstd,
+                             float* running_mean, float* running_var, void* stream);
 /* y = act((x-mean)*invstd*gamma + beta (+ res)) */
 int rdpn6d_bn_apply_f32(const float* x, int xcs, int xco, const float* mean, const float* invstd, const float* gamma,
                         const float* beta, const float* res, int rcs, int rco, float* y, int ycs, int yco, long long M, int C,
@@ -463,6 +472,7 @@ int rdpn6d_crop_builder_f32(const unsigned char* images, const float* depths, in
  * Selected by cfg.SOLVER.AMP.DTYPE / cfg.TEST.AMP_DTYPE = "fp16" (default "bf16"). */
 int rdpn6d_conv2d_fp16(const rdpn6d_conv_desc* d, int out_f32, void* stream);
 int rdpn6d_conv2d_splitk_fp16(const rdpn6d_conv_desc* d, int out_f32, int ksplit, float* workspace, void* stream);
+int rdpn6d_conv2d_fp16_bnstats(const rdpn6d_conv_desc* d, double* stats, int stats_row0, int* stats_rows, void* stream);
 void rdpn6d_conv_fp16_force_tile(int bm, int bn);
 void rdpn6d_conv_fp16_force_stages(int nst);
 int rdpn6d_conv_fp16_tile_for(const rdpn6d_conv_desc* d, int* bm, int* bn);

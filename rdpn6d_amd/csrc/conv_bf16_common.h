@@ -18,6 +18,11 @@ struct ConvBArgs {
     int kper;        // split-K: K-chunks per split (blockIdx.y = split); nk when not split
     float* partial;  // split-K: raw fp32 accumulators [split][M][Npad]; nullptr = fused epilogue
     int vec_out;  // 16-byte aligned output / residual channel slices: coalesced epilogue through LDS
+    // Training forward (rdpn6d_conv2d_bf16_bnstats): per-channel (sum, sum of squares) of the STORED 16-bit results, one row of
+    // [N][2] doubles per wave row of an M tile (row = stats_row0 + mtile * WM + wm) - the BatchNorm statistics' partial sums
+    // without a second pass over the tensor.  Only the coalesced epilogue writes them (the launcher checks the geometry).
+    double* stats = nullptr;
+    int stats_row0 = 0;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -79,6 +84,7 @@ __device__ __forceinline__ void conv_bf16_epilogue_vec(const ConvBArgs& a, f32x1
             scj[j] = d.scale ? d.scale[n] : 1.f;
             shj[j] = d.shift ? d.shift[n] : 0.f;
         }
+        float st1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, st2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // a.stats
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -126,7 +132,38 @@ __device__ __forceinline__ void conv_bf16_epilogue_vec(const ConvBArgs& a, f32x1
                         for (int q = 0; q < 8; ++q) v[q] += rv[q];
                     }
                     conv_bf16_act(v, d.act, d.slope);
-                    *reinterpret_cast<rd_u32x4*>(yb + pix * d.out_cs + d.out_co + nb + c8) = rd_pack8(v);
+                    const rd_u32x4 pk = rd_pack8(v);
+                    *reinterpret_cast<rd_u32x4*>(yb + pix * d.out_cs + d.out_co + nb + c8) = pk;
+                    if (a.stats) {  // of the values as stored (what a BatchNorm reading the tensor would see)
+                        float r[8];
+                        rd_unpack8(pk, r);
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            st1[q] += r[q];
+                            st2[q] += r[q] * r[q];
+                        }
+                    }
+                }
+            }
+        }
+        if (a.stats && !a.out_f32) {
+            // lanes with the same (lane % LPR) hold the same 8 channels of different rows: a fixed butterfly over the row-lane bits,
+            // then lanes 0 .. LPR-1 write the wave's row of partial sums (<= (BM / WM) values per sum in fp32, fp64 from here on)
+            constexpr int LPR = WC / 8;
+#pragma unroll
+            for (int off = LPR; off < 64; off <<= 1)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    st1[q] += __shfl_xor(st1[q], off, 64);
+                    st2[q] += __shfl_xor(st2[q], off, 64);
+                }
+            if (lane < LPR) {
+                const long long row = a.stats_row0 + (m0 / BM) * WM + wm;
+                double* p = a.stats + (row * d.N + nb + lane * 8) * 2;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    p[2 * q] = (double)st1[q];
+                    p[2 * q + 1] = (double)st2[q];
                 }
             }
         }

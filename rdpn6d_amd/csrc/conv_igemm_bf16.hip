@@ -320,7 +320,8 @@ static int conv_bf16_launch(const ConvBArgs& a, int bm, int bn, int nsplit, hipS
     return conv_bf16_launch_one<64, 64, RB, 2, 2, 2>(a, nsplit, s);
 }
 
-static int conv2d_bf16_impl(const rdpn6d_conv_desc* d, int out_f32, int ksplit, float* workspace, void* stream);
+static int conv2d_bf16_impl(const rdpn6d_conv_desc* d, int out_f32, int ksplit, float* workspace, void* stream, double* stats = nullptr,
+                            int stats_row0 = 0, int* stats_rows = nullptr);
 
 extern "C" int rdpn6d_conv2d_bf16(const rdpn6d_conv_desc* d, int out_f32, void* stream)
 {
@@ -334,7 +335,18 @@ extern "C" int rdpn6d_conv2d_splitk_bf16(const rdpn6d_conv_desc* d, int out_f32,
     return conv2d_bf16_impl(d, out_f32, ksplit, workspace, stream);
 }
 
-static int conv2d_bf16_impl(const rdpn6d_conv_desc* d, int out_f32, int ksplit, float* workspace, void* stream)
+// Training forward: the convolution + the per-channel partial sums of the BatchNorm that follows it, written by the epilogue
+// (see ConvBArgs::stats).  stats: [stats_row0 + rows][N][2] doubles; *stats_rows = the rows this launch wrote, or 0 when the geometry
+// does not allow it (ragged tiles, unaligned slices, fp32 output) - the convolution ran normally and the caller falls back to
+// rdpn6d_bn_train_stats_bf16.  rdpn6d_bn_stats_finalize turns the rows into mean / invstd / running statistics.
+extern "C" int rdpn6d_conv2d_bf16_bnstats(const rdpn6d_conv_desc* d, double* stats, int stats_row0, int* stats_rows, void* stream)
+{
+    RD_REQUIRE(stats && stats_rows && stats_row0 >= 0, "stats buffer");
+    return conv2d_bf16_impl(d, 0, 1, nullptr, stream, stats, stats_row0, stats_rows);
+}
+
+static int conv2d_bf16_impl(const rdpn6d_conv_desc* d, int out_f32, int ksplit, float* workspace, void* stream, double* stats,
+                            int stats_row0, int* stats_rows)
 {
     RD_REQUIRE(d && d->x && d->w && d->y, "null pointer");
     RD_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0, "empty tensor");
@@ -383,6 +395,13 @@ static int conv2d_bf16_impl(const rdpn6d_conv_desc* d, int out_f32, int ksplit, 
         bm = bn = 128;
         a.mtiles = rd_cdiv(a.M, bm);
         a.ntiles = d->Npad / bn;
+    }
+    if (stats_rows) *stats_rows = 0;
+    if (stats && !out_f32 && a.vec_out && d->N == d->Npad && ksplit <= 1 && ((bm == 256 && bn == 256) || a.M % bm == 0)) {
+        // every tile takes the coalesced epilogue (full column tiles: bn divides Npad = N; full row tiles, or the 8-phase kernel's masked rows)
+        a.stats = stats;
+        a.stats_row0 = stats_row0;
+        *stats_rows = a.mtiles * ((bm == 256 && bn == 128) ? 4 : 2);  // wave rows per tile: WM of the launch below
     }
     if (bm == 256 && bn == 256) {
         RD_REQUIRE(conv_bf16_8ph_eligible(a, rb), "256x256 tile needs Cin % 64 == 0, Npad % 256 == 0 and an even K-tile count");

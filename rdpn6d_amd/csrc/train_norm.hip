@@ -10,7 +10,8 @@
 #include "common.h"
 #include <float.h>
 
-#define NS_MAX 128  // row splits of the partial reductions
+#define NS_MAX 512  // row splits of the partial reductions (the scratch contract: 512 * C * 2 doubles).  128 left a 131 072 x 256 tensor on 256
+                    // workgroups of 4 waves, sixteen dependent load rounds each: latency-bound at a third of the HBM rate
 
 // The normalised value of the forward pass, ONE expression for bn_apply_kernel and for the backward kernels that re-derive the ReLU
 // mask from x instead of reading the stored activation (relu == 2): the same operations in the same order, so the same sign.
@@ -207,6 +208,51 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const double* __
     }
 }
 
+// The same finalize for MANY partial rows (the convolution epilogues' rows: rdpn6d_conv2d_bf16_bnstats writes one per wave row of
+// an M tile - 1 024 for a head layer at B = 32): 32 split lanes x 8 channels per workgroup, fixed-order tree.
+__global__ __launch_bounds__(256) void bn_stats_finalize_rows_kernel(const double* __restrict__ partial, int S, int C, long long M,
+                                                                     float eps, float momentum, float* __restrict__ mean,
+                                                                     float* __restrict__ invstd, float* __restrict__ running_mean,
+                                                                     float* __restrict__ running_var)
+{
+    constexpr int SL = 32, CH = 8;
+    __shared__ double s_a[SL][CH], s_b[SL][CH];
+    const int cl = threadIdx.x % CH, sl = threadIdx.x / CH;
+    const int c = blockIdx.x * CH + cl;
+    const bool ok = c < C;
+    double a = 0.0, b = 0.0;
+    if (ok) {
+        const double* p = partial + (long long)c * 2;
+        const long long st = (long long)C * 2;
+        int k = sl;
+        for (; k + 3 * SL < S; k += 4 * SL) {
+            const double a0 = p[k * st], b0 = p[k * st + 1], a1 = p[(k + SL) * st], b1 = p[(k + SL) * st + 1];
+            const double a2 = p[(k + 2 * SL) * st], b2 = p[(k + 2 * SL) * st + 1], a3 = p[(k + 3 * SL) * st], b3 = p[(k + 3 * SL) * st + 1];
+            a += (a0 + a1) + (a2 + a3);
+            b += (b0 + b1) + (b2 + b3);
+        }
+        for (; k < S; k += SL) { a += p[k * st]; b += p[k * st + 1]; }
+    }
+    s_a[sl][cl] = a; s_b[sl][cl] = b;
+    __syncthreads();
+#pragma unroll
+    for (int w = SL / 2; w >= 1; w >>= 1) {
+        if (sl < w) { s_a[sl][cl] += s_a[sl + w][cl]; s_b[sl][cl] += s_b[sl + w][cl]; }
+        __syncthreads();
+    }
+    if (sl != 0 || !ok) return;
+    const double mu = s_a[0][cl] / (double)M;
+    double var = s_b[0][cl] / (double)M - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)mu;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
+        running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mu);
+        running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+    }
+}
+
 // Stage 2 for plain sums (bias gradients) and for BN backward (dgamma, dbeta).
 __global__ __launch_bounds__(256) void chan_sum_finalize_kernel(const double* __restrict__ partial, int S, int C,
                                                                 float* __restrict__ out_a, float* __restrict__ out_b,
@@ -260,6 +306,23 @@ extern "C" int rdpn6d_bn_train_stats_bf16(const void* x, long long M, int C, int
 {
     return bn_train_stats_impl<rd_bf16_t>((const rd_bf16_t*)x, M, C, cs, co, eps, momentum, mean, invstd, running_mean,
                                           running_var, scratch, stream);
+}
+
+// Stage 2 alone: mean / invstd / running statistics from S rows of per-channel (sum, sum of squares) partials [S][C][2] that somebody
+// else produced - the epilogue of the convolution in front of the BatchNorm (rdpn6d_conv2d_bf16_bnstats)
+extern "C" int rdpn6d_bn_stats_finalize(const double* partial, int S, int C, long long M, float eps, float momentum, float* mean,
+                                        float* invstd, float* running_mean, float* running_var, void* stream)
+{
+    RD_REQUIRE(partial && mean && invstd && S > 0 && C > 0 && M > 0, "arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (S > 64)
+        hipLaunchKernelGGL(bn_stats_finalize_rows_kernel, dim3((C + 7) / 8), dim3(256), 0, s, partial, S, C, M, eps, momentum, mean, invstd,
+                           running_mean, running_var);
+    else
+        hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, s, partial, S, C, M, eps, momentum, mean,
+                           invstd, running_mean, running_var);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
 }
 
 // per-channel sum of rows (bias gradient): out[c] (+)= sum_m x[m, co + c]

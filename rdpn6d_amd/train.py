@@ -60,6 +60,8 @@ class TrainEngine:
         self.x3 = (not self.amp) and bool(model.cfg.get("SOLVER", {}).get("BF16X3", True))
         # BatchNorm + ReLU backward without the stored activation (the mask is re-derived from the BN input: csrc/train_norm.hip,
         # rdpn6d_bn_relu_backward_*): one tensor read less in both backward passes of every BN that has no residual before its ReLU
+        # conv + BatchNorm pairs of the mixed-precision step: the convolution's epilogue writes the BatchNorm statistics' partial sums
+        self.bn_fuse_stats = bool(model.cfg.get("SOLVER", {}).get("BN_FUSE_STATS", os.environ.get("RDPN6D_BN_FUSE_STATS", "1") != "0"))
         self.bn_remask = bool(model.cfg.get("SOLVER", {}).get("BN_REMASK", os.environ.get("RDPN6D_BN_REMASK", "1") != "0"))
         self.x3_launches = 0
         cfg = model.cfg
@@ -89,6 +91,8 @@ class TrainEngine:
         self._scratch_d = torch.empty(512 * 1024 * 2 + 4096, dtype=torch.float64, device=device)
         self._wg_floats = 0
         self._build()
+        if getattr(self, "_scratch_need", 0) > self._scratch_d.numel():  # (every launch reads the pointer when it runs)
+            self._scratch_d = torch.empty(self._scratch_need, dtype=torch.float64, device=device)
         self._wg_partial = torch.empty(max(self._wg_floats, 1), dtype=torch.float32, device=device)
         self.refresh_weights()
 
@@ -222,8 +226,17 @@ class TrainEngine:
                 def run():
                     _lib.check(self.lpf("rdpn6d_conv2d_splitk_bf16")(ctypes.byref(d), of, ksb, _ptr(wsb), self.st()), name)
             else:
+                rows = ctypes.c_int(0)
+
                 def run():
-                    _lib.check(self.lpf("rdpn6d_conv2d_bf16")(ctypes.byref(d), of, self.st()), name)
+                    if run.bn_stats:  # a BatchNorm follows: its statistics' partial sums come out of this launch's epilogue (bn_unit)
+                        _lib.check(self.lpf("rdpn6d_conv2d_bf16_bnstats")(ctypes.byref(d), _ptr(self._scratch_d), 0, ctypes.byref(rows),
+                                                                          self.st()), name)
+                        run.stats_rows = rows.value
+                    else:
+                        _lib.check(self.lpf("rdpn6d_conv2d_bf16")(ctypes.byref(d), of, self.st()), name)
+
+                run.bn_capable, run.bn_stats, run.stats_rows, run.desc = not of, False, 0, d
 
             run.keep = (d, keep)
             return run
@@ -477,9 +490,26 @@ class TrainEngine:
         assert y.dtype == x_raw.dtype and (res is None or res.dtype == x_raw.dtype), name
         f_stats, f_apply, f_bwd = (getattr(lib, f"rdpn6d_bn_{n}_{t}") for n in ("train_stats", "apply", "backward"))
 
+        # The convolution that produced x_raw is the previous launch and wrote all of it in 16 bits: its epilogue also writes the
+        # statistics' partial sums (rdpn6d_conv2d_bf16_bnstats) and only the finalize is left here - no second pass over x_raw
+        prev = self.fwd[-1] if self.fwd else None
+        pd = getattr(prev, "desc", None)
+        fused = (self.bn_fuse_stats and getattr(prev, "bn_capable", False) and pd.y == x_raw.data_ptr() and pd.out_cs == cs
+                 and pd.out_co == co and pd.N == C and pd.B * pd.Ho * pd.Wo == M and (pd.OH, pd.OW) == (pd.Ho, pd.Wo))
+        if fused:
+            prev.bn_stats = True
+            # rows the launch can write at most: two wave rows per 64-row tile (the kernels report the real count at run time)
+            self._scratch_need = max(getattr(self, "_scratch_need", 0), ((M + 63) // 64) * 2 * C * 2)
+
         def fwd():
-            _lib.check(f_stats(_ptr(x_raw), M, C, cs, co, BN_EPS, BN_MOM, _ptr(mean), _ptr(invstd), _ptr(bn.running_mean),
-                               _ptr(bn.running_var), _ptr(self._scratch_d), self.st()), "bn stats " + name)
+            if fused and prev.stats_rows > 0:
+                assert prev.stats_rows * C * 2 <= self._scratch_d.numel(), name
+                _lib.check(lib.rdpn6d_bn_stats_finalize(_ptr(self._scratch_d), prev.stats_rows, C, M, BN_EPS, BN_MOM, _ptr(mean),
+                                                        _ptr(invstd), _ptr(bn.running_mean), _ptr(bn.running_var), self.st()),
+                           "bn stats (finalize) " + name)
+            else:
+                _lib.check(f_stats(_ptr(x_raw), M, C, cs, co, BN_EPS, BN_MOM, _ptr(mean), _ptr(invstd), _ptr(bn.running_mean),
+                                   _ptr(bn.running_var), _ptr(self._scratch_d), self.st()), "bn stats " + name)
             _lib.check(f_apply(_ptr(x_raw), cs, co, _ptr(mean), _ptr(invstd), _ptr(ga), _ptr(be), _ptr(res), res_cs, 0, _ptr(y), ycs, yco,
                                M, C, 1 if relu else 0, self.st()), "bn apply " + name)
 

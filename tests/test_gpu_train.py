@@ -345,6 +345,79 @@ def test_bn_relu_backward_without_the_stored_activation_is_bit_identical(t, M, C
         assert (err > tol).double().mean().item() < 1e-5 and err.median().item() < tol / 10, (n, err.max().item())
 
 
+@pytest.mark.parametrize("t", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", [
+    # B, H, Cin, Cout, k, stride -> the tile the launcher picks
+    (16, 64, 256, 256, 3, 1),  # 256 x 256 eight-phase kernel (head layers)
+    (8, 64, 64, 64, 3, 1),     # 128 x 64 (layer1)
+    (8, 32, 128, 128, 3, 1),   # 64 x 128 (layer2)
+    (8, 16, 256, 256, 3, 1),   # 64 x 64 (layer3)
+    (8, 32, 64, 128, 1, 2),    # 1x1 stride 2 (downsample)
+    (3, 9, 64, 64, 3, 1),      # 243 rows: ragged tiles -> no rows, the caller's fallback
+])
+def test_conv_epilogue_writes_the_batchnorm_partial_sums(t, case):
+    """rdpn6d_conv2d_*_bnstats: same 16-bit output as the plain convolution, bit for bit, and - after rdpn6d_bn_stats_finalize - the
+    BatchNorm statistics rdpn6d_bn_train_stats_* computes in a second pass over that output (summation order differs: 1e-6)."""
+    import ctypes
+    from rdpn6d_amd import _lib
+    from rdpn6d_amd.gdrn import _pad_to, _ptr, pack_conv_weight
+
+    lib, dev = _lib.load(), torch.device("cuda:0")
+    dt = torch.bfloat16 if t == "bf16" else torch.float16
+    B, H, Cin, Cout, k, stride = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, H, H, Cin, generator=g).to(dev).to(dt)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).to(dev)
+    wp = pack_conv_weight(w, cin_pad=_pad_to(Cin, 32)).to(dt)
+    pad = k // 2
+    Ho = (H + 2 * pad - k) // stride + 1
+    M = B * Ho * Ho
+    d = _lib.ConvDesc()
+    d.B, d.H, d.W, d.Cin, d.in_cs, d.in_co = B, H, H, Cin, Cin, 0
+    d.Ho, d.Wo, d.stride = Ho, Ho, stride
+    taps = [(ky - pad, kx - pad) for ky in range(k) for kx in range(k)]
+    d.ntaps = len(taps)
+    for i, (dy, dx) in enumerate(taps):
+        d.dy[i], d.dx[i] = dy, dx
+    d.N, d.Npad, d.OH, d.OW = Cout, wp.shape[0], Ho, Ho
+    d.osy = d.osx = 1
+    d.out_cs = Cout
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    y0, y1 = torch.empty(B, Ho, Ho, Cout, device=dev, dtype=dt), torch.empty(B, Ho, Ho, Cout, device=dev, dtype=dt)
+    d.x, d.w, d.y = _ptr(x), _ptr(wp), _ptr(y0)
+    _lib.check(getattr(lib, f"rdpn6d_conv2d_{t}")(ctypes.byref(d), 0, st))
+    d.y = _ptr(y1)
+    scr = torch.full((((M + 63) // 64) * 2 * Cout * 2 + 8,), float("nan"), dtype=torch.float64, device=dev)
+    rows = ctypes.c_int(-1)
+    _lib.check(getattr(lib, f"rdpn6d_conv2d_{t}_bnstats")(ctypes.byref(d), _ptr(scr), 0, ctypes.byref(rows), st))
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    if M % 64:
+        assert rows.value == 0
+        return
+    assert 0 < rows.value <= ((M + 63) // 64) * 2
+    used = scr[: rows.value * Cout * 2]
+    assert torch.isfinite(used).all() and torch.isnan(scr[rows.value * Cout * 2:]).all()  # exactly the reported rows were written
+    stats = []
+    for fused in (True, False):
+        mean, istd = torch.zeros(Cout, device=dev), torch.zeros(Cout, device=dev)
+        rm, rv = torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)
+        if fused:
+            _lib.check(lib.rdpn6d_bn_stats_finalize(_ptr(scr), rows.value, Cout, M, 1e-5, 0.1, _ptr(mean), _ptr(istd), _ptr(rm), _ptr(rv), st))
+        else:
+            scr2 = torch.empty(512 * 1024 * 2 + 4096, dtype=torch.float64, device=dev)
+            _lib.check(getattr(lib, f"rdpn6d_bn_train_stats_{t}")(_ptr(y0), M, Cout, Cout, 0, 1e-5, 0.1, _ptr(mean), _ptr(istd), _ptr(rm), _ptr(rv),
+                                                                   _ptr(scr2), st))
+        torch.cuda.synchronize()
+        stats.append((mean.clone(), istd.clone(), rm.clone(), rv.clone()))
+    yd = y0.double().reshape(M, Cout)
+    ref_mean, ref_var = yd.mean(0), yd.var(0, unbiased=False)
+    for a, b, n in zip(stats[0], stats[1], ("mean", "invstd", "running_mean", "running_var")):
+        assert (a - b).abs().max().item() <= 2e-6 * max(1.0, b.abs().max().item()), n
+    assert (stats[0][0].double() - ref_mean).abs().max().item() < 2e-6
+    assert ((stats[0][1].double() - 1.0 / torch.sqrt(ref_var + 1e-5)).abs() * torch.sqrt(ref_var + 1e-5)).max().item() < 5e-6
+
+
 @pytest.mark.parametrize("case", [
     # Bn, Ha, Hb, stride, Ca, Cb, k
     (2, 16, 16, 1, 128, 128, 3),
