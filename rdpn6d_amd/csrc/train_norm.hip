@@ -9,6 +9,7 @@
 // global memory + a tiny finalize kernel) so results do not depend on atomics ordering.
 #include "common.h"
 #include <float.h>
+#include <cstdlib>
 
 #define NS_MAX 512  // row splits of the partial reductions (the scratch contract: 512 * C * 2 doubles).  128 left a 131 072 x 256 tensor on 256
                     // workgroups of 4 waves, sixteen dependent load rounds each: latency-bound at a third of the HBM rate
@@ -269,7 +270,10 @@ __global__ __launch_bounds__(256) void chan_sum_finalize_kernel(const double* __
 
 static int pick_splits(long long M, int C, int cb = 64)
 {
-    long long s = (M + 255) / 256;                       // >= 16 rows per row lane
+    // >= 4 rows per row lane = ONE round of loads per thread (was 16 = four dependent rounds: 18 us for a 4-MB layer3 tensor on 64
+    // workgroups, where the data takes 3)
+    static const int rows_lane = getenv("RDPN6D_BN_ROWS_PER_LANE") ? atoi(getenv("RDPN6D_BN_ROWS_PER_LANE")) : 4;  // profiling
+    long long s = (M + 16 * rows_lane - 1) / (16 * rows_lane);
     const long long want = 2048 / ((C + cb - 1) / cb) + 1;  // enough workgroups to fill the chip (8 per CU)
     if (s > want) s = want;
     if (s > NS_MAX) s = NS_MAX;

@@ -461,12 +461,31 @@ __global__ __launch_bounds__(256, (PL == 1 && BA <= 128) ? 3 : 2) void wgrad_bf1
     }
 }
 
-__global__ void splitk_reduce_kernel(const float* __restrict__ partial, int S, long long n, float* __restrict__ out)
+// 64 elements x 4 split lanes per workgroup: lane j adds the splits j, j + 4, ... (four loads in flight), the four lanes are combined
+// in a fixed order.  (One thread per element walking all S splits was a chain of S dependent-address loads on a handful of
+// workgroups: 61 us for ConvPnPNet's first layer - 10 240 outputs - where the partials are 10 MB.)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int S, long long n, float* __restrict__ out,
+                                                            int nsl)
 {
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    __shared__ float sm[4][64];
+    const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    for (long long base = (long long)blockIdx.x * 64; base < n; base += (long long)gridDim.x * 64) {
+        const long long i = base + e;
         float s = 0.f;
-        for (int k = 0; k < S; ++k) s += partial[(long long)k * n + i];
-        out[i] = s;
+        if (i < n && sl < nsl) {
+            const float* p = partial + i;
+            int k = sl;
+            for (; k + 3 * nsl < S; k += 4 * nsl) {
+                const float a0 = p[(long long)k * n], a1 = p[(long long)(k + nsl) * n], a2 = p[(long long)(k + 2 * nsl) * n],
+                            a3 = p[(long long)(k + 3 * nsl) * n];
+                s = (((s + a0) + a1) + a2) + a3;
+            }
+            for (; k < S; k += nsl) s += p[(long long)k * n];
+        }
+        sm[sl][e] = s;
+        __syncthreads();
+        if (sl == 0 && i < n) out[i] = nsl == 1 ? sm[0][e] : (sm[0][e] + sm[1][e]) + (sm[2][e] + sm[3][e]);
+        __syncthreads();
     }
 }
 
@@ -477,34 +496,50 @@ struct WgradOut {
     long long sa, st, sb;
     int Ca_out, Cb_out;
 };
-// four consecutive b per thread (Cb % 4 == 0): 16-byte loads of every split's partial, four splits in flight; the sum over
-// the splits runs in the fixed order 0..S-1 for every element (deterministic, same order as the scalar form)
-__global__ void splitk_reduce_strided_kernel(const float* __restrict__ partial, int S, int Ca, int ntaps, int Cb, WgradOut o)
+// four consecutive b per thread (Cb % 4 == 0: 16-byte loads of every split's partial), 64 such quads x 4 split lanes per workgroup
+// (see splitk_reduce_kernel); fixed summation order
+__global__ __launch_bounds__(256) void splitk_reduce_strided_kernel(const float* __restrict__ partial, int S, int Ca, int ntaps, int Cb,
+                                                                    WgradOut o, int nsl)
 {
+    __shared__ f32x4 sm[4][64];
     const long long n = (long long)Ca * ntaps * Cb;
     const long long n4 = n >> 2;
     const int cb4 = Cb >> 2;
-    for (long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x; i4 < n4; i4 += (long long)gridDim.x * blockDim.x) {
-        const int b = (int)(i4 % cb4) * 4;
-        const long long r = i4 / cb4;
-        const int t = (int)(r % ntaps);
-        const int a = (int)(r / ntaps);
-        if (a >= o.Ca_out || b >= o.Cb_out) continue;
-        const float* p = partial + i4 * 4;
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        int k = 0;
-        for (; k + 4 <= S; k += 4) {
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(p + (long long)k * n);
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (long long)(k + 1) * n);
-            const f32x4 v2 = *reinterpret_cast<const f32x4*>(p + (long long)(k + 2) * n);
-            const f32x4 v3 = *reinterpret_cast<const f32x4*>(p + (long long)(k + 3) * n);
-            s = (((s + v0) + v1) + v2) + v3;
+    const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    for (long long base = (long long)blockIdx.x * 64; base < n4; base += (long long)gridDim.x * 64) {
+        const long long i4 = base + e;
+        int a = 0, b = 0, t = 0;
+        bool ok = i4 < n4;
+        if (ok) {
+            b = (int)(i4 % cb4) * 4;
+            const long long r = i4 / cb4;
+            t = (int)(r % ntaps);
+            a = (int)(r / ntaps);
+            ok = a < o.Ca_out && b < o.Cb_out;
         }
-        for (; k < S; ++k) s = s + *reinterpret_cast<const f32x4*>(p + (long long)k * n);
-        float* q = o.out + a * o.sa + t * o.st + b * o.sb;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        if (ok && sl < nsl) {
+            const float* p = partial + i4 * 4;
+            int k = sl;
+            for (; k + 3 * nsl < S; k += 4 * nsl) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(p + (long long)k * n);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (long long)(k + nsl) * n);
+                const f32x4 v2 = *reinterpret_cast<const f32x4*>(p + (long long)(k + 2 * nsl) * n);
+                const f32x4 v3 = *reinterpret_cast<const f32x4*>(p + (long long)(k + 3 * nsl) * n);
+                s = (((s + v0) + v1) + v2) + v3;
+            }
+            for (; k < S; k += nsl) s = s + *reinterpret_cast<const f32x4*>(p + (long long)k * n);
+        }
+        sm[sl][e] = s;
+        __syncthreads();
+        if (sl == 0 && ok) {
+            const f32x4 r = nsl == 1 ? sm[0][e] : (sm[0][e] + sm[1][e]) + (sm[2][e] + sm[3][e]);
+            float* q = o.out + a * o.sa + t * o.st + b * o.sb;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (b + e < o.Cb_out) q[e * o.sb] = s[e];
+            for (int c = 0; c < 4; ++c)
+                if (b + c < o.Cb_out) q[c * o.sb] = r[c];
+        }
+        __syncthreads();
     }
 }
 
@@ -554,10 +589,11 @@ static void wgrad_reduce(const float* partial, int S, int Ca, int ntaps, int Cb,
         return;
     }
     const long long n = (long long)Ca * ntaps * Cb;
-    const int rblocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    const int rblocks4 = (int)((n / 4 + 255) / 256 < 4096 ? (n / 4 + 255) / 256 : 4096);
-    if (o) hipLaunchKernelGGL(splitk_reduce_strided_kernel, dim3(rblocks4), dim3(256), 0, s, partial, S, Ca, ntaps, Cb, *o);
-    else hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rblocks), dim3(256), 0, s, partial, S, n, out);
+    const int rblocks = (int)((n + 63) / 64 < 8192 ? (n + 63) / 64 : 8192);  // 64 elements (quads) x 4 split lanes per workgroup
+    const int rblocks4 = (int)((n / 4 + 63) / 64 < 8192 ? (n / 4 + 63) / 64 : 8192);
+    static const int nsl = getenv("RDPN6D_REDUCE_LANES") ? atoi(getenv("RDPN6D_REDUCE_LANES")) : 4;  // 1 | 2 | 4 (profiling)
+    if (o) hipLaunchKernelGGL(splitk_reduce_strided_kernel, dim3(rblocks4), dim3(256), 0, s, partial, S, Ca, ntaps, Cb, *o, nsl);
+    else hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rblocks), dim3(256), 0, s, partial, S, n, out, nsl);
 }
 
 // A [Bn*Ha*Wa rows, a_cs] ; Bg NHWC [Bn,Hb,Wb,b_cs]; out [Ca][ntaps][Cb] fp32;

@@ -170,7 +170,7 @@ def test_reference_api_do_loss_backward_and_optimizer_step(train_setup):
     inp = synth.make_inputs(4, seed=0)
     gt = synth.make_train_gt(4, inp)
     b = {k: torch.from_numpy(v).to(dev) for k, v in {**inp, **gt}.items()}
-    opt = Ranger([p for p in model.parameters()], lr=2e-3)
+    opt = Ranger([p for p in model.parameters()], lr=1e-3)  # (2e-3 overshoots on this ill-conditioned fixture: the trajectory is then chaotic in the last bit of the gradients)
     hist = []
     for it in range(6):
         od, ld = model(b["roi_img"], gt_xyz=b["roi_xyz"], gt_mask_trunc=b["roi_mask_trunc"], gt_mask_visib=b["roi_mask_visib"],
@@ -272,7 +272,7 @@ def test_amp_reference_loop_loss_goes_down(golden_dir):
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
     inp = synth.make_inputs(4, seed=0)
     b = {k: torch.from_numpy(v).to(dev) for k, v in {**inp, **synth.make_train_gt(4, inp)}.items()}
-    opt = Ranger([p for p in model.parameters()], lr=2e-3)
+    opt = Ranger([p for p in model.parameters()], lr=1e-3)  # (2e-3 overshoots on this ill-conditioned fixture: the trajectory is then chaotic in the last bit of the gradients)
     hist = []
     for it in range(6):
         _, ld = model(b["roi_img"], gt_xyz=b["roi_xyz"], gt_mask_trunc=b["roi_mask_trunc"], gt_mask_visib=b["roi_mask_visib"],
