@@ -106,6 +106,9 @@ void rdpn6d_conv_bf16_force_tile(int bm, int bn);
 /* profiling: LDS stages of the 4-wave tiles (0 = the heuristic: 3 for 64x64 tiles with >= 64 K-chunks, else 2) */
 void rdpn6d_conv_bf16_force_stages(int nst);
 int rdpn6d_conv_bf16_tile_for(const rdpn6d_conv_desc* d, int* bm, int* bn);
+/* 1 when rdpn6d_conv2d_bf16 runs this problem on the eight-wave ping-pong kernel (csrc/conv_igemm_bf16_pp.hip: N % 128 == 0, Cin % 64 == 0,
+ * >= 224 tiles of 128x128 / 256x128, the layer not taken by the 256x256 eight-phase kernel) */
+int rdpn6d_conv_bf16_uses_pingpong(const rdpn6d_conv_desc* d, int out_f32);
 /* fp32-ACCURATE convolution on the bf16 matrix pipe ("bf16x3", csrc/conv_igemm_bf16x3.hip): every fp32 operand is held as
  * three bf16 planes (a = a1 + a2 + a3, 24 significand bits) and a product is the six partial products a_i*b_j, i+j <= 4,
  * accumulated in fp32 - the dropped terms are <= 2^-26 relative, below one fp32 rounding.  Same operator and descriptor as
@@ -476,6 +479,7 @@ int rdpn6d_conv2d_fp16_bnstats(const rdpn6d_conv_desc* d, double* stats, int sta
 void rdpn6d_conv_fp16_force_tile(int bm, int bn);
 void rdpn6d_conv_fp16_force_stages(int nst);
 int rdpn6d_conv_fp16_tile_for(const rdpn6d_conv_desc* d, int* bm, int* bn);
+int rdpn6d_conv_fp16_uses_pingpong(const rdpn6d_conv_desc* d, int out_f32);
 void rdpn6d_conv_fp16_force_chunk(int row_bytes);
 int rdpn6d_stem_conv7x7_fp16(const float* x, int B, int xc, int R, const float* w, const float* scale,
                              const float* shift, void* y, void* stream);

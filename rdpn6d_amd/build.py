@@ -7,13 +7,13 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librdpn6d_hip.so")
-SOURCES = ["api.cpp", "conv_igemm.hip", "conv_igemm_bf16.hip", "conv_igemm_bf16_8ph.hip", "conv_igemm_bf16x3.hip", "conv_igemm_bf16x3_tile.hip", "conv_igemm_h2.hip", "conv_igemm_h2_pp.hip", "pointwise.hip", "pointwise_bf16.hip", "pointwise_h2.hip", "fps.hip", "ransac.hip", "train_norm.hip", "train_wgrad.hip", "train_misc.hip", "ranger.hip", "targets_eval.hip", "crop_builder.hip", "pnp.hip"]
+SOURCES = ["api.cpp", "conv_igemm.hip", "conv_igemm_bf16.hip", "conv_igemm_bf16_8ph.hip", "conv_igemm_bf16_pp.hip", "conv_igemm_bf16x3.hip", "conv_igemm_bf16x3_tile.hip", "conv_igemm_h2.hip", "conv_igemm_h2_pp.hip", "pointwise.hip", "pointwise_bf16.hip", "pointwise_h2.hip", "fps.hip", "ransac.hip", "train_norm.hip", "train_wgrad.hip", "train_misc.hip", "ranger.hip", "targets_eval.hip", "crop_builder.hip", "pnp.hip"]
 NO_CONTRACT = {"fps.hip", "ransac.hip", "targets_eval.hip", "crop_builder.hip", "pnp.hip"}  # bit-exact integer outputs depend on un-fused fp32 arithmetic
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # The 16-bit kernels are written once and built twice (csrc/common.h): bf16 with the sources above, IEEE fp16 - the reference's
 # AMP dtype - by compiling this group again with -DRDPN6D_LP_FP16.  The fp16 objects are merged (ld -r), their rdpn6d_*_bf16
 # entry points renamed to rdpn6d_*_fp16 and every other symbol made local (llvm-objcopy), so the two builds never meet.
-LP_SOURCES = ["conv_igemm_bf16.hip", "conv_igemm_bf16_8ph.hip", "pointwise_bf16.hip", "pointwise.hip", "train_norm.hip", "train_misc.hip",
+LP_SOURCES = ["conv_igemm_bf16.hip", "conv_igemm_bf16_8ph.hip", "conv_igemm_bf16_pp.hip", "pointwise_bf16.hip", "pointwise.hip", "train_norm.hip", "train_misc.hip",
               "train_wgrad.hip"]
 LP_EXTRA_RENAMES = {"rdpn6d_repack_f32": "rdpn6d_repack_fp16"}  # writes 16-bit weight mirrors next to the fp32 packed weights
 if os.environ.get("RDPN6D_PROBE"):  # timing-only ablation variants of the kernels (tools/, never the shipped build)

@@ -249,6 +249,9 @@ __global__ void conv_bf16_splitk_epilogue_kernel(const float* __restrict__ parti
     }
 }
 
+// conv_igemm_bf16_pp.hip: the eight-wave ping-pong form for the trunk layers (N % 128 == 0, >= 224 tiles)
+int conv_lp_pp_plan(const ConvBArgs& a, int rb, int* pbm, int* pbn);
+int conv_lp_launch_pp(const ConvBArgs& a, int shape, hipStream_t s);
 // conv_igemm_bf16_8ph.hip: the 256x256 8-phase form for the large GEMM-like layers
 bool conv_bf16_8ph_eligible(const ConvBArgs& a, int rb);
 int conv_bf16_launch_8ph(const ConvBArgs& a, hipStream_t s);
@@ -282,6 +285,22 @@ extern "C" int rdpn6d_conv_bf16_tile_for(const rdpn6d_conv_desc* d, int* bm, int
     RD_REQUIRE(d && bm && bn, "null pointer");
     conv_bf16_pick_tile(d, (long long)d->B * d->Ho * d->Wo, d->Cin % 64 == 0 ? 128 : 64, bm, bn);
     return RDPN6D_OK;
+}
+
+// 1 when rdpn6d_conv2d_bf16 (fused output, no split-K, no forced tile) runs this problem on the eight-wave ping-pong kernel
+extern "C" int rdpn6d_conv_bf16_uses_pingpong(const rdpn6d_conv_desc* d, int out_f32)
+{
+    if (!d || d->Cin <= 0 || d->Cin % 64 != 0 || g_bforce_bm || g_bforce_rb == 64) return 0;
+    ConvBArgs a;
+    a.d = *d;
+    a.M = (long long)d->B * d->Ho * d->Wo;
+    a.nk = d->ntaps * (d->Cin / 64);
+    const int al = out_f32 ? 4 : 8;
+    a.vec_out = (d->out_cs % al == 0 && d->out_co % al == 0 && (!d->res || (d->res_cs % al == 0 && d->res_co % al == 0))) ? 1 : 0;
+    int bm, bn;
+    conv_bf16_pick_tile(d, a.M, 128, &bm, &bn);
+    if (bm == 256 && bn == 256 && a.vec_out) return 0;  // the 256x256 eight-phase kernel takes it
+    return conv_lp_pp_plan(a, 128, &bm, &bn) >= 0 ? 1 : 0;
 }
 
 template <int BM, int BN, int RB, int WM, int WN, int NST>
@@ -409,6 +428,19 @@ static int conv2d_bf16_impl(const rdpn6d_conv_desc* d, int out_f32, int ksplit, 
         if (rc8 != RDPN6D_OK) return rc8;
         RD_LAUNCH_CHECK();
         return RDPN6D_OK;
+    }
+    if (ksplit <= 1 && !g_bforce_bm) {
+        int pbm, pbn;
+        const int shape = conv_lp_pp_plan(a, rb, &pbm, &pbn);
+        if (shape >= 0) {
+            a.mtiles = rd_cdiv(a.M, pbm);
+            a.ntiles = d->Npad / pbn;
+            if (a.stats) *stats_rows = a.mtiles * 2;  // WM = 2 (the kernel masks the rows of a ragged last tile)
+            const int rcp = conv_lp_launch_pp(a, shape, s);
+            if (rcp != RDPN6D_OK) return rcp;
+            RD_LAUNCH_CHECK();
+            return RDPN6D_OK;
+        }
     }
     if (ksplit > 1 && bm != 256) {
         RD_REQUIRE(a.linear_out, "split-K needs a linear output geometry");

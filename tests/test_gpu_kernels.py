@@ -836,6 +836,53 @@ BF16_8PH_CASES = [
 ]
 
 
+BF16_PP_CASES = [
+    # B, H, Cin, Cout, k, stride, res
+    (64, 16, 256, 256, 3, 1, True),    # layer3 at B = 64: 256 tiles of 128x128, four stages
+    (64, 32, 128, 128, 3, 1, True),    # layer2 at B = 64: 256 tiles of 256x128, three stages
+    (37, 32, 128, 128, 3, 1, False),   # 296 tiles of 128x128: two rounds, ragged over the XCDs
+    (31, 30, 128, 256, 3, 1, True),    # M = 27 900: ragged last row tile, odd spatial size
+    (64, 32, 512, 128, 1, 1, False),   # 1x1: 8 chunks, the shortest loop the kernel takes
+    (64, 32, 128, 256, 3, 2, False),   # stride 2
+]
+
+
+@pytest.mark.parametrize("case", BF16_PP_CASES)
+def test_conv_bf16_pingpong_kernel_bit_identical_to_128_tile(dev, case):
+    """the eight-wave ping-pong kernel (csrc/conv_igemm_bf16_pp.hip) accumulates every output in the same order as the 128x128 tile kernel
+    (K-chunks in order, four k16 steps each): the same bits as the forced tile - fp32 and 16-bit stores, with / without residual - on
+    every one of six launches (race screen for the counted-vmcnt / two-group barrier schedule)."""
+    import ctypes
+    from rdpn6d_amd import _lib, ops
+
+    lib = _lib.load()
+    B, H, Cin, Cout, k, stride, use_res = case
+    g = torch.Generator().manual_seed(sum(case) * 5 + 3)
+    x = torch.randn(B, H, H, Cin, generator=g).to(dev).bfloat16()
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).to(dev).bfloat16()
+    sc, sh = (torch.rand(Cout, generator=g) + 0.5).to(dev), torch.randn(Cout, generator=g).to(dev)
+    Ho = (H + 2 * (k // 2) - k) // stride + 1
+    res = torch.randn(B, Ho, Ho, Cout, generator=g).to(dev).bfloat16() if use_res else None
+    kw = dict(stride=stride, pad=k // 2, act=1, slope=0.1)
+    d = _lib.ConvDesc()
+    d.B, d.H, d.W, d.Cin, d.in_cs, d.Ho, d.Wo, d.stride, d.ntaps, d.N, d.Npad, d.out_cs, d.res_cs = B, H, H, Cin, Cin, Ho, Ho, stride, k * k, Cout, Cout, Cout, Cout
+    assert lib.rdpn6d_conv_bf16_uses_pingpong(ctypes.byref(d), 0) == 1 and lib.rdpn6d_conv_bf16_uses_pingpong(ctypes.byref(d), 1) == 1
+    try:
+        for out_f32 in (True, False):
+            r = (res.float() if out_f32 else res) if use_res else None
+            lib.rdpn6d_conv_bf16_force_tile(128, 128)
+            want = ops.conv2d_nhwc(x, w, sc, sh, residual=r, out_f32=out_f32, **kw)
+            torch.cuda.synchronize()
+            lib.rdpn6d_conv_bf16_force_tile(0, 0)
+            for rep in range(6):
+                got = ops.conv2d_nhwc(x, w, sc, sh, residual=r, out_f32=out_f32, **kw)
+                torch.cuda.synchronize()
+                assert torch.equal(got, want), (case, out_f32, rep, (got.float() - want.float()).abs().max().item())
+            assert want.float().abs().max().item() > 0.1
+    finally:
+        lib.rdpn6d_conv_bf16_force_tile(0, 0)
+
+
 @pytest.mark.parametrize("case", BF16_8PH_CASES)
 def test_conv_bf16_8phase_kernel_bit_identical_to_128_tile(dev, case):
     """the 256x256 8-phase ping-pong kernel accumulates every output in the same order as the 128x128 kernel (K-tiles in
