@@ -281,8 +281,10 @@ class TrainEngine:
         start = 0
         mirror_of = {id(t): tb for tb, t in self.mirrors}
         for r, e in zip(tab, self.repack):
-            r["src"], r["dst"] = e["src"].data_ptr(), e["dst"].data_ptr() + 4 * e["off"]
             tb = mirror_of.get(id(e["dst"]))
+            # a packed tensor with a 16-bit mirror is only ever read through the mirror (mixed precision: every convolution that has
+            # one takes it): its fp32 form is not written - half of the re-pack's 580 MB per step
+            r["src"], r["dst"] = e["src"].data_ptr(), (e["dst"].data_ptr() + 4 * e["off"] if tb is None else 0)
             r["dst_bf16"] = tb.data_ptr() + 2 * e["off"] if tb is not None else 0
             r["operm"] = e["operm"].data_ptr() if e["operm"] is not None else 0
             r["iperm"] = e["iperm"].data_ptr() if e["iperm"] is not None else 0
