@@ -102,6 +102,15 @@ int rdpn6d_conv2d_splitk_bf16(const rdpn6d_conv_desc* d, int out_f32, int ksplit
  * of a [rows][N][2] double array.  *stats_rows = 0: the geometry does not allow it (ragged tiles, unaligned slices), the convolution ran
  * normally and the caller uses rdpn6d_bn_train_stats_bf16.  rdpn6d_bn_stats_finalize (below) finishes the statistics. */
 int rdpn6d_conv2d_bf16_bnstats(const rdpn6d_conv_desc* d, double* stats, int stats_row0, int* stats_rows, void* stream);
+/* Training backward of a (BatchNorm + ReLU) -> conv pair: the input-gradient convolution of the LATER layer, whose output dy is the gradient
+ * w.r.t. the BatchNorm's activation; its epilogue also writes the BatchNorm's backward partial sums - per channel (sum g, sum g * xhat), the
+ * ReLU mask re-derived from the BatchNorm input bn_x as in rdpn6d_bn_relu_backward_* - rows [*rows][N][2] doubles (*rows = 0: geometry
+ * not eligible, plain convolution done).  rdpn6d_bn_relu_backward_apply_bf16 turns the rows into dgamma / dbeta and runs the dx pass. */
+int rdpn6d_conv2d_bf16_bnbwd(const rdpn6d_conv_desc* d, const void* bn_x, int bn_cs, int bn_co, const float* mean, const float* invstd,
+                             const float* gamma, const float* beta, double* partial, int* rows, void* stream);
+int rdpn6d_bn_relu_backward_apply_bf16(const void* x, int xcs, int xco, const void* dy, int dcs, int dco, const float* mean,
+                                       const float* invstd, const float* gamma, const float* beta, float* dgamma, float* dbeta, void* dx,
+                                       int xgcs, int xgco, long long M, int C, const double* partial, int S, void* stream);
 void rdpn6d_conv_bf16_force_tile(int bm, int bn);
 /* profiling: LDS stages of the 4-wave tiles (0 = the heuristic: 3 for 64x64 tiles with >= 64 K-chunks, else 2) */
 void rdpn6d_conv_bf16_force_stages(int nst);
@@ -475,6 +484,11 @@ int rdpn6d_crop_builder_f32(const unsigned char* images, const float* depths, in
  * Selected by cfg.SOLVER.AMP.DTYPE / cfg.TEST.AMP_DTYPE = "fp16" (default "bf16"). */
 int rdpn6d_conv2d_fp16(const rdpn6d_conv_desc* d, int out_f32, void* stream);
 int rdpn6d_conv2d_splitk_fp16(const rdpn6d_conv_desc* d, int out_f32, int ksplit, float* workspace, void* stream);
+int rdpn6d_conv2d_fp16_bnbwd(const rdpn6d_conv_desc* d, const void* bn_x, int bn_cs, int bn_co, const float* mean, const float* invstd,
+                             const float* gamma, const float* beta, double* partial, int* rows, void* stream);
+int rdpn6d_bn_relu_backward_apply_fp16(const void* x, int xcs, int xco, const void* dy, int dcs, int dco, const float* mean,
+                                       const float* invstd, const float* gamma, const float* beta, float* dgamma, float* dbeta, void* dx,
+                                       int xgcs, int xgco, long long M, int C, const double* partial, int S, void* stream);
 int rdpn6d_conv2d_fp16_bnstats(const rdpn6d_conv_desc* d, double* stats, int stats_row0, int* stats_rows, void* stream);
 void rdpn6d_conv_fp16_force_tile(int bm, int bn);
 void rdpn6d_conv_fp16_force_stages(int nst);

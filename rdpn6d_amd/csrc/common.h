@@ -180,4 +180,17 @@ template <typename T, int V> __device__ __forceinline__ void rd_stv(T* p, const 
     else *reinterpret_cast<rd_u32x4*>(p) = rd_pack8(v);
 }
 
+// The normalised value of the forward pass, ONE expression for bn_apply_kernel and for the backward kernels that re-derive the ReLU
+// mask from x instead of reading the stored activation (relu == 2): the same operations in the same order, so the same sign.
+__device__ __forceinline__ float bn_fwd_value(float x, float mean, float invstd, float gamma, float beta)
+{
+    return __builtin_fmaf((x - mean) * invstd, gamma, beta);
+}
+// y > 0 for the activation as it was STORED (type T): a positive fp32 value that rounds to zero in 16 bits has a zero mask
+template <typename T> __device__ __forceinline__ bool bn_stored_positive(float v)
+{
+    if constexpr (sizeof(T) == 2) return rd_bf2f(rd_f2bf(v)) > 0.f;
+    else return v > 0.f;
+}
+
 

@@ -23,6 +23,14 @@ struct ConvBArgs {
     // without a second pass over the tensor.  Only the coalesced epilogue writes them (the launcher checks the geometry).
     double* stats = nullptr;
     int stats_row0 = 0;
+    // Training backward (rdpn6d_conv2d_bf16_bnbwd): this launch is the input-gradient convolution whose output dy IS the gradient
+    // w.r.t. the activation of a BatchNorm + ReLU (no residual in between).  With bnb_x set, the rows written to `stats` are that
+    // BatchNorm's backward sums instead: per channel (sum g, sum g * xhat), g = dy as stored where the re-derived activation is
+    // positive (bn_fwd_value / bn_stored_positive, csrc/common.h), xhat from the BatchNorm's input bnb_x - chan_partial_kernel<1>'s pass
+    // over dy and x, done while the dy tile is in registers.
+    const void* bnb_x = nullptr;
+    int bnb_cs = 0, bnb_co = 0;
+    const float *bnb_mean = nullptr, *bnb_invstd = nullptr, *bnb_gamma = nullptr, *bnb_beta = nullptr;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -85,6 +93,17 @@ __device__ __forceinline__ void conv_bf16_epilogue_vec(const ConvBArgs& a, f32x1
             shj[j] = d.shift ? d.shift[n] : 0.f;
         }
         float st1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, st2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // a.stats
+        float bmu[8], bis[8], bga[8], bbe[8];  // a.bnb_x: the BatchNorm parameters of this lane's 8 channels
+        if (a.stats && a.bnb_x && !a.out_f32) {
+            const int c = nb + (lane % (WC / 8)) * 8;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                bmu[q] = a.bnb_mean[c + q];
+                bis[q] = a.bnb_invstd[c + q];
+                bga[q] = a.bnb_gamma[c + q];
+                bbe[q] = a.bnb_beta[c + q];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -137,10 +156,21 @@ __device__ __forceinline__ void conv_bf16_epilogue_vec(const ConvBArgs& a, f32x1
                     if (a.stats) {  // of the values as stored (what a BatchNorm reading the tensor would see)
                         float r[8];
                         rd_unpack8(pk, r);
+                        if (a.bnb_x) {  // backward sums of the BatchNorm + ReLU this gradient flows into (linear geometry: pix = row)
+                            float xr[8];
+                            rd_unpack8(*reinterpret_cast<const rd_u32x4*>(reinterpret_cast<const bf16_t*>(a.bnb_x) + pix * a.bnb_cs + a.bnb_co + nb + c8), xr);
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            st1[q] += r[q];
-                            st2[q] += r[q] * r[q];
+                            for (int q = 0; q < 8; ++q) {
+                                const float g = bn_stored_positive<bf16_t>(bn_fwd_value(xr[q], bmu[q], bis[q], bga[q], bbe[q])) ? r[q] : 0.f;
+                                st1[q] += g;
+                                st2[q] += g * ((xr[q] - bmu[q]) * bis[q]);
+                            }
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                st1[q] += r[q];
+                                st2[q] += r[q] * r[q];
+                            }
                         }
                     }
                 }

@@ -339,8 +339,13 @@ static int conv_bf16_launch(const ConvBArgs& a, int bm, int bn, int nsplit, hipS
     return conv_bf16_launch_one<64, 64, RB, 2, 2, 2>(a, nsplit, s);
 }
 
+struct ConvBnBwd {  // see ConvBArgs::bnb_x
+    const void* x;
+    int cs, co;
+    const float *mean, *invstd, *gamma, *beta;
+};
 static int conv2d_bf16_impl(const rdpn6d_conv_desc* d, int out_f32, int ksplit, float* workspace, void* stream, double* stats = nullptr,
-                            int stats_row0 = 0, int* stats_rows = nullptr);
+                            int stats_row0 = 0, int* stats_rows = nullptr, const ConvBnBwd* bnb = nullptr);
 
 extern "C" int rdpn6d_conv2d_bf16(const rdpn6d_conv_desc* d, int out_f32, void* stream)
 {
@@ -364,8 +369,23 @@ extern "C" int rdpn6d_conv2d_bf16_bnstats(const rdpn6d_conv_desc* d, double* sta
     return conv2d_bf16_impl(d, 0, 1, nullptr, stream, stats, stats_row0, stats_rows);
 }
 
+// Training backward: the input-gradient convolution of the layer AFTER a BatchNorm + ReLU, whose epilogue also writes that BatchNorm's
+// backward partial sums - per channel (sum g, sum g * xhat) with the ReLU mask re-derived from the BatchNorm input bn_x - instead of a
+// separate reduction pass over dy and x (rdpn6d_bn_relu_backward_*'s first kernel).  Rows / fall-back as rdpn6d_conv2d_bf16_bnstats;
+// rdpn6d_bn_relu_backward_apply_bf16 finishes.  Needs a linear output geometry and bn_x laid out like the output (same pixels).
+extern "C" int rdpn6d_conv2d_bf16_bnbwd(const rdpn6d_conv_desc* d, const void* bn_x, int bn_cs, int bn_co, const float* mean,
+                                        const float* invstd, const float* gamma, const float* beta, double* partial, int* rows,
+                                        void* stream)
+{
+    RD_REQUIRE(bn_x && mean && invstd && gamma && beta && partial && rows, "null pointer");
+    RD_REQUIRE(bn_cs % 8 == 0 && bn_co % 8 == 0 && d && bn_co + d->N <= bn_cs, "BatchNorm input slice: 16-byte aligned, N channels");
+    RD_REQUIRE(d->osy == 1 && d->osx == 1 && d->ooy == 0 && d->oox == 0 && d->OH == d->Ho && d->OW == d->Wo, "linear output geometry");
+    const ConvBnBwd b = {bn_x, bn_cs, bn_co, mean, invstd, gamma, beta};
+    return conv2d_bf16_impl(d, 0, 1, nullptr, stream, partial, 0, rows, &b);
+}
+
 static int conv2d_bf16_impl(const rdpn6d_conv_desc* d, int out_f32, int ksplit, float* workspace, void* stream, double* stats,
-                            int stats_row0, int* stats_rows)
+                            int stats_row0, int* stats_rows, const ConvBnBwd* bnb)
 {
     RD_REQUIRE(d && d->x && d->w && d->y, "null pointer");
     RD_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0, "empty tensor");
@@ -420,6 +440,10 @@ static int conv2d_bf16_impl(const rdpn6d_conv_desc* d, int out_f32, int ksplit, 
         // every tile takes the coalesced epilogue (full column tiles: bn divides Npad = N; full row tiles, or the 8-phase kernel's masked rows)
         a.stats = stats;
         a.stats_row0 = stats_row0;
+        if (bnb) {
+            a.bnb_x = bnb->x; a.bnb_cs = bnb->cs; a.bnb_co = bnb->co;
+            a.bnb_mean = bnb->mean; a.bnb_invstd = bnb->invstd; a.bnb_gamma = bnb->gamma; a.bnb_beta = bnb->beta;
+        }
         *stats_rows = a.mtiles * ((bm == 256 && bn == 128) ? 4 : 2);  // wave rows per tile: WM of the launch below
     }
     if (bm == 256 && bn == 256) {

@@ -14,19 +14,6 @@
 #define NS_MAX 512  // row splits of the partial reductions (the scratch contract: 512 * C * 2 doubles).  128 left a 131 072 x 256 tensor on 256
                     // workgroups of 4 waves, sixteen dependent load rounds each: latency-bound at a third of the HBM rate
 
-// The normalised value of the forward pass, ONE expression for bn_apply_kernel and for the backward kernels that re-derive the ReLU
-// mask from x instead of reading the stored activation (relu == 2): the same operations in the same order, so the same sign.
-__device__ __forceinline__ float bn_fwd_value(float x, float mean, float invstd, float gamma, float beta)
-{
-    return __builtin_fmaf((x - mean) * invstd, gamma, beta);
-}
-// y > 0 for the activation as it was STORED (type T): a positive fp32 value that rounds to zero in 16 bits has a zero mask
-template <typename T> __device__ __forceinline__ bool bn_stored_positive(float v)
-{
-    if constexpr (sizeof(T) == 2) return rd_bf2f(rd_f2bf(v)) > 0.f;
-    else return v > 0.f;
-}
-
 // ---------------------------------------------------------------------------------------------
 // Stage 1 of every per-channel reduction.  MODE 0: (sum x, sum x^2)         [BN statistics, bias grads]
 //                                            MODE 1: (sum g, sum g*xhat)       [BN backward], g = dy*(y>0) if relu
@@ -252,6 +239,40 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_rows_kernel(const doubl
         running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mu);
         running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
     }
+}
+
+// plain sums of MANY partial rows (the rows of rdpn6d_conv2d_bf16_bnbwd): out_a = sum of column 0, out_b = sum of column 1
+__global__ __launch_bounds__(256) void chan_sum_finalize_rows_kernel(const double* __restrict__ partial, int S, int C,
+                                                                     float* __restrict__ out_a, float* __restrict__ out_b)
+{
+    constexpr int SL = 32, CH = 8;
+    __shared__ double s_a[SL][CH], s_b[SL][CH];
+    const int cl = threadIdx.x % CH, sl = threadIdx.x / CH;
+    const int c = blockIdx.x * CH + cl;
+    const bool ok = c < C;
+    double a = 0.0, b = 0.0;
+    if (ok) {
+        const double* p = partial + (long long)c * 2;
+        const long long st = (long long)C * 2;
+        int k = sl;
+        for (; k + 3 * SL < S; k += 4 * SL) {
+            const double a0 = p[k * st], b0 = p[k * st + 1], a1 = p[(k + SL) * st], b1 = p[(k + SL) * st + 1];
+            const double a2 = p[(k + 2 * SL) * st], b2 = p[(k + 2 * SL) * st + 1], a3 = p[(k + 3 * SL) * st], b3 = p[(k + 3 * SL) * st + 1];
+            a += (a0 + a1) + (a2 + a3);
+            b += (b0 + b1) + (b2 + b3);
+        }
+        for (; k < S; k += SL) { a += p[k * st]; b += p[k * st + 1]; }
+    }
+    s_a[sl][cl] = a; s_b[sl][cl] = b;
+    __syncthreads();
+#pragma unroll
+    for (int w = SL / 2; w >= 1; w >>= 1) {
+        if (sl < w) { s_a[sl][cl] += s_a[sl + w][cl]; s_b[sl][cl] += s_b[sl + w][cl]; }
+        __syncthreads();
+    }
+    if (sl != 0 || !ok) return;
+    out_a[c] = (float)s_a[0][cl];
+    out_b[c] = (float)s_b[0][cl];
 }
 
 // Stage 2 for plain sums (bias gradients) and for BN backward (dgamma, dbeta).
@@ -536,6 +557,44 @@ extern "C" int rdpn6d_bn_relu_backward_bf16(const void* x, int xcs, int xco, con
 
 // ---------------------------------------------------------------------------------------------
 // GroupNorm(G groups of 4 channels) + ReLU, training form: out-of-place, statistics saved.
+// The second half of rdpn6d_bn_relu_backward_*: dgamma / dbeta from S rows [S][C][2] of (sum g, sum g * xhat) partials that the
+// input-gradient convolution in front wrote (rdpn6d_conv2d_bf16_bnbwd), then the dx pass (mask re-derived from x as there).
+template <typename T>
+static int bn_relu_backward_apply_impl(const T* x, int xcs, int xco, const T* dy, int dcs, int dco, const float* mean, const float* invstd,
+                                       const float* gamma, const float* beta, float* dgamma, float* dbeta, T* dx, int xgcs, int xgco,
+                                       long long M, int C, const double* partial, int S, void* stream)
+{
+    RD_REQUIRE(x && dy && mean && invstd && gamma && beta && dgamma && dbeta && dx && partial && S > 0, "null pointer");
+    RD_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "shape");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(chan_sum_finalize_rows_kernel, dim3((C + 7) / 8), dim3(256), 0, s, partial, S, C, dbeta, dgamma);
+    RD_LAUNCH_CHECK();
+    if constexpr (sizeof(T) == 2) {
+        if (C % 8 == 0 && xcs % 8 == 0 && xco % 8 == 0 && dcs % 8 == 0 && dco % 8 == 0 && xgcs % 8 == 0 && xgco % 8 == 0) {
+            const long long total8 = M * (C / 8);
+            const int blocks8 = (int)((total8 + 255) / 256 < 16384 ? (total8 + 255) / 256 : 16384);
+            hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 8>), dim3(blocks8), dim3(256), 0, s, x, xcs, xco, dy, dcs, dco, (const T*)nullptr, 0, 0,
+                               mean, invstd, gamma, beta, dgamma, dbeta, dx, xgcs, xgco, (T*)nullptr, 0, 0, M, C, 2);
+            RD_LAUNCH_CHECK();
+            return RDPN6D_OK;
+        }
+    }
+    const long long total = M * (C / 4);
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 4>), dim3(blocks), dim3(256), 0, s, x, xcs, xco, dy, dcs, dco, (const T*)nullptr, 0, 0, mean,
+                       invstd, gamma, beta, dgamma, dbeta, dx, xgcs, xgco, (T*)nullptr, 0, 0, M, C, 2);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}
+extern "C" int rdpn6d_bn_relu_backward_apply_bf16(const void* x, int xcs, int xco, const void* dy, int dcs, int dco, const float* mean,
+                                                  const float* invstd, const float* gamma, const float* beta, float* dgamma,
+                                                  float* dbeta, void* dx, int xgcs, int xgco, long long M, int C,
+                                                  const double* partial, int S, void* stream)
+{
+    return bn_relu_backward_apply_impl<rd_bf16_t>((const rd_bf16_t*)x, xcs, xco, (const rd_bf16_t*)dy, dcs, dco, mean, invstd, gamma, beta,
+                                                  dgamma, dbeta, (rd_bf16_t*)dx, xgcs, xgco, M, C, partial, S, stream);
+}
+
 // (NT threads per crop: 1024 for maps of >= 256 pixels - one workgroup per crop is all the parallelism there is, B = 32 workgroups on
 //  256 CUs, and with 256 threads each of them walked 128 pixels three times: 75 us forward / 110 us backward for ConvPnPNet's first map)
 template <int NT>

@@ -62,6 +62,10 @@ class TrainEngine:
         # rdpn6d_bn_relu_backward_*): one tensor read less in both backward passes of every BN that has no residual before its ReLU
         # conv + BatchNorm pairs of the mixed-precision step: the convolution's epilogue writes the BatchNorm statistics' partial sums
         self.bn_fuse_stats = bool(model.cfg.get("SOLVER", {}).get("BN_FUSE_STATS", os.environ.get("RDPN6D_BN_FUSE_STATS", "1") != "0"))
+        # (BatchNorm + ReLU) -> conv pairs of the mixed-precision step: the later layer's input-gradient convolution writes the
+        # BatchNorm's backward sums from its epilogue (rdpn6d_conv2d_bf16_bnbwd)
+        self.bn_fuse_bwd = bool(model.cfg.get("SOLVER", {}).get("BN_FUSE_BWD", os.environ.get("RDPN6D_BN_FUSE_BWD", "1") != "0"))
+        self._bn_by_dy, self._scratch_bnb_need = {}, 0
         self.bn_remask = bool(model.cfg.get("SOLVER", {}).get("BN_REMASK", os.environ.get("RDPN6D_BN_REMASK", "1") != "0"))
         self.x3_launches = 0
         cfg = model.cfg
@@ -93,6 +97,7 @@ class TrainEngine:
         self._build()
         if getattr(self, "_scratch_need", 0) > self._scratch_d.numel():  # (every launch reads the pointer when it runs)
             self._scratch_d = torch.empty(self._scratch_need, dtype=torch.float64, device=device)
+        self._scratch_bnb = torch.empty(max(self._scratch_bnb_need, 1), dtype=torch.float64, device=device)
         self._wg_partial = torch.empty(max(self._wg_floats, 1), dtype=torch.float32, device=device)
         self.refresh_weights()
 
@@ -233,10 +238,16 @@ class TrainEngine:
                         _lib.check(self.lpf("rdpn6d_conv2d_bf16_bnstats")(ctypes.byref(d), _ptr(self._scratch_d), 0, ctypes.byref(rows),
                                                                           self.st()), name)
                         run.stats_rows = rows.value
+                    elif run.bn_bwd is not None:  # an input-gradient convolution whose output is the gradient of a BatchNorm + ReLU:
+                        r = run.bn_bwd            # that BatchNorm's backward sums come out of this launch's epilogue (conv_unit)
+                        _lib.check(self.lpf("rdpn6d_conv2d_bf16_bnbwd")(ctypes.byref(d), _ptr(r["x_raw"]), r["cs"], r["co"], _ptr(r["mean"]),
+                                                                        _ptr(r["invstd"]), _ptr(r["ga"]), _ptr(r["be"]), _ptr(self._scratch_bnb),
+                                                                        ctypes.byref(rows), self.st()), name)
+                        run.stats_rows = rows.value
                     else:
                         _lib.check(self.lpf("rdpn6d_conv2d_bf16")(ctypes.byref(d), of, self.st()), name)
 
-                run.bn_capable, run.bn_stats, run.stats_rows, run.desc = not of, False, 0, d
+                run.bn_capable, run.bn_stats, run.bn_bwd, run.stats_rows, run.desc = not of, False, None, 0, d
 
             run.keep = (d, keep)
             return run
@@ -455,7 +466,14 @@ class TrainEngine:
                     dd.x, dd.w = _ptr(g3), _ptr(wd3)
                     launches.append(self._launch_conv_x3("dgrad " + name, dd, g3, wd3, (wd, dy)))
                 else:
-                    launches.append(dlaunch("dgrad " + name, dd, wd))
+                    drun = dlaunch("dgrad " + name, dd, wd)
+                    rec = self._bn_by_dy.get(dx.data_ptr())
+                    if (rec is not None and rec["producer"] is None and getattr(drun, "bn_capable", False) and dx_res is None
+                            and rec["dy_cs"] == dx_cs and rec["dy_co"] == in_co and rec["C"] == cin_real
+                            and rec["M"] == B * xhw[0] * xhw[1]):
+                        drun.bn_bwd, rec["producer"] = rec, drun
+                        self._scratch_bnb_need = max(self._scratch_bnb_need, ((rec["M"] + 63) // 64) * 2 * rec["C"] * 2)
+                    launches.append(drun)
             else:
                 assert stride == 2 and perm is None
                 if k == 3:
@@ -525,9 +543,21 @@ class TrainEngine:
 
         remask = relu and res is None and dres is None and self.bn_remask
         f_bwd_remask = getattr(lib, f"rdpn6d_bn_relu_backward_{t}")
+        # the convolution that CONSUMES y registers after this unit: if its input-gradient launch can also produce this BatchNorm's
+        # backward sums (conv_unit), the reduction pass over dy and x_raw is skipped here
+        rec = dict(x_raw=x_raw, cs=cs, co=co, C=C, M=M, mean=mean, invstd=invstd, ga=ga, be=be, dy_cs=dy_cs, dy_co=dy_co, producer=None)
+        if remask and t != "f32" and self.bn_fuse_bwd:
+            self._bn_by_dy[dy.data_ptr()] = rec
 
         def bwd():
             # dgamma / dbeta land directly in the parameters' gradients (C entries each, also read back by the dx pass)
+            prod = rec["producer"]
+            if prod is not None and prod.stats_rows > 0:
+                _lib.check(self.lpf("rdpn6d_bn_relu_backward_apply_bf16")(
+                    _ptr(x_raw), cs, co, _ptr(dy), dy_cs, dy_co, _ptr(mean), _ptr(invstd), _ptr(ga), _ptr(be), _ptr(self._grad(bn.weight)),
+                    _ptr(self._grad(bn.bias)), _ptr(dx), cs, co, M, C, _ptr(self._scratch_bnb), prod.stats_rows, self.st()),
+                    "bn+relu bwd (apply) " + name)
+                return
             if remask:
                 _lib.check(f_bwd_remask(_ptr(x_raw), cs, co, _ptr(dy), dy_cs, dy_co, _ptr(mean), _ptr(invstd), _ptr(ga), _ptr(be),
                                         _ptr(self._grad(bn.weight)), _ptr(self._grad(bn.bias)), _ptr(dx), cs, co, M, C,

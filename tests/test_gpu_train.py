@@ -418,6 +418,84 @@ def test_conv_epilogue_writes_the_batchnorm_partial_sums(t, case):
     assert ((stats[0][1].double() - 1.0 / torch.sqrt(ref_var + 1e-5)).abs() * torch.sqrt(ref_var + 1e-5)).max().item() < 5e-6
 
 
+@pytest.mark.parametrize("t", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", [
+    (16, 64, 256, 256, 3),  # 256 x 256 eight-phase kernel (head layers)
+    (8, 64, 64, 64, 3),     # 128 x 64 (layer1)
+    (64, 16, 256, 256, 3),  # the ping-pong kernel (layer3 at B = 64)
+    (8, 16, 256, 128, 1),   # 1x1, 64 x 128
+    (3, 9, 64, 64, 3),      # ragged tiles: no rows, the caller's fallback
+])
+def test_conv_epilogue_writes_the_batchnorm_backward_sums(t, case):
+    """rdpn6d_conv2d_*_bnbwd + rdpn6d_bn_relu_backward_apply_*: the input-gradient convolution stores the same 16-bit dy as the plain
+    launch, bit for bit, and - with the backward sums of the BatchNorm + ReLU in front taken from its epilogue - dgamma / dbeta / dx
+    equal rdpn6d_bn_relu_backward_*'s, which reduces dy and x in a pass of its own (summation order differs: 1e-6 of the largest sum)."""
+    import ctypes
+    from rdpn6d_amd import _lib
+    from rdpn6d_amd.gdrn import _pad_to, _ptr, pack_conv_weight
+
+    lib, dev = _lib.load(), torch.device("cuda:0")
+    dt = torch.bfloat16 if t == "bf16" else torch.float16
+    B, H, Cin, Cout, k = case
+    g = torch.Generator().manual_seed(sum(case) + 11)
+    gin = (torch.randn(B, H, H, Cin, generator=g) / 8).to(dev).to(dt)       # the gradient flowing into the convolution (its "input")
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).to(dev)
+    wp = pack_conv_weight(w, cin_pad=_pad_to(Cin, 32)).to(dt)
+    pad = k // 2
+    M = B * H * H
+    xbn = torch.randn(M, Cout, generator=g).to(dev).to(dt)                    # the BatchNorm's input, same pixels as the convolution's output
+    gamma = (torch.rand(Cout, generator=g) + 0.5).to(dev)
+    gamma[::5] *= -1.0
+    beta = (0.3 * torch.randn(Cout, generator=g)).to(dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    mean, istd, rm, rv = (torch.zeros(Cout, device=dev) for _ in range(4))
+    scr = torch.empty(512 * 1024 * 2 + 4096, dtype=torch.float64, device=dev)
+    _lib.check(getattr(lib, f"rdpn6d_bn_train_stats_{t}")(_ptr(xbn), M, Cout, Cout, 0, 1e-5, 0.1, _ptr(mean), _ptr(istd), _ptr(rm), _ptr(rv), _ptr(scr), st))
+    d = _lib.ConvDesc()
+    d.B, d.H, d.W, d.Cin, d.in_cs, d.in_co = B, H, H, Cin, Cin, 0
+    d.Ho, d.Wo, d.stride = H, H, 1
+    taps = [(ky - pad, kx - pad) for ky in range(k) for kx in range(k)]
+    d.ntaps = len(taps)
+    for i, (dy_, dx_) in enumerate(taps):
+        d.dy[i], d.dx[i] = dy_, dx_
+    d.N, d.Npad, d.OH, d.OW = Cout, wp.shape[0], H, H
+    d.osy = d.osx = 1
+    d.out_cs = Cout
+    y0, y1 = torch.empty(M, Cout, device=dev, dtype=dt), torch.empty(M, Cout, device=dev, dtype=dt)
+    d.x, d.w, d.y = _ptr(gin), _ptr(wp), _ptr(y0)
+    _lib.check(getattr(lib, f"rdpn6d_conv2d_{t}")(ctypes.byref(d), 0, st))
+    d.y = _ptr(y1)
+    part = torch.full((((M + 63) // 64) * 2 * Cout * 2 + 8,), float("nan"), dtype=torch.float64, device=dev)
+    rows = ctypes.c_int(-1)
+    _lib.check(getattr(lib, f"rdpn6d_conv2d_{t}_bnbwd")(ctypes.byref(d), _ptr(xbn), Cout, 0, _ptr(mean), _ptr(istd), _ptr(gamma), _ptr(beta),
+                                                       _ptr(part), ctypes.byref(rows), st))
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1)
+    if M % 64:
+        assert rows.value == 0
+        return
+    assert 0 < rows.value <= ((M + 63) // 64) * 2
+    assert torch.isfinite(part[: rows.value * Cout * 2]).all() and torch.isnan(part[rows.value * Cout * 2:]).all()
+    outs = []
+    for fused in (True, False):
+        dg, db = torch.full((Cout,), 3.0, device=dev), torch.full((Cout,), 3.0, device=dev)
+        dx = torch.empty_like(xbn)
+        if fused:
+            _lib.check(getattr(lib, f"rdpn6d_bn_relu_backward_apply_{t}")(_ptr(xbn), Cout, 0, _ptr(y0), Cout, 0, _ptr(mean), _ptr(istd), _ptr(gamma),
+                                                                          _ptr(beta), _ptr(dg), _ptr(db), _ptr(dx), Cout, 0, M, Cout, _ptr(part),
+                                                                          rows.value, st))
+        else:
+            _lib.check(getattr(lib, f"rdpn6d_bn_relu_backward_{t}")(_ptr(xbn), Cout, 0, _ptr(y0), Cout, 0, _ptr(mean), _ptr(istd), _ptr(gamma), _ptr(beta),
+                                                                    _ptr(dg), _ptr(db), _ptr(dx), Cout, 0, M, Cout, _ptr(scr), st))
+        torch.cuda.synchronize()
+        outs.append((dg.clone(), db.clone(), dx.clone()))
+    for a, b, n in zip(outs[0], outs[1], ("dgamma", "dbeta")):
+        assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item(), (n, (a - b).abs().max().item(), b.abs().max().item())
+    ulp = 2.0 ** -8 if t == "bf16" else 2.0 ** -11
+    assert (outs[0][2].float() - outs[1][2].float()).abs().max().item() <= ulp * outs[1][2].float().abs().max().item()  # (one 16-bit rounding apart at most)
+    assert outs[1][2].float().abs().max().item() > 1e-3
+
+
 @pytest.mark.parametrize("case", [
     # Bn, Ha, Hb, stride, Ca, Cb, k
     (2, 16, 16, 1, 128, 128, 3),
