@@ -56,7 +56,10 @@ __device__ __forceinline__ void conv_bf16_act(float (&v)[N], const int act, cons
 
 // Coalesced form of the fused epilogue (full column tiles, 16-byte aligned channel slices).  MASK_ROWS: rows >= M of a
 // ragged last tile are skipped (their accumulators are zeros from out-of-range input rows).
-template <int BM, int BN, int WM, int WN, int TM, int TN, bool MASK_ROWS>
+// STATS: the instantiation that also writes the BatchNorm partial sums (ConvBArgs::stats / bnb_x) - a template flag, not a run-time
+// branch, because its registers (parameters and pre-loaded rows of 8 channels) would otherwise raise the VGPR count of EVERY kernel that
+// shares this epilogue: the 64x128 inference tile went from 124 to 134 VGPRs = from four to three wavefronts per SIMD (-2.4 % crops/s).
+template <int BM, int BN, int WM, int WN, int TM, int TN, bool MASK_ROWS, bool STATS = false>
 __device__ __forceinline__ void conv_bf16_epilogue_vec(const ConvBArgs& a, f32x16 (&acc)[TM][TN], unsigned char* smem,
                                                        const long long m0, const int n0, const int wave, const int lane,
                                                        const int wm, const int wn)
@@ -94,7 +97,10 @@ __device__ __forceinline__ void conv_bf16_epilogue_vec(const ConvBArgs& a, f32x1
         }
         float st1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, st2[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // a.stats
         float bmu[8], bis[8], bga[8], bbe[8];  // a.bnb_x: the BatchNorm parameters of this lane's 8 channels
-        if (a.stats && a.bnb_x && !a.out_f32) {
+        constexpr int NRB = 32 / (64 / (WC / 8));  // row groups per 32-row accumulator tile in the 16-bit walk
+        rd_u32x4 bxq[TM][NRB];                     // ... and the BatchNorm-input rows of this lane's outputs, ALL requested up front (one
+                                                   // dependent load per row group cost the 256x256 kernel 34 us per head layer)
+        if (STATS && a.stats && a.bnb_x && !a.out_f32) {
             const int c = nb + (lane % (WC / 8)) * 8;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -103,6 +109,15 @@ __device__ __forceinline__ void conv_bf16_epilogue_vec(const ConvBArgs& a, f32x1
                 bga[q] = a.bnb_gamma[c + q];
                 bbe[q] = a.bnb_beta[c + q];
             }
+            constexpr int LPRB = WC / 8, RPIB = 64 / LPRB;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int rr = 0; rr < NRB; ++rr) {
+                    const long long mrow = m0 + wm * (BM / WM) + i * 32 + rr * RPIB + lane / LPRB;
+                    const long long mr = mrow < a.M ? mrow : 0;  // (linear geometry: pixel = row; rows past M are skipped below)
+                    bxq[i][rr] = *reinterpret_cast<const rd_u32x4*>(reinterpret_cast<const bf16_t*>(a.bnb_x) + mr * a.bnb_cs + a.bnb_co + c);
+                }
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -153,12 +168,12 @@ __device__ __forceinline__ void conv_bf16_epilogue_vec(const ConvBArgs& a, f32x1
                     conv_bf16_act(v, d.act, d.slope);
                     const rd_u32x4 pk = rd_pack8(v);
                     *reinterpret_cast<rd_u32x4*>(yb + pix * d.out_cs + d.out_co + nb + c8) = pk;
-                    if (a.stats) {  // of the values as stored (what a BatchNorm reading the tensor would see)
+                    if (STATS && a.stats) {  // of the values as stored (what a BatchNorm reading the tensor would see)
                         float r[8];
                         rd_unpack8(pk, r);
                         if (a.bnb_x) {  // backward sums of the BatchNorm + ReLU this gradient flows into (linear geometry: pix = row)
                             float xr[8];
-                            rd_unpack8(*reinterpret_cast<const rd_u32x4*>(reinterpret_cast<const bf16_t*>(a.bnb_x) + pix * a.bnb_cs + a.bnb_co + nb + c8), xr);
+                            rd_unpack8(bxq[i][rr], xr);
 #pragma unroll
                             for (int q = 0; q < 8; ++q) {
                                 const float g = bn_stored_positive<bf16_t>(bn_fwd_value(xr[q], bmu[q], bis[q], bga[q], bbe[q])) ? r[q] : 0.f;
@@ -176,7 +191,7 @@ __device__ __forceinline__ void conv_bf16_epilogue_vec(const ConvBArgs& a, f32x1
                 }
             }
         }
-        if (a.stats && !a.out_f32) {
+        if (STATS && a.stats && !a.out_f32) {
             // lanes with the same (lane % LPR) hold the same 8 channels of different rows: a fixed butterfly over the row-lane bits,
             // then lanes 0 .. LPR-1 write the wave's row of partial sums (<= (BM / WM) values per sum in fp32, fp64 from here on)
             constexpr int LPR = WC / 8;
@@ -202,7 +217,7 @@ __device__ __forceinline__ void conv_bf16_epilogue_vec(const ConvBArgs& a, f32x1
 
 // acc: the wave's (BM/WM) x (BN/WN) tile as TM x TN 32x32 MFMA accumulators; smem: the workgroup's dynamic LDS (idle
 // once the K loop is done); wm / wn: the wave's position in the WM x WN grid.
-template <int BM, int BN, int WM, int WN, int TM, int TN>
+template <int BM, int BN, int WM, int WN, int TM, int TN, bool STATS = false>
 __device__ __forceinline__ void conv_bf16_epilogue(const ConvBArgs& a, f32x16 (&acc)[TM][TN], unsigned char* smem, const long long m0,
                                                    const int n0, const int wave, const int lane, const int wm, const int wn)
 {
@@ -229,7 +244,7 @@ __device__ __forceinline__ void conv_bf16_epilogue(const ConvBArgs& a, f32x16 (&
     const bf16_t* resb = reinterpret_cast<const bf16_t*>(d.res);
     bf16_t* yb = reinterpret_cast<bf16_t*>(d.y);
     if (a.vec_out && n0 + BN <= d.N && m0 + BM <= a.M) {
-        conv_bf16_epilogue_vec<BM, BN, WM, WN, TM, TN, false>(a, acc, smem, m0, n0, wave, lane, wm, wn);
+        conv_bf16_epilogue_vec<BM, BN, WM, WN, TM, TN, false, STATS>(a, acc, smem, m0, n0, wave, lane, wm, wn);
         return;
     }
 #pragma unroll

@@ -20,7 +20,7 @@
 //     bytes per FLOP.
 #include "conv_bf16_common.h"
 
-template <int BM, int BN, int RB, int WM, int WN, int NST>
+template <int BM, int BN, int RB, int WM, int WN, int NST, bool STATS = false>
 __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_igemm_bf16_kernel(const ConvBArgs a)
 {
     constexpr int NW = WM * WN;      // wavefronts per workgroup
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_igemm
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing may still be landing in LDS when the block retires
     }
 
-    conv_bf16_epilogue<BM, BN, WM, WN, TM, TN>(a, acc, smem, m0, n0, wave, lane, wm, wn);
+    conv_bf16_epilogue<BM, BN, WM, WN, TM, TN, STATS>(a, acc, smem, m0, n0, wave, lane, wm, wn);
 }
 
 // split-K second pass: fixed-order sum of the partial accumulators + the epilogue (output / residual bf16, or fp32)
@@ -309,6 +309,16 @@ static int conv_bf16_launch_one(const ConvBArgs& a, int nsplit, hipStream_t s)
     constexpr int lds_stage = NST * (BM + BN) * RB;
     constexpr int lds_epi = WM * WN * 32 * (BN / WN + 8) * 4;  // per-wave transpose slices of the coalesced epilogue
     constexpr int lds = lds_stage > lds_epi ? lds_stage : lds_epi;
+    if (a.stats) {  // training: the instantiation whose epilogue writes BatchNorm partial sums (RB = 128 only: the trunk / head layers)
+        if constexpr (RB == 128 && WM * WN == 4) {
+            auto kern = conv_igemm_bf16_kernel<BM, BN, RB, WM, WN, NST, true>;
+            if (lds > 64 * 1024) {
+                RD_LDS_OPT_IN(kern, lds);
+            }
+            hipLaunchKernelGGL(kern, dim3((unsigned)(a.mtiles * a.ntiles), (unsigned)nsplit), dim3(64 * WM * WN), lds, s, a);
+            return RDPN6D_OK;
+        }
+    }
     auto kern = conv_igemm_bf16_kernel<BM, BN, RB, WM, WN, NST>;
     if (lds > 64 * 1024) {
         RD_LDS_OPT_IN(kern, lds);
@@ -436,7 +446,8 @@ static int conv2d_bf16_impl(const rdpn6d_conv_desc* d, int out_f32, int ksplit, 
         a.ntiles = d->Npad / bn;
     }
     if (stats_rows) *stats_rows = 0;
-    if (stats && !out_f32 && a.vec_out && d->N == d->Npad && ksplit <= 1 && ((bm == 256 && bn == 256) || a.M % bm == 0)) {
+    if (stats && !out_f32 && a.vec_out && d->N == d->Npad && ksplit <= 1 && rb == 128 && !(bm == 256 && bn == 128) &&
+        ((bm == 256 && bn == 256) || a.M % bm == 0)) {
         // every tile takes the coalesced epilogue (full column tiles: bn divides Npad = N; full row tiles, or the 8-phase kernel's masked rows)
         a.stats = stats;
         a.stats_row0 = stats_row0;
@@ -444,7 +455,7 @@ static int conv2d_bf16_impl(const rdpn6d_conv_desc* d, int out_f32, int ksplit, 
             a.bnb_x = bnb->x; a.bnb_cs = bnb->cs; a.bnb_co = bnb->co;
             a.bnb_mean = bnb->mean; a.bnb_invstd = bnb->invstd; a.bnb_gamma = bnb->gamma; a.bnb_beta = bnb->beta;
         }
-        *stats_rows = a.mtiles * ((bm == 256 && bn == 128) ? 4 : 2);  // wave rows per tile: WM of the launch below
+        *stats_rows = a.mtiles * 2;  // wave rows per tile: WM of the launch below
     }
     if (bm == 256 && bn == 256) {
         RD_REQUIRE(conv_bf16_8ph_eligible(a, rb), "256x256 tile needs Cin % 64 == 0, Npad % 256 == 0 and an even K-tile count");

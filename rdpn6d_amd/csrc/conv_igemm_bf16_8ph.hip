@@ -44,7 +44,7 @@ using ic = std::integral_constant<int, V>;
 
 // ABL: timing-only ablation mask of the probe build (-DRDPN6D_PROBE; results are wrong when != 0):
 // 1 = no DMA inside the loop, 2 = no fragment reads, 4 = no MFMAs, 8 = no counted vmcnt wait
-template <int ABL>
+template <int ABL, bool STATS = false>
 __global__ __launch_bounds__(512) void conv_igemm_bf16_8ph_kernel(const ConvBArgs a)
 {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(512) void conv_igemm_bf16_8ph_kernel(const ConvBArg
         if (sum == 123.456f) a.d.y[0] = sum;
     } else {
         // full column tiles and aligned channel slices are part of the eligibility: only the coalesced epilogue is needed
-        conv_bf16_epilogue_vec<256, 256, 2, 4, 4, 2, true>(a, acc, smem, m0, n0, wave, lane, wr, wc);
+        conv_bf16_epilogue_vec<256, 256, 2, 4, 4, 2, true, STATS>(a, acc, smem, m0, n0, wave, lane, wr, wc);
     }
 }
 
@@ -318,6 +318,14 @@ bool conv_bf16_8ph_eligible(const ConvBArgs& a, int rb)
 template <int ABL>
 static int launch_8ph(const ConvBArgs& a, hipStream_t s)
 {
+    if constexpr (ABL == 0) {
+        if (a.stats) {  // training: the instantiation whose epilogue writes BatchNorm partial sums
+            auto kern = conv_igemm_bf16_8ph_kernel<0, true>;
+            RD_LDS_OPT_IN(kern, LDS_8PH);
+            hipLaunchKernelGGL(kern, dim3((unsigned)(a.mtiles * a.ntiles)), dim3(512), LDS_8PH, s, a);
+            return RDPN6D_OK;
+        }
+    }
     auto kern = conv_igemm_bf16_8ph_kernel<ABL>;
     RD_LDS_OPT_IN(kern, LDS_8PH);
     hipLaunchKernelGGL(kern, dim3((unsigned)(a.mtiles * a.ntiles)), dim3(512), LDS_8PH, s, a);

@@ -15,7 +15,7 @@ using ic = std::integral_constant<int, V>;
 
 namespace {
 
-template <int BM, int BN, int WM, int WN, int NST, int PM>
+template <int BM, int BN, int WM, int WN, int NST, int PM, bool STATS = false>
 __global__ __launch_bounds__(512) void conv_lp_pp_kernel(const ConvBArgs a)
 {
     constexpr int RB = 128, RPP = 8, NW = 8;
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(512) void conv_lp_pp_kernel(const ConvBArgs a)
 
     // ---- epilogue: the shared coalesced one (scale / shift, residual, activation, 16-bit or fp32 store, BatchNorm partial sums);
     // every wave is past its last fragment read and no DMA is in flight - its __syncthreads() re-purposes the staging LDS
-    conv_bf16_epilogue_vec<BM, BN, WM, WN, TM, TN, true>(a, acc, smem, m0, n0, wave, lane, wm, wn);
+    conv_bf16_epilogue_vec<BM, BN, WM, WN, TM, TN, true, STATS>(a, acc, smem, m0, n0, wave, lane, wm, wn);
 }
 
 template <int BM, int BN, int WM, int WN, int NST, int PM>
@@ -227,6 +227,12 @@ static int launch_lp_pp(const ConvBArgs& a, hipStream_t s)
     constexpr int lds_epi = 8 * 32 * (BN / WN + 8) * 4;
     constexpr int lds = lds_stage > lds_epi ? lds_stage : lds_epi;
     static_assert(lds <= 160 * 1024, "LDS");
+    if (a.stats) {  // training: the instantiation whose epilogue writes BatchNorm partial sums
+        auto kern = conv_lp_pp_kernel<BM, BN, WM, WN, NST, PM, true>;
+        RD_LDS_OPT_IN(kern, lds);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(a.mtiles * a.ntiles)), dim3(512), lds, s, a);
+        return RDPN6D_OK;
+    }
     auto kern = conv_lp_pp_kernel<BM, BN, WM, WN, NST, PM>;
     RD_LDS_OPT_IN(kern, lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)(a.mtiles * a.ntiles)), dim3(512), lds, s, a);
