@@ -157,10 +157,67 @@ __global__ void upsample_bilinear_bwd_kernel(const T* __restrict__ dy, int B, in
     }
 }
 
+// the same sums (same order: oy outer, ox inner) for V consecutive channels per thread: the weights depend on the pixel pair only, the loads
+// are 16 bytes (one thread per element with 2-byte loads took 334 us on the ResNet-50 trunk's 2048-channel 10x10 -> 40x40 map, 75 us on
+// ResNet-34's)
+template <typename T, int V>
+__global__ void upsample_bilinear_bwd_vec_kernel(const T* __restrict__ dy, int B, int H, int W, int C, int f, T* __restrict__ dx)
+{
+    const int Ho = H * f, Wo = W * f, CV = C / V;
+    const float sy = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f;
+    const float sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+    const long long total = (long long)B * H * W * CV;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % CV) * V;
+        long long p = i / CV;
+        const int ix = (int)(p % W);
+        p /= W;
+        const int iy = (int)(p % H);
+        const int b = (int)(p / H);
+        float g[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) g[e] = 0.f;
+        const int oy_lo = iy == 0 ? 0 : (int)ceilf((float)(iy - 1) / sy) - 1, oy_hi = (int)floorf((float)(iy + 1) / sy) + 1;
+        const int ox_lo = ix == 0 ? 0 : (int)ceilf((float)(ix - 1) / sx) - 1, ox_hi = (int)floorf((float)(ix + 1) / sx) + 1;
+        for (int oy = oy_lo < 0 ? 0 : oy_lo; oy <= oy_hi && oy < Ho; ++oy) {
+            const float fy = sy * oy;
+            const int y0 = (int)fy, y1 = y0 + (y0 < H - 1);
+            const float ly = fy - y0, hy = 1.f - ly;
+            float wy = 0.f;
+            if (y0 == iy) wy += hy;
+            if (y1 == iy) wy += ly;
+            if (wy == 0.f) continue;
+            for (int ox = ox_lo < 0 ? 0 : ox_lo; ox <= ox_hi && ox < Wo; ++ox) {
+                const float fx = sx * ox;
+                const int x0 = (int)fx, x1 = x0 + (x0 < W - 1);
+                const float lx = fx - x0, hx = 1.f - lx;
+                float wx = 0.f;
+                if (x0 == ix) wx += hx;
+                if (x1 == ix) wx += lx;
+                if (wx == 0.f) continue;
+                float v[V];
+                rd_ldv<T, V>(dy + (((long long)b * Ho + oy) * Wo + ox) * C + c, v);
+                const float w = wy * wx;
+#pragma unroll
+                for (int e = 0; e < V; ++e) g[e] += w * v[e];
+            }
+        }
+        rd_stv<T, V>(dx + (((long long)b * H + iy) * W + ix) * C + c, g);
+    }
+}
+
 template <typename T>
 static int upsample_bwd_impl(const T* dy, int B, int H, int W, int C, int factor, T* dx, void* stream)
 {
     RD_REQUIRE(dy && dx && B > 0 && H > 1 && W > 1 && C > 0 && factor >= 2, "shape");
+    constexpr int V = sizeof(T) == 2 ? 8 : 4;
+    if (C % V == 0) {
+        const long long totalv = (long long)B * H * W * (C / V);
+        const int blocksv = (int)((totalv + 255) / 256 < 32768 ? (totalv + 255) / 256 : 32768);
+        hipLaunchKernelGGL((upsample_bilinear_bwd_vec_kernel<T, V>), dim3(blocksv), dim3(256), 0, (hipStream_t)stream, dy, B, H, W, C, factor, dx);
+        RD_LAUNCH_CHECK();
+        return RDPN6D_OK;
+    }
     const long long total = (long long)B * H * W * C;
     const int blocks = (int)((total + 255) / 256 < 32768 ? (total + 255) / 256 : 32768);
     hipLaunchKernelGGL(upsample_bilinear_bwd_kernel<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, B, H, W, C, factor, dx);
