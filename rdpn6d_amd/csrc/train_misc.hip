@@ -7,6 +7,7 @@
 //                                                                   utils.py:208-236, rot_reps.py:34-49,
 //                                                                   pm_loss.py:102-114, GDRN.py:529-554)
 #include "common.h"
+#include <cstdlib>
 #include <float.h>
 
 // ------------------------------------------------------------------------------------------------
@@ -491,8 +492,25 @@ __global__ __launch_bounds__(128) void dense_glue_bwd_kernel(const float* __rest
     float* s_g = s_rows + NT * sh;
     const long long i0 = (long long)blockIdx.x * NT, total = (long long)B * HW;
     const int npx = (int)(total - i0 < NT ? total - i0 : NT);
-    for (int j = threadIdx.x; j < npx * head_cs; j += NT) s_h[(j / head_cs) * sh + j % head_cs] = head[i0 * head_cs + j];
-    for (int j = threadIdx.x; j < npx * pnp_cs; j += NT) s_g[(j / pnp_cs) * sg + j % pnp_cs] = dpnp[i0 * pnp_cs + j];
+    // (eight loads in flight per thread: as one load -> LDS store per iteration the two copies were ~170 dependent round trips)
+    auto stage_rows = [&](const float* __restrict__ src, float* dst, const int cs, const int ss) {
+        const int n = npx * cs;
+        for (int j0 = threadIdx.x; j0 < n; j0 += 8 * NT) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u * NT;
+                v[u] = j < n ? src[i0 * cs + j] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u * NT;
+                if (j < n) dst[(j / cs) * ss + j % cs] = v[u];
+            }
+        }
+    };
+    stage_rows(head, s_h, head_cs, sh);
+    stage_rows(dpnp, s_g, pnp_cs, sg);
     __syncthreads();
     const long long i = i0 + threadIdx.x;
     if (threadIdx.x < npx) {
@@ -543,7 +561,22 @@ __global__ __launch_bounds__(128) void dense_glue_bwd_kernel(const float* __rest
         if (k < K) h[5 + k] = e[k] * (g[11 + k] * att - dot);
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < npx * head_cs; j += NT) dhead[i0 * head_cs + j] += s_h[(j / head_cs) * sh + j % head_cs];
+    {
+        const int n = npx * head_cs;
+        for (int j0 = threadIdx.x; j0 < n; j0 += 8 * NT) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u * NT;
+                v[u] = j < n ? dhead[i0 * head_cs + j] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int j = j0 + u * NT;
+                if (j < n) dhead[i0 * head_cs + j] = v[u] + s_h[(j / head_cs) * sh + j % head_cs];
+            }
+        }
+    }
 }
 
 // per-sample min/max terms of att = (m - mn)/(mx - mn): d/dmn = sum datt*(m - mx)/range^2 -> first arg-min pixel,
@@ -603,7 +636,8 @@ extern "C" int rdpn6d_dense_glue_backward_f32(const float* head, int head_cs, co
     hipStream_t s = (hipStream_t)stream;
     RD_REQUIRE(head_cs >= 5 + K && pnp_cs >= 11 + K && head_cs <= 128 && pnp_cs <= 128, "row strides");
     const int rowf = (head_cs | 1) + (pnp_cs | 1);          // floats of LDS per pixel
-    const int nt = rowf * 128 * 4 <= 64 * 1024 ? 128 : 64;  // pixels (= threads) per workgroup
+    static const int nt_env = getenv("RDPN6D_GLUE_BWD_NT") ? atoi(getenv("RDPN6D_GLUE_BWD_NT")) : 0;  // profiling
+    const int nt = nt_env ? nt_env : (rowf * 128 * 4 <= 64 * 1024 ? 128 : 64);  // pixels (= threads) per workgroup
     const unsigned blocks = (unsigned)(((long long)B * HW + nt - 1) / nt);
     const size_t lds = (size_t)rowf * nt * 4;
     if (K <= 32)
