@@ -194,6 +194,11 @@ int rdpn6d_stem_pool_h2(const float* x, int B, int xc, int R, const void* w_h2, 
  * front of the 16-bit inference mode (cfg.TEST.AMP_TEST; gdrn_evaluator.py:625): fp32-accurate arithmetic, one rounding on the store */
 int rdpn6d_stem_pool_h2_ex(const float* x, int B, int xc, int R, const void* w_h2, const float* scale, const float* shift, void* y,
                            int out_fmt, int* overflow_flag, void* stream);
+/* conv1 weights OIHW [64][3][7][7] fp32 -> the h2 weight tensor of rdpn6d_stem_pool_h2* ([64][6][2][32] fp16, reduction index
+ * k = (c*7 + ky)*8 + kx padded to 192) and the per-channel factor 2^-sw(n) / 16 to use as its `scale` (times a folded BatchNorm scale, if
+ * any): one launch - the training step re-packs after every optimizer step.  rdpn6d_stem_pool_h2_ex(out_fmt = 3 | 4) is the RAW stem
+ * convolution (no ReLU, no pooling) as a bf16 / fp16 NHWC tensor [B, R/2, R/2, 64]: the mixed-precision training forward. */
+int rdpn6d_stem_pack_h2(const float* w_oihw, void* w_h2, float* inv_scale, void* stream);
 void rdpn6d_conv_bf16_force_chunk(int row_bytes); /* profiling: 0 = auto, 64 forces 32-channel K-chunks (measured slower) */
 /* bf16 forms of the kernels between the bf16 convolutions (same argument meaning as the _f32 entry points; activations
  * bf16 NHWC with C % 8 == 0; the stem and the xyz subsample read the fp32 NCHW crop and write bf16) */

@@ -129,6 +129,7 @@ SIGNATURES = {
     "rdpn6d_xyz_subsample_h2": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp, _vp]),
     "rdpn6d_stem_pool_h2": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rdpn6d_stem_pool_h2_ex": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "rdpn6d_stem_pack_h2": (_i, [_vp, _vp, _vp, _vp]),
     "rdpn6d_global_max_concat_h2": (_i, [_vp, _i, _i, _i, _i, _vp]),
     "rdpn6d_upsample_bilinear_h2_ex": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _i, _i, _vp, _vp]),
     "rdpn6d_global_max_h2": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),

@@ -308,7 +308,10 @@ typedef unsigned sp_u32x4 __attribute__((ext_vector_type(4)));
 __host__ __device__ constexpr int sp_rowoff(int rw) { return rw >= 21 ? 0 : ((rw / 7) * SP_IH + rw % 7) * SP_IWS; }
 
 // OUT: 0 = the pooled activation as an h2 tensor; 1 / 2 = as a plain bf16 / fp16 NHWC tensor [B, R/4, R/4, 64] (the 16-bit inference
-// mode, cfg.TEST.AMP_TEST: the arithmetic stays the fp32-accurate h2 one, only the stored result is rounded)
+// mode, cfg.TEST.AMP_TEST: the arithmetic stays the fp32-accurate h2 one, only the stored result is rounded); 3 / 4 = NO pooling and
+// no ReLU: scale * conv + shift of the 16 x 32 stem pixels the tile owns as a bf16 / fp16 NHWC tensor [B, R/2, R/2, 64] - the RAW stem
+// convolution of the mixed-precision training forward (BatchNorm with batch statistics, ReLU and the max-pool are separate launches
+// there; the tile's first row / column, computed for the pooling windows of the inference forms, is simply not stored)
 template <int OUT>
 __global__ __launch_bounds__(256, 2) void stem_pool_h2_kernel(const float* __restrict__ x, int xc, int R, const _Float16* __restrict__ w_h2,
                                                               const float* __restrict__ scale, const float* __restrict__ shift,
@@ -465,11 +468,41 @@ __global__ __launch_bounds__(256, 2) void stem_pool_h2_kernel(const float* __res
                 if (wave + 4 * m >= SP_MT) continue;
                 float* tp = s_t + ((wave + 4 * m) * 32 + 4 * half) * SP_TS + (r & 15);
 #pragma unroll
-                for (int e = 0; e < 16; ++e) tp[((e & 3) + 8 * (e >> 2)) * SP_TS] = fmaxf(acc[m][nt][e] * sc + sh, 0.f);
+                for (int e = 0; e < 16; ++e) {
+                    const float v = acc[m][nt][e] * sc + sh;
+                    tp[((e & 3) + 8 * (e >> 2)) * SP_TS] = OUT >= 3 ? v : fmaxf(v, 0.f);
+                }
             }
         }
         __syncthreads();
-        {   // 3x3 / stride 2 max-pool + h2 record: one work item = (pooled pixel, 8 channels) per thread
+        if constexpr (OUT >= 3) {  // raw stem pixels (ty, tx) = (1 .. 16, 1 .. 32) of the tile: one work item = (pixel, 8 channels)
+            const int Rs = R / 2;
+#pragma unroll
+            for (int u = 0; u < (2 * SP_PH) * (2 * SP_PW) * 2 / 256; ++u) {
+                const int item = tid + 256 * u;
+                const int c8 = (item & 1) * 8, pix = item >> 1, ty = 1 + pix / (2 * SP_PW), tx = 1 + pix % (2 * SP_PW);
+                const int sy = sy0 + ty, sx = sx0 + tx;
+                if (sy < Rs && sx < Rs) {
+                    const float* tp = s_t + (ty * SP_SW + tx) * SP_TS + c8;
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(tp), c = *reinterpret_cast<const f32x4*>(tp + 4);
+                    const float m8[8] = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+                    sp_u32x4 pk;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        typedef float sp_f2 __attribute__((ext_vector_type(2)));
+                        if constexpr (OUT == 3) {
+                            typedef __bf16 sp_b2 __attribute__((ext_vector_type(2)));
+                            pk[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(sp_f2{m8[2 * e], m8[2 * e + 1]}, sp_b2));
+                        } else {
+                            typedef _Float16 sp_h2v __attribute__((ext_vector_type(2)));
+                            pk[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(sp_f2{m8[2 * e], m8[2 * e + 1]}, sp_h2v));
+                        }
+                    }
+                    unsigned short* dp = reinterpret_cast<unsigned short*>(y) + (((long long)b * Rs + sy) * Rs + sx) * 64 + q * 16 + c8;
+                    *reinterpret_cast<sp_u32x4*>(dp) = pk;
+                }
+            }
+        } else {   // 3x3 / stride 2 max-pool + h2 record: one work item = (pooled pixel, 8 channels) per thread
             const int c8 = (tid & 1) * 8, pq = tid >> 1, qy = pq / SP_PW, qx = pq - qy * SP_PW;
             const int py = py0 + qy, px = px0 + qx;
             if (py < Rp && px < Rp) {
@@ -544,7 +577,7 @@ extern "C" int rdpn6d_stem_pool_h2_ex(const float* x, int B, int xc, int R, cons
 {
     RD_REQUIRE(x && w_h2 && scale && shift && y, "null pointer");
     RD_REQUIRE(B > 0 && xc >= 3 && R > 0 && R % 4 == 0, "shape (R % 4)");
-    RD_REQUIRE(out_fmt >= 0 && out_fmt <= 2, "out_fmt: 0 = h2 tensor, 1 = bf16 NHWC, 2 = fp16 NHWC");
+    RD_REQUIRE(out_fmt >= 0 && out_fmt <= 4, "out_fmt: 0 = h2 tensor, 1 = bf16 NHWC, 2 = fp16 NHWC (pooled); 3 = bf16, 4 = fp16 raw stem output");
     RD_REQUIRE((reinterpret_cast<size_t>(x) & 15) == 0, "x must be 16-byte aligned (the patch is read with aligned 16-byte loads)");
     const int Rp = R / 4;
     dim3 grid(rd_cdiv(Rp, SP_PW), rd_cdiv(Rp, SP_PH), B);
@@ -555,10 +588,54 @@ extern "C" int rdpn6d_stem_pool_h2_ex(const float* x, int B, int xc, int R, cons
     } else if (out_fmt == 1) {
         RD_LDS_OPT_IN(stem_pool_h2_kernel<1>, SP_LDS);
         hipLaunchKernelGGL(stem_pool_h2_kernel<1>, grid, dim3(256), SP_LDS, s, x, xc, R, (const _Float16*)w_h2, scale, shift, (_Float16*)y, overflow_flag);
-    } else {
+    } else if (out_fmt == 2) {
         RD_LDS_OPT_IN(stem_pool_h2_kernel<2>, SP_LDS);
         hipLaunchKernelGGL(stem_pool_h2_kernel<2>, grid, dim3(256), SP_LDS, s, x, xc, R, (const _Float16*)w_h2, scale, shift, (_Float16*)y, overflow_flag);
+    } else if (out_fmt == 3) {
+        RD_LDS_OPT_IN(stem_pool_h2_kernel<3>, SP_LDS);
+        hipLaunchKernelGGL(stem_pool_h2_kernel<3>, grid, dim3(256), SP_LDS, s, x, xc, R, (const _Float16*)w_h2, scale, shift, (_Float16*)y, overflow_flag);
+    } else {
+        RD_LDS_OPT_IN(stem_pool_h2_kernel<4>, SP_LDS);
+        hipLaunchKernelGGL(stem_pool_h2_kernel<4>, grid, dim3(256), SP_LDS, s, x, xc, R, (const _Float16*)w_h2, scale, shift, (_Float16*)y, overflow_flag);
     }
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}
+
+// conv1 weights OIHW [64][3][7][7] fp32 -> the h2 tensor of the stem kernels + the per-channel factor 2^-sw(n) / 16 (what
+// gdrn.pack_stem_h2_weight computes with torch ops at plan-build time), as ONE launch: the training step re-packs after every
+// optimizer step.  One wavefront per output channel.
+__global__ __launch_bounds__(64) void stem_pack_h2_kernel(const float* __restrict__ w, _Float16* __restrict__ out, float* __restrict__ inv)
+{
+    const int n = blockIdx.x, lane = threadIdx.x;
+    const float* wn = w + n * 147;
+    float mx = 0.f;
+    for (int i = lane; i < 147; i += 64) mx = fmaxf(mx, fabsf(wn[i]));
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    // 2^sw brings the largest weight into [2^13, 2^14): sw = floor(13 - log2(mx))
+    int ex = 0;
+    float sw = 1.f;
+    if (mx > 0.f) {
+        const float m = frexpf(mx, &ex);  // mx = m * 2^ex, m in [0.5, 1)
+        sw = ldexpf(1.f, (m == 0.5f ? 14 : 13) - ex);
+    }
+    for (int k = lane; k < 192; k += 64) {
+        const int row = k >> 3, kx = k & 7;  // row = c * 7 + ky
+        const float v = (row < 21 && kx < 7) ? wn[row * 7 + kx] * sw : 0.f;
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        _Float16* o = out + ((size_t)(n * SP_KC + (k >> 5)) * 2) * 32 + (k & 31);
+        o[0] = hi;
+        o[32] = lo;
+    }
+    if (lane == 0) inv[n] = 1.f / (sw * H2_SCALE);
+}
+
+extern "C" int rdpn6d_stem_pack_h2(const float* w_oihw, void* w_h2, float* inv_scale, void* stream)
+{
+    RD_REQUIRE(w_oihw && w_h2 && inv_scale, "null pointer");
+    hipLaunchKernelGGL(stem_pack_h2_kernel, dim3(64), dim3(64), 0, (hipStream_t)stream, w_oihw, (_Float16*)w_h2, inv_scale);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
 }

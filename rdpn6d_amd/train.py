@@ -325,6 +325,9 @@ class TrainEngine:
                                               int(self._repack_bd.numel()), self.st()), "repack")
         for p3, t in self.mirrors3:
             _lib.check(self.lib.rdpn6d_split_bf16x3(_ptr(t), t.numel(), _ptr(p3), p3.shape[1], self.st()), "split weights")
+        if getattr(self, "_stem_h2", None) is not None:
+            w, wh, inv = self._stem_h2
+            _lib.check(self.lib.rdpn6d_stem_pack_h2(_ptr(w), _ptr(wh), _ptr(inv), self.st()), "stem weights")
 
     # ------------------------------------------------------------------ layer builders
     def conv_unit(self, name, P, x, xhw, in_cs, in_co, cin_real, y, yhw, out_cs, out_co, *, stride=1, perm=None, bias=None,
@@ -585,7 +588,18 @@ class TrainEngine:
         a0 = self.buf("act:stem", B, R2, R2, 64)
         sfx = self.sfx  # "bf16" under AMP: the kernels between the convolutions work on bf16-stored activations
         f_stem = getattr(lib, f"rdpn6d_stem_conv7x7_raw_{sfx}")
-        self.fwd.append(lambda: _lib.check(f_stem(_ptr(self.x), B, 6, R, _ptr(wst), _ptr(raw0), self.st()), "stem"))
+        self._stem_h2 = None
+        if self.amp and R % 4 == 0 and bool(self.model.cfg.get("SOLVER", {}).get("MFMA_STEM", os.environ.get("RDPN6D_MFMA_STEM", "1") != "0")):
+            # mixed precision: the raw stem convolution on the matrix pipe - the inference front's kernel (fp32-accurate h2 arithmetic on
+            # the patch in LDS) without ReLU / pooling, 16-bit output; its weight record is re-packed by refresh_weights (one launch)
+            wh = torch.empty(64, 6, 2, 32, dtype=torch.float16, device=self.dev)
+            inv, zero = torch.empty(64, dtype=torch.float32, device=self.dev), torch.zeros(64, dtype=torch.float32, device=self.dev)
+            self._stem_h2 = (bb.conv1.weight, wh, inv)
+            fmt = 3 if self.lp == "bf16" else 4
+            self.fwd.append(lambda: _lib.check(lib.rdpn6d_stem_pool_h2_ex(_ptr(self.x), B, 6, R, _ptr(wh), _ptr(inv), _ptr(zero), _ptr(raw0), fmt,
+                                                                          None, self.st()), "stem (MFMA)"))
+        else:
+            self.fwd.append(lambda: _lib.check(f_stem(_ptr(self.x), B, 6, R, _ptr(wst), _ptr(raw0), self.st()), "stem"))
         d_raw0 = self.buf("d:stem", B, R2, R2, 64, zero=True)
         xcol = self.buf("x_im2col", B * R2 * R2, 160, dtype=self.adt)   # stem patch matrix (built in the backward)
         wg_stem = self.buf("wg:stem", 64, 1, 160)
