@@ -218,6 +218,19 @@ def test_fused_stem_pool_h2_vs_fp64(B, R):
         err = (y16.cpu().double() - y64).abs()
         assert (err <= ulp * y64.abs() * 1.01 + e_h2 + 1e-7).all(), (fmt, err.max().item())  # (unit roundoff 2^-8 | 2^-11)
         assert torch.equal(y16.cpu(), mine.to(dt)) or (y16.cpu().double() - mine).abs().max().item() <= ulp * scale  # = the h2 result rounded once (up to double rounding)
+    # the RAW stem convolution (training forward, out_fmt 3 | 4: no ReLU, no pooling) with the device-packed weight record
+    wh2, inv2 = torch.empty_like(wh), torch.empty_like(inv)
+    _lib.check(lib.rdpn6d_stem_pack_h2(_ptr(w.to(dev).contiguous()), _ptr(wh2), _ptr(inv2), None))
+    torch.cuda.synchronize()
+    assert torch.equal(wh2, wh) and torch.equal(inv2, inv)  # = gdrn.pack_stem_h2_weight
+    raw64 = torch.nn.functional.conv2d(x[:, :3].double(), w.double(), stride=2, padding=3).permute(0, 2, 3, 1)
+    zero = torch.zeros(64, device=dev)
+    for fmt, dt, ulp in ((3, torch.bfloat16, 2.0 ** -8), (4, torch.float16, 2.0 ** -11)):
+        yr = torch.full((B, R // 2, R // 2, 64), float("nan"), dtype=dt, device=dev)
+        _lib.check(lib.rdpn6d_stem_pool_h2_ex(_ptr(xd), B, 6, R, _ptr(wh2), _ptr(inv2), _ptr(zero), _ptr(yr), fmt, None, None))
+        torch.cuda.synchronize()
+        err = (yr.cpu().double() - raw64).abs()
+        assert torch.isfinite(yr).all() and (err <= ulp * raw64.abs() * 1.01 + 2e-6 * raw64.abs().max().item()).all(), (fmt, err.max().item())
 
 
 def test_global_max_record_and_constant_input_bias_of_the_conv_transpose():
