@@ -925,3 +925,36 @@ def test_wgrad_bf16x3_has_fp32_accuracy(case):
           f"(rms {e32.pow(2).mean().sqrt().item() / scale:.2e} / {e3.pow(2).mean().sqrt().item() / scale:.2e})")
     assert e3.max().item() <= 1.5 * e32.max().item() + 1e-7 * scale
     assert e3.pow(2).mean().sqrt().item() <= 1.5 * e32.pow(2).mean().sqrt().item() + 1e-8 * scale
+
+
+@pytest.mark.parametrize("B,amp", [(32, "bf16"), (32, "fp16"), (4, False)])
+def test_training_step_is_deterministic(B, amp):
+    """Every reduction of the step has a fixed order (split-K slices and BatchNorm partial rows are added in index order, no atomics):
+    three forward + backward passes from the same weights and batch give the same nine losses and the same 164 gradients, BIT FOR BIT -
+    at B = 32 with the kernels the benchmark runs (256x256 eight-phase kernels whose epilogues write the BatchNorm sums, the 256x128
+    weight-gradient tile, split-lane split-K reduces, the MFMA stem) and on the fp32 path."""
+    from rdpn6d_amd import synth
+    from rdpn6d_amd.config import gdrn_base_cfg
+    from rdpn6d_amd.gdrn import build_model_optimizer
+
+    dev = torch.device("cuda:0")
+    cfg = gdrn_base_cfg(mask_attention="mul", device="cuda")
+    if amp:
+        cfg.SOLVER.AMP.ENABLED, cfg.SOLVER.AMP.DTYPE = True, amp
+    model, _ = build_model_optimizer(cfg)
+    sd = synth.make_trained_like_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=5)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    inp = synth.make_inputs(B, seed=3)
+    batch = {k: torch.from_numpy(v).to(dev) for k, v in {**inp, **synth.make_train_gt(B, inp)}.items()}
+    eng = model.train_engine(B, dev)
+    runs = []
+    for _ in range(3):
+        losses = eng.forward_backward(batch)
+        torch.cuda.synchronize()
+        runs.append(([float(v.item()) for v in losses.values()] if isinstance(losses, dict) else [float(v) for v in losses],
+                     [p.grad.clone() for p in model.parameters()]))
+    assert all(np.isfinite(runs[0][0])) and sum(g.abs().sum().item() for g in runs[0][1]) > 0
+    for r in runs[1:]:
+        assert r[0] == runs[0][0]
+        for (n, _), g0, g1 in zip(model.named_parameters(), runs[0][1], r[1]):
+            assert torch.equal(g0, g1), n
