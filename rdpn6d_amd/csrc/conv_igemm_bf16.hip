@@ -238,8 +238,18 @@ __global__ void conv_bf16_splitk_epilogue_kernel(const float* __restrict__ parti
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long m = i / d.N;
         const int n = (int)(i - m * d.N);
+        const float* p = partial + m * d.Npad + n;  // (slice order kept; eight loads in flight, see conv_igemm.hip)
+        const long long st = M * d.Npad;
         float v = 0.f;
-        for (int s = 0; s < nsplit; ++s) v += partial[((long long)s * M + m) * d.Npad + n];
+        int s = 0;
+        for (; s + 8 <= nsplit; s += 8) {
+            float t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = p[(long long)(s + u) * st];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v += t[u];
+        }
+        for (; s < nsplit; ++s) v += p[(long long)s * st];
         v = v * (d.scale ? d.scale[n] : 1.f) + (d.shift ? d.shift[n] : 0.f);
         if (d.res) v += out_f32 ? d.res[m * d.res_cs + d.res_co + n] : bf2f(resb[m * d.res_cs + d.res_co + n]);
         if (d.act == 1) v = v > 0.f ? v : 0.f;
