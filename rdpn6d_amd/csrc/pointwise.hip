@@ -291,13 +291,17 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm4_relu_kernel(float* __re
                                                                     const float* __restrict__ gamma,
                                                                     const float* __restrict__ beta)
 {
-    // thread t: group g = t % G (G = C/4 <= 64), pixel lane pl = t / G
-    const int G = C / 4;
+    // The groups are independent: workgroup (crop blockIdx.x, part blockIdx.y of gridDim.y) owns G = (C/4) / gridDim.y of them, thread t
+    // its group g = t % G and pixel lane pl = t / G.  (One workgroup per crop - gridDim.y = 1 - left 64 crops on a quarter of the CUs with
+    // 32 pixels per thread and pass: 34 us for the 32x32 map; four parts: a full chip, 8 pixels per thread.)
+    const int G = C / 4 / (int)gridDim.y;
     const int PL = GN_THREADS / G;
     __shared__ float s_part[GN_THREADS];
     __shared__ float s_mean[64], s_rstd[64];
     const int g = threadIdx.x % G, pl = threadIdx.x / G;
-    float* base = x + (long long)blockIdx.x * HW * C + g * 4;
+    float* base = x + (long long)blockIdx.x * HW * C + ((int)blockIdx.y * G + g) * 4;
+    gamma += (int)blockIdx.y * G * 4;
+    beta += (int)blockIdx.y * G * 4;
     float s = 0.f;
     for (int p = pl; p < HW; p += PL) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(base + (long long)p * C);
@@ -349,7 +353,8 @@ extern "C" int rdpn6d_groupnorm_relu_f32(float* x, int B, int HW, int C, int G, 
 {
     RD_REQUIRE(x && gamma && beta && B > 0 && HW > 0, "null/shape");
     RD_REQUIRE(C == 4 * G && G <= 64 && 256 % G == 0, "only C/G == 4 with G | 256 is implemented (GroupNorm(32,128))");
-    hipLaunchKernelGGL(groupnorm4_relu_kernel, dim3(B), dim3(GN_THREADS), 0, (hipStream_t)stream, x, HW, C, gamma, beta);
+    const int parts = (G % 4 == 0 && HW >= 256) ? 4 : 1;  // (small maps: one workgroup per crop is already short)
+    hipLaunchKernelGGL(groupnorm4_relu_kernel, dim3(B, parts), dim3(GN_THREADS), 0, (hipStream_t)stream, x, HW, C, gamma, beta);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
 }
