@@ -602,12 +602,13 @@ __global__ __launch_bounds__(NT) void gn4_fwd_train_kernel(const float* __restri
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* __restrict__ stats /* [B][G][2] mean, rstd */)
 {
-    const int G = C / 4, PL = NT / G;
+    // (the groups are independent: workgroup (crop blockIdx.x, part blockIdx.y) owns GT / gridDim.y of the GT = C / 4 groups)
+    const int GT = C / 4, G = GT / (int)gridDim.y, g0 = (int)blockIdx.y * G, PL = NT / G;
     __shared__ float s_part[NT];
     __shared__ float s_mean[64], s_rstd[64];
     const int g = threadIdx.x % G, pl = threadIdx.x / G;
-    const float* xb = x + (long long)blockIdx.x * HW * C + g * 4;
-    float* yb = y + (long long)blockIdx.x * HW * C + g * 4;
+    const float* xb = x + (long long)blockIdx.x * HW * C + (g0 + g) * 4;
+    float* yb = y + (long long)blockIdx.x * HW * C + (g0 + g) * 4;
     float s = 0.f;
     for (int p = pl; p < HW; p += PL) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(xb + (long long)p * C);
@@ -636,12 +637,12 @@ __global__ __launch_bounds__(NT) void gn4_fwd_train_kernel(const float* __restri
         for (int i = 0; i < PL; ++i) t += s_part[i * G + threadIdx.x];
         const float r = 1.0f / sqrtf(t / (float)(HW * 4) + 1e-5f);
         s_rstd[threadIdx.x] = r;
-        stats[((long long)blockIdx.x * G + threadIdx.x) * 2 + 0] = s_mean[threadIdx.x];
-        stats[((long long)blockIdx.x * G + threadIdx.x) * 2 + 1] = r;
+        stats[((long long)blockIdx.x * GT + g0 + threadIdx.x) * 2 + 0] = s_mean[threadIdx.x];
+        stats[((long long)blockIdx.x * GT + g0 + threadIdx.x) * 2 + 1] = r;
     }
     __syncthreads();
     const float rstd = s_rstd[g];
-    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + g * 4), be = *reinterpret_cast<const f32x4*>(beta + g * 4);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + (g0 + g) * 4), be = *reinterpret_cast<const f32x4*>(beta + (g0 + g) * 4);
     for (int p = pl; p < HW; p += PL) {
         f32x4 v = *reinterpret_cast<const f32x4*>(xb + (long long)p * C);
 #pragma unroll
@@ -658,14 +659,14 @@ __global__ __launch_bounds__(NT) void gn4_bwd_kernel(const float* __restrict__ x
                                                      const float* __restrict__ stats, float* __restrict__ dx,
                                                      float* __restrict__ dgb /* [B][2][C] */, int HW, int C)
 {
-    const int G = C / 4, PL = NT / G;
+    const int GT = C / 4, G = GT / (int)gridDim.y, g0 = (int)blockIdx.y * G, PL = NT / G;  // (parts of the groups as in the forward)
     __shared__ float s_p1[NT], s_p2[NT];
     __shared__ float s_s1[64], s_s2[64];
     __shared__ float s_dg[NT][4], s_db[NT][4];
     const int g = threadIdx.x % G, pl = threadIdx.x / G;
-    const long long base = (long long)blockIdx.x * HW * C + g * 4;
-    const float mean = stats[((long long)blockIdx.x * G + g) * 2], rstd = stats[((long long)blockIdx.x * G + g) * 2 + 1];
-    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + g * 4);
+    const long long base = (long long)blockIdx.x * HW * C + (g0 + g) * 4;
+    const float mean = stats[((long long)blockIdx.x * GT + g0 + g) * 2], rstd = stats[((long long)blockIdx.x * GT + g0 + g) * 2 + 1];
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + (g0 + g) * 4);
     float s1 = 0.f, s2 = 0.f;
     float dg[4] = {0, 0, 0, 0}, db[4] = {0, 0, 0, 0};
     for (int p = pl; p < HW; p += PL) {
@@ -699,8 +700,8 @@ __global__ __launch_bounds__(NT) void gn4_bwd_kernel(const float* __restrict__ x
         s_s2[threadIdx.x] = t2;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            dgb[((long long)blockIdx.x * 2 + 0) * C + threadIdx.x * 4 + e] = tg[e];
-            dgb[((long long)blockIdx.x * 2 + 1) * C + threadIdx.x * 4 + e] = tb[e];
+            dgb[((long long)blockIdx.x * 2 + 0) * C + (g0 + threadIdx.x) * 4 + e] = tg[e];
+            dgb[((long long)blockIdx.x * 2 + 1) * C + (g0 + threadIdx.x) * 4 + e] = tb[e];
         }
     }
     __syncthreads();
@@ -726,7 +727,7 @@ extern "C" int rdpn6d_groupnorm_relu_train_f32(const float* x, float* y, int B, 
 {
     RD_REQUIRE(x && y && gamma && beta && stats && B > 0 && HW > 0, "null/shape");
     RD_REQUIRE(C == 4 * G && G <= 64 && 256 % G == 0, "only C/G == 4 with G | 256 is implemented (GroupNorm(32,128))");
-    if (HW >= 256) hipLaunchKernelGGL(gn4_fwd_train_kernel<1024>, dim3(B), dim3(1024), 0, (hipStream_t)stream, x, y, HW, C, gamma, beta, stats);
+    if (HW >= 256) hipLaunchKernelGGL(gn4_fwd_train_kernel<1024>, dim3(B, G % 4 == 0 ? 4 : 1), dim3(1024), 0, (hipStream_t)stream, x, y, HW, C, gamma, beta, stats);
     else hipLaunchKernelGGL(gn4_fwd_train_kernel<256>, dim3(B), dim3(256), 0, (hipStream_t)stream, x, y, HW, C, gamma, beta, stats);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
@@ -739,7 +740,7 @@ extern "C" int rdpn6d_groupnorm_relu_backward_f32(const float* x, const float* y
 {
     RD_REQUIRE(x && y && dy && gamma && stats && dx && dgamma && dbeta && dgb_scratch && scratch, "null pointer");
     RD_REQUIRE(C == 4 * G && G <= 64 && 256 % G == 0, "only C/G == 4 with G | 256 is implemented");
-    if (HW >= 256) hipLaunchKernelGGL(gn4_bwd_kernel<1024>, dim3(B), dim3(1024), 0, (hipStream_t)stream, x, y, dy, gamma, stats, dx, dgb_scratch, HW, C);
+    if (HW >= 256) hipLaunchKernelGGL(gn4_bwd_kernel<1024>, dim3(B, G % 4 == 0 ? 4 : 1), dim3(1024), 0, (hipStream_t)stream, x, y, dy, gamma, stats, dx, dgb_scratch, HW, C);
     else hipLaunchKernelGGL(gn4_bwd_kernel<256>, dim3(B), dim3(256), 0, (hipStream_t)stream, x, y, dy, gamma, stats, dx, dgb_scratch, HW, C);
     RD_LAUNCH_CHECK();
     // [B][2C] rows -> per-column sums: dgamma = cols [0,C), dbeta = cols [C,2C)
