@@ -150,7 +150,7 @@ def test_fp16_training_through_the_reference_loop_with_gradscaler():
     assert np.isfinite(hist).all() and hist[-1] < hist[0]
     # the scale has settled: two halvings from 65536, then steady steps - at most ONE more skipped step in the last five (a gradient
     # spike of this ill-conditioned fixture; which step it hits depends on the last bit of the weight gradients)
-    assert scales[-1] >= scales[-5] / 2 and scales[-1] >= 4096.0 and len(set(hist[3:])) == len(hist[3:]), (scales, hist)
+    assert scales[-1] >= scales[-5] / 2 and scales[-1] >= 4096.0 and len(set(hist[3:])) >= len(hist[3:]) - 1, (scales, hist)  # (a skipped step repeats its loss)
 
 
 def test_fp16_step_vs_autocast_fp16_yardstick_and_c5_resnet50_320():
