@@ -260,12 +260,16 @@ class GDRNOracle(nn.Module):
     def dense(self, x):
         return self.rot_head_net(self.backbone(x))
 
-    def glue(self, mask, cx, cy, cz, region, roi_coord_2d, fps):
+    def glue(self, mask, cx, cy, cz, region, roi_coord_2d, fps, force_argmax=None):
+        """force_argmax (B, r, r) int: take the region decision from the implementation under test instead of the arg-max of the
+        oracle's own softmax (tests only: compares the pose branch GIVEN the same decisions at near-tie pixels)"""
         B = mask.shape[0]
         r = self.out_res
         coor_feat = torch.cat([cx, cy, cz, roi_coord_2d], 1)
         prob = F.softmax(region[:, 1:], dim=1)
         amax = prob.reshape(B, prob.shape[1], -1).argmax(dim=1)  # (B, HW), arg-max ON the softmax output
+        if force_argmax is not None:
+            amax = torch.as_tensor(force_argmax).reshape(B, -1).to(torch.int64)
         anchors = torch.gather(fps, 1, amax.unsqueeze(2).expand(-1, -1, 3))  # (B,HW,3)
         anchors = anchors.reshape(B, r, r, 3).permute(0, 3, 1, 2)
         coor_feat = torch.cat([coor_feat, anchors], 1)
@@ -276,9 +280,12 @@ class GDRNOracle(nn.Module):
             att = (mask - mn) / (mx - mn)
         return coor_feat, prob, att, amax.reshape(B, r, r)
 
-    def forward(self, x, roi_coord_2d, fps, roi_cams, roi_centers, roi_whs, resize_ratios, train_pose=False):
-        mask, cx, cy, cz, region = self.dense(x)
-        coor_feat, prob, att, amax = self.glue(mask, cx, cy, cz, region, roi_coord_2d, fps)
+    def forward(self, x, roi_coord_2d, fps, roi_cams, roi_centers, roi_whs, resize_ratios, train_pose=False, dense_maps=None,
+                force_argmax=None):
+        """dense_maps = (mask, coor_x, coor_y, coor_z, region): start from given head outputs (teacher forcing: the reference's own
+        golden maps) instead of running trunk + head on x; force_argmax: see glue()"""
+        mask, cx, cy, cz, region = self.dense(x) if dense_maps is None else dense_maps
+        coor_feat, prob, att, amax = self.glue(mask, cx, cy, cz, region, roi_coord_2d, fps, force_argmax=force_argmax)
         rot6d, pred_t = self.pnp_net(coor_feat, prob, att)
         rot_allo = rot6d_to_mat(rot6d)
         trans = site_translation(pred_t, roi_cams, roi_centers, roi_whs, resize_ratios)

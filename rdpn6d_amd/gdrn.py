@@ -1125,11 +1125,8 @@ class GDRN(nn.Module):
                  "roi_mask_visib": gt_mask_visib, "roi_mask_trunc": gt_mask_trunc, "roi_region": gt_region, "ego_rot": gt_ego_rot,
                  "roi_trans_ratio": gt_trans_ratio, "roi_points": gt_points, "sym_info": sym_infos}
         losses = eng.forward_losses(batch)  # (bumps the weights epoch: BatchNorm running statistics moved)
-        names = list(losses)
-        anchor = next(p for p in self.parameters() if p.requires_grad)
-        outs = _HipBackward.apply(anchor, eng, *[losses[n] for n in names])
         self.last_train_pose = (eng.rot, eng.trans)
-        return {}, dict(zip(names, outs))
+        return {}, _attach_hip_backward(self, eng, losses)
 
     def _stamp_list(self):
         ts = self._stamp_tensors
@@ -1322,27 +1319,73 @@ class GDRN(nn.Module):
 
 
 class _HipBackward(torch.autograd.Function):
-    """Glue between ``losses.backward()`` (engine.py:308) and the HIP backward pass: the nine loss tensors come out of
-    this node; when autograd reaches it, the whole hand-written backward runs and writes ``param.grad`` directly."""
+    """Glue between ``losses.backward()`` (engine.py:308) and the HIP backward pass.  One node per parameter group, chained in the
+    order the backward completes them (parallel.GROUPS: pnp_net -> rot_head_net -> backbone):
+
+        token_bb = stage(backbone params)            token_hd = stage(token_bb, rot_head params)
+        nine losses = stage(token_hd, losses, pnp_net params)
+
+    The group's trainable PARAMETERS are inputs of its node and the node's backward returns their gradients, so every parameter's
+    AccumulateGrad runs - which is what torch DDP (and Lightning-Lite's ``_LiteModule`` around it: main_gdrn.py:113, engine.py:308)
+    hangs its bucket all-reduce hooks on.  AccumulateGrad nodes outrank every other node in autograd's ready queue, so a group's
+    hooks fire right after its stage, while the later stages' kernels are still being issued: DDP's all-reduces overlap the rest
+    of the backward exactly like parallel.GradBuckets' do.
+    The kernels write the gradients into ``param.grad``'s memory (a view of Ranger's / GradBuckets' flat buffer, or a fresh tensor);
+    the stage then takes that tensor OUT of ``param.grad`` and hands it to autograd, whose AccumulateGrad adopts it without a
+    copy (an undefined .grad + a gradient nobody else references is stolen: torch/csrc/autograd/functions/accumulate_grad.h) -
+    ``param.grad`` ends up on the same memory, written once, never added to itself."""
 
     @staticmethod
-    def forward(ctx, anchor, engine, *losses):
-        ctx.engine = engine
-        return tuple(l.clone() for l in losses)
+    def forward(ctx, engine, state, group, n_losses, is_last, token, *rest):
+        ctx.engine, ctx.state, ctx.group, ctx.n_losses, ctx.is_last = engine, state, group, n_losses, is_last
+        ctx.params = rest[n_losses:]
+        ctx.has_token = token is not None
+        if n_losses:
+            return tuple(l.clone() for l in rest[:n_losses])
+        return torch.zeros((), device=engine.dev)
 
     @staticmethod
     def backward(ctx, *gouts):
-        # d(total)/d(loss_i) as autograd hands it over: 1 for the reference's un-weighted sum (engine.py:292), the loss scale
-        # under a GradScaler (engine.py:302-309), 1/accum for gradient accumulation, 0 for a loss left out of the sum.  One
-        # host read of the nine scalars per step (the reference's own loop reads every loss with .item(), engine.py:299-300).
-        eng = ctx.engine
-        w = torch.stack([g.detach().reshape(()).float() if g is not None else torch.zeros((), device=eng.dev) for g in gouts]).tolist()
-        eng.seed_backward(dict(zip(eng.LOSS_NAMES, w)))
-        eng.backward()
-        hook = getattr(ctx.engine, "after_backward", None)
-        if hook is not None:
-            hook()
-        return (None, None) + (None,) * len(gouts)
+        eng, state = ctx.engine, ctx.state
+        if ctx.n_losses:
+            # d(total)/d(loss_i) as autograd hands it over: 1 for the reference's un-weighted sum (engine.py:292), the loss scale
+            # under a GradScaler (engine.py:302-309), 1/accum for gradient accumulation, 0 for a loss left out of the sum.  One
+            # host read of the nine scalars per step (the reference's own loop reads every loss with .item(), engine.py:299-300).
+            w = torch.stack([g.detach().reshape(()).float() if g is not None else torch.zeros((), device=eng.dev) for g in gouts]).tolist()
+            eng.seed_backward(dict(zip(eng.LOSS_NAMES, w)))
+            state["stages"] = eng.backward_stages()
+        # run the engine's backward up to (and including) this node's group; the LAST node of the chain drains the generator
+        for done in state["stages"]:
+            if done == ctx.group and not ctx.is_last:
+                break
+        grads = []
+        for p in ctx.params:
+            g = p.grad
+            p.grad = None  # AccumulateGrad re-adopts g (no copy, no add): see the class comment
+            grads.append(g)
+        if ctx.is_last:
+            hook = getattr(eng, "after_backward", None)
+            if hook is not None:
+                hook()
+        gtok = torch.zeros((), device=eng.dev) if ctx.has_token else None
+        return (None, None, None, None, None, gtok) + (None,) * ctx.n_losses + tuple(grads)
+
+
+def _attach_hip_backward(model, eng, losses):
+    """the nine loss tensors, hanging off the chained _HipBackward nodes (one per parameter group with trainable parameters)"""
+    from .parallel import GROUPS
+
+    names = list(losses)
+    groups = [(g, [p for p in getattr(model, g).parameters() if p.requires_grad]) for g in GROUPS]
+    groups = [(g, ps) for g, ps in groups if ps]
+    if not groups:
+        raise RuntimeError("rdpn6d_amd.GDRN: do_loss=True with every parameter frozen - nothing to differentiate")
+    state, token = {}, None
+    for i in range(len(groups) - 1, -1, -1):  # built from the END of the backward (backbone) towards its start (pnp_net)
+        g, ps = groups[i]
+        n = len(names) if i == 0 else 0
+        token = _HipBackward.apply(eng, state, g, n, i == len(groups) - 1, token, *([losses[k] for k in names] if n else []), *ps)
+    return dict(zip(names, token))
 
 
 def _check_supported(cfg):

@@ -15,6 +15,21 @@ import torch.distributed as dist
 GROUPS = ("pnp_net", "rot_head_net", "backbone")  # completion order of the backward
 
 
+def flat_grad_storage(grads):
+    """the 1-D fp32 tensor spanning the ONE storage all of `grads` live in (the flat gradient buffer of GradBuckets / Ranger), or
+    None.  By storage rather than by ``_base``: a gradient autograd's AccumulateGrad adopted (torch DDP, gdrn._HipBackward) is a
+    detached alias of the flat buffer's memory, not a view of the flat tensor."""
+    grads = [g for g in grads if g is not None]
+    if not grads or any(g.dtype != torch.float32 or not g.is_contiguous() for g in grads):
+        return None
+    st = grads[0].untyped_storage()
+    if any(g.untyped_storage().data_ptr() != st.data_ptr() for g in grads[1:]) or st.nbytes() % 4:
+        return None
+    if sum(g.numel() for g in grads) * 4 > st.nbytes():  # (aliases of each other rather than tiles of one buffer)
+        return None
+    return torch.empty(0, dtype=torch.float32, device=grads[0].device).set_(st, 0, (st.nbytes() // 4,))
+
+
 def shard_range(n, rank, world):
     """contiguous shard [begin, end) of n items for this rank (InferenceSampler semantics)"""
     shard = (n - 1) // world + 1 if n > 0 else 0

@@ -58,10 +58,10 @@ class Ranger(Optimizer):
         # of all five flat buffers - the all-reduce views stay valid.  The work tables below address parameters by offset,
         # so no particular order is needed.  Otherwise a fresh buffer in param_groups order is made.
         fg = self._ext_flat_grad
-        if fg is None:
-            bases = {id(p.grad._base) for p in ps if p.grad is not None and p.grad._base is not None}
-            if len(bases) == 1 and all(p.grad is not None and p.grad._base is not None for p in ps):
-                fg = ps[0].grad._base
+        if fg is None and all(p.grad is not None for p in ps):
+            from .parallel import flat_grad_storage
+
+            fg = flat_grad_storage([p.grad for p in ps])  # (by storage: survives autograd's AccumulateGrad re-adopting the views)
         offs, adopt = {}, False
         if fg is not None:
             adopt = fg.dim() == 1 and fg.numel() == n and fg.dtype == torch.float32 and fg.is_contiguous() and fg.device == dev

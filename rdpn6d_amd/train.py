@@ -1026,11 +1026,54 @@ class TrainEngine:
         self._seed_factor = w[0] if all(x == w[0] for x in w) else None
 
     def _flat_or_list(self):
-        """(the one flat buffer all parameter gradients are views of - GradBuckets / Ranger layout - or None, the gradient list)"""
+        """(the one flat buffer all parameter gradients live in - GradBuckets / Ranger layout - or None, the gradient list).
+        Recognised by STORAGE, not by ``_base``: a gradient that went through autograd's AccumulateGrad (gdrn._HipBackward hands the
+        views back to it so that DDP's hooks fire) is a detached alias of the same memory, no longer a view of the flat tensor."""
+        from .parallel import flat_grad_storage
+
         grads = [p.grad for p in self.model.parameters() if p.grad is not None]
-        bases = {id(g._base) for g in grads if g._base is not None}
-        flat = grads[0]._base if grads and len(bases) == 1 and all(g._base is not None for g in grads) else None
-        return flat, grads
+        return flat_grad_storage(grads), grads
+
+    def backward_stages(self, unscale=1.0):
+        """The backward of sum(seed_i * loss_i) into param.grad as a GENERATOR: yields 'pnp_net', 'rot_head_net', 'backbone' - each
+        right after the launches that complete that group's parameter gradients (the order the backward finishes them).  backward()
+        drives it for the bucket hooks of parallel.GradBuckets; gdrn._HipBackward drives it from three chained autograd nodes, so
+        that under torch DDP the AccumulateGrad hooks of a group - and with them DDP's bucket all-reduces - fire while the rest
+        of the backward is still being issued.  Must be run to exhaustion."""
+        if self._consumed:
+            # the backward kernels work in place on the gradient buffers the loss kernels seeded (and on saved activations): a second
+            # pass over the same forward would start from overwritten data - autograd's "backward through the graph a second time"
+            raise RuntimeError("TrainEngine.backward was already run for this forward; the HIP backward consumes the forward's buffers "
+                               "(retain_graph is not supported) - call forward_losses / the model's forward again")
+        self._consumed = True
+        marks = getattr(self, "_group_marks", None) or {}
+        prev = None
+        if self.accumulate_grad:
+            flat, _ = self._flat_or_list()
+            prev = flat.clone() if flat is not None else {id(p): p.grad.clone() for p in self.model.parameters() if p.grad is not None}
+        last = min(marks) if marks else None  # the group whose completion ends the backward ('backbone', index 0)
+        for idx in range(len(self.bwd) - 1, -1, -1):
+            for fn in self.bwd[idx]:
+                fn()
+            if idx in marks:
+                if idx == last:
+                    self._finish_backward(unscale, prev)
+                yield marks[idx]
+        if last != 0:
+            self._finish_backward(unscale, prev)
+
+    def _finish_backward(self, unscale, prev):
+        if unscale != 1.0 or prev is not None:
+            flat, grads = self._flat_or_list()
+            if unscale != 1.0:
+                flat.mul_(1.0 / unscale) if flat is not None else torch._foreach_mul_(grads, 1.0 / unscale)
+            if prev is not None:
+                if torch.is_tensor(prev):  # (the flat buffer of GradBuckets / Ranger: same layout before and after)
+                    flat.add_(prev)
+                else:  # (a gradient this backward created had nothing accumulated before)
+                    ps = [p for p in self.model.parameters() if p.grad is not None and id(p) in prev]
+                    if ps:
+                        torch._foreach_add_([p.grad for p in ps], [prev[id(p)] for p in ps])
 
     def backward(self, on_group_done=None, unscale=1.0):
         """Backward of sum(seed_i * loss_i) into param.grad.  on_group_done(name) is called after the gradients of
@@ -1042,37 +1085,14 @@ class TrainEngine:
         all-reduce would average the running sum again).
         unscale: divide THIS backward's gradients by it (the loss scale the seeds carried) - before anything accumulated
         earlier is added back, so earlier micro-batches are never divided twice."""
-        if self._consumed:
-            # the backward kernels work in place on the gradient buffers the loss kernels seeded (and on saved activations): a second
-            # pass over the same forward would start from overwritten data - autograd's "backward through the graph a second time"
-            raise RuntimeError("TrainEngine.backward was already run for this forward; the HIP backward consumes the forward's buffers "
-                               "(retain_graph is not supported) - call forward_losses / the model's forward again")
-        self._consumed = True
-        marks = getattr(self, "_group_marks", None)
-        prev = None
-        if self.accumulate_grad:
-            if on_group_done is not None:
+        if on_group_done is not None:  # (checked before anything runs: a refused call leaves the forward differentiable)
+            if self.accumulate_grad:
                 raise NotImplementedError("accumulate_grad with gradient-bucket hooks: reduce once, after the last micro-batch")
-            flat, _ = self._flat_or_list()
-            prev = flat.clone() if flat is not None else {id(p): p.grad.clone() for p in self.model.parameters() if p.grad is not None}
-        for idx in range(len(self.bwd) - 1, -1, -1):
-            for fn in self.bwd[idx]:
-                fn()
-            if on_group_done is not None and marks and idx in marks:
-                on_group_done(marks[idx])
-        if unscale != 1.0 or prev is not None:
-            flat, grads = self._flat_or_list()
             if unscale != 1.0:
-                if on_group_done is not None:
-                    raise NotImplementedError("unscale with gradient-bucket hooks: un-scale the flat buffer after buckets.finish()")
-                flat.mul_(1.0 / unscale) if flat is not None else torch._foreach_mul_(grads, 1.0 / unscale)
-            if prev is not None:
-                if torch.is_tensor(prev):  # (the flat buffer of GradBuckets / Ranger: same layout before and after)
-                    flat.add_(prev)
-                else:  # (a gradient this backward created had nothing accumulated before)
-                    ps = [p for p in self.model.parameters() if p.grad is not None and id(p) in prev]
-                    if ps:
-                        torch._foreach_add_([p.grad for p in ps], [prev[id(p)] for p in ps])
+                raise NotImplementedError("unscale with gradient-bucket hooks: un-scale the flat buffer after buckets.finish()")
+        for group in self.backward_stages(unscale=unscale):
+            if on_group_done is not None:
+                on_group_done(group)
 
     def forward_backward(self, batch):
         """forward + losses + backward.  With `loss_scale` != 1 (fp16 storage of the activation gradients: the un-scaled seeds

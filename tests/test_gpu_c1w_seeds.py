@@ -1,0 +1,160 @@
+"""SEED-INDEPENDENT parity at the bare north-star tolerances: the well-conditioned fixture on EIGHT CONSECUTIVE
+input seeds (0..7, no search) = 32 crops captured from the REAL reference by tools/oracle/gen_model_golden_seeds.py, on the B = 64
+plan bench.py times (two shuffled copies of the 32 crops), for all three fp32-accurate plans:
+
+    h2   - two fp16 planes per operand, three exact partial products (the default, the headline's ``dtype: "f32"``)
+    x3   - three bf16 planes, six partial products
+    none - the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32: a k-ordered fmaf chain, undisputed fp32)
+
+Asserted per plan: dense maps <= 1e-4 max-abs on every crop; ZERO region arg-max flips outside the RECORDED tie set (reference's own
+top-2 logit gap < 2e-4, or a pixel the reference flips against itself between 1 and 8 threads / fp32 and float64 - the rule is in
+the fixture, tests/c1w_cases.tie_set); pose <= 1e-4 (MASK_ATTENTION none) / <= max(1e-4, 1.5 x the reference's own fp32-vs-float64
+pose error of that crop), capped at 2e-4 (mul).  A crop whose arg-max differs from the reference's at a tie pixel is compared with
+the reference-pinned oracle restarted from the reference's golden maps with OUR region decision at those pixels (one flipped pixel
+moves the reference's own pose by 3e-4 .. 3e-3: seed 2 crop 0, seed 3 crop 3 of the generator's log).
+And ACROSS plans: h2's worst map / pose error <= 1.25 x the fp32-MFMA plan's on this fixture - the end-to-end proof that the
+22-bit operands of h2 are not what the parity margin is spent on."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+MAPS = ("mask", "coor_x", "coor_y", "coor_z", "region")
+FAST = {"h2": dict(BF16X3=True, FP16X2=True), "x3": dict(BF16X3=True, FP16X2=False), "none": dict(BF16X3=False, FP16X2=True)}
+
+
+def _rel(a, b):
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+@pytest.fixture(scope="module")
+def seeds_run(golden_dir):
+    """every (plan, attention) forward of the 64-slot batch, evaluated once"""
+    from oracle import model_oracle
+    from rdpn6d_amd import synth
+    from rdpn6d_amd.config import gdrn_base_cfg
+    from rdpn6d_amd.gdrn import build_model_optimizer
+    from tests.c1w_cases import SEEDS, c1w_state_dict, tie_set
+
+    dev = torch.device("cuda:0")
+    gold = np.load(os.path.join(golden_dir, "model_c1w_seeds.npz"))
+    bn = np.load(os.path.join(golden_dir, "bn_stats_c1w.npz"))
+    assert tuple(int(s) for s in gold["seeds"]) == SEEDS
+    inps = []
+    for s in SEEDS:
+        inp = synth.make_inputs(4, seed=s)
+        assert synth.sha256_of([inp[k] for k in sorted(inp)]) == str(gold[f"s{s}_sha256_inputs"]), s
+        inps.append(inp)
+    inp32 = {k: np.concatenate([i[k] for i in inps], 0) for k in inps[0]}
+    crop = [(s, c) for s in SEEDS for c in range(4)]  # crop id -> (seed, index in the seed's batch)
+    order = np.concatenate([np.arange(32), np.random.default_rng(5).permutation(32)])  # 64 slots: every crop twice
+    t = {k: torch.from_numpy(np.ascontiguousarray(v[order])).to(dev) for k, v in inp32.items()}
+    ref = {k: np.concatenate([gold[f"s{s}_{k}"] for s in SEEDS], 0) for k in MAPS + ("argmax",)}
+    ref["tie"] = np.concatenate([tie_set(gold, s) for s in SEEDS], 0)
+    for att in ("none", "mul"):
+        for q in ("rot", "trans", "fp64err_rot", "fp64err_trans"):
+            ref[f"{att}_{q}"] = np.concatenate([gold[f"s{s}_{att}_{q}"] for s in SEEDS], 0)
+    out, sd = {}, None
+    for att in ("none", "mul"):
+        model, _ = build_model_optimizer(gdrn_base_cfg(mask_attention=att, device="cuda"))
+        if sd is None:
+            sdn = c1w_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, bn)
+            assert synth.sha256_of([sdn[k] for k in sorted(sdn) if not k.endswith("num_batches_tracked")]) == str(gold["sha256_weights"])
+            sd = {k: torch.from_numpy(np.asarray(v)) for k, v in sdn.items()}
+        model.load_state_dict(sd, strict=True)
+        model.eval()
+        for fast, sw in FAST.items():
+            model.cfg.TEST.BF16X3, model.cfg.TEST.FP16X2 = sw["BF16X3"], sw["FP16X2"]
+            with torch.no_grad():
+                o = model(t["roi_img"], roi_classes=t["roi_cls"], roi_coord_2d=t["roi_coord_2d"], roi_cams=t["roi_cam"],
+                          roi_centers=t["roi_center"], roi_whs=t["roi_wh"], roi_extents=t["roi_extent"],
+                          resize_ratios=t["resize_ratio"], do_loss=False, fps=t["fps"])
+            torch.cuda.synchronize()
+            plan = model.plan(64, dev)
+            assert plan.fast == (None if fast == "none" else fast), (fast, plan.fast)
+            assert not model.h2_range_exceeded(dev) and model.cfg.TEST.FP16X2 == sw["FP16X2"]
+            res = {k: o[k].cpu().numpy().astype(np.float64) for k in MAPS + ("rot", "trans")}
+            res["argmax"] = plan.argmax.cpu().numpy().reshape(64, 64, 64)
+            out[(fast, att)] = res
+            model.invalidate_plans()  # (2.3 GB of activation buffers per plan)
+            torch.cuda.empty_cache()
+    # the reference-pinned oracle for the pose branch of crops that flip a tie pixel (restarted from the reference's golden maps)
+    orcs = {}
+    for att in ("none", "mul"):
+        orc = model_oracle.GDRNOracle(32, att)
+        orc.load_state_dict(sd, strict=True)
+        orcs[att] = orc.eval()
+    return out, ref, order, crop, inp32, orcs
+
+
+def _pose_given_our_decisions(orc, ref, inp32, cid, amax):
+    """the oracle's pose branch on the REFERENCE's maps of crop `cid`, region decisions `amax` (64, 64) forced"""
+    sl = slice(cid, cid + 1)
+    ti = {k: torch.from_numpy(np.ascontiguousarray(v[sl])) for k, v in inp32.items()}
+    maps = tuple(torch.from_numpy(np.ascontiguousarray(ref[k][sl])) for k in MAPS)
+    with torch.no_grad():
+        o = orc(ti["roi_img"], ti["roi_coord_2d"], ti["fps"], ti["roi_cam"], ti["roi_center"], ti["roi_wh"], ti["resize_ratio"],
+                dense_maps=maps, force_argmax=amax[None])
+    return o["rot"][0].numpy().astype(np.float64), o["trans"][0].numpy().astype(np.float64)
+
+
+def _score(seeds_run, fast, att):
+    out, ref, order, crop, inp32, orcs = seeds_run
+    res = out[(fast, att)]
+    worst = {k: float(np.abs(res[k] - ref[k][order].astype(np.float64)).max()) for k in MAPS}
+    per_crop_map = np.max([np.abs(res[k] - ref[k][order].astype(np.float64)).reshape(64, -1).max(1) for k in MAPS], axis=0)
+    diff = res["argmax"] != ref["argmax"][order]
+    outside = int((diff & ~ref["tie"][order]).sum())
+    inside = int((diff & ref["tie"][order]).sum())
+    er, et, bare, forced, tols = [], [], 0, 0, []
+    for slot in range(64):
+        cid = int(order[slot])
+        R, T = ref[f"{att}_rot"][cid].astype(np.float64), ref[f"{att}_trans"][cid].astype(np.float64)
+        if diff[slot].any():  # a tie pixel took the other region: the reference's pose GIVEN that decision
+            R, T = _pose_given_our_decisions(orcs[att], ref, inp32, cid, res["argmax"][slot])
+            forced += 1
+        e_r, e_t = _rel(res["rot"][slot], R), _rel(res["trans"][slot], T)
+        tol = 1e-4 if att == "none" else min(2e-4, max(1e-4, 1.5 * float(ref[f"{att}_fp64err_rot"][cid])))
+        er.append(e_r), et.append(e_t), tols.append(tol)
+        bare += e_r <= 1e-4 and e_t <= 1e-4
+    return dict(worst=worst, per_crop_map=per_crop_map, outside=outside, inside=inside, er=np.asarray(er), et=np.asarray(et), bare=bare,
+                forced=forced, tols=np.asarray(tols), ntie=int(ref["tie"][order].sum()))
+
+
+@pytest.mark.parametrize("att", ["none", "mul"])
+@pytest.mark.parametrize("fast", ["h2", "x3", "none"])
+def test_bare_tolerances_on_eight_unsearched_seeds(seeds_run, fast, att):
+    s = _score(seeds_run, fast, att)
+    print(f"[seeds {fast} {att}] maps max-abs over 64 slots: " + " ".join(f"{k} {v:.2e}" for k, v in s["worst"].items())
+          + f" | arg-max flips outside the tie set {s['outside']}, inside {s['inside']} (tie set: {s['ntie']} of {64 * 4096} pixels; "
+          f"{s['forced']} slots compared given our decision) | pose worst R {s['er'].max():.2e} t {s['et'].max():.2e}; "
+          f"slots within the BARE 1e-4: {s['bare']} / 64")
+    for k, v in s["worst"].items():
+        assert v <= 1e-4, (k, v)
+    assert s["outside"] == 0
+    if att == "none":
+        assert s["bare"] == 64
+    elif fast == "h2":  # the default plan, the one bench.py times: per-crop bound from the reference's own fp32-vs-float64 error
+        assert (s["er"] <= s["tols"]).all() and (s["et"] <= s["tols"]).all(), (s["er"].max(), s["et"].max())
+    else:
+        # the two fall-back plans under MASK_ATTENTION = "mul": every ConvPnPNet input is scaled by the min-max normalised mask and the
+        # rotation moves by ~2x the map error (the reference's own fp32 rotation is 1.16e-4 from its float64 one on model_c1w.npz's
+        # batch); their maps are inside 1e-4 like h2's, their pose is held to 2e-4 and the count within the bare 1e-4 is printed
+        assert s["er"].max() <= 2e-4 and s["et"].max() <= 1e-4, (s["er"].max(), s["et"].max())
+
+
+def test_h2_is_as_accurate_as_the_fp32_mfma_plan_end_to_end(seeds_run):
+    """h2 holds each operand as two fp16 terms (22 bits); the claim that the headline is fp32-ACCURATE is checked where it counts:
+    on the whole network, against the real reference, next to the undisputed fp32-MFMA plan on the same 64 slots"""
+    rows = {f: _score(seeds_run, f, "none") for f in FAST}
+    rows_mul = {f: _score(seeds_run, f, "mul") for f in FAST}
+    for f in FAST:
+        print(f"[seeds {f}] worst map {max(rows[f]['worst'].values()):.2e} (mean over crops {rows[f]['per_crop_map'].mean():.2e}) | pose none: worst R "
+              f"{rows[f]['er'].max():.2e} mean {rows[f]['er'].mean():.2e} | pose mul: worst R {rows_mul[f]['er'].max():.2e} mean {rows_mul[f]['er'].mean():.2e}")
+    h, n = rows["h2"], rows["none"]
+    assert max(h["worst"].values()) <= 1.25 * max(n["worst"].values())
+    assert h["per_crop_map"].mean() <= 1.25 * n["per_crop_map"].mean()
+    assert h["er"].max() <= 1.25 * n["er"].max() and h["er"].mean() <= 1.25 * n["er"].mean()
+    assert rows_mul["h2"]["er"].mean() <= 1.25 * rows_mul["none"]["er"].mean()

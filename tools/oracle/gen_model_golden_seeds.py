@@ -1,0 +1,117 @@
+"""BUILD-CONTAINER ONLY: the well-conditioned fixture of gen_model_golden_w.py for EIGHT CONSECUTIVE, UN-SEARCHED input seeds.
+
+  python tools/oracle/gen_model_golden_seeds.py      # writes tests/golden/model_c1w_seeds.npz
+
+model_c1w.npz holds one batch of four crops whose input seed (36) was searched so that no pixel's region arg-max is a near-tie.
+This file removes the search: the REAL reference (/root/reference, built by its own factory from its own config, the same
+trained-like weights + shipped BatchNorm statistics as model_c1w.npz) is evaluated on the batches of input seeds 0..7 - 32 crops -
+and the near-tie pixels are excluded BY A RECORDED RULE instead of by choosing the seed.  Per seed s (keys ``s{s}_*``):
+
+  * ``sha256_inputs``                      - the seeded batch the GPU box must regenerate (rdpn6d_amd/synth.make_inputs(4, seed=s));
+  * ``mask, coor_x, coor_y, coor_z, region`` - the reference's dense maps (8 threads, MASK_ATTENTION none; they do not depend on it);
+  * ``argmax``                             - its region arg-max (on the softmax, first-max: GDRN.py:206-209), int8 (4,64,64);
+  * ``top2_gap``                           - per pixel, the reference's own top-2 region-LOGIT gap, float32 (4,64,64);
+  * ``flip_1v8`` / ``flip_fp64``           - per pixel: does the reference's arg-max change between 1 and 8 threads / between fp32
+                                             and its own float64 evaluation (packed bits of a (4,64,64) bool array);
+  * ``{att}_rot, {att}_trans``             - pose, att in (none, mul);
+  * ``{att}_noise_rot/_trans``             - per crop, relative pose difference of the reference 1 vs 8 threads;
+  * ``{att}_fp64err_rot/_trans``           - per crop, relative difference of the reference's fp32 pose from its float64 pose;
+  * ``noise_maps``                         - max-abs map difference of the reference 1 vs 8 threads (5 maps).
+
+THE TIE RULE (``tie_gap``, stored): a pixel belongs to the tie set iff the reference's top-2 logit gap there is < 2e-4 (= both
+logits moving by the map tolerance 1e-4 in opposite directions can swap them) OR the reference flips it against itself
+(flip_1v8 | flip_fp64).  The GPU test demands ZERO arg-max flips outside the tie set and reports the flips inside it.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import ref_stubs  # noqa: E402
+
+ref_stubs.install()
+
+from rdpn6d_amd import synth  # noqa: E402
+from gen_model_golden import GOLD, build_reference  # noqa: E402
+from gen_model_golden_w import ref_eval  # noqa: E402
+from tests.c1w_cases import SEEDS, TIE_GAP, c1w_state_dict  # noqa: E402
+
+MAPS = ("mask", "coor_x", "coor_y", "coor_z", "region")
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / np.linalg.norm(b))
+
+
+def argmax_of(region):
+    B = region.shape[0]
+    return torch.softmax(region[:, 1:], dim=1).reshape(B, 32, -1).argmax(1).reshape(B, 64, 64)
+
+
+def main():
+    torch.manual_seed(0)
+    B = 4
+    bn = np.load(os.path.join(GOLD, "bn_stats_c1w.npz"))
+    refs, refs64, full_sd = {}, {}, None
+    for att in ("none", "mul"):
+        ref, _ = build_reference(att)
+        if full_sd is None:
+            sd = c1w_state_dict({k: tuple(v.shape) for k, v in ref.state_dict().items()}, bn)
+            full_sd = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+        ref.load_state_dict(full_sd, strict=True)
+        refs[att] = ref.eval()
+        r64, _ = build_reference(att)
+        r64.load_state_dict(full_sd, strict=True)
+        refs64[att] = r64.double().eval()
+    gold_w = np.load(os.path.join(GOLD, "model_c1w.npz"))
+    sha_w = synth.sha256_of([full_sd[k].numpy() for k in sorted(full_sd) if not k.endswith("num_batches_tracked")])
+    assert sha_w == str(gold_w["sha256_weights"]), "weights differ from model_c1w.npz's"
+    out = {"seeds": np.asarray(SEEDS, dtype=np.int64), "tie_gap": np.float64(TIE_GAP), "sha256_weights": sha_w}
+    for s in SEEDS:
+        inp = synth.make_inputs(B, seed=s, res=256, num_regions=32, cam="lm")
+        tin = {k: torch.from_numpy(v) for k, v in inp.items()}
+        t64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in tin.items()}
+        p = f"s{s}_"
+        out[p + "sha256_inputs"] = synth.sha256_of([inp[k] for k in sorted(inp)])
+        for att in ("none", "mul"):
+            torch.set_num_threads(8)
+            o = ref_eval(refs[att], tin)
+            torch.set_num_threads(1)
+            o1 = ref_eval(refs[att], tin)
+            torch.set_num_threads(8)
+            o64 = ref_eval(refs64[att], t64)
+            out[p + f"{att}_rot"], out[p + f"{att}_trans"] = o["rot"].numpy(), o["trans"].numpy()
+            for q in ("rot", "trans"):
+                out[p + f"{att}_noise_{q}"] = np.asarray([rel(o1[q][i].numpy(), o[q][i].numpy()) for i in range(B)])
+                out[p + f"{att}_fp64err_{q}"] = np.asarray([rel(o[q][i].numpy(), o64[q][i].numpy()) for i in range(B)])
+            if att == "none":
+                for k in MAPS:
+                    out[p + k] = o[k].numpy()
+                out[p + "noise_maps"] = np.asarray([(o1[k] - o[k]).abs().max().item() for k in MAPS])
+                am, am1, am64 = argmax_of(o["region"]), argmax_of(o1["region"]), argmax_of(o64["region"])
+                out[p + "argmax"] = am.numpy().astype(np.int8)
+                top2 = o["region"][:, 1:].topk(2, dim=1).values
+                gap = (top2[:, 0] - top2[:, 1]).numpy().astype(np.float32)
+                out[p + "top2_gap"] = gap
+                f18, f64 = (am1 != am).numpy(), (am64 != am).numpy()
+                out[p + "flip_1v8"], out[p + "flip_fp64"] = np.packbits(f18), np.packbits(f64)
+                tie = (gap < TIE_GAP) | f18 | f64
+                print(f"[seed {s}] smallest top-2 gap {gap.min():.2e}; pixels with gap < {TIE_GAP:g}: {int((gap < TIE_GAP).sum())}; reference "
+                      f"flips 1-vs-8 threads {int(f18.sum())}, fp32-vs-fp64 {int(f64.sum())}; tie set {int(tie.sum())} of {tie.size} pixels "
+                      f"(per crop {tie.reshape(B, -1).sum(1).tolist()}); maps 1-vs-8 {out[p + 'noise_maps'].max():.1e}")
+            print(f"[seed {s} {att}] pose per crop: 1-vs-8 threads R {out[p + f'{att}_noise_rot'].max():.1e} t {out[p + f'{att}_noise_trans'].max():.1e}; "
+                  f"fp32-vs-fp64 R {np.array2string(out[p + f'{att}_fp64err_rot'], precision=2)} t {out[p + f'{att}_fp64err_trans'].max():.1e}")
+    path = os.path.join(GOLD, "model_c1w_seeds.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) / 1e6, "MB")
+
+
+if __name__ == "__main__":
+    main()
