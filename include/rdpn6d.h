@@ -380,6 +380,12 @@ int rdpn6d_pose_train_sym_f32(const float* rt, int rt_stride, const float* roi_c
                               int is_allo, float pm_lw, int pm_norm_by_extent, float centroid_lw, float z_lw,
                               const float* sym_rots, const int* sym_counts, int ksym, float* gt_rot_used, float* rot,
                               float* trans, float* d_rt, float* losses, float* scratch, void* stream);
+/* The per-step training scalars the reference pushes to detectron2's EventStorage (core/gdrn_modeling/models/GDRN.py:306-328:
+ * compute_mean_re_te of models/model_utils.py:45-57 = mean re [deg] / te over the batch, lib/pysixd/pose_error.py:400-440, and
+ * sixteen .item() reads of crop 0), on the device: out17 = {error_R, error_t [cm], error_tx/ty/tz [cm], t_pred xyz, pred_t_ xyz
+ * (rt columns 6..8), t_gt xyz, gt_trans_ratio xyz}.  No host synchronisation. */
+int rdpn6d_train_vis_scalars_f32(const float* rot, const float* trans, const float* gt_rot, const float* gt_trans, const float* rt,
+                                 int rt_stride, const float* gt_trans_ratio, int B, float* out17, void* stream);
 /* Fused multi-tensor Ranger step over flat buffers (replaces lib/torch_utils/solver/ranger.py:100-200).
  * work = array of {int64 off; int32 len; int32 row} runs (row = index of the centralisation mean, -1 = none);
  * row_off/row_len describe the rows whose gradient mean is subtracted (gradient centralisation);

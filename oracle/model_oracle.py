@@ -349,6 +349,31 @@ def rot_error_deg(r_est, r_gt):
     return float(np.rad2deg(np.arccos(min(1.0, max(-1.0, 0.5 * (tr - 1.0))))))
 
 
+VIS_NAMES = ("vis/error_R", "vis/error_t", "vis/error_tx", "vis/error_ty", "vis/error_tz", "vis/tx_pred", "vis/ty_pred", "vis/tz_pred",
+             "vis/tx_net", "vis/ty_net", "vis/tz_net", "vis/tx_gt", "vis/ty_gt", "vis/tz_gt", "vis/tx_rel_gt", "vis/ty_rel_gt", "vis/tz_rel_gt")
+
+
+def train_vis_scalars(pred_trans, pred_rot, pred_t_, gt_trans, gt_rot, gt_trans_ratio):
+    """The 17 scalars the reference's train forward pushes to EventStorage (core/gdrn_modeling/models/GDRN.py:306-328), numpy:
+    compute_mean_re_te (models/model_utils.py:45-57): float32 arrays of re (lib/pysixd/pose_error.py:400-415, degrees) and te
+    (:428-440) per crop, their float32 means; the rest are reads of crop 0.  Pinned by tests/golden/vis_scalars_golden.npz."""
+    f = lambda a: np.asarray(a.detach().cpu().numpy() if torch.is_tensor(a) else a, dtype=np.float32)  # noqa: E731
+    pred_trans, pred_rot, pred_t_, gt_trans, gt_rot, gt_trans_ratio = (f(a) for a in (pred_trans, pred_rot, pred_t_, gt_trans, gt_rot, gt_trans_ratio))
+    bs = pred_rot.shape[0]
+    r_errs, t_errs = np.zeros((bs,), dtype=np.float32), np.zeros((bs,), dtype=np.float32)
+    for i in range(bs):
+        trace = np.trace(np.dot(pred_rot[i], gt_rot[i].T))
+        trace = trace if trace <= 3 else 3
+        r_errs[i] = np.rad2deg(np.arccos(min(1.0, max(-1.0, 0.5 * (trace - 1.0)))))
+        t_errs[i] = np.linalg.norm(gt_trans[i].flatten() - pred_trans[i].flatten())
+    v = {"vis/error_R": r_errs.mean(), "vis/error_t": t_errs.mean() * 100}
+    for a, ax in enumerate("xyz"):
+        v[f"vis/error_t{ax}"] = np.abs(float(pred_trans[0, a]) - float(gt_trans[0, a])) * 100
+        v[f"vis/t{ax}_pred"], v[f"vis/t{ax}_net"] = float(pred_trans[0, a]), float(pred_t_[0, a])
+        v[f"vis/t{ax}_gt"], v[f"vis/t{ax}_rel_gt"] = float(gt_trans[0, a]), float(gt_trans_ratio[0, a])
+    return {k: float(v[k]) for k in VIS_NAMES}
+
+
 def closest_sym_rots(pred_rots, gt_rots, sym_infos):
     """PM_LOSS_SYM target choice (core/utils/pose_utils.py:430-482): per sample, among R_gt and R_gt @ S_k (S_k the
     model-to-model symmetry rotations, None / empty = not symmetric) the one with the smallest rotation error to the

@@ -876,6 +876,61 @@ extern "C" int rdpn6d_pose_train_f32(const float* rt, int rt_stride, const float
 }
 
 // ------------------------------------------------------------------------------------------------
+// The per-step scalars the reference's train forward pushes to detectron2's EventStorage (GDRN.py:306-328: compute_mean_re_te of
+// models/model_utils.py:45-57 + sixteen `.item()` reads of crop 0), computed on the device into one row of 17 floats - no host sync:
+//   0 error_R  = mean_b re(R_pred, R_gt) [deg]  (lib/pysixd/pose_error.py:400-415: acos of the clamped (trace(R_est R_gt^T) - 1) / 2)
+//   1 error_t  = 100 * mean_b |t_gt - t_pred|   [cm]  (pose_error.py:428-440)
+//   2..4  100 * |t_pred[0] - t_gt[0]| per axis; 5..7 t_pred[0]; 8..10 pred_t_[0] (the network's raw (dcx, dcy, z_rel));
+//   11..13 t_gt[0]; 14..16 gt_trans_ratio[0]
+// One wavefront; the means are float32 sums over float32 per-crop errors like numpy's (order: sequential lanes, then a fixed
+// butterfly - within 1e-6 of numpy's pairwise float32 mean at these batch sizes).
+__global__ void train_vis_scalars_kernel(const float* __restrict__ rot, const float* __restrict__ trans, const float* __restrict__ gt_rot,
+                                         const float* __restrict__ gt_trans, const float* __restrict__ rt, int rt_stride,
+                                         const float* __restrict__ gt_ratio, int B, float* __restrict__ out)
+{
+    const int lane = threadIdx.x;
+    float sr = 0.f, st = 0.f;
+    for (int b = lane; b < B; b += 64) {
+        const float* R = rot + (size_t)b * 9;
+        const float* G = gt_rot + (size_t)b * 9;
+        float tr = 0.f;  // trace(R G^T) = sum_ij R_ij G_ij, float32 like np.dot / np.trace of float32 arrays
+        for (int i = 0; i < 3; ++i) tr += R[i * 3 + 0] * G[i * 3 + 0] + R[i * 3 + 1] * G[i * 3 + 1] + R[i * 3 + 2] * G[i * 3 + 2];
+        double t = (double)tr <= 3.0 ? (double)tr : 3.0;
+        double c = 0.5 * (t - 1.0);
+        c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
+        sr += (float)(acos(c) * (180.0 / 3.14159265358979323846));
+        const float dx = gt_trans[b * 3 + 0] - trans[b * 3 + 0], dy = gt_trans[b * 3 + 1] - trans[b * 3 + 1], dz = gt_trans[b * 3 + 2] - trans[b * 3 + 2];
+        st += sqrtf(dx * dx + dy * dy + dz * dz);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        sr += __shfl_xor(sr, o);
+        st += __shfl_xor(st, o);
+    }
+    if (lane == 0) {
+        out[0] = sr / (float)B;
+        out[1] = st / (float)B * 100.f;
+        for (int a = 0; a < 3; ++a) {
+            out[2 + a] = fabsf(trans[a] - gt_trans[a]) * 100.f;
+            out[5 + a] = trans[a];
+            out[8 + a] = rt[6 + a];
+            out[11 + a] = gt_trans[a];
+            out[14 + a] = gt_ratio[a];
+        }
+    }
+}
+
+extern "C" int rdpn6d_train_vis_scalars_f32(const float* rot, const float* trans, const float* gt_rot, const float* gt_trans,
+                                            const float* rt, int rt_stride, const float* gt_trans_ratio, int B, float* out17,
+                                            void* stream)
+{
+    RD_REQUIRE(rot && trans && gt_rot && gt_trans && rt && gt_trans_ratio && out17 && B > 0 && rt_stride >= 9, "null/shape");
+    hipLaunchKernelGGL(train_vis_scalars_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, rot, trans, gt_rot, gt_trans, rt, rt_stride,
+                       gt_trans_ratio, B, out17);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // dy *= (y > 0 ? 1 : slope)   (ReLU: slope 0, LeakyReLU(0.1): slope 0.1; the activation output has the sign of
 // its input, so the saved output is enough)
 __global__ void act_backward_kernel(float* __restrict__ dy, const float* __restrict__ y, long long n, float slope)

@@ -53,7 +53,47 @@ RESNET_SPEC = {18: (1, (2, 2, 2, 2)), 34: (1, (3, 4, 6, 3)), 50: (4, (3, 4, 6, 3
 
 
 # ----------------------------------------------------------------------------- parameter holders
-class _Holder(nn.Module):
+_TREE_EPOCH = [0]  # bumped whenever a Parameter / buffer / sub-module OBJECT is (re)assigned anywhere in a holder tree
+
+
+class _TreeWatch:
+    """mixin: replacing a tensor or module object (``blk.conv1.weight = nn.Parameter(...)``, ``head.features[3] = ...``,
+    ``register_buffer``) is invisible to the ``_version`` counters GDRN._weights_stamp sums over its CACHED tensor list - so such an
+    assignment bumps the tree epoch, which makes every model re-walk its parameters() before it trusts a plan again"""
+
+    def __setattr__(self, name, value):
+        if isinstance(value, (torch.Tensor, nn.Module)) or (value is None and (name in self.__dict__.get("_parameters", ())
+                                                                                 or name in self.__dict__.get("_buffers", ())
+                                                                                 or name in self.__dict__.get("_modules", ()))):
+            _TREE_EPOCH[0] += 1
+        super().__setattr__(name, value)
+
+    def __delattr__(self, name):
+        _TREE_EPOCH[0] += 1
+        super().__delattr__(name)
+
+    def register_parameter(self, name, param):
+        _TREE_EPOCH[0] += 1
+        super().register_parameter(name, param)
+
+    def register_buffer(self, name, tensor, persistent=True):
+        _TREE_EPOCH[0] += 1
+        super().register_buffer(name, tensor, persistent=persistent)
+
+    def add_module(self, name, module):
+        _TREE_EPOCH[0] += 1
+        super().add_module(name, module)
+
+
+class _HolderList(_TreeWatch, nn.ModuleList):
+    pass
+
+
+class _HolderSeq(_TreeWatch, nn.Sequential):
+    pass
+
+
+class _Holder(_TreeWatch, nn.Module):
     def forward(self, *a, **k):  # pragma: no cover
         raise RuntimeError("parameter holder: compute happens in the HIP engine, not in nn.Module.forward")
 
@@ -109,7 +149,7 @@ class BlockP(_Holder):
         self.conv2 = ConvP(cout, cout, 3, 1, 1)
         self.bn2 = BNP(cout)
         if downsample:
-            self.downsample = nn.Sequential(ConvP(cin, cout, 1, stride, 0), BNP(cout))
+            self.downsample = _HolderSeq(ConvP(cin, cout, 1, stride, 0), BNP(cout))
         else:
             self.downsample = None
 
@@ -126,7 +166,7 @@ class BottleneckP(_Holder):
         self.conv3 = ConvP(planes, planes * 4, 1, 1, 0)
         self.bn3 = BNP(planes * 4)
         if downsample:
-            self.downsample = nn.Sequential(ConvP(cin, planes * 4, 1, stride, 0), BNP(planes * 4))
+            self.downsample = _HolderSeq(ConvP(cin, planes * 4, 1, stride, 0), BNP(planes * 4))
         else:
             self.downsample = None
 
@@ -162,7 +202,7 @@ class BackboneP(_Holder):
                 ds = bi == 0 and (s != 1 or cin != cout)
                 blocks.append(BlockP(cin, planes, s, ds) if exp == 1 else BottleneckP(cin, planes, s, ds))
                 cin = cout
-            setattr(self, f"layer{li + 1}", nn.Sequential(*blocks))
+            setattr(self, f"layer{li + 1}", _HolderSeq(*blocks))
 
 
 class RotHeadP(_Holder):
@@ -172,7 +212,7 @@ class RotHeadP(_Holder):
         for _ in range(2 * num_layers):
             f += [ConvP(num_filters, num_filters, 3, 1, 1), BNP(num_filters), Slot()]
         f.append(ConvP(num_filters, 1 + 3 + num_regions + 1, 1, bias=True))
-        self.features = nn.ModuleList(f)
+        self.features = _HolderList(f)
 
 
 class ConvPnPP(_Holder):
@@ -181,7 +221,7 @@ class ConvPnPP(_Holder):
         f = []
         for i in range(3):
             f += [ConvP(n_in if i == 0 else featdim, featdim, 3, 2, 1), GNP(32, featdim), Slot()]
-        self.features = nn.ModuleList(f)
+        self.features = _HolderList(f)
         self.fc1 = LinearP(featdim * (out_res // 8) ** 2, 1024)
         self.fc2 = LinearP(1024, 256)
         self.fc_r = LinearP(256, rot_dim, std=0.01)
@@ -1018,7 +1058,7 @@ def get_xyz_mask_region_out_dim(cfg):
     return 3, 1, region_out_dim
 
 
-class GDRN(nn.Module):
+class GDRN(_TreeWatch, nn.Module):
     def __init__(self, cfg, backbone, rot_head_net, trans_head_net=None, pnp_net=None):
         super().__init__()
         assert cfg.MODEL.CDPN.NAME == "GDRN", cfg.MODEL.CDPN.NAME
@@ -1029,7 +1069,8 @@ class GDRN(nn.Module):
         self.cfg = cfg
         self._plans = {}
         self._weights_epoch = 0
-        self._stamp_tensors = None  # cached [parameters + buffers] of the stamp (rebuilt when the module tree changes)
+        self._stamp_tensors = None  # cached [parameters + buffers] of the stamp (rebuilt when the module tree changes: _TreeWatch)
+        self._stamp_tree_epoch = -1
         _MODELS.add(self)
         self._h2_flags = {}  # device -> (device int32 flag written by the h2 kernels, pinned host copy, [event of the last copy])
 
@@ -1126,13 +1167,98 @@ class GDRN(nn.Module):
                  "roi_trans_ratio": gt_trans_ratio, "roi_points": gt_points, "sym_info": sym_infos}
         losses = eng.forward_losses(batch)  # (bumps the weights epoch: BatchNorm running statistics moved)
         self.last_train_pose = (eng.rot, eng.trans)
+        if bool(self.cfg.get("TRAIN", {}).get("VIS_SCALARS", False)):
+            self._vis_scalars_step(eng, gt_trans, gt_ego_rot, gt_trans_ratio)
         return {}, _attach_hip_backward(self, eng, losses)
+
+    def __getstate__(self):
+        """copy.deepcopy / pickle (an EMA or teacher copy): the copy starts without plans, range flags or a cached tensor list - they
+        hold device buffers, ctypes argument blocks and the ORIGINAL's tensors"""
+        d = self.__dict__.copy()
+        d["_plans"], d["_h2_flags"], d["_stamp_tensors"] = {}, {}, None
+        return d
+
+    def __setstate__(self, d):
+        super().__setstate__(d)
+        _MODELS.add(self)  # (a copy never ran __init__: without this the fused Ranger step would not bump ITS weights epoch)
+
+    # ---- the per-step `vis/*` scalars of the reference's train forward (GDRN.py:306-368), without its 18 host syncs per step
+    VIS_NAMES = ("vis/error_R", "vis/error_t", "vis/error_tx", "vis/error_ty", "vis/error_tz", "vis/tx_pred", "vis/ty_pred", "vis/tz_pred",
+                 "vis/tx_net", "vis/ty_net", "vis/tz_net", "vis/tx_gt", "vis/ty_gt", "vis/tz_gt", "vis/tx_rel_gt", "vis/ty_rel_gt", "vis/tz_rel_gt")
+
+    def _vis_scalars_step(self, eng, gt_trans, gt_rot, gt_ratio):
+        """cfg.TRAIN.VIS_SCALARS = True: one small kernel per step writes the 17 scalars (compute_mean_re_te + the reads of crop 0) into
+        row `step % N` of a device table, N = cfg.TRAIN.VIS_PERIOD (default 20); every N steps the table goes to pinned host memory
+        with ONE asynchronous copy, and is handed on - `model.vis_sink(dict)` if set, else detectron2's
+        `get_event_storage().put_scalars(**dict)` when a storage is active, always `model.vis_history` - the next time a forward finds
+        the copy complete.  Nothing waits for the GPU."""
+        period = max(1, int(self.cfg.get("TRAIN", {}).get("VIS_PERIOD", 20)))
+        st = self.__dict__.get("_vis")
+        if st is None or st["period"] != period or st["dev"].device != eng.dev:
+            st = dict(period=period, dev=torch.zeros(period, 17, device=eng.dev), host=torch.zeros(period, 17).pin_memory(), slot=0,
+                      event=None)
+            self.__dict__["_vis"] = st
+        self._vis_deliver(wait=False)
+        f32 = lambda t: t.detach().to(device=eng.dev, dtype=torch.float32).contiguous()  # noqa: E731
+        gt_trans, gt_rot, gt_ratio = f32(gt_trans), f32(gt_rot), f32(gt_ratio)
+        _lib.check(eng.lib.rdpn6d_train_vis_scalars_f32(_ptr(eng.rot), _ptr(eng.trans), _ptr(gt_rot), _ptr(gt_trans), _ptr(eng.rt), 16,
+                                                        _ptr(gt_ratio), eng.B, _ptr(st["dev"][st["slot"]]),
+                                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "train_vis_scalars")
+        st["slot"] += 1
+        if st["slot"] == period:
+            self._vis_deliver(wait=True)  # (the previous block's copy finished N steps ago: never a real wait)
+            st["host"].copy_(st["dev"], non_blocking=True)
+            st["event"] = torch.cuda.Event()
+            st["event"].record()
+            st["slot"] = 0
+
+    def _vis_deliver(self, wait):
+        st = self.__dict__.get("_vis")
+        if st is None or st["event"] is None or not (wait or st["event"].query()):
+            return
+        st["event"].synchronize()
+        st["event"] = None
+        rows = st["host"].tolist()
+        sink = getattr(self, "vis_sink", None)
+        storage = None
+        if sink is None:
+            try:
+                from detectron2.utils.events import get_event_storage
+
+                storage = get_event_storage()  # (raises outside a `with EventStorage(...)` block)
+            except Exception:  # noqa: BLE001
+                storage = None
+        hist = self.__dict__.setdefault("vis_history", [])
+        for row in rows:
+            d = dict(zip(self.VIS_NAMES, row))
+            hist.append(d)
+            if sink is not None:
+                sink(d)
+            elif storage is not None:
+                storage.put_scalars(**d)
+        del hist[:-1024]
+
+    def flush_vis_scalars(self):
+        """hand on whatever the device table holds now (end of training, tests): one device synchronisation"""
+        st = self.__dict__.get("_vis")
+        if st is None:
+            return
+        self._vis_deliver(wait=True)
+        if st["slot"]:
+            rows = st["dev"][: st["slot"]].cpu()
+            keep, st["host"] = st["host"], rows
+            st["event"] = torch.cuda.Event()
+            st["event"].record()
+            self._vis_deliver(wait=True)
+            st["host"], st["slot"] = keep, 0
 
     def _stamp_list(self):
         ts = self._stamp_tensors
-        if ts is None:
+        if ts is None or self._stamp_tree_epoch != _TREE_EPOCH[0]:
+            _MODELS.add(self)
             ts = self._stamp_tensors = list(self.parameters()) + list(self.buffers())
             self._stamp_ids = frozenset(id(t) for t in ts)
+            self._stamp_tree_epoch = _TREE_EPOCH[0]
         return ts
 
     def _tensor_ids(self):
@@ -1143,7 +1269,8 @@ class GDRN(nn.Module):
         """changes whenever a parameter or buffer may have changed since a plan packed its copies (comment above
         bump_weights_epoch): eval -> train steps -> eval must not serve the old weights.  (epoch of this model, sum of the
         tensors' in-place version counters - they only grow - over a cached tensor list: ~20 us per forward)"""
-        return (self._weights_epoch, sum(t._version for t in self._stamp_list()))
+        ts = self._stamp_list()
+        return (self._weights_epoch, self._stamp_tree_epoch, sum(t._version for t in ts))
 
     def plan(self, B, device, bf16=None):
         """bf16=None follows cfg.TEST.AMP_TEST (the reference's autocast switch, gdrn_evaluator.py:625) with the 16-bit format
@@ -1208,7 +1335,7 @@ class GDRN(nn.Module):
         if pcfg.TRANS_TYPE != "centroid_z" or pcfg.Z_TYPE != "REL":
             raise ValueError("only TRANS_TYPE='centroid_z' with Z_TYPE='REL' is implemented")
         use_pnp = bool(tcfg.get("USE_PNP", False))
-        net_mode, kabsch, im_hw = 0, False, None
+        net_mode, kabsch = 0, False
         if use_pnp:
             # the three choices of gdrn_evaluator.py:136-145 = the reference's 2D-3D solve (reprojection error, P3P / Gauss-Newton:
             # rdpn6d_ransac_pnp_f32), and the same three on the RGB-D residual geometry P - delta = R anchor + t (3D-3D Kabsch,
@@ -1225,14 +1352,13 @@ class GDRN(nn.Module):
                                           "on-device correspondence selection implements the 'L1' (min-max) mask normalisation only")
             assert roi_extents is not None, "USE_PNP needs roi_extents"
             roi_extents = f32c(roi_extents)
-            if not kabsch:
-                im_hw = self._image_sizes(im_H, im_W, B, x.device, tcfg)
         is_allo = "allo" in pcfg.ROT_TYPE
 
         def infer():
             plan = self.plan(B, x.device)
             if tuple(x.shape[1:]) != (6, plan.R, plan.R):
                 raise ValueError(f"expected x of shape (B,6,{plan.R},{plan.R}), got {tuple(x.shape)}")
+            im_hw = self._image_sizes(im_H, im_W, B, x.device, tcfg, plan=plan) if (use_pnp and not kabsch) else None
 
             def kabsch_solve():
                 # per-crop RANSAC + Kabsch on the residual correspondences, result next to the learned pose
@@ -1302,20 +1428,41 @@ class GDRN(nn.Module):
         return out
 
     @staticmethod
-    def _image_sizes(im_H, im_W, B, device, tcfg):
+    def _image_sizes(im_H, im_W, B, device, tcfg, plan=None):
         """(B, 2) int32 [H, W] of the image every crop was cut from: the reference scales coord2d by each input's own im_H / im_W
         (gdrn_evaluator.py:346-347,107-108; batch keys "im_H", "im_W" of engine_utils.batch_data_test).  Taken from the forward's
         im_H / im_W arguments (scalar, list or tensor of B), else from cfg.TEST.IM_H / IM_W when BOTH are set; there is no default -
-        a silently assumed 480 x 640 mis-scales the 2D points of every other camera (T-LESS 540 x 720, ITODD, ...)."""
+        a silently assumed 480 x 640 mis-scales the 2D points of every other camera (T-LESS 540 x 720, ITODD, ...).
+        plan: the table lives in the plan's persistent ``im_hw`` buffer (a stable address: the hipGraph key of TEST.HIP_GRAPH holds
+        it) and is only re-written when the sizes change; host values never cost a device sync, DEVICE tensors are rounded / cast on
+        the device and their positivity is checked once per distinct (address, version)."""
         if im_H is None and im_W is None and "IM_H" in tcfg and "IM_W" in tcfg:
             im_H, im_W = tcfg.get("IM_H"), tcfg.get("IM_W")
         if im_H is None or im_W is None:
             raise ValueError("TEST.USE_PNP with a 2D-3D PNP_TYPE needs the image size of every crop: pass im_H / im_W to forward "
                              "(batch['im_H'], batch['im_W']) or set cfg.TEST.IM_H and cfg.TEST.IM_W")
-        hw = torch.stack([torch.as_tensor(v).reshape(-1).to(torch.float64).round().to(torch.int32).cpu().expand(B) for v in (im_H, im_W)], dim=1)
-        if int(hw.min()) <= 0:
-            raise ValueError(f"im_H / im_W must be positive, got {hw.tolist()}")
-        return hw.contiguous().to(device)
+        on_dev = any(torch.is_tensor(v) and v.is_cuda for v in (im_H, im_W))
+        if on_dev:
+            key = ("dev",) + tuple((v.data_ptr(), v._version, tuple(v.shape)) if torch.is_tensor(v) else repr(v) for v in (im_H, im_W))
+            if plan is not None and getattr(plan, "_im_hw_key", None) == key:
+                return plan.bufs["im_hw"]
+            hw = torch.stack([torch.as_tensor(v, device=device).reshape(-1).to(torch.float64).round().to(torch.int32).expand(B)
+                              for v in (im_H, im_W)], dim=1)
+            if int(hw.min()) <= 0:  # (one device read per NEW tensor, not per forward)
+                raise ValueError(f"im_H / im_W must be positive, got {hw.tolist()}")
+        else:
+            hw = torch.stack([torch.as_tensor(v).reshape(-1).to(torch.float64).round().to(torch.int32).expand(B) for v in (im_H, im_W)], dim=1)
+            key = ("host", tuple(hw.reshape(-1).tolist()))
+            if plan is not None and getattr(plan, "_im_hw_key", None) == key:
+                return plan.bufs["im_hw"]
+            if int(hw.min()) <= 0:
+                raise ValueError(f"im_H / im_W must be positive, got {hw.tolist()}")
+        if plan is None:
+            return hw.contiguous().to(device)
+        buf = plan.buf("im_hw", B, 2, dtype=torch.int32)
+        buf.copy_(hw.contiguous(), non_blocking=True)
+        plan._im_hw_key = key
+        return buf
 
 
 class _HipBackward(torch.autograd.Function):

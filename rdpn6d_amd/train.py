@@ -244,6 +244,7 @@ class TrainEngine:
                                                                         _ptr(r["invstd"]), _ptr(r["ga"]), _ptr(r["be"]), _ptr(self._scratch_bnb),
                                                                         ctypes.byref(rows), self.st()), name)
                         run.stats_rows = rows.value
+                        self._bnb_owner = r  # the ONE shared sums buffer now holds this BatchNorm's partial sums (checked by its bwd)
                     else:
                         _lib.check(self.lpf("rdpn6d_conv2d_bf16")(ctypes.byref(d), of, self.st()), name)
 
@@ -556,6 +557,11 @@ class TrainEngine:
             # dgamma / dbeta land directly in the parameters' gradients (C entries each, also read back by the dx pass)
             prod = rec["producer"]
             if prod is not None and prod.stats_rows > 0:
+                if getattr(self, "_bnb_owner", None) is not rec:
+                    # every fused producer writes the same scratch rows: the consumer must be the NEXT fused user after its producer
+                    # (true for the chained ResNet / head topologies; a re-ordered _build would otherwise read another layer's sums)
+                    raise RuntimeError(f"fused BatchNorm backward of {name}: the shared partial-sum buffer was overwritten by another "
+                                       "layer's input-gradient convolution before this BatchNorm consumed it (set SOLVER.BN_FUSE_BWD=False)")
                 _lib.check(self.lpf("rdpn6d_bn_relu_backward_apply_bf16")(
                     _ptr(x_raw), cs, co, _ptr(dy), dy_cs, dy_co, _ptr(mean), _ptr(invstd), _ptr(ga), _ptr(be), _ptr(self._grad(bn.weight)),
                     _ptr(self._grad(bn.bias)), _ptr(dx), cs, co, M, C, _ptr(self._scratch_bnb), prod.stats_rows, self.st()),

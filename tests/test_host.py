@@ -234,3 +234,36 @@ def test_image_sizes_of_the_2d3d_pnp_and_per_model_weight_epochs():
     sa, sb = a._weights_stamp(), b._weights_stamp()
     gdrn.bump_weights_epoch()                                   # unknown writer: every live model
     assert a._weights_stamp() != sa and b._weights_stamp() != sb
+
+
+def test_replaced_parameter_objects_and_model_copies_are_seen_by_the_plan_stamp():
+    """(1) assigning a NEW Parameter / module object anywhere in the holder tree (invisible to the `_version` counters of the
+    cached tensor list) changes the stamp GDRN.plan() compares; (2) a deepcopy / unpickled copy (EMA / teacher model) registers itself
+    for the raw-pointer writers' epoch bumps and starts without the original's plans."""
+    import copy
+    import pickle
+
+    import torch
+
+    from rdpn6d_amd import gdrn
+    from rdpn6d_amd.config import gdrn_base_cfg
+
+    m, _ = gdrn.build_model_optimizer(gdrn_base_cfg(device="cpu"))
+    s0 = m._weights_stamp()
+    assert m._weights_stamp() == s0
+    m.backbone.conv1.weight = torch.nn.Parameter(torch.zeros_like(m.backbone.conv1.weight))
+    s1 = m._weights_stamp()
+    assert s1 != s0 and id(m.backbone.conv1.weight) in m._tensor_ids()
+    m.rot_head_net.features[3] = gdrn.ConvP(256, 256, 3, 1, 1)  # through the ModuleList
+    s2 = m._weights_stamp()
+    assert s2 != s1 and id(m.rot_head_net.features[3].weight) in m._tensor_ids()
+    m.backbone.layer2[0].downsample[1].register_buffer("running_mean", torch.zeros(128))
+    assert m._weights_stamp() != s2
+    m._plans[("sentinel",)] = object()
+    m2 = copy.deepcopy(m)
+    assert m2 in gdrn._MODELS and m2._plans == {} and m2._h2_flags == {} and len(m2.state_dict()) == 305
+    gdrn.bump_weights_epoch(list(m2.parameters())[:1])
+    assert m2._weights_epoch == m._weights_epoch + 1
+    m._plans.clear()
+    m3 = pickle.loads(pickle.dumps(m))
+    assert m3 in gdrn._MODELS and len(m3.state_dict()) == 305

@@ -280,3 +280,20 @@ def test_oracle_on_the_eight_unsearched_seeds_and_teacher_forced_pose_branch(gol
                 assert np.abs(o[k].numpy() - gold[f"s{s}_{k}"]).max() < 1e-4, k
             diff = o["region_argmax"].numpy() != gold[f"s{s}_argmax"]
             assert not (diff & ~tie_set(gold, s)).any()
+
+
+def test_train_vis_scalars_restatement_is_pinned_by_the_references_own_event_storage_values(golden_dir):
+    """tests/golden/vis_scalars_golden.npz (tools/oracle/gen_vis_golden.py): the 17 `vis/*` values the REAL reference pushed to its
+    EventStorage on the training batch of the well-conditioned fixture, and the train-mode pose it computed them from.  The numpy
+    restatement on exactly those inputs reproduces them (float32 arithmetic of compute_mean_re_te: <= 1e-6 relative)."""
+    gold = np.load(os.path.join(golden_dir, "vis_scalars_golden.npz"))
+    inp = synth.make_inputs(4, seed=int(gold["train_input_seed"]))
+    gt = synth.make_train_gt(4, inp)
+    assert set(str(n) for n in gold["names"]) == set(model_oracle.VIS_NAMES)
+    for att in ("none", "mul"):
+        net = np.zeros((4, 3), dtype=np.float32)
+        net[0] = [float(gold[f"{att}_vis/t{a}_net"]) for a in "xyz"]
+        v = model_oracle.train_vis_scalars(gold[f"{att}_pred_trans"], gold[f"{att}_pred_rot"], net, gt["trans"], gt["ego_rot"], gt["roi_trans_ratio"])
+        for k in model_oracle.VIS_NAMES:
+            ref = float(gold[f"{att}_{k}"])
+            assert abs(v[k] - ref) <= 1e-6 * max(1.0, abs(ref)), (att, k, v[k], ref)
