@@ -233,6 +233,9 @@ int rdpn6d_global_max_concat_f32(float* buf, int B, int HW, int C, int cs, void*
 /* GroupNorm(G, C) + ReLU (conv_pnp_net.py:80-82), NHWC in place; eps 1e-5                 */
 int rdpn6d_groupnorm_relu_f32(float* x, int B, int HW, int C, int G, const float* gamma, const float* beta,
                               void* stream);
+/* GroupNorm(G, C) + ReLU reading the fp32 tensor (left unchanged) and writing the result as an h2 tensor [B*HW][C/32][hi|lo] */
+int rdpn6d_groupnorm_relu_h2(const float* x, int B, int HW, int C, int G, const float* gamma, const float* beta, void* y_h2,
+                             int* overflow_flag, void* stream);
 
 /* ------------------------------------------------------------------ dense-map glue
  * GDRN.forward:196-233 + get_mask_prob (model_utils.py:24-42) + ConvPnPNet input assembly
@@ -246,6 +249,12 @@ int rdpn6d_groupnorm_relu_f32(float* x, int B, int HW, int C, int G, const float
 int rdpn6d_dense_glue_f32(const float* head, int head_cs, const float* coord2d, const float* fps, int B, int HW,
                           int K, int mask_attention, float* minmax_scratch, float* out_nchw, float* pnp_in,
                           int pnp_cs, int* argmax_out, void* stream);
+/* The same pass with the ConvPnPNet input as an h2 tensor [B*HW][pnp_cs/32][hi x 32 | lo x 32] fp16 (16 * value; pnp_cs % 32 == 0,
+ * zero padded) for ConvPnPNet on the fp16 matrix pipe (conv_pnp_net.py:129-137 -> rdpn6d_conv2d_h2); a value outside the format's
+ * range (|v| > 4094, inf, NaN) raises *overflow_flag like every other h2 writer. */
+int rdpn6d_dense_glue_h2(const float* head, int head_cs, const float* coord2d, const float* fps, int B, int HW, int K,
+                         int mask_attention, float* minmax_scratch, float* out_nchw, void* pnp_in_h2, int pnp_cs,
+                         int* argmax_out, int* overflow_flag, void* stream);
 
 /* ------------------------------------------------------------------ pose decode
  * ortho6d_to_mat_batch (core/utils/rot_reps.py:34-49) + pose_from_predictions_test

@@ -311,8 +311,12 @@ class forced_relu_masks:
     the arithmetic of the backward itself, which can then be compared at 1e-4.  The forward values change by at most the
     magnitude of the near-zero pre-activations concerned (1e-6)."""
 
-    def __init__(self, model, masks):
-        self.model, self.masks, self.saved, self.used = model, masks, [], set()
+    def __init__(self, model, masks, round_dtype=None):
+        """round_dtype (torch.bfloat16 | torch.float16): additionally round the OUTPUT of every trunk / fusion / head ReLU - and the
+        gradient arriving at it - to that format: the mixed-precision step stores these activations (and their gradients) in 16
+        bits (lowp_storage below emulates the rest of that step)."""
+        self.model, self.masks, self.saved, self.used, self.round_dtype = model, masks, [], set(), round_dtype
+        self.outputs = {}  # (module name, call index) -> the activation this call produced (stage-by-stage debugging)
 
     def __enter__(self):
         for name, m in self.model.named_modules():
@@ -326,10 +330,105 @@ class forced_relu_masks:
                     mask = self.masks[key].to(x.dtype)
                     assert mask.shape == x.shape, (key, tuple(mask.shape), tuple(x.shape))
                     self.used.add(key)
-                    return x * (mask + slope * (1 - mask)) if slope else x * mask
+                    y = x * (mask + slope * (1 - mask)) if slope else x * mask
+                    if self.round_dtype is not None and name.startswith(("backbone", "rot_head_net")):
+                        y = _RoundSTE.apply(y, self.round_dtype)
+                    self.outputs[key] = y.detach()
+                    return y
 
                 self.saved.append((m, m.__dict__.get("forward")))
                 m.forward = fwd
+        return self
+
+    def __exit__(self, *exc):
+        for m, old in self.saved:
+            if old is None:
+                del m.__dict__["forward"]
+            else:
+                m.forward = old
+        return False
+
+
+# --------------------------------------------------------------------------------------- 16-bit storage emulation
+class _RoundSTE(torch.autograd.Function):
+    """value AND gradient rounded to a 16-bit format (round-to-nearest-even), carried in the wider dtype"""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.dtype = dtype
+        return x.to(dtype).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dtype).to(g.dtype), None
+
+
+class _RoundValue(torch.autograd.Function):
+    """value rounded to a 16-bit format, gradient passed through unchanged (weights: their 16-bit mirror is what the matrix pipe
+    reads, their gradient is accumulated and kept in fp32)"""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        return x.to(dtype).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+class _RoundGrad(torch.autograd.Function):
+    """identity forward; the gradient is rounded to a 16-bit format"""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.dtype = dtype
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dtype).to(g.dtype), None
+
+
+class lowp_storage:
+    """Context manager for the parity test of the MIXED-PRECISION training step (cfg.SOLVER.AMP: the reference's autocast +
+    GradScaler switch, engine.py:279-309): the fp32 oracle evaluated on 16-BIT-ROUNDED OPERANDS with fp32 accumulation, rounding
+    wherever the HIP step stores 16 bits (rdpn6d_amd/train.py: buffers raw:* act:* d:* dres:*):
+
+      * every convolution of trunk / fusion branch / dense head reads a 16-bit input and 16-bit weights, accumulates in fp32 and
+        stores a 16-bit output (conv1 of the stem: fp32-accurate arithmetic on the fp32 crop, 16-bit output; the head's 1x1
+        output convolution: 16-bit operands, fp32 output whose gradient is rounded for its dgrad / wgrad);
+      * BatchNorm arithmetic is fp32 on the stored values; what it hands on is stored in 16 bits: after the ReLU
+        (forced_relu_masks(round_dtype=...)), after the two ReLU-less norms (downsample.1, spatial_net.b3);
+      * the same rounding is applied to the gradients flowing back through those points (activation gradients are stored in
+        16 bits); ConvPnPNet, the losses, parameter gradients and the pose branch stay fp32.
+    Combine with forced_relu_masks(model, masks, round_dtype=dtype) and GDRNOracle.forward(force_argmax=...)."""
+
+    def __init__(self, model, dtype):
+        self.model, self.dtype, self.saved = model, dtype, []
+
+    def __enter__(self):
+        dt = self.dtype
+        last = f"rot_head_net.features.{len(self.model.rot_head_net.features) - 1}"
+        for name, m in self.model.named_modules():
+            if not name.startswith(("backbone", "rot_head_net")):
+                continue
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                def fwd(x, m=m, name=name):
+                    first = name == "backbone.conv1"
+                    xin = x if first else _RoundSTE.apply(x, dt)
+                    w = m.weight if first else _RoundValue.apply(m.weight, dt)
+                    if isinstance(m, nn.ConvTranspose2d):
+                        y = F.conv_transpose2d(xin, w, m.bias, m.stride, m.padding, m.output_padding, m.groups, m.dilation)
+                    else:
+                        y = F.conv2d(xin, w, m.bias, m.stride, m.padding, m.dilation, m.groups)
+                    return _RoundGrad.apply(y, dt) if name == last else _RoundSTE.apply(y, dt)
+            elif isinstance(m, nn.BatchNorm2d) and name.endswith(("downsample.1", "spatial_net.b3")):
+                def fwd(x, m=m, orig=type(m).forward):
+                    return _RoundSTE.apply(orig(m, x), dt)
+            else:
+                continue
+            self.saved.append((m, m.__dict__.get("forward")))
+            m.forward = fwd
         return self
 
     def __exit__(self, *exc):

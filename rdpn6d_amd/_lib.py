@@ -70,7 +70,9 @@ SIGNATURES = {
     "rdpn6d_xyz_subsample_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "rdpn6d_global_max_concat_f32": (_i, [_vp, _i, _i, _i, _i, _vp]),
     "rdpn6d_groupnorm_relu_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "rdpn6d_groupnorm_relu_h2": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "rdpn6d_dense_glue_f32": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "rdpn6d_dense_glue_h2": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "rdpn6d_pose_decode_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "rdpn6d_ransac_kabsch_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _f, _u, _vp, _vp, _vp, _vp]),
     "rdpn6d_ransac_kabsch_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _f, _u, _vp, _vp, _vp, _vp, _vp]),

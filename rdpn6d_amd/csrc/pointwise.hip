@@ -1,6 +1,7 @@
 // Bandwidth-bound kernels of the RDPN6D forward path (everything that is not a GEMM).
 // All activations are NHWC fp32; loads/stores are 16 bytes per lane wherever the layout allows.
 #include "common.h"
+#include "h2_format.h"
 #include <float.h>
 
 // ------------------------------------------------------------------------------------------------
@@ -287,9 +288,13 @@ __device__ __forceinline__ float wave_sum(float v)
 }
 
 #define GN_THREADS 1024  // one workgroup per sample: 1024 lanes keep a single crop (per-image inference) short
+// H2 = false: in place on the fp32 tensor.  H2 = true: x stays as it is, the result goes out as an h2 tensor [B*HW][C/32][hi x 32 | lo x 32]
+// fp16 holding 16 * value (conv_igemm_h2.hip) - the input format of the next ConvPnPNet layer on the fp16 matrix pipe.
+template <bool H2>
 __global__ __launch_bounds__(GN_THREADS) void groupnorm4_relu_kernel(float* __restrict__ x, int HW, int C,
                                                                     const float* __restrict__ gamma,
-                                                                    const float* __restrict__ beta)
+                                                                    const float* __restrict__ beta, _Float16* __restrict__ y_h2,
+                                                                    int* __restrict__ overflow_flag)
 {
     // The groups are independent: workgroup (crop blockIdx.x, part blockIdx.y of gridDim.y) owns G = (C/4) / gridDim.y of them, thread t
     // its group g = t % G and pixel lane pl = t / G.  (One workgroup per crop - gridDim.y = 1 - left 64 crops on a quarter of the CUs with
@@ -337,6 +342,7 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm4_relu_kernel(float* __re
     const float rstd = s_rstd[g];
     const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + g * 4);
     const f32x4 be = *reinterpret_cast<const f32x4*>(beta + g * 4);
+    bool over = false;
     for (int p = pl; p < HW; p += PL) {
         f32x4 v = *reinterpret_cast<const f32x4*>(base + (long long)p * C);
 #pragma unroll
@@ -344,8 +350,26 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm4_relu_kernel(float* __re
             const float o = (v[e] - mean) * rstd * ga[e] + be[e];
             v[e] = o > 0.f ? o : 0.f;
         }
-        *reinterpret_cast<f32x4*>(base + (long long)p * C) = v;
+        if constexpr (H2) {
+            typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+            f16x4 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float sc = v[e] * 16.f;
+                over |= !(fabsf(sc) <= 65504.f);
+                sc = fminf(fmaxf(sc, -65504.f), 65504.f);
+                hi[e] = (_Float16)sc;
+                lo[e] = (_Float16)(sc - (float)hi[e]);
+            }
+            const int c = ((int)blockIdx.y * G + g) * 4;
+            _Float16* q = y_h2 + ((long long)blockIdx.x * HW + p) * (2 * (long long)C) + (c >> 5) * 64 + (c & 31);
+            *reinterpret_cast<f16x4*>(q) = hi;
+            *reinterpret_cast<f16x4*>(q + 32) = lo;
+        } else {
+            *reinterpret_cast<f32x4*>(base + (long long)p * C) = v;
+        }
     }
+    if (H2 && over && overflow_flag) *overflow_flag = 1;
 }
 
 extern "C" int rdpn6d_groupnorm_relu_f32(float* x, int B, int HW, int C, int G, const float* gamma, const float* beta,
@@ -354,7 +378,20 @@ extern "C" int rdpn6d_groupnorm_relu_f32(float* x, int B, int HW, int C, int G, 
     RD_REQUIRE(x && gamma && beta && B > 0 && HW > 0, "null/shape");
     RD_REQUIRE(C == 4 * G && G <= 64 && 256 % G == 0, "only C/G == 4 with G | 256 is implemented (GroupNorm(32,128))");
     const int parts = (G % 4 == 0 && HW >= 256) ? 4 : 1;  // (small maps: one workgroup per crop is already short)
-    hipLaunchKernelGGL(groupnorm4_relu_kernel, dim3(B, parts), dim3(GN_THREADS), 0, (hipStream_t)stream, x, HW, C, gamma, beta);
+    hipLaunchKernelGGL(groupnorm4_relu_kernel<false>, dim3(B, parts), dim3(GN_THREADS), 0, (hipStream_t)stream, x, HW, C, gamma, beta,
+                       (_Float16*)nullptr, (int*)nullptr);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}
+
+extern "C" int rdpn6d_groupnorm_relu_h2(const float* x, int B, int HW, int C, int G, const float* gamma, const float* beta, void* y_h2,
+                                        int* overflow_flag, void* stream)
+{
+    RD_REQUIRE(x && gamma && beta && y_h2 && B > 0 && HW > 0, "null/shape");
+    RD_REQUIRE(C == 4 * G && G <= 64 && 256 % G == 0 && C % 32 == 0, "only C/G == 4 with G | 256 and C % 32 == 0 is implemented (GroupNorm(32,128))");
+    const int parts = (G % 4 == 0 && HW >= 256) ? 4 : 1;
+    hipLaunchKernelGGL(groupnorm4_relu_kernel<true>, dim3(B, parts), dim3(GN_THREADS), 0, (hipStream_t)stream, const_cast<float*>(x), HW, C,
+                       gamma, beta, (_Float16*)y_h2, overflow_flag);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
 }
@@ -389,13 +426,16 @@ __global__ __launch_bounds__(256) void mask_minmax_kernel(const float* __restric
 // API returns and (b) the ConvPnPNet input row [xyz | coord2d | anchor | softmax(region[1:]) | pad].
 // The arg-max is taken ON the softmax output with first-max tie-break, exactly like
 // GDRN.py:206-209 (two different logits can round to the same probability).
-template <int KMAX>
+// H2: the ConvPnPNet input row goes out as an h2 record (pnp_cs % 32 == 0 channels: [hi x 32 | lo x 32] fp16 per 32-channel group,
+// 16 * value; conv_igemm_h2.hip) instead of fp32, and a value outside the format's range (|v| > 4094, inf, NaN - the inputs are
+// caller data: depth xyz, anchors) raises the plan's range flag like every other h2 writer.
+template <int KMAX, bool H2 = false>
 __global__ __launch_bounds__(256) void dense_glue_kernel(const float* __restrict__ head, int head_cs,
                                                          const float* __restrict__ coord2d,
                                                          const float* __restrict__ fps, int B, int HW, int K,
                                                          int mask_attention, const float* __restrict__ minmax,
                                                          float* __restrict__ out_nchw, float* __restrict__ pnp_in,
-                                                         int pnp_cs, int* __restrict__ argmax_out)
+                                                         int pnp_cs, int* __restrict__ argmax_out, int* __restrict__ overflow_flag)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= (long long)B * HW) return;
@@ -444,7 +484,6 @@ __global__ __launch_bounds__(256) void dense_glue_kernel(const float* __restrict
         const float mn = minmax[b * 2], mxm = minmax[b * 2 + 1];
         att = (v[0] - mn) / (mxm - mn);  // no epsilon, as model_utils.py:34
     }
-    float* q = pnp_in + i * pnp_cs;
     const float* cd = coord2d + (long long)b * 5 * HW + p;
     const float* an = fps + ((long long)b * K + am) * 3;
     float row[11];
@@ -452,6 +491,38 @@ __global__ __launch_bounds__(256) void dense_glue_kernel(const float* __restrict
 #pragma unroll
     for (int c = 0; c < 5; ++c) row[3 + c] = cd[(long long)c * HW];
     row[8] = an[0]; row[9] = an[1]; row[10] = an[2];
+    if constexpr (H2) {
+        _Float16* qh = reinterpret_cast<_Float16*>(pnp_in) + i * (2 * (long long)pnp_cs);
+        bool over = false;
+#pragma unroll
+        for (int c8 = 0; c8 < (11 + KMAX + 31) / 32 * 4; ++c8) {  // groups of 8 channels; whole 32-channel groups (zero padded)
+            if (c8 * 8 < pnp_cs) {
+                float sv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int ch = c8 * 8 + u;
+                    float val = 0.f;
+                    if (ch < 11) val = row[ch < 11 ? ch : 0];
+                    else if (ch - 11 < KMAX) val = (ch - 11 < K) ? e[ch - 11 < KMAX ? ch - 11 : 0] : 0.f;
+                    sv[u] = val * att * 16.f;
+                }
+                rd_h8 hi, lo;
+                over |= rd_h2_split8(sv, hi, lo);
+                _Float16* dst = qh + (c8 >> 2) * 64 + (c8 & 3) * 8;
+                *reinterpret_cast<rd_h8*>(dst) = hi;
+                *reinterpret_cast<rd_h8*>(dst + 32) = lo;
+            }
+        }
+        const rd_h8 z = {};
+        for (int c = (11 + KMAX + 31) / 32 * 32; c < pnp_cs; c += 8) {
+            _Float16* dst = qh + (c >> 5) * 64 + (c & 31);
+            *reinterpret_cast<rd_h8*>(dst) = z;
+            *reinterpret_cast<rd_h8*>(dst + 32) = z;
+        }
+        if (over && overflow_flag) *overflow_flag = 1;
+        return;
+    }
+    float* q = pnp_in + i * pnp_cs;
     // 11 + K channels, then zero pad up to pnp_cs (all register indices are compile-time constants)
 #pragma unroll
     for (int c4 = 0; c4 < (11 + KMAX + 3) / 4 + 1; ++c4) {
@@ -487,10 +558,34 @@ extern "C" int rdpn6d_dense_glue_f32(const float* head, int head_cs, const float
     const unsigned blocks = (unsigned)(((long long)B * HW + 255) / 256);
     if (K <= 32)
         hipLaunchKernelGGL(dense_glue_kernel<32>, dim3(blocks), dim3(256), 0, s, head, head_cs, coord2d, fps, B, HW, K,
-                           mask_attention, minmax_scratch, out_nchw, pnp_in, pnp_cs, argmax_out);
+                           mask_attention, minmax_scratch, out_nchw, pnp_in, pnp_cs, argmax_out, (int*)nullptr);
     else
         hipLaunchKernelGGL(dense_glue_kernel<64>, dim3(blocks), dim3(256), 0, s, head, head_cs, coord2d, fps, B, HW, K,
-                           mask_attention, minmax_scratch, out_nchw, pnp_in, pnp_cs, argmax_out);
+                           mask_attention, minmax_scratch, out_nchw, pnp_in, pnp_cs, argmax_out, (int*)nullptr);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}
+
+extern "C" int rdpn6d_dense_glue_h2(const float* head, int head_cs, const float* coord2d, const float* fps, int B, int HW, int K,
+                                    int mask_attention, float* minmax_scratch, float* out_nchw, void* pnp_in_h2, int pnp_cs,
+                                    int* argmax_out, int* overflow_flag, void* stream)
+{
+    RD_REQUIRE(head && coord2d && fps && out_nchw && pnp_in_h2, "null pointer");
+    RD_REQUIRE(B > 0 && HW > 0 && K >= 2 && K <= 64, "K in 2..64");
+    RD_REQUIRE(head_cs % 4 == 0 && head_cs >= 5 + K && pnp_cs % 32 == 0 && pnp_cs >= 11 + K, "channel strides (h2 row: pnp_cs % 32 == 0)");
+    RD_REQUIRE(!mask_attention || minmax_scratch, "mask attention needs a [B,2] scratch");
+    hipStream_t s = (hipStream_t)stream;
+    if (mask_attention) {
+        hipLaunchKernelGGL(mask_minmax_kernel, dim3(B), dim3(256), 0, s, head, head_cs, HW, minmax_scratch);
+        RD_LAUNCH_CHECK();
+    }
+    const unsigned blocks = (unsigned)(((long long)B * HW + 255) / 256);
+    if (K <= 32)
+        hipLaunchKernelGGL((dense_glue_kernel<32, true>), dim3(blocks), dim3(256), 0, s, head, head_cs, coord2d, fps, B, HW, K, mask_attention,
+                           minmax_scratch, out_nchw, reinterpret_cast<float*>(pnp_in_h2), pnp_cs, argmax_out, overflow_flag);
+    else
+        hipLaunchKernelGGL((dense_glue_kernel<64, true>), dim3(blocks), dim3(256), 0, s, head, head_cs, coord2d, fps, B, HW, K, mask_attention,
+                           minmax_scratch, out_nchw, reinterpret_cast<float*>(pnp_in_h2), pnp_cs, argmax_out, overflow_flag);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
 }

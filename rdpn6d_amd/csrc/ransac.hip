@@ -28,6 +28,23 @@
 #define RS_WAVES (RS_THREADS / 64)
 #define RS_MAX_ITERS 256
 
+#ifdef RDPN6D_PROBE
+// probe build only (RDPN6D_PROBE=1 python -m rdpn6d_amd.build; tools/debug/ransac_phases.py): 100 MHz timestamps of workgroup 0 at the
+// phase boundaries of ransac_kabsch_kernel
+__device__ unsigned long long* g_rs_probe = nullptr;
+extern "C" int rdpn6d_debug_ransac_probe(void* buf)
+{
+    RD_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_rs_probe), &buf, sizeof(buf)));
+    return RDPN6D_OK;
+}
+#define RS_STAMP(i)                                                                                    \
+    do {                                                                                               \
+        if (g_rs_probe && blockIdx.x == 0 && threadIdx.x == 0) g_rs_probe[i] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define RS_STAMP(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ unsigned rs_hash(unsigned seed, unsigned b, unsigned h, unsigned t, unsigned j)
 {
     unsigned x = seed;
@@ -208,6 +225,7 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_kabsch_kernel(
     const float ratio = ratios[b];
     const int* am = region_argmax + (size_t)b * HW;
 
+    RS_STAMP(0);
     // ---- phase 0: min / max of the mask
     float mn = FLT_MAX, mx = -FLT_MAX;
     for (int p = tid; p < HW; p += RS_THREADS) { const float v = m[p]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
@@ -224,6 +242,7 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_kabsch_kernel(
     const float range = mx - mn;
     __syncthreads();
 
+    RS_STAMP(1);
     // ---- phase 1: ordered compaction, RS_THREADS pixels per pass
     int n = 0;
     for (int base = 0; base < HW; base += RS_THREADS) {
@@ -257,6 +276,7 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_kabsch_kernel(
         __syncthreads();
     }
 
+    RS_STAMP(2);
     const float thr2 = inlier_thr * inlier_thr;
     for (int h = tid; h < iters; h += RS_THREADS) s_cnt[h] = -1;
     __syncthreads();
@@ -314,6 +334,7 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_kabsch_kernel(
             }
         }
         __syncthreads();
+        RS_STAMP(3);
         // ---- phase 3: scoreboard scan with the confidence-driven stop
         if (tid == 0) {
             int niters = iters;
@@ -349,6 +370,7 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_kabsch_kernel(
         return;
     }
 
+    RS_STAMP(4);
     // ---- phase 4: inliers of the winner + Kabsch / Horn refit (double, fixed reduction tree)
     float pose[12];
 #pragma unroll
@@ -386,9 +408,11 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_kabsch_kernel(
                 for (int c = 0; c < 3; c++) S[r * 3 + c] += ((double)ak[r] - abar[r]) * ((double)s_q[3 * i + c] - qbar[c]);
     }
     rs_block_sum<9>(S, s_dbl);
+    RS_STAMP(5);
     if (tid == 0) {
         double R[9];
         rs_horn(S, R);
+        RS_STAMP(6);
 #pragma unroll
         for (int i = 0; i < 9; i++) po[i] = (float)R[i];
 #pragma unroll

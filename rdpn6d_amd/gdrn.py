@@ -474,7 +474,7 @@ class InferencePlan:
         cur = self.bufs.get("h2_workspace")
         if cur is None or cur.numel() < nbytes:
             self.bufs["h2_workspace"] = cur = torch.empty(max(nbytes, 8 << 20), dtype=torch.uint8, device=self.device)
-            for L in self.launches:  # launches built against a smaller buffer: point them at the new one
+            for L in list(self.launches) + list(getattr(self, "_main_launches", ())):  # launches built against a smaller buffer: point them at the new one
                 if L.fn is self.lib.rdpn6d_conv2d_h2_ws:
                     L.args = L.args[:5] + (_ptr(cur), cur.numel())
         return cur
@@ -860,16 +860,25 @@ class InferencePlan:
 
         # --- glue -> NCHW API maps + ConvPnPNet input
         HW = R4 * R4
-        self.pnp_cs = _pad_to(11 + K, 16)
+        # cfg.TEST.PNP_H2 (default on): ConvPnPNet on the fp16 matrix pipe too (h2: fp32-accurate) - the glue kernel writes its input row
+        # as an h2 record, GroupNorm hands h2 on, the FC stack stays in h2.  0.21 GFLOP per crop, but ten launches at the fp32 MFMA
+        # kernel's small-problem rates were the step's tail (0.3 ms of 7 at B = 64).  The intermediate activations are bounded at plan
+        # time (_pnp_h2_range_ok: GroupNorm output, fc1 / fc2 rows); the input row is caller data and is range-checked by the glue kernel
+        self.pnp_h2 = bool(h2_pw and x3_head and self.fast == "h2" and model.cfg.get("TEST", {}).get("PNP_H2", True)
+                           and pnp.features[0].weight.shape[0] % 32 == 0 and self._pnp_h2_range_ok(pnp, R4))
+        self.pnp_cs = _pad_to(11 + K, 32 if self.pnp_h2 else 16)
         self.out_nchw = self.buf("out_nchw", B, nout, R4, R4)
-        pnp_in = self.buf("pnp_in", B, HW, self.pnp_cs)
+        pnp_in = self.planes_buf("pnp_in_planes", B * HW * self.pnp_cs, 1) if self.pnp_h2 else self.buf("pnp_in", B, HW, self.pnp_cs)
         self.argmax = self.buf("argmax", B, HW, dtype=torch.int32)
         minmax = self.buf("minmax", B, 2)
+        self.glue_fn = lib.rdpn6d_dense_glue_h2 if self.pnp_h2 else lib.rdpn6d_dense_glue_f32
         self.glue_args = lambda coord2d, fps: (_ptr(ho), self.head_cs, _ptr(coord2d), _ptr(fps), B, HW, K,
                                                1 if self.mask_attention == "mul" else 0, _ptr(minmax),
-                                               _ptr(self.out_nchw), _ptr(pnp_in), self.pnp_cs, _ptr(self.argmax))
+                                               _ptr(self.out_nchw), _ptr(pnp_in), self.pnp_cs, _ptr(self.argmax)) + (
+                                                   (_ptr(self.h2_flag),) if self.pnp_h2 else ())
         self.post = []  # launches after the glue
         main, self.launches = self.launches, self.post
+        self._main_launches = main
 
         # --- ConvPnPNet
         x, hw, cin = pnp_in, R4, self.pnp_cs
@@ -878,10 +887,18 @@ class InferencePlan:
             fd = conv.weight.shape[0]
             wpn = pack_conv_weight(conv.weight.detach().float(), cin_pad=cin)
             y = self.buf(f"pnp_c{i}", B, hw // 2, hw // 2, fd)
-            self.conv(f"pnp_net.features.{i}", x, (hw, hw), wpn, None, None, y, (hw // 2, hw // 2), cin=cin, in_cs=cin,
-                      k=3, stride=2, pad=1, N=fd, out_cs=fd)
             g, bta = gn.weight.detach().float().contiguous(), gn.bias.detach().float().contiguous()
             self.keep += [g, bta]
+            if self.pnp_h2:
+                self.conv_x3(f"pnp_net.features.{i}", x, (hw, hw), wpn, None, None, y, None, (hw // 2, hw // 2), cin=cin, in_cs=cin, k=3,
+                             stride=2, pad=1, N=fd, out_cs=fd, act=0)
+                yh = self.planes_buf(f"pnp_c{i}_planes", B * (hw // 2) ** 2 * fd, 1)
+                self.call(f"pnp_net.features.{i + 1}", lib.rdpn6d_groupnorm_relu_h2, _ptr(y), B, (hw // 2) ** 2, fd, gn.groups, _ptr(g),
+                          _ptr(bta), _ptr(yh), _ptr(self.h2_flag))
+                x, hw, cin = yh, hw // 2, fd
+                continue
+            self.conv(f"pnp_net.features.{i}", x, (hw, hw), wpn, None, None, y, (hw // 2, hw // 2), cin=cin, in_cs=cin,
+                      k=3, stride=2, pad=1, N=fd, out_cs=fd)
             self.call(f"pnp_net.features.{i + 1}", lib.rdpn6d_groupnorm_relu_f32, _ptr(y), B, (hw // 2) ** 2, fd, gn.groups,
                       _ptr(g), _ptr(bta))
             x, hw, cin = y, hw // 2, fd
@@ -890,13 +907,9 @@ class InferencePlan:
         w1 = pnp.fc1.weight.detach().float().view(-1, cin, hw, hw).permute(0, 2, 3, 1).reshape(-1, kin)
         w1p = torch.zeros(_pad_to(w1.shape[0], 64), 1, kin, **f32)
         w1p[: w1.shape[0], 0] = w1
-        f1 = self.buf("fc1", B, w1.shape[0])
-        self._fc("pnp_net.fc1", x, kin, w1p, pnp.fc1.bias, f1, w1.shape[0], act=2)
         w2 = pnp.fc2.weight.detach().float()
         w2p = torch.zeros(_pad_to(w2.shape[0], 64), 1, w2.shape[1], **f32)
         w2p[: w2.shape[0], 0] = w2
-        f2 = self.buf("fc2", B, w2.shape[0])
-        self._fc("pnp_net.fc2", f1, w2.shape[1], w2p, pnp.fc2.bias, f2, w2.shape[0], act=2)
         wrt = torch.cat([pnp.fc_r.weight.detach().float(), pnp.fc_t.weight.detach().float()], 0)  # (6+3, 256)
         brt = torch.cat([pnp.fc_r.bias.detach().float(), pnp.fc_t.bias.detach().float()], 0)
         if wrt.shape[0] != 9:
@@ -904,7 +917,23 @@ class InferencePlan:
         wrtp = torch.zeros(64, 1, wrt.shape[1], **f32)
         wrtp[:9, 0] = wrt
         self.rt = self.buf("rt", B, 16, zero=True)
-        self._fc("pnp_net.fc_r|fc_t", f2, wrt.shape[1], wrtp, brt, self.rt, 9, act=0, out_cs=16)
+        if self.pnp_h2:
+            # the h2 record of the last GroupNorm output [B*hw*hw][cin/32][hi|lo] IS the h2 row of the NHWC-flattened vector [B][kin/32][hi|lo]
+            n1, n2 = w1.shape[0], w2.shape[0]
+            f1, f2 = self.planes_buf("fc1_planes", B * n1, 1), self.planes_buf("fc2_planes", B * n2, 1)
+            b1 = _pad_vec(pnp.fc1.bias.detach().float(), w1p.shape[0], 0.0)
+            b2 = _pad_vec(pnp.fc2.bias.detach().float(), w2p.shape[0], 0.0)
+            b3 = _pad_vec(brt, 64, 0.0)
+            self.conv_x3("pnp_net.fc1", x, (1, 1), w1p, None, b1, None, f1, (1, 1), cin=kin, in_cs=kin, N=n1, out_cs=n1, act=2, slope=0.1)
+            self.conv_x3("pnp_net.fc2", f1, (1, 1), w2p, None, b2, None, f2, (1, 1), cin=n1, in_cs=n1, N=n2, out_cs=n2, act=2, slope=0.1)
+            # N = 16: rows 9..15 have zero weights and bias (the h2 kernels write 8 channels per lane)
+            self.conv_x3("pnp_net.fc_r|fc_t", f2, (1, 1), wrtp, None, b3, self.rt, None, (1, 1), cin=n2, in_cs=n2, N=16, out_cs=16, act=0)
+        else:
+            f1 = self.buf("fc1", B, w1.shape[0])
+            self._fc("pnp_net.fc1", x, kin, w1p, pnp.fc1.bias, f1, w1.shape[0], act=2)
+            f2 = self.buf("fc2", B, w2.shape[0])
+            self._fc("pnp_net.fc2", f1, w2.shape[1], w2p, pnp.fc2.bias, f2, w2.shape[0], act=2)
+            self._fc("pnp_net.fc_r|fc_t", f2, wrt.shape[1], wrtp, brt, self.rt, 9, act=0, out_cs=16)
         # the small per-crop outputs live in ONE byte buffer (16-byte aligned segments): forward() hands out a private copy of them
         # with one device copy instead of five (~5 us each at the launch floor: 2 % of a one-crop forward)
         segs = (("rot", (B, 3, 3), torch.float32), ("trans", (B, 3), torch.float32),
@@ -920,6 +949,54 @@ class InferencePlan:
             setattr(self, nm, t)
         self.pnp_best = self.buf("pnp_best", B, dtype=torch.int32)
         self.launches = main
+
+    @staticmethod
+    def _pnp_h2_range_ok(pnp, R4, limit=4000.0):
+        """Can ConvPnPNet's intermediate activations be HELD in the h2 format (|a| < 4094) whatever the input?  Proven from the weights
+        at plan time:
+          * a GroupNorm output is gamma * xhat + beta with |xhat| <= sqrt(n) (n = elements of a group: unit variance);
+          * an fc1 row over such a vector is bounded per GroupNorm group by Cauchy-Schwarz (||xhat_group||_2 <= sqrt(n)), ReLU /
+            LeakyReLU only shrink magnitudes;
+          * an fc2 row by ||w2_row||_2 * ||fc1 pre-activation||_2 with ||W1 relu(z) + b1||_2 <= sigma_max(W1) * (max|gamma| * sqrt(len)
+            + ||beta||_2) + ||b1||_2 (sigma_max from the 1024 x 1024 Gram matrix in fp64 - an l1 bound over the 1024 fc1 units is
+            3-4 x too pessimistic to pass for He-scaled weights).
+        (The convolutions' and fc_r / fc_t's OUTPUTS are fp32 - no constraint.)  False -> the plan keeps ConvPnPNet on the fp32 MFMA."""
+        hw = R4
+        gn = None
+        with torch.no_grad():
+            for i in (0, 3, 6):
+                gn, hw = pnp.features[i + 1], hw // 2
+                n = (gn.weight.numel() // gn.groups) * hw * hw
+                if float(gn.weight.abs().max()) * n ** 0.5 + float(gn.bias.abs().max()) >= limit:
+                    return False
+            C = gn.weight.numel()
+            n = (C // gn.groups) * hw * hw  # NCHW flatten (conv_pnp_net.py:151): a group's elements are contiguous in fc1's input
+            w1 = pnp.fc1.weight.double()
+            if w1.shape[1] != C * hw * hw:
+                return False
+            gam = gn.weight.double().repeat_interleave(hw * hw)
+            bet = gn.bias.double().repeat_interleave(hw * hw)
+            b1 = (w1 * gam).view(w1.shape[0], gn.groups, n).norm(dim=2).sum(1) * n ** 0.5 + (w1 * bet).abs().sum(1) + pnp.fc1.bias.double().abs()
+            if float(b1.max()) >= limit:
+                return False
+            smax = float(torch.linalg.eigvalsh(w1 @ w1.t())[-1].clamp_min(0.0)) ** 0.5
+            pre = smax * (float(gn.weight.abs().max()) * float(w1.shape[1]) ** 0.5 + float(bet.norm())) + float(pnp.fc1.bias.double().norm())
+            pre = min(pre, float(b1.norm()))  # (the element-wise bounds of fc1 give another valid 2-norm bound)
+            b2 = pnp.fc2.weight.double().norm(dim=1) * pre + pnp.fc2.bias.double().abs()
+            return bool(float(b2.max()) < limit)
+
+    def bind_outputs(self, fresh):
+        """fresh=True: THIS forward writes its API outputs - the NCHW maps (glue kernel) and the small per-crop outputs (pose decode,
+        RANSAC / PnP) - straight into newly allocated tensors that forward() hands to the caller: no 39-MB clone + five small copies
+        behind every step (42 us of 7 ms at B = 64).  fresh=False: the plan's fixed buffers (a captured hipGraph needs stable
+        addresses; forward() then hands out clones)."""
+        if fresh:
+            self.out_nchw = torch.empty_like(self.bufs["out_nchw"])
+            self._small = torch.empty_like(self.bufs["small_outputs"])
+        else:
+            self.out_nchw, self._small = self.bufs["out_nchw"], self.bufs["small_outputs"]
+        for nm, t in self.small_views(self._small).items():
+            setattr(self, nm, t)
 
     def small_views(self, buf):
         """rot / trans / pnp_pose / pnp_ninl / pnp_mask as typed views of a byte buffer laid out like self._small"""
@@ -948,10 +1025,15 @@ class InferencePlan:
         for L in self.launches:
             _lib.check(L.fn(*L.args, st), L.name)
         self.flag_read_queued = False
-        if after_h2 is not None and not torch.cuda.is_current_stream_capturing():
+        if not self.pnp_h2 and after_h2 is not None and not torch.cuda.is_current_stream_capturing():
             after_h2()
             self.flag_read_queued = True
-        _lib.check(lib.rdpn6d_dense_glue_f32(*self.glue_args(roi_coord_2d, fps), st), "dense_glue")
+        _lib.check(self.glue_fn(*self.glue_args(roi_coord_2d, fps), st), "dense_glue")
+        if self.pnp_h2 and after_h2 is not None and not torch.cuda.is_current_stream_capturing():
+            # ConvPnPNet on h2: the glue kernel writes (and range-checks) its input row - the last DATA-dependent h2 write of the step
+            # (what follows is bounded by the weights: _pnp_h2_range_ok), so the flag is read behind the glue kernel
+            after_h2()
+            self.flag_read_queued = True
         side = None
         if after_glue is not None:
             if self._side_stream is None:
@@ -1283,7 +1365,7 @@ class GDRN(_TreeWatch, nn.Module):
         tc = self.cfg.get("TEST", {})
         key = (B, str(device), bf16 or False, bool(tc.get("BF16X3", True)), bool(tc.get("FP16X2", True)), bool(tc.get("FOLD_GLOBAL_MAX", True)),
                bool(tc.get("FUSED_FRONT_LP", True)),
-               bool(tc.get("CONV_BEFORE_UPSAMPLE", True)), bool(tc.get("COMPOSE_CONV3_CONVT", True)))
+               bool(tc.get("CONV_BEFORE_UPSAMPLE", True)), bool(tc.get("COMPOSE_CONV3_CONVT", True)), bool(tc.get("PNP_H2", True)))
         stamp = self._weights_stamp()
         plan = self._plans.get(key)
         if plan is not None and plan.weights_stamp != stamp:
@@ -1392,7 +1474,9 @@ class GDRN(_TreeWatch, nn.Module):
                 elif use_pnp:
                     kabsch_solve()
 
-            if tcfg.get("HIP_GRAPH", False):
+            graphed = bool(tcfg.get("HIP_GRAPH", False))
+            plan.bind_outputs(fresh=not graphed)
+            if graphed:
                 # one hipGraph per set of input buffers: a serving loop that re-fills the same device buffers replays ~90
                 # kernel launches with one call (extension over the reference's config surface, off by default)
                 key = tuple(t.data_ptr() for t in (x, roi_coord_2d, fps, roi_cams, roi_centers, roi_whs, resize_ratios)) + (
@@ -1402,8 +1486,10 @@ class GDRN(_TreeWatch, nn.Module):
                 plan.run_graphed(key, launch)
             else:
                 launch()
-            o = plan.out_nchw.clone()  # the plan's buffers are overwritten by the next forward: hand out private copies
-            sm = plan.small_views(plan._small.clone())  # (rot, trans and the solve's outputs: one copy)
+            if graphed:  # the graph's fixed buffers are overwritten by the next replay: hand out private copies
+                o, sm = plan.out_nchw.clone(), plan.small_views(plan._small.clone())
+            else:        # this forward's own tensors (bind_outputs): nothing to copy
+                o, sm = plan.out_nchw, plan.small_views(plan._small)
             K = plan.K
             out = {
                 "rot": sm["rot"], "trans": sm["trans"],

@@ -92,6 +92,9 @@ class TrainEngine:
         self._bn_counters = []  # num_batches_tracked buffers, bumped together once per forward
         self.repack = []     # table entries of the one-launch weight re-pack (see _pack_map)
         self.fwd, self.bwd = [], []   # launch closures
+        # what each unit reads and writes (tensors by reference, no copies): the local, teacher-forced parity test of the mixed-precision
+        # step recomputes every layer's weight / BatchNorm gradients from exactly these stored operands (tests/test_gpu_c1w.py)
+        self.records = []
         self._scratch_d = torch.empty(512 * 1024 * 2 + 4096, dtype=torch.float64, device=device)
         self._wg_floats = 0
         self._build()
@@ -375,6 +378,9 @@ class TrainEngine:
                 self.fwd.append(self._launch_conv(name, d, (wf, bvec), ksplit=True))
         # ---- backward
         dy = self.buf("d:" + name, *y.shape, zero=True, dtype=y.dtype)  # gradient w.r.t. the raw conv output (same layout as y)
+        self.records.append(dict(kind="conv", name=name, P=P, bias=bias, x=x, xhw=xhw, in_cs=in_cs, in_co=in_co, cin=cin_real, y=y, yhw=yhw,
+                                 out_cs=out_cs, out_co=out_co, cout=cout, k=k, stride=stride, perm=perm, dy=dy, dx=dx, dx_cs=dx_cs or in_cs,
+                                 dx_res=dx_res, lowp=lowp))
         M = B * yhw[0] * yhw[1]
         ca = _pad_to(cout, 4)
         cb = _pad_to(cin_real, 4)
@@ -550,6 +556,8 @@ class TrainEngine:
         # the convolution that CONSUMES y registers after this unit: if its input-gradient launch can also produce this BatchNorm's
         # backward sums (conv_unit), the reduction pass over dy and x_raw is skipped here
         rec = dict(x_raw=x_raw, cs=cs, co=co, C=C, M=M, mean=mean, invstd=invstd, ga=ga, be=be, dy_cs=dy_cs, dy_co=dy_co, producer=None)
+        self.records.append(dict(kind="bn", name=name, bn=bn, x_raw=x_raw, cs=cs, co=co, C=C, M=M, y=y, ycs=ycs, yco=yco, relu=relu, res=res,
+                                 res_cs=res_cs, dx=dx, dres=dres, dy=dy, dy_cs=dy_cs, dy_co=dy_co))
         if remask and t != "f32" and self.bn_fuse_bwd:
             self._bn_by_dy[dy.data_ptr()] = rec
 
@@ -624,6 +632,7 @@ class TrainEngine:
             self._grad(bb.conv1.weight).copy_(wg_stem[:, 0, :147].view(64, 7, 7, 3).permute(0, 3, 1, 2))
 
         self.bwd.append([stem_wgrad])
+        self.records.append(dict(kind="stem", name="backbone.conv1", P=bb.conv1, x=self.x, y=raw0, dy=d_raw0, lowp=self.amp))
         d_a0 = self.bn_unit("bn1", bb.bn1, raw0, 64, 0, 64, B * R2 * R2, a0, 64, 0, True, dx=d_raw0)
         p0 = self.buf("act:pool", B, R4, R4, 64)
         f_pool, f_pool_b = getattr(lib, f"rdpn6d_maxpool3x3s2_{sfx}"), getattr(lib, f"rdpn6d_maxpool3x3s2_backward_{sfx}")
@@ -801,6 +810,7 @@ class TrainEngine:
         else:
             dgradT = self._launch_conv("dgrad convT", ddT, wdT, lowp=self.amp, out_f32=not self.amp)
         self.bwd.append(convT_bwd + [convT_wgrad, dgradT])
+        self.records.append(dict(kind="convT", name="rot_head_net.features.0", P=head.features[0], x=feat, y=rt0, dy=d_rt0, dx=d_feat, lowp=self.amp))
         d_prev = self.bn_unit("head.bn0", head.features[1], rt0, F, 0, F, Mh, at0, F, 0, True, dx=d_rt0)
         a_prev = at0
         nfeat = len(head.features)

@@ -432,7 +432,7 @@ def test_pose_teacher_forced_on_reference_maps(golden_setup, dev, att):
     ho.zero_()
     ho[:, :, :37] = torch.from_numpy(maps).to(dev).reshape(4, 37, 4096).permute(0, 2, 1)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    _lib.check(plan.lib.rdpn6d_dense_glue_f32(*plan.glue_args(t["roi_coord_2d"].contiguous(), t["fps"].contiguous()), st), "glue")
+    _lib.check(plan.glue_fn(*plan.glue_args(t["roi_coord_2d"].contiguous(), t["fps"].contiguous()), st), "glue")  # (h2 plan: writes ConvPnPNet's input as an h2 record)
     for L in plan.post:
         _lib.check(L.fn(*L.args, st), L.name)
     g = {k: t[k].float().contiguous() for k in ("roi_cam", "roi_center", "roi_wh", "resize_ratio")}
@@ -1096,8 +1096,8 @@ def test_fp32_plan_fast_forms_match_the_fp32_mfma_path(golden_setup, truth, dev)
     models, t, gold = golden_setup
     model = models["mul"]
     assert model.plan(4, dev).fast == "h2"
-    assert model.plan(4, dev).x3_launches == 51 and model.plan(4, dev).x3_trunk  # h2: the whole network on its tile kernels from one crop on
-    assert model.plan(1, dev).x3_launches == 51
+    assert model.plan(4, dev).x3_launches == 57 and model.plan(4, dev).pnp_h2 and model.plan(4, dev).x3_trunk  # h2: the whole network on its tile kernels from one crop on
+    assert model.plan(1, dev).x3_launches == 57
     rep = torch.arange(16, device=dev) % 4
     t16 = {k: (v[rep].contiguous() if v.shape[0] == 4 else v) for k, v in t.items()}
     tcfg = model.cfg.TEST
@@ -1113,7 +1113,8 @@ def test_fp32_plan_fast_forms_match_the_fp32_mfma_path(golden_setup, truth, dev)
             # h2 additionally keeps the point-wise fusion branch (4 convolutions), the ConvTranspose phases (4, tile kernel) and the 1x1
             # output convolution in its format: no fp32 copies / split passes in between; + the one-pixel convolution of the folded
             # global-max half of the ConvTranspose input (cfg.TEST.FOLD_GLOBAL_MAX)
-            assert plan.x3_launches == {"h2": 6 + 35 + 4 + 4 + 1 + 1, "x3": 6 + 35, "none": 0}[mode] and plan.x3_trunk == (mode != "none")
+            # ... + ConvPnPNet's three convolutions and three FC layers (cfg.TEST.PNP_H2)
+            assert plan.x3_launches == {"h2": 6 + 35 + 4 + 4 + 1 + 1 + 6, "x3": 6 + 35, "none": 0}[mode] and plan.x3_trunk == (mode != "none")
             assert plan.h2_pointwise == (mode == "h2")
             o = _run(model, t16)
             assert not plan.range_exceeded(wait=True)

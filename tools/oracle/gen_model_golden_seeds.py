@@ -16,7 +16,8 @@ and the near-tie pixels are excluded BY A RECORDED RULE instead of by choosing t
   * ``{att}_rot, {att}_trans``             - pose, att in (none, mul);
   * ``{att}_noise_rot/_trans``             - per crop, relative pose difference of the reference 1 vs 8 threads;
   * ``{att}_fp64err_rot/_trans``           - per crop, relative difference of the reference's fp32 pose from its float64 pose;
-  * ``noise_maps``                         - max-abs map difference of the reference 1 vs 8 threads (5 maps).
+  * ``noise_maps``                         - max-abs map difference of the reference 1 vs 8 threads (5 maps);
+  * ``fp64diff_{map}``                     - (the reference evaluated in float64) - (its fp32 maps), x 2^14, float16.
 
 THE TIE RULE (``tie_gap``, stored): a pixel belongs to the tie set iff the reference's top-2 logit gap there is < 2e-4 (= both
 logits moving by the map tolerance 1e-4 in opposite directions can swap them) OR the reference flips it against itself
@@ -94,6 +95,10 @@ def main():
             if att == "none":
                 for k in MAPS:
                     out[p + k] = o[k].numpy()
+                    # the reference's OWN float64 evaluation minus its fp32 maps, x 2^14 as float16 (|diff| ~ 1e-5: half the bytes, 1e-8
+                    # absolute resolution): lets the GPU test measure every plan's error against the EXACT answer, not only against
+                    # the reference's fp32 one (which is itself ~5e-5 from exact)
+                    out[p + "fp64diff_" + k] = ((o64[k].numpy() - o[k].numpy().astype(np.float64)) * 16384.0).astype(np.float16)
                 out[p + "noise_maps"] = np.asarray([(o1[k] - o[k]).abs().max().item() for k in MAPS])
                 am, am1, am64 = argmax_of(o["region"]), argmax_of(o1["region"]), argmax_of(o64["region"])
                 out[p + "argmax"] = am.numpy().astype(np.int8)
