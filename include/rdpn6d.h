@@ -295,6 +295,15 @@ int rdpn6d_ransac_kabsch_net_f32(const float* out_nchw, const float* coord2d, co
                                  int HW, int K, float mask_thr, float inlier_thr, int iters, float confidence,
                                  unsigned seed, int mode, float max_t_diff, float* pose_out, int* n_inliers,
                                  unsigned char* inlier_mask, int* best_hyp, void* stream);
+/* The same solves with a caller-provided workspace of rdpn6d_ransac_workspace_bytes(B) bytes: with fewer crops than CUs the hypotheses
+ * of a crop are spread over up to 4 workgroups (global scoreboard) and a second launch scans + refits - bit-identical results.
+ * net_pose NULL = the plain solve; else mode 1 / 2 as above. */
+long long rdpn6d_ransac_workspace_bytes(int B);
+int rdpn6d_ransac_kabsch_ws(const float* out_nchw, const float* coord2d, const float* fps, const float* extents,
+                            const float* resize_ratios, const int* region_argmax, const float* net_pose, int B, int HW, int K,
+                            float mask_thr, float inlier_thr, int iters, float confidence, unsigned seed, int mode,
+                            float max_t_diff, float* pose_out, int* n_inliers, unsigned char* inlier_mask, int* best_hyp,
+                            void* workspace, long long workspace_bytes, void* stream);
 
 
 /* ================================================================== training step (forward with batch statistics,

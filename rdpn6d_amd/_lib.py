@@ -78,6 +78,8 @@ SIGNATURES = {
     "rdpn6d_ransac_kabsch_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _f, _u, _vp, _vp, _vp, _vp, _vp]),
     "rdpn6d_ransac_kabsch_net_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _f, _u, _i, _f, _vp, _vp, _vp,
                                           _vp, _vp]),
+    "rdpn6d_ransac_workspace_bytes": (ctypes.c_longlong, [_i]),
+    "rdpn6d_ransac_kabsch_ws": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _f, _u, _i, _f, _vp, _vp, _vp, _vp, _vp, _ll, _vp]),
     "rdpn6d_stem_conv7x7_raw_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "rdpn6d_bn_train_stats_f32": (_i, [_vp, _ll, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rdpn6d_bn_apply_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _ll, _i, _i, _vp]),

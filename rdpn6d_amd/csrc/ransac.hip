@@ -21,6 +21,7 @@
 // cv2.solvePnPRansac plays at lib/pysixd/misc.py:170-179 / gdrn_evaluator.py:316-435.
 #include "common.h"
 #include <float.h>
+#include <cstdlib>
 
 #pragma clang fp contract(off)
 
@@ -133,7 +134,12 @@ __device__ void rs_horn(const double* S, double* R)
                       {Szx - Sxz, Sxy + Syx, -Sxx + Syy - Szz, Syz + Szy},
                       {Sxy - Syx, Szx + Sxz, Syz + Szy, -Sxx - Syy + Szz}};
     double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
-    for (int sweep = 0; sweep < 16; sweep++)
+    for (int sweep = 0; sweep < 16; sweep++) {
+        // converged?  (cyclic Jacobi converges quadratically: 5 - 7 sweeps for a 4 x 4; the remaining ones of the 16 would rotate by
+        // angles below 1e-15 - on ONE lane, in software fp64 sqrt / div, they were 45 us of this kernel's 140)
+        const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[0][3] * A[0][3] + A[1][2] * A[1][2] + A[1][3] * A[1][3] + A[2][3] * A[2][3];
+        const double dg = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2] + A[3][3] * A[3][3];
+        if (off <= 1e-32 * dg) break;
 #pragma unroll
         for (int p = 0; p < 3; p++)
 #pragma unroll
@@ -162,6 +168,7 @@ __device__ void rs_horn(const double* S, double* R)
                     V[k][q] = s * vkp + c * vkq;
                 }
             }
+    }
     // select the eigenvector of the largest eigenvalue with compile-time indices only
     double best = A[0][0];
     double w = V[0][0], x = V[1][0], y = V[2][0], z = V[3][0];
@@ -203,12 +210,16 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_kabsch_kernel(
     const float* __restrict__ extents, const float* __restrict__ ratios, const int* __restrict__ region_argmax, int HW,
     int K, float mask_thr, float inlier_thr, int iters, float confidence, unsigned seed, float* __restrict__ pose_out,
     int* __restrict__ n_inliers, unsigned char* __restrict__ inlier_mask, int* __restrict__ best_hyp,
-    const float* __restrict__ net_pose, float max_t_diff)
+    const float* __restrict__ net_pose, float max_t_diff, int stage, int* __restrict__ g_cnt, float* __restrict__ g_pose)
 {
+    // stage 0: the whole solve in one workgroup per crop.  stage 1 (grid B x parts): selection + this part's share of the hypotheses,
+    // counts / poses to the GLOBAL scoreboard g_cnt [B][RS_MAX_ITERS] / g_pose [B][RS_MAX_ITERS][12]; stage 2 (grid B): selection again,
+    // the scoreboard read back, scan + refit.  Same hypotheses, same counts, same scan order: bit-identical results - the split only
+    // spreads the 100 wavefront-hypotheses of a crop over `parts` CUs (B = 64 crops left three quarters of the chip idle).
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     // carve (all offsets multiples of 16 bytes)
-    double* s_dbl = reinterpret_cast<double*>(smem_raw);                       // RS_WAVES*9 + 16 doubles
-    float* s_pose = reinterpret_cast<float*>(s_dbl + RS_WAVES * 9 + 16);        // 12 * RS_MAX_ITERS
+    double* s_dbl = reinterpret_cast<double*>(smem_raw);                       // RS_WAVES*15 + 16 doubles
+    float* s_pose = reinterpret_cast<float*>(s_dbl + RS_WAVES * 15 + 16);       // 12 * RS_MAX_ITERS
     int* s_cnt = reinterpret_cast<int*>(s_pose + 12 * RS_MAX_ITERS);            // RS_MAX_ITERS
     float* s_anchor = reinterpret_cast<float*>(s_cnt + RS_MAX_ITERS);           // 3 * 64
     int* s_misc = reinterpret_cast<int*>(s_anchor + 3 * 64);                    // 64 ints
@@ -234,7 +245,7 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_kabsch_kernel(
     float* s_f = reinterpret_cast<float*>(s_misc);
     if (lane == 0) { s_f[wave] = mn; s_f[RS_WAVES + wave] = mx; }
     for (int i = tid; i < 3 * K; i += RS_THREADS) s_anchor[i] = A[i];
-    if (inlier_mask) for (int p = tid; p < HW; p += RS_THREADS) inlier_mask[(size_t)b * HW + p] = 0;
+    if (inlier_mask && stage != 1) for (int p = tid; p < HW; p += RS_THREADS) inlier_mask[(size_t)b * HW + p] = 0;
     __syncthreads();
     mn = s_f[0]; mx = s_f[RS_WAVES];
 #pragma unroll
@@ -282,9 +293,18 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_kabsch_kernel(
     __syncthreads();
 
     int best = -1, best_cnt = 0;
+    const int hstep = stage == 1 ? RS_WAVES * (int)gridDim.y : RS_WAVES;
+    if (stage == 1 && n < 3) {
+        for (int h = (int)blockIdx.y * RS_THREADS + tid; h < iters; h += RS_THREADS * (int)gridDim.y) g_cnt[(size_t)b * RS_MAX_ITERS + h] = -1;
+        return;
+    }
+    if (stage == 2 && n >= 3) {
+        for (int h = tid; h < iters; h += RS_THREADS) s_cnt[h] = g_cnt[(size_t)b * RS_MAX_ITERS + h];
+        __syncthreads();
+    }
     if (n >= 3) {
         // ---- phase 2: one hypothesis per wavefront
-        for (int h = wave; h < iters; h += RS_WAVES) {
+        for (int h = (stage == 1 ? (int)blockIdx.y * RS_WAVES : 0) + wave; h < iters && stage != 2; h += hstep) {
             float pose[12];
             bool ok = false;
             if (net_pose && h == 0) {  // hypothesis 0 = the network's own pose (process_net_and_pnp: extrinsic guess)
@@ -306,7 +326,10 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_kabsch_kernel(
                 }
                 ok = rs_triad(a0, a1, a2, q0, q1, q2, pose);
             }
-            if (!ok) continue;  // wave-uniform
+            if (!ok) {  // wave-uniform
+                if (stage == 1 && lane == 0) g_cnt[(size_t)b * RS_MAX_ITERS + h] = -1;
+                continue;
+            }
             // lanes < K hold the transformed anchor of region `lane`
             float ta[3] = {0.f, 0.f, 0.f};
             if (lane < K) {
@@ -328,11 +351,18 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_kabsch_kernel(
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
             if (lane == 0) {
-                s_cnt[h] = cnt;  // the LDS inlier scoreboard
+                if (stage == 1) {  // the scoreboard of the split solve lives in global memory (read back by stage 2)
+                    g_cnt[(size_t)b * RS_MAX_ITERS + h] = cnt;
 #pragma unroll
-                for (int i = 0; i < 12; i++) s_pose[12 * h + i] = pose[i];
+                    for (int i = 0; i < 12; i++) g_pose[((size_t)b * RS_MAX_ITERS + h) * 12 + i] = pose[i];
+                } else {
+                    s_cnt[h] = cnt;  // the LDS inlier scoreboard
+#pragma unroll
+                    for (int i = 0; i < 12; i++) s_pose[12 * h + i] = pose[i];
+                }
             }
         }
+        if (stage == 1) return;
         __syncthreads();
         RS_STAMP(3);
         // ---- phase 3: scoreboard scan with the confidence-driven stop
@@ -374,8 +404,13 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_kabsch_kernel(
     // ---- phase 4: inliers of the winner + Kabsch / Horn refit (double, fixed reduction tree)
     float pose[12];
 #pragma unroll
-    for (int i = 0; i < 12; i++) pose[i] = s_pose[12 * best + i];
-    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < 12; i++) pose[i] = stage == 2 ? g_pose[((size_t)b * RS_MAX_ITERS + best) * 12 + i] : s_pose[12 * best + i];
+    // ONE sweep over the correspondences: first and (un-centred) second moments of the winner's inliers in double, then
+    // S = sum a q^T - n abar qbar^T (coordinates of order 0.1 .. 1 m: the subtraction loses two of sixteen digits; the oracle's
+    // two-pass centred form agrees to 1e-12) - half the LDS traffic and one block reduction instead of two
+    double acc[15];
+#pragma unroll
+    for (int c = 0; c < 15; c++) acc[c] = 0.0;
     for (int i = tid; i < n; i += RS_THREADS) {
         const int k = s_ai[i];
         const float ak[3] = {s_anchor[3 * k], s_anchor[3 * k + 1], s_anchor[3 * k + 2]};
@@ -387,27 +422,20 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_kabsch_kernel(
             if (inlier_mask) inlier_mask[(size_t)b * HW + s_pix[i]] = 1;
 #pragma unroll
             for (int c = 0; c < 3; c++) { acc[c] += (double)ak[c]; acc[3 + c] += (double)s_q[3 * i + c]; }
-        }
-    }
-    rs_block_sum<6>(acc, s_dbl);
-    double abar[3], qbar[3];
-#pragma unroll
-    for (int c = 0; c < 3; c++) { abar[c] = acc[c] / (double)best_cnt; qbar[c] = acc[3 + c] / (double)best_cnt; }
-    double S[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = tid; i < n; i += RS_THREADS) {
-        const int k = s_ai[i];
-        const float ak[3] = {s_anchor[3 * k], s_anchor[3 * k + 1], s_anchor[3 * k + 2]};
-        float ta[3];
-        rs_apply(pose, ak, ta);
-        const float r0 = ta[0] - s_q[3 * i], r1 = ta[1] - s_q[3 * i + 1], r2 = ta[2] - s_q[3 * i + 2];
-        float d2 = r0 * r0; d2 = d2 + r1 * r1; d2 = d2 + r2 * r2;
-        if (d2 < thr2)
 #pragma unroll
             for (int r = 0; r < 3; r++)
 #pragma unroll
-                for (int c = 0; c < 3; c++) S[r * 3 + c] += ((double)ak[r] - abar[r]) * ((double)s_q[3 * i + c] - qbar[c]);
+                for (int c = 0; c < 3; c++) acc[6 + r * 3 + c] += (double)ak[r] * (double)s_q[3 * i + c];
+        }
     }
-    rs_block_sum<9>(S, s_dbl);
+    rs_block_sum<15>(acc, s_dbl);
+    double abar[3], qbar[3], S[9];
+#pragma unroll
+    for (int c = 0; c < 3; c++) { abar[c] = acc[c] / (double)best_cnt; qbar[c] = acc[3 + c] / (double)best_cnt; }
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) S[r * 3 + c] = acc[6 + r * 3 + c] - (double)best_cnt * abar[r] * qbar[c];
     RS_STAMP(5);
     if (tid == 0) {
         double R[9];
@@ -434,16 +462,20 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_kabsch_kernel(
 
 static size_t rs_smem_bytes(int HW)
 {
-    size_t s = sizeof(double) * (RS_WAVES * 9 + 16) + sizeof(float) * 12 * RS_MAX_ITERS + sizeof(int) * RS_MAX_ITERS +
+    size_t s = sizeof(double) * (RS_WAVES * 15 + 16) + sizeof(float) * 12 * RS_MAX_ITERS + sizeof(int) * RS_MAX_ITERS +
                sizeof(float) * 3 * 64 + sizeof(int) * 64;
     s += sizeof(float) * 3 * (size_t)HW + sizeof(unsigned short) * (size_t)HW + (size_t)HW;
     return (s + 15) & ~(size_t)15;
 }
 
+// Workspace of the split solve (global scoreboard): counts [B][RS_MAX_ITERS] int32 + poses [B][RS_MAX_ITERS][12] fp32
+extern "C" long long rdpn6d_ransac_workspace_bytes(int B) { return B > 0 ? (long long)B * RS_MAX_ITERS * (4 + 48) : 0; }
+
 static int rs_launch(const float* out_nchw, const float* coord2d, const float* fps, const float* extents,
                      const float* resize_ratios, const int* region_argmax, int B, int HW, int K, float mask_thr,
                      float inlier_thr, int iters, float confidence, unsigned seed, float* pose_out, int* n_inliers,
-                     unsigned char* inlier_mask, int* best_hyp, const float* net_pose, float max_t_diff, void* stream)
+                     unsigned char* inlier_mask, int* best_hyp, const float* net_pose, float max_t_diff, void* workspace,
+                     long long workspace_bytes, void* stream)
 {
     RD_REQUIRE(out_nchw && coord2d && fps && extents && resize_ratios && region_argmax && pose_out && n_inliers, "null pointer");
     RD_REQUIRE(B > 0 && HW > 0 && HW <= 16384, "HW must be in 1..16384 (LDS-resident correspondences)");
@@ -454,9 +486,29 @@ static int rs_launch(const float* out_nchw, const float* coord2d, const float* f
     const size_t smem = rs_smem_bytes(HW);
     RD_REQUIRE(smem <= 160 * 1024, "correspondences do not fit the 160 KiB LDS");
     RD_LDS_OPT_IN(ransac_kabsch_kernel, 160 * 1024);
+    // Split solve: with fewer crops than CUs the hypotheses of a crop are spread over `parts` workgroups (stage 1), a second launch scans
+    // the global scoreboard and refits (stage 2).  Bit-identical to the one-workgroup form (same hypotheses, counts, scan order).
+    int parts = 256 / B;
+    parts = parts > 4 ? 4 : parts;
+    const int rounds = (iters + RS_WAVES - 1) / RS_WAVES;
+    parts = parts > rounds ? rounds : parts;
+    static const int no_split = getenv("RDPN6D_RANSAC_NO_SPLIT") ? 1 : 0;  // profiling
+    if (parts >= 2 && !no_split && workspace && workspace_bytes >= rdpn6d_ransac_workspace_bytes(B)) {
+        int* g_cnt = reinterpret_cast<int*>(workspace);
+        float* g_pose = reinterpret_cast<float*>(g_cnt + (size_t)B * RS_MAX_ITERS);
+        hipLaunchKernelGGL(ransac_kabsch_kernel, dim3(B, parts), dim3(RS_THREADS), smem, (hipStream_t)stream, out_nchw, coord2d, fps,
+                           extents, resize_ratios, region_argmax, HW, K, mask_thr, inlier_thr, iters, confidence, seed,
+                           pose_out, n_inliers, inlier_mask, best_hyp, net_pose, max_t_diff, 1, g_cnt, g_pose);
+        RD_LAUNCH_CHECK();
+        hipLaunchKernelGGL(ransac_kabsch_kernel, dim3(B), dim3(RS_THREADS), smem, (hipStream_t)stream, out_nchw, coord2d, fps,
+                           extents, resize_ratios, region_argmax, HW, K, mask_thr, inlier_thr, iters, confidence, seed,
+                           pose_out, n_inliers, inlier_mask, best_hyp, net_pose, max_t_diff, 2, g_cnt, g_pose);
+        RD_LAUNCH_CHECK();
+        return RDPN6D_OK;
+    }
     hipLaunchKernelGGL(ransac_kabsch_kernel, dim3(B), dim3(RS_THREADS), smem, (hipStream_t)stream, out_nchw, coord2d, fps,
                        extents, resize_ratios, region_argmax, HW, K, mask_thr, inlier_thr, iters, confidence, seed,
-                       pose_out, n_inliers, inlier_mask, best_hyp, net_pose, max_t_diff);
+                       pose_out, n_inliers, inlier_mask, best_hyp, net_pose, max_t_diff, 0, (int*)nullptr, (float*)nullptr);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
 }
@@ -468,7 +520,28 @@ extern "C" int rdpn6d_ransac_kabsch_ex(const float* out_nchw, const float* coord
                                        int* best_hyp, void* stream)
 {
     return rs_launch(out_nchw, coord2d, fps, extents, resize_ratios, region_argmax, B, HW, K, mask_thr, inlier_thr, iters,
-                     confidence, seed, pose_out, n_inliers, inlier_mask, best_hyp, nullptr, 0.f, stream);
+                     confidence, seed, pose_out, n_inliers, inlier_mask, best_hyp, nullptr, 0.f, nullptr, 0, stream);
+}
+
+// The same solves with a caller-provided workspace (rdpn6d_ransac_workspace_bytes(B) bytes): enables the split form above.
+// net_pose == NULL: the plain solve (mode ignored); else mode 1 / 2 as rdpn6d_ransac_kabsch_net_f32.
+extern "C" int rdpn6d_ransac_kabsch_ws(const float* out_nchw, const float* coord2d, const float* fps, const float* extents,
+                                       const float* resize_ratios, const int* region_argmax, const float* net_pose, int B, int HW, int K,
+                                       float mask_thr, float inlier_thr, int iters, float confidence, unsigned seed, int mode,
+                                       float max_t_diff, float* pose_out, int* n_inliers, unsigned char* inlier_mask, int* best_hyp,
+                                       void* workspace, long long workspace_bytes, void* stream)
+{
+    if (net_pose) {
+        RD_REQUIRE(mode == 1 || mode == 2, "mode: 1 = net + RANSAC, 2 = net + least-squares over all points");
+        RD_REQUIRE(max_t_diff > 0.f, "max_t_diff");
+        if (mode == 2) {
+            iters = 1;
+            inlier_thr = __builtin_huge_valf();
+        }
+    }
+    return rs_launch(out_nchw, coord2d, fps, extents, resize_ratios, region_argmax, B, HW, K, mask_thr, inlier_thr, iters, confidence,
+                     seed, pose_out, n_inliers, inlier_mask, best_hyp, net_pose, net_pose ? max_t_diff : 0.f, workspace, workspace_bytes,
+                     stream);
 }
 
 // Network-initialised solve = process_net_and_pnp (gdrn_evaluator.py:187-314).  net_pose [B,12] (R row-major | t) is the
@@ -491,7 +564,7 @@ extern "C" int rdpn6d_ransac_kabsch_net_f32(const float* out_nchw, const float* 
         inlier_thr = __builtin_huge_valf();  // every selected correspondence counts
     }
     return rs_launch(out_nchw, coord2d, fps, extents, resize_ratios, region_argmax, B, HW, K, mask_thr, inlier_thr, iters,
-                     confidence, seed, pose_out, n_inliers, inlier_mask, best_hyp, net_pose, max_t_diff, stream);
+                     confidence, seed, pose_out, n_inliers, inlier_mask, best_hyp, net_pose, max_t_diff, nullptr, 0, stream);
 }
 
 extern "C" int rdpn6d_ransac_kabsch_f32(const float* out_nchw, const float* coord2d, const float* fps,

@@ -1112,19 +1112,17 @@ class InferencePlan:
         network-initialised variants (process_net_and_pnp): the pose run() just decoded seeds / guards the solve."""
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         HW = self.out_nchw.shape[2] * self.out_nchw.shape[3]
+        netp = None
         if net_mode:
             netp = self.buf("net_pose", self.B, 12)
             netp[:, :9].copy_(self.rot.view(self.B, 9))
             netp[:, 9:].copy_(self.trans)
-            _lib.check(self.lib.rdpn6d_ransac_kabsch_net_f32(
-                _ptr(self.out_nchw), _ptr(roi_coord_2d), _ptr(fps), _ptr(roi_extents), _ptr(resize_ratios), _ptr(self.argmax),
-                _ptr(netp), self.B, HW, self.K, mask_thr, inlier_thr, iters, confidence, seed, net_mode, max_t_diff,
-                _ptr(self.pnp_pose), _ptr(self.pnp_ninl), _ptr(self.pnp_mask), _ptr(self.pnp_best), st), "ransac_kabsch_net")
-            return
-        _lib.check(self.lib.rdpn6d_ransac_kabsch_ex(
-            _ptr(self.out_nchw), _ptr(roi_coord_2d), _ptr(fps), _ptr(roi_extents), _ptr(resize_ratios), _ptr(self.argmax),
-            self.B, HW, self.K, mask_thr, inlier_thr, iters, confidence, seed, _ptr(self.pnp_pose), _ptr(self.pnp_ninl),
-            _ptr(self.pnp_mask), _ptr(self.pnp_best), st), "ransac_kabsch")
+        # (the workspace enables the split form: a crop's hypotheses on up to four workgroups when the batch leaves CUs idle)
+        ws = self.buf("ransac_ws", int(self.lib.rdpn6d_ransac_workspace_bytes(self.B)), dtype=torch.uint8)
+        _lib.check(self.lib.rdpn6d_ransac_kabsch_ws(
+            _ptr(self.out_nchw), _ptr(roi_coord_2d), _ptr(fps), _ptr(roi_extents), _ptr(resize_ratios), _ptr(self.argmax), _ptr(netp),
+            self.B, HW, self.K, mask_thr, inlier_thr, iters, confidence, seed, net_mode or 1, max_t_diff, _ptr(self.pnp_pose),
+            _ptr(self.pnp_ninl), _ptr(self.pnp_mask), _ptr(self.pnp_best), _ptr(ws), ws.numel(), st), "ransac_kabsch")
 
 
 # ----------------------------------------------------------------------------- the model

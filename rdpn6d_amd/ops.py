@@ -262,7 +262,7 @@ def farthest_point_sampling(pts, sn, init_center=False, start=None):
 
 
 def ransac_kabsch(out_nchw, coord2d, fps, extents, resize_ratios, region_argmax, mask_thr=0.5, inlier_thr=0.01,
-                  iters=100, confidence=0.99, seed=0, net_pose=None, net_mode="ransac", max_t_diff=1.0):
+                  iters=100, confidence=0.99, seed=0, net_pose=None, net_mode="ransac", max_t_diff=1.0, split=True):
     """Per-crop RANSAC + Kabsch on the dense maps (device tensors).  Returns pose [B,12] (R row-major | t),
     n_inliers [B] int32, inlier_mask [B,HW] uint8, best_hyp [B] int32.  Role of process_pnp_ransac
     (gdrn_evaluator.py:316-435) for the RGB-D residual formulation; sentinel pose -100 when < 3 points."""
@@ -277,17 +277,14 @@ def ransac_kabsch(out_nchw, coord2d, fps, extents, resize_ratios, region_argmax,
     best = torch.empty(B, dtype=torch.int32, device=dev)
     args = [t.contiguous() for t in (out_nchw, coord2d, fps, extents, resize_ratios, region_argmax)]
     assert args[5].dtype == torch.int32
-    if net_pose is not None:
-        # process_net_and_pnp (gdrn_evaluator.py:187-314): the learned pose [B,12] initialises / guards the solve
-        npz = net_pose.float().contiguous()
-        _lib.check(_lib.load().rdpn6d_ransac_kabsch_net_f32(*[_ptr(t) for t in args], _ptr(npz), B, HW, K, mask_thr, inlier_thr,
-                                                            iters, confidence, seed, {"ransac": 1, "iter": 2}[net_mode],
-                                                            max_t_diff, _ptr(pose), _ptr(nin), _ptr(mask), _ptr(best),
-                                                            _stream()), "ransac_kabsch_net")
-        return pose, nin, mask, best
-    _lib.check(_lib.load().rdpn6d_ransac_kabsch_ex(*[_ptr(t) for t in args], B, HW, K, mask_thr, inlier_thr, iters,
-                                                   confidence, seed, _ptr(pose), _ptr(nin), _ptr(mask), _ptr(best),
-                                                   _stream()), "ransac_kabsch")
+    lib = _lib.load()
+    # (workspace of the split form: with fewer crops than CUs a crop's hypotheses are spread over up to four workgroups - same results)
+    ws = torch.empty(int(lib.rdpn6d_ransac_workspace_bytes(B)) if split else 1, dtype=torch.uint8, device=dev)
+    # process_net_and_pnp (gdrn_evaluator.py:187-314): the learned pose [B,12] initialises / guards the solve
+    npz = net_pose.float().contiguous() if net_pose is not None else None
+    _lib.check(lib.rdpn6d_ransac_kabsch_ws(*[_ptr(t) for t in args], _ptr(npz), B, HW, K, mask_thr, inlier_thr, iters, confidence, seed,
+                                           {"ransac": 1, "iter": 2}[net_mode], max_t_diff, _ptr(pose), _ptr(nin), _ptr(mask), _ptr(best),
+                                           _ptr(ws) if split else None, ws.numel() if split else 0, _stream()), "ransac_kabsch")
     return pose, nin, mask, best
 
 

@@ -386,6 +386,8 @@ def test_amp_step_every_layer_gradient_recomputed_from_the_stored_operands(c1w, 
                     X = torch.zeros_like(Xb)
                     X[:, r["perm"]] = Xb
                 DY = _nchw(r["dy"], r["out_co"], r["cout"])
+                if r["lowp"] and r["dy"].dtype == torch.float32:  # (the head output's fp32 gradient: wgrad / dgrad read a compact 16-bit copy)
+                    DY = DY.to(dt).double()
                 fwd = lambda X, w, r=r: F.conv2d(X, w, None, r["stride"], r["k"] // 2)  # noqa: E731
             wl = w.to(fdt).requires_grad_(True)
             gw, = torch.autograd.grad(fwd(X.to(fdt), wl), wl, DY.to(fdt))

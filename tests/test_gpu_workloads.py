@@ -130,6 +130,28 @@ def test_c4_ransac_stress_b64_outliers_0_to_70_percent(oracle_lib):
     assert recovered >= 58
 
 
+@pytest.mark.parametrize("B", [4, 64, 130])
+def test_ransac_split_over_workgroups_is_bit_identical(B):
+    """round 4: with fewer crops than CUs the 100 wavefront-hypotheses of a crop are spread over up to four workgroups (global
+    scoreboard, second launch for scan + refit: rdpn6d_ransac_kabsch_ws).  Same hypotheses, same counts, same scan order - every
+    output must be BIT-identical to the one-workgroup-per-crop form, plain and network-initialised, also where the split is not taken
+    (B = 130: more than 128 crops -> one part)."""
+    from rdpn6d_amd import ops
+    from tests.ransac_cases import make_case
+
+    dev = torch.device("cuda:0")
+    c = make_case(B=B, K=32, side=64, outliers=np.linspace(0.0, 0.7, B), seed=31)
+    g = {k: torch.from_numpy(c[k]).to(dev) for k in ("out_nchw", "coord2d", "fps", "extents", "ratios", "argmax")}
+    args = (g["out_nchw"], g["coord2d"], g["fps"], g["extents"], g["ratios"], g["argmax"])
+    netp = torch.from_numpy(np.concatenate([c["R"].reshape(B, 9), c["t"].reshape(B, 3)], 1).astype(np.float32)).to(dev)
+    for kw in (dict(), dict(iters=20, net_pose=netp, net_mode="ransac"), dict(net_pose=netp, net_mode="iter"), dict(iters=7)):
+        a = ops.ransac_kabsch(*args, seed=9, split=True, **kw)
+        b = ops.ransac_kabsch(*args, seed=9, split=False, **kw)
+        torch.cuda.synchronize()
+        for x, y, nm in zip(a, b, ("pose", "n_inliers", "mask", "best_hyp")):
+            assert torch.equal(x, y), (B, kw.keys(), nm)
+
+
 def test_c3_amp_training_at_b32_copies_and_small_batch_losses():
     """C3's per-GPU batch in mixed precision (cfg.SOLVER.AMP.ENABLED, bf16 storage): B = 32 = 8 copies of 4 crops has the same
     batch statistics as those 4 crops alone, so the nine losses must equal the B = 4 AMP losses, every copy of a crop must
