@@ -315,6 +315,8 @@ def train_bench(args, rank, world, device, dist):
     inp = synth.make_inputs(B, seed=200 + rank, res=args.res)
     batch = {k: torch.from_numpy(v).to(device) for k, v in {**inp, **synth.make_train_gt(B, inp)}.items()}
 
+    skipped = [0]
+
     def one_step():
         losses = eng.forward_losses(batch)
         if eng.loss_scale != 1.0:
@@ -322,6 +324,12 @@ def train_bench(args, rank, world, device, dist):
         eng.backward(on_group_done=buckets.reduce)
         buckets.finish()
         if eng.loss_scale != 1.0:
+            # fp16: GradScaler's rule (engine.py:302-309) - a step whose reduced gradients are not finite is SKIPPED and the scale halved
+            # (one host read per step, as scaler.step() has); un-skipped, one overflow of an fp16 activation gradient poisons the weights
+            if not bool(torch.isfinite(buckets.flat).all()):
+                skipped[0] += 1
+                eng.loss_scale = max(eng.loss_scale * 0.5, 1.0)
+                return losses
             buckets.flat.mul_(1.0 / eng.loss_scale)
         opt.step()
         eng.refresh_weights()
@@ -372,6 +380,7 @@ def train_bench(args, rank, world, device, dist):
                                                    if (amp and (args.backbone, args.res) == (34, 256)) else None),
             "gflop_per_crop": {"fwd+dgrad+wgrad": 132.3} if (args.backbone, args.res) == (34, 256) else None,
             "preheat_s": args.preheat, "roofline": roof,
+            "loss_scale_final": eng.loss_scale if args.dtype == "fp16" else None, "steps_skipped_for_overflow": skipped[0] if args.dtype == "fp16" else None,
             "loss_total": round(float(sum(v.item() for v in losses.values())), 4)}))
     if dist is not None:
         dist.destroy_process_group()

@@ -162,6 +162,15 @@ int rdpn6d_conv2d_h2_cb(const rdpn6d_conv_desc* d, void* y_h2, const void* res_h
 long long rdpn6d_conv_h2_workspace_bytes(const rdpn6d_conv_desc* d);
 int rdpn6d_conv2d_h2_ws(const rdpn6d_conv_desc* d, void* y_h2, const void* res_h2, int* overflow_flag, const float* crop_bias,
                         void* workspace, long long workspace_bytes, void* stream);
+/* The same convolution with a 1x1 OUTPUT convolution fused into its epilogue - the dense head's last 3x3 layer + features.21
+ * (core/gdrn_modeling/models/cdpn_rot_head_region.py:130-138): out[pixel][n] = scale1[n] * sum_c act(conv)[pixel][c] * w1[n][c] +
+ * bias1[n], n < n_out; the 256-channel activation is never written.  w1_h2: h2 records [64][N/32][hi|lo] of the [64][1][N] fp32 matrix
+ * (rows >= n_out zero); scale1 / bias1: 64 floats; out fp32 [pixels][out_cs], out_cs % 8 == 0, n_out <= out_cs <= 64; desc.y must be
+ * NULL.  Needs the 256x256 kernel with one tile across N: rdpn6d_conv_h2_fuse1x1_ok(desc) != 0. */
+int rdpn6d_conv_h2_fuse1x1_ok(const rdpn6d_conv_desc* d);
+int rdpn6d_conv2d_h2_fuse1x1(const rdpn6d_conv_desc* d, const void* res_h2, int* overflow_flag, const float* crop_bias,
+                             const void* w1_h2, const float* scale1, const float* bias1, float* out, int out_cs, int n_out,
+                             void* stream);
 /* h2 forms of the kernels between the h2 convolutions of the point-wise fusion branch (same argument meaning as the _f32 entry
  * points; activations are h2 tensors, C / out_cs / out_co multiples of 32; the xyz subsample fills one whole 32-channel group
  * [x y z 0 ...]; csrc/pointwise_h2.hip) */

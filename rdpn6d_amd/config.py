@@ -158,5 +158,5 @@ def gdrn_base_cfg(num_regions=32, mask_attention="none", device="cuda", num_clas
         INPUT=dict(FORMAT="BGR", DZI_PAD_SCALE=1.5),
         # VIS_SCALARS / VIS_PERIOD (not reference keys): the vis/* scalars of GDRN.py:306-368 computed on the device, delivered every N steps
         TRAIN=dict(VIS_SCALARS=False, VIS_PERIOD=20),
-        TEST=dict(USE_PNP=False, PNP_TYPE="ransac_pnp", AMP_TEST=False, AMP_DTYPE="bf16", BF16X3=True, FP16X2=True, FOLD_GLOBAL_MAX=True, CONV_BEFORE_UPSAMPLE=True, COMPOSE_CONV3_CONVT=True, PNP_H2=True, PNP_SIDE_STREAM=True, TEST_BBOX_TYPE="est"),
+        TEST=dict(USE_PNP=False, PNP_TYPE="ransac_pnp", AMP_TEST=False, AMP_DTYPE="bf16", BF16X3=True, FP16X2=True, FOLD_GLOBAL_MAX=True, CONV_BEFORE_UPSAMPLE=True, COMPOSE_CONV3_CONVT=True, PNP_H2=True, FUSE_HEAD_OUT=True, PNP_SIDE_STREAM=True, TEST_BBOX_TYPE="est"),
     )

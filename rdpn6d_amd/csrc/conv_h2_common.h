@@ -19,6 +19,14 @@ struct ConvH2Args {
     // ([slice][mtiles*BM][Npad]); h2_splitk_reduce_kernel adds the slices in slice order (deterministic) and runs the epilogue
     float* partial;
     int nsplit, mpad;
+    // Fused 1x1 output convolution (eight-phase kernel, one N tile = all channels of a pixel in the workgroup): out[pix][n] =
+    // fuse_scale[n] * sum_c relu(...)[pix][c] * fuse_w[n][c] + fuse_bias[n], n < fuse_n <= 64 - the activation tile is multiplied by the
+    // 1x1 weights (h2 records [64][N/32][hi|lo]) straight out of the epilogue and never written (cdpn_rot_head_region.py:130-138)
+    const void* fuse_w;
+    const float* fuse_scale;
+    const float* fuse_bias;
+    float* fuse_out;
+    int fuse_cs, fuse_n;
 };
 
 

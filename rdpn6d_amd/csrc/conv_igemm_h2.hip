@@ -44,10 +44,13 @@ namespace {
 // ============================================================================================ 256x256 eight-phase kernel
 constexpr int HT_BYTES = 16384;            // one half-tile slot: 128 rows x 128 B
 constexpr int LDS_8PH = 2 * 4 * HT_BYTES;  // 128 KiB
+constexpr int LDS_8PH_FUSED = 8 * (32 * 72 * 4 + 32 * 272);  // 140 KiB: the fused-1x1 epilogue's per-wave transposition + A-fragment slices
+static_assert(LDS_8PH_FUSED >= LDS_8PH && LDS_8PH_FUSED <= 160 * 1024, "LDS");
 
 // Schedule, LDS map, DMA stream and counted waits: see conv_igemm_bf16_8ph.hip (this is that kernel with the h2 inner
 // product - 12 MFMAs per phase instead of 8 - and the h2 epilogue).  A K-tile = one 128-byte row = 32 channels (hi | lo).
-__global__ __launch_bounds__(512) void conv_h2_8ph_kernel(const ConvH2Args ax)
+template <bool FUSE>
+__global__ __launch_bounds__(512) void conv_h2_8ph_kernel_t(const ConvH2Args ax)
 {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 #ifdef RDPN6D_PROBE
@@ -306,6 +309,116 @@ __global__ __launch_bounds__(512) void conv_h2_8ph_kernel(const ConvH2Args ax)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (wr == 0) __builtin_amdgcn_s_barrier();  // re-align the two groups
 
+    if constexpr (FUSE) {
+        // ---- fused epilogue: activation tile x 1x1 output weights.  Per wave and 32-row block: (1) transpose the block through the
+        // wave's LDS slice, folded BatchNorm + ReLU, h2 split; (2) the h2 records go into a second slice in MFMA A-fragment order
+        // (row stride 272 B: conflict-free 16-byte reads); (3) 24 MFMAs against the wave's 64-channel slice of the 1x1 weights (held in
+        // registers for the whole epilogue) give the partial [32 x 64]; (4) the four waves that share the rows add their partials in
+        // wave order (fixed: bit-reproducible whatever the batch slot) and write [32 x fuse_n] fp32.
+        constexpr int CS = 64 + 8, AST = 272;
+        constexpr int SLICE = 32 * CS * 4 + 32 * AST;  // 9216 + 8704 bytes per wave
+        const int hi = lane >> 5;
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        float* cst = reinterpret_cast<float*>(smem + wave * SLICE);
+        unsigned char* ast = smem + wave * SLICE + 32 * CS * 4;
+        const int rrow = lane >> 3, c8 = (lane & 7) * 8;
+        // this wave's slice of the 1x1 weights: n-block jn, channel chunk cch (channels nb + 32 cch ..), slot pair j
+        u32x4 fw[2][2][4];
+        {
+            const unsigned char* wbase = reinterpret_cast<const unsigned char*>(ax.fuse_w);
+            const int nchunks = d.Npad / 32;
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+                for (int cch = 0; cch < 2; ++cch)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        fw[jn][cch][j] = *reinterpret_cast<const u32x4*>(wbase + ((size_t)(jn * 32 + frow) * nchunks + (nb >> 5) + cch) * 128 + ((2 * j + half) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e)
+                    cst[((e & 3) + 8 * (e >> 2) + 4 * hi) * CS + j * 32 + frow] = acc[i][j][e] * scj[j] + shj[j];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int row = rr * 8 + rrow;
+                const f32x4 lo4 = *reinterpret_cast<const f32x4*>(cst + row * CS + c8);
+                const f32x4 hi4 = *reinterpret_cast<const f32x4*>(cst + row * CS + c8 + 4);
+                float v[8] = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+                conv_bf16_act(v, d.act, d.slope);
+                float sv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) sv[q] = v[q] * H2_SCALE;
+                f16x8 vh, vl;
+                const bool over = h2_split8(sv, vh, vl);
+                if (over && ax.overflow_flag && m0 + wr * 128 + i * 32 + row < a.M) *ax.overflow_flag = 1;
+                unsigned char* ap = ast + row * AST + (c8 >> 5) * 128 + (c8 & 31) * 2;
+                *reinterpret_cast<f16x8*>(ap) = vh;
+                *reinterpret_cast<f16x8*>(ap + 64) = vl;
+            }
+            // (the wave's own LDS writes are ordered before its reads; data dependence through lgkmcnt)
+            f32x16 oacc[2];
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) oacc[jn][e] = 0.f;
+            {
+                H2_PAIRS;
+#pragma unroll
+                for (int cch = 0; cch < 2; ++cch) {
+                    u32x4 af[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) af[j] = *reinterpret_cast<const u32x4*>(ast + frow * AST + cch * 128 + ((2 * j + half) << 4));
+#pragma unroll
+                    for (int pr = 0; pr < 6; ++pr)
+#pragma unroll
+                        for (int jn = 0; jn < 2; ++jn) oacc[jn] = h2_mfma(af[H2_PA[pr]], fw[jn][cch][H2_PB[pr]], oacc[jn]);
+                }
+            }
+            // partial [32 rows x 64 n] of this wave -> its cst slice (free again), then the four waves of the row group add in wave order
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) cst[((e & 3) + 8 * (e >> 2) + 4 * hi) * CS + jn * 32 + frow] = oacc[jn][e];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            {
+                const int row = lane >> 1, n8 = wc * 16 + (lane & 1) * 8;  // this wave finishes columns [16 wc, 16 wc + 16) of the 32 rows
+                float r[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int w4 = 0; w4 < 4; ++w4) {
+                    const float* ps = reinterpret_cast<const float*>(smem + (wr * 4 + w4) * SLICE) + row * CS + n8;
+                    const f32x4 p0 = *reinterpret_cast<const f32x4*>(ps), p1 = *reinterpret_cast<const f32x4*>(ps + 4);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        r[q] += p0[q];
+                        r[4 + q] += p1[q];
+                    }
+                }
+                const long long mrow = m0 + wr * 128 + i * 32 + row;
+                if (mrow < a.M && n8 < ax.fuse_cs) {
+                    float* op = ax.fuse_out + h2_pixel_of(a, mrow) * ax.fuse_cs + n8;
+                    f32x4 o0, o1;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        o0[q] = r[q] * ax.fuse_scale[n8 + q] + ax.fuse_bias[n8 + q];
+                        o1[q] = r[4 + q] * ax.fuse_scale[n8 + 4 + q] + ax.fuse_bias[n8 + 4 + q];
+                    }
+                    *reinterpret_cast<f32x4*>(op) = o0;
+                    *reinterpret_cast<f32x4*>(op + 4) = o1;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // every wave has read the partials before the next block overwrites them
+            asm volatile("" ::: "memory");
+        }
+        return;
+    }
     // ---- epilogue: each wave transposes its 128 x 64 tile through its own LDS slice, 8 channels per lane on the way out
     {
         const int hi = lane >> 5;
@@ -352,6 +465,8 @@ __global__ __launch_bounds__(512) void conv_h2_8ph_kernel(const ConvH2Args ax)
     }
 #endif
 }
+
+constexpr auto conv_h2_8ph_kernel = conv_h2_8ph_kernel_t<false>;
 
 // ============================================================================================ 128x128 .. 64x64 tile kernel
 // conv_igemm_bf16.hip's two-stage form (2x2 wavefronts, LDS-DMA staging, one barrier per K-chunk, fragment double buffer,
@@ -896,10 +1011,46 @@ extern "C" int rdpn6d_conv2d_h2_cb(const rdpn6d_conv_desc* d, void* y_h2, const 
     return rdpn6d_conv2d_h2_ws(d, y_h2, res_h2, overflow_flag, crop_bias, nullptr, 0, stream);
 }
 
+struct H2Fuse {
+    const void* w;
+    const float *scale, *bias;
+    float* out;
+    int cs, n;
+};
+static int conv2d_h2_impl(const rdpn6d_conv_desc* d, void* y_h2, const void* res_h2, int* overflow_flag, const float* crop_bias,
+                          void* workspace, long long workspace_bytes, const H2Fuse* fuse, void* stream);
+
 extern "C" int rdpn6d_conv2d_h2_ws(const rdpn6d_conv_desc* d, void* y_h2, const void* res_h2, int* overflow_flag, const float* crop_bias,
                                    void* workspace, long long workspace_bytes, void* stream)
 {
-    RD_REQUIRE(d && d->x && d->w && (d->y || y_h2), "null pointer");
+    return conv2d_h2_impl(d, y_h2, res_h2, overflow_flag, crop_bias, workspace, workspace_bytes, nullptr, stream);
+}
+
+// The convolution with a 1x1 output convolution fused into its epilogue (the dense head's last 3x3 layer + features.21,
+// cdpn_rot_head_region.py:130-138): out[pixel][n] = scale1[n] * sum_c act(conv)[pixel][c] * w1[n][c] + bias1[n], n < n_out.  The
+// activation is never written.  w1: h2 records [64][N/32][hi|lo] (gdrn.pack_h2_weight of the [64][1][N] fp32 matrix, rows >= n_out
+// zero); scale1 / bias1: 64 floats; out: fp32 [pixels][out_cs], out_cs % 8 == 0, n_out <= out_cs <= 64.  Needs the 256x256 kernel with
+// ONE tile across N (N == Npad == 256): rdpn6d_conv_h2_fuse1x1_ok.
+extern "C" int rdpn6d_conv_h2_fuse1x1_ok(const rdpn6d_conv_desc* d)
+{
+    return d && rdpn6d_conv_h2_kernel_for(d) == 2 && d->Npad == 256 && d->N == 256;
+}
+extern "C" int rdpn6d_conv2d_h2_fuse1x1(const rdpn6d_conv_desc* d, const void* res_h2, int* overflow_flag, const float* crop_bias,
+                                        const void* w1_h2, const float* scale1, const float* bias1, float* out, int out_cs, int n_out,
+                                        void* stream)
+{
+    RD_REQUIRE(d && w1_h2 && scale1 && bias1 && out, "null pointer");
+    RD_REQUIRE(rdpn6d_conv_h2_fuse1x1_ok(d), "fused 1x1 output convolution: needs the 256x256 kernel with N == Npad == 256");
+    RD_REQUIRE(n_out >= 1 && n_out <= out_cs && out_cs <= 64 && out_cs % 8 == 0, "n_out <= out_cs <= 64, out_cs % 8 == 0");
+    RD_REQUIRE(d->y == nullptr, "the fused form does not write the activation (desc.y must be null)");
+    const H2Fuse f = {w1_h2, scale1, bias1, out, out_cs, n_out};
+    return conv2d_h2_impl(d, nullptr, res_h2, overflow_flag, crop_bias, nullptr, 0, &f, stream);
+}
+
+static int conv2d_h2_impl(const rdpn6d_conv_desc* d, void* y_h2, const void* res_h2, int* overflow_flag, const float* crop_bias,
+                          void* workspace, long long workspace_bytes, const H2Fuse* fuse, void* stream)
+{
+    RD_REQUIRE(d && d->x && d->w && (d->y || y_h2 || fuse), "null pointer");
     const int which = rdpn6d_conv_h2_kernel_for(d);
     RD_REQUIRE(which != 0, "h2 needs Cin, in_cs, in_co % 32 == 0, N % 8 == 0, Npad % 64 == 0, 16-byte aligned output slices");
     RD_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0 && d->ntaps >= 1 && d->ntaps <= 9, "shape");
@@ -929,6 +1080,12 @@ extern "C" int rdpn6d_conv2d_h2_ws(const rdpn6d_conv_desc* d, void* y_h2, const 
     ax.overflow_flag = overflow_flag;
     ax.crop_bias = crop_bias;
     ax.partial = nullptr;
+    ax.fuse_w = fuse ? fuse->w : nullptr;
+    ax.fuse_scale = fuse ? fuse->scale : nullptr;
+    ax.fuse_bias = fuse ? fuse->bias : nullptr;
+    ax.fuse_out = fuse ? fuse->out : nullptr;
+    ax.fuse_cs = fuse ? fuse->cs : 0;
+    ax.fuse_n = fuse ? fuse->n : 0;
     ax.nsplit = 1;
     ax.mpad = 0;
     a.dy_pack = a.dx_pack = 0;
@@ -981,6 +1138,12 @@ extern "C" int rdpn6d_conv2d_h2_ws(const rdpn6d_conv_desc* d, void* y_h2, const 
     }
     a.mtiles = rd_cdiv(a.M, 256);
     a.ntiles = d->Npad / 256;
+    if (fuse) {
+        RD_LDS_OPT_IN(conv_h2_8ph_kernel_t<true>, LDS_8PH_FUSED);
+        hipLaunchKernelGGL(conv_h2_8ph_kernel_t<true>, dim3((unsigned)(a.mtiles * a.ntiles)), dim3(512), LDS_8PH_FUSED, s, ax);
+        RD_LAUNCH_CHECK();
+        return RDPN6D_OK;
+    }
     RD_LDS_OPT_IN(conv_h2_8ph_kernel, LDS_8PH);
 #ifdef RDPN6D_PROBE
     if (const char* e = getenv("RDPN6D_H2_ABL_A")) ax.nsplit = 100 + atoi(e);

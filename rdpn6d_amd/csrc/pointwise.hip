@@ -290,7 +290,9 @@ __device__ __forceinline__ float wave_sum(float v)
 #define GN_THREADS 1024  // one workgroup per sample: 1024 lanes keep a single crop (per-image inference) short
 // H2 = false: in place on the fp32 tensor.  H2 = true: x stays as it is, the result goes out as an h2 tensor [B*HW][C/32][hi x 32 | lo x 32]
 // fp16 holding 16 * value (conv_igemm_h2.hip) - the input format of the next ConvPnPNet layer on the fp16 matrix pipe.
-template <bool H2>
+// RES: the thread's pixels (at most RES of them) stay in REGISTERS between the three passes - one read of the tensor instead of three;
+// the sums are formed in the same order as the re-reading form (RES = 0, any map size), so both give identical bits.
+template <bool H2, int RES>
 __global__ __launch_bounds__(GN_THREADS) void groupnorm4_relu_kernel(float* __restrict__ x, int HW, int C,
                                                                     const float* __restrict__ gamma,
                                                                     const float* __restrict__ beta, _Float16* __restrict__ y_h2,
@@ -307,35 +309,67 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm4_relu_kernel(float* __re
     float* base = x + (long long)blockIdx.x * HW * C + ((int)blockIdx.y * G + g) * 4;
     gamma += (int)blockIdx.y * G * 4;
     beta += (int)blockIdx.y * G * 4;
-    float s = 0.f;
-    for (int p = pl; p < HW; p += PL) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(base + (long long)p * C);
-        s += (v[0] + v[1]) + (v[2] + v[3]);
+    f32x4 keep[RES > 0 ? RES : 1];
+    if constexpr (RES > 0) {
+#pragma unroll
+        for (int j = 0; j < RES; ++j) {
+            const int p = pl + j * PL;
+            keep[j] = p < HW ? *reinterpret_cast<const f32x4*>(base + (long long)p * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     }
-    s_part[threadIdx.x] = s;
+    float s = 0.f;
+    if constexpr (RES > 0) {
+#pragma unroll
+        for (int j = 0; j < RES; ++j)
+            if (pl + j * PL < HW) s += (keep[j][0] + keep[j][1]) + (keep[j][2] + keep[j][3]);
+    } else {
+        for (int p = pl; p < HW; p += PL) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(base + (long long)p * C);
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+    }
+    // block sum per group in a FIXED order: lanes of a wave that share a group (G <= 32 divides 64: lane % G) by xor-shuffles, then the
+    // sixteen wave partials by one thread per group (a serial walk over all PL partials was 128 dependent LDS reads - 4.5 us per phase
+    // with the whole workgroup waiting)
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    for (int o = 32; o >= G; o >>= 1) s += __shfl_xor(s, o);
+    if (ln < G) s_part[wv * G + ln] = s;
     __syncthreads();
     if (threadIdx.x < G) {
         float t = 0.f;
-        for (int i = 0; i < PL; ++i) t += s_part[i * G + threadIdx.x];
+        for (int i = 0; i < GN_THREADS / 64; ++i) t += s_part[i * G + threadIdx.x];
         s_mean[threadIdx.x] = t / (float)(HW * 4);
     }
     __syncthreads();
     const float mean = s_mean[g];
     float q = 0.f;
-    for (int p = pl; p < HW; p += PL) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(base + (long long)p * C);
+    if constexpr (RES > 0) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float dlt = v[e] - mean;
-            q += dlt * dlt;
+        for (int j = 0; j < RES; ++j)
+            if (pl + j * PL < HW) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float dlt = keep[j][e] - mean;
+                    q += dlt * dlt;
+                }
+            }
+    } else {
+        for (int p = pl; p < HW; p += PL) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(base + (long long)p * C);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float dlt = v[e] - mean;
+                q += dlt * dlt;
+            }
         }
     }
+    for (int o = 32; o >= G; o >>= 1) q += __shfl_xor(q, o);
     __syncthreads();
-    s_part[threadIdx.x] = q;
+    if (ln < G) s_part[wv * G + ln] = q;
     __syncthreads();
     if (threadIdx.x < G) {
         float t = 0.f;
-        for (int i = 0; i < PL; ++i) t += s_part[i * G + threadIdx.x];
+        for (int i = 0; i < GN_THREADS / 64; ++i) t += s_part[i * G + threadIdx.x];
         s_rstd[threadIdx.x] = 1.0f / sqrtf(t / (float)(HW * 4) + 1e-5f);
     }
     __syncthreads();
@@ -343,8 +377,7 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm4_relu_kernel(float* __re
     const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + g * 4);
     const f32x4 be = *reinterpret_cast<const f32x4*>(beta + g * 4);
     bool over = false;
-    for (int p = pl; p < HW; p += PL) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(base + (long long)p * C);
+    auto emit = [&](const int p, f32x4 v) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float o = (v[e] - mean) * rstd * ga[e] + be[e];
@@ -362,14 +395,36 @@ __global__ __launch_bounds__(GN_THREADS) void groupnorm4_relu_kernel(float* __re
                 lo[e] = (_Float16)(sc - (float)hi[e]);
             }
             const int c = ((int)blockIdx.y * G + g) * 4;
-            _Float16* q = y_h2 + ((long long)blockIdx.x * HW + p) * (2 * (long long)C) + (c >> 5) * 64 + (c & 31);
-            *reinterpret_cast<f16x4*>(q) = hi;
-            *reinterpret_cast<f16x4*>(q + 32) = lo;
+            _Float16* qq = y_h2 + ((long long)blockIdx.x * HW + p) * (2 * (long long)C) + (c >> 5) * 64 + (c & 31);
+            *reinterpret_cast<f16x4*>(qq) = hi;
+            *reinterpret_cast<f16x4*>(qq + 32) = lo;
         } else {
             *reinterpret_cast<f32x4*>(base + (long long)p * C) = v;
         }
+    };
+    if constexpr (RES > 0) {
+#pragma unroll
+        for (int j = 0; j < RES; ++j)
+            if (pl + j * PL < HW) emit(pl + j * PL, keep[j]);
+    } else {
+        for (int p = pl; p < HW; p += PL) emit(p, *reinterpret_cast<const f32x4*>(base + (long long)p * C));
     }
     if (H2 && over && overflow_flag) *overflow_flag = 1;
+}
+
+template <bool H2>
+static void gn_launch(float* x, int B, int HW, int C, int G, const float* gamma, const float* beta, _Float16* y_h2, int* flag, hipStream_t s)
+{
+    const int parts = (G % 4 == 0 && HW >= 256) ? 4 : 1;  // (small maps: one workgroup per crop is already short)
+    const int per_thread = (HW + GN_THREADS / (G / parts) - 1) / (GN_THREADS / (G / parts));  // pixels a thread owns
+    if (per_thread <= 2)
+        hipLaunchKernelGGL((groupnorm4_relu_kernel<H2, 2>), dim3(B, parts), dim3(GN_THREADS), 0, s, x, HW, C, gamma, beta, y_h2, flag);
+    else if (per_thread <= 8)
+        hipLaunchKernelGGL((groupnorm4_relu_kernel<H2, 8>), dim3(B, parts), dim3(GN_THREADS), 0, s, x, HW, C, gamma, beta, y_h2, flag);
+    else if (per_thread <= 16)
+        hipLaunchKernelGGL((groupnorm4_relu_kernel<H2, 16>), dim3(B, parts), dim3(GN_THREADS), 0, s, x, HW, C, gamma, beta, y_h2, flag);
+    else
+        hipLaunchKernelGGL((groupnorm4_relu_kernel<H2, 0>), dim3(B, parts), dim3(GN_THREADS), 0, s, x, HW, C, gamma, beta, y_h2, flag);
 }
 
 extern "C" int rdpn6d_groupnorm_relu_f32(float* x, int B, int HW, int C, int G, const float* gamma, const float* beta,
@@ -377,9 +432,7 @@ extern "C" int rdpn6d_groupnorm_relu_f32(float* x, int B, int HW, int C, int G, 
 {
     RD_REQUIRE(x && gamma && beta && B > 0 && HW > 0, "null/shape");
     RD_REQUIRE(C == 4 * G && G <= 64 && 256 % G == 0, "only C/G == 4 with G | 256 is implemented (GroupNorm(32,128))");
-    const int parts = (G % 4 == 0 && HW >= 256) ? 4 : 1;  // (small maps: one workgroup per crop is already short)
-    hipLaunchKernelGGL(groupnorm4_relu_kernel<false>, dim3(B, parts), dim3(GN_THREADS), 0, (hipStream_t)stream, x, HW, C, gamma, beta,
-                       (_Float16*)nullptr, (int*)nullptr);
+    gn_launch<false>(x, B, HW, C, G, gamma, beta, nullptr, nullptr, (hipStream_t)stream);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
 }
@@ -389,9 +442,7 @@ extern "C" int rdpn6d_groupnorm_relu_h2(const float* x, int B, int HW, int C, in
 {
     RD_REQUIRE(x && gamma && beta && y_h2 && B > 0 && HW > 0, "null/shape");
     RD_REQUIRE(C == 4 * G && G <= 64 && 256 % G == 0 && C % 32 == 0, "only C/G == 4 with G | 256 and C % 32 == 0 is implemented (GroupNorm(32,128))");
-    const int parts = (G % 4 == 0 && HW >= 256) ? 4 : 1;
-    hipLaunchKernelGGL(groupnorm4_relu_kernel<true>, dim3(B, parts), dim3(GN_THREADS), 0, (hipStream_t)stream, const_cast<float*>(x), HW, C,
-                       gamma, beta, (_Float16*)y_h2, overflow_flag);
+    gn_launch<true>(const_cast<float*>(x), B, HW, C, G, gamma, beta, (_Float16*)y_h2, overflow_flag, (hipStream_t)stream);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
 }
@@ -492,7 +543,14 @@ __global__ __launch_bounds__(256) void dense_glue_kernel(const float* __restrict
     for (int c = 0; c < 5; ++c) row[3 + c] = cd[(long long)c * HW];
     row[8] = an[0]; row[9] = an[1]; row[10] = an[2];
     if constexpr (H2) {
-        _Float16* qh = reinterpret_cast<_Float16*>(pnp_in) + i * (2 * (long long)pnp_cs);
+        // The row (pnp_cs x 4 bytes per pixel) is STAGED through LDS and leaves the workgroup as one contiguous block of 256 rows in 16-byte
+        // pieces, consecutive lanes on consecutive addresses: a thread writing its own 256-byte row put every store instruction of a wave
+        // on 64 different rows (the kernel ran 71 us against 38 for the fp32 row).  LDS row stride = row bytes + 8: 8-byte accesses, two
+        // lanes per bank.  (The host launches this variant only when B * HW is a multiple of 256: no partial workgroup.)
+        extern __shared__ __attribute__((aligned(16))) unsigned char glue_smem[];
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        const int rowb = pnp_cs * 4, rows = rowb + 8;
+        unsigned char* mine = glue_smem + (size_t)threadIdx.x * rows;
         bool over = false;
 #pragma unroll
         for (int c8 = 0; c8 < (11 + KMAX + 31) / 32 * 4; ++c8) {  // groups of 8 channels; whole 32-channel groups (zero padded)
@@ -508,18 +566,29 @@ __global__ __launch_bounds__(256) void dense_glue_kernel(const float* __restrict
                 }
                 rd_h8 hi, lo;
                 over |= rd_h2_split8(sv, hi, lo);
-                _Float16* dst = qh + (c8 >> 2) * 64 + (c8 & 3) * 8;
-                *reinterpret_cast<rd_h8*>(dst) = hi;
-                *reinterpret_cast<rd_h8*>(dst + 32) = lo;
+                unsigned char* dst = mine + (c8 >> 2) * 128 + (c8 & 3) * 16;
+                *reinterpret_cast<f16x4*>(dst) = f16x4{hi[0], hi[1], hi[2], hi[3]};
+                *reinterpret_cast<f16x4*>(dst + 8) = f16x4{hi[4], hi[5], hi[6], hi[7]};
+                *reinterpret_cast<f16x4*>(dst + 64) = f16x4{lo[0], lo[1], lo[2], lo[3]};
+                *reinterpret_cast<f16x4*>(dst + 72) = f16x4{lo[4], lo[5], lo[6], lo[7]};
             }
         }
-        const rd_h8 z = {};
-        for (int c = (11 + KMAX + 31) / 32 * 32; c < pnp_cs; c += 8) {
-            _Float16* dst = qh + (c >> 5) * 64 + (c & 31);
-            *reinterpret_cast<rd_h8*>(dst) = z;
-            *reinterpret_cast<rd_h8*>(dst + 32) = z;
+        const f16x4 z = {};
+        for (int c = (11 + KMAX + 31) / 32 * 32; c < pnp_cs; c += 4) {
+            unsigned char* dst = mine + (c >> 5) * 128 + (c & 31) * 2;
+            *reinterpret_cast<f16x4*>(dst) = z;
+            *reinterpret_cast<f16x4*>(dst + 64) = z;
         }
         if (over && overflow_flag) *overflow_flag = 1;
+        __syncthreads();
+        unsigned char* gout = reinterpret_cast<unsigned char*>(pnp_in) + (size_t)blockIdx.x * 256 * rowb;
+        const int ppr = rowb / 16, pieces = 256 * ppr;  // 16-byte pieces per row / per workgroup
+        for (int q = threadIdx.x; q < pieces; q += 256) {
+            const int px = q / ppr, j = q - px * ppr;
+            const unsigned char* src = glue_smem + (size_t)px * rows + j * 16;
+            const f16x4 a0 = *reinterpret_cast<const f16x4*>(src), a1 = *reinterpret_cast<const f16x4*>(src + 8);
+            *reinterpret_cast<rd_h8*>(gout + (size_t)q * 16) = rd_h8{a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        }
         return;
     }
     float* q = pnp_in + i * pnp_cs;
@@ -579,13 +648,20 @@ extern "C" int rdpn6d_dense_glue_h2(const float* head, int head_cs, const float*
         hipLaunchKernelGGL(mask_minmax_kernel, dim3(B), dim3(256), 0, s, head, head_cs, HW, minmax_scratch);
         RD_LAUNCH_CHECK();
     }
-    const unsigned blocks = (unsigned)(((long long)B * HW + 255) / 256);
-    if (K <= 32)
-        hipLaunchKernelGGL((dense_glue_kernel<32, true>), dim3(blocks), dim3(256), 0, s, head, head_cs, coord2d, fps, B, HW, K, mask_attention,
+    RD_REQUIRE(((long long)B * HW) % 256 == 0, "the h2 glue kernel stages whole workgroups of 256 pixels: B * HW % 256 == 0");
+    const unsigned blocks = (unsigned)(((long long)B * HW) / 256);
+    const size_t smem = (size_t)256 * (pnp_cs * 4 + 8);
+    if (K <= 32) {
+        auto kern = dense_glue_kernel<32, true>;
+        RD_LDS_OPT_IN(kern, 160 * 1024);
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), smem, s, head, head_cs, coord2d, fps, B, HW, K, mask_attention,
                            minmax_scratch, out_nchw, reinterpret_cast<float*>(pnp_in_h2), pnp_cs, argmax_out, overflow_flag);
-    else
-        hipLaunchKernelGGL((dense_glue_kernel<64, true>), dim3(blocks), dim3(256), 0, s, head, head_cs, coord2d, fps, B, HW, K, mask_attention,
+    } else {
+        auto kern = dense_glue_kernel<64, true>;
+        RD_LDS_OPT_IN(kern, 160 * 1024);
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), smem, s, head, head_cs, coord2d, fps, B, HW, K, mask_attention,
                            minmax_scratch, out_nchw, reinterpret_cast<float*>(pnp_in_h2), pnp_cs, argmax_out, overflow_flag);
+    }
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
 }

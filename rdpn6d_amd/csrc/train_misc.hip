@@ -620,6 +620,11 @@ __global__ __launch_bounds__(256) void mask_attention_extrema_bwd_kernel(const f
             if (s_mn[k] < vmn || (s_mn[k] == vmn && s_imn[k] < imn)) { vmn = s_mn[k]; imn = s_imn[k]; }
             if (s_mx[k] > vmx || (s_mx[k] == vmx && s_imx[k] < imx)) { vmx = s_mx[k]; imx = s_imx[k]; }
         }
+        // (a crop whose mask channel is all NaN - a diverged fp16 run - never passes `m < vmn`: the indices are still the sentinels.  The
+        // gradient is NaN either way, but it must not be written 2^31 rows past the tensor: round 4's bench pre-heat ran such a run into a
+        // GPU memory fault)
+        if ((unsigned)imn >= (unsigned)HW) imn = 0;
+        if ((unsigned)imx >= (unsigned)HW) imx = 0;
         dhead[((long long)b * HW + imn) * head_cs] += a;
         dhead[((long long)b * HW + imx) * head_cs] += c;
     }

@@ -480,7 +480,7 @@ class InferencePlan:
         return cur
 
     def conv_x3(self, name, xp, xshape, w32, scale, shift, y, yp, yshape, *, cin, in_cs, k=1, stride=1, pad=0, N, out_cs, act=0,
-                slope=0.0, taps=None, phase=None, res_planes=None, res_cs=0, crop_bias=None):
+                slope=0.0, taps=None, phase=None, res_planes=None, res_cs=0, crop_bias=None, fuse=None):
         """bf16x3 convolution: xp = input planes [3, >= B*H*W*in_cs]; y fp32 output or None; yp output planes or None;
         res_planes = the residual as planes (output geometry, res_cs channels per pixel)."""
         if self.fast == "h2":
@@ -509,6 +509,14 @@ class InferencePlan:
         assert w32.shape[1] == d.ntaps and w32.shape[2] == cin, name
         self.keep += [wp, scale, shift]
         self.x3_launches += 1
+        if self.fast == "h2" and fuse is not None:
+            # fuse = (w1 h2 records, scale1, bias1, out fp32, out_cs, n_out): the 1x1 output convolution in this launch's epilogue
+            w1, s1, b1, out, ocs, nout = fuse
+            assert y is None and yp is None and self.lib.rdpn6d_conv_h2_fuse1x1_ok(ctypes.byref(d)), name
+            self.keep += [w1, s1, b1]
+            self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_h2_fuse1x1, (ctypes.byref(d), _ptr(res_planes), _ptr(self.h2_flag), _ptr(crop_bias),
+                                                                                    _ptr(w1), _ptr(s1), _ptr(b1), _ptr(out), ocs, nout), keep=(d,)))
+            return
         if self.fast == "h2":
             assert self.lib.rdpn6d_conv_h2_kernel_for(ctypes.byref(d)), name
             ws_bytes = int(self.lib.rdpn6d_conv_h2_workspace_bytes(ctypes.byref(d)))
@@ -827,11 +835,32 @@ class InferencePlan:
         pa, pb = (pA, pB) if x3_head else (None, None)
         nfeat = len(head.features)
         convs = list(range(3, nfeat - 1, 3))
+        last = head.features[nfeat - 1]
+        nout = last.weight.shape[0]
+        assert nout == 5 + K
+        self.head_cs = _pad_to(nout, 4)
+        ho = self.buf("head_out", B, R4 * R4, self.head_cs, zero=True)  # fp32 in both modes
+        # cfg.TEST.FUSE_HEAD_OUT (default on): the 1x1 output convolution (features.21) runs in the EPILOGUE of the last 3x3 layer's
+        # 256x256 launch - the workgroup holds all 256 channels of its pixels - so that layer's 268-MB activation (B = 64) is never
+        # written and the 80-us HBM-bound 1x1 launch disappears
+        self.fused_out = False
+        fuse_ok = (h2_pw and x3_head and self.fast == "h2" and self.head_cs % 8 == 0 and self.head_cs <= 64 and F == 256
+                   and bool(model.cfg.get("TEST", {}).get("FUSE_HEAD_OUT", True)) and self.x3_ok(B * R4 * R4, F, F, 9))
         for i in convs:
             if x3_head:  # planes -> planes; the last layer writes the fp32 tensor the 1x1 output convolution reads
                 w32 = pack_conv_weight(head.features[i].weight.detach().float())
                 sch, shh = fold_bn(head.features[i + 1], npad=w32.shape[0])
                 is_last = i == convs[-1] and not h2_pw  # (h2 mode: the 1x1 output convolution reads the h2 tensor too)
+                if i == convs[-1] and fuse_ok:
+                    w1 = torch.zeros(64, 1, F, **f32)
+                    w1[:nout, 0] = last.weight.detach().float().reshape(nout, F)
+                    w1h, inv1 = pack_h2_weight(w1)
+                    b1 = _pad_vec(last.bias.detach().float(), 64, 0.0)
+                    self.conv_x3(f"rot_head.features.{i}+out", pa, (R4, R4), w32, sch, shh, None, None, (R4, R4), cin=F, in_cs=F, k=3, pad=1,
+                                 N=F, out_cs=F, act=1, fuse=(w1h, inv1.contiguous(), b1, ho, self.head_cs, nout))
+                    self.fused_out = True
+                    pa, pb = pb, pa
+                    continue
                 self.conv_x3(f"rot_head.features.{i}", pa, (R4, R4), w32, sch, shh, b if is_last else None,
                              None if is_last else pb, (R4, R4), cin=F, in_cs=F, k=3, pad=1, N=F, out_cs=F, act=1)
                 pa, pb = pb, pa
@@ -841,14 +870,11 @@ class InferencePlan:
                 self.conv(f"rot_head.features.{i}", a, (R4, R4), wh, sch, shh, b, (R4, R4), cin=F, in_cs=F, k=3, stride=1,
                           pad=1, N=F, out_cs=F, act=1, lowp=lp)
             a, b = b, a
-        last = head.features[nfeat - 1]
-        nout = last.weight.shape[0]
-        assert nout == 5 + K
-        self.head_cs = _pad_to(nout, 4)
         wl = pw(last.weight.detach().float())
         bl = _pad_vec(last.bias.detach().float(), wl.shape[0], 0.0)
-        ho = self.buf("head_out", B, R4 * R4, self.head_cs, zero=True)  # fp32 in both modes
-        if h2_pw and x3_head and self.head_cs % 8 == 0:
+        if self.fused_out:
+            pass  # (the last 3x3 launch wrote head_out)
+        elif h2_pw and x3_head and self.head_cs % 8 == 0:
             # N = head_cs (the rows past nout have zero weights and bias: the padding channels stay 0)
             self.conv_x3("rot_head.out", pa, (R4, R4), wl, None, bl, ho, None, (R4, R4), cin=F, in_cs=F, k=1, N=self.head_cs,
                          out_cs=self.head_cs, act=0)
@@ -865,7 +891,7 @@ class InferencePlan:
         # kernel's small-problem rates were the step's tail (0.3 ms of 7 at B = 64).  The intermediate activations are bounded at plan
         # time (_pnp_h2_range_ok: GroupNorm output, fc1 / fc2 rows); the input row is caller data and is range-checked by the glue kernel
         self.pnp_h2 = bool(h2_pw and x3_head and self.fast == "h2" and model.cfg.get("TEST", {}).get("PNP_H2", True)
-                           and pnp.features[0].weight.shape[0] % 32 == 0 and self._pnp_h2_range_ok(pnp, R4))
+                           and pnp.features[0].weight.shape[0] % 32 == 0 and (B * R4 * R4) % 256 == 0 and self._pnp_h2_range_ok(pnp, R4))
         self.pnp_cs = _pad_to(11 + K, 32 if self.pnp_h2 else 16)
         self.out_nchw = self.buf("out_nchw", B, nout, R4, R4)
         pnp_in = self.planes_buf("pnp_in_planes", B * HW * self.pnp_cs, 1) if self.pnp_h2 else self.buf("pnp_in", B, HW, self.pnp_cs)
@@ -1363,7 +1389,7 @@ class GDRN(_TreeWatch, nn.Module):
         tc = self.cfg.get("TEST", {})
         key = (B, str(device), bf16 or False, bool(tc.get("BF16X3", True)), bool(tc.get("FP16X2", True)), bool(tc.get("FOLD_GLOBAL_MAX", True)),
                bool(tc.get("FUSED_FRONT_LP", True)),
-               bool(tc.get("CONV_BEFORE_UPSAMPLE", True)), bool(tc.get("COMPOSE_CONV3_CONVT", True)), bool(tc.get("PNP_H2", True)))
+               bool(tc.get("CONV_BEFORE_UPSAMPLE", True)), bool(tc.get("COMPOSE_CONV3_CONVT", True)), bool(tc.get("PNP_H2", True)), bool(tc.get("FUSE_HEAD_OUT", True)))
         stamp = self._weights_stamp()
         plan = self._plans.get(key)
         if plan is not None and plan.weights_stamp != stamp:

@@ -67,6 +67,8 @@ def seeds_run(golden_dir):
             sd = {k: torch.from_numpy(np.asarray(v)) for k, v in sdn.items()}
         model.load_state_dict(sd, strict=True)
         model.eval()
+        for kv in filter(None, os.environ.get("RDPN6D_SEEDS_TEST_CFG", "").split(",")):  # A/B runs: "FUSE_HEAD_OUT=0,PNP_H2=0"
+            model.cfg.TEST[kv.split("=")[0].strip()] = bool(int(kv.split("=")[1]))
         for fast, sw in FAST.items():
             model.cfg.TEST.BF16X3, model.cfg.TEST.FP16X2 = sw["BF16X3"], sw["FP16X2"]
             with torch.no_grad():

@@ -315,3 +315,53 @@ def test_folded_global_max_plan_equals_the_concat_plan(backbone, res):
             d = (a - b).abs().max().item()
             print(f"fold vs concat {k}: max abs diff {d:.3e} (|max| {b.abs().max().item():.3f})")
             assert d <= 1e-4 * max(1.0, b.abs().max().item()), k
+
+
+@pytest.mark.parametrize("att", ["none", "mul"])
+def test_round4_plan_switches_leave_the_outputs_alone(att):
+    """cfg.TEST.FUSE_HEAD_OUT (the head's 1x1 output convolution inside the last 3x3 layer's 256x256 epilogue - that layer's activation is
+    never written) and cfg.TEST.PNP_H2 (ConvPnPNet on the fp16 matrix pipe in the h2 form, input row written by the glue kernel as an h2
+    record, plan-time range proof): the same function as the separate 1x1 launch / the fp32-MFMA ConvPnPNet - dense maps equal up to
+    fp32 summation order, poses to 1e-5 - at the batch bench.py times (B = 64) on the well-conditioned weights; and every copy of a crop
+    gives the same bits whatever its batch slot (the fused epilogue adds its four partial sums in a fixed order)."""
+    import numpy as np
+
+    from rdpn6d_amd import synth
+    from rdpn6d_amd.config import gdrn_base_cfg
+    from rdpn6d_amd.gdrn import build_model_optimizer
+
+    dev = torch.device("cuda:0")
+    B = 64
+    inp = synth.make_inputs(8, seed=5)
+    order = np.random.default_rng(3).permutation(np.repeat(np.arange(8), 8))
+    t = {k: torch.from_numpy(np.ascontiguousarray(v[order])).to(dev) for k, v in inp.items()}
+    model, _ = build_model_optimizer(gdrn_base_cfg(mask_attention=att, device="cuda"))
+    sd = synth.make_trained_like_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=1234)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    model.eval()
+    outs = {}
+    for fuse, pnph2 in ((True, True), (False, True), (True, False), (False, False)):
+        model.cfg.TEST.FUSE_HEAD_OUT, model.cfg.TEST.PNP_H2 = fuse, pnph2
+        with torch.no_grad():
+            o = model(t["roi_img"], roi_classes=t["roi_cls"], roi_coord_2d=t["roi_coord_2d"], roi_cams=t["roi_cam"], roi_centers=t["roi_center"],
+                      roi_whs=t["roi_wh"], roi_extents=t["roi_extent"], resize_ratios=t["resize_ratio"], do_loss=False, fps=t["fps"])
+        torch.cuda.synchronize()
+        plan = model.plan(B, dev)
+        assert plan.fast == "h2" and plan.fused_out == fuse and plan.pnp_h2 == pnph2 and not model.h2_range_exceeded(dev)
+        names = [L.name for L in plan.launches]
+        assert ("rot_head.out" in names) != fuse
+        outs[(fuse, pnph2)] = {k: o[k].clone() for k in ("mask", "coor_x", "coor_y", "coor_z", "region", "rot", "trans")}
+        if fuse and pnph2:  # copies of a crop: identical bits in every slot
+            for c in range(8):
+                slots = np.nonzero(order == c)[0]
+                for s in slots[1:]:
+                    for k in ("region", "coor_x", "rot", "trans"):
+                        assert torch.equal(o[k][slots[0]], o[k][s]), (c, int(s), k)
+    ref = outs[(False, False)]
+    for key, o in outs.items():
+        dm = max((o[k] - ref[k]).abs().max().item() for k in ("mask", "coor_x", "coor_y", "coor_z", "region"))
+        dr = max(((o["rot"][b] - ref["rot"][b]).norm() / ref["rot"][b].norm()).item() for b in range(B))
+        dt_ = max(((o["trans"][b] - ref["trans"][b]).norm() / ref["trans"][b].norm()).item() for b in range(B))
+        print(f"[{att}] FUSE_HEAD_OUT={key[0]} PNP_H2={key[1]} vs both off: maps {dm:.2e}, pose R {dr:.2e} t {dt_:.2e}")
+        assert dm <= 2e-5 and dr <= 2e-5 and dt_ <= 2e-5, key
+    assert torch.equal(outs[(True, True)]["region"], outs[(True, False)]["region"])  # (the maps do not depend on ConvPnPNet's form)

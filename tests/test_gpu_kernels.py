@@ -1114,7 +1114,8 @@ def test_fp32_plan_fast_forms_match_the_fp32_mfma_path(golden_setup, truth, dev)
             # output convolution in its format: no fp32 copies / split passes in between; + the one-pixel convolution of the folded
             # global-max half of the ConvTranspose input (cfg.TEST.FOLD_GLOBAL_MAX)
             # ... + ConvPnPNet's three convolutions and three FC layers (cfg.TEST.PNP_H2)
-            assert plan.x3_launches == {"h2": 6 + 35 + 4 + 4 + 1 + 1 + 6, "x3": 6 + 35, "none": 0}[mode] and plan.x3_trunk == (mode != "none")
+            # (the 1x1 output convolution rides in the last 3x3 layer's epilogue when that layer runs on the 256x256 kernel: one launch less)
+            assert plan.x3_launches == {"h2": 6 + 35 + 4 + 4 + 1 + 1 + 6 - int(plan.fused_out), "x3": 6 + 35, "none": 0}[mode] and plan.x3_trunk == (mode != "none")
             assert plan.h2_pointwise == (mode == "h2")
             o = _run(model, t16)
             assert not plan.range_exceeded(wait=True)

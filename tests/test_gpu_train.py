@@ -958,3 +958,26 @@ def test_training_step_is_deterministic(B, amp):
         assert r[0] == runs[0][0]
         for (n, _), g0, g1 in zip(model.named_parameters(), runs[0][1], r[1]):
             assert torch.equal(g0, g1), n
+
+
+def test_non_finite_head_output_does_not_fault_the_glue_backward():
+    """round 4: a diverged run (fp16 overflow un-skipped -> NaN weights -> NaN head output) drove `mask_attention_extrema_bwd_kernel` to
+    write at its sentinel arg-min / arg-max index (2^31 rows past the tensor): a GPU memory fault that killed the process.  NaN in must
+    give NaN out, never an out-of-bounds access."""
+    import ctypes
+
+    from rdpn6d_amd import _lib
+    from rdpn6d_amd.gdrn import _ptr
+
+    dev = torch.device("cuda:0")
+    B, HW, K, hcs, pcs = 2, 4096, 32, 48, 48
+    head = torch.full((B, HW, hcs), float("nan"), device=dev)
+    coord2d, fps = torch.rand(B, 5, HW, device=dev), torch.rand(B, K, 3, device=dev)
+    argmax = torch.zeros(B, HW, dtype=torch.int32, device=dev)
+    dpnp, dhead, datt = torch.rand(B, HW, pcs, device=dev), torch.zeros(B, HW, hcs, device=dev), torch.zeros(B, HW, device=dev)
+    minmax = torch.full((B, 2), float("nan"), device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(_lib.load().rdpn6d_dense_glue_backward_f32(_ptr(head), hcs, _ptr(coord2d), _ptr(fps), _ptr(argmax), _ptr(dpnp), pcs, B, HW, K, 1,
+                                                          _ptr(minmax), _ptr(dhead), _ptr(datt), st), "glue bwd")
+    torch.cuda.synchronize()  # (the fault surfaced here)
+    assert not torch.isfinite(dhead[:, 0, 0]).any()

@@ -1,0 +1,8 @@
+#!/bin/bash
+O=gpurun_out/r4_g; mkdir -p $O
+timeout 300 python -m pytest tests/test_gpu_h2.py -m gpu -q -s -k "layer1_kernel" > $O/c64.log 2>&1; tail -12 $O/c64.log | cut -c1-300
+timeout 600 python tools/debug/c5_nan_probe.py 400 > $O/c5_nan.log 2>&1; tail -25 $O/c5_nan.log | cut -c1-200
+timeout 300 python -m pytest tests/test_gpu_c1w.py tests/test_gpu_c1w_seeds.py -m gpu -q -k "bare or seeds" > $O/parity.log 2>&1; tail -5 $O/parity.log
+timeout 300 python bench.py --steps 20 --no-cpu-baseline > $O/bench.json 2> $O/bench.err; cut -c1-200 $O/bench.json
+timeout 300 python bench.py --steps 20 --no-cpu-baseline --test-cfg C64_KERNEL=0 > $O/bench_noc64.json 2>> $O/bench.err; cut -c1-200 $O/bench_noc64.json
+bash tools/debug/run_timeline.sh r4_g/tl 700 > /dev/null 2>&1; grep -n "stem_pool" -A12 gpurun_out/r4_g/tl/timeline.txt | tail -14

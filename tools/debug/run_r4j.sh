@@ -1,0 +1,7 @@
+#!/bin/bash
+O=gpurun_out/r4_j; mkdir -p $O
+timeout 300 python -m pytest tests/test_gpu_h2.py -m gpu -q -s -k "layer1_kernel" > $O/c64.log 2>&1; tail -7 $O/c64.log | cut -c1-300
+timeout 300 python bench.py --steps 20 --no-cpu-baseline > $O/bench.json 2> $O/bench.err; cut -c1-200 $O/bench.json
+timeout 300 python bench.py --steps 20 --no-cpu-baseline --test-cfg C64_KERNEL=0 > $O/bench_noc64.json 2>> $O/bench.err; cut -c1-200 $O/bench_noc64.json
+bash tools/debug/run_timeline.sh r4_j/tl 700 > /dev/null 2>&1; grep -n "stem_pool" -A8 gpurun_out/r4_j/tl/timeline.txt | tail -10; grep -n "dense_glue" -A8 gpurun_out/r4_j/tl/timeline.txt | tail -10
+timeout 900 python tools/debug/c5_nan_probe.py 400 full 200 > $O/c5_nan.log 2>&1; tail -4 $O/c5_nan.log | cut -c1-200; cat gpurun_out/c5_last_launch.txt
