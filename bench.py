@@ -125,7 +125,7 @@ def roofline(model, t, B, device, reps=3):
     extra = {}
     if tile in ("h2", "h2tile"):
         # fp32-accurate products as three fp16 partial products: the ceiling for ALGORITHMIC flops is the fp16 pipe / 3
-        kname, peak = ("conv_h2_8ph_kernel" if tile == "h2" else "conv_h2_tile_kernel"), round(BF16_MFMA_PEAK_TFLOPS / 3.0, 1)
+        kname, peak = ("conv_h2_8ph_kernel_t<false>" if tile == "h2" else "conv_h2_tile_kernel"), round(BF16_MFMA_PEAK_TFLOPS / 3.0, 1)
         extra = {"peak_note": "2500 TFLOP/s dense fp16 MFMA / 3 partial products per fp32 product (157.3 on the fp32 MFMA pipe)",
                  "mfma_tflops_issued": round(3.0 * achieved, 1)}
     elif tile in ("x3", "x3tile"):

