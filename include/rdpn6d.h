@@ -168,9 +168,6 @@ int rdpn6d_conv2d_h2_ws(const rdpn6d_conv_desc* d, void* y_h2, const void* res_h
  * (rows >= n_out zero); scale1 / bias1: 64 floats; out fp32 [pixels][out_cs], out_cs % 8 == 0, n_out <= out_cs <= 64; desc.y must be
  * NULL.  Needs the 256x256 kernel with one tile across N: rdpn6d_conv_h2_fuse1x1_ok(desc) != 0. */
 int rdpn6d_conv_h2_fuse1x1_ok(const rdpn6d_conv_desc* d);
-/* Kernel / tile selection of the h2 convolutions counts tiles against the whole chip; a caller that keeps TWO launches in flight (two
- * half-batch pipelines on two streams) declares it (2) and every launch is sized for its half of the CUs.  Process-wide; 1 = default. */
-int rdpn6d_conv_h2_set_chip_share(int launches_in_flight);
 int rdpn6d_conv2d_h2_fuse1x1(const rdpn6d_conv_desc* d, const void* res_h2, int* overflow_flag, const float* crop_bias,
                              const void* w1_h2, const float* scale1, const float* bias1, float* out, int out_cs, int n_out,
                              void* stream);

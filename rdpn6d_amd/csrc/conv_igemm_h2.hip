@@ -905,28 +905,14 @@ bool h2_big_ok(const rdpn6d_conv_desc* d)
     const int nk = d->ntaps * (d->Cin / 32);
     return h2_common_ok(d) && d->Npad % 256 == 0 && d->N == d->Npad && nk >= 2 && (nk & 1) == 0;
 }
-// Kernel / tile selection counts tiles against the WHOLE chip.  A plan that runs its batch as two half-batch pipelines on two streams
-// (gdrn.py: cfg.TEST.PIPELINE_HALVES) has two launches in flight, each on about half of the CUs: it declares that share and the
-// selection sees the row count the chip as a whole is working on.
-static int g_h2_share = 1;
-extern "C" int rdpn6d_conv_h2_set_chip_share(int launches_in_flight)
-{
-    RD_REQUIRE(launches_in_flight == 1 || launches_in_flight == 2, "h2 kernel selection: 1 or 2 concurrent launches");
-    g_h2_share = launches_in_flight;
-    return RDPN6D_OK;
-}
-static inline long long sel_rows(long long M) { return M * g_h2_share; }
-
 bool h2_big_pays(const rdpn6d_conv_desc* d, long long M)
 {
-    M = sel_rows(M);
     const long long tiles = (long long)rd_cdiv(M, 256) * (d->Npad / 256);
     const long long rounds = (tiles + 255) / 256;
     return tiles >= 160 && (double)tiles >= 0.62 * 256.0 * (double)rounds;
 }
 void h2_pick_tile(const rdpn6d_conv_desc* d, long long M, int* pbm, int* pbn)
 {
-    M = sel_rows(M);
     int bn = (d->Npad % 128 == 0) ? 128 : 64;
     int bm = 128;
     if ((long long)rd_cdiv(M, 128) * (d->Npad / bn) < 512) bm = 64;
@@ -966,7 +952,6 @@ static int h2_pp_plan(const rdpn6d_conv_desc* d, long long M, int* pbm, int* pbn
     static const int on = getenv("RDPN6D_H2_PP") ? atoi(getenv("RDPN6D_H2_PP")) : 1;
     static const int force = getenv("RDPN6D_H2_PP_SHAPE") ? atoi(getenv("RDPN6D_H2_PP_SHAPE")) : -1;  // profiling: 0 | 2
     if (!on || d->Npad % 128 != 0 || d->ntaps * (d->Cin / 32) < 8) return -1;
-    M = sel_rows(M);
     int shape = 0;
     if ((long long)rd_cdiv(M, 256) * (d->Npad / 128) >= 224 && (long long)rd_cdiv(M, 128) * (d->Npad / 128) > 288) shape = 2;
     if (force == 0 || force == 2) shape = force;
@@ -982,7 +967,7 @@ static int h2_pp_plan(const rdpn6d_conv_desc* d, long long M, int* pbm, int* pbn
 static int h2_tile_ksplit(const rdpn6d_conv_desc* d, long long M, int bm, int bn)
 {
     static const int off = getenv("RDPN6D_H2_NO_SPLITK") ? 1 : 0;  // profiling
-    const long long tiles = (long long)rd_cdiv(sel_rows(M), bm) * (d->Npad / bn);
+    const long long tiles = (long long)rd_cdiv(M, bm) * (d->Npad / bn);
     static const int tmax = getenv("RDPN6D_H2_SPLIT_TILES") ? atoi(getenv("RDPN6D_H2_SPLIT_TILES")) : 128;  // profiling
     if (off || tiles >= tmax) return 0;
     const int nk = d->ntaps * (d->Cin / 32);
