@@ -373,6 +373,15 @@ int rdpn6d_wgrad_bf16_strided(const void* A, int a_cs, int a_co, int Ca, int Ca_
                               int Cb_ld, int Bn, int Ha, int Wa, int Hb, int Wb, int stride, int ntaps, const int* dy,
                               const int* dx, float* out, long long sa, long long st, long long sb, int Ca_out, int Cb_out,
                               float* partial, void* stream);
+/* G (1..16) weight gradients of ONE geometry - the same-shaped k x k convolutions of a ResNet stage - in one launch and one reduce:
+ * the chip is filled by the problems' tiles instead of by K-splits of each.  A_list / B_list / out_list: HOST arrays of G device
+ * pointers (gradient w.r.t. the output, input activation, OIHW gradient = the strided target of rdpn6d_wgrad_bf16_strided with
+ * st = 1, sb = ntaps); partial: at least rdpn6d_wgrad_group_scratch_floats(G, ...) floats. */
+long long rdpn6d_wgrad_group_scratch_floats(int G, int Bn, int Ha, int Wa, int Ca, int Cb, int ntaps);
+int rdpn6d_wgrad_bf16_group(int G, const void* const* A_list, int a_cs, int a_co, int Ca, int Ca_ld, const void* const* B_list, int b_cs,
+                            int b_co, int Cb, int Cb_ld, int Bn, int Ha, int Wa, int Hb, int Wb, int stride, int ntaps, const int* dy,
+                            const int* dx, float* const* out_list, long long sa, long long st, long long sb, int Ca_out, int Cb_out,
+                            float* partial, long long partial_floats, void* stream);
 /* bf16x3 form (fp32-accurate weight gradient on the bf16 matrix pipe, see rdpn6d_conv2d_bf16x3): A / Bg = plane 0 of the three
  * bf16 planes [3][a_plane_elems] / [3][b_plane_elems] of the NHWC gradient / activation (rdpn6d_split_bf16x3); Ca, Cb > 64 */
 int rdpn6d_wgrad_bf16x3_strided(const void* A, long long a_plane_elems, int a_cs, int a_co, int Ca, int Ca_ld, const void* Bg,
@@ -549,6 +558,10 @@ int rdpn6d_wgrad_fp16_strided(const void* A, int a_cs, int a_co, int Ca, int Ca_
                               int Cb_ld, int Bn, int Ha, int Wa, int Hb, int Wb, int stride, int ntaps, const int* dy,
                               const int* dx, float* out, long long sa, long long st, long long sb, int Ca_out, int Cb_out,
                               float* partial, void* stream);
+int rdpn6d_wgrad_fp16_group(int G, const void* const* A_list, int a_cs, int a_co, int Ca, int Ca_ld, const void* const* B_list, int b_cs,
+                            int b_co, int Cb, int Cb_ld, int Bn, int Ha, int Wa, int Hb, int Wb, int stride, int ntaps, const int* dy,
+                            const int* dx, float* const* out_list, long long sa, long long st, long long sb, int Ca_out, int Cb_out,
+                            float* partial, long long partial_floats, void* stream);
 int rdpn6d_bn_train_stats_fp16(const void* x, long long M, int C, int cs, int co, float eps, float momentum, float* mean,
                                float* invstd, float* running_mean, float* running_var, double* scratch, void* stream);
 int rdpn6d_bn_apply_fp16(const void* x, int xcs, int xco, const float* mean, const float* invstd, const float* gamma,

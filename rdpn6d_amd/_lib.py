@@ -96,6 +96,9 @@ SIGNATURES = {
                                       _vp, _vp]),
     "rdpn6d_wgrad_bf16_strided": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _ll, _ll, _ll,
                                        _i, _i, _vp, _vp]),
+    "rdpn6d_wgrad_group_scratch_floats": (_ll, [_i, _i, _i, _i, _i, _i, _i]),
+    "rdpn6d_wgrad_bf16_group": (_i, [_i, _vp, _i, _i, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _ll, _ll, _ll,
+                                     _i, _i, _vp, _ll, _vp]),
     "rdpn6d_wgrad_bf16x3_strided": (_i, [_vp, _ll, _i, _i, _i, _i, _vp, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp,
                                          _ll, _ll, _ll, _i, _i, _vp, _vp]),
     "rdpn6d_maxpool3x3s2_backward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),

@@ -153,7 +153,7 @@ def gdrn_base_cfg(num_regions=32, mask_attention="none", device="cuda", num_clas
                                 Z_TYPE="REL"),
             ),
         ),
-        SOLVER=dict(IMS_PER_BATCH=24, BASE_LR=1e-4, BF16X3=True, OPTIMIZER_CFG=dict(type="Ranger", lr=1e-4, weight_decay=0),
+        SOLVER=dict(IMS_PER_BATCH=24, BASE_LR=1e-4, BF16X3=True, GROUP_WGRAD=True, OPTIMIZER_CFG=dict(type="Ranger", lr=1e-4, weight_decay=0),
                     WEIGHT_DECAY=0.0, AMP=dict(ENABLED=False, DTYPE="bf16")),
         INPUT=dict(FORMAT="BGR", DZI_PAD_SCALE=1.5),
         # VIS_SCALARS / VIS_PERIOD (not reference keys): the vis/* scalars of GDRN.py:306-368 computed on the device, delivered every N steps

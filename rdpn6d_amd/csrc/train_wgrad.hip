@@ -202,6 +202,7 @@ __global__ __launch_bounds__(256, 3) void wgrad_f32_kernel(const WgradKArgs a)
 // four pixels): two reads per 8-k fragment, no ds_write, no register shuffles.  16-byte chunks of a row are
 // XOR-swizzled with the pixel index (on the DMA source address and on the read) so that the 8 row segments one
 // read cycle touches cover all 64 banks.
+#define RD_WGRAD_MAX_GROUP 16
 struct WgradBArgs {
     const unsigned short* A;
     const unsigned short* Bg;
@@ -220,6 +221,11 @@ struct WgradBArgs {
     long long rows_per_split;
     unsigned a_bytes, b_bytes;
     unsigned a_plane, b_plane;  // bf16x3 form: byte distance between the operand planes (0 otherwise)
+    // grouped form (rdpn6d_wgrad_bf16_group): ngroup problems of ONE geometry in one launch - the same-shaped convolutions of a
+    // ResNet stage.  Workgroup -> (tile, split, problem); partial = [problem][split][Ca][ntaps][Cb]; A / Bg = Ag[0] / Bgg[0]
+    int ngroup;
+    const unsigned short* Ag[RD_WGRAD_MAX_GROUP];
+    const unsigned short* Bgg[RD_WGRAD_MAX_GROUP];
 };
 
 typedef short rd_s16x4 __attribute__((ext_vector_type(4)));
@@ -248,12 +254,14 @@ __global__ __launch_bounds__(256, (PL == 1 && BA <= 128) ? 3 : 2) void wgrad_bf1
     auto Bs = [&](int st, int pl) { return wg_smem + NST * PL * (KP * ARB) + (st * PL + pl) * (KP * BRB); };
 
     const int ntile = a.atiles * a.btiles * a.ntaps;
-    const int nblk = ntile * a.nsplit;
+    const int nblk = ntile * a.nsplit * a.ngroup;
     const int bid = blockIdx.x;
     const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, kk = bid >> 3;
     const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + kk;
     const int tile = logical % ntile;
-    const int split = logical / ntile;
+    const int sg = logical / ntile;
+    const int split = sg % a.nsplit;
+    const int grp = sg / a.nsplit;
     const int at = tile % a.atiles;
     const int rest = tile / a.atiles;
     const int bt = rest % a.btiles;
@@ -264,8 +272,8 @@ __global__ __launch_bounds__(256, (PL == 1 && BA <= 128) ? 3 : 2) void wgrad_bf1
     const long long m_hi = m_lo + a.rows_per_split < a.M ? m_lo + a.rows_per_split : a.M;
     const int nchunks = m_hi > m_lo ? (int)((m_hi - m_lo + KP - 1) / KP) : 0;
 
-    const __amdgpu_buffer_rsrc_t asrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.A), 0, a.a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t bsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.Bg), 0, a.b_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t asrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.Ag[grp]), 0, a.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t bsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.Bgg[grp]), 0, a.b_bytes, 0x00020000);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -446,7 +454,7 @@ __global__ __launch_bounds__(256, (PL == 1 && BA <= 128) ? 3 : 2) void wgrad_bf1
     }
 
     const int frow = lane & 31, hi = lane >> 5;
-    float* po = a.partial + (long long)split * a.Ca * a.ntaps * a.Cb;
+    float* po = a.partial + ((long long)grp * a.nsplit + split) * a.Ca * a.ntaps * a.Cb;
 #pragma unroll
     for (int j = 0; j < TB; ++j) {
         const int bch = b0 + wb * (BB / 2) + j * 32 + frow;
@@ -546,12 +554,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_strided_kernel(const float*
 // The OIHW case of the scatter (st == 1, sb == ntaps > 1: row a of the gradient is one contiguous run of Cb_out * ntaps floats, element
 // (t, b) at b * ntaps + t): a workgroup sums a [ntaps][BC] panel of row a with the same 16-byte loads and the same fixed order, turns
 // it through LDS and writes the run with consecutive lanes on consecutive addresses (the strided form writes 4-byte pieces 36 bytes apart).
+struct WgradGroupOut {
+    float* outs[RD_WGRAD_MAX_GROUP];  // problem blockIdx.z of a grouped launch writes outs[blockIdx.z]; outs[0] == nullptr: o.out
+};
 template <int BC>
-__global__ __launch_bounds__(256) void splitk_reduce_oihw_kernel(const float* __restrict__ partial, int S, int Ca, int ntaps, int Cb, WgradOut o)
+__global__ __launch_bounds__(256) void splitk_reduce_oihw_kernel(const float* __restrict__ partial, int S, int Ca, int ntaps, int Cb, WgradOut o,
+                                                                 const WgradGroupOut go)
 {
     __shared__ float s_v[9][BC + 1];
     const int a = blockIdx.y, b0 = blockIdx.x * BC;
     const long long n = (long long)Ca * ntaps * Cb;
+    if (go.outs[0]) {
+        partial += (long long)blockIdx.z * S * n;
+        o.out = go.outs[blockIdx.z];
+    }
     const int nb = Cb - b0 < BC ? Cb - b0 : BC;  // multiple of 4
     const int nb4 = nb >> 2;
     for (int task = threadIdx.x; task < ntaps * nb4; task += 256) {
@@ -579,13 +595,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_oihw_kernel(const float* __
     }
 }
 
-static void wgrad_reduce(const float* partial, int S, int Ca, int ntaps, int Cb, float* out, const WgradOut* o, hipStream_t s)
+static bool wgrad_reduce_is_oihw(const WgradOut* o, int Ca, int ntaps, int Cb)
 {
-    if (o && o->st == 1 && o->sb == ntaps && ntaps > 1 && ntaps <= 9 && Cb % 4 == 0 && o->Ca_out <= Ca) {
+    return o && o->st == 1 && o->sb == ntaps && ntaps > 1 && ntaps <= 9 && Cb % 4 == 0 && o->Ca_out <= Ca;
+}
+static void wgrad_reduce(const float* partial, int S, int Ca, int ntaps, int Cb, float* out, const WgradOut* o, hipStream_t s,
+                         const WgradGroupOut* go = nullptr, int G = 1)
+{
+    if (wgrad_reduce_is_oihw(o, Ca, ntaps, Cb)) {
+        WgradGroupOut g;
+        if (go) g = *go;
+        else g.outs[0] = nullptr;
         if (Cb >= 128)
-            hipLaunchKernelGGL(splitk_reduce_oihw_kernel<128>, dim3((Cb + 127) / 128, o->Ca_out), dim3(256), 0, s, partial, S, Ca, ntaps, Cb, *o);
+            hipLaunchKernelGGL(splitk_reduce_oihw_kernel<128>, dim3((Cb + 127) / 128, o->Ca_out, G), dim3(256), 0, s, partial, S, Ca, ntaps, Cb, *o, g);
         else
-            hipLaunchKernelGGL(splitk_reduce_oihw_kernel<64>, dim3((Cb + 63) / 64, o->Ca_out), dim3(256), 0, s, partial, S, Ca, ntaps, Cb, *o);
+            hipLaunchKernelGGL(splitk_reduce_oihw_kernel<64>, dim3((Cb + 63) / 64, o->Ca_out, G), dim3(256), 0, s, partial, S, Ca, ntaps, Cb, *o, g);
         return;
     }
     const long long n = (long long)Ca * ntaps * Cb;
@@ -710,7 +734,8 @@ static int wgrad_bf16_launch(const WgradBArgs& a, dim3 grid, hipStream_t s)
 static int wgrad_bf16_impl(const void* A, int a_cs, int a_co, int Ca, int Ca_ld, const void* Bg, int b_cs, int b_co, int Cb,
                            int Cb_ld, int Bn, int Ha, int Wa, int Hb, int Wb, int stride, int ntaps, const int* dy, const int* dx,
                            float* out, const WgradOut* so, float* partial, void* stream, long long a_plane_elems = 0,
-                           long long b_plane_elems = 0)
+                           long long b_plane_elems = 0, int G = 1, const void* const* A_list = nullptr, const void* const* B_list = nullptr,
+                           float* const* out_list = nullptr, long long partial_floats = 0)
 {
     RD_REQUIRE(A && Bg && out && partial && dy && dx, "null pointer");
     RD_REQUIRE(Bn > 0 && Ha > 0 && Wa > 0 && Hb > 0 && Wb > 0 && stride >= 1, "shape");
@@ -721,6 +746,14 @@ static int wgrad_bf16_impl(const void* A, int a_cs, int a_co, int Ca, int Ca_ld,
     RD_REQUIRE(ntaps >= 1 && ntaps <= 9, "ntaps in 1..9");
     WgradBArgs a;
     a.A = (const unsigned short*)A; a.Bg = (const unsigned short*)Bg; a.partial = partial;
+    a.ngroup = G;
+    WgradGroupOut gout;
+    gout.outs[0] = nullptr;
+    for (int g = 0; g < RD_WGRAD_MAX_GROUP; ++g) {
+        a.Ag[g] = (const unsigned short*)(G > 1 && g < G ? A_list[g] : A);
+        a.Bgg[g] = (const unsigned short*)(G > 1 && g < G ? B_list[g] : Bg);
+        if (G > 1) gout.outs[g] = g < G ? out_list[g] : out_list[0];
+    }
     a.M = (long long)Bn * Ha * Wa;
     RD_REQUIRE(a.M < (1LL << 31), "pixel count must fit 31 bits");
     a.Ha = Ha; a.Wa = Wa; a.HaWa = Ha * Wa; a.Hb = Hb; a.Wb = Wb; a.stride = stride; a.ntaps = ntaps;
@@ -747,14 +780,15 @@ static int wgrad_bf16_impl(const void* A, int a_cs, int a_co, int Ca, int Ca_ld,
     a.atiles = (Ca + ba - 1) / ba;
     a.btiles = (Cb + bb - 1) / bb;
     int tiles = a.atiles * a.btiles * ntaps;
-    int S = wgrad_pick_splits(a.M, tiles, ba, bb);  // same split count (and scratch size) as the fp32 form
+    // (grouped: the split count that fills the chip with ALL the problems' tiles - a fraction of what each problem alone would take)
+    int S = wgrad_pick_splits(a.M, tiles * G, ba, bb);  // same split count (and scratch size) as the fp32 form
     // 256 x 128 tile (2x2 waves of 128 x 64, one k16 step per chunk) for the wide layers with many pixels - the head's 256 -> 256 and
     // the ConvTranspose: a quarter fewer bytes through LDS-DMA per FLOP (the launch moves ~2.4 GB L2 -> LDS, > 10 TB/s), 12 transpose
     // reads per 8 MFMAs instead of 8 per 4, half the partial tiles: head layer at B = 32 247 -> 228 us, 1x1 512 -> 256 at 32^2 46 -> 42;
     // with few pixels (layer3 / layer4: 8 192 / 2 048) the halved workgroup count costs more (43 -> 47 us).  Never more splits than
     // the scratch was sized for.
     static const bool wide_off = getenv("RDPN6D_WGRAD_WIDE") && atoi(getenv("RDPN6D_WGRAD_WIDE")) == 0;  // profiling
-    if (!x3 && !wide_off && Ca % 256 == 0 && bb == 128 && a.M >= 32768) {
+    if (!x3 && !wide_off && G == 1 && Ca % 256 == 0 && bb == 128 && a.M >= 32768) {
         const int t2 = (Ca / 256) * a.btiles * ntaps;
         // the FEWEST splits that fill whole rounds of the 512 resident workgroups to >= 97 % (every split costs one partial tile
         // written and read again by the reduce: 2.4 MB for a head layer), else the best fill
@@ -775,7 +809,11 @@ static int wgrad_bf16_impl(const void* A, int a_cs, int a_co, int Ca, int Ca_ld,
     a.rows_per_split = ((a.M + S - 1) / S + 31) / 32 * 32;
     hipStream_t s = (hipStream_t)stream;
     a.nsplit = S;
-    dim3 grid(tiles * S);
+    if (G > 1) {
+        RD_REQUIRE(wgrad_reduce_is_oihw(so, Ca, ntaps, Cb), "grouped weight gradient: OIHW targets of a k x k convolution (k > 1)");
+        RD_REQUIRE((long long)G * S * Ca * ntaps * Cb <= partial_floats, "grouped weight gradient: scratch too small (rdpn6d_wgrad_group_scratch_floats)");
+    }
+    dim3 grid(tiles * S * G);
     int rc;
     if (x3) rc = wgrad_bf16_launch<128, 128, 3>(a, grid, s);
     else if (ba == 256) rc = wgrad_bf16_launch<256, 128, 1, 1>(a, grid, s);  // (two k16 steps per chunk spill: 269 vs 228 us)
@@ -785,9 +823,36 @@ static int wgrad_bf16_impl(const void* A, int a_cs, int a_co, int Ca, int Ca_ld,
     else rc = wgrad_bf16_launch<64, 64, 1>(a, grid, s);
     if (rc != RDPN6D_OK) return rc;
     RD_LAUNCH_CHECK();
-    wgrad_reduce(partial, S, Ca, ntaps, Cb, out, so, s);
+    wgrad_reduce(partial, S, Ca, ntaps, Cb, out, so, s, G > 1 ? &gout : nullptr, G);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
+}
+
+// G weight gradients of ONE geometry (the same-shaped 3x3 convolutions of a ResNet stage) in one launch + one reduce: the chip is
+// filled by the problems' tiles instead of by K-splits of each (layer3 at B = 32: 36 tiles x 14 splits per convolution -> 396 tiles
+// x 7 splits for eleven), i.e. longer K loops, a fraction of the partial-sum traffic and two launches instead of 2 G.
+// A_list / B_list / out_list: HOST arrays of G device pointers (gradient w.r.t. the output, input activation, OIHW gradient).
+extern "C" long long rdpn6d_wgrad_group_scratch_floats(int G, int Bn, int Ha, int Wa, int Ca, int Cb, int ntaps)
+{
+    const int ba = Ca > 64 ? 128 : 64, bb = Cb > 64 ? 128 : 64;
+    const int tiles = ((Ca + ba - 1) / ba) * ((Cb + bb - 1) / bb) * ntaps;
+    return (long long)G * wgrad_pick_splits((long long)Bn * Ha * Wa, tiles * G, ba, bb) * Ca * ntaps * Cb;
+}
+
+extern "C" int rdpn6d_wgrad_bf16_group(int G, const void* const* A_list, int a_cs, int a_co, int Ca, int Ca_ld, const void* const* B_list,
+                                       int b_cs, int b_co, int Cb, int Cb_ld, int Bn, int Ha, int Wa, int Hb, int Wb, int stride, int ntaps,
+                                       const int* dy, const int* dx, float* const* out_list, long long sa, long long st, long long sb,
+                                       int Ca_out, int Cb_out, float* partial, long long partial_floats, void* stream)
+{
+    RD_REQUIRE(G >= 1 && G <= RD_WGRAD_MAX_GROUP && A_list && B_list && out_list, "grouped weight gradient: 1..16 problems");
+    for (int g = 0; g < G; ++g) RD_REQUIRE(A_list[g] && B_list[g] && out_list[g], "grouped weight gradient: null pointer");
+    RD_REQUIRE(Ca_out > 0 && Ca_out <= Ca && Cb_out > 0 && Cb_out <= Cb, "output extents");
+    const WgradOut so = {out_list[0], sa, st, sb, Ca_out, Cb_out};
+    if (G == 1)
+        return wgrad_bf16_impl(A_list[0], a_cs, a_co, Ca, Ca_ld, B_list[0], b_cs, b_co, Cb, Cb_ld, Bn, Ha, Wa, Hb, Wb, stride, ntaps, dy, dx,
+                               out_list[0], &so, partial, stream);
+    return wgrad_bf16_impl(A_list[0], a_cs, a_co, Ca, Ca_ld, B_list[0], b_cs, b_co, Cb, Cb_ld, Bn, Ha, Wa, Hb, Wb, stride, ntaps, dy, dx,
+                           out_list[0], &so, partial, stream, 0, 0, G, A_list, B_list, out_list, partial_floats);
 }
 
 extern "C" int rdpn6d_wgrad_bf16(const void* A, int a_cs, int a_co, int Ca, int Ca_ld, const void* Bg, int b_cs, int b_co, int Cb,

@@ -97,7 +97,14 @@ class TrainEngine:
         self.records = []
         self._scratch_d = torch.empty(512 * 1024 * 2 + 4096, dtype=torch.float64, device=device)
         self._wg_floats = 0
+        self.group_wgrad = bool(model.cfg.get("SOLVER", {}).get("GROUP_WGRAD", True)) and os.environ.get("RDPN6D_GROUP_WGRAD", "1") != "0"  # (env: profiling)
+        self._wgrad_groups = {}
         self._build()
+        for grp in self._wgrad_groups.values():
+            _, _, _, ca, _, _, _, cb, _, yhw, _, _, k, _, _ = grp["geom"]
+            if len(grp["members"]) > 1:
+                self._wg_floats = max(self._wg_floats, int(self.lib.rdpn6d_wgrad_group_scratch_floats(len(grp["members"]), B, yhw[0], yhw[1],
+                                                                                                         ca, cb, k * k)))
         if getattr(self, "_scratch_need", 0) > self._scratch_d.numel():  # (every launch reads the pointer when it runs)
             self._scratch_d = torch.empty(self._scratch_need, dtype=torch.float64, device=device)
         self._scratch_bnb = torch.empty(max(self._scratch_bnb_need, 1), dtype=torch.float64, device=device)
@@ -445,7 +452,24 @@ class TrainEngine:
                     _lib.check(csum(_ptr(dy), M, ca, out_cs, out_co, _ptr(bg), 0, _ptr(self._scratch_d), self.st()), "bias grad " + name)
                     self._grad(bias).copy_(bg[:cout])
 
-        launches.append(wgrad)
+        # The same-shaped k x k convolutions of a ResNet stage (5 .. 11 of them) take their weight gradients in ONE grouped launch
+        # (rdpn6d_wgrad_bf16_group) issued where the stage's first such convolution would have taken its own - the last of them in
+        # the backward order: every member's gradient and input activation live in their own buffers until the step ends.  One
+        # launch + one reduce instead of two per convolution, and the chip is filled by the members' tiles instead of 14 .. 23
+        # K-splits of each (cfg.SOLVER.GROUP_WGRAD, default on).
+        grouped = False
+        if (lowp and self.group_wgrad and name.startswith("layer") and k > 1 and bias is None and inv_perm is None and dyb is dy
+                and xb is x and cin_real % 4 == 0 and cout % 4 == 0):
+            geom = (name.split(".")[0], dyb_cs, dyb_co, ca, min(_pad_to(cout, 8), dyb_cs - dyb_co), xb_cs, xb_co, cb,
+                    min(_pad_to(cin_real, 8), xb_cs - xb_co), yhw, xhw, stride, k, cout, cin_real)
+            grp = self._wgrad_groups.get(geom)
+            if grp is None or len(grp["members"]) >= 16:
+                grp = self._wgrad_groups[geom] = dict(members=[], geom=geom, tdy=tdy, tdx=tdx)
+                launches.append(lambda grp=grp: self._run_wgrad_group(grp))
+            grp["members"].append((name, dyb, xb, w))
+            grouped = True
+        if not grouped:
+            launches.append(wgrad)
         if dx is not None:
             n_red = _pad_to(cout, 32 if lowp else 16)  # reduction channels of the dgrad = output channels of the forward
             cdx = _pad_to(cin_real, 64)
@@ -506,6 +530,24 @@ class TrainEngine:
                     launches.append(dlaunch("dgrad " + name, dd, wd))
         self.bwd.append(launches)
         return dy
+
+    def _run_wgrad_group(self, grp):
+        m = grp["members"]
+        _, dcs, dco, ca, ca_ld, xcs, xco, cb, cb_ld, yhw, xhw, stride, k, cout, cin = grp["geom"]
+        if len(m) == 1:
+            name, dyb, xb, w = m[0]
+            _lib.check(self.lpf("rdpn6d_wgrad_bf16_strided")(
+                _ptr(dyb), dcs, dco, ca, ca_ld, _ptr(xb), xcs, xco, cb, cb_ld, self.B, yhw[0], yhw[1], xhw[0], xhw[1], stride, k * k,
+                grp["tdy"], grp["tdx"], _ptr(self._grad(w)), cin * k * k, 1, k * k, cout, cin, _ptr(self._wg_partial), self.st()),
+                "wgrad " + name)
+            return
+        G = len(m)
+        P = ctypes.c_void_p * G
+        _lib.check(self.lpf("rdpn6d_wgrad_bf16_group")(
+            G, P(*[t[1].data_ptr() for t in m]), dcs, dco, ca, ca_ld, P(*[t[2].data_ptr() for t in m]), xcs, xco, cb, cb_ld, self.B,
+            yhw[0], yhw[1], xhw[0], xhw[1], stride, k * k, grp["tdy"], grp["tdx"], P(*[self._grad(t[3]).data_ptr() for t in m]),
+            cin * k * k, 1, k * k, cout, cin, _ptr(self._wg_partial), self._wg_partial.numel(), self.st()),
+            f"wgrad group {m[0][0]} .. {m[-1][0]}")
 
     def bn_unit(self, name, bn, x_raw, cs, co, C, M, y, ycs, yco, relu, res=None, res_cs=0, dx=None, dres=None, dy=None,
                 dy_cs=None):

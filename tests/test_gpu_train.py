@@ -550,6 +550,119 @@ def test_wgrad_bf16_vs_fp32_kernel(case):
     assert e32 < 1e-5 and e16 < 1e-5
 
 
+@pytest.mark.parametrize("t", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", [
+    # G, Bn, Ha, Hb, stride, Ca, Cb
+    (6, 4, 64, 64, 1, 64, 64),     # layer1's six convolutions (64x64 tiles)
+    (11, 4, 16, 16, 1, 256, 256),  # layer3's eleven (128x128 tiles, 2 x 2 x 9 tiles each)
+    (3, 2, 8, 8, 1, 512, 512),
+    (2, 3, 7, 14, 2, 36, 68),      # ragged channels, stride 2
+    (16, 1, 8, 8, 1, 128, 128),    # the largest group
+])
+def test_grouped_weight_gradient_equals_the_single_launches(t, case):
+    """rdpn6d_wgrad_*_group: G same-shaped problems in one launch + one reduce.  Every problem's OIHW gradient within 1e-6 of its own
+    single launch (same exact products, fp32 sums split differently over K) and of autograd in float64 on one of them; buffers of
+    the other problems untouched by construction (each problem is compared with ITS operands)."""
+    import ctypes
+    from rdpn6d_amd import _lib
+    from rdpn6d_amd.gdrn import _pad_to, _ptr
+
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    G, Bn, Ha, Hb, stride, Ca, Cb = case
+    k, dt = 3, (torch.bfloat16 if t == "bf16" else torch.float16)
+    g = torch.Generator().manual_seed(sum(case))
+    Cap, Cbp = _pad_to(Ca, 32), _pad_to(Cb, 32)
+    dys, xs = [], []
+    for _ in range(G):
+        dy = torch.zeros(Bn, Ha, Ha, Cap)
+        dy[..., :Ca] = torch.randn(Bn, Ha, Ha, Ca, generator=g)
+        x = torch.zeros(Bn, Hb, Hb, Cbp)
+        x[..., :Cb] = torch.randn(Bn, Hb, Hb, Cb, generator=g)
+        dys.append(dy.to(dev).to(dt))
+        xs.append(x.to(dev).to(dt))
+    taps = [(ky - 1, kx - 1) for ky in range(k) for kx in range(k)]
+    tdy = (ctypes.c_int * 9)(*[a for a, _ in taps])
+    tdx = (ctypes.c_int * 9)(*[b for _, b in taps])
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ca4, cb4 = _pad_to(Ca, 4), _pad_to(Cb, 4)
+    n1 = int(lib.rdpn6d_wgrad_scratch_floats(Bn, Ha, Ha, ca4, cb4, 9))
+    nG = int(lib.rdpn6d_wgrad_group_scratch_floats(G, Bn, Ha, Ha, ca4, cb4, 9))
+    scr = torch.empty(max(n1, nG), device=dev)
+    single = [torch.full((Ca, Cb, k, k), 7.0, device=dev) for _ in range(G)]
+    grouped = [torch.full((Ca, Cb, k, k), -7.0, device=dev) for _ in range(G)]
+    f1, fG = getattr(lib, f"rdpn6d_wgrad_{t}_strided"), getattr(lib, f"rdpn6d_wgrad_{t}_group")
+    for i in range(G):
+        _lib.check(f1(_ptr(dys[i]), Cap, 0, ca4, _pad_to(Ca, 8), _ptr(xs[i]), Cbp, 0, cb4, _pad_to(Cb, 8), Bn, Ha, Ha, Hb, Hb, stride, 9, tdy,
+                      tdx, _ptr(single[i]), Cb * 9, 1, 9, Ca, Cb, _ptr(scr), st))
+    P = ctypes.c_void_p * G
+    _lib.check(fG(G, P(*[d.data_ptr() for d in dys]), Cap, 0, ca4, _pad_to(Ca, 8), P(*[x.data_ptr() for x in xs]), Cbp, 0, cb4,
+                  _pad_to(Cb, 8), Bn, Ha, Ha, Hb, Hb, stride, 9, tdy, tdx, P(*[o.data_ptr() for o in grouped]), Cb * 9, 1, 9, Ca, Cb,
+                  _ptr(scr), scr.numel(), st))
+    torch.cuda.synchronize()
+    worst = 0.0
+    for i in range(G):
+        scale = single[i].abs().max().item()
+        worst = max(worst, (grouped[i] - single[i]).abs().max().item() / scale)
+    # float64 autograd on the last problem
+    xt = xs[-1][..., :Cb].permute(0, 3, 1, 2).double().cpu()
+    w = torch.zeros(Ca, Cb, k, k, dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv2d(xt, w, stride=stride, padding=1).backward(dys[-1][..., :Ca].permute(0, 3, 1, 2).double().cpu())
+    e64 = (grouped[-1].cpu().double() - w.grad).abs().max().item() / w.grad.abs().max().item()
+    print(f"{t} {case}: grouped vs single launches {worst:.2e}, grouped vs float64 autograd {e64:.2e}")
+    assert worst < 2e-6 and e64 < 1e-5
+    # a scratch one float too small is refused
+    if nG > 1:
+        assert fG(G, P(*[d.data_ptr() for d in dys]), Cap, 0, ca4, _pad_to(Ca, 8), P(*[x.data_ptr() for x in xs]), Cbp, 0, cb4,
+                  _pad_to(Cb, 8), Bn, Ha, Ha, Hb, Hb, stride, 9, tdy, tdx, P(*[o.data_ptr() for o in grouped]), Cb * 9, 1, 9, Ca, Cb,
+                  _ptr(scr), nG - 1, st) != 0
+
+
+@pytest.mark.parametrize("amp", ["bf16", "fp16"])
+def test_training_step_with_grouped_weight_gradients_equals_the_ungrouped_step(amp):
+    """cfg.SOLVER.GROUP_WGRAD (default on): the stage-wise grouped weight-gradient launches change nothing but the order in which
+    fp32 partial sums over the pixels are added: same losses bit for bit, the grouped convolutions' gradients within 2e-6 of the
+    per-layer launches, every other gradient bit-identical.  B = 32 = the batch the benchmark runs."""
+    from rdpn6d_amd import synth
+    from rdpn6d_amd.config import gdrn_base_cfg
+    from rdpn6d_amd.gdrn import build_model_optimizer
+
+    dev = torch.device("cuda:0")
+    B = 32
+    inp = synth.make_inputs(B, seed=3)
+    res = {}
+    for on in (True, False):
+        cfg = gdrn_base_cfg(mask_attention="mul", device="cuda")
+        cfg.SOLVER.AMP.ENABLED, cfg.SOLVER.AMP.DTYPE, cfg.SOLVER.GROUP_WGRAD = True, amp, on
+        model, _ = build_model_optimizer(cfg)
+        sd = synth.make_trained_like_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=5)
+        model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+        batch = {k: torch.from_numpy(v).to(dev) for k, v in {**inp, **synth.make_train_gt(B, inp)}.items()}
+        eng = model.train_engine(B, dev)
+        assert eng.group_wgrad == on
+        groups = sorted(len(g["members"]) for g in eng._wgrad_groups.values() if len(g["members"]) > 1)  # (a stage's stride-2 conv is alone)
+        assert (groups == [5, 6, 7, 11]) if on else (groups == []), groups  # ResNet-34: layer4, layer1, layer2, layer3
+        losses = eng.forward_backward(batch)
+        torch.cuda.synchronize()
+        res[on] = ([float(v.item()) for v in losses.values()] if isinstance(losses, dict) else [float(v) for v in losses],
+                   {n: p.grad.clone() for n, p in model.named_parameters()},
+                   {t[0] + ".weight" for g in eng._wgrad_groups.values() if len(g["members"]) > 1 for t in g["members"]})
+        del eng, model
+        torch.cuda.empty_cache()
+    assert res[True][0] == res[False][0]
+    grouped, worst = res[True][2], 0.0
+    assert len(grouped) == 29
+    for n, g1 in res[True][1].items():
+        g0 = res[False][1][n]
+        key = n.replace("backbone.", "", 1)
+        if any(key == m for m in grouped):
+            worst = max(worst, float((g1 - g0).abs().max() / g0.abs().max()))
+        else:
+            assert torch.equal(g0, g1), n
+    print(f"[{amp}] 29 grouped weight gradients vs their per-layer launches: worst {worst:.2e} of the tensor's largest element")
+    assert 0.0 < worst < 2e-6
+
+
 def test_maxpool_backward_first_max_rule_and_stem_im2col():
     import ctypes
     import torch.nn.functional as F
