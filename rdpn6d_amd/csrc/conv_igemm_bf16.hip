@@ -20,6 +20,8 @@
 //     bytes per FLOP.
 #include "conv_bf16_common.h"
 
+#include <cstdlib>
+
 template <int BM, int BN, int RB, int WM, int WN, int NST, bool STATS = false>
 __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_igemm_bf16_kernel(const ConvBArgs a)
 {
@@ -346,7 +348,13 @@ static int conv_bf16_launch(const ConvBArgs& a, int bm, int bn, int nsplit, hipS
     // Three LDS stages (the DMA two chunks ahead, never drained inside the loop) for the 4-wave tiles: pays where the K loop is
     // long and the tile small - 64x64 tiles of the 512-channel layers (layer4: 72 chunks; 38 -> 25 us at B = 32, 40 -> 32 at B = 64) -
     // and loses occupancy (96 KiB for a 128x128 tile: one workgroup per CU instead of two) everywhere else (measured, B = 32 / 64)
-    const int nst = g_bforce_nst ? g_bforce_nst : ((bm == 64 && bn == 64 && a.kper >= 64) ? 3 : 2);
+    // Round 4: those measurements re-launched one problem on hot caches.  Inside a step every operand is cold (the working set of a
+    // training step is GBs; weights are touched once per step): behind a 512-MB fill the two-stage loop, whose __syncthreads drains the
+    // DMA queue every chunk, exposes the HBM miss of EVERY chunk - layer3 at B = 32 (36 chunks): 17.5 us hot, 30.8 us cold = what the
+    // step's kernel trace shows - and three stages hide most of it (18.1 / 23.0 us); 128x128 40.3 -> 29.1, 64x128 35.6 -> 22.7.  Short
+    // loops (layer1 / layer2: 9 / 18 chunks) stay on two stages (cold: 26.0 vs 28.7 us, 22.4 vs 26.2).  RDPN6D_CONV_LP_NST3_K: threshold.
+    static const int k3 = getenv("RDPN6D_CONV_LP_NST3_K") ? atoi(getenv("RDPN6D_CONV_LP_NST3_K")) : 24;  // profiling
+    const int nst = g_bforce_nst ? g_bforce_nst : ((a.kper >= 64 && bm == 64 && bn == 64) || a.kper >= k3 ? 3 : 2);
     if (nst == 3) {
         if (bm == 128 && bn == 128) return conv_bf16_launch_one<128, 128, RB, 2, 2, 3>(a, nsplit, s);
         if (bm == 128 && bn == 64) return conv_bf16_launch_one<128, 64, RB, 2, 2, 3>(a, nsplit, s);

@@ -65,8 +65,30 @@ def bench(name, H, Cin, Cout, k, stride, tiles=None, reps=20):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     fl = 2.0 * B * Ho * Ho * Cout * k * k * Cin
+    extra = ""
+    if os.environ.get("STATS") and Cout % 64 == 0:  # the training forward's instantiation: the epilogue also writes BatchNorm partial sums
+        d.scale = d.shift = None
+        d.act = 0
+        stats = torch.empty(((B * Ho * Ho + 63) // 64) * 2 * Cout * 2 + 1024, device=dev, dtype=torch.float64)
+        rows = ctypes.c_int()
+        for _ in range(3): _lib.check(lib.rdpn6d_conv2d_bf16_bnstats(ctypes.byref(d), _ptr(stats), 0, ctypes.byref(rows), st))
+        e0.record()
+        for _ in range(reps): lib.rdpn6d_conv2d_bf16_bnstats(ctypes.byref(d), _ptr(stats), 0, ctypes.byref(rows), st)
+        e1.record(); torch.cuda.synchronize()
+        extra = f"   with BatchNorm partial sums: {e0.elapsed_time(e1) / reps * 1e3:7.1f} us ({rows.value} rows)"
+    if os.environ.get("FLUSH"):  # every launch behind a fill of FLUSH MB (cold L2s; 512: cold Infinity Cache too), timed one by one
+        junk = torch.empty(int(os.environ["FLUSH"]) << 20, device=dev, dtype=torch.uint8)
+        tot = 0.0
+        for i in range(10):
+            junk.fill_(i)
+            e0.record()
+            lib.rdpn6d_conv2d_bf16(ctypes.byref(d), 0, st)
+            e1.record(); torch.cuda.synchronize()
+            tot += e0.elapsed_time(e1)
+        extra += f"   behind a {os.environ['FLUSH']}-MB fill: {tot / 10 * 1e3:7.1f} us"
+        del junk
     lib.rdpn6d_conv_bf16_force_tile(0, 0)
-    print(f"{name:34s} tile {bm.value:3d}x{bn.value:3d} {ms*1e3:9.1f} us  {fl/ms/1e9:7.1f} TF/s  ({fl/ms/1e9/2500*100:5.1f}% of bf16 MFMA peak)")
+    print(f"{name:34s} tile {bm.value:3d}x{bn.value:3d} {ms*1e3:9.1f} us  {fl/ms/1e9:7.1f} TF/s  ({fl/ms/1e9/2500*100:5.1f}% of bf16 MFMA peak){extra}")
 if os.environ.get("NST"): lib.rdpn6d_conv_bf16_force_stages(int(os.environ["NST"]))  # profiling: LDS stages of the 4-wave tiles
 for s in SHAPES: check(*s)
 for s in SHAPES: bench(*s)
