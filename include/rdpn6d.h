@@ -45,6 +45,13 @@ int rdpn6d_fps_host(const float* pts, int* idxs, int pn, int sn, int start);
  * d_idxs [nobj, sn]; d_mindist = scratch of d_offsets[nobj] floats.                      */
 int rdpn6d_fps_device(const float* d_pts, const int* d_offsets, int nobj, int max_pn, int sn, int start,
                       int* d_idxs, float* d_mindist, void* stream);
+/* The same with a workspace of rdpn6d_fps_workspace_bytes(nobj) bytes: a cloud of 16 385 .. 262 144 points is sampled by
+ * ceil(max_pn / 16 384) workgroups (points and minimum distances in registers, one cross-workgroup barrier per sample) instead of one
+ * workgroup streaming it from L2; same indices bit for bit.  workspace[obj] = {int barrier counter, int error, ...}: error != 0 after
+ * the launch = a barrier timed out (indices -1). */
+long long rdpn6d_fps_workspace_bytes(int nobj);
+int rdpn6d_fps_device_ws(const float* d_pts, const int* d_offsets, int nobj, int max_pn, int sn, int start, int* d_idxs,
+                         float* d_mindist, void* workspace, long long workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------ implicit-GEMM convolution
  * One kernel family serves every conv / transposed-conv phase / FC layer of

@@ -36,6 +36,8 @@ SIGNATURES = {
     "farthest_point_sampling_init_center": (None, [_vp, _vp, _i, _i]),
     "rdpn6d_fps_host": (_i, [_vp, _vp, _i, _i, _i]),
     "rdpn6d_fps_device": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "rdpn6d_fps_workspace_bytes": (_ll, [_i]),
+    "rdpn6d_fps_device_ws": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _ll, _vp]),
     "rdpn6d_conv2d_f32": (_i, [ctypes.POINTER(ConvDesc), _vp]),
     "rdpn6d_conv_tile_for": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp]),
     "rdpn6d_conv_force_tile": (None, [_i, _i]),

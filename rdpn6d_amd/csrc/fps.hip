@@ -183,6 +183,175 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_kernel(const float* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Clouds of more than 16 384 points: the single-workgroup kernel streams them from L2 every iteration (one CU's bandwidth).  This form
+// gives a cloud G = ceil(pn / 16 384) <= 16 workgroups, each with ITS slice of the points and their running minimum distance in
+// registers; an iteration is a local arg-max, one 64-bit record (value bits << 32 | index) per workgroup in a double-buffered slot
+// array, a counter barrier across the cloud's workgroups (agent-scope atomics; a monotonic counter, never reset) and the same
+// (value desc, index asc) merge of the G records by every workgroup - the indices are those of the single-workgroup kernel, bit for
+// bit.  All G workgroups of every cloud must be resident at once (the launcher keeps G * clouds <= 128 on the 256 CUs); a barrier that
+// does not complete within ~10 ms raises the error word in the workspace instead of hanging the device.
+struct FpsMultiWs {
+    int counter, error, pad[2];
+    unsigned long long slot[2][16];
+    int bbox[16][8];  // float bits: max xyz, min xyz
+};
+
+__device__ __forceinline__ void fps_grid_sync(FpsMultiWs* ws, const int target, bool& dead)
+{
+    __syncthreads();
+    if (threadIdx.x == 0 && !dead) {
+        __hip_atomic_fetch_add(&ws->counter, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while (__hip_atomic_load(&ws->counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1 << 18) || __hip_atomic_load(&ws->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(&ws->error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    if (__hip_atomic_load(&ws->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) dead = true;
+}
+
+__global__ __launch_bounds__(FPS_THREADS) void fps_multi_kernel(const float* __restrict__ pts_all, const int* __restrict__ offsets, int sn,
+                                                                int start, int* __restrict__ idxs_all, FpsMultiWs* __restrict__ ws_all)
+{
+    constexpr int PPT = 16;
+    __shared__ float s_v[17];
+    __shared__ int s_i[17];
+    __shared__ float s_red[6][16];
+    const int obj = blockIdx.y, g = blockIdx.x, G = gridDim.x;
+    const int p0 = offsets[obj], pn = offsets[obj + 1] - p0;
+    const float* pts = pts_all + (long long)p0 * 3;
+    int* idxs = idxs_all + (long long)obj * sn;
+    FpsMultiWs* ws = ws_all + obj;
+    const int tid = threadIdx.x;
+    if (pn <= 0) return;  // (every workgroup of the cloud)
+    const int base = g * PPT * FPS_THREADS;
+    bool dead = false;
+    int phase = 0;
+
+    float rx[PPT], ry[PPT], rz[PPT], rmd[PPT];
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int i = base + tid + j * FPS_THREADS;
+        const bool ok = i < pn;
+        rx[j] = ok ? pts[(long long)i * 3 + 0] : 0.f;
+        ry[j] = ok ? pts[(long long)i * 3 + 1] : 0.f;
+        rz[j] = ok ? pts[(long long)i * 3 + 2] : 0.f;
+        rmd[j] = ok ? FLT_MAX : -1.f;
+    }
+    // the cloud-wide winner of this workgroup's (bv, bi): publish, barrier, merge
+    auto merge = [&](float bv, int bi) -> int {
+        const int w = fps_block_argmax(bv, bi, s_v, s_i);  // (returns the index; the value is s_v-reduced in wave 0: recompute below)
+        // the winning VALUE of this workgroup: every thread knows the index; the owner publishes
+        if (tid == 0) s_v[16] = 0.f;
+        __syncthreads();
+        if (bi == w && bv > 0.f) s_v[16] = bv;  // exactly one thread holds index w as its candidate when any value is > 0
+        __syncthreads();
+        const int buf = phase & 1;
+        if (tid == 0) {
+            const unsigned long long rec = ((unsigned long long)__float_as_uint(s_v[16]) << 32) | (unsigned)w;
+            __hip_atomic_store(&ws->slot[buf][g], rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        ++phase;
+        fps_grid_sync(ws, G * phase, dead);
+        if (tid == 0) {
+            float v = 0.f;
+            int idx = INT_MAX;
+            for (int q = 0; q < G; ++q) {
+                const unsigned long long r = __hip_atomic_load(&ws->slot[buf][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float ov = __uint_as_float((unsigned)(r >> 32));
+                const int oi = (int)(unsigned)r;
+                if (ov > v || (ov == v && ov > 0.f && oi < idx)) { v = ov; idx = oi; }
+            }
+            s_i[16] = (idx == INT_MAX || dead) ? 0 : idx;
+        }
+        __syncthreads();
+        return s_i[16];
+    };
+
+    int cur;
+    if (start < 0) {
+        float mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX}, mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
+#pragma unroll
+        for (int j = 0; j < PPT; ++j)
+            if (base + tid + j * FPS_THREADS < pn) {
+                mx[0] = fmaxf(mx[0], rx[j]); mx[1] = fmaxf(mx[1], ry[j]); mx[2] = fmaxf(mx[2], rz[j]);
+                mn[0] = fminf(mn[0], rx[j]); mn[1] = fminf(mn[1], ry[j]); mn[2] = fminf(mn[2], rz[j]);
+            }
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o));
+                mn[c] = fminf(mn[c], __shfl_xor(mn[c], o));
+            }
+        if ((tid & 63) == 0)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { s_red[c][tid >> 6] = mx[c]; s_red[3 + c][tid >> 6] = mn[c]; }
+        __syncthreads();
+        if (tid < 6) {
+            float a = s_red[tid][0];
+            for (int w = 1; w < FPS_THREADS / 64; ++w) a = tid < 3 ? fmaxf(a, s_red[tid][w]) : fminf(a, s_red[tid][w]);
+            __hip_atomic_store(&ws->bbox[g][tid], (int)__float_as_uint(a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        ++phase;
+        fps_grid_sync(ws, G * phase, dead);
+        if (tid < 6) {
+            float a = tid < 3 ? -FLT_MAX : FLT_MAX;
+            for (int q = 0; q < G; ++q) {
+                const float b = __uint_as_float((unsigned)__hip_atomic_load(&ws->bbox[q][tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                a = tid < 3 ? fmaxf(a, b) : fminf(a, b);
+            }
+            s_red[tid][0] = a;
+        }
+        __syncthreads();
+        float ctr[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) ctr[c] = __fmul_rn(__fadd_rn(s_red[c][0], s_red[3 + c][0]), 0.5f);
+        float bv = 0.f;
+        int bi = INT_MAX;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j)
+            if (base + tid + j * FPS_THREADS < pn) {
+                const float dd = fps_sqdist(rx[j], ry[j], rz[j], ctr[0], ctr[1], ctr[2]);
+                rmd[j] = fminf(dd, FLT_MAX);
+                if (rmd[j] > bv) { bv = rmd[j]; bi = base + tid + j * FPS_THREADS; }
+            }
+        cur = merge(bv, bi);
+    } else {
+        cur = start % pn;
+    }
+
+    for (int it = 0; it < sn; ++it) {
+        if (tid == 0 && g == 0) idxs[it] = dead ? -1 : cur;
+        if (it == sn - 1) break;
+        const float cx = pts[(long long)cur * 3 + 0], cy = pts[(long long)cur * 3 + 1], cz = pts[(long long)cur * 3 + 2];
+        float bv = 0.f;
+        int bi = INT_MAX;
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const int i = base + tid + j * FPS_THREADS;
+            if (i == cur) rmd[j] = -1.f;
+            const float dd = fps_sqdist(rx[j], ry[j], rz[j], cx, cy, cz);
+            if (dd < rmd[j]) rmd[j] = dd;
+            if (rmd[j] > bv) { bv = rmd[j]; bi = i; }
+        }
+        cur = merge(bv, bi);
+    }
+}
+
+__global__ void fps_multi_init_kernel(FpsMultiWs* ws, int nobj)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nobj) { ws[i].counter = 0; ws[i].error = 0; }
+}
+
+extern "C" long long rdpn6d_fps_workspace_bytes(int nobj) { return (long long)(nobj > 0 ? nobj : 0) * (long long)sizeof(FpsMultiWs); }
+
 extern "C" int rdpn6d_fps_device(const float* d_pts, const int* d_offsets, int nobj, int max_pn, int sn, int start,
                                  int* d_idxs, float* d_mindist, void* stream)
 {
@@ -199,29 +368,59 @@ extern "C" int rdpn6d_fps_device(const float* d_pts, const int* d_offsets, int n
     return RDPN6D_OK;
 }
 
+// with a workspace of rdpn6d_fps_workspace_bytes(nobj) bytes: clouds of 16 385 .. 262 144 points run on ceil(max_pn / 16 384) workgroups
+// each (fps_multi_kernel above) when all of them fit the chip at once; everything else as rdpn6d_fps_device.  The first int of the
+// workspace entry [obj] is a barrier counter, the second an error word: non-zero after the launch = a barrier timed out (indices -1).
+extern "C" int rdpn6d_fps_device_ws(const float* d_pts, const int* d_offsets, int nobj, int max_pn, int sn, int start, int* d_idxs,
+                                    float* d_mindist, void* workspace, long long workspace_bytes, void* stream)
+{
+    RD_REQUIRE(d_pts && d_offsets && d_idxs && d_mindist, "null pointer");
+    RD_REQUIRE(nobj > 0 && max_pn > 0 && sn > 0, "shape");
+    static const bool off = getenv("RDPN6D_FPS_NO_MULTI") != nullptr;  // profiling
+    const int G = (max_pn + 16 * FPS_THREADS - 1) / (16 * FPS_THREADS);
+    if (off || !workspace || G < 2 || G > 16 || (long long)G * nobj > 128 || workspace_bytes < rdpn6d_fps_workspace_bytes(nobj))
+        return rdpn6d_fps_device(d_pts, d_offsets, nobj, max_pn, sn, start, d_idxs, d_mindist, stream);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(fps_multi_init_kernel, dim3((nobj + 63) / 64), dim3(64), 0, s, (FpsMultiWs*)workspace, nobj);
+    hipLaunchKernelGGL(fps_multi_kernel, dim3(G, nobj), dim3(FPS_THREADS), 0, s, d_pts, d_offsets, sn, start, d_idxs, (FpsMultiWs*)workspace);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}
+
 extern "C" int rdpn6d_fps_host(const float* pts, int* idxs, int pn, int sn, int start)
 {
     RD_REQUIRE(pts && idxs, "null pointer");
     RD_REQUIRE(pn > 0 && sn > 0, "pn and sn must be positive");
     float *d_pts = nullptr, *d_md = nullptr;
     int *d_off = nullptr, *d_idx = nullptr;
+    void* d_ws = nullptr;
     const int off[2] = {0, pn};
     int rc = RDPN6D_OK;
     hipError_t e;
     if ((e = hipMalloc(&d_pts, sizeof(float) * 3 * (size_t)pn)) != hipSuccess ||
-        (e = hipMalloc(&d_md, sizeof(float) * (size_t)pn)) != hipSuccess ||
+        (e = hipMalloc(&d_md, sizeof(float) * (size_t)pn)) != hipSuccess || (e = hipMalloc(&d_ws, sizeof(FpsMultiWs))) != hipSuccess ||
         (e = hipMalloc(&d_off, sizeof(off))) != hipSuccess || (e = hipMalloc(&d_idx, sizeof(int) * (size_t)sn)) != hipSuccess ||
         (e = hipMemcpy(d_pts, pts, sizeof(float) * 3 * (size_t)pn, hipMemcpyHostToDevice)) != hipSuccess ||
         (e = hipMemcpy(d_off, off, sizeof(off), hipMemcpyHostToDevice)) != hipSuccess) {
         rdpn6d_set_error("fps: device staging failed: %s", hipGetErrorString(e));
         rc = RDPN6D_EHIP;
     }
-    if (rc == RDPN6D_OK) rc = rdpn6d_fps_device(d_pts, d_off, 1, pn, sn, start, d_idx, d_md, nullptr);
-    if (rc == RDPN6D_OK && (e = hipMemcpy(idxs, d_idx, sizeof(int) * (size_t)sn, hipMemcpyDeviceToHost)) != hipSuccess) {
+    if (rc == RDPN6D_OK && (e = hipMemset(d_ws, 0, sizeof(FpsMultiWs))) != hipSuccess) {
+        rdpn6d_set_error("fps: workspace: %s", hipGetErrorString(e));
+        rc = RDPN6D_EHIP;
+    }
+    if (rc == RDPN6D_OK) rc = rdpn6d_fps_device_ws(d_pts, d_off, 1, pn, sn, start, d_idx, d_md, d_ws, sizeof(FpsMultiWs), nullptr);
+    int wsh[2] = {0, 0};
+    if (rc == RDPN6D_OK && ((e = hipMemcpy(idxs, d_idx, sizeof(int) * (size_t)sn, hipMemcpyDeviceToHost)) != hipSuccess ||
+                            (e = hipMemcpy(wsh, d_ws, sizeof(wsh), hipMemcpyDeviceToHost)) != hipSuccess)) {
         rdpn6d_set_error("fps: copy back failed: %s", hipGetErrorString(e));
         rc = RDPN6D_EHIP;
     }
-    (void)hipFree(d_pts); (void)hipFree(d_md); (void)hipFree(d_off); (void)hipFree(d_idx);
+    if (rc == RDPN6D_OK && wsh[1] != 0) {
+        rdpn6d_set_error("fps: a cross-workgroup barrier timed out (the cloud's workgroups were not resident together)");
+        rc = RDPN6D_EHIP;
+    }
+    (void)hipFree(d_pts); (void)hipFree(d_md); (void)hipFree(d_off); (void)hipFree(d_idx); (void)hipFree(d_ws);
     return rc;
 }
 

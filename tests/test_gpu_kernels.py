@@ -160,6 +160,34 @@ def test_fps_bit_exact(dev, oracle_lib, golden_dir):
         assert np.array_equal(idx, gold[name]), f"{name}: {idx[:8]} vs {gold[name][:8]}"
 
 
+def test_fps_many_workgroups_per_cloud_bit_identical(dev):
+    """clouds above 16 384 points: rdpn6d_fps_device_ws spreads a cloud over ceil(N / 16 384) workgroups (points in registers, one
+    cross-workgroup barrier per sample); the indices are those of the single-workgroup kernel bit for bit - a batch of three clouds of
+    different sizes (one of them a lattice full of exact distance ties), bounding-box-centre and fixed starts; no barrier timed out."""
+    from rdpn6d_amd import _lib
+    from tests.fps_cases import make_cloud
+
+    lib = _lib.load()
+    clouds = [make_cloud("gauss", 50000, 3), make_cloud("lattice", 70001, 4), make_cloud("sphere", 20000, 5)]
+    off = np.concatenate([[0], np.cumsum([len(c) for c in clouds])]).astype(np.int32)
+    pts = torch.from_numpy(np.concatenate(clouds)).to(dev)
+    d_off = torch.from_numpy(off).to(dev)
+    sn, nobj, max_pn = 48, 3, int(max(len(c) for c in clouds))
+    md = torch.empty(int(off[-1]), device=dev)
+    ws = torch.zeros(int(lib.rdpn6d_fps_workspace_bytes(nobj)), dtype=torch.uint8, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    for start in (-1, 0, 12345):
+        one = torch.full((nobj, sn), -7, dtype=torch.int32, device=dev)
+        many = torch.full((nobj, sn), -9, dtype=torch.int32, device=dev)
+        _lib.check(lib.rdpn6d_fps_device(P(pts), P(d_off), nobj, max_pn, sn, start, P(one), P(md), st))
+        _lib.check(lib.rdpn6d_fps_device_ws(P(pts), P(d_off), nobj, max_pn, sn, start, P(many), P(md), P(ws), ws.numel(), st))
+        torch.cuda.synchronize()
+        assert int(ws.view(torch.int32).view(nobj, -1)[:, 1].abs().sum()) == 0, "a cross-workgroup barrier timed out"
+        assert torch.equal(one, many), (start, one[:, :6], many[:, :6])
+        assert int(one.min()) >= 0
+
+
 def test_fps_reference_symbols(dev, oracle_lib):
     """the two reference-named void symbols (ext.h) with host pointers."""
     from rdpn6d_amd import _lib

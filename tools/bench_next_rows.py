@@ -65,8 +65,14 @@ out_bytes = B * (6 * 256 * 256 + 5 * 64 * 64) * 4
 c = np.array([0.5 * (boxes[0, 0] + boxes[0, 2]), 0.5 * (boxes[0, 1] + boxes[0, 3])])
 sc = min(max(wh[0, 0], wh[0, 1], 1) * 1.5, 640) * 1.0
 cpu = cpu_time(lambda: crop_oracle.build_roi(img[idx[0]], depth[idx[0]], cams[0], c, sc), 3.0)
+Bl = 1024
+idx_l, boxes_l, cams_l = np.tile(idx, Bl // B), np.tile(boxes, (Bl // B, 1)), np.tile(cams, (Bl // B, 1, 1))
+secl = gpu_time(lambda: build_crops(dimg, ddep, idx_l, boxes_l, cams_l), n=5)
 row("crop builder (frames + boxes -> roi_img, roi_coord_2d; incl. the host-side affine set-up)", B, "crops", sec,
-    out_bytes + B * 260 * 260 * 7, cpu, 1, "algorithmic bytes: outputs + the source window of every crop (uint8 RGB + fp32 depth)")
+    out_bytes + B * 260 * 260 * 7, cpu, 1, "algorithmic bytes: outputs + the source window of every crop (uint8 RGB + fp32 depth); 64 crops = "
+    f"136 MB in {sec * 1e6:.0f} us includes the host-side affine set-up and its small H2D copy per call; {Bl} crops in one call: "
+    f"{secl * 1e3:.3f} ms = {(Bl * (6 * 256 * 256 + 5 * 64 * 64) * 4 + Bl * 260 * 260 * 7) / secl / 1e9:.0f} GB/s = "
+    f"{(Bl * (6 * 256 * 256 + 5 * 64 * 64) * 4 + Bl * 260 * 260 * 7) / secl / 1e9 / HBM:.2f} of the HBM peak")
 
 # ---- 3. training targets: nearest anchor + residual (data_utils.py:229-244, data_loader.py:881-903)
 from oracle import targets_eval_oracle as teo  # noqa: E402
@@ -76,7 +82,13 @@ fps64 = torch.randn(Bt, K, 3, dtype=torch.float64, device=dev) * 0.05
 rot = torch.eye(3, device=dev).repeat(Bt, 1, 1)
 ext = torch.rand(Bt, 3, device=dev) * 0.2 + 0.05
 sec = gpu_time(lambda: ops.region_targets(xyz, fps64, rot, ext))
-row("training targets (region labels + residual xyz)", Bt, "crops", sec, Bt * 4096 * (12 + 12 + 8))
+Bl = 2048  # the same kernel on a batch that outlasts the launch floor
+xyzl, fpsl = torch.randn(Bl, 64, 64, 3, device=dev) * 0.05, torch.randn(Bl, K, 3, dtype=torch.float64, device=dev) * 0.05
+rotl, extl = torch.eye(3, device=dev).repeat(Bl, 1, 1), torch.rand(Bl, 3, device=dev) * 0.2 + 0.05
+secl = gpu_time(lambda: ops.region_targets(xyzl, fpsl, rotl, extl))
+row("training targets (region labels + residual xyz)", Bt, "crops", sec, Bt * 4096 * (12 + 12 + 8),
+    note=f"64 crops = 8.4 MB: a {sec * 1e6:.0f}-us launch sits on the launch floor, not on HBM; {Bl} crops in one launch: {secl * 1e3:.3f} ms = "
+    f"{Bl * 4096 * 32 / secl / 1e9:.0f} GB/s = {Bl * 4096 * 32 / secl / 1e9 / HBM:.2f} of the HBM peak")
 
 # ---- 4. ADD / ADI / re / te (lib/pysixd/pose_error.py:297-337,400-436)
 Be, n = 256, 3000
@@ -103,7 +115,19 @@ if os.path.exists(so):
     idxs = np.zeros(32, np.int32)
     P = ctypes.c_void_p
     cpu = cpu_time(lambda: ol.oracle_fps_init_center(pts_h.ctypes.data_as(P), idxs.ctypes.data_as(P), 50000, 32), 2.0)
-row("fps, host ABI (50 000 points, 32 samples, init_center; includes the copies)", 1, "clouds", sec, 50000 * 12, cpu)
+row("fps, host ABI (50 000 points, 32 samples, init_center; includes the copies)", 1, "clouds", sec, 50000 * 12, cpu,
+    note="the reference's ABI hands over host pointers: 4 hipMalloc + 2 copies + 1 launch + 1 copy per call dominate; the kernel alone is the next row")
+# device-resident: one launch, the cloud on ceil(N / 16384) workgroups (points in registers) vs one workgroup streaming it from L2
+d_pts = torch.from_numpy(pts_h).to(dev)
+d_off = torch.tensor([0, 50000], dtype=torch.int32, device=dev)
+d_idx, d_md = torch.zeros(32, dtype=torch.int32, device=dev), torch.empty(50000, device=dev)
+d_ws = torch.zeros(int(lib.rdpn6d_fps_workspace_bytes(1)), dtype=torch.uint8, device=dev)
+stf = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)  # noqa: E731
+sec1 = gpu_time(lambda: lib.rdpn6d_fps_device(_ptr(d_pts), _ptr(d_off), 1, 50000, 32, -1, _ptr(d_idx), _ptr(d_md), stf()))
+secm = gpu_time(lambda: lib.rdpn6d_fps_device_ws(_ptr(d_pts), _ptr(d_off), 1, 50000, 32, -1, _ptr(d_idx), _ptr(d_md), _ptr(d_ws), d_ws.numel(), stf()))
+row("fps, device-resident (50 000 points, 32 samples): 4 workgroups, points in registers, one barrier per sample", 1, "clouds", secm,
+    50000 * 12, note=f"one workgroup streaming the cloud from L2 every sample: {sec1 * 1e3:.3f} ms; sequential by construction (32 dependent "
+    "arg-max rounds): latency bound, bytes = the cloud once")
 
 # ---- RANSAC / Kabsch: 64 crops, 100 hypotheses each, on synthetic maps
 from tests.ransac_cases import make_case  # noqa: E402
@@ -128,7 +152,14 @@ maps_d, c5_d, ext_d = torch.from_numpy(maps_h).to(dev), torch.from_numpy(c5_h).t
 sec = gpu_time(lambda: ops.select_correspondences(maps_d, c5_d, ext_d, 480, 640))
 nm0 = select_oracle.out_mask_l1(maps_h[:1, :1])
 cpu = cpu_time(lambda: select_oracle.select_correspondences(nm0[0, 0], maps_h[0, 1:4].transpose(1, 2, 0), c5_h[0, 3:5].transpose(1, 2, 0), 480, 640, ext_h[0]), 2.0)
-row("correspondence selection A8 (mask / coordinate filter + ordered compaction)", 64, "crops", sec, 64 * 4096 * (6 * 4 + 20), cpu, 1)
+Bl = 1024
+maps_l = torch.from_numpy(np.tile(maps_h, (Bl // 64, 1, 1, 1))).to(dev)
+c5_l, ext_l = torch.from_numpy(np.tile(c5_h, (Bl // 64, 1, 1, 1))).to(dev), torch.from_numpy(np.tile(ext_h, (Bl // 64, 1))).to(dev)
+secl = gpu_time(lambda: ops.select_correspondences(maps_l, c5_l, ext_l, 480, 640))
+row("correspondence selection A8 (mask / coordinate filter + ordered compaction)", 64, "crops", sec, 64 * 4096 * (6 * 4 + 20), cpu, 1,
+    note=f"64 crops = 11.5 MB: a {sec * 1e6:.0f}-us launch (one workgroup per crop, ordered compaction = two passes + a scan) is launch / "
+    f"latency bound; {Bl} crops in one launch: {secl * 1e3:.3f} ms = {Bl * 4096 * 44 / secl / 1e9:.0f} GB/s = "
+    f"{Bl * 4096 * 44 / secl / 1e9 / HBM:.2f} of the HBM peak")
 
 # ---- A9: 2D-3D RANSAC-PnP, 64 crops x 100 hypotheses (P3P per wavefront, reprojection scoring from LDS, Gauss-Newton refit)
 from tests.pnp_cases import make_pnp_case  # noqa: E402
