@@ -3,7 +3,8 @@
 set -u
 TAG=${1:-r2_x}
 R=$(pwd); O=$R/gpurun_out/$TAG; mkdir -p $O
-if [ "${2:-}" != "notests" ]; then python -m pytest tests -m gpu -q > $O/gpu_tests.log 2>&1; tail -3 $O/gpu_tests.log; fi
+if [ "${2:-}" != "notests" ]; then python -m pytest tests -m gpu -q -rs > $O/gpu_tests.log 2>&1; tail -3 $O/gpu_tests.log
+  python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log; fi
 python bench.py > $O/bench.json 2> $O/bench.err; cut -c1-200 $O/bench.json
 python bench.py --mask-attention mul --no-cpu-baseline > $O/bench_mul.json 2>> $O/bench.err
 python bench.py --mask-attention mul --cam ycbv --no-cpu-baseline > $O/bench_c4_ycbv_mul.json 2>> $O/bench.err
@@ -20,6 +21,10 @@ python bench.py --steps 4000 --trace 200 --no-cpu-baseline > $O/bench_sustained.
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python3 $R/bench.py --no-cpu-baseline --steps 20 > /dev/null 2>&1
 cd $R; f=$(ls $O/prof/*/*kernel_stats.csv | head -1); cp $f $O/kernel_stats.csv; rm -rf $O/prof
+python3 tools/conv_stack_fraction.py $O/kernel_stats.csv > $O/conv_stack_fraction.txt; tail -1 $O/conv_stack_fraction.txt
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/proft -- python3 $R/bench.py --train --dtype bf16 --no-cpu-baseline --steps 10 --warmup 2 > /dev/null 2>&1
+cd $R; f=$(ls $O/proft/*/*kernel_stats.csv | head -1); cp $f $O/train_bf16_kernel_stats.csv; rm -rf $O/proft
 bash tools/pmc_bench.sh $TAG > $O/pmc.log 2>&1; cp gpurun_out/pmc_$TAG/summary.json $O/pmc_summary.json; cp gpurun_out/pmc_$TAG/summary.md $O/pmc_summary.md; rm -rf gpurun_out/pmc_$TAG/raw_*
 for f in bench_mul bench_c4_ycbv_mul bench_x3 bench_fp32mfma bench_bf16 bench_fp16 bench_train_bf16 bench_train_fp16 bench_train_f32 bench_train_c5_fp16 bench_sustained; do python3 -c "
 import json; d=json.load(open('$O/$f.json')); print('$f', d['value'], d['ms_per_step'], d.get('ms_per_step_trace', {}).get('drift_last_vs_first'))"; done
