@@ -7,8 +7,9 @@ python3 - "$OUT/kernel_stats.csv" <<'PY'
 import csv, sys
 rows=list(csv.DictReader(open(sys.argv[1])))
 tot=sum(int(r["TotalDurationNs"]) for r in rows)
-print("total kernel ms per step", tot/1e6/12)
-for r in rows[:36]:
+steps=next(int(r["Calls"]) for r in rows if r["Name"].startswith("ranger_update_kernel"))
+print(f"{steps} steps profiled; total kernel ms per step", tot/1e6/steps)
+for r in rows[:40]:
     n=r["Name"].replace("(anonymous namespace)::","").replace("void ","")[:74]
-    print(f'{int(r["TotalDurationNs"])/1e6/12:7.3f} ms/step {r["Percentage"]:>6}%  calls/step {int(r["Calls"])/12:6.1f} avg {float(r["AverageNs"])/1e3:8.1f} us  {n}')
+    print(f'{int(r["TotalDurationNs"])/1e6/steps:7.3f} ms/step {r["Percentage"]:>6}%  calls/step {int(r["Calls"])/steps:6.1f} avg {float(r["AverageNs"])/1e3:8.1f} us  {n}')
 PY
