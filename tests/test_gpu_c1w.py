@@ -366,7 +366,7 @@ def test_amp_step_every_layer_gradient_recomputed_from_the_stored_operands(c1w, 
     for r in eng.records:
         if r.get("dx") is not None:
             writers[r["dx"].data_ptr()] = writers.get(r["dx"].data_ptr(), 0) + 1
-    rows, drows, covered = [], [], set()
+    rows, drows, srows, covered = [], [], [], set()
 
     def rel(a, b):
         return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
@@ -425,6 +425,10 @@ def test_amp_step_every_layer_gradient_recomputed_from_the_stored_operands(c1w, 
             if r["relu"]:
                 y = r["y"][..., r["yco"]:r["yco"] + C].detach().double().cpu().reshape(-1, C)
                 g = g * (y > 0)
+            # the statistics the forward used (from the convolution epilogue's partial sums where the step fuses them) against the
+            # float64 statistics of the very tensor it stored
+            srows.append((rel(eng.bufs["mean:" + r["name"]][:C].detach().cpu(), mean), "mean " + r["name"]))
+            srows.append((rel(eng.bufs["istd:" + r["name"]][:C].detach().cpu(), istd), "invstd " + r["name"]))
             rows.append((rel(bn.weight.grad.detach().cpu(), (g * xh).sum(0)), pname[id(bn.weight)]))
             rows.append((rel(bn.bias.grad.detach().cpu(), g.sum(0)), pname[id(bn.bias)]))
             covered.update((pname[id(bn.weight)], pname[id(bn.bias)]))
@@ -437,6 +441,9 @@ def test_amp_step_every_layer_gradient_recomputed_from_the_stored_operands(c1w, 
                 drows.append((rel(r["dres"][..., :C].detach().double().cpu().reshape(-1, C), g), "bn dres " + r["name"]))
     rows.sort(reverse=True)
     drows.sort(reverse=True)
+    srows.sort(reverse=True)
+    print(f"[amp local {lp} B={B}] {len(srows)} BatchNorm batch statistics vs float64 of the stored tensor: worst " + ", ".join(f"{n} {e:.1e}" for e, n in srows[:3]))
+    assert len(srows) >= 80 and srows[0][0] <= 2e-6, srows[:3]
     print(f"[amp local {lp} B={B}] {len(rows)} parameter gradients recomputed from the stored operands: median {np.median([e for e, _ in rows]):.1e}, worst "
           + ", ".join(f"{n} {e:.1e}" for e, n in rows[:4]) + f" | {len(drows)} stored activation gradients (one rounding = {ulp / 2:.1e}): median "
           f"{np.median([e for e, _ in drows]):.1e}, worst " + ", ".join(f"{n} {e:.1e}" for e, n in drows[:3]))
