@@ -98,9 +98,9 @@ class TrainEngine:
         self._scratch_d = torch.empty(512 * 1024 * 2 + 4096, dtype=torch.float64, device=device)
         self._wg_floats = 0
         self.group_wgrad = bool(model.cfg.get("SOLVER", {}).get("GROUP_WGRAD", True)) and os.environ.get("RDPN6D_GROUP_WGRAD", "1") != "0"  # (env: profiling)
-        self._wgrad_groups = {}
+        self._wgrad_groups, self._wgrad_group_list = {}, []
         self._build()
-        for grp in self._wgrad_groups.values():
+        for grp in self._wgrad_group_list:
             _, _, _, ca, _, _, _, cb, _, yhw, _, _, k, _, _ = grp["geom"]
             if len(grp["members"]) > 1:
                 self._wg_floats = max(self._wg_floats, int(self.lib.rdpn6d_wgrad_group_scratch_floats(len(grp["members"]), B, yhw[0], yhw[1],
@@ -465,6 +465,7 @@ class TrainEngine:
             grp = self._wgrad_groups.get(geom)
             if grp is None or len(grp["members"]) >= 16:
                 grp = self._wgrad_groups[geom] = dict(members=[], geom=geom, tdy=tdy, tdx=tdx)
+                self._wgrad_group_list.append(grp)  # (a stage with more than 16 same-shaped convolutions - ResNet-101 / 152 - has several)
                 launches.append(lambda grp=grp: self._run_wgrad_group(grp))
             grp["members"].append((name, dyb, xb, w))
             grouped = True

@@ -663,6 +663,39 @@ def test_training_step_with_grouped_weight_gradients_equals_the_ungrouped_step(a
     assert 0.0 < worst < 2e-6
 
 
+def test_grouped_weight_gradients_with_more_than_sixteen_members_per_stage():
+    """ResNet-101's layer3 has 22 same-shaped 3x3 convolutions: two grouped launches (16 + 6), both sized into the shared scratch; the
+    gradients of members of BOTH groups equal the per-layer launches to 2e-6."""
+    from rdpn6d_amd import synth
+    from rdpn6d_amd.config import gdrn_base_cfg
+    from rdpn6d_amd.gdrn import build_model_optimizer
+
+    dev = torch.device("cuda:0")
+    B, R = 2, 128
+    inp = synth.make_inputs(B, seed=4, res=R)
+    res = {}
+    for on in (True, False):
+        cfg = gdrn_base_cfg(mask_attention="none", device="cuda")
+        cfg.MODEL.CDPN.BACKBONE.NUM_LAYERS = 101
+        cfg.MODEL.CDPN.BACKBONE.INPUT_RES, cfg.MODEL.CDPN.BACKBONE.OUTPUT_RES = R, R // 4
+        cfg.SOLVER.AMP.ENABLED, cfg.SOLVER.AMP.DTYPE, cfg.SOLVER.GROUP_WGRAD = True, "bf16", on
+        model, _ = build_model_optimizer(cfg)
+        sd = synth.make_trained_like_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=6)
+        model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+        batch = {k: torch.from_numpy(v).to(dev) for k, v in {**inp, **synth.make_train_gt(B, inp)}.items()}
+        eng = model.train_engine(B, dev)
+        if on:
+            sizes = sorted(len(g["members"]) for g in eng._wgrad_group_list if g["members"][0][0].startswith("layer3"))
+            assert sizes[-2:] == [6, 16], sizes
+        eng.forward_backward(batch)
+        torch.cuda.synchronize()
+        res[on] = {n: p.grad.clone() for n, p in model.named_parameters() if ".conv2.weight" in n and "layer3" in n}
+        del eng, model
+        torch.cuda.empty_cache()
+    worst = max(float((res[True][n] - res[False][n]).abs().max() / res[False][n].abs().max()) for n in res[True])
+    assert len(res[True]) == 23 and worst < 2e-6, (len(res[True]), worst)  # (at this size both forms may even split K alike: 0.0)
+
+
 def test_maxpool_backward_first_max_rule_and_stem_im2col():
     import ctypes
     import torch.nn.functional as F
