@@ -282,6 +282,37 @@ def test_oracle_on_the_eight_unsearched_seeds_and_teacher_forced_pose_branch(gol
             assert not (diff & ~tie_set(gold, s)).any()
 
 
+def test_oracle_training_losses_on_unsearched_seeds(golden_dir):
+    """tests/golden/train_c1w_seeds.npz (the REAL reference's training step on input seeds 0..7): the oracle's train-mode forward +
+    losses on two of the seeds land on the reference's nine losses (dense ones 1e-5; pose-branch ones 1e-5 when the train-mode arg-max
+    is the reference's, which the oracle reproduces outside the recorded tie set)."""
+    from tests.c1w_cases import c1w_state_dict
+
+    gold = np.load(os.path.join(golden_dir, "train_c1w_seeds.npz"))
+    bn = np.load(os.path.join(golden_dir, "bn_stats_c1w.npz"))
+    for att, s in (("none", 0), ("mul", 3)):
+        m = model_oracle.GDRNOracle(32, att)
+        sd = c1w_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, bn)
+        assert synth.sha256_of([sd[k] for k in sorted(sd) if not k.endswith("num_batches_tracked")]) == str(gold["sha256_weights"])
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+        m.train()
+        inp = synth.make_inputs(4, seed=s)
+        gt = synth.make_train_gt(4, inp)
+        assert synth.sha256_of([gt[k] for k in sorted(gt)]) == str(gold[f"s{s}_sha256_gt"])
+        t = {k: torch.from_numpy(v) for k, v in {**inp, **gt}.items()}
+        with torch.no_grad():
+            o = m(t["roi_img"], t["roi_coord_2d"], t["fps"], t["roi_cam"], t["roi_center"], t["roi_wh"], t["resize_ratio"], train_pose=True)
+            L = model_oracle.gdrn_losses(o, t, t["roi_extent"])
+        tie = (gold[f"s{s}_top2_gap"] < float(gold["tie_gap"])) | np.unpackbits(gold[f"s{s}_flip_1v8"])[: 4 * 4096].reshape(4, 64, 64).astype(bool)
+        diff = o["region_argmax"].numpy().reshape(4, 64, 64) != gold[f"s{s}_argmax"]
+        assert not (diff & ~tie).any()
+        for k, v in L.items():
+            ref = float(gold[f"s{s}_{att}_{k}"])
+            if k in ("loss_PM_R", "loss_centroid", "loss_z") and diff.any():
+                continue
+            assert abs(v.item() - ref) <= 1e-5 * max(1.0, abs(ref)), (att, s, k, v.item(), ref)
+
+
 def test_train_vis_scalars_restatement_is_pinned_by_the_references_own_event_storage_values(golden_dir):
     """tests/golden/vis_scalars_golden.npz (tools/oracle/gen_vis_golden.py): the 17 `vis/*` values the REAL reference pushed to its
     EventStorage on the training batch of the well-conditioned fixture, and the train-mode pose it computed them from.  The numpy
