@@ -285,8 +285,13 @@ def train_roofline(eng, one_step, reps=3):
         return None
     ms = [a.elapsed_time(b) for a, b in evs]
     achieved = sum(flops) / (sum(ms) * 1e-3) / 1e12
+    # HBM-side bytes per launch from the committed PMC passes of `bench.py --train --dtype bf16` (profiles/*train_bf16_pmc_summary.json:
+    # the forward instantiation <0, true> - it carries the BatchNorm sums - stands for both directions; the fp16 build has no own profile)
+    traffic, traffic_src, prof_us = pmc_traffic("conv_igemm_bf16_8ph_kernel<0, true>", bf16=True) if eng.lp == "bf16" else (None, None, None)
+    avg_us = sum(ms) / len(ms) * 1e3
     return {"bound": "mfma", "achieved": round(achieved, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch (HBM+fabric, PMC)",
+            "traffic_source": traffic_src, "traffic_stale": None if traffic is None else bool(abs(prof_us - avg_us) > 0.25 * avg_us),
             "kernel": f"conv_igemm_bf16_8ph_kernel ({eng.lp} build)", "launches_per_step": nf + nb,
             "launches_forward": nf, "launches_input_gradient": nb, "avg_launch_ms": round(sum(ms) / len(ms), 4),
             "algorithmic_gflop_per_launch": round(sum(flops) / len(flops) / 1e9, 2),

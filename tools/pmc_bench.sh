@@ -9,7 +9,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VALU_MFMA_MOPS_BF16"; do
   name=${set%% *}
-  timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/raw_$name -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 "$@" > /dev/null 2>&1
+  timeout 600 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/raw_$name -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 --preheat 0 "$@" > /dev/null 2>&1
   f=$(ls $OUT/raw_$name/*/*counter_collection.csv 2>/dev/null | head -1)
   [ -n "$f" ] && cp "$f" $OUT/${name}_counter_collection.csv
 done

@@ -19,7 +19,7 @@ for n in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES"):
 out = {}
 for k, v in agg.items():
     kk = k.replace("void ", "").replace("(anonymous namespace)::", "")
-    if not kk.startswith(("conv_igemm", "conv_x3", "conv_h2", "split_h2", "_ZN12_GLOBAL__N_1", "split_bf16x3", "stem_", "maxpool", "global_max", "upsample", "dense_glue", "groupnorm", "ransac")):
+    if not kk.startswith(("conv_igemm", "conv_x3", "conv_h2", "split_h2", "_ZN12_GLOBAL__N_1", "split_bf16x3", "stem_", "maxpool", "global_max", "upsample", "dense_glue", "groupnorm", "ransac", "wgrad", "bn_", "chan_", "conv_lp")):
         continue
     m = {c: s / n for c, (n, s, t) in v.items()}
     us = v["FETCH_SIZE"][2] / v["FETCH_SIZE"][0] / 1e3
