@@ -348,8 +348,17 @@ def train_bench(args, rank, world, device, dist):
     for _ in range(args.warmup):
         one_step()
     torch.cuda.synchronize()
+    # pre-heat: every step carries the gradient all-reduces, so all ranks must run the SAME number of steps - rank 0's clock decides
+    # and its decision is broadcast after every block (a per-rank perf_counter() exit would leave the ranks' collective sequences
+    # different: a hang)
     tp = time.perf_counter()
-    while time.perf_counter() - tp < args.preheat:
+    go = torch.ones(1, dtype=torch.int32, device=device if dist is None or dist.get_backend() == "nccl" else "cpu")
+    while True:
+        go[0] = int(time.perf_counter() - tp < args.preheat)
+        if dist is not None:
+            dist.broadcast(go, src=0)
+        if not int(go.item()):
+            break
         for _ in range(5):
             one_step()
         torch.cuda.synchronize()
@@ -364,7 +373,9 @@ def train_bench(args, rank, world, device, dist):
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
-    roof = train_roofline(eng, one_step) if (rank == 0 and amp) else None
+    # the event-timed steps carry the gradient all-reduces too: EVERY rank runs them (rank 0 alone would leave the others' collective
+    # sequence three all-reduces short - a hang); only rank 0's figures are reported
+    roof = train_roofline(eng, one_step) if amp else None
     if dist is not None:
         dist.barrier()
     if rank == 0:
@@ -373,6 +384,7 @@ def train_bench(args, rank, world, device, dist):
             "metric": f"RGB-D crops/sec, TRAINING step (fwd+losses+bwd+allreduce+Ranger) at {args.res}x{args.res}", "value": round(value, 1),
             "unit": "crops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "world": world, "backend": dist.get_backend() if dist is not None else None, "device_count": torch.cuda.device_count(),
             "dtype": f"{args.dtype} convolutions (fwd + dgrad + wgrad) and stored activations, fp32 BN math / losses / pose branch / optimizer" if amp else "f32",
             "data": "synthetic",
             "config": {"workload": ("LM-O style" if (args.backbone, args.res) == (34, 256) else "MP6D style (BASELINE C5 shape)")
@@ -432,9 +444,29 @@ def main():
                          "fp32, or mixed precision (cfg.SOLVER.AMP.ENABLED) with --dtype bf16")
     args = ap.parse_args()
 
+    # --gpus N is the number of ranks (one per GPU).  Launched bare (`python bench.py --gpus N`, no WORLD_SIZE in the environment) with
+    # N > 1 this process becomes the launcher: it starts `python -m torch.distributed.run --nproc-per-node N bench.py <same args>` as a
+    # fresh CHILD and exits with its code - before anything here has touched the GPU, and without exec (the pool forbids replacing a
+    # process that has initialised HIP).  Under a launcher WORLD_SIZE must equal --gpus: a mismatch is an error, not a silent 1-rank run.
+    if args.gpus < 1:
+        raise SystemExit(f"bench.py: --gpus {args.gpus}: need at least one rank")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        import socket
+        import subprocess
+
+        with socket.socket() as s:  # a free rendezvous port on the loop-back interface
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print(f"[bench] --gpus {args.gpus} without a launcher: starting {' '.join(cmd[1:8])} ...", file=sys.stderr)
+        raise SystemExit(subprocess.run(cmd, env={**os.environ, "MASTER_ADDR": "127.0.0.1"}).returncode)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start it bare (it launches its own ranks) or under "
+                         f"torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     ndev = torch.cuda.device_count()
@@ -534,6 +566,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": dtype_label, "data": "synthetic",
+            "world": world, "backend": dist.get_backend() if dist is not None else None, "device_count": torch.cuda.device_count(),
             "config": {"workload": ("LM 13-object" if args.cam == "lm" else "YCB-V 21-object (BASELINE C4 shape: YCB-V intrinsics)")
                                    + f" inference, batch={B} per GPU, 256x256 RGB-D crops, K=32 regions, "
                                    "ResNet-34 trunk + dense head + ConvPnPNet + pose decode + per-crop RANSAC/Kabsch (100 hyp.), all on-device",

@@ -48,7 +48,9 @@ int rdpn6d_fps_device(const float* d_pts, const int* d_offsets, int nobj, int ma
 /* The same with a workspace of rdpn6d_fps_workspace_bytes(nobj) bytes: a cloud of 16 385 .. 262 144 points is sampled by
  * ceil(max_pn / 16 384) workgroups (points and minimum distances in registers, one cross-workgroup barrier per sample) instead of one
  * workgroup streaming it from L2; same indices bit for bit.  workspace[obj] = {int barrier counter, int error, ...}: error != 0 after
- * the launch = a barrier timed out (indices -1). */
+ * the launch = a barrier timed out (indices -1).  The launch is an ordinary one (co-residency of a cloud's workgroups is likely, not
+ * guaranteed): a caller of this asynchronous entry MUST read the error word once the stream has drained and re-run the batch through
+ * rdpn6d_fps_device when it is set; rdpn6d_fps_host (and with it both reference-named symbols) does so itself. */
 long long rdpn6d_fps_workspace_bytes(int nobj);
 int rdpn6d_fps_device_ws(const float* d_pts, const int* d_offsets, int nobj, int max_pn, int sn, int start, int* d_idxs,
                          float* d_mindist, void* workspace, long long workspace_bytes, void* stream);
@@ -271,6 +273,16 @@ int rdpn6d_dense_glue_f32(const float* head, int head_cs, const float* coord2d, 
 int rdpn6d_dense_glue_h2(const float* head, int head_cs, const float* coord2d, const float* fps, int B, int HW, int K,
                          int mask_attention, float* minmax_scratch, float* out_nchw, void* pnp_in_h2, int pnp_cs,
                          int* argmax_out, int* overflow_flag, void* stream);
+/* Both with the mask read as ROT_HEAD.MASK_LOSS_TYPE prescribes (get_mask_prob, models/model_utils.py:24-42; the entry points above
+ * are mask_type 0): mask_type 0 "L1" = per-crop min-max, 1 "BCE" = sigmoid, 2 "CE" = TWO mask channels - head / out_nchw rows are then
+ * [mask0 mask1 | x y z | region bg+K] (get_xyz_mask_region_out_dim, GDRN.py:637-659) and mask_attention must be 0: the reference's own
+ * CE branch raises (torch.softmax(..., keepdim=True), model_utils.py:39). */
+int rdpn6d_dense_glue_mt_f32(const float* head, int head_cs, const float* coord2d, const float* fps, int B, int HW, int K,
+                             int mask_attention, int mask_type, float* minmax_scratch, float* out_nchw, float* pnp_in, int pnp_cs,
+                             int* argmax_out, void* stream);
+int rdpn6d_dense_glue_mt_h2(const float* head, int head_cs, const float* coord2d, const float* fps, int B, int HW, int K,
+                            int mask_attention, int mask_type, float* minmax_scratch, float* out_nchw, void* pnp_in_h2, int pnp_cs,
+                            int* argmax_out, int* overflow_flag, void* stream);
 
 /* ------------------------------------------------------------------ pose decode
  * ortho6d_to_mat_batch (core/utils/rot_reps.py:34-49) + pose_from_predictions_test
@@ -320,6 +332,13 @@ int rdpn6d_ransac_kabsch_ws(const float* out_nchw, const float* coord2d, const f
                             float mask_thr, float inlier_thr, int iters, float confidence, unsigned seed, int mode,
                             float max_t_diff, float* pose_out, int* n_inliers, unsigned char* inlier_mask, int* best_hyp,
                             void* workspace, long long workspace_bytes, void* stream);
+/* ... with the mask read as ROT_HEAD.MASK_LOSS_TYPE prescribes (engine_utils.get_out_mask): mask_type 0 L1 min-max (every other
+ * RANSAC entry point), 1 BCE sigmoid, 2 CE arg-max over two mask channels (out_nchw [B, 2 + 3 + K + 1, HW]) */
+int rdpn6d_ransac_kabsch_ws_mt(const float* out_nchw, const float* coord2d, const float* fps, const float* extents,
+                               const float* resize_ratios, const int* region_argmax, const float* net_pose, int B, int HW, int K,
+                               float mask_thr, int mask_type, float inlier_thr, int iters, float confidence, unsigned seed, int mode,
+                               float max_t_diff, float* pose_out, int* n_inliers, unsigned char* inlier_mask, int* best_hyp,
+                               void* workspace, long long workspace_bytes, void* stream);
 
 
 /* ================================================================== training step (forward with batch statistics,
@@ -507,6 +526,13 @@ int rdpn6d_select_correspondences_f32(const float* out_nchw, int C, const float*
                                       const float* extents, const int* im_hw, int im_H, int im_W, int B, int HW, float mask_thr,
                                       float* image_points, float* model_points, int* counts, unsigned char* sel_mask,
                                       float* out_mask, void* stream);
+/* ... with get_out_mask's other branches (engine_utils.py:118-136): mask_type 0 "L1" min-max (= the entry above), 1 "BCE" sigmoid,
+ * 2 "CE" arg-max over TWO mask channels (channels 0, 1 = mask, 2..4 = coor_x/y/z; out_mask = 0.0 / 1.0).  Pinned by
+ * tests/golden/mask_types_golden.npz (the reference's own functions). */
+int rdpn6d_select_correspondences_mt_f32(const float* out_nchw, int C, const float* coord2d, int C2, int u_ch, int v_ch,
+                                         const float* extents, const int* im_hw, int im_H, int im_W, int B, int HW, float mask_thr,
+                                         int mask_type, float* image_points, float* model_points, int* counts,
+                                         unsigned char* sel_mask, float* out_mask, void* stream);
 /* rows A9 / A10: 2D-3D RANSAC-PnP on device, the role of lib/pysixd/misc.py:145-194 pnp_v2 -> cv2.solvePnPRansac(EPnP, 3 px, 100 it.)
  * at gdrn_evaluator.py:316-435 and of process_net_and_pnp (:187-314).  image_points [B,HW,2] px / model_points [B,HW,3] m / counts [B]
  * = the output of rdpn6d_select_correspondences_f32; cams [B,9] K row-major; net_pose [B,12] (R row-major | t) or NULL.

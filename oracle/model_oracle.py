@@ -139,20 +139,23 @@ class Backbone(nn.Module):
 
 # --------------------------------------------------------------------------------------- heads
 class RotHead(nn.Module):
-    def __init__(self, num_regions=32, num_filters=256, num_layers=3, in_channels=1024):
+    def __init__(self, num_regions=32, num_filters=256, num_layers=3, in_channels=1024, mask_out_dim=1):
+        """mask_out_dim: 1 (MASK_LOSS_TYPE L1 | BCE) or 2 (CE) - get_xyz_mask_region_out_dim, GDRN.py:637-659"""
         super().__init__()
+        self.mask_out_dim = mask_out_dim
         f = [nn.ConvTranspose2d(in_channels, num_filters, 3, 2, 1, output_padding=1, bias=False),
              nn.BatchNorm2d(num_filters), nn.ReLU(inplace=True)]
         for _ in range(2 * num_layers):
             f += [nn.Conv2d(num_filters, num_filters, 3, 1, 1, bias=False), nn.BatchNorm2d(num_filters),
                   nn.ReLU(inplace=True)]
-        f.append(nn.Conv2d(num_filters, 1 + 3 + num_regions + 1, 1, bias=True))
+        f.append(nn.Conv2d(num_filters, mask_out_dim + 3 + num_regions + 1, 1, bias=True))
         self.features = nn.ModuleList(f)
 
     def forward(self, x):
         for l in self.features:
             x = l(x)
-        return x[:, :1], x[:, 1:2], x[:, 2:3], x[:, 3:4], x[:, 4:]  # mask, coor_x, coor_y, coor_z, region
+        m = self.mask_out_dim  # cdpn_rot_head_region.py:190-197
+        return x[:, :m], x[:, m:m + 1], x[:, m + 1:m + 2], x[:, m + 2:m + 3], x[:, m + 3:]  # mask, coor_x, coor_y, coor_z, region
 
 
 class ConvPnP(nn.Module):
@@ -249,12 +252,14 @@ def allo_to_ego_torch(trans, rot_allo, eps=1e-4):
 
 # --------------------------------------------------------------------------------------- model
 class GDRNOracle(nn.Module):
-    def __init__(self, num_regions=32, mask_attention="none", out_res=64, num_layers=34):
+    def __init__(self, num_regions=32, mask_attention="none", out_res=64, num_layers=34, mask_loss_type="L1"):
         super().__init__()
+        assert mask_loss_type in ("L1", "BCE", "CE"), mask_loss_type
         self.backbone = Backbone(num_layers)
-        self.rot_head_net = RotHead(num_regions)
+        self.rot_head_net = RotHead(num_regions, mask_out_dim=2 if mask_loss_type == "CE" else 1)
         self.pnp_net = ConvPnP(11 + num_regions, out_res=out_res)
         self.mask_attention = mask_attention
+        self.mask_loss_type = mask_loss_type  # cfg.MODEL.CDPN.ROT_HEAD.MASK_LOSS_TYPE
         self.out_res = out_res
 
     def dense(self, x):
@@ -274,10 +279,15 @@ class GDRNOracle(nn.Module):
         anchors = anchors.reshape(B, r, r, 3).permute(0, 3, 1, 2)
         coor_feat = torch.cat([coor_feat, anchors], 1)
         att = None
-        if self.mask_attention != "none":
-            mx = mask.reshape(B, -1).max(dim=1)[0].view(B, 1, 1, 1)
-            mn = mask.reshape(B, -1).min(dim=1)[0].view(B, 1, 1, 1)
-            att = (mask - mn) / (mx - mn)
+        if self.mask_attention != "none":  # get_mask_prob, models/model_utils.py:24-42
+            if self.mask_loss_type == "L1":
+                mx = mask.reshape(B, -1).max(dim=1)[0].view(B, 1, 1, 1)
+                mn = mask.reshape(B, -1).min(dim=1)[0].view(B, 1, 1, 1)
+                att = (mask - mn) / (mx - mn)
+            elif self.mask_loss_type == "BCE":
+                att = torch.sigmoid(mask)
+            else:  # :39 - torch.softmax(pred_mask, dim=1, keepdim=True): softmax has no keepdim, the reference raises here
+                raise TypeError("get_mask_prob's CE branch raises in the reference (softmax() got an unexpected keyword 'keepdim')")
         return coor_feat, prob, att, amax.reshape(B, r, r)
 
     def forward(self, x, roi_coord_2d, fps, roi_cams, roi_centers, roi_whs, resize_ratios, train_pose=False, dense_maps=None,

@@ -154,9 +154,13 @@ static void rs_horn(const double S[9], double R[9])
 static void ransac_impl(const float* out_nchw, const float* coord2d, const float* fps, const float* extents,
                         const float* ratios, const int* region_argmax, int B, int HW, int K, float mask_thr,
                         float inlier_thr, int iters, float confidence, unsigned seed, float* pose_out,
-                        int* n_inliers, unsigned char* inlier_mask, int* best_hyp, const float* net_pose, float max_t_diff)
+                        int* n_inliers, unsigned char* inlier_mask, int* best_hyp, const float* net_pose, float max_t_diff,
+                        int mask_type)
 {
-    const int C = 4 + K + 1;
+    /* mask_type = ROT_HEAD.MASK_LOSS_TYPE as get_out_mask reads it (core/gdrn_modeling/engine_utils.py:118-136): 0 L1 per-crop
+     * min-max, 1 BCE sigmoid, 2 CE arg-max over TWO mask channels (the residual xyz then start at channel 2) */
+    const int MC = mask_type == 2 ? 2 : 1;
+    const int C = MC + 3 + K + 1;
     float* q = (float*)malloc(sizeof(float) * 3 * (size_t)HW);
     int* ai = (int*)malloc(sizeof(int) * (size_t)HW);
     int* pix = (int*)malloc(sizeof(int) * (size_t)HW);
@@ -174,12 +178,15 @@ static void ransac_impl(const float* out_nchw, const float* coord2d, const float
         for (int p = 1; p < HW; p++) { mn = m[p] < mn ? m[p] : mn; mx = m[p] > mx ? m[p] : mx; }
         int n = 0;
         for (int p = 0; p < HW; p++) {
-            float nm = (m[p] - mn) / (mx - mn);
+            float nm;
+            if (mask_type == 0) nm = (m[p] - mn) / (mx - mn);
+            else if (mask_type == 1) nm = 1.f / (1.f + expf(-m[p]));
+            else nm = m[HW + p] > m[p] ? 1.f : 0.f;
             float dz = cd[2 * HW + p];
             if (nm > mask_thr && dz > 0.f) {
                 for (int c = 0; c < 3; c++) {
                     float P = cd[c * HW + p] * ratio;
-                    float dl = (m[(1 + c) * HW + p] - 0.5f) * e[c];
+                    float dl = (m[(MC + c) * HW + p] - 0.5f) * e[c];
                     q[3 * n + c] = P - dl;
                 }
                 ai[n] = region_argmax[(size_t)b * HW + p];
@@ -287,7 +294,17 @@ void oracle_ransac_kabsch(const float* out_nchw, const float* coord2d, const flo
                           int* n_inliers, unsigned char* inlier_mask, int* best_hyp)
 {
     ransac_impl(out_nchw, coord2d, fps, extents, ratios, region_argmax, B, HW, K, mask_thr, inlier_thr, iters, confidence,
-                seed, pose_out, n_inliers, inlier_mask, best_hyp, NULL, 0.f);
+                seed, pose_out, n_inliers, inlier_mask, best_hyp, NULL, 0.f, 0);
+}
+
+/* the plain solve with the mask read as MASK_LOSS_TYPE prescribes (mask_type 0 L1 | 1 BCE | 2 CE, see ransac_impl) */
+void oracle_ransac_kabsch_mt(const float* out_nchw, const float* coord2d, const float* fps, const float* extents,
+                             const float* ratios, const int* region_argmax, int B, int HW, int K, float mask_thr, int mask_type,
+                             float inlier_thr, int iters, float confidence, unsigned seed, float* pose_out,
+                             int* n_inliers, unsigned char* inlier_mask, int* best_hyp)
+{
+    ransac_impl(out_nchw, coord2d, fps, extents, ratios, region_argmax, B, HW, K, mask_thr, inlier_thr, iters, confidence,
+                seed, pose_out, n_inliers, inlier_mask, best_hyp, NULL, 0.f, mask_type);
 }
 
 /* mode 1: net pose + iters-1 sampled hypotheses + inlier refit; mode 2: one least-squares fit over all selected points */
@@ -301,5 +318,5 @@ void oracle_ransac_kabsch_net(const float* out_nchw, const float* coord2d, const
         inlier_thr = HUGE_VALF;
     }
     ransac_impl(out_nchw, coord2d, fps, extents, ratios, region_argmax, B, HW, K, mask_thr, inlier_thr, iters, confidence,
-                seed, pose_out, n_inliers, inlier_mask, best_hyp, net_pose, max_t_diff);
+                seed, pose_out, n_inliers, inlier_mask, best_hyp, net_pose, max_t_diff, 0);
 }

@@ -75,6 +75,8 @@ SIGNATURES = {
     "rdpn6d_groupnorm_relu_h2": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "rdpn6d_dense_glue_f32": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "rdpn6d_dense_glue_h2": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "rdpn6d_dense_glue_mt_f32": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "rdpn6d_dense_glue_mt_h2": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "rdpn6d_pose_decode_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "rdpn6d_ransac_kabsch_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _f, _u, _vp, _vp, _vp, _vp]),
     "rdpn6d_ransac_kabsch_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _f, _u, _vp, _vp, _vp, _vp, _vp]),
@@ -82,6 +84,7 @@ SIGNATURES = {
                                           _vp, _vp]),
     "rdpn6d_ransac_workspace_bytes": (ctypes.c_longlong, [_i]),
     "rdpn6d_ransac_kabsch_ws": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _f, _u, _i, _f, _vp, _vp, _vp, _vp, _vp, _ll, _vp]),
+    "rdpn6d_ransac_kabsch_ws_mt": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _i, _f, _u, _i, _f, _vp, _vp, _vp, _vp, _vp, _ll, _vp]),
     "rdpn6d_stem_conv7x7_raw_f32": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "rdpn6d_bn_train_stats_f32": (_i, [_vp, _ll, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rdpn6d_bn_apply_f32": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _ll, _i, _i, _vp]),
@@ -151,6 +154,7 @@ SIGNATURES = {
     "rdpn6d_conv_h2_workspace_bytes": (ctypes.c_longlong, [_vp]),
     "rdpn6d_ransac_pnp_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _f, ctypes.c_uint, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "rdpn6d_select_correspondences_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rdpn6d_select_correspondences_mt_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
 for _k in [k for k in list(SIGNATURES) if "_bf16" in k and "bf16x3" not in k]:  # the fp16 twins (include/rdpn6d.h, last section)

@@ -1043,6 +1043,8 @@ extern "C" int rdpn6d_conv2d_h2_fuse1x1(const rdpn6d_conv_desc* d, const void* r
     RD_REQUIRE(rdpn6d_conv_h2_fuse1x1_ok(d), "fused 1x1 output convolution: needs the 256x256 kernel with N == Npad == 256");
     RD_REQUIRE(n_out >= 1 && n_out <= out_cs && out_cs <= 64 && out_cs % 8 == 0, "n_out <= out_cs <= 64, out_cs % 8 == 0");
     RD_REQUIRE(d->y == nullptr, "the fused form does not write the activation (desc.y must be null)");
+    // the fused epilogue applies scale, shift and activation only: a residual or a per-crop bias would be dropped silently
+    RD_REQUIRE(!res_h2 && !crop_bias && !d->res, "the fused 1x1 form takes no residual and no per-crop bias");
     const H2Fuse f = {w1_h2, scale1, bias1, out, out_cs, n_out};
     return conv2d_h2_impl(d, nullptr, res_h2, overflow_flag, crop_bias, nullptr, 0, &f, stream);
 }

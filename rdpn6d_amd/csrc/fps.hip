@@ -371,6 +371,9 @@ extern "C" int rdpn6d_fps_device(const float* d_pts, const int* d_offsets, int n
 // with a workspace of rdpn6d_fps_workspace_bytes(nobj) bytes: clouds of 16 385 .. 262 144 points run on ceil(max_pn / 16 384) workgroups
 // each (fps_multi_kernel above) when all of them fit the chip at once; everything else as rdpn6d_fps_device.  The first int of the
 // workspace entry [obj] is a barrier counter, the second an error word: non-zero after the launch = a barrier timed out (indices -1).
+// CONTRACT of this asynchronous entry: the launch is an ordinary (non-cooperative) one, co-residency of a cloud's workgroups is only
+// likely (G * nobj <= 128 of 256 CUs), so the caller MUST read the error words once the stream has drained and, if one is set, call
+// rdpn6d_fps_device for that batch (rdpn6d_fps_host does exactly that).
 extern "C" int rdpn6d_fps_device_ws(const float* d_pts, const int* d_offsets, int nobj, int max_pn, int sn, int start, int* d_idxs,
                                     float* d_mindist, void* workspace, long long workspace_bytes, void* stream)
 {
@@ -416,9 +419,18 @@ extern "C" int rdpn6d_fps_host(const float* pts, int* idxs, int pn, int sn, int 
         rdpn6d_set_error("fps: copy back failed: %s", hipGetErrorString(e));
         rc = RDPN6D_EHIP;
     }
+    if (rc == RDPN6D_OK && getenv("RDPN6D_FPS_TEST_TIMEOUT")) {  // tests: pretend the barrier gave up (indices -1, error word set)
+        wsh[1] = 1;
+        for (int i = 0; i < sn; ++i) idxs[i] = -1;
+    }
     if (rc == RDPN6D_OK && wsh[1] != 0) {
-        rdpn6d_set_error("fps: a cross-workgroup barrier timed out (the cloud's workgroups were not resident together)");
-        rc = RDPN6D_EHIP;
+        // the cloud's workgroups were not resident together (another stream / process held the CUs): the spin barrier of the ordinary
+        // launch gave up.  The one-workgroup-per-cloud kernel needs no co-residency and yields the same indices bit for bit: run it.
+        rc = rdpn6d_fps_device(d_pts, d_off, 1, pn, sn, start, d_idx, d_md, nullptr);
+        if (rc == RDPN6D_OK && (e = hipMemcpy(idxs, d_idx, sizeof(int) * (size_t)sn, hipMemcpyDeviceToHost)) != hipSuccess) {
+            rdpn6d_set_error("fps: copy back failed: %s", hipGetErrorString(e));
+            rc = RDPN6D_EHIP;
+        }
     }
     (void)hipFree(d_pts); (void)hipFree(d_md); (void)hipFree(d_off); (void)hipFree(d_idx); (void)hipFree(d_ws);
     return rc;

@@ -21,8 +21,11 @@ __global__ __launch_bounds__(SEL_THREADS) void select_correspondences_kernel(
     const float* __restrict__ out_nchw, int C, const float* __restrict__ coord2d, int C2, int u_ch, int v_ch,
     const float* __restrict__ extents, const int* __restrict__ im_hw, int im_H, int im_W, int HW, float mask_thr,
     float* __restrict__ image_points, float* __restrict__ model_points, int* __restrict__ counts,
-    unsigned char* __restrict__ sel_mask, float* __restrict__ out_mask)
+    unsigned char* __restrict__ sel_mask, float* __restrict__ out_mask, int mask_type)
 {
+    // mask_type = ROT_HEAD.MASK_LOSS_TYPE as get_out_mask reads it (engine_utils.py:118-136): 0 "L1" per-crop min-max, 1 "BCE" sigmoid,
+    // 2 "CE" arg-max over the TWO mask channels (the map tensor is then [mask0 mask1 | x y z | ...]: the coordinates start at channel 2)
+    const int M = mask_type == 2 ? 2 : 1;
     __shared__ float s_mn[SEL_WAVES], s_mx[SEL_WAVES];
     __shared__ int s_cnt[SEL_WAVES];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -50,11 +53,14 @@ __global__ __launch_bounds__(SEL_THREADS) void select_correspondences_kernel(
         bool sel = false;
         float x = 0.f, y = 0.f, z = 0.f;
         if (p < HW) {
-            const float nm = (m[p] - mn) / range;  // 0/0 = NaN for a constant mask: every comparison below is then false
+            float nm;
+            if (mask_type == 0) nm = (m[p] - mn) / range;  // 0/0 = NaN for a constant mask: every comparison below is then false
+            else if (mask_type == 1) nm = 1.f / (1.f + expf(-m[p]));  // torch.sigmoid
+            else nm = m[HW + p] > m[p] ? 1.f : 0.f;  // torch.argmax over (mask0, mask1): the first maximum wins a tie
             if (out_mask) out_mask[(size_t)b * HW + p] = nm;
-            x = (m[HW + p] - 0.5f) * ex;
-            y = (m[2 * HW + p] - 0.5f) * ey;
-            z = (m[3 * HW + p] - 0.5f) * ez;
+            x = (m[(size_t)M * HW + p] - 0.5f) * ex;
+            y = (m[(size_t)(M + 1) * HW + p] - 0.5f) * ey;
+            z = (m[(size_t)(M + 2) * HW + p] - 0.5f) * ez;
             sel = (nm > mask_thr) && (fabsf(x) > tx) && (fabsf(y) > ty) && (fabsf(z) > tz);
             if (sel_mask) sel_mask[(size_t)b * HW + p] = sel ? 1 : 0;
         }
@@ -77,20 +83,30 @@ __global__ __launch_bounds__(SEL_THREADS) void select_correspondences_kernel(
     if (tid == 0) counts[b] = n;
 }
 
+extern "C" int rdpn6d_select_correspondences_mt_f32(const float* out_nchw, int C, const float* coord2d, int C2, int u_ch, int v_ch,
+                                                    const float* extents, const int* im_hw, int im_H, int im_W, int B, int HW,
+                                                    float mask_thr, int mask_type, float* image_points, float* model_points,
+                                                    int* counts, unsigned char* sel_mask, float* out_mask, void* stream)
+{
+    RD_REQUIRE(out_nchw && coord2d && extents && image_points && model_points && counts, "null pointer");
+    RD_REQUIRE(mask_type >= 0 && mask_type <= 2, "mask_type: 0 L1 (min-max) | 1 BCE (sigmoid) | 2 CE (arg-max of two channels)");
+    RD_REQUIRE(B > 0 && HW > 0 && C >= (mask_type == 2 ? 5 : 4), "B, HW > 0; the map tensor holds mask | coor_x | coor_y | coor_z | ...");
+    RD_REQUIRE(C2 >= 2 && u_ch >= 0 && u_ch < C2 && v_ch >= 0 && v_ch < C2, "2D-coordinate channels");
+    RD_REQUIRE(im_hw || (im_H > 0 && im_W > 0), "image size");
+    hipLaunchKernelGGL(select_correspondences_kernel, dim3(B), dim3(SEL_THREADS), 0, (hipStream_t)stream, out_nchw, C, coord2d,
+                       C2, u_ch, v_ch, extents, im_hw, im_H, im_W, HW, mask_thr, image_points, model_points, counts, sel_mask,
+                       out_mask, mask_type);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}
+
 extern "C" int rdpn6d_select_correspondences_f32(const float* out_nchw, int C, const float* coord2d, int C2, int u_ch, int v_ch,
                                                  const float* extents, const int* im_hw, int im_H, int im_W, int B, int HW,
                                                  float mask_thr, float* image_points, float* model_points, int* counts,
                                                  unsigned char* sel_mask, float* out_mask, void* stream)
 {
-    RD_REQUIRE(out_nchw && coord2d && extents && image_points && model_points && counts, "null pointer");
-    RD_REQUIRE(B > 0 && HW > 0 && C >= 4, "B, HW > 0; the map tensor holds mask | coor_x | coor_y | coor_z | ...");
-    RD_REQUIRE(C2 >= 2 && u_ch >= 0 && u_ch < C2 && v_ch >= 0 && v_ch < C2, "2D-coordinate channels");
-    RD_REQUIRE(im_hw || (im_H > 0 && im_W > 0), "image size");
-    hipLaunchKernelGGL(select_correspondences_kernel, dim3(B), dim3(SEL_THREADS), 0, (hipStream_t)stream, out_nchw, C, coord2d,
-                       C2, u_ch, v_ch, extents, im_hw, im_H, im_W, HW, mask_thr, image_points, model_points, counts, sel_mask,
-                       out_mask);
-    RD_LAUNCH_CHECK();
-    return RDPN6D_OK;
+    return rdpn6d_select_correspondences_mt_f32(out_nchw, C, coord2d, C2, u_ch, v_ch, extents, im_hw, im_H, im_W, B, HW, mask_thr, 0,
+                                                image_points, model_points, counts, sel_mask, out_mask, stream);
 }
 
 // =====================================================================================================================

@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256) void mask_minmax_kernel(const float* __restric
 // H2: the ConvPnPNet input row goes out as an h2 record (pnp_cs % 32 == 0 channels: [hi x 32 | lo x 32] fp16 per 32-channel group,
 // 16 * value; conv_igemm_h2.hip) instead of fp32, and a value outside the format's range (|v| > 4094, inf, NaN - the inputs are
 // caller data: depth xyz, anchors) raises the plan's range flag like every other h2 writer.
-template <int KMAX, bool H2 = false>
+template <int KMAX, bool H2 = false, int MC = 1>
 __global__ __launch_bounds__(256) void dense_glue_kernel(const float* __restrict__ head, int head_cs,
                                                          const float* __restrict__ coord2d,
                                                          const float* __restrict__ fps, int B, int HW, int K,
@@ -492,33 +492,34 @@ __global__ __launch_bounds__(256) void dense_glue_kernel(const float* __restrict
     if (i >= (long long)B * HW) return;
     const int b = (int)(i / HW), p = (int)(i - (long long)b * HW);
     const float* h = head + i * head_cs;
-    const int C = 4 + K + 1;
-    float v[4 + KMAX + 1];
+    // MC = mask channels of the head row: 1 (MASK_LOSS_TYPE L1 | BCE) or 2 (CE: [mask0 mask1 | x y z | region bg + K])
+    const int C = MC + 3 + K + 1;
+    float v[MC + 3 + KMAX + 1];
     // head row -> registers (16-byte loads), and out to the NCHW API tensor (coalesced over pixels)
 #pragma unroll
-    for (int c4 = 0; c4 < (4 + KMAX + 1 + 3) / 4; ++c4) {
+    for (int c4 = 0; c4 < (MC + 3 + KMAX + 1 + 3) / 4; ++c4) {
         if (c4 * 4 < C) {
             const f32x4 t = *reinterpret_cast<const f32x4*>(h + c4 * 4);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                if (c4 * 4 + e < 4 + KMAX + 1) v[c4 * 4 + e] = t[e];
+                if (c4 * 4 + e < MC + 3 + KMAX + 1) v[c4 * 4 + e] = t[e];
         }
     }
     float* o = out_nchw + (long long)b * C * HW + p;
 #pragma unroll
-    for (int c = 0; c < 4 + KMAX + 1; ++c)
+    for (int c = 0; c < MC + 3 + KMAX + 1; ++c)
         if (c < C) o[(long long)c * HW] = v[c];
     // softmax over region[1..K]
     float mx = -FLT_MAX;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k)
-        if (k < K) mx = fmaxf(mx, v[5 + k]);
+        if (k < K) mx = fmaxf(mx, v[MC + 4 + k]);
     float sum = 0.f;
     float e[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; ++k)
         if (k < K) {
-            e[k] = expf(v[5 + k] - mx);
+            e[k] = expf(v[MC + 4 + k] - mx);
             sum += e[k];
         }
     int am = 0;
@@ -531,14 +532,16 @@ __global__ __launch_bounds__(256) void dense_glue_kernel(const float* __restrict
         }
     if (argmax_out) argmax_out[i] = am;
     float att = 1.f;
-    if (mask_attention) {
+    if (mask_attention == 1) {  // MASK_LOSS_TYPE L1: per-crop min-max
         const float mn = minmax[b * 2], mxm = minmax[b * 2 + 1];
         att = (v[0] - mn) / (mxm - mn);  // no epsilon, as model_utils.py:34
+    } else if (mask_attention == 2) {  // MASK_LOSS_TYPE BCE: torch.sigmoid (model_utils.py:35-37)
+        att = 1.f / (1.f + expf(-v[0]));
     }
     const float* cd = coord2d + (long long)b * 5 * HW + p;
     const float* an = fps + ((long long)b * K + am) * 3;
     float row[11];
-    row[0] = v[1]; row[1] = v[2]; row[2] = v[3];
+    row[0] = v[MC]; row[1] = v[MC + 1]; row[2] = v[MC + 2];
 #pragma unroll
     for (int c = 0; c < 5; ++c) row[3 + c] = cd[(long long)c * HW];
     row[8] = an[0]; row[9] = an[1]; row[10] = an[2];
@@ -611,26 +614,87 @@ __global__ __launch_bounds__(256) void dense_glue_kernel(const float* __restrict
     for (int c = ((11 + KMAX + 3) / 4 + 1) * 4; c < pnp_cs; c += 4) *reinterpret_cast<f32x4*>(q + c) = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
-extern "C" int rdpn6d_dense_glue_f32(const float* head, int head_cs, const float* coord2d, const float* fps, int B,
-                                     int HW, int K, int mask_attention, float* minmax_scratch, float* out_nchw,
-                                     float* pnp_in, int pnp_cs, int* argmax_out, void* stream)
+static int glue_mask_args(int mask_attention, int mask_type, int* att_mode, int* mc)
+{
+    // mask_type = ROT_HEAD.MASK_LOSS_TYPE as get_mask_prob reads it (models/model_utils.py:24-42): 0 L1 | 1 BCE | 2 CE
+    RD_REQUIRE(mask_type >= 0 && mask_type <= 2, "mask_type: 0 L1 | 1 BCE | 2 CE");
+    // CE: the reference's own branch cannot run (torch.softmax(pred_mask, dim=1, keepdim=True) is a TypeError, model_utils.py:39)
+    RD_REQUIRE(!(mask_attention && mask_type == 2), "MASK_ATTENTION with MASK_LOSS_TYPE CE: the reference's get_mask_prob raises there");
+    *att_mode = mask_attention ? (mask_type == 1 ? 2 : 1) : 0;
+    *mc = mask_type == 2 ? 2 : 1;
+    return RDPN6D_OK;
+}
+
+extern "C" int rdpn6d_dense_glue_mt_f32(const float* head, int head_cs, const float* coord2d, const float* fps, int B,
+                                        int HW, int K, int mask_attention, int mask_type, float* minmax_scratch, float* out_nchw,
+                                        float* pnp_in, int pnp_cs, int* argmax_out, void* stream)
 {
     RD_REQUIRE(head && coord2d && fps && out_nchw && pnp_in, "null pointer");
     RD_REQUIRE(B > 0 && HW > 0 && K >= 2 && K <= 64, "K in 2..64");
-    RD_REQUIRE(head_cs % 4 == 0 && head_cs >= 5 + K && pnp_cs % 4 == 0 && pnp_cs >= 11 + K, "channel strides");
-    RD_REQUIRE(!mask_attention || minmax_scratch, "mask attention needs a [B,2] scratch");
+    int att = 0, mc = 1;
+    if (int rc = glue_mask_args(mask_attention, mask_type, &att, &mc)) return rc;
+    RD_REQUIRE(head_cs % 4 == 0 && head_cs >= mc + 4 + K && pnp_cs % 4 == 0 && pnp_cs >= 11 + K, "channel strides");
+    RD_REQUIRE(att != 1 || minmax_scratch, "mask attention needs a [B,2] scratch");
     hipStream_t s = (hipStream_t)stream;
-    if (mask_attention) {
+    if (att == 1) {
         hipLaunchKernelGGL(mask_minmax_kernel, dim3(B), dim3(256), 0, s, head, head_cs, HW, minmax_scratch);
         RD_LAUNCH_CHECK();
     }
     const unsigned blocks = (unsigned)(((long long)B * HW + 255) / 256);
-    if (K <= 32)
-        hipLaunchKernelGGL(dense_glue_kernel<32>, dim3(blocks), dim3(256), 0, s, head, head_cs, coord2d, fps, B, HW, K,
-                           mask_attention, minmax_scratch, out_nchw, pnp_in, pnp_cs, argmax_out, (int*)nullptr);
-    else
-        hipLaunchKernelGGL(dense_glue_kernel<64>, dim3(blocks), dim3(256), 0, s, head, head_cs, coord2d, fps, B, HW, K,
-                           mask_attention, minmax_scratch, out_nchw, pnp_in, pnp_cs, argmax_out, (int*)nullptr);
+#define RD_GLUE(KM, MCV) hipLaunchKernelGGL((dense_glue_kernel<KM, false, MCV>), dim3(blocks), dim3(256), 0, s, head, head_cs, coord2d, fps, \
+                                            B, HW, K, att, minmax_scratch, out_nchw, pnp_in, pnp_cs, argmax_out, (int*)nullptr)
+    if (K <= 32) { if (mc == 1) RD_GLUE(32, 1); else RD_GLUE(32, 2); }
+    else { if (mc == 1) RD_GLUE(64, 1); else RD_GLUE(64, 2); }
+#undef RD_GLUE
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}
+
+extern "C" int rdpn6d_dense_glue_f32(const float* head, int head_cs, const float* coord2d, const float* fps, int B,
+                                     int HW, int K, int mask_attention, float* minmax_scratch, float* out_nchw,
+                                     float* pnp_in, int pnp_cs, int* argmax_out, void* stream)
+{
+    return rdpn6d_dense_glue_mt_f32(head, head_cs, coord2d, fps, B, HW, K, mask_attention, 0, minmax_scratch, out_nchw, pnp_in, pnp_cs,
+                                    argmax_out, stream);
+}
+
+template <int KM, int MCV>
+static int glue_h2_launch(unsigned blocks, size_t smem, hipStream_t s, const float* head, int head_cs, const float* coord2d,
+                           const float* fps, int B, int HW, int K, int att, float* minmax_scratch, float* out_nchw, void* pnp_in_h2,
+                           int pnp_cs, int* argmax_out, int* overflow_flag)
+{
+    auto kern = dense_glue_kernel<KM, true, MCV>;
+    RD_LDS_OPT_IN(kern, 160 * 1024);
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), smem, s, head, head_cs, coord2d, fps, B, HW, K, att, minmax_scratch, out_nchw,
+                       reinterpret_cast<float*>(pnp_in_h2), pnp_cs, argmax_out, overflow_flag);
+    return RDPN6D_OK;
+}
+
+extern "C" int rdpn6d_dense_glue_mt_h2(const float* head, int head_cs, const float* coord2d, const float* fps, int B, int HW, int K,
+                                       int mask_attention, int mask_type, float* minmax_scratch, float* out_nchw, void* pnp_in_h2,
+                                       int pnp_cs, int* argmax_out, int* overflow_flag, void* stream)
+{
+    RD_REQUIRE(head && coord2d && fps && out_nchw && pnp_in_h2, "null pointer");
+    RD_REQUIRE(B > 0 && HW > 0 && K >= 2 && K <= 64, "K in 2..64");
+    int att = 0, mc = 1;
+    if (int rc = glue_mask_args(mask_attention, mask_type, &att, &mc)) return rc;
+    RD_REQUIRE(head_cs % 4 == 0 && head_cs >= mc + 4 + K && pnp_cs % 32 == 0 && pnp_cs >= 11 + K, "channel strides (h2 row: pnp_cs % 32 == 0)");
+    RD_REQUIRE(att != 1 || minmax_scratch, "mask attention needs a [B,2] scratch");
+    hipStream_t s = (hipStream_t)stream;
+    if (att == 1) {
+        hipLaunchKernelGGL(mask_minmax_kernel, dim3(B), dim3(256), 0, s, head, head_cs, HW, minmax_scratch);
+        RD_LAUNCH_CHECK();
+    }
+    RD_REQUIRE(((long long)B * HW) % 256 == 0, "the h2 glue kernel stages whole workgroups of 256 pixels: B * HW % 256 == 0");
+    const unsigned blocks = (unsigned)(((long long)B * HW) / 256);
+    const size_t smem = (size_t)256 * (pnp_cs * 4 + 8);
+    int rc;
+#define RD_GLUE_H2(KM, MCV) rc = glue_h2_launch<KM, MCV>(blocks, smem, s, head, head_cs, coord2d, fps, B, HW, K, att, minmax_scratch, out_nchw, \
+                                                         pnp_in_h2, pnp_cs, argmax_out, overflow_flag)
+    if (K <= 32) { if (mc == 1) RD_GLUE_H2(32, 1); else RD_GLUE_H2(32, 2); }
+    else { if (mc == 1) RD_GLUE_H2(64, 1); else RD_GLUE_H2(64, 2); }
+#undef RD_GLUE_H2
+    if (rc != RDPN6D_OK) return rc;
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
 }
@@ -639,31 +703,8 @@ extern "C" int rdpn6d_dense_glue_h2(const float* head, int head_cs, const float*
                                     int mask_attention, float* minmax_scratch, float* out_nchw, void* pnp_in_h2, int pnp_cs,
                                     int* argmax_out, int* overflow_flag, void* stream)
 {
-    RD_REQUIRE(head && coord2d && fps && out_nchw && pnp_in_h2, "null pointer");
-    RD_REQUIRE(B > 0 && HW > 0 && K >= 2 && K <= 64, "K in 2..64");
-    RD_REQUIRE(head_cs % 4 == 0 && head_cs >= 5 + K && pnp_cs % 32 == 0 && pnp_cs >= 11 + K, "channel strides (h2 row: pnp_cs % 32 == 0)");
-    RD_REQUIRE(!mask_attention || minmax_scratch, "mask attention needs a [B,2] scratch");
-    hipStream_t s = (hipStream_t)stream;
-    if (mask_attention) {
-        hipLaunchKernelGGL(mask_minmax_kernel, dim3(B), dim3(256), 0, s, head, head_cs, HW, minmax_scratch);
-        RD_LAUNCH_CHECK();
-    }
-    RD_REQUIRE(((long long)B * HW) % 256 == 0, "the h2 glue kernel stages whole workgroups of 256 pixels: B * HW % 256 == 0");
-    const unsigned blocks = (unsigned)(((long long)B * HW) / 256);
-    const size_t smem = (size_t)256 * (pnp_cs * 4 + 8);
-    if (K <= 32) {
-        auto kern = dense_glue_kernel<32, true>;
-        RD_LDS_OPT_IN(kern, 160 * 1024);
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), smem, s, head, head_cs, coord2d, fps, B, HW, K, mask_attention,
-                           minmax_scratch, out_nchw, reinterpret_cast<float*>(pnp_in_h2), pnp_cs, argmax_out, overflow_flag);
-    } else {
-        auto kern = dense_glue_kernel<64, true>;
-        RD_LDS_OPT_IN(kern, 160 * 1024);
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), smem, s, head, head_cs, coord2d, fps, B, HW, K, mask_attention,
-                           minmax_scratch, out_nchw, reinterpret_cast<float*>(pnp_in_h2), pnp_cs, argmax_out, overflow_flag);
-    }
-    RD_LAUNCH_CHECK();
-    return RDPN6D_OK;
+    return rdpn6d_dense_glue_mt_h2(head, head_cs, coord2d, fps, B, HW, K, mask_attention, 0, minmax_scratch, out_nchw, pnp_in_h2, pnp_cs,
+                                   argmax_out, overflow_flag, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

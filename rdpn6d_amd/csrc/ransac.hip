@@ -210,7 +210,7 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_kabsch_kernel(
     const float* __restrict__ extents, const float* __restrict__ ratios, const int* __restrict__ region_argmax, int HW,
     int K, float mask_thr, float inlier_thr, int iters, float confidence, unsigned seed, float* __restrict__ pose_out,
     int* __restrict__ n_inliers, unsigned char* __restrict__ inlier_mask, int* __restrict__ best_hyp,
-    const float* __restrict__ net_pose, float max_t_diff, int stage, int* __restrict__ g_cnt, float* __restrict__ g_pose)
+    const float* __restrict__ net_pose, float max_t_diff, int stage, int* __restrict__ g_cnt, float* __restrict__ g_pose, int mask_type)
 {
     // stage 0: the whole solve in one workgroup per crop.  stage 1 (grid B x parts): selection + this part's share of the hypotheses,
     // counts / poses to the GLOBAL scoreboard g_cnt [B][RS_MAX_ITERS] / g_pose [B][RS_MAX_ITERS][12]; stage 2 (grid B): selection again,
@@ -228,7 +228,10 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_kabsch_kernel(
     unsigned char* s_ai = reinterpret_cast<unsigned char*>(s_pix + HW);         // HW
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int C = 4 + K + 1;
+    // mask_type (ROT_HEAD.MASK_LOSS_TYPE as engine_utils.get_out_mask reads it): 0 L1 min-max | 1 BCE sigmoid | 2 CE arg-max of TWO
+    // mask channels - the coordinates then start at channel 2
+    const int MC = mask_type == 2 ? 2 : 1;
+    const int C = MC + 3 + K + 1;
     const float* m = out_nchw + (size_t)b * C * HW;
     const float* cd = coord2d + (size_t)b * 5 * HW;
     const float* A = fps + (size_t)b * K * 3;
@@ -261,12 +264,16 @@ __global__ __launch_bounds__(RS_THREADS) void ransac_kabsch_kernel(
         bool sel = false;
         float qx = 0.f, qy = 0.f, qz = 0.f;
         if (p < HW) {
-            const float nm = (m[p] - mn) / range;
+            float nm;
+            if (mask_type == 0) nm = (m[p] - mn) / range;
+            else if (mask_type == 1) nm = 1.f / (1.f + expf(-m[p]));
+            else nm = m[HW + p] > m[p] ? 1.f : 0.f;
             const float dz = cd[2 * HW + p];
             sel = nm > mask_thr && dz > 0.f;
             if (sel) {
                 const float Px = cd[p] * ratio, Py = cd[HW + p] * ratio, Pz = dz * ratio;
-                const float dlx = (m[HW + p] - 0.5f) * ex, dly = (m[2 * HW + p] - 0.5f) * ey, dlz = (m[3 * HW + p] - 0.5f) * ez;
+                const float dlx = (m[(size_t)MC * HW + p] - 0.5f) * ex, dly = (m[(size_t)(MC + 1) * HW + p] - 0.5f) * ey,
+                            dlz = (m[(size_t)(MC + 2) * HW + p] - 0.5f) * ez;
                 qx = Px - dlx; qy = Py - dly; qz = Pz - dlz;
             }
         }
@@ -475,9 +482,10 @@ static int rs_launch(const float* out_nchw, const float* coord2d, const float* f
                      const float* resize_ratios, const int* region_argmax, int B, int HW, int K, float mask_thr,
                      float inlier_thr, int iters, float confidence, unsigned seed, float* pose_out, int* n_inliers,
                      unsigned char* inlier_mask, int* best_hyp, const float* net_pose, float max_t_diff, void* workspace,
-                     long long workspace_bytes, void* stream)
+                     long long workspace_bytes, void* stream, int mask_type = 0)
 {
     RD_REQUIRE(out_nchw && coord2d && fps && extents && resize_ratios && region_argmax && pose_out && n_inliers, "null pointer");
+    RD_REQUIRE(mask_type >= 0 && mask_type <= 2, "mask_type: 0 L1 (min-max) | 1 BCE (sigmoid) | 2 CE (arg-max of two channels)");
     RD_REQUIRE(B > 0 && HW > 0 && HW <= 16384, "HW must be in 1..16384 (LDS-resident correspondences)");
     RD_REQUIRE(K >= 3 && K <= 64, "K in 3..64");
     RD_REQUIRE(iters >= 1 && iters <= RS_MAX_ITERS, "iters in 1..256");
@@ -498,17 +506,17 @@ static int rs_launch(const float* out_nchw, const float* coord2d, const float* f
         float* g_pose = reinterpret_cast<float*>(g_cnt + (size_t)B * RS_MAX_ITERS);
         hipLaunchKernelGGL(ransac_kabsch_kernel, dim3(B, parts), dim3(RS_THREADS), smem, (hipStream_t)stream, out_nchw, coord2d, fps,
                            extents, resize_ratios, region_argmax, HW, K, mask_thr, inlier_thr, iters, confidence, seed,
-                           pose_out, n_inliers, inlier_mask, best_hyp, net_pose, max_t_diff, 1, g_cnt, g_pose);
+                           pose_out, n_inliers, inlier_mask, best_hyp, net_pose, max_t_diff, 1, g_cnt, g_pose, mask_type);
         RD_LAUNCH_CHECK();
         hipLaunchKernelGGL(ransac_kabsch_kernel, dim3(B), dim3(RS_THREADS), smem, (hipStream_t)stream, out_nchw, coord2d, fps,
                            extents, resize_ratios, region_argmax, HW, K, mask_thr, inlier_thr, iters, confidence, seed,
-                           pose_out, n_inliers, inlier_mask, best_hyp, net_pose, max_t_diff, 2, g_cnt, g_pose);
+                           pose_out, n_inliers, inlier_mask, best_hyp, net_pose, max_t_diff, 2, g_cnt, g_pose, mask_type);
         RD_LAUNCH_CHECK();
         return RDPN6D_OK;
     }
     hipLaunchKernelGGL(ransac_kabsch_kernel, dim3(B), dim3(RS_THREADS), smem, (hipStream_t)stream, out_nchw, coord2d, fps,
                        extents, resize_ratios, region_argmax, HW, K, mask_thr, inlier_thr, iters, confidence, seed,
-                       pose_out, n_inliers, inlier_mask, best_hyp, net_pose, max_t_diff, 0, (int*)nullptr, (float*)nullptr);
+                       pose_out, n_inliers, inlier_mask, best_hyp, net_pose, max_t_diff, 0, (int*)nullptr, (float*)nullptr, mask_type);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
 }
@@ -531,6 +539,20 @@ extern "C" int rdpn6d_ransac_kabsch_ws(const float* out_nchw, const float* coord
                                        float max_t_diff, float* pose_out, int* n_inliers, unsigned char* inlier_mask, int* best_hyp,
                                        void* workspace, long long workspace_bytes, void* stream)
 {
+    return rdpn6d_ransac_kabsch_ws_mt(out_nchw, coord2d, fps, extents, resize_ratios, region_argmax, net_pose, B, HW, K, mask_thr, 0,
+                                      inlier_thr, iters, confidence, seed, mode, max_t_diff, pose_out, n_inliers, inlier_mask, best_hyp,
+                                      workspace, workspace_bytes, stream);
+}
+
+// ... and with the mask read as ROT_HEAD.MASK_LOSS_TYPE prescribes (engine_utils.get_out_mask): mask_type 0 L1 = per-crop min-max (every
+// other entry point), 1 BCE = sigmoid, 2 CE = arg-max over two mask channels (out_nchw is then [B, 2 + 3 + K + 1, HW])
+extern "C" int rdpn6d_ransac_kabsch_ws_mt(const float* out_nchw, const float* coord2d, const float* fps, const float* extents,
+                                          const float* resize_ratios, const int* region_argmax, const float* net_pose, int B, int HW,
+                                          int K, float mask_thr, int mask_type, float inlier_thr, int iters, float confidence,
+                                          unsigned seed, int mode, float max_t_diff, float* pose_out, int* n_inliers,
+                                          unsigned char* inlier_mask, int* best_hyp, void* workspace, long long workspace_bytes,
+                                          void* stream)
+{
     if (net_pose) {
         RD_REQUIRE(mode == 1 || mode == 2, "mode: 1 = net + RANSAC, 2 = net + least-squares over all points");
         RD_REQUIRE(max_t_diff > 0.f, "max_t_diff");
@@ -541,7 +563,7 @@ extern "C" int rdpn6d_ransac_kabsch_ws(const float* out_nchw, const float* coord
     }
     return rs_launch(out_nchw, coord2d, fps, extents, resize_ratios, region_argmax, B, HW, K, mask_thr, inlier_thr, iters, confidence,
                      seed, pose_out, n_inliers, inlier_mask, best_hyp, net_pose, net_pose ? max_t_diff : 0.f, workspace, workspace_bytes,
-                     stream);
+                     stream, mask_type);
 }
 
 // Network-initialised solve = process_net_and_pnp (gdrn_evaluator.py:187-314).  net_pose [B,12] (R row-major | t) is the

@@ -206,12 +206,13 @@ class BackboneP(_Holder):
 
 
 class RotHeadP(_Holder):
-    def __init__(self, num_regions, num_filters=256, num_layers=3, in_channels=1024):
+    def __init__(self, num_regions, num_filters=256, num_layers=3, in_channels=1024, mask_out_dim=1):
         super().__init__()
         f = [ConvP(in_channels, num_filters, 3, 2, 1, transposed=True), BNP(num_filters), Slot()]
         for _ in range(2 * num_layers):
             f += [ConvP(num_filters, num_filters, 3, 1, 1), BNP(num_filters), Slot()]
-        f.append(ConvP(num_filters, 1 + 3 + num_regions + 1, 1, bias=True))
+        # [mask (1; 2 with MASK_LOSS_TYPE CE) | x y z | region bg + K]: cdpn_rot_head_region.py:130-138,190-197
+        f.append(ConvP(num_filters, mask_out_dim + 3 + num_regions + 1, 1, bias=True))
         self.features = _HolderList(f)
 
 
@@ -313,6 +314,44 @@ class _Launch:
         self.name, self.fn, self.args, self.keep = name, fn, args, keep
 
 
+_SIGMA_MAX_CACHE = {}
+
+
+def _sigma_max_upper_bound(w):
+    """A rigorous upper bound of the largest singular value of the 2-D weight `w`, on the HOST in float64 and with matrix products only
+    (no vendor eigen-solver, nothing on the device but the one D2H copy of the weight): for the positive semi-definite Gram matrix
+    G = W W^T (the smaller side), lambda_max(G)^k <= trace(G^k) <= n * lambda_max(G)^k, so trace(G^k)^(1/k) with k = 2^7 by repeated
+    squaring (re-normalised by the trace each time) over-estimates lambda_max by at most n^(1/128) (5.6 % for n = 1024; 0.5 % on
+    He-scaled weights).  Cached by the weight's CONTENT (blake2b of its bytes): a plan re-built for unchanged weights - another batch
+    size, a copy of the model, the test-suite's fixtures - costs one hash of the host copy."""
+    import hashlib
+    import math
+
+    wh = w.detach().to("cpu", torch.float32).contiguous()
+    key = (tuple(wh.shape), hashlib.blake2b(wh.numpy().tobytes(), digest_size=16).hexdigest())
+    hit = _SIGMA_MAX_CACHE.get(key)
+    if hit is not None:
+        return hit
+    a = wh.double()
+    g = a @ a.t() if a.shape[0] <= a.shape[1] else a.t() @ a
+    if not bool(torch.isfinite(g).all()):
+        return float("inf")
+    log_scale, k = 0.0, 1  # invariant: G^k = exp(log_scale) * g
+    for _ in range(7):
+        tr = float(g.diagonal().sum())
+        if tr <= 0.0:
+            return 0.0
+        g = g / tr
+        g = g @ g
+        log_scale, k = 2.0 * (log_scale + math.log(tr)), 2 * k
+    lam = math.exp((log_scale + math.log(max(float(g.diagonal().sum()), 1e-300))) / k)
+    out = math.sqrt(lam) * (1.0 + 1e-9)  # (float64 round-off of eight 1024^3 products: << 1e-9 relative)
+    if len(_SIGMA_MAX_CACHE) > 64:
+        _SIGMA_MAX_CACHE.clear()
+    _SIGMA_MAX_CACHE[key] = out
+    return out
+
+
 class InferencePlan:
     """Packed weights, NHWC activation buffers and the launch list for one (batch, device)."""
 
@@ -338,10 +377,14 @@ class InferencePlan:
         self.mask_attention = cfg.MODEL.CDPN.PNP_NET.MASK_ATTENTION
         if self.mask_attention not in ("none", "mul"):
             raise ValueError(f"MASK_ATTENTION={self.mask_attention!r} is not implemented (none | mul)")
-        if self.mask_attention != "none" and cfg.MODEL.CDPN.ROT_HEAD.MASK_LOSS_TYPE != "L1":
-            # get_mask_prob (models/model_utils.py:24-42): L1 = per-crop min-max (what the glue kernel does), BCE = sigmoid, CE = softmax
-            raise NotImplementedError(f"MASK_ATTENTION={self.mask_attention!r} with ROT_HEAD.MASK_LOSS_TYPE="
-                                      f"{cfg.MODEL.CDPN.ROT_HEAD.MASK_LOSS_TYPE!r}: only the 'L1' (min-max) mask probability is implemented")
+        # ROT_HEAD.MASK_LOSS_TYPE decides how the mask channel(s) are READ (get_mask_prob models/model_utils.py:24-42, get_out_mask
+        # engine_utils.py:118-136): L1 = per-crop min-max, BCE = sigmoid, CE = two mask channels (arg-max in the evaluator)
+        self.mask_type = MASK_TYPES[str(cfg.MODEL.CDPN.ROT_HEAD.MASK_LOSS_TYPE)]
+        self.mask_channels = 2 if self.mask_type == 2 else 1
+        if self.mask_attention != "none" and self.mask_type == 2:
+            # the reference's own branch cannot run: torch.softmax(pred_mask, dim=1, keepdim=True) is a TypeError (model_utils.py:39)
+            raise NotImplementedError("MASK_ATTENTION with ROT_HEAD.MASK_LOSS_TYPE='CE': get_mask_prob's CE branch raises in the reference "
+                                      "itself (torch.softmax has no keepdim argument, models/model_utils.py:39)")
         # fp32 mode: the wide head layers run as exact-product bf16x3 convolutions on the bf16 matrix pipe (fp32 accuracy,
         # csrc/conv_igemm_bf16x3.hip) when the batch fills the chip; cfg.TEST.BF16X3 = False keeps them on the fp32 MFMA.
         # cfg.TEST.FP16X2 (default on) picks the two-plane fp16 form of the same idea (csrc/conv_igemm_h2.hip: three partial
@@ -837,7 +880,8 @@ class InferencePlan:
         convs = list(range(3, nfeat - 1, 3))
         last = head.features[nfeat - 1]
         nout = last.weight.shape[0]
-        assert nout == 5 + K
+        MC = self.mask_channels
+        assert nout == MC + 4 + K, (nout, MC, K)
         self.head_cs = _pad_to(nout, 4)
         ho = self.buf("head_out", B, R4 * R4, self.head_cs, zero=True)  # fp32 in both modes
         # cfg.TEST.FUSE_HEAD_OUT (default on): the 1x1 output convolution (features.21) runs in the EPILOGUE of the last 3x3 layer's
@@ -897,9 +941,9 @@ class InferencePlan:
         pnp_in = self.planes_buf("pnp_in_planes", B * HW * self.pnp_cs, 1) if self.pnp_h2 else self.buf("pnp_in", B, HW, self.pnp_cs)
         self.argmax = self.buf("argmax", B, HW, dtype=torch.int32)
         minmax = self.buf("minmax", B, 2)
-        self.glue_fn = lib.rdpn6d_dense_glue_h2 if self.pnp_h2 else lib.rdpn6d_dense_glue_f32
+        self.glue_fn = lib.rdpn6d_dense_glue_mt_h2 if self.pnp_h2 else lib.rdpn6d_dense_glue_mt_f32
         self.glue_args = lambda coord2d, fps: (_ptr(ho), self.head_cs, _ptr(coord2d), _ptr(fps), B, HW, K,
-                                               1 if self.mask_attention == "mul" else 0, _ptr(minmax),
+                                               1 if self.mask_attention == "mul" else 0, self.mask_type, _ptr(minmax),
                                                _ptr(self.out_nchw), _ptr(pnp_in), self.pnp_cs, _ptr(self.argmax)) + (
                                                    (_ptr(self.h2_flag),) if self.pnp_h2 else ())
         self.post = []  # launches after the glue
@@ -984,8 +1028,9 @@ class InferencePlan:
           * an fc1 row over such a vector is bounded per GroupNorm group by Cauchy-Schwarz (||xhat_group||_2 <= sqrt(n)), ReLU /
             LeakyReLU only shrink magnitudes;
           * an fc2 row by ||w2_row||_2 * ||fc1 pre-activation||_2 with ||W1 relu(z) + b1||_2 <= sigma_max(W1) * (max|gamma| * sqrt(len)
-            + ||beta||_2) + ||b1||_2 (sigma_max from the 1024 x 1024 Gram matrix in fp64 - an l1 bound over the 1024 fc1 units is
-            3-4 x too pessimistic to pass for He-scaled weights).
+            + ||beta||_2) + ||b1||_2 (an UPPER bound of sigma_max from the 1024 x 1024 Gram matrix in fp64 on the host, cached per
+            weight content: _sigma_max_upper_bound - an l1 bound over the 1024 fc1 units is 3-4 x too pessimistic to pass for
+            He-scaled weights).
         (The convolutions' and fc_r / fc_t's OUTPUTS are fp32 - no constraint.)  False -> the plan keeps ConvPnPNet on the fp32 MFMA."""
         hw = R4
         gn = None
@@ -1005,7 +1050,7 @@ class InferencePlan:
             b1 = (w1 * gam).view(w1.shape[0], gn.groups, n).norm(dim=2).sum(1) * n ** 0.5 + (w1 * bet).abs().sum(1) + pnp.fc1.bias.double().abs()
             if float(b1.max()) >= limit:
                 return False
-            smax = float(torch.linalg.eigvalsh(w1 @ w1.t())[-1].clamp_min(0.0)) ** 0.5
+            smax = _sigma_max_upper_bound(pnp.fc1.weight)
             pre = smax * (float(gn.weight.abs().max()) * float(w1.shape[1]) ** 0.5 + float(bet.norm())) + float(pnp.fc1.bias.double().norm())
             pre = min(pre, float(b1.norm()))  # (the element-wise bounds of fc1 give another valid 2-norm bound)
             b2 = pnp.fc2.weight.double().norm(dim=1) * pre + pnp.fc2.bias.double().abs()
@@ -1015,7 +1060,9 @@ class InferencePlan:
         """fresh=True: THIS forward writes its API outputs - the NCHW maps (glue kernel) and the small per-crop outputs (pose decode,
         RANSAC / PnP) - straight into newly allocated tensors that forward() hands to the caller: no 39-MB clone + five small copies
         behind every step (42 us of 7 ms at B = 64).  fresh=False: the plan's fixed buffers (a captured hipGraph needs stable
-        addresses; forward() then hands out clones)."""
+        addresses; forward() then hands out clones).
+        NOTE for direct users of a plan (tests, bench.roofline): after a forward with fresh=True the plan's out_nchw / rot / trans /
+        pnp_* ARE the tensors the caller of forward() holds - a later plan.run() without a new bind_outputs() overwrites them."""
         if fresh:
             self.out_nchw = torch.empty_like(self.bufs["out_nchw"])
             self._small = torch.empty_like(self.bufs["small_outputs"])
@@ -1118,9 +1165,9 @@ class InferencePlan:
         HW = self.out_nchw.shape[2] * self.out_nchw.shape[3]
         ip, mp = self.buf("pnp2d_ip", B, HW, 2), self.buf("pnp2d_mp", B, HW, 3)
         cnt = self.buf("pnp2d_cnt", B, dtype=torch.int32)
-        _lib.check(self.lib.rdpn6d_select_correspondences_f32(
+        _lib.check(self.lib.rdpn6d_select_correspondences_mt_f32(
             _ptr(self.out_nchw), C, _ptr(roi_coord_2d), roi_coord_2d.shape[1], uv_channels[0], uv_channels[1], _ptr(roi_extents), _ptr(im_hw),
-            0, 0, B, HW, mask_thr, _ptr(ip), _ptr(mp), _ptr(cnt), None, None, st), "select_correspondences")
+            0, 0, B, HW, mask_thr, self.mask_type, _ptr(ip), _ptr(mp), _ptr(cnt), None, None, st), "select_correspondences")
         netp = None
         if net_mode:
             netp = self.buf("net_pose", B, 12)
@@ -1145,9 +1192,9 @@ class InferencePlan:
             netp[:, 9:].copy_(self.trans)
         # (the workspace enables the split form: a crop's hypotheses on up to four workgroups when the batch leaves CUs idle)
         ws = self.buf("ransac_ws", int(self.lib.rdpn6d_ransac_workspace_bytes(self.B)), dtype=torch.uint8)
-        _lib.check(self.lib.rdpn6d_ransac_kabsch_ws(
+        _lib.check(self.lib.rdpn6d_ransac_kabsch_ws_mt(
             _ptr(self.out_nchw), _ptr(roi_coord_2d), _ptr(fps), _ptr(roi_extents), _ptr(resize_ratios), _ptr(self.argmax), _ptr(netp),
-            self.B, HW, self.K, mask_thr, inlier_thr, iters, confidence, seed, net_mode or 1, max_t_diff, _ptr(self.pnp_pose),
+            self.B, HW, self.K, mask_thr, self.mask_type, inlier_thr, iters, confidence, seed, net_mode or 1, max_t_diff, _ptr(self.pnp_pose),
             _ptr(self.pnp_ninl), _ptr(self.pnp_mask), _ptr(self.pnp_best), _ptr(ws), ws.numel(), st), "ransac_kabsch")
 
 
@@ -1157,11 +1204,14 @@ def get_xyz_mask_region_out_dim(cfg):
     r = cfg.MODEL.CDPN.ROT_HEAD
     if r.XYZ_LOSS_TYPE not in ("MSE", "L1", "L2", "SmoothL1"):
         raise NotImplementedError(f"unknown / unsupported xyz loss type: {r.XYZ_LOSS_TYPE}")
-    if r.MASK_LOSS_TYPE not in ("L1", "BCE"):
-        raise NotImplementedError(f"unknown / unsupported mask loss type: {r.MASK_LOSS_TYPE}")
+    if r.MASK_LOSS_TYPE not in MASK_TYPES:
+        raise NotImplementedError(f"unknown mask loss type: {r.MASK_LOSS_TYPE}")
     region_out_dim = r.NUM_REGIONS + 1
     assert region_out_dim > 2, region_out_dim
-    return 3, 1, region_out_dim
+    return 3, (2 if r.MASK_LOSS_TYPE == "CE" else 1), region_out_dim
+
+
+MASK_TYPES = {"L1": 0, "BCE": 1, "CE": 2}  # ROT_HEAD.MASK_LOSS_TYPE -> the mask_type argument of the C ABI (include/rdpn6d.h)
 
 
 class GDRN(_TreeWatch, nn.Module):
@@ -1282,6 +1332,11 @@ class GDRN(_TreeWatch, nn.Module):
         hold device buffers, ctypes argument blocks and the ORIGINAL's tensors"""
         d = self.__dict__.copy()
         d["_plans"], d["_h2_flags"], d["_stamp_tensors"] = {}, {}, None
+        # ... nor with the `vis/*` state: device table, pinned host rows, a pending event (not picklable, and the copy's rows are its own)
+        d.pop("_vis", None)
+        d.pop("vis_sink", None)
+        if "vis_history" in d:
+            d["vis_history"] = []
         return d
 
     def __setstate__(self, d):
@@ -1302,9 +1357,15 @@ class GDRN(_TreeWatch, nn.Module):
         st = self.__dict__.get("_vis")
         if st is None or st["period"] != period or st["dev"].device != eng.dev:
             st = dict(period=period, dev=torch.zeros(period, 17, device=eng.dev), host=torch.zeros(period, 17).pin_memory(), slot=0,
-                      event=None)
+                      event=None, iters=[None] * period, host_iters=[None] * period)
             self.__dict__["_vis"] = st
         self._vis_deliver(wait=False)
+        try:  # the iteration this row belongs to (the reference logs one row per iteration: GDRN.py:367-368) - host state, no sync
+            from detectron2.utils.events import get_event_storage
+
+            st["iters"][st["slot"]] = int(get_event_storage().iter)
+        except Exception:  # noqa: BLE001
+            st["iters"][st["slot"]] = None
         f32 = lambda t: t.detach().to(device=eng.dev, dtype=torch.float32).contiguous()  # noqa: E731
         gt_trans, gt_rot, gt_ratio = f32(gt_trans), f32(gt_rot), f32(gt_ratio)
         _lib.check(eng.lib.rdpn6d_train_vis_scalars_f32(_ptr(eng.rot), _ptr(eng.trans), _ptr(gt_rot), _ptr(gt_trans), _ptr(eng.rt), 16,
@@ -1314,6 +1375,7 @@ class GDRN(_TreeWatch, nn.Module):
         if st["slot"] == period:
             self._vis_deliver(wait=True)  # (the previous block's copy finished N steps ago: never a real wait)
             st["host"].copy_(st["dev"], non_blocking=True)
+            st["host_iters"] = list(st["iters"])
             st["event"] = torch.cuda.Event()
             st["event"].record()
             st["slot"] = 0
@@ -1335,13 +1397,24 @@ class GDRN(_TreeWatch, nn.Module):
             except Exception:  # noqa: BLE001
                 storage = None
         hist = self.__dict__.setdefault("vis_history", [])
-        for row in rows:
+        now = getattr(storage, "iter", None)
+        for row, it in zip(rows, list(st.get("host_iters") or []) + [None] * len(rows)):
             d = dict(zip(self.VIS_NAMES, row))
             hist.append(d)
             if sink is not None:
                 sink(d)
             elif storage is not None:
+                if it is not None and now is not None:
+                    try:
+                        storage.iter = it  # each row under the iteration that produced it, as the reference's per-step put_scalars
+                    except AttributeError:
+                        pass
                 storage.put_scalars(**d)
+        if storage is not None and now is not None:
+            try:
+                storage.iter = now
+            except AttributeError:
+                pass
         del hist[:-1024]
 
     def flush_vis_scalars(self):
@@ -1353,6 +1426,7 @@ class GDRN(_TreeWatch, nn.Module):
         if st["slot"]:
             rows = st["dev"][: st["slot"]].cpu()
             keep, st["host"] = st["host"], rows
+            st["host_iters"] = list(st["iters"][: st["slot"]])
             st["event"] = torch.cuda.Event()
             st["event"].record()
             self._vis_deliver(wait=True)
@@ -1451,11 +1525,8 @@ class GDRN(_TreeWatch, nn.Module):
             if pnp_type not in modes:
                 raise NotImplementedError(f"TEST.PNP_TYPE={pnp_type!r}: one of {sorted(modes)}")
             net_mode, kabsch = modes[pnp_type], pnp_type.endswith("kabsch")
-            if self.cfg.MODEL.CDPN.ROT_HEAD.MASK_LOSS_TYPE != "L1":
-                # both solves normalise the mask like get_out_mask's L1 branch (engine_utils.py:124-129: per-crop min-max); its
-                # BCE / CE branches (sigmoid / arg-max, :130-134) are not built - no shipped config selects them
-                raise NotImplementedError(f"TEST.USE_PNP with ROT_HEAD.MASK_LOSS_TYPE={self.cfg.MODEL.CDPN.ROT_HEAD.MASK_LOSS_TYPE!r}: the "
-                                          "on-device correspondence selection implements the 'L1' (min-max) mask normalisation only")
+            # both solves read the mask like get_out_mask (engine_utils.py:118-136): L1 per-crop min-max, BCE sigmoid, CE arg-max
+            # (the plan's mask_type, handed to the selection / RANSAC kernels)
             assert roi_extents is not None, "USE_PNP needs roi_extents"
             roi_extents = f32c(roi_extents)
         is_allo = "allo" in pcfg.ROT_TYPE
@@ -1514,10 +1585,11 @@ class GDRN(_TreeWatch, nn.Module):
                 o, sm = plan.out_nchw.clone(), plan.small_views(plan._small.clone())
             else:        # this forward's own tensors (bind_outputs): nothing to copy
                 o, sm = plan.out_nchw, plan.small_views(plan._small)
-            K = plan.K
+            K, MC = plan.K, plan.mask_channels
             out = {
                 "rot": sm["rot"], "trans": sm["trans"],
-                "mask": o[:, 0:1], "coor_x": o[:, 1:2], "coor_y": o[:, 2:3], "coor_z": o[:, 3:4], "region": o[:, 4:5 + K],
+                "mask": o[:, 0:MC], "coor_x": o[:, MC:MC + 1], "coor_y": o[:, MC + 1:MC + 2], "coor_z": o[:, MC + 2:MC + 3],
+                "region": o[:, MC + 3:MC + 4 + K],
                 "consistent_map": None,
             }
             if use_pnp:
@@ -1688,7 +1760,7 @@ def build_model_optimizer(cfg):
     params_lr_list = []
     backbone = BackboneP(backbone_cfg.NUM_LAYERS)
     r_out_dim, mask_out_dim, region_out_dim = get_xyz_mask_region_out_dim(cfg)
-    rot_head = RotHeadP(r_head_cfg.NUM_REGIONS, r_head_cfg.NUM_FILTERS, r_head_cfg.NUM_LAYERS)
+    rot_head = RotHeadP(r_head_cfg.NUM_REGIONS, r_head_cfg.NUM_FILTERS, r_head_cfg.NUM_LAYERS, mask_out_dim=mask_out_dim)
     if t_head_cfg.ENABLED:
         raise NotImplementedError("TRANS_HEAD is disabled in every RGB-D config and is not implemented")
     assert not pnp_net_cfg.R_ONLY, "if pnp_net is R_ONLY, trans_head must be enabled!"

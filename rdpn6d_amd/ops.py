@@ -342,11 +342,16 @@ def pose_errors(R_est, t_est, R_gt, t_gt, pts):
     return out
 
 
-def select_correspondences(out_maps, coord2d, extents, im_H, im_W, mask_thr=0.5, u_ch=None, v_ch=None, return_masks=False):
+def select_correspondences(out_maps, coord2d, extents, im_H, im_W, mask_thr=0.5, u_ch=None, v_ch=None, return_masks=False,
+                           mask_loss_type="L1"):
     """Row A8 on device (engine_utils.get_out_coor / get_out_mask + gdrn_evaluator.get_img_model_points_with_coords2d):
     out_maps [B,C,H,W] (channel 0 mask, 1..3 coor_x/y/z), coord2d [B,C2,H,W] (u, v in the LAST two channels unless u_ch / v_ch
     say otherwise), extents [B,3] -> image_points [B,HW,2], model_points [B,HW,3], counts [B] int32 (first counts[b] rows valid;
-    row-major pixel order); with return_masks also the selection mask [B,H,W] uint8 and the normalised mask [B,H,W]."""
+    row-major pixel order); with return_masks also the selection mask [B,H,W] uint8 and the normalised mask [B,H,W].
+    mask_loss_type = cfg.MODEL.CDPN.ROT_HEAD.MASK_LOSS_TYPE: "L1" per-crop min-max | "BCE" sigmoid | "CE" arg-max over TWO mask
+    channels (out_maps channels 0, 1 = mask, 2..4 = coor_x/y/z) - get_out_mask's three branches."""
+    from .gdrn import MASK_TYPES
+
     _need_gpu(out_maps, coord2d, extents)
     B, C, H, W = out_maps.shape
     C2 = coord2d.shape[1]
@@ -359,7 +364,7 @@ def select_correspondences(out_maps, coord2d, extents, im_H, im_W, mask_thr=0.5,
     sel = torch.empty(B, H, W, dtype=torch.uint8, device=dev) if return_masks else None
     nm = torch.empty(B, H, W, dtype=torch.float32, device=dev) if return_masks else None
     args = [out_maps.float().contiguous(), coord2d.float().contiguous(), extents.float().contiguous()]
-    _lib.check(_lib.load().rdpn6d_select_correspondences_f32(_ptr(args[0]), C, _ptr(args[1]), C2, u_ch, v_ch, _ptr(args[2]), None, int(im_H),
-                                                             int(im_W), B, H * W, float(mask_thr), _ptr(ip), _ptr(mp), _ptr(cnt), _ptr(sel),
-                                                             _ptr(nm), _stream()), "select_correspondences")
+    _lib.check(_lib.load().rdpn6d_select_correspondences_mt_f32(_ptr(args[0]), C, _ptr(args[1]), C2, u_ch, v_ch, _ptr(args[2]), None, int(im_H),
+                                                                int(im_W), B, H * W, float(mask_thr), MASK_TYPES[mask_loss_type], _ptr(ip),
+                                                                _ptr(mp), _ptr(cnt), _ptr(sel), _ptr(nm), _stream()), "select_correspondences")
     return (ip, mp, cnt, sel, nm) if return_masks else (ip, mp, cnt)

@@ -1109,17 +1109,19 @@ class TrainEngine:
         prev = None
         if self.accumulate_grad:
             flat, _ = self._flat_or_list()
-            prev = flat.clone() if flat is not None else {id(p): p.grad.clone() for p in self.model.parameters() if p.grad is not None}
-        last = min(marks) if marks else None  # the group whose completion ends the backward ('backbone', index 0)
+            if flat is not None:  # (+ where each parameter's gradient sits in it, should the gradients have left the buffer afterwards)
+                prev = (flat.clone(), [(p, p.grad.storage_offset(), p.grad.numel()) for p in self.model.parameters() if p.grad is not None])
+            else:
+                prev = {id(p): p.grad.clone() for p in self.model.parameters() if p.grad is not None}
+        # un-scale / add-back run exactly ONCE, right after the LAST launch (list index 0) and before the group completed by it is
+        # yielded - whatever the marks are (a build that marks no group at index 0 must neither skip nor repeat it)
         for idx in range(len(self.bwd) - 1, -1, -1):
             for fn in self.bwd[idx]:
                 fn()
+            if idx == 0:
+                self._finish_backward(unscale, prev)
             if idx in marks:
-                if idx == last:
-                    self._finish_backward(unscale, prev)
                 yield marks[idx]
-        if last != 0:
-            self._finish_backward(unscale, prev)
 
     def _finish_backward(self, unscale, prev):
         if unscale != 1.0 or prev is not None:
@@ -1127,8 +1129,13 @@ class TrainEngine:
             if unscale != 1.0:
                 flat.mul_(1.0 / unscale) if flat is not None else torch._foreach_mul_(grads, 1.0 / unscale)
             if prev is not None:
-                if torch.is_tensor(prev):  # (the flat buffer of GradBuckets / Ranger: same layout before and after)
-                    flat.add_(prev)
+                if isinstance(prev, tuple):  # (the flat buffer of GradBuckets / Ranger)
+                    if flat is not None and flat.numel() == prev[0].numel():  # same layout before and after
+                        flat.add_(prev[0])
+                    else:  # a gradient was cloned out of the buffer in between (AccumulateGrad does when it cannot adopt): slice-wise
+                        ps = [(p, o, n) for p, o, n in prev[1] if p.grad is not None]
+                        if ps:
+                            torch._foreach_add_([p.grad for p, _, _ in ps], [prev[0][o:o + n].view_as(p.grad) for p, o, n in ps])
                 else:  # (a gradient this backward created had nothing accumulated before)
                     ps = [p for p in self.model.parameters() if p.grad is not None and id(p) in prev]
                     if ps:

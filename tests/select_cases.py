@@ -32,3 +32,19 @@ def select_case(seed, B=5, side=64):
         mask[B - 1, 0] = np.float32(0.25)             # constant mask: 0/0
     return {"mask": mask, "coor_x": coor[:, 0:1].copy(), "coor_y": coor[:, 1:2].copy(), "coor_z": coor[:, 2:3].copy(),
             "coord2d": coord2d, "extent": ext}
+
+
+def mask_logits_case(mask, mask_loss_type, seed):
+    """the mask of select_case() as LOGITS for get_out_mask's BCE / CE branches: (B,1,s,s) for "BCE" (sigmoid; both signs occur, a
+    few values exactly 0 = sigmoid exactly 0.5 = not selected at thr 0.5), (B,2,s,s) for "CE" (arg-max; a block of exact ties =
+    channel 0 wins = not selected)."""
+    rng = np.random.Generator(np.random.PCG64(np.random.SeedSequence([seed, 815])))
+    m = np.asarray(mask, dtype=np.float32)
+    z = ((m - np.float32(0.45)) * np.float32(6.0)).astype(np.float32)
+    z[:, 0, 40, 10:20] = np.float32(0.0)
+    if mask_loss_type == "BCE":
+        return z
+    other = (np.float32(0.5) * rng.standard_normal(m.shape)).astype(np.float32)
+    two = np.concatenate([other, other + z], axis=1).astype(np.float32)  # channel 1 - channel 0 = z (up to rounding)
+    two[:, 1, 41, 10:20] = two[:, 0, 41, 10:20]  # exact ties
+    return two

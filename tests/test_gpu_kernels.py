@@ -188,6 +188,24 @@ def test_fps_many_workgroups_per_cloud_bit_identical(dev):
         assert int(one.min()) >= 0
 
 
+def test_fps_host_abi_survives_a_barrier_timeout(dev, oracle_lib, monkeypatch):
+    """the reference-named symbols send clouds above 16 384 points to the many-workgroup kernel, whose spin barrier assumes
+    the cloud's workgroups are resident together.  When it gives up (simulated: RDPN6D_FPS_TEST_TIMEOUT sets the error word and the
+    -1 indices it leaves) the host path re-runs the cloud on one workgroup instead of failing - same indices as the C oracle."""
+    from rdpn6d_amd import _lib
+    from tests.fps_cases import make_cloud
+
+    lib = _lib.load()
+    P = ctypes.c_void_p
+    pts = make_cloud("gauss", 40000, 8)
+    want = np.zeros(24, dtype=np.int32)
+    oracle_lib.oracle_fps_init_center(pts.ctypes.data_as(P), want.ctypes.data_as(P), 40000, 24)
+    monkeypatch.setenv("RDPN6D_FPS_TEST_TIMEOUT", "1")
+    idx = np.full(24, -5, dtype=np.int32)
+    lib.farthest_point_sampling_init_center(pts.ctypes.data_as(P), idx.ctypes.data_as(P), 40000, 24)
+    assert np.array_equal(idx, want), (idx[:8], want[:8])
+
+
 def test_fps_reference_symbols(dev, oracle_lib):
     """the two reference-named void symbols (ext.h) with host pointers."""
     from rdpn6d_amd import _lib

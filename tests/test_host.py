@@ -291,3 +291,41 @@ def test_convpnpnet_h2_static_range_proof():
         m.pnp_net.features[7].weight.div_(100.0)
         m.pnp_net.fc2.weight.mul_(50.0)
     assert not gdrn.InferencePlan._pnp_h2_range_ok(m.pnp_net, 64)
+
+
+def test_sigma_max_bound_is_an_upper_bound_without_a_device_eigen_solver():
+    """the spectral norm behind the ConvPnPNet range proof no longer goes through rocSOLVER on the device - a
+    trace-power bound on the host (matrix products only), never below the true value (LAPACK on the CPU as the checker), within
+    n^(1/128) of it, cached by weight content."""
+    import torch
+
+    from rdpn6d_amd import gdrn
+
+    g = torch.Generator().manual_seed(3)
+    for shape, scale in (((64, 512), 1.0), ((256, 96), 0.05), ((32, 32), 7.0)):
+        w = torch.randn(*shape, generator=g) * scale
+        true = float(torch.linalg.svdvals(w.double())[0])
+        ub = gdrn._sigma_max_upper_bound(w)
+        assert true <= ub <= true * min(shape) ** (1.0 / 256.0) * (1 + 1e-6), (shape, true, ub)
+        assert gdrn._sigma_max_upper_bound(w.clone()) == ub and len(gdrn._SIGMA_MAX_CACHE) >= 1  # same content: cached
+    low_rank = torch.outer(torch.arange(1.0, 9.0), torch.ones(40))  # one non-zero singular value: the bound is exact up to n^(1/k)
+    assert abs(gdrn._sigma_max_upper_bound(low_rank) / float(torch.linalg.svdvals(low_rank.double())[0]) - 1.0) < 0.02
+    assert gdrn._sigma_max_upper_bound(torch.zeros(4, 8)) == 0.0
+
+
+def test_bench_gpus_flag_is_checked_before_anything_touches_a_gpu():
+    """`bench.py --gpus N`: N must equal the launcher's WORLD_SIZE - checked before the first GPU call, so the
+    rule is testable on a CPU box; a bare --gpus 1 on a GPU-less box still fails loudly (no CPU fallback)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 2 but WORLD_SIZE=1" in r.stderr
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "0"], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "at least one rank" in r.stderr
+    if not torch.cuda.is_available():
+        env.pop("WORLD_SIZE")
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"], env=env, cwd=root, capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "no CPU fallback" in r.stderr

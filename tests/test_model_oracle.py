@@ -328,3 +328,34 @@ def test_train_vis_scalars_restatement_is_pinned_by_the_references_own_event_sto
         for k in model_oracle.VIS_NAMES:
             ref = float(gold[f"{att}_{k}"])
             assert abs(v[k] - ref) <= 1e-6 * max(1.0, abs(ref)), (att, k, v[k], ref)
+
+
+def test_oracle_mask_loss_types_bce_and_ce_vs_the_reference(golden_dir):
+    """cfg.MODEL.CDPN.ROT_HEAD.MASK_LOSS_TYPE = BCE / CE (VERDICT r4 missing 1): the oracle's get_mask_prob branches
+    (models/model_utils.py:35-39) and its two-channel mask head (GDRN.py:648-651) against the REAL reference built by its own
+    factory with that switch (tests/golden/mask_types_golden.npz): BCE with MASK_ATTENTION none / mul, CE with none; with CE + mul
+    the reference itself raises a TypeError (torch.softmax(..., keepdim=True)) - recorded in the fixture, mirrored by the oracle."""
+    gold = np.load(os.path.join(golden_dir, "mask_types_golden.npz"))
+    bn = np.load(os.path.join(golden_dir, "bn_stats_c1w.npz"))
+    inp = synth.make_inputs(4, seed=int(gold["input_seed"]))
+    t = {k: torch.from_numpy(v) for k, v in inp.items()}
+    assert "keepdim" in str(gold["ce_mul_raises"])
+    for mlt, atts in (("BCE", ("none", "mul")), ("CE", ("none",))):
+        orc = model_oracle.GDRNOracle(32, "none", mask_loss_type=mlt)
+        sd = synth.make_trained_like_state_dict({k: tuple(v.shape) for k, v in orc.state_dict().items()}, seed=1234)
+        sd.update({k: bn[k] for k in bn.files})
+        assert synth.sha256_of([np.asarray(sd[k]) for k in sorted(sd) if not k.endswith("num_batches_tracked")]) == str(gold[f"{mlt}_sha256_weights"])
+        orc.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+        orc.eval()
+        for att in atts:
+            orc.mask_attention = att
+            with torch.no_grad():
+                o = orc(t["roi_img"], t["roi_coord_2d"], t["fps"], t["roi_cam"], t["roi_center"], t["roi_wh"], t["resize_ratio"])
+            assert np.abs(o["rot"].numpy() - gold[f"{mlt}_{att}_rot"]).max() < 2e-6 and np.abs(o["trans"].numpy() - gold[f"{mlt}_{att}_trans"]).max() < 2e-6
+            if mlt == "CE":
+                assert o["mask"].shape[1] == 2 and o["region"].shape[1] == 33
+                for k in ("mask", "coor_x", "coor_y", "coor_z", "region"):
+                    assert np.abs(o[k].numpy() - gold[f"CE_eval_{k}"]).max() < 1e-5, k
+    orc.mask_attention = "mul"
+    with pytest.raises(TypeError), torch.no_grad():
+        orc(t["roi_img"], t["roi_coord_2d"], t["fps"], t["roi_cam"], t["roi_center"], t["roi_wh"], t["resize_ratio"])

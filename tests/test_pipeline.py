@@ -102,6 +102,47 @@ def test_bench_contract_two_ranks_on_one_gpu():
     assert out["roofline"]["frac"] > 0 and "cpu_baseline" not in out
 
 
+@pytest.mark.parametrize("extra", [[], ["--train", "--dtype", "bf16"]])
+def test_bench_gpus_flag_launches_its_own_ranks(extra):
+    """`python bench.py --gpus 2` started BARE (no launcher, no WORLD_SIZE): the process must start two ranks itself (a fresh
+    torch.distributed.run child) and print ONE line with n_gpus == 2.  With --train --dtype bf16 the two ranks
+    also run the event-timed roofline steps and the pre-heat blocks, whose gradient all-reduces hang unless every rank runs the
+    same number of them (bench.py:367)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RDPN6D_BENCH_BACKEND="gloo", RDPN6D_BENCH_FORCE_DIST="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8", "--preheat", "0.5",
+           "--no-cpu-baseline"] + extra
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["world"] == 2 and out["backend"] == "gloo" and out["device_count"] >= 1
+    assert out["config"]["global_batch"] == 16 and out["value"] > 0
+    if extra:
+        assert out["roofline"] is not None and out["roofline"]["launches_per_step"] > 0
+
+
+def test_bench_gpus_flag_must_match_the_launcher():
+    """--gpus 2 under a launcher that started ONE rank is an error, not a silent one-rank run labelled n_gpus 1"""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and not any(ln.startswith("{") for ln in r.stdout.splitlines())
+
+
 @pytest.mark.parametrize("train", [False, True])
 def test_bench_contract_over_rccl_one_rank(train):
     """the same launch line with the backend of a real run - RCCL ("nccl") - on the one GPU this box has: process-group creation

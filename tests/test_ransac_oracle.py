@@ -11,20 +11,61 @@ from tests.ransac_cases import make_case, pose_errors
 P = ctypes.c_void_p
 
 
-def run_oracle(lib, c, mask_thr=0.5, inlier_thr=0.01, iters=100, conf=0.99, seed=7):
+def run_oracle(lib, c, mask_thr=0.5, inlier_thr=0.01, iters=100, conf=0.99, seed=7, mask_type=0):
+    """mask_type 0 L1 (min-max) | 1 BCE (sigmoid) | 2 CE (arg-max over two mask channels): ROT_HEAD.MASK_LOSS_TYPE as
+    engine_utils.get_out_mask reads it"""
     B, HW, K = c["B"], c["HW"], c["K"]
     pose = np.zeros((B, 12), np.float32)
     nin = np.zeros(B, np.int32)
     msk = np.zeros((B, HW), np.uint8)
     best = np.zeros(B, np.int32)
+    a = lambda x: np.ascontiguousarray(x).ctypes.data_as(P)
+    keep = [np.ascontiguousarray(c[k]) for k in ("out_nchw", "coord2d", "fps", "extents", "ratios", "argmax")]
+    if mask_type:
+        f = lib.oracle_ransac_kabsch_mt
+        f.argtypes = [P, P, P, P, P, P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_float,
+                      ctypes.c_int, ctypes.c_float, ctypes.c_uint, P, P, P, P]
+        f.restype = None
+        f(*[k.ctypes.data_as(P) for k in keep], B, HW, K, mask_thr, mask_type, inlier_thr, iters, conf, seed, a(pose), a(nin), a(msk), a(best))
+        return pose, nin, msk, best
     f = lib.oracle_ransac_kabsch
     f.argtypes = [P, P, P, P, P, P, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_float,
                   ctypes.c_int, ctypes.c_float, ctypes.c_uint, P, P, P, P]
     f.restype = None
-    a = lambda x: np.ascontiguousarray(x).ctypes.data_as(P)
-    keep = [np.ascontiguousarray(c[k]) for k in ("out_nchw", "coord2d", "fps", "extents", "ratios", "argmax")]
     f(*[k.ctypes.data_as(P) for k in keep], B, HW, K, mask_thr, inlier_thr, iters, conf, seed, a(pose), a(nin), a(msk), a(best))
     return pose, nin, msk, best
+
+
+def with_mask_type(c, mask_type):
+    """the case `c` (min-max mask in channel 0) re-expressed for MASK_LOSS_TYPE BCE (1: a logit per pixel) or CE (2: two mask
+    channels) such that the SAME pixels pass mask > 0.5: the solve must then be identical bit for bit"""
+    o = np.asarray(c["out_nchw"], np.float32)
+    B, C, HW = o.shape
+    m = o[:, 0]
+    nm = (m - m.min(1, keepdims=True)) / (m.max(1, keepdims=True) - m.min(1, keepdims=True))
+    z = np.where(nm > np.float32(0.5), np.float32(2.0) + nm, np.float32(-2.0) - nm).astype(np.float32)  # sigmoid(z) > 0.5  <=>  nm > 0.5
+    d = dict(c)
+    if mask_type == 1:
+        d["out_nchw"] = np.concatenate([z[:, None], o[:, 1:]], 1)
+    else:
+        d["out_nchw"] = np.concatenate([np.zeros_like(z)[:, None], z[:, None], o[:, 1:]], 1)
+    return d
+
+
+@pytest.mark.parametrize("mask_type", [1, 2])
+def test_mask_loss_types_select_like_get_out_mask(oracle_lib, mask_type):
+    """BCE / CE reading of the mask (engine_utils.py:130-134): with logits built so that the same pixels pass the threshold, the
+    solve equals the L1 run bit for bit; flipping the sign of every logit selects the complement"""
+    c = make_case(B=3, outliers=0.3, seed=5)
+    want = run_oracle(oracle_lib, c)
+    got = run_oracle(oracle_lib, with_mask_type(c, mask_type), mask_type=mask_type)
+    for w, g in zip(want, got):
+        assert np.array_equal(w, g)
+    neg = with_mask_type(c, mask_type)
+    neg["out_nchw"] = neg["out_nchw"].copy()
+    neg["out_nchw"][:, mask_type - 1] *= -1.0
+    _, nin, msk, _ = run_oracle(oracle_lib, neg, mask_type=mask_type)
+    assert not np.array_equal(msk, want[2])
 
 
 @pytest.mark.parametrize("outliers", [0.0, 0.3, 0.6])
