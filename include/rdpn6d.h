@@ -169,6 +169,14 @@ int rdpn6d_conv2d_h2_cb(const rdpn6d_conv_desc* d, void* y_h2, const void* res_h
  * rdpn6d_conv_h2_workspace_bytes = what the layer wants (0: it does not split); launches of one stream can share a buffer; without
  * a (large enough) workspace the call is rdpn6d_conv2d_h2_cb. */
 long long rdpn6d_conv_h2_workspace_bytes(const rdpn6d_conv_desc* d);
+/* Weights once more, FRAGMENT-MAJOR, for the kernels that load their weight fragments straight from L2 instead of staging the weight
+ * tile through LDS (the LDS port is what bounds the trunk's K loops; layer3 at B = 64): rdpn6d_h2_weight_frag re-orders an h2 weight
+ * tensor [Npad][ntaps][cchunks][hi x 32 | lo x 32] into [Npad/32][ntaps][cchunks][slot 0..7][row 0..31][8 halfs] (same bytes);
+ * rdpn6d_conv_h2_wfrag_wanted says whether a layer's kernel has that form; rdpn6d_conv2d_h2_wf = rdpn6d_conv2d_h2 + the re-ordered
+ * weights (null or an unwanted w_frag: the ordinary kernel).  Results are bit-identical with and without. */
+int rdpn6d_conv_h2_wfrag_wanted(const rdpn6d_conv_desc* d);
+int rdpn6d_h2_weight_frag(const void* w_h2, int Npad, int ntaps, int cchunks, void* w_frag, void* stream);
+int rdpn6d_conv2d_h2_wf(const rdpn6d_conv_desc* d, void* y_h2, const void* res_h2, int* overflow_flag, const void* w_frag, void* stream);
 int rdpn6d_conv2d_h2_ws(const rdpn6d_conv_desc* d, void* y_h2, const void* res_h2, int* overflow_flag, const float* crop_bias,
                         void* workspace, long long workspace_bytes, void* stream);
 /* The same convolution with a 1x1 OUTPUT convolution fused into its epilogue - the dense head's last 3x3 layer + features.21

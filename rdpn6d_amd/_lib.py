@@ -152,6 +152,9 @@ SIGNATURES = {
     "rdpn6d_conv_h2_fuse1x1_ok": (_i, [ctypes.POINTER(ConvDesc)]),
     "rdpn6d_conv2d_h2_fuse1x1": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "rdpn6d_conv_h2_workspace_bytes": (ctypes.c_longlong, [_vp]),
+    "rdpn6d_conv_h2_wfrag_wanted": (_i, [ctypes.POINTER(ConvDesc)]),
+    "rdpn6d_h2_weight_frag": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "rdpn6d_conv2d_h2_wf": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
     "rdpn6d_ransac_pnp_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _f, ctypes.c_uint, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "rdpn6d_select_correspondences_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rdpn6d_select_correspondences_mt_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -27,6 +27,9 @@ struct ConvH2Args {
     const float* fuse_bias;
     float* fuse_out;
     int fuse_cs, fuse_n;
+    // the weights once more, FRAGMENT-MAJOR ([Npad/32][ntaps][Cin/32][slot 0..7][row 0..31][8 halfs]: rdpn6d_h2_weight_frag), for the kernels
+    // that load their weight fragments straight from L2 instead of staging the weight tile through LDS (conv_igemm_h2_pp.hip, BFG); null = none
+    const void* w_frag;
 };
 
 

@@ -977,6 +977,14 @@ static int h2_tile_ksplit(const rdpn6d_conv_desc* d, long long M, int bm, int bn
     return best;
 }
 
+// shapes of the ping-pong kernel that have a weights-from-L2 form (conv_igemm_h2_pp.hip, BFG): the 128x128 tile (layer3 at B = 64);
+// RDPN6D_H2_BFG = 0 switches it off, = 2 adds the 256x128 tile (profiling)
+static bool h2_wfrag_shape_ok(int shape)
+{
+    static const int mode = getenv("RDPN6D_H2_BFG") ? atoi(getenv("RDPN6D_H2_BFG")) : 1;
+    return mode >= 1 && (shape == 0 || (mode >= 2 && shape == 2));
+}
+
 // which h2 kernel rdpn6d_conv2d_h2 would use: 2 = 256x256 eight-phase, 1 = 128x128..64x64 tile kernel, 0 = not eligible
 extern "C" int rdpn6d_conv_h2_kernel_for(const rdpn6d_conv_desc* d)
 {
@@ -1018,12 +1026,55 @@ struct H2Fuse {
     int cs, n;
 };
 static int conv2d_h2_impl(const rdpn6d_conv_desc* d, void* y_h2, const void* res_h2, int* overflow_flag, const float* crop_bias,
-                          void* workspace, long long workspace_bytes, const H2Fuse* fuse, void* stream);
+                          void* workspace, long long workspace_bytes, const H2Fuse* fuse, void* stream, const void* w_frag = nullptr);
 
 extern "C" int rdpn6d_conv2d_h2_ws(const rdpn6d_conv_desc* d, void* y_h2, const void* res_h2, int* overflow_flag, const float* crop_bias,
                                    void* workspace, long long workspace_bytes, void* stream)
 {
     return conv2d_h2_impl(d, y_h2, res_h2, overflow_flag, crop_bias, workspace, workspace_bytes, nullptr, stream);
+}
+
+// Does this layer's kernel take its weights FRAGMENT-MAJOR (rdpn6d_h2_weight_frag) next to the row-major h2 tensor?  1: pass them to
+// rdpn6d_conv2d_h2_wf; the call works without them (the kernel then stages the weight tile through LDS like every other).
+extern "C" int rdpn6d_conv_h2_wfrag_wanted(const rdpn6d_conv_desc* d)
+{
+    if (!d || rdpn6d_conv_h2_kernel_for(d) != 1) return 0;
+    int bm, bn;
+    const int shape = h2_pp_plan(d, (long long)d->B * d->Ho * d->Wo, &bm, &bn);
+    return shape >= 0 && h2_wfrag_shape_ok(shape) ? 1 : 0;
+}
+
+extern "C" int rdpn6d_conv2d_h2_wf(const rdpn6d_conv_desc* d, void* y_h2, const void* res_h2, int* overflow_flag, const void* w_frag,
+                                   void* stream)
+{
+    return conv2d_h2_impl(d, y_h2, res_h2, overflow_flag, nullptr, nullptr, 0, nullptr, stream, w_frag);
+}
+
+// h2 weight tensor [Npad][ntaps][cchunks][hi x 32 | lo x 32] fp16 (gdrn.pack_h2_weight; a 128-byte record = eight 16-byte slots) ->
+// fragment-major [Npad / 32][ntaps][cchunks][slot 0..7][row 0..31][8 halfs]: the 16-byte fragment slot s of the 32 rows of a block
+// contiguous, so that a wave's fragment load (lane l: row l & 31, slot 2 j + (l >> 5)) is ONE 1-KiB run.  Npad % 32 == 0.
+__global__ void h2_weight_frag_kernel(const uint4* __restrict__ w, uint4* __restrict__ out, int ntaps, int cchunks, long long nslots)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // destination slot index
+    if (i >= nslots) return;
+    const int r = (int)(i & 31), sl = (int)((i >> 5) & 7);
+    const long long blk = i >> 8;  // (n32 * ntaps + tap) * cchunks + cc
+    const int cc = (int)(blk % cchunks);
+    const long long t2 = blk / cchunks;
+    const int tap = (int)(t2 % ntaps);
+    const long long n32 = t2 / ntaps;
+    out[i] = w[(((n32 * 32 + r) * ntaps + tap) * cchunks + cc) * 8 + sl];
+}
+
+extern "C" int rdpn6d_h2_weight_frag(const void* w_h2, int Npad, int ntaps, int cchunks, void* w_frag, void* stream)
+{
+    RD_REQUIRE(w_h2 && w_frag && w_h2 != w_frag, "null pointer / in place");
+    RD_REQUIRE(Npad > 0 && Npad % 32 == 0 && ntaps >= 1 && cchunks >= 1, "shape (Npad % 32)");
+    const long long nslots = (long long)Npad * ntaps * cchunks * 8;
+    hipLaunchKernelGGL(h2_weight_frag_kernel, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint4*)w_h2, (uint4*)w_frag, ntaps, cchunks, nslots);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
 }
 
 // The convolution with a 1x1 output convolution fused into its epilogue (the dense head's last 3x3 layer + features.21,
@@ -1050,7 +1101,7 @@ extern "C" int rdpn6d_conv2d_h2_fuse1x1(const rdpn6d_conv_desc* d, const void* r
 }
 
 static int conv2d_h2_impl(const rdpn6d_conv_desc* d, void* y_h2, const void* res_h2, int* overflow_flag, const float* crop_bias,
-                          void* workspace, long long workspace_bytes, const H2Fuse* fuse, void* stream)
+                          void* workspace, long long workspace_bytes, const H2Fuse* fuse, void* stream, const void* w_frag)
 {
     RD_REQUIRE(d && d->x && d->w && (d->y || y_h2 || fuse), "null pointer");
     const int which = rdpn6d_conv_h2_kernel_for(d);
@@ -1088,6 +1139,7 @@ static int conv2d_h2_impl(const rdpn6d_conv_desc* d, void* y_h2, const void* res
     ax.fuse_out = fuse ? fuse->out : nullptr;
     ax.fuse_cs = fuse ? fuse->cs : 0;
     ax.fuse_n = fuse ? fuse->n : 0;
+    ax.w_frag = nullptr;
     ax.nsplit = 1;
     ax.mpad = 0;
     a.dy_pack = a.dx_pack = 0;
@@ -1105,6 +1157,7 @@ static int conv2d_h2_impl(const rdpn6d_conv_desc* d, void* y_h2, const void* res
         if (shape >= 0) {
             a.mtiles = rd_cdiv(a.M, bm);
             a.ntiles = d->Npad / bn;
+            ax.w_frag = h2_wfrag_shape_ok(shape) ? w_frag : nullptr;  // fragment-major weights: the kernel loads its weight fragments from L2
             const int rc = conv_h2_launch_pp(ax, shape, s);
             if (rc != RDPN6D_OK) return rc;
             RD_LAUNCH_CHECK();

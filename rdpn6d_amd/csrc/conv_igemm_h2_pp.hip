@@ -40,14 +40,25 @@ extern "C" int rdpn6d_debug_h2pp_probe(void* buf)
 
 namespace {
 
-template <int BM, int BN, int WM, int WN, int NST, int PM>
+// BFG (round 5, "B from global"): the weight fragments do not pass through LDS.  The probe of the plain form says the K loop is bound by
+// the CU's LDS port - per 32-channel chunk a 128x128 tile moves 32 KiB of DMA into LDS and its eight waves read 96 KiB of fragments out
+// of it: 1 024 cycles at 128 B/clk against 768 cycles of MFMA.  A third of that traffic is the weight tile (16 KiB in, 32 KiB out), and
+// weights are static: packed FRAGMENT-MAJOR at plan time ([n/32][tap][chunk][slot 0..7][row 0..31][16 B]: rdpn6d_h2_weight_frag), the
+// four 16-byte fragments a lane feeds to the MFMAs of a chunk are four fully coalesced 1-KiB wave loads (lane * 16 bytes apart) straight
+// into registers - two chunks ahead through a three-slot register ring, so the loop is unrolled three times.  LDS then carries the
+// activation tile only (16 KiB in, 64 KiB out per chunk: 640 cycles), the vector-memory path the activation DMA plus the weight
+// fragments (48 KiB per chunk at 64 B/clk: 768 cycles) and the matrix pipe its 768 cycles - three balanced paths instead of one
+// overloaded.  Same k order per accumulator: results bit-identical to the plain form.
+template <int BM, int BN, int WM, int WN, int NST, int PM, bool BFG = false>
 __global__ __launch_bounds__(512) void conv_h2_pp_kernel(const ConvH2Args ax)
 {
     constexpr int RB = 128, RPP = 8, NW = 8;
     constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
-    constexpr int AG = BM / RPP / NW, BG = BN / RPP / NW;  // LDS-DMA pieces per wave and chunk
+    constexpr int AG = BM / RPP / NW, BG = BFG ? 0 : BN / RPP / NW;  // LDS-DMA pieces per wave and chunk
+    constexpr int NB = BFG ? 4 * TN : 0;                              // BFG: 16-byte weight-fragment loads per wave and chunk
     constexpr int P = AG + BG, PL = P - PM, D = NST - 1;
-    static_assert(WM * WN == NW && WM == 2 && TM >= 1 && TN >= 1 && AG >= 1 && BG >= 1, "wave grid / tile");
+    constexpr int Q = P + NB;                                         // entries of the wave's vmcnt queue per chunk
+    static_assert(WM * WN == NW && WM == 2 && TM >= 1 && TN >= 1 && AG >= 1 && (BFG || BG >= 1), "wave grid / tile");
     static_assert(PM >= 0 && PM <= 2 && PL >= 1 && D >= 2, "pieces in the MFMA part; at least three stages");
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     unsigned char* As = smem;
@@ -98,7 +109,7 @@ __global__ __launch_bounds__(512) void conv_h2_pp_kernel(const ConvH2Args ax)
         }
         a_mask[i] = mask;
     }
-    unsigned w_off[BG];
+    unsigned w_off[BG > 0 ? BG : 1];
 #pragma unroll
     for (int i = 0; i < BG; ++i) {
         const int row = (wave + NW * i) * RPP + prow;
@@ -106,7 +117,7 @@ __global__ __launch_bounds__(512) void conv_h2_pp_kernel(const ConvH2Args ax)
         w_off[i] = (unsigned)(n0 + row) * (unsigned)a.Ktot * 4u + (unsigned)lslot * 16u;
     }
     const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.x), 0, a.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.w), 0, a.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(BFG ? ax.w_frag : (const void*)d.w), 0, a.w_bytes, 0x00020000);
 
     unsigned dma_off[P];
     auto stage_addr = [&](const int tap, const int cc, const bool valid) {
@@ -191,7 +202,24 @@ __global__ __launch_bounds__(512) void conv_h2_pp_kernel(const ConvH2Args ax)
 
     // ---- fragment addressing
     const int half = lane >> 5;
-    u32x4 fa[TM][4], fb[TN][4];
+    u32x4 fa[TM][4], fb[BFG ? 3 * TN : TN][4];  // BFG: ring of three chunks (slot s holds chunk k with k % 3 == s)
+    // BFG: the fragments of 32-column block (n0 + wn * WTN) / 32 + jn, chunk (tap, cc): 4 KiB at ((n32 * ntaps + tap) * cchunks + cc) * 4096,
+    // fragment j of lane l at + j * 1024 + l * 16
+    const unsigned wf_lane = (unsigned)lane * 16u;
+    const unsigned wf_n32 = (unsigned)(n0 + wn * WTN) / 32u;
+    auto load_bfrags = [&](auto slotc, const int tap, const int cc, const bool valid) {
+        constexpr int slot = decltype(slotc)::value;
+        if constexpr (BFG) {
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) {
+                const unsigned base = (((wf_n32 + (unsigned)jn) * (unsigned)d.ntaps + (unsigned)tap) * (unsigned)a.cchunks + (unsigned)cc) * 4096u;
+                const unsigned so = valid ? base : 0xFFFFF000u;  // past the last chunk: out of range, zeros (never used)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    fb[slot * TN + jn][j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wsrc, (int)wf_lane, (int)(so + j * 1024u), 0));
+            }
+        }
+    };
     auto read_frags = [&](const int st) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -201,13 +229,15 @@ __global__ __launch_bounds__(512) void conv_h2_pp_kernel(const ConvH2Args ax)
 #pragma unroll
             for (int j = 0; j < 4; ++j) fa[i][j] = *reinterpret_cast<const u32x4*>(q + (((2 * j + half) ^ sw) << 4));
         }
+        if constexpr (!BFG) {
 #pragma unroll
-        for (int jn = 0; jn < TN; ++jn) {
-            const int R = wn * WTN + jn * 32 + frow;
-            const int sw = (R >> 1) & 7;
-            const unsigned char* q = Bs + ((st * BN) + R) * RB;
+            for (int jn = 0; jn < TN; ++jn) {
+                const int R = wn * WTN + jn * 32 + frow;
+                const int sw = (R >> 1) & 7;
+                const unsigned char* q = Bs + ((st * BN) + R) * RB;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fb[jn][j] = *reinterpret_cast<const u32x4*>(q + (((2 * j + half) ^ sw) << 4));
+                for (int j = 0; j < 4; ++j) fb[jn][j] = *reinterpret_cast<const u32x4*>(q + (((2 * j + half) ^ sw) << 4));
+            }
         }
     };
 
@@ -219,24 +249,48 @@ __global__ __launch_bounds__(512) void conv_h2_pp_kernel(const ConvH2Args ax)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    auto mma_group = [&](auto prc) {
-        constexpr int pr = decltype(prc)::value;
+    auto mma_group = [&](auto prc, auto slotc) {
+        constexpr int pr = decltype(prc)::value, slot = decltype(slotc)::value;
         H2_PAIRS;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int jn = 0; jn < TN; ++jn) acc[i][jn] = h2_mfma(fa[i][H2_PA[pr]], fb[jn][H2_PB[pr]], acc[i][jn]);
+            for (int jn = 0; jn < TN; ++jn) acc[i][jn] = h2_mfma(fa[i][H2_PA[pr]], fb[slot * TN + jn][H2_PB[pr]], acc[i][jn]);
     };
 
-    // ---- prologue: chunks 0 .. D-1 into stages 0 .. D-1
-#pragma unroll
-    for (int c = 0; c < D; ++c) {
-        stage_addr(ld_tap, ld_cc, ld_idx < nk);
-        stage_pieces(ic<0>{}, ic<P>{}, c);
-        next_chunk();
-    }
+    // BFG: position of the weight-fragment stream (two chunks ahead of the MFMAs)
+    int lb_cc = 0, lb_tap = 0, lb_idx = 0;
+    auto next_b = [&]() {
+        ++lb_idx;
+        ++lb_tap;
+        const int wrap = lb_tap == d.ntaps ? 1 : 0;
+        lb_tap = wrap ? 0 : lb_tap;
+        lb_cc += wrap;
+    };
+    static_assert(!BFG || D <= 3, "BFG: the counted waits below assume the weight stream (2 chunks ahead) is not behind the DMA ring");
+
+    // ---- prologue: chunks 0 .. D-1 into stages 0 .. D-1, issued as the steps -D .. -1 of the loop would (step s: first PL pieces of chunk
+    // s + D, [BFG] the weight fragments of chunk s + 2, the remaining PM pieces) so that the counted waits hold from step 0 on
+    auto pro_step = [&](auto cc_) {
+        constexpr int c = decltype(cc_)::value;
+        if constexpr (c < D) {
+            stage_addr(ld_tap, ld_cc, ld_idx < nk);
+            stage_pieces(ic<0>{}, ic<PL>{}, c);
+            if constexpr (BFG && c - D + 2 >= 0) {
+                load_bfrags(ic<c - D + 2>{}, lb_tap, lb_cc, lb_idx < nk);
+                next_b();
+            }
+            stage_pieces(ic<PL>{}, ic<P>{}, c);
+            next_chunk();
+        }
+    };
+    pro_step(ic<0>{});
+    pro_step(ic<1>{});
+    pro_step(ic<2>{});
+    pro_step(ic<3>{});
+    static_assert(D <= 4, "prologue steps");
     stage_addr(ld_tap, ld_cc, ld_idx < nk);                              // addresses of chunk D, issued in step 0
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * P) : "memory");  // chunk 0 has landed (this wave's pieces)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * Q) : "memory");  // chunk 0 has landed (this wave's pieces)
     __builtin_amdgcn_s_barrier();                                        // ... and everybody's
     asm volatile("" ::: "memory");
     if (grp == 1) __builtin_amdgcn_s_barrier();  // the second wave group runs one barrier behind from here on
@@ -246,18 +300,29 @@ __global__ __launch_bounds__(512) void conv_h2_pp_kernel(const ConvH2Args ax)
     unsigned long long pp_sum[6] = {0, 0, 0, 0, 0, 0};
     const unsigned long long pp_t0 = __builtin_readcyclecounter();
 #endif
-    for (int k = 0; k < nk; ++k) {
+    // vmcnt queue of a wave, per step s: [PL pieces of chunk s + D] [NB weight fragments of chunk s + 2] [PM pieces of chunk s + D]
+    //   end of L(k): chunk k + 1's pieces (steps k + 1 - D) are older than steps k + 2 - D .. k - 1 (Q each) and this step's PL + NB;
+    //                BFG: the fragments of chunk k (step k - 2) are older than 2 Q entries
+    //   end of M(k): chunk k + 1's pieces are older than steps k + 2 - D .. k
+    constexpr int N1a = (D - 2) * Q + PL + NB, N1 = (BFG && N1a > 2 * Q) ? 2 * Q : N1a, N3 = (D - 1) * Q;
+    static_assert(N1 <= 63 && N3 <= 63, "vmcnt is a 6-bit counter");
+    auto step = [&](auto slotc) {
+        constexpr int slot = decltype(slotc)::value;  // BFG: ring slot of this chunk's weight fragments
         // ---- L(k): fragments of chunk k; this wave's first PL pieces of chunk k + D
         __builtin_amdgcn_sched_barrier(0);
         PP_T(0);
         read_frags(st_rd);
         __builtin_amdgcn_sched_barrier(0);
         stage_pieces(ic<0>{}, ic<PL>{}, st_wr);  // (addresses of chunk k + D: computed between the MFMAs of the previous step)
+        if constexpr (BFG) {
+            load_bfrags(ic<(slot + 2) % 3>{}, lb_tap, lb_cc, lb_idx < nk);
+            next_b();
+        }
         __builtin_amdgcn_sched_barrier(0);
         PP_T(1);
-        // outstanding and newer than chunk k + 1: chunks k + 2 .. k + D - 1 (P each) + the PL pieces just issued -> chunk k + 1 has
-        // landed; the fragment reads are back (nobody may still be reading a stage the other group is about to re-fill)
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((D - 2) * P + PL) : "memory");
+        // chunk k + 1 has landed (and, BFG, this chunk's weight fragments); the fragment reads are back (nobody may still be reading a
+        // stage the other group is about to re-fill)
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N1) : "memory");
         PP_T(2);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -265,13 +330,13 @@ __global__ __launch_bounds__(512) void conv_h2_pp_kernel(const ConvH2Args ax)
         __builtin_amdgcn_sched_barrier(0);
         PP_T(3);
         __builtin_amdgcn_s_setprio(1);
-        mma_group(ic<0>{});
-        mma_group(ic<1>{});
+        mma_group(ic<0>{}, slotc);
+        mma_group(ic<1>{}, slotc);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (PM >= 1) stage_piece(ic<PL>{}, st_wr);
         __builtin_amdgcn_sched_barrier(0);
-        mma_group(ic<2>{});
-        mma_group(ic<3>{});
+        mma_group(ic<2>{}, slotc);
+        mma_group(ic<3>{}, slotc);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (PM >= 2) stage_piece(ic<PL + 1>{}, st_wr);
         __builtin_amdgcn_sched_barrier(0);
@@ -279,14 +344,14 @@ __global__ __launch_bounds__(512) void conv_h2_pp_kernel(const ConvH2Args ax)
         // MFMAs instead of lengthening the L part (probe: per chunk 1 105 -> 987 cycles on layer3)
         next_chunk();
         stage_addr(ld_tap, ld_cc, ld_idx < nk);
-        mma_group(ic<4>{});
-        mma_group(ic<5>{});
+        mma_group(ic<4>{}, slotc);
+        mma_group(ic<5>{}, slotc);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         PP_T(4);
         st_rd = st_rd == NST - 1 ? 0 : st_rd + 1;
         st_wr = st_wr == NST - 1 ? 0 : st_wr + 1;
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * P) : "memory");  // newer than chunk k + 1: chunks k + 2 .. k + D
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N3) : "memory");  // chunk k + 1 has landed
         PP_T(5);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -297,6 +362,18 @@ __global__ __launch_bounds__(512) void conv_h2_pp_kernel(const ConvH2Args ax)
         PP_ACC(3, 3, 4);  // MFMAs + PM pieces
         PP_ACC(4, 4, 5);  // s_waitcnt vmcnt
         PP_ACC(5, 5, 6);  // barrier after M
+    };
+    if constexpr (BFG) {
+        int k = 0;
+        for (; k + 3 <= nk; k += 3) {
+            step(ic<0>{});
+            step(ic<1>{});
+            step(ic<2>{});
+        }
+        if (k < nk) step(ic<0>{});
+        if (k + 1 < nk) step(ic<1>{});
+    } else {
+        for (int k = 0; k < nk; ++k) step(ic<0>{});
     }
 #ifdef RDPN6D_PROBE
     const unsigned long long pp_loop_end = __builtin_readcyclecounter();
@@ -356,14 +433,14 @@ __global__ __launch_bounds__(512) void conv_h2_pp_kernel(const ConvH2Args ax)
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int NST, int PM>
+template <int BM, int BN, int WM, int WN, int NST, int PM, bool BFG = false>
 int launch_pp(const ConvH2Args& ax, hipStream_t s)
 {
-    constexpr int lds_stage = NST * (BM + BN) * 128;
+    constexpr int lds_stage = NST * (BM + (BFG ? 0 : BN)) * 128;
     constexpr int lds_epi = 8 * 32 * (BN / WN + 8) * 4;
     constexpr int lds = lds_stage > lds_epi ? lds_stage : lds_epi;
     static_assert(lds <= 160 * 1024, "LDS");
-    auto kern = conv_h2_pp_kernel<BM, BN, WM, WN, NST, PM>;
+    auto kern = conv_h2_pp_kernel<BM, BN, WM, WN, NST, PM, BFG>;
     RD_LDS_OPT_IN(kern, lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)(ax.b.mtiles * ax.b.ntiles)), dim3(512), lds, s, ax);
     return RDPN6D_OK;
@@ -375,6 +452,11 @@ int launch_pp(const ConvH2Args& ax, hipStream_t s)
 int conv_h2_launch_pp(ConvH2Args& ax, int shape, hipStream_t s)
 {
     static const int pm = getenv("RDPN6D_H2_PP_PM") ? atoi(getenv("RDPN6D_H2_PP_PM")) : 2;  // profiling: DMA pieces inside the MFMA part
+    if (ax.w_frag) {  // weight fragments straight from L2 (fragment-major weights: rdpn6d_h2_weight_frag); A ring one stage deeper
+        static const int bpm = getenv("RDPN6D_H2_BFG_PM") ? atoi(getenv("RDPN6D_H2_BFG_PM")) : 1;
+        if (shape == 0) return bpm == 0 ? launch_pp<128, 128, 2, 4, 4, 0, true>(ax, s) : launch_pp<128, 128, 2, 4, 4, 1, true>(ax, s);
+        if (shape == 2) return bpm == 0 ? launch_pp<256, 128, 2, 4, 4, 0, true>(ax, s) : bpm == 1 ? launch_pp<256, 128, 2, 4, 4, 1, true>(ax, s) : launch_pp<256, 128, 2, 4, 4, 2, true>(ax, s);
+    }
     if (shape == 0) return pm == 0 ? launch_pp<128, 128, 2, 4, 4, 0>(ax, s) : pm == 1 ? launch_pp<128, 128, 2, 4, 4, 1>(ax, s) : launch_pp<128, 128, 2, 4, 4, 2>(ax, s);
     if (shape == 2) return pm == 0 ? launch_pp<256, 128, 2, 4, 3, 0>(ax, s) : pm == 1 ? launch_pp<256, 128, 2, 4, 3, 1>(ax, s) : launch_pp<256, 128, 2, 4, 3, 2>(ax, s);
     rdpn6d_set_error("conv_h2_launch_pp: unknown tile shape %d", shape);

@@ -7,6 +7,7 @@
 #include "common.h"
 #include "h2_format.h"
 #include <float.h>
+#include <cstdlib>
 
 namespace {
 
@@ -307,27 +308,10 @@ typedef unsigned sp_u32x4 __attribute__((ext_vector_type(4)));
 // first patch element (relative to the pixel's top-left sample) of the 8-wide k-row rw = k / 8 = c*7 + ky; rows 21..23 are padding
 __host__ __device__ constexpr int sp_rowoff(int rw) { return rw >= 21 ? 0 : ((rw / 7) * SP_IH + rw % 7) * SP_IWS; }
 
-// OUT: 0 = the pooled activation as an h2 tensor; 1 / 2 = as a plain bf16 / fp16 NHWC tensor [B, R/4, R/4, 64] (the 16-bit inference
-// mode, cfg.TEST.AMP_TEST: the arithmetic stays the fp32-accurate h2 one, only the stored result is rounded); 3 / 4 = NO pooling and
-// no ReLU: scale * conv + shift of the 16 x 32 stem pixels the tile owns as a bf16 / fp16 NHWC tensor [B, R/2, R/2, 64] - the RAW stem
-// convolution of the mixed-precision training forward (BatchNorm with batch statistics, ReLU and the max-pool are separate launches
-// there; the tile's first row / column, computed for the pooling windows of the inference forms, is simply not stored)
-template <int OUT>
-__global__ __launch_bounds__(256, 2) void stem_pool_h2_kernel(const float* __restrict__ x, int xc, int R, const _Float16* __restrict__ w_h2,
-                                                              const float* __restrict__ scale, const float* __restrict__ shift,
-                                                              _Float16* __restrict__ y, int* __restrict__ overflow_flag)
+// the 39 x 71 x 3 input patch of a tile -> hi / lo fp16 planes in LDS (zero outside the image); the caller synchronises
+__device__ __forceinline__ void sp_load_patch(const float* __restrict__ x, const int xc, const int R, const int b, const int iy0, const int ix0,
+                                              const int tid, _Float16* s_hi, _Float16* s_lo)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
-    _Float16* s_hi = reinterpret_cast<_Float16*>(sp_smem);
-    _Float16* s_lo = s_hi + SP_PLANE;
-    float* s_t = reinterpret_cast<float*>(sp_smem);  // stem-tile slice, overlays the patch after the MFMA phase
-    const int Rp = R / 4;                            // pooled resolution (stem: R / 2)
-    const int b = blockIdx.z, py0 = blockIdx.y * SP_PH, px0 = blockIdx.x * SP_PW;
-    const int sy0 = 2 * py0 - 1, sx0 = 2 * px0 - 1;  // first stem pixel of the tile
-    const int iy0 = 2 * sy0 - 3, ix0 = 2 * sx0 - 3;  // first input sample of the patch
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    SPT(0);
-
     {   // The patch, as ALIGNED 16-byte loads: ix0 = 4*px0 - 5, so columns ix0 - 3 + 4j (j = 0 .. 18) are 16-byte aligned in the crop's
         // rows (R % 4 == 0) and cover patch columns -3 .. 72 - the 71 real ones, two of the three padding columns (read times zero
         // weights only: any finite value does) and three in front that are dropped.  9 loads per thread instead of 33 scalar ones; all
@@ -377,6 +361,30 @@ __global__ __launch_bounds__(256, 2) void stem_pool_h2_kernel(const float* __res
             }
         }
     }
+}
+
+// OUT: 0 = the pooled activation as an h2 tensor; 1 / 2 = as a plain bf16 / fp16 NHWC tensor [B, R/4, R/4, 64] (the 16-bit inference
+// mode, cfg.TEST.AMP_TEST: the arithmetic stays the fp32-accurate h2 one, only the stored result is rounded); 3 / 4 = NO pooling and
+// no ReLU: scale * conv + shift of the 16 x 32 stem pixels the tile owns as a bf16 / fp16 NHWC tensor [B, R/2, R/2, 64] - the RAW stem
+// convolution of the mixed-precision training forward (BatchNorm with batch statistics, ReLU and the max-pool are separate launches
+// there; the tile's first row / column, computed for the pooling windows of the inference forms, is simply not stored)
+template <int OUT>
+__global__ __launch_bounds__(256, 2) void stem_pool_h2_kernel(const float* __restrict__ x, int xc, int R, const _Float16* __restrict__ w_h2,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              _Float16* __restrict__ y, int* __restrict__ overflow_flag)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
+    _Float16* s_hi = reinterpret_cast<_Float16*>(sp_smem);
+    _Float16* s_lo = s_hi + SP_PLANE;
+    float* s_t = reinterpret_cast<float*>(sp_smem);  // stem-tile slice, overlays the patch after the MFMA phase
+    const int Rp = R / 4;                            // pooled resolution (stem: R / 2)
+    const int b = blockIdx.z, py0 = blockIdx.y * SP_PH, px0 = blockIdx.x * SP_PW;
+    const int sy0 = 2 * py0 - 1, sx0 = 2 * px0 - 1;  // first stem pixel of the tile
+    const int iy0 = 2 * sy0 - 3, ix0 = 2 * sx0 - 3;  // first input sample of the patch
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    SPT(0);
+
+    sp_load_patch(x, xc, R, b, iy0, ix0, tid, s_hi, s_lo);
     __syncthreads();
     SPT(1);
 
@@ -567,6 +575,257 @@ __global__ __launch_bounds__(256, 2) void stem_pool_h2_kernel(const float* __res
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 5: the pooled forms (OUT 0 / 1 / 2) with the 3x3 / stride-2 max taken IN REGISTERS.  Probe of the kernel above: 7 600 cycles of
+// patch load, 19 000 of MFMA phase, 21 300 of epilogue per workgroup - the epilogue wrote every accumulator to LDS (160 ds_write per
+// lane, four 16-channel slices with two barriers each) and read each value back ~2.25 times for the pooling.  Here the m-tiles follow
+// the pooling structure instead of the row-major pixel order:
+//     m-tile t = 0 .. 16 : stem ROW t of the 17 x 33 tile, columns 0 .. 31  (MFMA row i = column i)
+//     m-tile 17          : stem COLUMN 32, rows 0 .. 16                      (MFMA row i = row i; rows 17 .. 31 idle)
+//   - still 18 m-tiles.  Wave w owns rows 4w .. 4w + 3 (wave 3 also row 16, wave 0 the column tile).  An accumulator register of lane
+//   (r, half) holds channel nt*32 + r at columns 8g + 4*half + j (e = 4g + j): the horizontal window of pooled column q is
+//       q even: columns 4(q/2) .. + 2        = three registers of ONE lane
+//       q odd : two registers of one lane + the first register of the NEXT group of four, which the lane 32 away holds (one
+//               cross-half exchange per group), or the column tile's value for q = 15 (through LDS: 17 x 64 floats)
+//   and the vertical window of pooled row 2w + {0, 1} is rows 4w .. 4w + 2 / 4w + 2 .. 4w + 4 = the wave's own m-tiles, except row
+//   4w + 4, whose horizontally pooled values the next wave publishes through LDS (3 x 16 x 64 floats).  The pooled 8 x 16 x 64 tile is
+//   then staged in LDS as finished records and leaves in 16-byte pieces.  LDS traffic of the epilogue: 20 KB instead of ~480 KB.
+// The conv values are those of the kernel above bit for bit (same k order per element; the all-padding second k16 step of the last
+// chunk - zero weights - is skipped), max is exact: identical outputs (tests/test_gpu_h2.py).
+constexpr int SP2_ROWB0 = 256 + 32, SP2_ROWB1 = 128 + 32;      // staged output row: h2 record / 16-bit row, + 32 bytes against bank conflicts
+constexpr int SP2_OUT_BYTES = SP_PH * SP_PW * SP2_ROWB0;       // 36 864 >= the patch planes
+constexpr int SP2_COL = SP2_OUT_BYTES > SP_LDS_A ? SP2_OUT_BYTES : SP_LDS_A;
+constexpr int SP2_ROW = SP2_COL + SP_SH * 64 * 4;
+constexpr int SP2_LDS = SP2_ROW + 3 * 16 * 64 * 4;
+
+template <int OUT>
+__global__ __launch_bounds__(256, 2) void stem_pool_h2_v2_kernel(const float* __restrict__ x, int xc, int R, const _Float16* __restrict__ w_h2,
+                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                 _Float16* __restrict__ y, int* __restrict__ overflow_flag)
+{
+    static_assert(OUT >= 0 && OUT <= 2, "pooled forms only");
+    extern __shared__ __attribute__((aligned(16))) unsigned char sp_smem[];
+    _Float16* s_hi = reinterpret_cast<_Float16*>(sp_smem);
+    _Float16* s_lo = s_hi + SP_PLANE;
+    float* s_col = reinterpret_cast<float*>(sp_smem + SP2_COL);
+    float* s_row = reinterpret_cast<float*>(sp_smem + SP2_ROW);
+    const int Rp = R / 4;
+    const int b = blockIdx.z, py0 = blockIdx.y * SP_PH, px0 = blockIdx.x * SP_PW;
+    const int sy0 = 2 * py0 - 1, sx0 = 2 * px0 - 1;
+    const int iy0 = 2 * sy0 - 3, ix0 = 2 * sx0 - 3;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    SPT(0);
+    sp_load_patch(x, xc, R, b, iy0, ix0, tid, s_hi, s_lo);
+    __syncthreads();
+    SPT(1);
+
+    // ---- MFMA phase
+    const int r = lane & 31, half = lane >> 5;
+    constexpr int MPW = 5;
+    const bool has5 = wave == 0 || wave == 3;  // wave-uniform
+    f32x16 acc[MPW][2];
+    int base[MPW];
+#pragma unroll
+    for (int m = 0; m < MPW; ++m) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][j][e] = 0.f;
+        int sy = 4 * wave + m, sx = r;
+        if (m == 4) {
+            sy = wave == 3 ? 16 : (r < SP_SH ? r : 0);
+            sx = wave == 3 ? r : 32;
+        }
+        base[m] = 2 * sy * SP_IWS + 2 * sx;
+    }
+    const unsigned char* wrow[2] = {reinterpret_cast<const unsigned char*>(w_h2) + (size_t)(r * SP_KC) * 128 + half * 16,
+                                    reinterpret_cast<const unsigned char*>(w_h2) + (size_t)((32 + r) * SP_KC) * 128 + half * 16};
+    sp_u32x4 fb[2][4], fbn[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[nt][j] = *reinterpret_cast<const sp_u32x4*>(wrow[nt] + j * 32);
+#pragma unroll
+    for (int cc = 0; cc < SP_KC; ++cc) {
+        if (cc + 1 < SP_KC) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fbn[nt][j] = *reinterpret_cast<const sp_u32x4*>(wrow[nt] + (cc + 1) * 128 + j * 32);
+        }
+        // k-rows 4*cc + 2*s + half; rows 21 .. 23 are padding (zero weights): the second k16 step of the last chunk is all padding
+        constexpr int NS_LAST = 1;
+#pragma unroll
+        for (int m = 0; m < MPW; ++m) {
+            if (m == 4 && !has5) continue;
+            sp_u32x4 ah[2], al[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                if (cc == SP_KC - 1 && s >= NS_LAST) continue;
+                const int off = base[m] + (half ? sp_rowoff(4 * cc + 2 * s + 1) : sp_rowoff(4 * cc + 2 * s));
+                const unsigned* ph = reinterpret_cast<const unsigned*>(s_hi + off);
+                const unsigned* pl = reinterpret_cast<const unsigned*>(s_lo + off);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    ah[s][q] = ph[q];
+                    al[s][q] = pl[q];
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                if (cc == SP_KC - 1 && s >= NS_LAST) continue;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, al[s]), __builtin_bit_cast(f16x8, fb[nt][s]), acc[m][nt], 0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[s]), __builtin_bit_cast(f16x8, fb[nt][2 + s]), acc[m][nt], 0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    acc[m][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ah[s]), __builtin_bit_cast(f16x8, fb[nt][s]), acc[m][nt], 0, 0, 0);
+            }
+        }
+        if (cc + 1 < SP_KC) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb[nt][j] = fbn[nt][j];
+        }
+    }
+
+    SPT(2);
+    // ---- BatchNorm + ReLU in place.  Stem pixels outside the image (row / column -1 at the top / left edge of the crop) become 0, which a
+    // ReLU output can never lose to (MaxPool2d pads with -inf).
+    const bool top = sy0 < 0, left = sx0 < 0;  // block-uniform
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const float sc = scale[nt * 32 + r], sh = shift[nt * 32 + r];
+#pragma unroll
+        for (int m = 0; m < MPW; ++m) {
+            if (m == 4 && !has5) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[m][nt][e] = fmaxf(acc[m][nt][e] * sc + sh, 0.f);
+            const bool row_tile = m < 4 || wave == 3;
+            if (row_tile && left && half == 0) acc[m][nt][0] = 0.f;               // column 0 of a row tile
+            if (m == 0 && wave == 0 && top) {                                     // row 0
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[m][nt][e] = 0.f;
+            }
+            if (m == 4 && wave == 0 && top && half == 0) acc[m][nt][0] = 0.f;     // (row 0, column 32) of the column tile
+        }
+    }
+    // the column tile's values for the q = 15 windows of every row
+    if (wave == 0) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int ty = (e & 3) + 8 * (e >> 2) + 4 * half;
+                if (ty < SP_SH) s_col[ty * 64 + nt * 32 + r] = acc[4][nt][e];
+            }
+    }
+    __syncthreads();
+
+    // ---- horizontal 3-max per row tile: hp[2g + u] = pooled column 4g + 2*half + u
+    auto hpool = [&](const f32x16& v, const float xcol, float(&hp)[8]) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            hp[2 * g] = fmaxf(fmaxf(v[4 * g], v[4 * g + 1]), v[4 * g + 2]);
+            const float send = half ? v[4 * g] : v[4 * ((g + 1) & 3)];
+            float recv = __shfl_xor(send, 32, 64);
+            if (g == 3) recv = half ? xcol : recv;  // (lower half: slot 3 is unused)
+            hp[2 * g + 1] = fmaxf(fmaxf(v[4 * g + 2], v[4 * g + 3]), recv);
+        }
+    };
+    float hp[MPW][2][8];
+#pragma unroll
+    for (int m = 0; m < MPW; ++m) {
+        if (m == 4 && wave != 3) continue;
+        const int t = m == 4 ? 16 : 4 * wave + m;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) hpool(acc[m][nt], s_col[t * 64 + nt * 32 + r], hp[m][nt]);
+    }
+    if (wave >= 1) {  // row 4*wave is the last row of the previous wave's second pooled row
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s_row[((wave - 1) * 16 + nt * 8 + k) * 64 + lane] = hp[0][nt][k];
+    }
+    __syncthreads();
+
+    // ---- vertical 3-max, the finished records into LDS (over the dead patch), out in 16-byte pieces
+    constexpr int ROWB = OUT == 0 ? SP2_ROWB0 : SP2_ROWB1;
+    bool over = false;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        float p0[8], p1[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            p0[k] = fmaxf(fmaxf(hp[0][nt][k], hp[1][nt][k]), hp[2][nt][k]);
+            const float xr = wave == 3 ? hp[4][nt][k] : s_row[(wave * 16 + nt * 8 + k) * 64 + lane];
+            p1[k] = fmaxf(fmaxf(hp[2][nt][k], hp[3][nt][k]), xr);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float(&pv)[8] = q ? p1 : p0;
+            unsigned char* dst = sp_smem + (size_t)((2 * wave + q) * SP_PW + 2 * half) * ROWB;  // pooled pixel (2*wave + q, 4g + 2*half + u)
+            if constexpr (OUT == 0) {
+                f16x8 hi, lo;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) pv[k] *= H2_SCALE;
+                over |= rd_h2_split8(pv, hi, lo);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    _Float16* d = reinterpret_cast<_Float16*>(dst + (size_t)(4 * (k >> 1) + (k & 1)) * ROWB + nt * 128) + r;
+                    d[0] = hi[k];
+                    d[32] = lo[k];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    unsigned short* d = reinterpret_cast<unsigned short*>(dst + (size_t)(4 * (k >> 1) + (k & 1)) * ROWB) + nt * 32 + r;
+                    typedef float sp_f2 __attribute__((ext_vector_type(2)));
+                    if constexpr (OUT == 1) {
+                        typedef __bf16 sp_b2 __attribute__((ext_vector_type(2)));
+                        *d = (unsigned short)(__builtin_bit_cast(unsigned, __builtin_convertvector(sp_f2{pv[k], 0.f}, sp_b2)) & 0xffffu);
+                    } else {
+                        typedef _Float16 sp_h2v __attribute__((ext_vector_type(2)));
+                        *d = (unsigned short)(__builtin_bit_cast(unsigned, __builtin_convertvector(sp_f2{pv[k], 0.f}, sp_h2v)) & 0xffffu);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    constexpr int PPP = OUT == 0 ? 16 : 8;  // 16-byte pieces per pooled pixel
+#pragma unroll
+    for (int i = 0; i < SP_PH * SP_PW * PPP / 256; ++i) {
+        const int piece = tid + 256 * i, pix = piece / PPP, j = piece - pix * PPP;
+        const int py = py0 + pix / SP_PW, px = px0 + pix % SP_PW;
+        if (py < Rp && px < Rp) {
+            const sp_u32x4 v = *reinterpret_cast<const sp_u32x4*>(sp_smem + (size_t)pix * ROWB + j * 16);
+            unsigned char* dp = reinterpret_cast<unsigned char*>(y) + ((((long long)b * Rp + py) * Rp + px) * PPP + j) * 16;
+            *reinterpret_cast<sp_u32x4*>(dp) = v;
+        }
+    }
+    if (over && overflow_flag) *overflow_flag = 1;
+#ifdef RDPN6D_PROBE
+    {
+        const unsigned long long spt3 = __builtin_readcyclecounter();
+        if (g_stem_probe && lane == 0) {
+            unsigned long long* o = g_stem_probe + (((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 4 * 4 + wave * 4;
+            o[0] = spt1 - spt0;
+            o[1] = spt2 - spt1;
+            o[2] = spt3 - spt2;
+            o[3] = 1;
+        }
+    }
+#endif
+}
+
 }  // namespace
 
 // x [B, xc, R, R] fp32 NCHW (channels 0..2 used); w_h2: conv1 weights with the reduction index k = (c*7 + ky)*8 + kx padded to
@@ -577,11 +836,28 @@ extern "C" int rdpn6d_stem_pool_h2_ex(const float* x, int B, int xc, int R, cons
 {
     RD_REQUIRE(x && w_h2 && scale && shift && y, "null pointer");
     RD_REQUIRE(B > 0 && xc >= 3 && R > 0 && R % 4 == 0, "shape (R % 4)");
+    const bool force_v1 = (out_fmt & 0x100) != 0;  // tests: + 0x100 = the round-3 kernel (pooling through LDS) for the pooled forms
+    out_fmt &= 0xff;
     RD_REQUIRE(out_fmt >= 0 && out_fmt <= 4, "out_fmt: 0 = h2 tensor, 1 = bf16 NHWC, 2 = fp16 NHWC (pooled); 3 = bf16, 4 = fp16 raw stem output");
     RD_REQUIRE((reinterpret_cast<size_t>(x) & 15) == 0, "x must be 16-byte aligned (the patch is read with aligned 16-byte loads)");
     const int Rp = R / 4;
     dim3 grid(rd_cdiv(Rp, SP_PW), rd_cdiv(Rp, SP_PH), B);
     hipStream_t s = (hipStream_t)stream;
+    static const bool v1 = getenv("RDPN6D_STEM_V1") != nullptr;  // A/B runs: the round-3 kernel (pooling through LDS)
+    if (out_fmt <= 2 && !v1 && !force_v1) {  // pooled forms: the 3x3 / stride-2 max in registers (stem_pool_h2_v2_kernel)
+        if (out_fmt == 0) {
+            RD_LDS_OPT_IN(stem_pool_h2_v2_kernel<0>, SP2_LDS);
+            hipLaunchKernelGGL(stem_pool_h2_v2_kernel<0>, grid, dim3(256), SP2_LDS, s, x, xc, R, (const _Float16*)w_h2, scale, shift, (_Float16*)y, overflow_flag);
+        } else if (out_fmt == 1) {
+            RD_LDS_OPT_IN(stem_pool_h2_v2_kernel<1>, SP2_LDS);
+            hipLaunchKernelGGL(stem_pool_h2_v2_kernel<1>, grid, dim3(256), SP2_LDS, s, x, xc, R, (const _Float16*)w_h2, scale, shift, (_Float16*)y, overflow_flag);
+        } else {
+            RD_LDS_OPT_IN(stem_pool_h2_v2_kernel<2>, SP2_LDS);
+            hipLaunchKernelGGL(stem_pool_h2_v2_kernel<2>, grid, dim3(256), SP2_LDS, s, x, xc, R, (const _Float16*)w_h2, scale, shift, (_Float16*)y, overflow_flag);
+        }
+        RD_LAUNCH_CHECK();
+        return RDPN6D_OK;
+    }
     if (out_fmt == 0) {
         RD_LDS_OPT_IN(stem_pool_h2_kernel<0>, SP_LDS);
         hipLaunchKernelGGL(stem_pool_h2_kernel<0>, grid, dim3(256), SP_LDS, s, x, xc, R, (const _Float16*)w_h2, scale, shift, (_Float16*)y, overflow_flag);

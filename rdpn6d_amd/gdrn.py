@@ -372,6 +372,7 @@ class InferencePlan:
         self.bufs = {}
         self.keep = []  # packed weights etc. kept alive
         cfg = model.cfg
+        self.h2_wfrag = bool(cfg.get("TEST", {}).get("H2_WFRAG", True))  # weight fragments from L2 where a layer's kernel has that form
         self.R = int(cfg.MODEL.CDPN.BACKBONE.INPUT_RES)
         self.K = int(cfg.MODEL.CDPN.ROT_HEAD.NUM_REGIONS)
         self.mask_attention = cfg.MODEL.CDPN.PNP_NET.MASK_ATTENTION
@@ -571,6 +572,15 @@ class InferencePlan:
             if crop_bias is not None:  # per-crop bias rows [B][4][Npad] (the folded global-max half of the ConvTranspose input)
                 self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_h2_cb, (ctypes.byref(d), _ptr(yp), _ptr(res_planes), _ptr(self.h2_flag),
                                                                                    _ptr(crop_bias)), keep=(d, crop_bias)))
+                return
+            if self.h2_wfrag and self.lib.rdpn6d_conv_h2_wfrag_wanted(ctypes.byref(d)):
+                # this layer's kernel can take its weight fragments straight from L2 (fragment-major copy of the weights, same bytes):
+                # a third of the K loop's LDS traffic gone (csrc/conv_igemm_h2_pp.hip, BFG); bit-identical results
+                wf = torch.empty_like(wp)
+                _lib.check(self.lib.rdpn6d_h2_weight_frag(_ptr(wp), wp.shape[0], d.ntaps, cin // 32, _ptr(wf), None), "h2_weight_frag")
+                self.keep.append(wf)
+                self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_h2_wf, (ctypes.byref(d), _ptr(yp), _ptr(res_planes), _ptr(self.h2_flag), _ptr(wf)),
+                                             keep=(d,)))
                 return
             self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_h2, (ctypes.byref(d), _ptr(yp), _ptr(res_planes), _ptr(self.h2_flag)), keep=(d,)))
             return
@@ -881,7 +891,9 @@ class InferencePlan:
         last = head.features[nfeat - 1]
         nout = last.weight.shape[0]
         MC = self.mask_channels
-        assert nout == MC + 4 + K, (nout, MC, K)
+        if nout != MC + 4 + K:
+            raise ValueError(f"the head's output convolution has {nout} channels; ROT_HEAD.MASK_LOSS_TYPE={cfg.MODEL.CDPN.ROT_HEAD.MASK_LOSS_TYPE!r} "
+                             f"with NUM_REGIONS={K} needs {MC} + 3 + {K + 1} (GDRN.py:637-659): build the model with the config it is run with")
         self.head_cs = _pad_to(nout, 4)
         ho = self.buf("head_out", B, R4 * R4, self.head_cs, zero=True)  # fp32 in both modes
         # cfg.TEST.FUSE_HEAD_OUT (default on): the 1x1 output convolution (features.21) runs in the EPILOGUE of the last 3x3 layer's
@@ -1533,6 +1545,9 @@ class GDRN(_TreeWatch, nn.Module):
 
         def infer():
             plan = self.plan(B, x.device)
+            if plan.mask_type != MASK_TYPES.get(str(self.cfg.MODEL.CDPN.ROT_HEAD.MASK_LOSS_TYPE), -1):
+                self.invalidate_plans()  # ROT_HEAD.MASK_LOSS_TYPE was changed on the live model: how the mask is read is part of the plan
+                plan = self.plan(B, x.device)
             if tuple(x.shape[1:]) != (6, plan.R, plan.R):
                 raise ValueError(f"expected x of shape (B,6,{plan.R},{plan.R}), got {tuple(x.shape)}")
             im_hw = self._image_sizes(im_H, im_W, B, x.device, tcfg, plan=plan) if (use_pnp and not kabsch) else None

@@ -147,11 +147,11 @@ def merge_h2(h2, shape):
 
 
 def conv2d_nhwc_h2(x, weight, scale=None, shift=None, stride=1, pad=0, residual=None, act=0, slope=0.0, want_h2=False, residual_h2=None,
-                   split_k=True):
+                   split_k=True, wfrag=False):
     """fp32-accurate convolution on the fp16 matrix pipe, two planes per operand (rdpn6d_conv2d_h2): x NHWC fp32 [B,H,W,C] or
     (h2 tensor, shape) from split_h2 / a previous call; weight OIHW fp32 (Cin % 32 == 0).  Returns y fp32 NHWC and, with
     want_h2, ((h2 tensor, shape) of y, overflow flag).  split_k=False withholds the workspace, so a launch that would cut K into
-    slices (rdpn6d_conv_h2_workspace_bytes != 0: too few tiles to fill the chip) runs un-split."""
+    slices (rdpn6d_conv_h2_workspace_bytes != 0: too few tiles to fill the chip) runs un-split.  wfrag: rdpn6d_conv2d_h2_wf."""
     from .gdrn import pack_h2_weight
 
     lib = _lib.load()
@@ -193,7 +193,13 @@ def conv2d_nhwc_h2(x, weight, scale=None, shift=None, stride=1, pad=0, residual=
     if not lib.rdpn6d_conv_h2_kernel_for(ctypes.byref(d)):
         raise ValueError("layer not eligible for the h2 kernels (Cin % 32, N % 8, aligned slices)")
     ws_bytes = int(lib.rdpn6d_conv_h2_workspace_bytes(ctypes.byref(d))) if split_k else 0
-    if ws_bytes:  # a launch too small to fill the chip: K slices + a fixed-order reduce
+    if wfrag:  # the kernel form that loads its weight fragments from L2 (fragment-major weights), where the layer's kernel has one
+        if not lib.rdpn6d_conv_h2_wfrag_wanted(ctypes.byref(d)):
+            raise ValueError("this layer's kernel has no weights-from-L2 form")
+        wf = torch.empty_like(wh)
+        _lib.check(lib.rdpn6d_h2_weight_frag(_ptr(wh), wh.shape[0], d.ntaps, wcin // 32, _ptr(wf), _stream()), "h2_weight_frag")
+        _lib.check(lib.rdpn6d_conv2d_h2_wf(ctypes.byref(d), _ptr(yh), _ptr(rh), _ptr(flag), _ptr(wf), _stream()), "conv2d_h2_wf")
+    elif ws_bytes:  # a launch too small to fill the chip: K slices + a fixed-order reduce
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=xh.device)
         _lib.check(lib.rdpn6d_conv2d_h2_ws(ctypes.byref(d), _ptr(yh), _ptr(rh), _ptr(flag), None, _ptr(ws), ws_bytes, _stream()), "conv2d_h2")
     else:

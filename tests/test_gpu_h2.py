@@ -36,6 +36,8 @@ H2_CASES = [
     (64, 32, 256, 128, 1, 1, False, 0),   # 1x1: 8 chunks, the shortest loop the kernel takes
     (40, 16, 256, 384, 3, 1, True, 1),    # three column tiles (N = 384): 80 x 3 = 240 tiles of 128x128
     (64, 32, 256, 512, 1, 2, False, 0),   # Bottleneck-style 1x1 stride-2 downsample: 64 x 4 = 256 tiles of 256x128, 8 chunks
+    (30, 32, 320, 128, 1, 1, False, 1),   # 1x1 over 320 channels: 240 tiles of 128x128, 10 chunks (10 % 3 = 1: the ring's remainder step)
+    (30, 32, 352, 128, 1, 1, True, 1),    # ... 11 chunks (two remainder steps)
 ]
 
 
@@ -97,6 +99,14 @@ def test_conv_h2_has_fp32_accuracy(case):
     d.B, d.H, d.W, d.Cin, d.in_cs, d.Ho, d.Wo, d.stride, d.ntaps, d.N, d.Npad, d.out_cs = B, H, H, Cin, Cin, Ho, Ho, stride, k * k, Cout, (Cout + 63) // 64 * 64, Cout
     which = _lib.load().rdpn6d_conv_h2_kernel_for(ctypes.byref(d))
     assert which == (2 if B in (11, 12) else 1), which  # the two big cases run on the eight-phase kernel
+    d.dy[0] = -(k // 2)  # (the tap offsets do not matter for the queries below)
+    if _lib.load().rdpn6d_conv_h2_wfrag_wanted(ctypes.byref(d)):
+        # round 5: the ping-pong kernel's 128x128 form loads its WEIGHT fragments straight from L2 (fragment-major copy of the weights,
+        # three-slot register ring) instead of staging the weight tile through LDS - same k order per accumulator: bit-identical
+        yf = ops.conv2d_nhwc_h2(xd, wd, scd, shd, residual=resd, wfrag=True, **kw)
+        torch.cuda.synchronize()
+        assert torch.equal(yf, yh), (case, (yf - yh).abs().max().item())
+        print(f"{case}: weights-from-L2 form bit-identical")
     wsb = _lib.load().rdpn6d_conv_h2_workspace_bytes(ctypes.byref(d))
     assert wsb > 0 if B == 1 else (wsb == 0 if which == 2 else True), (case, wsb)  # one crop's layers cut K into slices ...
     if wsb:  # ... with the same bits on every run (slices are added in slice order), fp32 rounding away from the un-split launch
@@ -218,6 +228,15 @@ def test_fused_stem_pool_h2_vs_fp64(B, R):
         err = (y16.cpu().double() - y64).abs()
         assert (err <= ulp * y64.abs() * 1.01 + e_h2 + 1e-7).all(), (fmt, err.max().item())  # (unit roundoff 2^-8 | 2^-11)
         assert torch.equal(y16.cpu(), mine.to(dt)) or (y16.cpu().double() - mine).abs().max().item() <= ulp * scale  # = the h2 result rounded once (up to double rounding)
+    # round 5: the pooled forms take the 3x3 / stride-2 max in registers (stem_pool_h2_v2_kernel: m-tiles = stem rows, one cross-half
+    # exchange per odd pooled column, two small LDS hand-offs) - the same convolution values, an exact max: BIT-IDENTICAL to the
+    # round-3 kernel that pooled through LDS (out_fmt + 0x100), in all three output formats
+    for fmt, ref_t in ((0, yh), (1, torch.empty(B, Rp, Rp, 64, dtype=torch.bfloat16, device=dev)), (2, torch.empty(B, Rp, Rp, 64, dtype=torch.float16, device=dev))):
+        new_t, old_t = torch.full_like(ref_t, 7.0), torch.full_like(ref_t, 9.0)
+        _lib.check(lib.rdpn6d_stem_pool_h2_ex(_ptr(xd), B, 6, R, _ptr(wh), _ptr(scf), _ptr(sh.to(dev)), _ptr(new_t), fmt, _ptr(flag), None))
+        _lib.check(lib.rdpn6d_stem_pool_h2_ex(_ptr(xd), B, 6, R, _ptr(wh), _ptr(scf), _ptr(sh.to(dev)), _ptr(old_t), fmt | 0x100, _ptr(flag), None))
+        torch.cuda.synchronize()
+        assert torch.equal(new_t.view(torch.int16), old_t.view(torch.int16)), (fmt, (new_t.float() - old_t.float()).abs().max().item())
     # the RAW stem convolution (training forward, out_fmt 3 | 4: no ReLU, no pooling) with the device-packed weight record
     wh2, inv2 = torch.empty_like(wh), torch.empty_like(inv)
     _lib.check(lib.rdpn6d_stem_pack_h2(_ptr(w.to(dev).contiguous()), _ptr(wh2), _ptr(inv2), None))

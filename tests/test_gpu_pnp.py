@@ -153,6 +153,20 @@ def test_model_pnp_type_2d3d_inside_forward(oracle_lib, golden_dir, pnp_type):
         for k in ("pnp_pose", "pnp_num_points", "pnp_inlier_mask"):
             assert torch.equal(o2[k], o3[k])
         assert not torch.equal(o2["pnp_pose"][1], o["pnp_pose"][1]) and torch.equal(o2["pnp_num_points"], o["pnp_num_points"])
+        # round 5: get_out_mask's sigmoid branch (engine_utils.py:130-132) is built.  Switching the mask type on a live model re-builds the
+        # plan; the selection then keeps sigmoid(mask) > 0.5 (& the |xyz| filter) instead of the min-max normalised mask > 0.5
+        from oracle import select_oracle
+
         cfg.MODEL.CDPN.ROT_HEAD.MASK_LOSS_TYPE = "BCE"
-        with torch.no_grad(), pytest.raises(NotImplementedError, match="MASK_LOSS_TYPE"):
-            model(t["roi_img"], **kw)
+        with torch.no_grad():
+            o4 = model(t["roi_img"], **kw)
+        torch.cuda.synchronize()
+        assert model.plan(4, t["roi_img"].device).mask_type == 1
+        nm = select_oracle.out_mask(o4["mask"].cpu().numpy(), "BCE")
+        for b in range(4):
+            xyz = np.stack([o4[k][b, 0].cpu().numpy() for k in ("coor_x", "coor_y", "coor_z")], -1)
+            _, _, sel = select_oracle.select_correspondences(nm[b, 0], xyz, t["roi_coord_2d"][b, 3:5].permute(1, 2, 0).cpu().numpy(), 480, 640,
+                                                             t["roi_extent"][b].cpu().numpy(), 0.5)
+            assert int(o4["pnp_num_points"][b]) == int(sel.sum()), (b, int(o4["pnp_num_points"][b]), int(sel.sum()))
+        assert not torch.equal(o4["pnp_num_points"], o2["pnp_num_points"])
+        cfg.MODEL.CDPN.ROT_HEAD.MASK_LOSS_TYPE = "L1"

@@ -117,3 +117,67 @@ def test_gradient_norms_on_eight_unsearched_seeds(seeds_steps, att):
             assert e <= 2e-2, (s, n, g, ref)
     print(f"[train seeds {att}] gradient norms of all parameters vs the reference: worst {worst[0]:.1e} ({worst[1]}); the reference's own "
           f"1-vs-8-thread gradient noise on these batches: up to {noise:.1e}")
+
+
+@pytest.mark.parametrize("att,seed", [("none", 0), ("mul", 1), ("none", 1), ("mul", 0)])
+def test_all_164_gradients_decision_forced_on_unsearched_seeds(golden_dir, att, seed):
+    """the SHARP gradient test - every one of the 164 parameter gradients as a full tensor against the autograd of
+    the reference-pinned oracle, with the HIP forward's 48 ReLU / LeakyReLU decisions (oracle.forced_relu_masks) and its region arg-max
+    (force_argmax) forced in, bound 2e-4 - no longer lives on the one searched training batch of model_c1w.npz only
+    (tests/test_gpu_c1w.py): here on unsearched seeds 0 and 1, both attention variants.  The losses of the forced oracle equal the
+    reference's golden losses for the same seed (1e-5; pose-branch losses when no tie pixel flipped), which ties the forced oracle
+    to the real reference on this very batch."""
+    from oracle import model_oracle
+    from rdpn6d_amd import synth
+    from rdpn6d_amd.config import gdrn_base_cfg
+    from rdpn6d_amd.gdrn import build_model_optimizer
+    from rdpn6d_amd.train import TrainEngine
+    from tests.c1w_cases import c1w_state_dict
+    from tests.test_gpu_c1w import _hip_relu_masks
+
+    dev = torch.device("cuda:0")
+    gold = np.load(os.path.join(golden_dir, "train_c1w_seeds.npz"))
+    bn = np.load(os.path.join(golden_dir, "bn_stats_c1w.npz"))
+    model, _ = build_model_optimizer(gdrn_base_cfg(mask_attention=att, device="cuda"))
+    sdn = c1w_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, bn)
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in sdn.items()}
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    inp = synth.make_inputs(4, seed=seed)
+    gt = synth.make_train_gt(4, inp)
+    assert synth.sha256_of([inp[k] for k in sorted(inp)]) == str(gold[f"s{seed}_sha256_inputs"])
+    eng = TrainEngine(model, 4, dev)
+    batch = {k: torch.from_numpy(v).to(dev) for k, v in {**inp, **gt}.items()}
+    losses = {k: float(v.item()) for k, v in eng.forward_backward(batch).items()}
+    torch.cuda.synchronize()
+    amax = eng.argmax.cpu().numpy().reshape(4, 64, 64).astype(np.int64)
+    flips = int((amax != gold[f"s{seed}_argmax"].astype(np.int64)).sum())
+    grads = {n: p.grad.detach().cpu().double().clone() for n, p in model.named_parameters()}
+    orc = model_oracle.GDRNOracle(32, att)
+    orc.load_state_dict(sd, strict=True)
+    orc.train()
+    tc = {k: torch.from_numpy(v) for k, v in {**inp, **gt}.items()}
+    with model_oracle.forced_relu_masks(orc, _hip_relu_masks(eng, orc)) as forced:
+        oo = orc(tc["roi_img"], tc["roi_coord_2d"], tc["fps"], tc["roi_cam"], tc["roi_center"], tc["roi_wh"], tc["resize_ratio"],
+                 train_pose=True, force_argmax=amax)
+        olosses = model_oracle.gdrn_losses(oo, tc, tc["roi_extent"])
+        sum(olosses.values()).backward()
+    assert len(forced.used) == len(forced.masks) == 48
+    for k, v in losses.items():
+        ref = float(gold[f"s{seed}_{att}_{k}"])
+        if k not in POSE or flips == 0:
+            assert abs(v - ref) <= 1e-5 * max(1.0, abs(ref)), (k, v, ref)
+        assert abs(float(olosses[k]) - v) <= 1e-5 * max(1.0, abs(v)), (k, float(olosses[k]), v)  # forced oracle vs HIP: same decisions
+    rows = []
+    for name, g in grads.items():
+        ref = dict(orc.named_parameters())[name].grad.double()
+        if ref.norm().item() < 1e-4:  # exact gradient zero up to round-off (a conv bias in front of a BatchNorm)
+            assert g.norm().item() < 1e-4, name
+            continue
+        rows.append(((g - ref).norm().item() / ref.norm().item(), name))
+    rows.sort(reverse=True)
+    print(f"[train seeds {att} seed {seed}] HIP vs decision-forced oracle autograd, {len(rows)} tensors ({flips} tie px on the other region): "
+          f"median {np.median([r[0] for r in rows]):.2e}, worst " + ", ".join(f"{n} {e:.2e}" for e, n in rows[:3]))
+    assert len(rows) == 160
+    for e, name in rows:
+        assert e <= 2e-4, (name, e)

@@ -155,7 +155,7 @@ def test_ransac_split_over_workgroups_is_bit_identical(B):
 def test_c3_amp_training_at_b32_copies_and_small_batch_losses():
     """C3's per-GPU batch in mixed precision (cfg.SOLVER.AMP.ENABLED, bf16 storage): B = 32 = 8 copies of 4 crops has the same
     batch statistics as those 4 crops alone, so the nine losses must equal the B = 4 AMP losses, every copy of a crop must
-    decode to the same pose bits, and the parameter gradients must agree with the B = 4 step to bf16 round-off."""
+    decode to the same pose bits; the gradients of this batch size are held by the layer-local float64 recompute test."""
     from rdpn6d_amd import synth
     from rdpn6d_amd.config import gdrn_base_cfg
     from rdpn6d_amd.gdrn import build_model_optimizer
@@ -172,7 +172,7 @@ def test_c3_amp_training_at_b32_copies_and_small_batch_losses():
     res = {}
     keys = ["rot_head_net.features.3.weight", "rot_head_net.features.18.weight", "backbone.layer2.0.conv1.weight", "pnp_net.fc1.weight",
             "backbone.conv1.weight"]
-    for B, amp in ((4, False), (4, True), (32, True)):
+    for B, amp in ((4, True), (32, True)):
         model.cfg.SOLVER.AMP.ENABLED = amp
         model.load_state_dict(sd, strict=True)
         rep = np.tile(np.arange(4), B // 4)
@@ -185,7 +185,6 @@ def test_c3_amp_training_at_b32_copies_and_small_batch_losses():
         res[(B, amp)] = (losses, {k: named[k].grad.detach().double().cpu().clone() for k in keys}, eng.rot.cpu().clone(), eng.trans.cpu().clone())
         del eng
         torch.cuda.empty_cache()
-    _, g4f, _, _ = res[(4, False)]
     l4, g4, _, _ = res[(4, True)]
     l32, g32, rot, trans = res[(32, True)]
     for k in l4:
@@ -196,12 +195,10 @@ def test_c3_amp_training_at_b32_copies_and_small_batch_losses():
         assert abs(l32[k] - l4[k]) <= tol * max(1.0, abs(l4[k])), k
     for s in range(32):
         assert torch.equal(rot[s], rot[s % 4]) and torch.equal(trans[s], trans[s % 4]), s
-    # Gradients.  With 8-bit mantissas in the stored activations a ReLU network's backward is dominated by the units / arg-max
-    # pixels that round-off flips (the B=4 AMP gradients are themselves 0.6 - 0.85 away from the fp32 ones, on the HIP path as
-    # under torch.autocast: test_amp_training_step_vs_autocast_yardstick), so the full-size step is held to that yardstick: it
-    # must be as close to the B=4 AMP step as that step is to fp32, and point the same way.
+    # Gradients: the parameter gradients of the B = 32 step are checked where a 16-bit step CAN be checked sharply - layer by layer, every
+    # weight / BatchNorm gradient recomputed in float64 from the very 16-bit operands the kernels read, at this batch size
+    # (tests/test_gpu_c1w.py::test_amp_step_every_layer_gradient_recomputed_from_the_stored_operands[32-bf16]: 150 tensors, worst 2e-5).
+    # (A whole-step comparison with the B = 4 step - "as close as that one is to fp32, cos > 0.5" - stood here until round 4; it could
+    # not fail for anything short of a sign error)  Here only: finite.
     for k in keys:
-        r32, r4 = ((g32[k] - g4[k]).norm() / g4[k].norm()).item(), ((g4[k] - g4f[k]).norm() / g4f[k].norm()).item()
-        cos = (g32[k] * g4[k]).sum().item() / (g32[k].norm() * g4[k].norm()).item()
-        print(f"C3 AMP grad {k}: B=32 vs B=4 (both AMP) rel {r32:.2e} cos {cos:.3f} | B=4 AMP vs B=4 fp32 rel {r4:.2e}")
-        assert torch.isfinite(g32[k]).all() and r32 <= r4 + 0.05 and cos > 0.5, k
+        assert torch.isfinite(g32[k]).all(), k

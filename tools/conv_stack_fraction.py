@@ -9,7 +9,7 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 gflop_crop = float(sys.argv[2]) if len(sys.argv) > 2 else 40.48  # 44.10 of the reference's order - 3.62 the exact rewrites do not execute
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 64
-steps = next(int(r["Calls"]) for r in rows if "stem_pool_h2_kernel" in r["Name"])  # one fused stem launch per step
+steps = next(int(r["Calls"]) for r in rows if "stem_pool_h2" in r["Name"])  # one fused stem launch per step
 conv = [r for r in rows if any(k in r["Name"] for k in ("conv_h2", "conv_igemm", "conv_x3", "stem_pool_h2"))]
 tot_all = sum(float(r["TotalDurationNs"]) for r in rows) / steps / 1e6
 tot = sum(float(r["TotalDurationNs"]) for r in conv) / steps / 1e6
