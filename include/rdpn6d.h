@@ -174,6 +174,7 @@ long long rdpn6d_conv_h2_workspace_bytes(const rdpn6d_conv_desc* d);
  * tensor [Npad][ntaps][cchunks][hi x 32 | lo x 32] into [Npad/32][ntaps][cchunks][slot 0..7][row 0..31][8 halfs] (same bytes);
  * rdpn6d_conv_h2_wfrag_wanted says whether a layer's kernel has that form; rdpn6d_conv2d_h2_wf = rdpn6d_conv2d_h2 + the re-ordered
  * weights (null or an unwanted w_frag: the ordinary kernel).  Results are bit-identical with and without. */
+void rdpn6d_conv_h2_set_wfrag(int mode); /* 0 (default): no layer wants them - measured slower, kept for the record; 1: 128x128; 2: + 256x128 */
 int rdpn6d_conv_h2_wfrag_wanted(const rdpn6d_conv_desc* d);
 int rdpn6d_h2_weight_frag(const void* w_h2, int Npad, int ntaps, int cchunks, void* w_frag, void* stream);
 int rdpn6d_conv2d_h2_wf(const rdpn6d_conv_desc* d, void* y_h2, const void* res_h2, int* overflow_flag, const void* w_frag, void* stream);

@@ -977,11 +977,15 @@ static int h2_tile_ksplit(const rdpn6d_conv_desc* d, long long M, int bm, int bn
     return best;
 }
 
-// shapes of the ping-pong kernel that have a weights-from-L2 form (conv_igemm_h2_pp.hip, BFG): the 128x128 tile (layer3 at B = 64);
-// RDPN6D_H2_BFG = 0 switches it off, = 2 adds the 256x128 tile (profiling)
+// shapes of the ping-pong kernel that have a weights-from-L2 form (conv_igemm_h2_pp.hip, BFG).  MEASURED AND PARKED (round 5,
+// profiles/r5_experiments.md): bit-identical, but layer3 runs 55.2 us against 52.5 with the weight tile in LDS and layer2 59 against 54 -
+// the vector-memory path is no faster than the LDS port it relieves.  Off unless asked for: mode 1 = the 128x128 tile, 2 = + 256x128
+// (rdpn6d_conv_h2_set_wfrag, or RDPN6D_H2_BFG in the environment for profiling runs)
+static int g_h2_wfrag_mode = getenv("RDPN6D_H2_BFG") ? atoi(getenv("RDPN6D_H2_BFG")) : 0;
+extern "C" void rdpn6d_conv_h2_set_wfrag(int mode) { g_h2_wfrag_mode = mode; }
 static bool h2_wfrag_shape_ok(int shape)
 {
-    static const int mode = getenv("RDPN6D_H2_BFG") ? atoi(getenv("RDPN6D_H2_BFG")) : 1;
+    const int mode = g_h2_wfrag_mode;
     return mode >= 1 && (shape == 0 || (mode >= 2 && shape == 2));
 }
 

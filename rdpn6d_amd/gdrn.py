@@ -372,7 +372,11 @@ class InferencePlan:
         self.bufs = {}
         self.keep = []  # packed weights etc. kept alive
         cfg = model.cfg
-        self.h2_wfrag = bool(cfg.get("TEST", {}).get("H2_WFRAG", True))  # weight fragments from L2 where a layer's kernel has that form
+        # cfg.TEST.H2_WFRAG: weight fragments straight from L2 where a layer's kernel has that form (csrc/conv_igemm_h2_pp.hip, BFG) -
+        # bit-identical, measured 3-5 % SLOWER per layer on MI355X (profiles/r5_experiments.md): off, kept as a switch
+        self.h2_wfrag = bool(cfg.get("TEST", {}).get("H2_WFRAG", False))
+        if self.h2_wfrag:
+            self.lib.rdpn6d_conv_h2_set_wfrag(1)
         self.R = int(cfg.MODEL.CDPN.BACKBONE.INPUT_RES)
         self.K = int(cfg.MODEL.CDPN.ROT_HEAD.NUM_REGIONS)
         self.mask_attention = cfg.MODEL.CDPN.PNP_NET.MASK_ATTENTION

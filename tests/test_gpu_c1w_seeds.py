@@ -8,8 +8,8 @@ plan bench.py times (two shuffled copies of the 32 crops), for all three fp32-ac
 
 Asserted per plan: dense maps <= 1e-4 max-abs on every crop; ZERO region arg-max flips outside the RECORDED tie set (reference's own
 top-2 logit gap < 2e-4, or a pixel the reference flips against itself between 1 and 8 threads / fp32 and float64 - the rule is in
-the fixture, tests/c1w_cases.tie_set); pose <= 1e-4 (MASK_ATTENTION none) / <= max(1e-4, 1.5 x the reference's own fp32-vs-float64
-pose error of that crop), capped at 2e-4 (mul).  A crop whose arg-max differs from the reference's at a tie pixel is compared with
+the fixture, tests/c1w_cases.tie_set); pose <= 1e-4 on all 64 slots for the default plan h2, both attention variants; for the two
+fall-back plans <= 3e-4 with the crops over 1e-4 being the RECORDED ones (OVER_BARE), each with its pose branch alone inside 1e-4.  A crop whose arg-max differs from the reference's at a tie pixel is compared with
 the reference-pinned oracle restarted from the reference's golden maps with OUR region decision at those pixels (one flipped pixel
 moves the reference's own pose by 3e-4 .. 3e-3: seed 2 crop 0, seed 3 crop 3 of the generator's log).
 And ACROSS plans: h2's worst map / pose error <= 1.25 x the fp32-MFMA plan's on this fixture - the end-to-end proof that the
@@ -22,6 +22,9 @@ import torch
 
 pytestmark = pytest.mark.gpu
 MAPS = ("mask", "coor_x", "coor_y", "coor_z", "region")
+# crops (seed, index in the seed's batch) whose end-to-end rotation error is over the bare 1e-4 on the two fall-back plans, as measured
+# on the round-5 code (deterministic kernels: the same on every box); the default plan has none
+OVER_BARE = {("x3", "none"): set(), ("x3", "mul"): {(0, 2), (6, 3)}, ("none", "none"): {(7, 0)}, ("none", "mul"): {(5, 0), (6, 3)}}
 FAST = {"h2": dict(BF16X3=True, FP16X2=True), "x3": dict(BF16X3=True, FP16X2=False), "none": dict(BF16X3=False, FP16X2=True)}
 
 
@@ -160,18 +163,18 @@ def test_bare_tolerances_on_eight_unsearched_seeds(seeds_run, fast, att):
     # wherever a pose is over the bare tolerance end to end, the pose branch itself is inside it: what is left is the reference's own
     # sensitivity to a <= 1e-4 change of its maps on that crop
     assert all(g[3] <= 1e-4 for g in s["given_maps"].values()), s["given_maps"]
-    if att == "none" and fast == "h2":
-        assert s["bare"] == 64
-    elif att == "none":
-        assert s["er"].max() <= 3e-4 and s["et"].max() <= 1e-4 and s["bare"] >= 60, (s["er"].max(), s["et"].max(), s["bare"])
-    elif fast == "h2":  # the default plan, the one bench.py times: per-crop bound from the reference's own fp32-vs-float64 error
-        assert (s["er"] <= s["tols"]).all() and (s["et"] <= s["tols"]).all(), (s["er"].max(), s["et"].max())
+    over = {crop for crop, _, _, _ in s["given_maps"].values()}  # crops (seed, index) whose rotation is over the bare 1e-4 end to end
+    if fast == "h2":
+        # the default plan, the one bench.py times, BOTH attention variants: every slot inside the bare 1e-4 (measured: worst R 5.6e-5 none /
+        # 5.3e-5 mul, t 2.2e-5) - round 4 accepted up to 2e-4 under "mul", where a regression to 1.98e-4 once hid
+        assert s["bare"] == 64 and s["er"].max() <= 1e-4 and s["et"].max() <= 1e-4, (s["bare"], s["er"].max(), s["et"].max())
     else:
-        # the two fall-back plans under MASK_ATTENTION = "mul": every ConvPnPNet input is scaled by the min-max normalised mask and the
-        # rotation moves by ~2x the map error (the reference's own fp32 rotation is 1.16e-4 from its float64 one on model_c1w.npz's
-        # batch).  Same bound as without attention: maps inside 1e-4 like h2's, pose inside 3e-4 with at most 4 slots over the bare
-        # 1e-4, each of which has its pose branch alone inside 1e-4 (asserted above)
-        assert s["er"].max() <= 3e-4 and s["et"].max() <= 1e-4 and s["bare"] >= 60, (s["er"].max(), s["et"].max(), s["bare"])
+        # the two fall-back plans: maps inside 1e-4 like h2's (asserted above), pose inside 3e-4, and the crops over the bare 1e-4 are
+        # the RECORDED ones - not a count.  Each of them has its pose branch alone inside 1e-4 (asserted above):
+        # what is left is the reference's own sensitivity to a <= 6e-5 change of its maps on that crop.
+        assert s["er"].max() <= 3e-4 and s["et"].max() <= 1e-4, (s["er"].max(), s["et"].max())
+        assert over <= OVER_BARE[(fast, att)], (fast, att, sorted(over), sorted(OVER_BARE[(fast, att)]))
+        assert s["bare"] == 64 - 2 * len(over)  # (every crop sits in two slots)
 
 
 def test_h2_is_as_accurate_as_the_fp32_mfma_plan_end_to_end(seeds_run):

@@ -100,13 +100,17 @@ def test_conv_h2_has_fp32_accuracy(case):
     which = _lib.load().rdpn6d_conv_h2_kernel_for(ctypes.byref(d))
     assert which == (2 if B in (11, 12) else 1), which  # the two big cases run on the eight-phase kernel
     d.dy[0] = -(k // 2)  # (the tap offsets do not matter for the queries below)
-    if _lib.load().rdpn6d_conv_h2_wfrag_wanted(ctypes.byref(d)):
+    _lib.load().rdpn6d_conv_h2_set_wfrag(2)  # (the form is off by default: measured slower; here its bit-identity is what is checked)
+    wanted = _lib.load().rdpn6d_conv_h2_wfrag_wanted(ctypes.byref(d))
+    assert wanted or case != (64, 16, 256, 256, 3, 1, True, 1)  # layer3 at B = 64 is the shape it was written for
+    if wanted:
         # round 5: the ping-pong kernel's 128x128 form loads its WEIGHT fragments straight from L2 (fragment-major copy of the weights,
         # three-slot register ring) instead of staging the weight tile through LDS - same k order per accumulator: bit-identical
         yf = ops.conv2d_nhwc_h2(xd, wd, scd, shd, residual=resd, wfrag=True, **kw)
         torch.cuda.synchronize()
         assert torch.equal(yf, yh), (case, (yf - yh).abs().max().item())
         print(f"{case}: weights-from-L2 form bit-identical")
+    _lib.load().rdpn6d_conv_h2_set_wfrag(0)
     wsb = _lib.load().rdpn6d_conv_h2_workspace_bytes(ctypes.byref(d))
     assert wsb > 0 if B == 1 else (wsb == 0 if which == 2 else True), (case, wsb)  # one crop's layers cut K into slices ...
     if wsb:  # ... with the same bits on every run (slices are added in slice order), fp32 rounding away from the un-split launch

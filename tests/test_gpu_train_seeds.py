@@ -19,6 +19,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+FLIPPED_SEEDS = {2}  # seeds whose train-mode arg-max differs from the reference's at a pixel of the recorded tie set (round-5 code)
 POSE = ("loss_PM_R", "loss_centroid", "loss_z")  # see the maps through the region arg-max; the other six are continuous in the maps
 
 
@@ -65,7 +66,7 @@ def test_training_losses_on_eight_unsearched_seeds(seeds_steps, att):
 
     res, gold = seeds_steps
     tie_gap = float(gold["tie_gap"])
-    exact, worst_dense, worst_pose = 0, 0.0, 0.0
+    exact, worst_dense, worst_pose, flipped = 0, 0.0, 0.0, set()
     for s in SEEDS:
         losses, amax, _ = res[(att, s)]
         assert len(losses) == 9
@@ -75,6 +76,8 @@ def test_training_losses_on_eight_unsearched_seeds(seeds_steps, att):
         assert int((diff & ~tie).sum()) == 0, (s, int((diff & ~tie).sum()))
         flips = int(diff.sum())
         exact += flips == 0
+        if flips:
+            flipped.add(s)
         row = []
         for k, v in losses.items():
             ref = float(gold[f"s{s}_{att}_{k}"])
@@ -91,7 +94,9 @@ def test_training_losses_on_eight_unsearched_seeds(seeds_steps, att):
         print(f"[train seeds {att}] seed {s}: tie set {int(tie.sum())} px, arg-max differs at {flips} tie px | " + " ".join(row))
     print(f"[train seeds {att}] dense losses worst {worst_dense:.1e}; pose-branch losses worst {worst_pose:.1e} on the {exact} of 8 batches "
           f"whose arg-max is reproduced exactly")
-    assert exact >= 5
+    # the batches on which a tie pixel takes the other region are the RECORDED ones (seed 2: one pixel of its 8-pixel tie set, both
+    # attention variants; deterministic kernels), not "at most three of eight" 
+    assert flipped <= FLIPPED_SEEDS, (sorted(flipped), sorted(FLIPPED_SEEDS))
 
 
 @pytest.mark.parametrize("att", ["none", "mul"])
