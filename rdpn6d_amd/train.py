@@ -99,6 +99,13 @@ class TrainEngine:
         self._wg_floats = 0
         self.group_wgrad = bool(model.cfg.get("SOLVER", {}).get("GROUP_WGRAD", True)) and os.environ.get("RDPN6D_GROUP_WGRAD", "1") != "0"  # (env: profiling)
         self._wgrad_groups, self._wgrad_group_list = {}, []
+        # cfg.SOLVER.WGRAD_SIDE_STREAM (default OFF): weight gradients whose operands are read in place from per-layer buffers on a second
+        # HIP stream (_side_launch) - nothing downstream of them in the backward depends on a weight gradient.  Bit-identical
+        # (tests/test_gpu_train.py), and measured NOT faster: bf16 B = 32 10.07 ms against 9.86 on one stream, fp16 10.38 against 10.50
+        # (profiles/r5_experiments.md) - the step's kernels already run back to back (sum of kernel durations = step time), two streams
+        # only make the big kernels share the chip.  Kept as a switch; RDPN6D_WGRAD_SIDE=1 forces it on for profiling runs.
+        self.wgrad_side = (bool(model.cfg.get("SOLVER", {}).get("WGRAD_SIDE_STREAM", False)) or os.environ.get("RDPN6D_WGRAD_SIDE", "0") == "1")
+        self._side, self._side_join, self._side_dirty, self._wg_partial_side = None, None, False, None
         self._build()
         for grp in self._wgrad_group_list:
             _, _, _, ca, _, _, _, cb, _, yhw, _, _, k, _, _ = grp["geom"]
@@ -466,11 +473,13 @@ class TrainEngine:
             if grp is None or len(grp["members"]) >= 16:
                 grp = self._wgrad_groups[geom] = dict(members=[], geom=geom, tdy=tdy, tdx=tdx)
                 self._wgrad_group_list.append(grp)  # (a stage with more than 16 same-shaped convolutions - ResNet-101 / 152 - has several)
-                launches.append(lambda grp=grp: self._run_wgrad_group(grp))
+                launches.append(self._side_launch(lambda grp=grp: self._run_wgrad_group(grp), lambda grp=grp: [t[3] for t in grp["members"]]))
             grp["members"].append((name, dyb, xb, w))
             grouped = True
         if not grouped:
-            launches.append(wgrad)
+            # (operands read in place from this layer's own buffers, gradient scattered straight into the parameter's: safe on the side stream)
+            side_ok = lowp and inv_perm is None and bias is None and dyb is dy and xb is x
+            launches.append(self._side_launch(wgrad, [w]) if side_ok else wgrad)
         if dx is not None:
             n_red = _pad_to(cout, 32 if lowp else 16)  # reduction channels of the dgrad = output channels of the forward
             cdx = _pad_to(cin_real, 64)
@@ -531,6 +540,42 @@ class TrainEngine:
                     launches.append(dlaunch("dgrad " + name, dd, wd))
         self.bwd.append(launches)
         return dy
+
+    def _side_launch(self, fn, params):
+        """`fn` (a weight-gradient launch closure writing the gradients of `params`) on the engine's side stream: the side stream waits for an event recorded on the
+        current stream at the closure's place in the launch list (its operands - this layer's output gradient and input activation -
+        are complete there and are not written again before the step ends), uses its own split-K scratch, and is joined by
+        _join_side() before a parameter group's gradients are handed on."""
+        if not self.wgrad_side:
+            return fn
+        ev = [None]
+
+        def run():
+            main = torch.cuda.current_stream(self.dev)
+            for q in params() if callable(params) else params:
+                self._grad(q)  # (a gradient tensor that has to be created is created - and zero-filled - on the main stream, in front of the event)
+            if self._side is None:
+                self._side, self._side_join = torch.cuda.Stream(self.dev), torch.cuda.Event()
+                self._wg_partial_side = torch.empty_like(self._wg_partial)
+            if ev[0] is None:
+                ev[0] = torch.cuda.Event()
+            ev[0].record(main)
+            self._side.wait_event(ev[0])
+            keep, self._wg_partial = self._wg_partial, self._wg_partial_side
+            try:
+                with torch.cuda.stream(self._side):
+                    fn()
+            finally:
+                self._wg_partial = keep
+            self._side_dirty = True
+
+        return run
+
+    def _join_side(self):
+        if self._side_dirty:
+            self._side_join.record(self._side)
+            torch.cuda.current_stream(self.dev).wait_event(self._side_join)
+            self._side_dirty = False
 
     def _run_wgrad_group(self, grp):
         m = grp["members"]
@@ -1118,6 +1163,8 @@ class TrainEngine:
         for idx in range(len(self.bwd) - 1, -1, -1):
             for fn in self.bwd[idx]:
                 fn()
+            if idx == 0 or idx in marks:
+                self._join_side()  # the weight gradients issued on the side stream belong to the groups completed here
             if idx == 0:
                 self._finish_backward(unscale, prev)
             if idx in marks:

@@ -1106,6 +1106,49 @@ def test_training_step_is_deterministic(B, amp):
             assert torch.equal(g0, g1), n
 
 
+@pytest.mark.parametrize("B,amp", [(32, "bf16"), (8, "fp16")])
+def test_weight_gradients_on_the_side_stream_change_nothing(B, amp):
+    """cfg.SOLVER.WGRAD_SIDE_STREAM (round 5, default on): the weight-gradient launches whose operands are read in place run on a second
+    HIP stream, ordered by events (their operands complete before, the parameter group's gradients joined before they are handed on).
+    Same kernels, same reductions: losses and all 164 gradients are BIT-IDENTICAL to the one-stream step, over three steps with the
+    optimizer in between (a missed dependency would show as a stale or torn gradient) - and the side stream is really used."""
+    from rdpn6d_amd import synth
+    from rdpn6d_amd.config import gdrn_base_cfg
+    from rdpn6d_amd.gdrn import build_model_optimizer
+    from rdpn6d_amd.train import TrainEngine
+
+    dev = torch.device("cuda:0")
+    inp = synth.make_inputs(B, seed=9)
+    batch = {k: torch.from_numpy(v).to(dev) for k, v in {**inp, **synth.make_train_gt(B, inp)}.items()}
+    res = {}
+    for side in (False, True):
+        cfg = gdrn_base_cfg(mask_attention="mul", device="cuda")
+        cfg.SOLVER.AMP.ENABLED, cfg.SOLVER.AMP.DTYPE, cfg.SOLVER.WGRAD_SIDE_STREAM = True, amp, side
+        model, opt = build_model_optimizer(cfg)
+        sd = synth.make_trained_like_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=5)
+        model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+        eng = TrainEngine(model, B, dev, amp=amp)
+        assert eng.wgrad_side == side
+        if amp == "fp16":
+            eng.loss_scale = 1024.0
+        out = []
+        for _ in range(3):
+            opt.zero_grad(set_to_none=True)  # (the reference loop's: gradient tensors are re-created every step)
+            losses = eng.forward_backward(batch)
+            torch.cuda.synchronize()
+            out.append(([float(v.item()) for v in losses.values()], [p.grad.clone() for p in model.parameters()]))
+            opt.step()
+            eng.refresh_weights()
+        assert (eng._side is not None) == side
+        res[side] = out
+        del eng, model, opt
+        torch.cuda.empty_cache()
+    for (l0, g0), (l1, g1) in zip(res[False], res[True]):
+        assert l0 == l1 and all(np.isfinite(l0))
+        for a, b in zip(g0, g1):
+            assert torch.equal(a, b)
+
+
 def test_non_finite_head_output_does_not_fault_the_glue_backward():
     """round 4: a diverged run (fp16 overflow un-skipped -> NaN weights -> NaN head output) drove `mask_attention_extrema_bwd_kernel` to
     write at its sentinel arg-min / arg-max index (2^31 rows past the tensor): a GPU memory fault that killed the process.  NaN in must
