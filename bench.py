@@ -150,6 +150,8 @@ def roofline(model, t, B, device, reps=3):
         "bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
         "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch (HBM+fabric, PMC)",
         "traffic_source": traffic_src, "traffic_stale": stale,
+        # the launch duration of the same kernel in the PROFILE the traffic figure comes from, beside the live one (avg_launch_ms)
+        "traffic_profile_avg_launch_ms": None if prof_us is None else round(prof_us * 1e-3, 4),
         "kernel": kname.replace(", ", ","), "launches_per_step": len(sel),
         "avg_launch_ms": round(avg_ms, 4), "algorithmic_gflop_per_launch": round(flops / max(len(sel), 1) / 1e9, 2),
         "share_of_step_flops": round(flops / (44.10e9 * B), 3), **extra,
@@ -292,6 +294,7 @@ def train_roofline(eng, one_step, reps=3):
     return {"bound": "mfma", "achieved": round(achieved, 1), "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch (HBM+fabric, PMC)",
             "traffic_source": traffic_src, "traffic_stale": None if traffic is None else bool(abs(prof_us - avg_us) > 0.25 * avg_us),
+            "traffic_profile_avg_launch_ms": None if prof_us is None else round(prof_us * 1e-3, 4),
             "kernel": f"conv_igemm_bf16_8ph_kernel ({eng.lp} build)", "launches_per_step": nf + nb,
             "launches_forward": nf, "launches_input_gradient": nb, "avg_launch_ms": round(sum(ms) / len(ms), 4),
             "algorithmic_gflop_per_launch": round(sum(flops) / len(flops) / 1e9, 2),

@@ -434,6 +434,15 @@ int rdpn6d_dense_losses_f32(const float* head, int head_cs, const float* gt_xyz,
 int rdpn6d_dense_glue_backward_f32(const float* head, int head_cs, const float* coord2d, const float* fps, const int* argmax,
                                    const float* dpnp, int pnp_cs, int B, int HW, int K, int mask_attention,
                                    const float* minmax, float* dhead, float* datt_scratch, void* stream);
+/* ... with ROT_HEAD.MASK_LOSS_TYPE (GDRN.py:450-463, models/model_utils.py:24-42): mask_type 0 "L1" (the two entries above), 1 "BCE"
+ * (nn.BCEWithLogitsLoss mean; sigmoid mask attention), 2 "CE" (nn.CrossEntropyLoss over TWO mask channels, mean; head rows are then
+ * [mask0 mask1 | x y z | region bg+K] and mask_attention must be 0 - the reference's get_mask_prob raises there) */
+int rdpn6d_dense_losses_mt_f32(const float* head, int head_cs, const float* gt_xyz, const float* mask_visib, const float* mask_trunc,
+                               const long long* gt_region, int B, int HW, int K, float xyz_lw, float mask_lw, float region_lw,
+                               int mask_type, float* dhead, float* losses, double* scratch, void* stream);
+int rdpn6d_dense_glue_backward_mt_f32(const float* head, int head_cs, const float* coord2d, const float* fps, const int* argmax,
+                                      const float* dpnp, int pnp_cs, int B, int HW, int K, int mask_attention, int mask_type,
+                                      const float* minmax, float* dhead, float* datt_scratch, void* stream);
 /* pose decode (train variant) + loss_PM_R, loss_centroid, loss_z and their gradient w.r.t. the 9 head outputs */
 int rdpn6d_pose_train_f32(const float* rt, int rt_stride, const float* roi_cams, const float* roi_centers,
                           const float* roi_whs, const float* resize_ratios, const float* roi_extents, const float* gt_rot,

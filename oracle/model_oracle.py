@@ -503,15 +503,23 @@ def closest_sym_rots(pred_rots, gt_rots, sym_infos):
     return torch.as_tensor(out, dtype=gt_rots.dtype, device=gt_rots.device)
 
 
-def gdrn_losses(out, gt, roi_extents, sym_infos=None):
+def gdrn_losses(out, gt, roi_extents, sym_infos=None, mask_loss_type="L1"):
     """Active losses of the shipped configs (GDRN.py:411-424,452-454,470-483,529-531,552-554;
-    pm_loss.py:97-114 with PM_R_ONLY, PM_NORM_BY_EXTENT, L1; sym_infos != None = PM_LOSS_SYM)."""
+    pm_loss.py:97-114 with PM_R_ONLY, PM_NORM_BY_EXTENT, L1; sym_infos != None = PM_LOSS_SYM).
+    mask_loss_type = ROT_HEAD.MASK_LOSS_TYPE: the three branches of GDRN.py:450-463."""
     mv = gt["roi_mask_visib"]
     denom = mv.sum().float().clamp(min=1.0)
     L = {}
     for i, k in enumerate(("coor_x", "coor_y", "coor_z")):
         L[f"loss_{k}"] = F.l1_loss(out[k] * mv[:, None], gt["roi_xyz"][:, i:i + 1] * mv[:, None], reduction="sum") / denom
-    L["loss_mask"] = F.l1_loss(out["mask"][:, 0], gt["roi_mask_trunc"], reduction="mean")
+    if mask_loss_type == "L1":
+        L["loss_mask"] = F.l1_loss(out["mask"][:, 0], gt["roi_mask_trunc"], reduction="mean")
+    elif mask_loss_type == "BCE":  # nn.BCEWithLogitsLoss(reduction="mean")
+        L["loss_mask"] = F.binary_cross_entropy_with_logits(out["mask"][:, 0], gt["roi_mask_trunc"], reduction="mean")
+    elif mask_loss_type == "CE":   # nn.CrossEntropyLoss(reduction="mean")(out_mask, gt_mask.long())
+        L["loss_mask"] = F.cross_entropy(out["mask"], gt["roi_mask_trunc"].long(), reduction="mean")
+    else:
+        raise NotImplementedError(f"unknown mask loss type: {mask_loss_type}")
     L["loss_region"] = F.cross_entropy(out["region"] * mv[:, None], gt["roi_region"].long() * mv.long(),
                                        reduction="sum") / denom
     L["loss_region_my"] = F.l1_loss(mv, out["region"][:, 0], reduction="mean")

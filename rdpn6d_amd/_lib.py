@@ -111,6 +111,8 @@ SIGNATURES = {
     "rdpn6d_global_max_concat_backward_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "rdpn6d_dense_losses_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp]),
     "rdpn6d_dense_glue_backward_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "rdpn6d_dense_losses_mt_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _i, _vp, _vp, _vp, _vp]),
+    "rdpn6d_dense_glue_backward_mt_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "rdpn6d_pose_train_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _f, _vp, _vp, _vp,
                                    _vp, _vp, _vp]),
     "rdpn6d_pose_train_sym_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _f, _vp, _vp, _i,

@@ -348,13 +348,15 @@ __global__ __launch_bounds__(1024) void mask_sum_kernel(const float* __restrict_
     }
 }
 
-template <int KMAX>
+// MC = mask channels of the head row: 1 (ROT_HEAD.MASK_LOSS_TYPE L1 | BCE) or 2 (CE) - [mask(MC) | x y z | region bg + K]; mask_type 0 L1,
+// 1 BCE (nn.BCEWithLogitsLoss, mean), 2 CE (nn.CrossEntropyLoss over the two mask channels, mean): GDRN.py:450-463
+template <int KMAX, int MC = 1>
 __global__ __launch_bounds__(256) void dense_loss_kernel(const float* __restrict__ head, int head_cs, const float* __restrict__ gt_xyz,
                                                          const float* __restrict__ m_visib, const float* __restrict__ m_trunc,
                                                          const long long* __restrict__ gt_region, int B, int HW, int K,
                                                          const double* __restrict__ sums, float xyz_lw, float mask_lw,
                                                          float region_lw, float* __restrict__ dhead,
-                                                         double* __restrict__ partial)
+                                                         double* __restrict__ partial, int mask_type)
 {
     __shared__ double s_red[4][6];
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -370,33 +372,43 @@ __global__ __launch_bounds__(256) void dense_loss_kernel(const float* __restrict
         // xyz L1 on the visible mask
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float d = h[1 + c] * mv - gt_xyz[((long long)b * 3 + c) * HW + p] * mv;
+            const float d = h[MC + c] * mv - gt_xyz[((long long)b * 3 + c) * HW + p] * mv;
             acc[c] = fabs((double)d);
             const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-            dh[1 + c] = xyz_lw * sg * mv * inv_d;
+            dh[MC + c] = xyz_lw * sg * mv * inv_d;
         }
-        // mask L1 (mean)
-        {
+        if (mask_type == 0) {  // mask L1 (mean)
             const float d = h[0] - mt;
             acc[3] = fabs((double)d);
             dh[0] = mask_lw * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * inv_n;
+        } else if (mask_type == 1) {  // BCEWithLogits (mean): max(x, 0) - x t + log(1 + exp(-|x|)); d/dx = sigmoid(x) - t
+            const float xv = h[0];
+            acc[3] = (double)(fmaxf(xv, 0.f) - xv * mt + log1pf(expf(-fabsf(xv))));
+            dh[0] = mask_lw * (1.f / (1.f + expf(-xv)) - mt) * inv_n;
+        } else {  // cross entropy over the two mask channels (mean), target = gt_mask.long()
+            const int tg = (int)(long long)mt;
+            const float z0 = h[0], z1 = h[MC > 1 ? 1 : 0], zm = fmaxf(z0, z1);
+            const float e0 = expf(z0 - zm), e1 = expf(z1 - zm), se2 = e0 + e1;
+            acc[3] = (double)(logf(se2) + zm - (tg == 1 ? z1 : z0));
+            dh[0] = mask_lw * (e0 / se2 - (tg == 0 ? 1.f : 0.f)) * inv_n;
+            if (MC > 1) dh[1] = mask_lw * (e1 / se2 - (tg == 1 ? 1.f : 0.f)) * inv_n;
         }
         // region cross-entropy on logits*mask, target gt*mask (sum reduction / denom)
         const int tgt = (int)(gt_region[i] * (long long)mv);
         float z[KMAX + 1], mx = -FLT_MAX;
 #pragma unroll
         for (int k = 0; k <= KMAX; ++k)
-            if (k <= K) { z[k] = h[4 + k] * mv; mx = fmaxf(mx, z[k]); }
+            if (k <= K) { z[k] = h[MC + 3 + k] * mv; mx = fmaxf(mx, z[k]); }
         float se = 0.f, zt = 0.f;
 #pragma unroll
         for (int k = 0; k <= KMAX; ++k)
             if (k <= K) { z[k] = expf(z[k] - mx); se += z[k]; }
 #pragma unroll
         for (int k = 0; k <= KMAX; ++k)
-            if (k <= K && k == tgt) zt = h[4 + k] * mv;
+            if (k <= K && k == tgt) zt = h[MC + 3 + k] * mv;
         acc[4] = (double)(logf(se) + mx - zt);
         // region_my: L1(mask_visib, bg logit), mean
-        const float dm = mv - h[4];
+        const float dm = mv - h[MC + 3];
         acc[5] = fabs((double)dm);
         const float g_my = -region_lw * (dm > 0.f ? 1.f : (dm < 0.f ? -1.f : 0.f)) * inv_n;
 #pragma unroll
@@ -404,9 +416,9 @@ __global__ __launch_bounds__(256) void dense_loss_kernel(const float* __restrict
             if (k <= K) {
                 float g = region_lw * (z[k] / se - (k == tgt ? 1.f : 0.f)) * mv * inv_d;
                 if (k == 0) g += g_my;
-                dh[4 + k] = g;
+                dh[MC + 3 + k] = g;
             }
-        for (int c = 5 + K; c < head_cs; ++c) dh[c] = 0.f;
+        for (int c = MC + 4 + K; c < head_cs; ++c) dh[c] = 0.f;
     }
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
@@ -448,35 +460,46 @@ __global__ void dense_loss_finalize_kernel(const double* __restrict__ partial, i
     losses[k] = (float)v;
 }
 
-extern "C" int rdpn6d_dense_losses_f32(const float* head, int head_cs, const float* gt_xyz, const float* mask_visib,
-                                       const float* mask_trunc, const long long* gt_region, int B, int HW, int K, float xyz_lw,
-                                       float mask_lw, float region_lw, float* dhead, float* losses /* [6] */,
-                                       double* scratch /* >= 8 + 6*ceil(B*HW/256) doubles */, void* stream)
+extern "C" int rdpn6d_dense_losses_mt_f32(const float* head, int head_cs, const float* gt_xyz, const float* mask_visib,
+                                          const float* mask_trunc, const long long* gt_region, int B, int HW, int K, float xyz_lw,
+                                          float mask_lw, float region_lw, int mask_type, float* dhead, float* losses /* [6] */,
+                                          double* scratch /* >= 8 + 6*ceil(B*HW/256) doubles */, void* stream)
 {
     RD_REQUIRE(head && gt_xyz && mask_visib && mask_trunc && gt_region && dhead && losses && scratch, "null pointer");
-    RD_REQUIRE(B > 0 && HW > 0 && K >= 2 && K <= 64 && head_cs >= 5 + K, "shape");
+    RD_REQUIRE(mask_type >= 0 && mask_type <= 2, "mask_type: 0 L1 | 1 BCE | 2 CE");
+    const int mc = mask_type == 2 ? 2 : 1;
+    RD_REQUIRE(B > 0 && HW > 0 && K >= 2 && K <= 64 && head_cs >= mc + 4 + K, "shape");
     hipStream_t s = (hipStream_t)stream;
     const long long n = (long long)B * HW;
     const int nblk = (int)((n + 255) / 256);
     hipLaunchKernelGGL(mask_sum_kernel, dim3(1), dim3(1024), 0, s, mask_visib, n, scratch);
     RD_LAUNCH_CHECK();
-    if (K <= 32)
-        hipLaunchKernelGGL(dense_loss_kernel<32>, dim3(nblk), dim3(256), 0, s, head, head_cs, gt_xyz, mask_visib, mask_trunc, gt_region,
-                           B, HW, K, scratch, xyz_lw, mask_lw, region_lw, dhead, scratch + 8);
-    else
-        hipLaunchKernelGGL(dense_loss_kernel<64>, dim3(nblk), dim3(256), 0, s, head, head_cs, gt_xyz, mask_visib, mask_trunc, gt_region,
-                           B, HW, K, scratch, xyz_lw, mask_lw, region_lw, dhead, scratch + 8);
+#define RD_DL(KM, MCV) hipLaunchKernelGGL((dense_loss_kernel<KM, MCV>), dim3(nblk), dim3(256), 0, s, head, head_cs, gt_xyz, mask_visib, \
+                                          mask_trunc, gt_region, B, HW, K, scratch, xyz_lw, mask_lw, region_lw, dhead, scratch + 8, mask_type)
+    if (K <= 32) { if (mc == 1) RD_DL(32, 1); else RD_DL(32, 2); }
+    else { if (mc == 1) RD_DL(64, 1); else RD_DL(64, 2); }
+#undef RD_DL
     RD_LAUNCH_CHECK();
     hipLaunchKernelGGL(dense_loss_finalize_kernel, dim3(1), dim3(384), 0, s, scratch + 8, nblk, scratch, n, xyz_lw, mask_lw, region_lw, losses);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
 }
 
+extern "C" int rdpn6d_dense_losses_f32(const float* head, int head_cs, const float* gt_xyz, const float* mask_visib,
+                                       const float* mask_trunc, const long long* gt_region, int B, int HW, int K, float xyz_lw,
+                                       float mask_lw, float region_lw, float* dhead, float* losses /* [6] */,
+                                       double* scratch /* >= 8 + 6*ceil(B*HW/256) doubles */, void* stream)
+{
+    return rdpn6d_dense_losses_mt_f32(head, head_cs, gt_xyz, mask_visib, mask_trunc, gt_region, B, HW, K, xyz_lw, mask_lw, region_lw, 0, dhead,
+                                      losses, scratch, stream);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Glue backward: dpnp [B,HW,pnp_cs] (gradient of the ConvPnPNet input) -> accumulated into dhead [B,HW,head_cs].
 //   pnp_in = att * [x y z | coord2d(5) | anchor(3) | softmax(region[1:])],  att = 1 or (mask-mn)/(mx-mn)
 // datt_out [B,HW] (only with mask attention) feeds the per-sample min/max terms handled by the second kernel.
-template <int KMAX>
+// MC = mask channels (1 | 2, see dense_loss_kernel); mask_attention: 0 none, 1 min-max (MASK_LOSS_TYPE L1), 2 sigmoid (BCE)
+template <int KMAX, int MC = 1>
 __global__ __launch_bounds__(128) void dense_glue_bwd_kernel(const float* __restrict__ head, int head_cs,
                                                              const float* __restrict__ coord2d, const float* __restrict__ fps,
                                                              const int* __restrict__ argmax, const float* __restrict__ dpnp,
@@ -518,18 +541,20 @@ __global__ __launch_bounds__(128) void dense_glue_bwd_kernel(const float* __rest
     float* h = s_h + threadIdx.x * sh;
     const float* g = s_g + threadIdx.x * sg;
     float att = 1.f, range = 1.f;
-    if (mask_attention) {
+    if (mask_attention == 1) {
         range = minmax[b * 2 + 1] - minmax[b * 2];
         att = (h[0] - minmax[b * 2]) / range;
+    } else if (mask_attention == 2) {
+        att = 1.f / (1.f + expf(-h[0]));
     }
     // softmax over region[1..K]
     float e[KMAX], mx = -FLT_MAX, se = 0.f;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k)
-        if (k < K) mx = fmaxf(mx, h[5 + k]);
+        if (k < K) mx = fmaxf(mx, h[MC + 4 + k]);
 #pragma unroll
     for (int k = 0; k < KMAX; ++k)
-        if (k < K) { e[k] = expf(h[5 + k] - mx); se += e[k]; }
+        if (k < K) { e[k] = expf(h[MC + 4 + k] - mx); se += e[k]; }
     float dot = 0.f;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k)
@@ -539,7 +564,7 @@ __global__ __launch_bounds__(128) void dense_glue_bwd_kernel(const float* __rest
         // datt = sum_c dpnp[c] * (un-attenuated input c)
         float da = 0.f;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) da += g[c] * h[1 + c];
+        for (int c = 0; c < 3; ++c) da += g[c] * h[MC + c];
 #pragma unroll
         for (int c = 0; c < 5; ++c) da += g[3 + c] * coord2d[((long long)b * 5 + c) * HW + p];
         const float* an = fps + ((long long)b * K + argmax[i]) * 3;
@@ -548,17 +573,21 @@ __global__ __launch_bounds__(128) void dense_glue_bwd_kernel(const float* __rest
 #pragma unroll
         for (int k = 0; k < KMAX; ++k)
             if (k < K) da += g[11 + k] * e[k];
-        d0 = da / range;
-        datt_out[i] = da;
+        if (mask_attention == 1) {
+            d0 = da / range;
+            datt_out[i] = da;
+        } else {
+            d0 = da * att * (1.f - att);  // d sigmoid / d mask; no per-sample extrema terms
+        }
     }
     // the row now becomes the contribution to dhead (every read of h is done)
     for (int c = 0; c < head_cs; ++c) h[c] = 0.f;
     h[0] = d0;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) h[1 + c] = g[c] * att;
+    for (int c = 0; c < 3; ++c) h[MC + c] = g[c] * att;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k)
-        if (k < K) h[5 + k] = e[k] * (g[11 + k] * att - dot);
+        if (k < K) h[MC + 4 + k] = e[k] * (g[11 + k] * att - dot);
     }
     __syncthreads();
     {
@@ -630,33 +659,44 @@ __global__ __launch_bounds__(256) void mask_attention_extrema_bwd_kernel(const f
     }
 }
 
-extern "C" int rdpn6d_dense_glue_backward_f32(const float* head, int head_cs, const float* coord2d, const float* fps,
-                                              const int* argmax, const float* dpnp, int pnp_cs, int B, int HW, int K,
-                                              int mask_attention, const float* minmax, float* dhead, float* datt_scratch,
-                                              void* stream)
+extern "C" int rdpn6d_dense_glue_backward_mt_f32(const float* head, int head_cs, const float* coord2d, const float* fps,
+                                                 const int* argmax, const float* dpnp, int pnp_cs, int B, int HW, int K,
+                                                 int mask_attention, int mask_type, const float* minmax, float* dhead,
+                                                 float* datt_scratch, void* stream)
 {
     RD_REQUIRE(head && coord2d && fps && argmax && dpnp && dhead, "null pointer");
     RD_REQUIRE(B > 0 && HW > 0 && K >= 2 && K <= 64, "K in 2..64");
-    RD_REQUIRE(!mask_attention || (minmax && datt_scratch), "mask attention needs minmax and a [B,HW] scratch");
+    RD_REQUIRE(mask_type >= 0 && mask_type <= 2, "mask_type: 0 L1 | 1 BCE | 2 CE");
+    RD_REQUIRE(!(mask_attention && mask_type == 2), "MASK_ATTENTION with MASK_LOSS_TYPE CE: the reference's get_mask_prob raises there");
+    const int att = mask_attention ? (mask_type == 1 ? 2 : 1) : 0, mc = mask_type == 2 ? 2 : 1;
+    RD_REQUIRE(att != 1 || (minmax && datt_scratch), "min-max mask attention needs minmax and a [B,HW] scratch");
     hipStream_t s = (hipStream_t)stream;
-    RD_REQUIRE(head_cs >= 5 + K && pnp_cs >= 11 + K && head_cs <= 128 && pnp_cs <= 128, "row strides");
+    RD_REQUIRE(head_cs >= mc + 4 + K && pnp_cs >= 11 + K && head_cs <= 128 && pnp_cs <= 128, "row strides");
     const int rowf = (head_cs | 1) + (pnp_cs | 1);          // floats of LDS per pixel
     static const int nt_env = getenv("RDPN6D_GLUE_BWD_NT") ? atoi(getenv("RDPN6D_GLUE_BWD_NT")) : 0;  // profiling
     const int nt = nt_env ? nt_env : (rowf * 128 * 4 <= 64 * 1024 ? 128 : 64);  // pixels (= threads) per workgroup
     const unsigned blocks = (unsigned)(((long long)B * HW + nt - 1) / nt);
     const size_t lds = (size_t)rowf * nt * 4;
-    if (K <= 32)
-        hipLaunchKernelGGL(dense_glue_bwd_kernel<32>, dim3(blocks), dim3(nt), lds, s, head, head_cs, coord2d, fps, argmax, dpnp, pnp_cs, B,
-                           HW, K, mask_attention, minmax, dhead, datt_scratch);
-    else
-        hipLaunchKernelGGL(dense_glue_bwd_kernel<64>, dim3(blocks), dim3(nt), lds, s, head, head_cs, coord2d, fps, argmax, dpnp, pnp_cs, B,
-                           HW, K, mask_attention, minmax, dhead, datt_scratch);
+#define RD_GB(KM, MCV) hipLaunchKernelGGL((dense_glue_bwd_kernel<KM, MCV>), dim3(blocks), dim3(nt), lds, s, head, head_cs, coord2d, fps, argmax, \
+                                          dpnp, pnp_cs, B, HW, K, att, minmax, dhead, datt_scratch)
+    if (K <= 32) { if (mc == 1) RD_GB(32, 1); else RD_GB(32, 2); }
+    else { if (mc == 1) RD_GB(64, 1); else RD_GB(64, 2); }
+#undef RD_GB
     RD_LAUNCH_CHECK();
-    if (mask_attention) {
+    if (att == 1) {
         hipLaunchKernelGGL(mask_attention_extrema_bwd_kernel, dim3(B), dim3(256), 0, s, head, head_cs, datt_scratch, HW, minmax, dhead);
         RD_LAUNCH_CHECK();
     }
     return RDPN6D_OK;
+}
+
+extern "C" int rdpn6d_dense_glue_backward_f32(const float* head, int head_cs, const float* coord2d, const float* fps,
+                                              const int* argmax, const float* dpnp, int pnp_cs, int B, int HW, int K,
+                                              int mask_attention, const float* minmax, float* dhead, float* datt_scratch,
+                                              void* stream)
+{
+    return rdpn6d_dense_glue_backward_mt_f32(head, head_cs, coord2d, fps, argmax, dpnp, pnp_cs, B, HW, K, mask_attention, 0, minmax, dhead,
+                                             datt_scratch, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

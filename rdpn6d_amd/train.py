@@ -75,8 +75,17 @@ class TrainEngine:
         self.mask_attention = 1 if pc.MASK_ATTENTION == "mul" else 0
         if pc.MASK_ATTENTION not in ("none", "mul"):
             raise ValueError("MASK_ATTENTION must be none | mul")
-        if rc.XYZ_LOSS_TYPE != "L1" or rc.MASK_LOSS_TYPE != "L1" or rc.REGION_LOSS_TYPE != "CE":
-            raise NotImplementedError("only the loss types of the shipped RGB-D configs (L1 / L1 / CE) are implemented")
+        if rc.XYZ_LOSS_TYPE != "L1" or rc.REGION_LOSS_TYPE != "CE":
+            raise NotImplementedError("only the xyz / region loss types of the shipped RGB-D configs (L1 / CE) are implemented")
+        from .gdrn import MASK_TYPES
+
+        if rc.MASK_LOSS_TYPE not in MASK_TYPES:
+            raise NotImplementedError(f"unknown mask loss type: {rc.MASK_LOSS_TYPE}")
+        # ROT_HEAD.MASK_LOSS_TYPE: L1 (the shipped configs) | BCE (BCEWithLogits, sigmoid attention) | CE (two mask channels): GDRN.py:450-463
+        self.mask_type = MASK_TYPES[str(rc.MASK_LOSS_TYPE)]
+        if self.mask_type == 2 and self.mask_attention:
+            raise NotImplementedError("MASK_ATTENTION with ROT_HEAD.MASK_LOSS_TYPE='CE': get_mask_prob's CE branch raises in the reference "
+                                      "itself (torch.softmax has no keepdim argument, models/model_utils.py:39)")
         if rc.XYZ_LOSS_MASK_GT != "visib" or rc.MASK_LOSS_GT != "trunc" or rc.REGION_LOSS_MASK_GT != "visib":
             raise NotImplementedError("loss mask selection other than visib/trunc/visib is not implemented")
         if not (pc.PM_R_ONLY and pc.PM_LOSS_TYPE == "L1" and pc.PM_LW > 0):
@@ -926,13 +935,13 @@ class TrainEngine:
         datt = self.buf("datt", B, HW)
         self.coord2d = self.buf("coord2d", B, 5, R4, R4)
         self.fps_t = self.buf("fps", B, K, 3)
-        self.fwd.append(lambda: _lib.check(lib.rdpn6d_dense_glue_f32(_ptr(ho), self.head_cs, _ptr(self.coord2d), _ptr(self.fps_t), B, HW, K,
-                                                                  self.mask_attention, _ptr(self.minmax), _ptr(self.out_nchw), _ptr(pnp_in),
+        self.fwd.append(lambda: _lib.check(lib.rdpn6d_dense_glue_mt_f32(_ptr(ho), self.head_cs, _ptr(self.coord2d), _ptr(self.fps_t), B, HW, K,
+                                                                     self.mask_attention, self.mask_type, _ptr(self.minmax), _ptr(self.out_nchw), _ptr(pnp_in),
                                                                   self.pnp_cs, _ptr(self.argmax), self.st()), "glue"))
-        self.bwd.append([lambda: _lib.check(lib.rdpn6d_dense_glue_backward_f32(_ptr(ho), self.head_cs, _ptr(self.coord2d), _ptr(self.fps_t),
-                                                                            _ptr(self.argmax), _ptr(d_pnp_in), self.pnp_cs, B, HW, K,
-                                                                            self.mask_attention, _ptr(self.minmax), _ptr(d_ho), _ptr(datt),
-                                                                            self.st()), "glue bwd")])
+        self.bwd.append([lambda: _lib.check(lib.rdpn6d_dense_glue_backward_mt_f32(_ptr(ho), self.head_cs, _ptr(self.coord2d), _ptr(self.fps_t),
+                                                                               _ptr(self.argmax), _ptr(d_pnp_in), self.pnp_cs, B, HW, K,
+                                                                               self.mask_attention, self.mask_type, _ptr(self.minmax), _ptr(d_ho),
+                                                                               _ptr(datt), self.st()), "glue bwd")])
         # ---- ConvPnPNet
         self._group_marks[len(self.bwd)] = "pnp_net"
         x, d_x, hw, cin_real, cs = pnp_in, d_pnp_in, R4, 11 + K, self.pnp_cs
@@ -1095,9 +1104,9 @@ class TrainEngine:
                                                  _ptr(sym_rots) if ksym else None, _ptr(sym_counts) if ksym else None, ksym,
                                                  _ptr(self.gt_rot_used), _ptr(self.rot), _ptr(self.trans), _ptr(self.d_rt),
                                                  _ptr(losses9[6:]), _ptr(sc), self.st()), "pose_train")
-        _lib.check(lib.rdpn6d_dense_losses_f32(_ptr(self.head_out), self.head_cs, _ptr(gt_xyz), _ptr(mv), _ptr(mt), _ptr(gt_region), B, HW,
-                                               K, lw["xyz"], lw["mask"], lw["region"], _ptr(self.d_head), _ptr(losses9),
-                                               _ptr(self._scratch_d), self.st()), "dense_losses")
+        _lib.check(lib.rdpn6d_dense_losses_mt_f32(_ptr(self.head_out), self.head_cs, _ptr(gt_xyz), _ptr(mv), _ptr(mt), _ptr(gt_region), B, HW,
+                                                  K, lw["xyz"], lw["mask"], lw["region"], self.mask_type, _ptr(self.d_head), _ptr(losses9),
+                                                  _ptr(self._scratch_d), self.st()), "dense_losses")
 
     def seed_backward(self, weights):
         """d(total)/d(loss_i) for the next backward() - what autograd hands to the node the nine losses hang off

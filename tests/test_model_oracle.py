@@ -359,3 +359,34 @@ def test_oracle_mask_loss_types_bce_and_ce_vs_the_reference(golden_dir):
     orc.mask_attention = "mul"
     with pytest.raises(TypeError), torch.no_grad():
         orc(t["roi_img"], t["roi_coord_2d"], t["fps"], t["roi_cam"], t["roi_center"], t["roi_wh"], t["resize_ratio"])
+
+
+@pytest.mark.parametrize("mlt,att", [("BCE", "mul"), ("CE", "none")])
+def test_oracle_training_step_with_bce_and_ce_mask_losses_vs_the_reference(golden_dir, mlt, att):
+    """loss_mask = BCEWithLogits / CrossEntropy (GDRN.py:455-460) and the sigmoid mask attention in the TRAINING step: the oracle's
+    nine losses and every parameter's gradient norm against the real reference built with that MASK_LOSS_TYPE
+    (tests/golden/mask_types_golden.npz, tools/oracle/gen_mask_types_golden.py)."""
+    gold = np.load(os.path.join(golden_dir, "mask_types_golden.npz"))
+    bn = np.load(os.path.join(golden_dir, "bn_stats_c1w.npz"))
+    inp = synth.make_inputs(4, seed=int(gold["train_input_seed"]))
+    tc = {k: torch.from_numpy(v) for k, v in {**inp, **synth.make_train_gt(4, inp)}.items()}
+    orc = model_oracle.GDRNOracle(32, att, mask_loss_type=mlt)
+    sd = synth.make_trained_like_state_dict({k: tuple(v.shape) for k, v in orc.state_dict().items()}, seed=1234)
+    sd.update({k: bn[k] for k in bn.files})
+    orc.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    orc.train()
+    oo = orc(tc["roi_img"], tc["roi_coord_2d"], tc["fps"], tc["roi_cam"], tc["roi_center"], tc["roi_wh"], tc["resize_ratio"], train_pose=True)
+    losses = model_oracle.gdrn_losses(oo, tc, tc["roi_extent"], mask_loss_type=mlt)
+    sum(losses.values()).backward()
+    for k, v in losses.items():
+        ref = float(gold[f"train_{mlt}_{att}_{k}"])
+        assert abs(float(v) - ref) <= 1e-5 * max(1.0, abs(ref)), (k, float(v), ref)
+    worst = 0.0
+    for n, p in orc.named_parameters():
+        ref = float(gold[f"train_{mlt}_{att}_gradnorm/{n}"])
+        g = float(p.grad.double().norm())
+        if ref <= 1e-4:
+            assert g <= 1e-3, n
+            continue
+        worst = max(worst, abs(g - ref) / ref)
+    assert worst <= 2e-2, worst  # (an fp32 ReLU network's gradients: the reference vs itself is no closer between thread counts)

@@ -7,10 +7,13 @@
    GDRN_Evaluator.get_img_model_points_with_coords2d, in the order process_pnp_ransac calls them (gdrn_evaluator.py:325-374), on
    the seeded cases of tests/select_cases.py (mask logits = the case's mask shifted / scaled so that both signs occur; CE: a
    second, seeded channel).
+3. (below) the training step.
 2. The whole model built by the reference's own factory with MASK_LOSS_TYPE = "BCE" (MASK_ATTENTION none and mul: get_mask_prob's
    sigmoid branch, models/model_utils.py:35-37) and "CE" (MASK_ATTENTION none; 38 head channels: two mask channels) on the
    well-conditioned weights / inputs of model_c1w.npz: rot, trans and - CE - the dense maps.  With MASK_ATTENTION = mul the
    reference's CE branch raises (torch.softmax(..., keepdim=True)): recorded as `ce_mul_raises`.
+3. The training step of the same three models on model_c1w.npz's training batch: the nine losses (loss_mask = BCEWithLogits /
+   CrossEntropy, GDRN.py:455-460) and the gradient norm of every parameter.
 """
 import os
 import sys
@@ -114,6 +117,41 @@ def main():
                 oo = orc(tin["roi_img"], tin["roi_coord_2d"], tin["fps"], tin["roi_cam"], tin["roi_center"], tin["roi_wh"], tin["resize_ratio"])
             for k in ("rot", "trans", "mask", "coor_x", "region"):
                 print(f"[{mlt} {att}] oracle vs reference {k}: max abs diff {(oo[k] - o[k]).abs().max().item():.3e}")
+    # ---- 3. the training step (GDRN.py:450-463: BCEWithLogits / CrossEntropy mask loss; sigmoid attention) on model_c1w.npz's training batch
+    inp = synth.make_inputs(B, seed=synth.C1W_TRAIN_INPUT_SEED, res=256, num_regions=32, cam="lm")
+    tin = {k: torch.from_numpy(v) for k, v in inp.items()}
+    gt = synth.make_train_gt(B, inp)
+    tgt = {k: torch.from_numpy(v) for k, v in gt.items()}
+    out["train_input_seed"] = np.int64(synth.C1W_TRAIN_INPUT_SEED)
+    for mlt, atts in (("BCE", ("none", "mul")), ("CE", ("none",))):
+        orc = model_oracle.GDRNOracle(num_regions=32, mask_attention="none", mask_loss_type=mlt)
+        shapes = {k: tuple(v.shape) for k, v in orc.state_dict().items()}
+        sd = {k: torch.from_numpy(v) for k, v in synth.make_trained_like_state_dict(shapes, seed=1234).items()}
+        sd.update({k: torch.from_numpy(bn[k]) for k in bn.files})
+        for att in atts:
+            torch.set_num_threads(8)
+            ref, _ = build_reference(att, mlt)
+            ref.load_state_dict(sd, strict=True)
+            ref.train()
+            _, losses = ref(tin["roi_img"].clone(), gt_xyz=tgt["roi_xyz"], gt_xyz_bin=None, gt_mask_trunc=tgt["roi_mask_trunc"],
+                            gt_mask_visib=tgt["roi_mask_visib"], gt_mask_obj=tgt["roi_mask_obj"], gt_region=tgt["roi_region"],
+                            gt_ego_rot=tgt["ego_rot"], gt_points=tgt["roi_points"], sym_infos=None, gt_trans=tgt["trans"],
+                            gt_trans_ratio=tgt["roi_trans_ratio"], roi_classes=tin["roi_cls"], roi_coord_2d=tin["roi_coord_2d"].clone(),
+                            roi_cams=tin["roi_cam"].clone(), roi_centers=tin["roi_center"], roi_whs=tin["roi_wh"],
+                            roi_extents=tin["roi_extent"], resize_ratios=tin["resize_ratio"], do_loss=True, fps=tin["fps"])
+            sum(losses.values()).backward()
+            for k, v in losses.items():
+                out[f"train_{mlt}_{att}_{k}"] = np.float64(v.item())
+            for n, p in ref.named_parameters():
+                out[f"train_{mlt}_{att}_gradnorm/{n}"] = np.float64(p.grad.double().norm().item())
+            # the oracle restatement on the spot
+            orc.mask_attention = att
+            orc.load_state_dict(sd, strict=True)
+            orc.train()
+            oo = orc(tin["roi_img"], tin["roi_coord_2d"], tin["fps"], tin["roi_cam"], tin["roi_center"], tin["roi_wh"], tin["resize_ratio"],
+                     train_pose=True)
+            ol = model_oracle.gdrn_losses(oo, tgt, tin["roi_extent"], mask_loss_type=mlt)
+            print(f"[train {mlt} {att}] " + " ".join(f"{k.replace('loss_', '')} {float(v):.6f}/{float(ol[k]):.6f}" for k, v in losses.items()))
     np.savez_compressed(os.path.join(GOLD, "mask_types_golden.npz"), **out)
     print("wrote mask_types_golden.npz", os.path.getsize(os.path.join(GOLD, "mask_types_golden.npz")) / 1e6, "MB on disk")
 
