@@ -175,6 +175,13 @@ long long rdpn6d_conv_h2_workspace_bytes(const rdpn6d_conv_desc* d);
  * rdpn6d_conv_h2_wfrag_wanted says whether a layer's kernel has that form; rdpn6d_conv2d_h2_wf = rdpn6d_conv2d_h2 + the re-ordered
  * weights (null or an unwanted w_frag: the ordinary kernel).  Results are bit-identical with and without. */
 void rdpn6d_conv_h2_set_wfrag(int mode); /* 0 (default): no layer wants them - measured slower, kept for the record; 1: 128x128; 2: + 256x128 */
+/* Column-max form: for a layer whose output only a per-group channel max reads (resnet_backbone.py:51-52: the point-wise branch's
+ * adaptive max over a crop's pixels, when nothing else needs the layer's output).  keys [groups][Npad] uint64 (zero before the call)
+ * receive the h2 record of max over the group's rows of scale * conv + shift; rdpn6d_h2_colmax_decode turns them into the record
+ * rdpn6d_global_max_h2 would have produced from the written activation and zeroes them again.  The activation is never written. */
+int rdpn6d_conv_h2_colmax_ok(const rdpn6d_conv_desc* d, int rows_per_group);
+int rdpn6d_conv2d_h2_colmax(const rdpn6d_conv_desc* d, unsigned long long* keys, int rows_per_group, int* overflow_flag, void* stream);
+int rdpn6d_h2_colmax_decode(unsigned long long* keys, int groups, int N, int Npad, void* out_h2, void* stream);
 int rdpn6d_conv_h2_wfrag_wanted(const rdpn6d_conv_desc* d);
 int rdpn6d_h2_weight_frag(const void* w_h2, int Npad, int ntaps, int cchunks, void* w_frag, void* stream);
 int rdpn6d_conv2d_h2_wf(const rdpn6d_conv_desc* d, void* y_h2, const void* res_h2, int* overflow_flag, const void* w_frag, void* stream);

@@ -154,6 +154,9 @@ SIGNATURES = {
     "rdpn6d_conv_h2_fuse1x1_ok": (_i, [ctypes.POINTER(ConvDesc)]),
     "rdpn6d_conv2d_h2_fuse1x1": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "rdpn6d_conv_h2_workspace_bytes": (ctypes.c_longlong, [_vp]),
+    "rdpn6d_conv_h2_colmax_ok": (_i, [ctypes.POINTER(ConvDesc), _i]),
+    "rdpn6d_conv2d_h2_colmax": (_i, [ctypes.POINTER(ConvDesc), _vp, _i, _vp, _vp]),
+    "rdpn6d_h2_colmax_decode": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "rdpn6d_conv_h2_set_wfrag": (None, [_i]),
     "rdpn6d_conv_h2_wfrag_wanted": (_i, [ctypes.POINTER(ConvDesc)]),
     "rdpn6d_h2_weight_frag": (_i, [_vp, _i, _i, _i, _vp, _vp]),

@@ -49,8 +49,15 @@ static_assert(LDS_8PH_FUSED >= LDS_8PH && LDS_8PH_FUSED <= 160 * 1024, "LDS");
 
 // Schedule, LDS map, DMA stream and counted waits: see conv_igemm_bf16_8ph.hip (this is that kernel with the h2 inner
 // product - 12 MFMAs per phase instead of 8 - and the h2 epilogue).  A K-tile = one 128-byte row = 32 channels (hi | lo).
-template <bool FUSE>
-__global__ __launch_bounds__(512) void conv_h2_8ph_kernel_t(const ConvH2Args ax)
+// CMAX (round 5): the COLUMN-MAX form for a layer whose output only a per-crop channel max reads (the point-wise branch's last
+// convolution + BatchNorm under the exact rewrites of gdrn.py: its 134-MB h2 output was written by this kernel and read back by
+// global_max_h2_kernel - 0.05 ms of a 6.7-ms step for nothing).  The epilogue takes scale * acc + shift exactly as the plain one, makes
+// the h2 record of every value, and keeps per column the record of the largest reconstructed value of the workgroup's 256 rows (all
+// of one crop: rows_per_group % 256 == 0) as a 64-bit key [ordered float bits of hi + lo | hi bits | lo bits]; one atomic max per
+// (wave, column) merges the keys of a crop's workgroups - max is order-independent, the result is deterministic.  The activation is
+// never written.  ax.fuse_out = the key table [groups][Npad] (zero = empty), ax.fuse_cs = rows per group.
+template <bool FUSE, bool CMAX>
+__device__ __forceinline__ void conv_h2_8ph_body(const ConvH2Args& ax)
 {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 #ifdef RDPN6D_PROBE
@@ -419,6 +426,47 @@ __global__ __launch_bounds__(512) void conv_h2_8ph_kernel_t(const ConvH2Args ax)
         }
         return;
     }
+    if constexpr (CMAX) {
+        // lane (frow, half) holds column nb + j*32 + frow at rows i*32 + (e&3) + 8*(e>>2) + 4*half of the wave's 128 rows.  The h2 record of a
+        // value is a monotonic function of the value, so the record of the column's largest value is the record of max(scale * acc + shift):
+        // one v_max per element, ONE split per lane and column (the element-wise form - split every value, compare 64-bit keys - ran
+        // 64 us against the plain launch's 57); the range check of the format (|16 v| > 65504, inf, NaN) is one unsigned max of the |bit
+        // patterns| per element, as in h2_format.h
+        unsigned long long* keys = reinterpret_cast<unsigned long long*>(ax.fuse_out);
+        const int hi = lane >> 5;
+        const long long rbase = m0 + wr * 128 + 4 * hi;
+        const bool full = m0 + 256 <= a.M;  // block-uniform: no row of the tile lies past M
+        unsigned mbits = 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float vmax = -__builtin_huge_valf();
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float v = acc[i][j][e] * scj[j] + shj[j];
+                    const bool valid = full || rbase + i * 32 + (e & 3) + 8 * (e >> 2) < a.M;
+                    const unsigned ub = __float_as_uint(v) & 0x7fffffffu;
+                    mbits = (valid && ub > mbits) ? ub : mbits;
+                    vmax = valid ? __builtin_fmaxf(vmax, v) : vmax;
+                }
+            const float vo = __shfl_xor(vmax, 32, 64);
+            vmax = __builtin_fmaxf(vmax, vo);
+            const int n = nb + j * 32 + frow;
+            if (hi == 0 && n < d.N && vmax > -__builtin_huge_valf()) {
+                _Float16 hq, lq;
+                h2_split(vmax * H2_SCALE, hq, lq);
+                const float r = (float)hq + (float)lq;
+                const unsigned u = __float_as_uint(r);
+                const unsigned ord = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+                const unsigned pay = ((unsigned)__builtin_bit_cast(unsigned short, hq) << 16) | (unsigned)__builtin_bit_cast(unsigned short, lq);
+                atomicMax(keys + (m0 / ax.fuse_cs) * d.Npad + n, ((unsigned long long)ord << 32) | pay);
+            }
+        }
+        // |16 v| > 65504  <=>  |v| > 4094 (0x457fe000), inf and NaN order above it too
+        if (mbits > 0x457fe000u && ax.overflow_flag) *ax.overflow_flag = 1;
+        return;
+    }
     // ---- epilogue: each wave transposes its 128 x 64 tile through its own LDS slice, 8 channels per lane on the way out
     {
         const int hi = lane >> 5;
@@ -465,6 +513,13 @@ __global__ __launch_bounds__(512) void conv_h2_8ph_kernel_t(const ConvH2Args ax)
     }
 #endif
 }
+
+template <bool FUSE>
+__global__ __launch_bounds__(512) void conv_h2_8ph_kernel_t(const ConvH2Args ax)
+{
+    conv_h2_8ph_body<FUSE, false>(ax);
+}
+__global__ __launch_bounds__(512) void conv_h2_8ph_colmax_kernel(const ConvH2Args ax) { conv_h2_8ph_body<false, true>(ax); }
 
 constexpr auto conv_h2_8ph_kernel = conv_h2_8ph_kernel_t<false>;
 
@@ -1024,7 +1079,7 @@ extern "C" int rdpn6d_conv2d_h2_cb(const rdpn6d_conv_desc* d, void* y_h2, const 
 }
 
 struct H2Fuse {
-    const void* w;
+    const void* w;  // null: the column-max form (out = the 64-bit key table, cs = rows per group)
     const float *scale, *bias;
     float* out;
     int cs, n;
@@ -1102,6 +1157,48 @@ extern "C" int rdpn6d_conv2d_h2_fuse1x1(const rdpn6d_conv_desc* d, const void* r
     RD_REQUIRE(!res_h2 && !crop_bias && !d->res, "the fused 1x1 form takes no residual and no per-crop bias");
     const H2Fuse f = {w1_h2, scale1, bias1, out, out_cs, n_out};
     return conv2d_h2_impl(d, nullptr, res_h2, overflow_flag, crop_bias, nullptr, 0, &f, stream);
+}
+
+// The convolution whose output only a per-group (per-crop) channel max reads: keys [groups][Npad] uint64, ZERO before the call (the
+// decode kernel below leaves them zero), get per (group, channel) the h2 record of the largest value scale * conv + shift over the
+// group's rows_per_group consecutive output rows - see conv_h2_8ph_body<.., CMAX>.  Needs the 256x256 kernel, rows_per_group % 256 == 0,
+// no activation, no residual; the activation itself is never written (desc.y must be null).
+extern "C" int rdpn6d_conv_h2_colmax_ok(const rdpn6d_conv_desc* d, int rows_per_group)
+{
+    return d && rdpn6d_conv_h2_kernel_for(d) == 2 && rows_per_group > 0 && rows_per_group % 256 == 0 && d->act == 0 && !d->res &&
+           ((long long)d->B * d->Ho * d->Wo) % rows_per_group == 0 && d->osy == 1 && d->osx == 1 && d->ooy == 0 && d->oox == 0 && d->OH == d->Ho && d->OW == d->Wo;
+}
+extern "C" int rdpn6d_conv2d_h2_colmax(const rdpn6d_conv_desc* d, unsigned long long* keys, int rows_per_group, int* overflow_flag,
+                                       void* stream)
+{
+    RD_REQUIRE(d && keys, "null pointer");
+    RD_REQUIRE(rdpn6d_conv_h2_colmax_ok(d, rows_per_group), "column-max form: 256x256 kernel, rows_per_group % 256 == 0, linear output, no activation / residual");
+    RD_REQUIRE(d->y == nullptr, "the column-max form does not write the activation (desc.y must be null)");
+    const H2Fuse f = {nullptr, nullptr, nullptr, reinterpret_cast<float*>(keys), rows_per_group, 0};
+    return conv2d_h2_impl(d, nullptr, nullptr, overflow_flag, nullptr, nullptr, 0, &f, stream);
+}
+
+// keys [groups][Npad] -> the h2 record [groups][N/32][hi x 32 | lo x 32] of the maxima (what rdpn6d_global_max_h2 writes), and the
+// keys back to zero for the next forward
+__global__ void h2_colmax_decode_kernel(unsigned long long* __restrict__ keys, int groups, int N, int Npad, _Float16* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= groups * N) return;
+    const int g = i / N, n = i - g * N;
+    const unsigned long long k = keys[(size_t)g * Npad + n];
+    keys[(size_t)g * Npad + n] = 0ull;
+    const unsigned pay = (unsigned)(k & 0xffffffffull);
+    _Float16* o = out + ((size_t)g * (N / 32) + (n >> 5)) * 64 + (n & 31);
+    o[0] = __builtin_bit_cast(_Float16, (unsigned short)(pay >> 16));
+    o[32] = __builtin_bit_cast(_Float16, (unsigned short)(pay & 0xffffu));
+}
+extern "C" int rdpn6d_h2_colmax_decode(unsigned long long* keys, int groups, int N, int Npad, void* out_h2, void* stream)
+{
+    RD_REQUIRE(keys && out_h2 && groups > 0 && N > 0 && N % 32 == 0 && Npad >= N, "shape (N % 32)");
+    hipLaunchKernelGGL(h2_colmax_decode_kernel, dim3((unsigned)((groups * N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, keys, groups, N,
+                       Npad, (_Float16*)out_h2);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
 }
 
 static int conv2d_h2_impl(const rdpn6d_conv_desc* d, void* y_h2, const void* res_h2, int* overflow_flag, const float* crop_bias,
@@ -1197,6 +1294,12 @@ static int conv2d_h2_impl(const rdpn6d_conv_desc* d, void* y_h2, const void* res
     }
     a.mtiles = rd_cdiv(a.M, 256);
     a.ntiles = d->Npad / 256;
+    if (fuse && !fuse->w) {  // column max (rdpn6d_conv2d_h2_colmax): nothing written but the key table
+        RD_LDS_OPT_IN(conv_h2_8ph_colmax_kernel, LDS_8PH);
+        hipLaunchKernelGGL(conv_h2_8ph_colmax_kernel, dim3((unsigned)(a.mtiles * a.ntiles)), dim3(512), LDS_8PH, s, ax);
+        RD_LAUNCH_CHECK();
+        return RDPN6D_OK;
+    }
     if (fuse) {
         RD_LDS_OPT_IN(conv_h2_8ph_kernel_t<true>, LDS_8PH_FUSED);
         hipLaunchKernelGGL(conv_h2_8ph_kernel_t<true>, dim3((unsigned)(a.mtiles * a.ntiles)), dim3(512), LDS_8PH_FUSED, s, ax);

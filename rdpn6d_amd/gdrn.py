@@ -374,6 +374,7 @@ class InferencePlan:
         cfg = model.cfg
         # cfg.TEST.H2_WFRAG: weight fragments straight from L2 where a layer's kernel has that form (csrc/conv_igemm_h2_pp.hip, BFG) -
         # bit-identical, measured 3-5 % SLOWER per layer on MI355X (profiles/r5_experiments.md): off, kept as a switch
+        self.fused_gmax = False  # cfg.TEST.FUSE_GLOBAL_MAX took effect (the h2 plan with the exact rewrites, 256-row-aligned crops)
         self.h2_wfrag = bool(cfg.get("TEST", {}).get("H2_WFRAG", False))
         if self.h2_wfrag:
             self.lib.rdpn6d_conv_h2_set_wfrag(1)
@@ -791,6 +792,7 @@ class InferencePlan:
             self.fold_gmax = bool(model.cfg.get("TEST", {}).get("FOLD_GLOBAL_MAX", True))
             fcs = 512 if self.fold_gmax else 1024
             feat = self.planes_buf("feat_planes", npx * fcs, 1)
+            i_conv3 = len(self.launches)
             self.conv_x3("spatial_net.conv3", l2, (R8, R8), wc3, s3, h3, None, feat, (R8, R8), cin=256, in_cs=256, N=512, out_cs=fcs, act=0)
             if self.fold_gmax:
                 gmax = self.planes_buf("gmax_planes", B * 512, 1)
@@ -862,6 +864,22 @@ class InferencePlan:
                 wt_ct = torch.einsum("cnyx,ck->knyx", Wl, A).float()  # (256, F, 3, 3)
                 vconst = torch.einsum("cnyx,c->yxn", Wl, h3[:512].double()).reshape(9 * F).float().contiguous()
                 pF, ct_cin = l2, 256
+                # cfg.TEST.FUSE_GLOBAL_MAX (round 5, default on): with the composition above NOTHING but the per-crop max reads l3 any
+                # more - its convolution takes the column-max form (rdpn6d_conv2d_h2_colmax: the h2 record of max over a crop's pixels
+                # straight out of the epilogue, merged across the crop's workgroups by 64-bit atomic max) and the 134-MB tensor (B = 64)
+                # is neither written nor read back: the launch pair [conv3, global_max] becomes [conv3 + max, decode]
+                L3 = self.launches[i_conv3]
+                d3 = L3.keep[0] if L3.keep else None
+                if (bool(model.cfg.get("TEST", {}).get("FUSE_GLOBAL_MAX", True)) and L3.name == "spatial_net.conv3"
+                        and self.launches[i_conv3 + 1].name == "global_max" and d3 is not None and L3.fn is lib.rdpn6d_conv2d_h2
+                        and lib.rdpn6d_conv_h2_colmax_ok(ctypes.byref(d3), R8 * R8)):
+                    keys = self.buf("gmax_keys", B, d3.Npad, dtype=torch.int64, zero=True)
+                    self.launches[i_conv3] = _Launch("spatial_net.conv3+max", lib.rdpn6d_conv2d_h2_colmax,
+                                                     (ctypes.byref(d3), _ptr(keys), R8 * R8, _ptr(self.h2_flag)), keep=(d3,))
+                    self.launches[i_conv3 + 1] = _Launch("global_max.decode", lib.rdpn6d_h2_colmax_decode, (_ptr(keys), B, 512, d3.Npad, _ptr(gmax)))
+                    self.fused_gmax = True
+                    self.bufs.pop("feat_planes", None)  # (never written now)
+                    feat = None
             V = self.buf("convT_const", B, 9 * F)
             self.conv_x3("rot_head.convT.const", gmax, (1, 1), wconst, None, vconst, V, None, (1, 1), cin=512, in_cs=512, N=9 * F,
                          out_cs=9 * F, act=0)

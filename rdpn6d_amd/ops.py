@@ -207,6 +207,43 @@ def conv2d_nhwc_h2(x, weight, scale=None, shift=None, stride=1, pad=0, residual=
     return (out, ((yh, tuple(out.shape)), flag)) if want_h2 else out
 
 
+def conv2d_h2_colmax(x, weight, scale, shift, rows_per_group):
+    """The column-max form of a 1x1 / kxk h2 convolution (rdpn6d_conv2d_h2_colmax + rdpn6d_h2_colmax_decode): x NHWC fp32 [B,H,W,C], weight
+    OIHW -> the h2 record [groups][N/32][2][32] fp16 of max over each group's rows of scale * conv + shift (stride 1, 'same' padding).
+    The activation itself is never written."""
+    from .gdrn import pack_h2_weight
+
+    lib = _lib.load()
+    B, H, W, cs = x.shape
+    xh, _ = split_h2(x)
+    N, wcin, k, _ = weight.shape
+    wp32 = pack_conv_weight(weight.float(), cin_pad=wcin)
+    wh, inv = pack_h2_weight(wp32)
+    sc = _pad_vec(scale.float(), wp32.shape[0], 1.0) * inv
+    sh = _pad_vec(shift.float(), wp32.shape[0], 0.0)
+    d = _lib.ConvDesc()
+    d.x, d.w, d.scale, d.shift, d.res, d.y = _ptr(xh), _ptr(wh), _ptr(sc), _ptr(sh), None, None
+    d.B, d.H, d.W, d.Cin, d.in_cs, d.in_co = B, H, W, wcin, cs, 0
+    d.Ho, d.Wo, d.stride = H, W, 1
+    taps = [(ky - k // 2, kx - k // 2) for ky in range(k) for kx in range(k)]
+    d.ntaps = len(taps)
+    for t, (dy, dx) in enumerate(taps):
+        d.dy[t], d.dx[t] = dy, dx
+    d.N, d.Npad, d.OH, d.OW = N, wp32.shape[0], H, W
+    d.osy = d.osx = 1
+    d.ooy = d.oox = 0
+    d.out_cs, d.out_co, d.act, d.slope = N, 0, 0, 0.0
+    if not lib.rdpn6d_conv_h2_colmax_ok(ctypes.byref(d), rows_per_group):
+        raise ValueError("layer not eligible for the column-max form (256x256 kernel, rows_per_group % 256 == 0)")
+    groups = B * H * W // rows_per_group
+    keys = torch.zeros(groups, d.Npad, dtype=torch.int64, device=x.device)
+    out = torch.empty(groups, N // 32, 2, 32, dtype=torch.float16, device=x.device)
+    flag = torch.zeros(1, dtype=torch.int32, device=x.device)
+    _lib.check(lib.rdpn6d_conv2d_h2_colmax(ctypes.byref(d), _ptr(keys), rows_per_group, _ptr(flag), _stream()), "conv2d_h2_colmax")
+    _lib.check(lib.rdpn6d_h2_colmax_decode(_ptr(keys), groups, N, d.Npad, _ptr(out), _stream()), "h2_colmax_decode")
+    return out, keys, flag
+
+
 def stem_conv7x7(x_nchw, weight, scale, shift):
     _need_gpu(x_nchw, weight, scale, shift)
     B, xc, R, _ = x_nchw.shape
