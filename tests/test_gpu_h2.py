@@ -437,3 +437,35 @@ def test_fused_global_max_leaves_the_outputs_alone():
         slots = np.nonzero(order == c)[0]
         for s_ in slots[1:]:
             assert torch.equal(outs[True]["rot"][slots[0]], outs[True]["rot"][s_])
+
+
+def test_conv_h2_column_max_form_equals_the_max_of_the_written_records():
+    """rdpn6d_conv2d_h2_colmax + rdpn6d_h2_colmax_decode (round 5): per group of rows and channel, the h2 record of max(scale * conv + shift)
+    - against the ordinary launch's written h2 tensor reduced with torch (the record of the largest reconstructed value; the record is a
+    monotonic function of the value, so the two agree value for value), for a 1x1 and a 3x3 layer; the key table is left at zero; a value
+    beyond the h2 range (or a NaN) raises the range flag like every other h2 writer."""
+    from rdpn6d_amd import ops
+
+    dev = torch.device("cuda:0")
+    for (B, H, Cin, N, k) in ((64, 32, 256, 512, 1), (48, 32, 64, 256, 3)):
+        g = torch.Generator().manual_seed(B + k)
+        x = torch.randn(B, H, H, Cin, generator=g).to(dev)
+        w = (torch.randn(N, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).to(dev)
+        sc, sh = (torch.rand(N, generator=g) + 0.5).to(dev), torch.randn(N, generator=g).to(dev)
+        _, ((h2, _), flag) = ops.conv2d_nhwc_h2(x, w, sc, sh, pad=k // 2, want_h2=True)
+        rec, keys, fl = ops.conv2d_h2_colmax(x, w, sc, sh, H * H)
+        torch.cuda.synchronize()
+        h = h2.view(B, H * H, N // 32, 2, 32).float()
+        want = (h[:, :, :, 0] + h[:, :, :, 1]).amax(dim=1)
+        got = rec[:, :, 0].float() + rec[:, :, 1].float()
+        assert torch.equal(got, want), (B, k, (got - want).abs().max().item())
+        assert int(keys.abs().sum()) == 0 and int(fl) == 0 and int(flag) == 0
+    xb = x.clone()
+    xb[3, 5, 5, :] = 3.0e4  # one pixel far beyond +-4094 after the convolution
+    _, _, fl = ops.conv2d_h2_colmax(xb, w, sc, sh, H * H)
+    torch.cuda.synchronize()
+    assert int(fl) == 1
+    xb[3, 5, 5, 0] = float("nan")
+    _, _, fl = ops.conv2d_h2_colmax(xb, w, sc, sh, H * H)
+    torch.cuda.synchronize()
+    assert int(fl) == 1
