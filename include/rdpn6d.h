@@ -482,6 +482,9 @@ int rdpn6d_ranger_step_f32(float* param, const float* grad, float* exp_avg, floa
                            float beta2, float eps, float neg_step_lr, float wd_lr, int rectified, int lookahead, float alpha,
                            void* stream);
 int rdpn6d_act_backward_f32(float* dy, const float* y, long long n, float slope, void* stream);
+/* y[b][c][r] = x[b][r][c] (B matrices of R x C floats): the last ConvPnPNet map in the reference's NCHW-flatten order for fc1
+ * (conv_pnp_net.py:151: x.view(-1, featdim * 8 * 8) of an NCHW tensor), and its gradient back - instead of permuting fc1's 8.4 M weights every step */
+int rdpn6d_transpose_rc_f32(const float* x, int B, int R, int C, float* y, void* stream);
 int rdpn6d_rgb_to_nhwc4_f32(const float* x, int B, int xc, int R, float* y, void* stream);
 /* patch matrix of the stem for its weight gradient: out [B*(R/2)^2][160], column (ky*7+kx)*3+c = x[b][c][2oy-3+ky][2ox-3+kx]
  * (0 outside the image; columns 147..159 zero) - dW(conv1) is then one rdpn6d_wgrad_f32 call with a single tap */
@@ -489,9 +492,11 @@ int rdpn6d_stem_im2col_f32(const float* x, int B, int xc, int R, float* out, voi
 
 /* Weight re-packing of the training step in one launch.  Entry: dst[(o*dT + t)*dIpad + i] = src[operm(o)*so +
  * iperm(i)*si + toff[t]] for o < O, t < T, i < I (operm / iperm may be NULL = identity; dst and/or dst_bf16 are written;
- * padding entries of dst are never touched).  Workgroup b handles 256 (o, i) pairs - all T taps of each - of entry blk_desc[b],
- * starting at pair blk_off[b] (pair = o*I + i); table and maps live in device memory (`start` is unused by the kernel, kept
- * for bookkeeping). */
+ * padding entries of dst are never touched).  Workgroup b handles 1 024 consecutive (o, i) pairs (2 048 when T == 1) - all T taps of
+ * each - of entry blk_desc[b], starting at pair blk_off[b] (pair = o*I + i); with bit 30 of blk_desc[b] set (operm == iperm == NULL
+ * only) it handles the tile of 64 i x 16 o (64 o when T <= 2) whose first pair is blk_off[b], moved through LDS - the form for
+ * entries whose consecutive i are far apart in src (si > so).  Table and maps live in device memory (`start` is unused by the
+ * kernel, kept for bookkeeping). */
 typedef struct {
     const float* src;
     float* dst;

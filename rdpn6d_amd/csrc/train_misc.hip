@@ -975,6 +975,30 @@ extern "C" int rdpn6d_train_vis_scalars_f32(const float* rot, const float* trans
     return RDPN6D_OK;
 }
 
+// y[b][c][r] = x[b][r][c]: the last ConvPnPNet map (B x 64 pixels x 128 channels, 1 MB at B = 32) in the NCHW-flatten order the
+// reference's fc1 weight is stored in (conv_pnp_net.py:151, x.view(-1, featdim * 8 * 8) of an NCHW tensor) - so the per-step weight re-pack and the fc1 weight
+// gradient need no permutation of 8.4 M elements - and back for the gradient.  32 x 32 tiles through LDS, both sides coalesced.
+__global__ __launch_bounds__(256) void transpose_rc_kernel(const float* __restrict__ x, int R, int C, float* __restrict__ y)
+{
+    __shared__ float t[32][33];
+    const int b = blockIdx.z, r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* xb = x + (long long)b * R * C;
+    float* yb = y + (long long)b * R * C;
+    for (int k = ty; k < 32; k += 8)
+        if (r0 + k < R && c0 + tx < C) t[k][tx] = xb[(long long)(r0 + k) * C + c0 + tx];
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8)
+        if (c0 + k < C && r0 + tx < R) yb[(long long)(c0 + k) * R + r0 + tx] = t[tx][k];
+}
+extern "C" int rdpn6d_transpose_rc_f32(const float* x, int B, int R, int C, float* y, void* stream)
+{
+    RD_REQUIRE(x && y && x != y && B > 0 && R > 0 && C > 0 && B < 65536, "shape");
+    hipLaunchKernelGGL(transpose_rc_kernel, dim3((C + 31) / 32, (R + 31) / 32, B), dim3(256), 0, (hipStream_t)stream, x, R, C, y);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // dy *= (y > 0 ? 1 : slope)   (ReLU: slope 0, LeakyReLU(0.1): slope 0.1; the activation output has the sign of
 // its input, so the saved output is enough)
@@ -1078,28 +1102,125 @@ extern "C" int rdpn6d_rgb_to_nhwc4_f32(const float* x, int B, int xc, int R, flo
 // a bf16 mirror).  A table entry maps the real elements of one packed tensor:
 //   dst[(o*dT + t)*dIpad + i] = src[operm(o)*so + iperm(i)*si + toff[t]]      o < O, t < T, i < I
 // (padding entries of dst are zeroed once at allocation and never touched).  Replaces ~700 tiny ATen launches per step.
+// Transposing entries (si > so: consecutive i are far apart in the source - every input-gradient pack, the transposed-convolution
+// phase packs) take the tile form, flagged by bit 30 of blk_desc: a workgroup moves RP_IT = 64 i x OT o (OT = 16, or 64 when T <= 2)
+// through LDS - read with the (o, tap) index fastest (for so == T one contiguous run of OT * T floats per i), written with i fastest
+// (128 bytes of 16-bit mirror per (o, tap) row).  The pair form below read 36 bytes of each 128-byte line per wave and relied on the
+// L2 for the rest: with the workgroups of neighbouring o on different XCDs that was up to 3.5x (T = 9) / 32x (T = 1) the bytes.
+#define RP_IT 64
+#define RP_TILE_BIT 0x40000000
+#define RP_LDS_STRIDE 145  // 16 o x 9 taps (or 64 o x 2 taps) + 1: odd, so the transposed walk is conflict-free
 __global__ __launch_bounds__(256) void repack_kernel(const rdpn6d_repack_desc* __restrict__ tab, const int* __restrict__ blk_desc,
                                                      const long long* __restrict__ blk_off)
 {
+    const int bdesc = blk_desc[blockIdx.x];
+    const rdpn6d_repack_desc& D = tab[bdesc & ~RP_TILE_BIT];
+    if (bdesc & RP_TILE_BIT) {
+        __shared__ float tile[RP_IT * RP_LDS_STRIDE];
+        const int T = D.T, OT = T <= 2 ? 64 : 16, EW = OT * T;  // EW <= 144
+        const int o0 = (int)(blk_off[blockIdx.x] / D.I), i0 = (int)(blk_off[blockIdx.x] % D.I);
+        // (no per-element division: a lane's <= 3 (o, tap) slots are fixed for the whole tile; the store walk steps its (o, tap) by four)
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        long long soff[3];
+        bool sok[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int e = lane + 64 * k;
+            const int ol = e / T, t = e - ol * T;
+            sok[k] = e < EW && o0 + ol < D.O;
+            soff[k] = sok[k] ? (long long)(o0 + ol) * D.so + D.toff[t] : 0;
+        }
+        // eight rows of loads in flight per lane before the first LDS write (one row at a time = 16 dependent round trips per tile)
+        for (int il0 = wave; il0 < RP_IT; il0 += 32) {
+            float r[8][3];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int il = il0 + 4 * j;
+                const bool iok = i0 + il < D.I;
+                const float* sp = D.src + (long long)(i0 + il) * D.si;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) r[j][k] = (iok && sok[k]) ? sp[soff[k]] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    if (lane + 64 * k < EW) tile[(il0 + 4 * j) * RP_LDS_STRIDE + lane + 64 * k] = r[j][k];
+        }
+        __syncthreads();
+        if (i0 + lane < D.I) {
+            int ol = 0, t = wave;
+            while (t >= T) { t -= T; ++ol; }
+            for (int e = wave; e < EW && o0 + ol < D.O; e += 4) {
+                const float v = tile[lane * RP_LDS_STRIDE + e];
+                const long long di = ((long long)(o0 + ol) * D.dT + t) * D.dIpad + i0 + lane;
+                if (D.dst) D.dst[di] = v;
+                if (D.dst_bf16) reinterpret_cast<unsigned short*>(D.dst_bf16)[di] = rd_f2bf(v);
+                t += 4;
+                while (t >= T) { t -= T; ++ol; }
+            }
+        }
+        return;
+    }
     // workgroup -> (table entry, first (o, i) pair) comes from a host-built map: no per-element search.  One thread = one (o, i)
     // pair and its T taps: the taps of a pair are adjacent in the source (a 3x3 filter = 36 contiguous bytes, read once per
     // cache line instead of once per tap), and for each tap consecutive lanes write consecutive i of the packed slab.
-    const rdpn6d_repack_desc& D = tab[blk_desc[blockIdx.x]];
-    const long long pair = blk_off[blockIdx.x] + threadIdx.x;
-    if (pair >= (long long)D.O * D.I) return;
-    const int i = (int)(pair % D.I);
-    const int o = (int)(pair / D.I);
-    const int oo = D.operm ? D.operm[o] : o, ii = D.iperm ? D.iperm[i] : i;
-    const float* sp = D.src + oo * D.so + ii * D.si;
-    float v[9];
+    // A workgroup takes 1 024 consecutive pairs (2 048 when T == 1), all loads of a round issued before its first store: with 256 pairs (x 1 tap for
+    // the FC packs) per workgroup the launch was 83 000 workgroups of four dependent round trips each - latency, not bytes (round 5).
+    const long long npairs = (long long)D.O * D.I;
+    const long long base = blk_off[blockIdx.x] + threadIdx.x;
+    unsigned short* db = reinterpret_cast<unsigned short*>(D.dst_bf16);
+    if (D.T == 1) {
+        float v[8];
+        long long di[8];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) v[t] = t < D.T ? sp[D.toff[t]] : 0.f;
+        for (int u = 0; u < 8; ++u) {
+            const long long pair = base + 256 * u;
+            v[u] = 0.f;
+            di[u] = -1;
+            if (pair < npairs) {
+                const int i = (int)(pair % D.I), o = (int)(pair / D.I);
+                const int oo = D.operm ? D.operm[o] : o, ii = D.iperm ? D.iperm[i] : i;
+                v[u] = D.src[oo * D.so + ii * D.si + D.toff[0]];
+                di[u] = (long long)o * D.dT * D.dIpad + i;
+            }
+        }
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        if (t >= D.T) break;
-        const long long idx = ((long long)o * D.dT + t) * D.dIpad + i;
-        if (D.dst) D.dst[idx] = v[t];
-        if (D.dst_bf16) reinterpret_cast<unsigned short*>(D.dst_bf16)[idx] = rd_f2bf(v[t]);
+        for (int u = 0; u < 8; ++u) {
+            if (di[u] < 0) continue;
+            if (D.dst) D.dst[di[u]] = v[u];
+            if (db) db[di[u]] = rd_f2bf(v[u]);
+        }
+        return;
+    }
+#pragma unroll 1
+    for (int u0 = 0; u0 < 4; u0 += 2) {
+        float v[2][9];
+        int oi[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long long pair = base + 256 * (u0 + u);
+            oi[u][0] = -1;
+            if (pair >= npairs) continue;
+            const int i = (int)(pair % D.I), o = (int)(pair / D.I);
+            oi[u][0] = o;
+            oi[u][1] = i;
+            const int oo = D.operm ? D.operm[o] : o, ii = D.iperm ? D.iperm[i] : i;
+            const float* sp = D.src + oo * D.so + ii * D.si;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) v[u][t] = t < D.T ? sp[D.toff[t]] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (oi[u][0] < 0) continue;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                if (t >= D.T) break;
+                const long long idx = ((long long)oi[u][0] * D.dT + t) * D.dIpad + oi[u][1];
+                if (D.dst) D.dst[idx] = v[u][t];
+                if (db) db[idx] = rd_f2bf(v[u][t]);
+            }
+        }
     }
 }
 

@@ -66,6 +66,8 @@ class TrainEngine:
         # BatchNorm's backward sums from its epilogue (rdpn6d_conv2d_bf16_bnbwd)
         self.bn_fuse_bwd = bool(model.cfg.get("SOLVER", {}).get("BN_FUSE_BWD", os.environ.get("RDPN6D_BN_FUSE_BWD", "1") != "0"))
         self._bn_by_dy, self._scratch_bnb_need = {}, 0
+        # transposing weight packs through LDS tiles (repack_kernel); RDPN6D_REPACK_TILES=0: the pair form for every entry (A/B, tests)
+        self.repack_tiles = os.environ.get("RDPN6D_REPACK_TILES", "1") != "0"
         self.bn_remask = bool(model.cfg.get("SOLVER", {}).get("BN_REMASK", os.environ.get("RDPN6D_BN_REMASK", "1") != "0"))
         self.x3_launches = 0
         cfg = model.cfg
@@ -330,11 +332,20 @@ class TrainEngine:
             r["O"], r["T"], r["I"], r["dT"], r["dIpad"] = e["O"], e["T"], e["I"], e["dT"], e["dIpad"]
             r["toff"][: e["T"]] = e["toff"]
             start += e["O"] * e["T"] * e["I"]
-        # workgroup map: 256 (o, i) pairs (x T taps) per workgroup, never straddling two entries
+        # workgroup map: 1024 (o, i) pairs (x T taps; 2048 when T = 1) per workgroup, never straddling two entries
+        # (transposing entries - consecutive i far apart in the source - go through LDS in 64-i x 16|64-o tiles: bit 30 of the map entry,
+        #  offset = the tile's first pair; see repack_kernel)
         bd, bo = [], []
         for di, e in enumerate(self.repack):
             n = e["O"] * e["I"]
-            offs = np.arange(0, n, 256, dtype=np.int64)
+            if self.repack_tiles and e["operm"] is None and e["iperm"] is None and e["si"] > e["so"] and e["I"] >= 32:
+                ot = 64 if e["T"] <= 2 else 16
+                o0, i0 = np.meshgrid(np.arange(0, e["O"], ot, dtype=np.int64), np.arange(0, e["I"], 64, dtype=np.int64), indexing="ij")
+                offs = (o0 * e["I"] + i0).reshape(-1)
+                bo.append(offs)
+                bd.append(np.full(len(offs), di | 0x40000000, dtype=np.int32))
+                continue
+            offs = np.arange(0, n, 2048 if e["T"] == 1 else 1024, dtype=np.int64)
             bo.append(offs)
             bd.append(np.full(len(offs), di, dtype=np.int32))
         self._repack_dev = torch.from_numpy(tab.view(np.uint8).reshape(-1)).to(self.dev)
@@ -971,9 +982,14 @@ class TrainEngine:
         self.rt = self.buf("act:rt", B, 16, zero=True)
         d_f1, d_f2 = self.buf("d:fc1", B, 1024, zero=True), self.buf("d:fc2", B, 256, zero=True)
         self.d_rt = self.buf("d:rt", B, 16, zero=True)
-        self._fc("fc1", pnp.fc1.weight, pnp.fc1.bias, x.view(B, kin), d_x.view(B, kin), kin, f1, d_f1, 1024, act=2,
-                 w_view=lambda w: w.view(-1, cs, hw, hw).permute(0, 2, 3, 1).reshape(-1, kin),
-                 g_view=lambda g: g.view(-1, hw, hw, cs).permute(0, 3, 1, 2).reshape(-1, kin))
+        # fc1 reads the map in the reference's NCHW-flatten order (conv_pnp_net.py:151): a 1-MB transposition of the activation (and of
+        # its gradient on the way back) instead of a permutation of fc1's 8.4 M weights in every re-pack and of their gradient - the
+        # permuted pack read one float per 128-byte line (round 5: ~100 us of the 218-us re-pack, 29 us of gradient copy)
+        x_t, d_xt = self.buf("act:pnp_flat", B, cs, hw * hw), self.buf("d:pnp_flat", B, cs, hw * hw, zero=True)
+        self.fwd.append(lambda x=x, x_t=x_t: _lib.check(lib.rdpn6d_transpose_rc_f32(_ptr(x), B, hw * hw, cs, _ptr(x_t), self.st()), "flatten"))
+        self.bwd.append([lambda d_x=d_x, d_xt=d_xt: _lib.check(lib.rdpn6d_transpose_rc_f32(_ptr(d_xt), B, cs, hw * hw, _ptr(d_x), self.st()),
+                                                              "flatten bwd")])
+        self._fc("fc1", pnp.fc1.weight, pnp.fc1.bias, x_t.view(B, kin), d_xt.view(B, kin), kin, f1, d_f1, 1024, act=2)
         self._fc("fc2", pnp.fc2.weight, pnp.fc2.bias, f1, d_f1, 1024, f2, d_f2, 256, act=2)
         self._fc("fc_rt", (pnp.fc_r.weight, pnp.fc_t.weight), (pnp.fc_r.bias, pnp.fc_t.bias), f2, d_f2, 256, self.rt, self.d_rt, 9, act=0, out_cs=16)
         self.rot, self.trans = self.buf("rot", B, 3, 3), self.buf("trans", B, 3)
@@ -1019,8 +1035,13 @@ class TrainEngine:
         def bwd():
             if act == 2:
                 _lib.check(lib.rdpn6d_act_backward_f32(_ptr(d_y), _ptr(y), B * out_cs, 0.1, self.st()), "leaky bwd " + name)
-            _lib.check(lib.rdpn6d_wgrad_f32(_ptr(d_y), out_cs, 0, ca, _ptr(x), kin, 0, kin, B, 1, 1, 1, 1, 1, 1, z9, z9, _ptr(wg_out),
-                                            _ptr(self._wg_partial), self.st()), "wgrad " + name)
+            # one weight in the buffer's own K order: the [nout][kin] result IS the parameter's gradient - written in place (fc1: 34 MB
+            # not copied)
+            direct = len(ws) == 1 and g_view is None and ca == nout and tuple(ws[0].shape) == (nout, kin)
+            gw = self._grad(ws[0]) if direct else None
+            direct = direct and gw.is_contiguous()
+            _lib.check(lib.rdpn6d_wgrad_f32(_ptr(d_y), out_cs, 0, ca, _ptr(x), kin, 0, kin, B, 1, 1, 1, 1, 1, 1, z9, z9,
+                                            _ptr(gw if direct else wg_out), _ptr(self._wg_partial), self.st()), "wgrad " + name)
             g = wg_out[:nout, 0]
             if g_view:
                 g = g_view(g)
@@ -1028,7 +1049,8 @@ class TrainEngine:
             o = 0
             for wp, bp in zip(ws, bs):
                 n = wp.shape[0]
-                self._grad(wp).copy_(g[o:o + n])
+                if not direct:
+                    self._grad(wp).copy_(g[o:o + n])
                 self._grad(bp).copy_(bg[o:o + n])
                 o += n
 

@@ -1149,6 +1149,40 @@ def test_weight_gradients_on_the_side_stream_change_nothing(B, amp):
             assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("amp", [None, "bf16", "fp16"])
+def test_repack_tile_form_writes_the_same_packed_weights(amp, monkeypatch):
+    """The per-step weight re-pack moves its transposing entries (every input-gradient pack, the transposed convolution's phase packs)
+    through LDS tiles (repack_kernel, bit 30 of the workgroup map); the other entries keep the pair form.  Every packed tensor and
+    16-bit mirror must be bit-identical to the all-pairs launch, padding included, and the tile form must really be in use."""
+    from rdpn6d_amd.config import gdrn_base_cfg
+    from rdpn6d_amd.gdrn import build_model_optimizer
+    from rdpn6d_amd.train import TrainEngine
+
+    dev = torch.device("cuda:0")
+    cfg = gdrn_base_cfg(mask_attention="mul", device="cuda")
+    if amp:
+        cfg.SOLVER.AMP.ENABLED, cfg.SOLVER.AMP.DTYPE = True, amp
+    model, _ = build_model_optimizer(cfg)
+    torch.manual_seed(3)
+    with torch.no_grad():
+        for p_ in model.parameters():
+            p_.copy_(torch.randn_like(p_))
+    packed = {}
+    for tiles in ("0", "1"):
+        monkeypatch.setenv("RDPN6D_REPACK_TILES", tiles)
+        eng = TrainEngine(model, 4, dev, amp=amp)
+        assert eng.repack_tiles == (tiles == "1")
+        eng.refresh_weights()
+        torch.cuda.synchronize()
+        ntile = int((eng._repack_bd >= 0x40000000).sum().item())
+        assert (ntile > 0) == (tiles == "1")
+        packed[tiles] = [e["dst"].clone() for e in eng.repack] + [tb.clone() for tb, _ in eng.mirrors]
+        del eng
+    assert len(packed["0"]) == len(packed["1"]) > 100
+    for a, b in zip(packed["0"], packed["1"]):
+        assert a.dtype == b.dtype and torch.equal(a.view(torch.uint8), b.view(torch.uint8))
+
+
 def test_non_finite_head_output_does_not_fault_the_glue_backward():
     """round 4: a diverged run (fp16 overflow un-skipped -> NaN weights -> NaN head output) drove `mask_attention_extrema_bwd_kernel` to
     write at its sentinel arg-min / arg-max index (2^31 rows past the tensor): a GPU memory fault that killed the process.  NaN in must
