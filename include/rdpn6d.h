@@ -489,6 +489,11 @@ int rdpn6d_rgb_to_nhwc4_f32(const float* x, int B, int xc, int R, float* y, void
 /* patch matrix of the stem for its weight gradient: out [B*(R/2)^2][160], column (ky*7+kx)*3+c = x[b][c][2oy-3+ky][2ox-3+kx]
  * (0 outside the image; columns 147..159 zero) - dW(conv1) is then one rdpn6d_wgrad_f32 call with a single tap */
 int rdpn6d_stem_im2col_f32(const float* x, int B, int xc, int R, float* out, void* stream);
+/* row-patch matrix of the stem (what the training step uses): out [B*(R/2)^2][64], column r*32 + kx*3 + c = x[b][c][2j+r][2ox-3+kx]
+ * for pixel (j, ox) (0 outside the image; columns 21..31 of each half zero) - dW(conv1) is then one stride-1 rdpn6d_wgrad_* call
+ * with the four taps dy = -2..1, dx = 0 over the (R/2) x (R/2) map: dW[n][c][ky][kx] = out4[n][t][r*32 + kx*3 + c], r = (ky+1)&1,
+ * t = (ky+1-r)/2 (resnet_backbone.py:272 backward) */
+int rdpn6d_stem_rowpatch_f32(const float* x, int B, int xc, int R, float* out, void* stream);
 
 /* Weight re-packing of the training step in one launch.  Entry: dst[(o*dT + t)*dIpad + i] = src[operm(o)*so +
  * iperm(i)*si + toff[t]] for o < O, t < T, i < I (operm / iperm may be NULL = identity; dst and/or dst_bf16 are written;
@@ -532,6 +537,7 @@ int rdpn6d_upsample_bilinear_backward_bf16(const void* dy, int B, int H, int W, 
 int rdpn6d_global_max_concat_backward_bf16(const void* feat, const void* dfeat, int B, int HW, int C, int cs, void* dl3,
                                            void* stream);
 int rdpn6d_stem_im2col_bf16(const float* x, int B, int xc, int R, void* out, void* stream);
+int rdpn6d_stem_rowpatch_bf16(const float* x, int B, int xc, int R, void* out, void* stream);
 int rdpn6d_stem_conv7x7_raw_bf16(const float* x, int B, int xc, int R, const float* w, void* y, void* stream);
 
 /* ================================================================== "next" rows of SURVEY.md section 8f
@@ -644,6 +650,7 @@ int rdpn6d_upsample_bilinear_backward_fp16(const void* dy, int B, int H, int W, 
 int rdpn6d_global_max_concat_backward_fp16(const void* feat, const void* dfeat, int B, int HW, int C, int cs, void* dl3,
                                            void* stream);
 int rdpn6d_stem_im2col_fp16(const float* x, int B, int xc, int R, void* out, void* stream);
+int rdpn6d_stem_rowpatch_fp16(const float* x, int B, int xc, int R, void* out, void* stream);
 int rdpn6d_stem_conv7x7_raw_fp16(const float* x, int B, int xc, int R, const float* w, void* y, void* stream);
 int rdpn6d_repack_fp16(const rdpn6d_repack_desc* table_dev, const int* blk_desc_dev, const long long* blk_off_dev, int nblocks,
                       void* stream);

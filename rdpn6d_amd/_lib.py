@@ -126,6 +126,7 @@ SIGNATURES = {
     "rdpn6d_train_vis_scalars_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp]),
     "rdpn6d_rgb_to_nhwc4_f32": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "rdpn6d_stem_im2col_f32": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "rdpn6d_stem_rowpatch_f32": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "rdpn6d_stem_conv7x7_raw_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "rdpn6d_bn_train_stats_bf16": (_i, [_vp, _ll, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rdpn6d_bn_apply_bf16": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _ll, _i, _i, _vp]),
@@ -137,6 +138,7 @@ SIGNATURES = {
     "rdpn6d_upsample_bilinear_backward_bf16": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "rdpn6d_global_max_concat_backward_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "rdpn6d_stem_im2col_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "rdpn6d_stem_rowpatch_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "rdpn6d_repack_f32": (_i, [_vp, _vp, _vp, _i, _vp]),
     "rdpn6d_split_h2": (_i, [_vp, _i, _i, _i, _vp, _ll, _vp, _vp]),
     "rdpn6d_conv_h2_kernel_for": (_i, [_vp]),

@@ -1087,6 +1087,58 @@ extern "C" int rdpn6d_stem_im2col_bf16(const float* x, int B, int xc, int R, voi
     return stem_im2col_impl<rd_bf16_t>(x, B, xc, R, (rd_bf16_t*)out, stream);
 }
 
+// Row-patch matrix of the stem for its weight gradient (round 5; replaces the 160-column patch matrix above in the training step):
+//   out[b][j][ox][r*32 + kx*3 + c] = x[b][c][2j + r][2ox - 3 + kx]     r = 0 | 1, kx < 7, c < 3 (0 outside the image; 21..31 of each half zero)
+// i.e. only the HORIZONTAL taps are unrolled, the two input-row parities side by side as 64 "channels" of a (R/2) x (R/2) map.  The
+// 7 x 7 / stride-2 weight gradient is then an ordinary stride-1 four-tap one over that map (rdpn6d_wgrad_*: taps dy = -2..1, dx = 0):
+//   dW[n][c][ky][kx] = out4[n][t][r*32 + kx*3 + c]  with  r = (ky + 1) & 1,  t = (ky + 1 - r) / 2      (t = 0, r = 0 is ky = -1: unused)
+// - a 64-column operand (67 MB at B = 32, one column tile: the output gradient is read once) instead of 160 columns (168 MB, three tiles).
+template <typename T>
+__global__ __launch_bounds__(256) void stem_rowpatch_kernel(const float* __restrict__ x, int B, int xc, int R, T* __restrict__ out)
+{
+    constexpr int TP = 32, WIN = 2 * TP + 5;
+    __shared__ float s[3][2][WIN + 3];
+    const int Ro = R / 2, segs = (Ro + TP - 1) / TP;
+    const int seg = blockIdx.x % segs, j = (blockIdx.x / segs) % Ro, b = blockIdx.x / (segs * Ro);
+    const int ox0 = seg * TP, ix0 = 2 * ox0 - 3;
+    for (int e = threadIdx.x; e < 3 * 2 * WIN; e += 256) {
+        const int col = e % WIN, r = (e / WIN) % 2, c = e / (2 * WIN);
+        const int ix = ix0 + col;
+        s[c][r][col] = (unsigned)ix < (unsigned)R ? x[(((long long)b * xc + c) * R + 2 * j + r) * R + ix] : 0.f;
+    }
+    __syncthreads();
+    const int p = threadIdx.x >> 3, q = threadIdx.x & 7;  // pixel of the segment, group of 8 columns
+    if (ox0 + p >= Ro) return;
+    const int r = q >> 2;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = (q & 3) * 8 + e, kx = k / 3, c = k - kx * 3;
+        v[e] = k < 21 ? s[c][r][2 * p + kx] : 0.f;
+    }
+    T* dst = out + (((long long)b * Ro + j) * Ro + ox0 + p) * 64 + q * 8;
+    rd_st4<T>(dst, f32x4{v[0], v[1], v[2], v[3]});
+    rd_st4<T>(dst + 4, f32x4{v[4], v[5], v[6], v[7]});
+}
+template <typename T>
+static int stem_rowpatch_impl(const float* x, int B, int xc, int R, T* out, void* stream)
+{
+    RD_REQUIRE(x && out && B > 0 && xc >= 3 && R > 0 && R % 2 == 0, "shape");
+    const long long blocks = (long long)B * (R / 2) * ((R / 2 + 31) / 32);
+    RD_REQUIRE(blocks < (1LL << 31), "batch too large for one launch");
+    hipLaunchKernelGGL(stem_rowpatch_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, B, xc, R, out);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}
+extern "C" int rdpn6d_stem_rowpatch_f32(const float* x, int B, int xc, int R, float* out, void* stream)
+{
+    return stem_rowpatch_impl<float>(x, B, xc, R, out, stream);
+}
+extern "C" int rdpn6d_stem_rowpatch_bf16(const float* x, int B, int xc, int R, void* out, void* stream)
+{
+    return stem_rowpatch_impl<rd_bf16_t>(x, B, xc, R, (rd_bf16_t*)out, stream);
+}
+
 extern "C" int rdpn6d_rgb_to_nhwc4_f32(const float* x, int B, int xc, int R, float* y, void* stream)
 {
     RD_REQUIRE(x && y && B > 0 && xc >= 3 && R > 0, "shape");

@@ -723,21 +723,25 @@ class TrainEngine:
         else:
             self.fwd.append(lambda: _lib.check(f_stem(_ptr(self.x), B, 6, R, _ptr(wst), _ptr(raw0), self.st()), "stem"))
         d_raw0 = self.buf("d:stem", B, R2, R2, 64, zero=True)
-        xcol = self.buf("x_im2col", B * R2 * R2, 160, dtype=self.adt)   # stem patch matrix (built in the backward)
-        wg_stem = self.buf("wg:stem", 64, 1, 160)
-        self._wg_floats = max(self._wg_floats, int(lib.rdpn6d_wgrad_scratch_floats(B, R2, R2, 64, 160, 1)))
-        z9 = (ctypes.c_int * 9)(*([0] * 9))
+        # dW(conv1): the stem's row-patch matrix (horizontal taps unrolled, the two input-row parities side by side: 64 columns) and ONE
+        # stride-1 four-tap weight gradient over it - rdpn6d_stem_rowpatch_*; 67 MB + one read of the output gradient instead of the
+        # 160-column patch matrix (168 MB, three column tiles): 81 + 124 us -> see profiles/r5_experiments.md
+        xrow = self.buf("x_rowpatch", B * R2 * R2, 64, dtype=self.adt)   # (built in the backward)
+        wg_stem = self.buf("wg:stem", 64, 4, 64)
+        self._wg_floats = max(self._wg_floats, int(lib.rdpn6d_wgrad_scratch_floats(B, R2, R2, 64, 64, 4)))
+        t_dy, t_dx = (ctypes.c_int * 9)(-2, -1, 0, 1, 0, 0, 0, 0, 0), (ctypes.c_int * 9)(*([0] * 9))
 
         def stem_wgrad():
-            # dW(conv1)[n][ky][kx][c] = sum over output pixels of dY[p][n] * patch[p][(ky,kx,c)]: one pixel-reduction GEMM
-            _lib.check(getattr(lib, f"rdpn6d_stem_im2col_{sfx}")(_ptr(self.x), B, 6, R, _ptr(xcol), self.st()), "stem im2col")
+            _lib.check(getattr(lib, f"rdpn6d_stem_rowpatch_{sfx}")(_ptr(self.x), B, 6, R, _ptr(xrow), self.st()), "stem row patches")
             if self.amp:
-                _lib.check(self.lpf("rdpn6d_wgrad_bf16")(_ptr(d_raw0), 64, 0, 64, 64, _ptr(xcol), 160, 0, 160, 160, B, R2, R2, R2, R2, 1, 1, z9, z9,
+                _lib.check(self.lpf("rdpn6d_wgrad_bf16")(_ptr(d_raw0), 64, 0, 64, 64, _ptr(xrow), 64, 0, 64, 64, B, R2, R2, R2, R2, 1, 4, t_dy, t_dx,
                                                  _ptr(wg_stem), _ptr(self._wg_partial), self.st()), "wgrad stem")
             else:
-                _lib.check(lib.rdpn6d_wgrad_f32(_ptr(d_raw0), 64, 0, 64, _ptr(xcol), 160, 0, 160, B, R2, R2, R2, R2, 1, 1, z9, z9,
+                _lib.check(lib.rdpn6d_wgrad_f32(_ptr(d_raw0), 64, 0, 64, _ptr(xrow), 64, 0, 64, B, R2, R2, R2, R2, 1, 4, t_dy, t_dx,
                                                 _ptr(wg_stem), _ptr(self._wg_partial), self.st()), "wgrad stem")
-            self._grad(bb.conv1.weight).copy_(wg_stem[:, 0, :147].view(64, 7, 7, 3).permute(0, 3, 1, 2))
+            # [n][t][r][kx*3 + c] -> ky + 1 = 2t + r (entry 0 = the unused ky = -1) -> [n][c][ky][kx]
+            g = wg_stem.view(64, 4, 2, 32)[..., :21].reshape(64, 8, 7, 3)[:, 1:]
+            self._grad(bb.conv1.weight).copy_(g.permute(0, 3, 1, 2))
 
         self.bwd.append([stem_wgrad])
         self.records.append(dict(kind="stem", name="backbone.conv1", P=bb.conv1, x=self.x, y=raw0, dy=d_raw0, lowp=self.amp))

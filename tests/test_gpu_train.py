@@ -722,6 +722,28 @@ def test_maxpool_backward_first_max_rule_and_stem_im2col():
     ref = F.unfold(img[:, :3].cpu(), 7, padding=3, stride=2)            # (B, c*49 + ky*7 + kx, L)
     ref = ref.view(2, 3, 49, 64).permute(0, 3, 2, 1).reshape(128, 147)  # -> [pixel][(ky*7+kx)*3 + c]
     assert torch.equal(col[:, :147].cpu(), ref) and col[:, 147:].abs().max().item() == 0
+    # the row-patch form the training step uses (horizontal taps unrolled, the two input-row parities as 2 x 32 columns) and the
+    # four-tap stride-1 weight gradient over it: the stem's dW equals autograd's conv2d weight gradient
+    for R, Bq in ((16, 2), (70, 3)):  # 70: a ragged 32-pixel segment
+        img = torch.rand(Bq, 6, R, R, generator=g).to(dev)
+        Ro = R // 2
+        rowp = torch.full((Bq * Ro * Ro, 64), 7.0, device=dev)
+        _lib.check(lib.rdpn6d_stem_rowpatch_f32(_ptr(img), Bq, 6, R, _ptr(rowp), st))
+        pad = F.pad(img[:, :3].cpu(), (3, 3, 0, 0))                        # columns 2ox - 3 + kx -> 2ox + kx
+        ref = torch.zeros(Bq, Ro, Ro, 2, 32)
+        for r in range(2):
+            for kx in range(7):
+                ref[:, :, :, r, kx * 3:kx * 3 + 3] = pad[:, :, r::2, kx:kx + 2 * Ro:2].permute(0, 2, 3, 1)
+        assert torch.equal(rowp.cpu().view(Bq, Ro, Ro, 2, 32), ref)
+        dyo = torch.randn(Bq, Ro, Ro, 64, generator=g).to(dev)
+        wg = torch.empty(64, 4, 64, device=dev)
+        part = torch.empty(int(lib.rdpn6d_wgrad_scratch_floats(Bq, Ro, Ro, 64, 64, 4)), device=dev)
+        t_dy, t_dx = (ctypes.c_int * 9)(-2, -1, 0, 1, 0, 0, 0, 0, 0), (ctypes.c_int * 9)(*([0] * 9))
+        _lib.check(lib.rdpn6d_wgrad_f32(_ptr(dyo), 64, 0, 64, _ptr(rowp), 64, 0, 64, Bq, Ro, Ro, Ro, Ro, 1, 4, t_dy, t_dx, _ptr(wg), _ptr(part), st))
+        got = wg.view(64, 4, 2, 32)[..., :21].reshape(64, 8, 7, 3)[:, 1:].permute(0, 3, 1, 2).cpu()
+        w = torch.zeros(64, 3, 7, 7, dtype=torch.float64, requires_grad=True)
+        F.conv2d(img[:, :3].cpu().double(), w, stride=2, padding=3).backward(dyo.cpu().double().permute(0, 3, 1, 2))
+        assert (got.double() - w.grad).abs().max().item() <= 2e-5 * w.grad.abs().max().item()
 
 
 @pytest.mark.parametrize("amp", [False, True])
