@@ -333,13 +333,16 @@ def train_bench(args, rank, world, device, dist):
         buckets.finish()
         if eng.loss_scale != 1.0:
             # fp16: GradScaler's rule (engine.py:302-309) - a step whose reduced gradients are not finite is SKIPPED and the scale halved
-            # (one host read per step, as scaler.step() has); un-skipped, one overflow of an fp16 activation gradient poisons the weights
-            if not bool(torch.isfinite(buckets.flat).all()):
+            # (one host read per step, as scaler.step() has); un-skipped, one overflow of an fp16 activation gradient poisons the weights.
+            # The un-scaling and the finite check ride in the optimizer's own launches (Ranger.step): one 144-MB read instead of
+            # torch's isfinite().all() + mul_() (nine launches, 227 us of a 10.6-ms step)
+            opt.step(grad_scale=eng.loss_scale, skip_if_nonfinite=True)
+            if opt.found_inf():
                 skipped[0] += 1
                 eng.loss_scale = max(eng.loss_scale * 0.5, 1.0)
                 return losses
-            buckets.flat.mul_(1.0 / eng.loss_scale)
-        opt.step()
+        else:
+            opt.step()
         eng.refresh_weights()
         return losses
 

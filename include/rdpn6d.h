@@ -481,6 +481,15 @@ int rdpn6d_ranger_step_f32(float* param, const float* grad, float* exp_avg, floa
                            int nwork, const long long* row_off, const int* row_len, int nrows, float* row_mean, float beta1,
                            float beta2, float eps, float neg_step_lr, float wd_lr, int rectified, int lookahead, float alpha,
                            void* stream);
+/* The same step under a loss scale (the reference: GradScaler.unscale_ / GradScaler.step around the optimizer, engine.py:302-309)
+ * without separate passes over the gradients: every gradient is read as grad * inv_scale (the buffer keeps the scaled values); with
+ * found_inf != NULL the whole step is skipped on the device when *found_inf != 0.  rdpn6d_grad_nonfinite_f32 computes that flag:
+ * *flag = 1 if any of grad[0 .. n) is NaN or +-Inf, else 0 (grad 16-byte aligned). */
+int rdpn6d_ranger_step_scaled_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* slow, const void* work,
+                                  int nwork, const long long* row_off, const int* row_len, int nrows, float* row_mean, float beta1,
+                                  float beta2, float eps, float neg_step_lr, float wd_lr, int rectified, int lookahead, float alpha,
+                                  float inv_scale, const int* found_inf, void* stream);
+int rdpn6d_grad_nonfinite_f32(const float* grad, long long n, int* flag, void* stream);
 int rdpn6d_act_backward_f32(float* dy, const float* y, long long n, float slope, void* stream);
 /* y[b][c][r] = x[b][r][c] (B matrices of R x C floats): the last ConvPnPNet map in the reference's NCHW-flatten order for fc1
  * (conv_pnp_net.py:151: x.view(-1, featdim * 8 * 8) of an NCHW tensor), and its gradient back - instead of permuting fc1's 8.4 M weights every step */

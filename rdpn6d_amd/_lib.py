@@ -118,6 +118,8 @@ SIGNATURES = {
     "rdpn6d_pose_train_sym_f32": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _f, _vp, _vp, _i,
                                        _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rdpn6d_ranger_step_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _f, _f, _f, _f, _f, _i, _i, _f, _vp]),
+    "rdpn6d_ranger_step_scaled_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _f, _f, _f, _f, _f, _i, _i, _f, _f, _vp, _vp]),
+    "rdpn6d_grad_nonfinite_f32": (_i, [_vp, _ll, _vp, _vp]),
     "rdpn6d_region_targets_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "rdpn6d_pose_errors_f64": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "rdpn6d_crop_builder_f32": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),

@@ -154,7 +154,11 @@ class Ranger(Optimizer):
 
     # ------------------------------------------------------------------ step
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, grad_scale=1.0, skip_if_nonfinite=False):
+        """grad_scale / skip_if_nonfinite (round 5): the step under a loss scale as the reference runs it (GradScaler.unscale_ +
+        GradScaler.step, engine.py:302-309) without the separate passes - every gradient is read as grad / grad_scale (the buffer
+        keeps the scaled values), and with skip_if_nonfinite one pass sets a device flag for NaN / Inf anywhere in the flat gradient
+        and the update kernels skip the whole step on it; found_inf() reads the flag (the one host read GradScaler.step has)."""
         if self._flat is None:
             self._build()
         F = self._flat
@@ -174,6 +178,11 @@ class Ranger(Optimizer):
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         P = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
         first = True
+        scaled = float(grad_scale) != 1.0 or skip_if_nonfinite
+        if skip_if_nonfinite:
+            if getattr(self, "_found_inf", None) is None:
+                self._found_inf = torch.zeros(1, dtype=torch.int32, device=F["g"].device)
+            _lib.check(lib.rdpn6d_grad_nonfinite_f32(P(F["g"]), F["g"].numel(), P(self._found_inf), st), "grad_nonfinite")
         for gi, g in enumerate(self.param_groups):
             if self._nwork[gi] == 0:
                 continue
@@ -186,14 +195,31 @@ class Ranger(Optimizer):
                 step_size = math.sqrt((1 - beta2_t) * (n_sma - 4) / (n_max - 4) * (n_sma - 2) / n_sma * n_max / (n_max - 2)) / (1 - beta1 ** step)
             else:
                 step_size = 1.0 / (1 - beta1 ** step)
-            _lib.check(lib.rdpn6d_ranger_step_f32(
-                P(F["p"]), P(F["g"]), P(F["m"]), P(F["v"]), P(F["s"]), P(self._groups[gi]), self._nwork[gi], P(self._row_off),
-                P(self._row_len), self._nrows if first else 0, P(self._row_mean), beta1, beta2, g["eps"], -step_size * g["lr"],
-                g["weight_decay"] * g["lr"], 1 if rect else 0, 1 if step % g["k"] == 0 else 0, g["alpha"], st), "ranger_step")
+            if scaled:
+                _lib.check(lib.rdpn6d_ranger_step_scaled_f32(
+                    P(F["p"]), P(F["g"]), P(F["m"]), P(F["v"]), P(F["s"]), P(self._groups[gi]), self._nwork[gi], P(self._row_off),
+                    P(self._row_len), self._nrows if first else 0, P(self._row_mean), beta1, beta2, g["eps"], -step_size * g["lr"],
+                    g["weight_decay"] * g["lr"], 1 if rect else 0, 1 if step % g["k"] == 0 else 0, g["alpha"], 1.0 / float(grad_scale),
+                    P(self._found_inf) if skip_if_nonfinite else None, st), "ranger_step")
+            else:
+                _lib.check(lib.rdpn6d_ranger_step_f32(
+                    P(F["p"]), P(F["g"]), P(F["m"]), P(F["v"]), P(F["s"]), P(self._groups[gi]), self._nwork[gi], P(self._row_off),
+                    P(self._row_len), self._nrows if first else 0, P(self._row_mean), beta1, beta2, g["eps"], -step_size * g["lr"],
+                    g["weight_decay"] * g["lr"], 1 if rect else 0, 1 if step % g["k"] == 0 else 0, g["alpha"], st), "ranger_step")
             first = False  # the row means cover all groups and are computed once
         for p in self._params:
             self.state[p]["step"] = step
         return None
+
+    def found_inf(self):
+        """True when the last step(skip_if_nonfinite=True) found a NaN / Inf gradient and left parameters and state untouched (one host
+        read; the step counter has advanced all the same - rewound here, as a skipped GradScaler step does not count)."""
+        bad = bool(int(self._found_inf.item()))
+        if bad:
+            self._step -= 1
+            for p in self._params:
+                self.state[p]["step"] = self._step
+        return bad
 
     def load_state_dict(self, state_dict):
         """copy a reference-format optimizer state (per-parameter step / exp_avg / exp_avg_sq / slow_buffer) into the flat buffers"""

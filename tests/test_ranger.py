@@ -89,3 +89,41 @@ def test_hip_ranger_matches_reference_golden(gold):
         p.grad = torch.ones_like(p)
     opt.step()
     assert all(torch.isfinite(p).all() for p in ps)
+
+
+@pytest.mark.gpu
+def test_hip_ranger_step_under_a_loss_scale(gold):
+    """Ranger.step(grad_scale=S, skip_if_nonfinite=True): what GradScaler.unscale_ + GradScaler.step do around the reference's optimizer
+    (engine.py:302-309) inside the optimizer's own launches.  With S a power of two the trajectory on S-times-scaled gradients is the
+    un-scaled one BIT FOR BIT (so the reference golden holds); a step with an Inf or a NaN anywhere in the flat gradient changes no
+    parameter, no state and not the step count, and the next clean step continues as if it had not happened."""
+    from rdpn6d_amd.ranger import Ranger
+
+    dev, S = "cuda:0", 4096.0
+    plain, _, _ = _run(Ranger, dev)
+    ps = [torch.nn.Parameter(torch.from_numpy(a.copy()).to(dev)) for a in make_params()]
+    opt = Ranger([{"params": ps[:2], "lr": 1e-2}, {"params": ps[2:], "lr": 3e-2}], lr=1e-2, weight_decay=0)
+    for step in range(14):
+        for poison in ((float("inf"), float("nan"))[step % 2:step % 2 + 1] if step in (3, 8) else ()) + (None,):
+            for p, g in zip(ps, make_grads(step)):
+                gg = torch.from_numpy(g.copy()).to(dev) * S
+                if p.grad is None:
+                    p.grad = gg
+                else:
+                    p.grad.copy_(gg)
+            if poison is not None:
+                ps[4].grad.view(-1)[4321] = poison  # one element of 45 000
+                before = [p.detach().clone() for p in ps]
+                state = [opt.state[p]["exp_avg"].clone() for p in ps] if step else None
+            opt.step(grad_scale=S, skip_if_nonfinite=True)
+            if poison is not None:
+                assert opt.found_inf()
+                assert all(torch.equal(a, p.detach()) for a, p in zip(before, ps))
+                if state is not None:
+                    assert all(torch.equal(a, opt.state[p]["exp_avg"]) for a, p in zip(state, ps))
+                assert opt.state[ps[0]]["step"] == step
+            else:
+                assert not opt.found_inf()
+        for a, p in zip(plain[step], ps):
+            assert np.array_equal(a, p.detach().cpu().numpy()), step
+    _check([[p.detach().cpu().numpy() for p in ps]], {f"s0_p{i}": gold[f"s13_p{i}"] for i in range(len(ps))}, 3e-6)
