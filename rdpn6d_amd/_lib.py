@@ -7,7 +7,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "librdpn6d_hip.so")
+LIB_PATH = os.environ.get("RDPN6D_LIB") or os.path.join(HERE, "librdpn6d_hip.so")  # (RDPN6D_LIB: another build of the same ABI, for A/B runs)
 
 _ll = ctypes.c_longlong
 c_float_p = ctypes.c_void_p

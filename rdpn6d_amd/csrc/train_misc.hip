@@ -16,8 +16,11 @@
 // A workgroup owns 16 x 16 input pixels x <= 64 channels: phase 1 finds the arg-max tap of the 9 x 9 windows that touch them
 // (one thread = one window x V channels, 9 vector loads) and parks (tap, dy) in LDS; phase 2 gives every pixel the gradient of the
 // <= 4 windows whose arg-max it is.  ~1.3 reads of x per element instead of the 36 of a per-pixel window scan.
+// (MPB_THREADS = 1024: the 648 window tasks and the 2 048 pixel tasks of a tile are one and two rounds of a workgroup instead of 2.5 and 8 -
+//  every round is a dependent trip to memory; 256 threads: 75 us for the stem map at B = 32, round 5)
+#define MPB_THREADS 1024
 template <typename T, int V>
-__global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, int B, int H, int W, int C,
+__global__ __launch_bounds__(MPB_THREADS) void maxpool3x3s2_bwd_kernel(const T* __restrict__ x, const T* __restrict__ dy, int B, int H, int W, int C,
                                                                T* __restrict__ dx)
 {
     constexpr int TP = 16, TW = TP / 2 + 1, CH = 64;
@@ -35,7 +38,7 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const T* __restri
     const int ng = nch / V;
     const int oy0 = ty / 2, ox0 = tx / 2;
     const T* xb = x + (long long)b * H * W * C + c0;
-    for (int task = threadIdx.x; task < TW * TW * ng; task += 256) {
+    for (int task = threadIdx.x; task < TW * TW * ng; task += MPB_THREADS) {
         const int g = task % ng, w = task / ng;
         const int oy = oy0 + w / TW, ox = ox0 + w % TW;
         float best[V], d[V];
@@ -66,7 +69,7 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const T* __restri
         for (int e = 0; e < V; ++e) { s_tap[w][g * V + e] = (unsigned char)tap[e]; s_dy[w][g * V + e] = d[e]; }
     }
     __syncthreads();
-    for (int task = threadIdx.x; task < TP * TP * ng; task += 256) {
+    for (int task = threadIdx.x; task < TP * TP * ng; task += MPB_THREADS) {
         const int g = task % ng, p = task / ng;
         const int iy = ty + p / TP, ix = tx + p % TP;
         if (iy >= H || ix >= W) continue;
@@ -95,12 +98,12 @@ static int maxpool_bwd_impl(const T* x, const T* dy, int B, int H, int W, int C,
     const dim3 grid((unsigned)tiles, (unsigned)((C + 63) / 64));
     if constexpr (sizeof(T) == 2) {
         if (C % 8 == 0) {
-            hipLaunchKernelGGL((maxpool3x3s2_bwd_kernel<T, 8>), grid, dim3(256), 0, (hipStream_t)stream, x, dy, B, H, W, C, dx);
+            hipLaunchKernelGGL((maxpool3x3s2_bwd_kernel<T, 8>), grid, dim3(MPB_THREADS), 0, (hipStream_t)stream, x, dy, B, H, W, C, dx);
             RD_LAUNCH_CHECK();
             return RDPN6D_OK;
         }
     }
-    hipLaunchKernelGGL((maxpool3x3s2_bwd_kernel<T, 4>), grid, dim3(256), 0, (hipStream_t)stream, x, dy, B, H, W, C, dx);
+    hipLaunchKernelGGL((maxpool3x3s2_bwd_kernel<T, 4>), grid, dim3(MPB_THREADS), 0, (hipStream_t)stream, x, dy, B, H, W, C, dx);
     RD_LAUNCH_CHECK();
     return RDPN6D_OK;
 }
@@ -255,14 +258,27 @@ __global__ __launch_bounds__(256) void global_max_concat_bwd_kernel(const T* __r
     int mi[V];
 #pragma unroll
     for (int e = 0; e < V; ++e) { m[e] = -FLT_MAX; s[e] = 0.f; mi[e] = 0x7fffffff; }
-    for (int p = pl; p < HW; p += PL) {
-        float v[V], d[V];
-        rd_ldv<T, V>(f + (long long)p * cs + c, v);
-        rd_ldv<T, V>(g + (long long)p * cs + C + c, d);
+    // (four pixels = eight loads in flight per thread, then the same updates in the same order: one pixel per iteration was HW / PL = 32
+    //  dependent round trips for the 256 workgroups of a B = 32 batch - 47 us for 133 MB, round 5)
+    for (int p0 = pl; p0 < HW; p0 += 4 * PL) {
+        float v[4][V], d[4][V];
 #pragma unroll
-        for (int e = 0; e < V; ++e) {
-            if (v[e] > m[e]) { m[e] = v[e]; mi[e] = p; }
-            s[e] += d[e];
+        for (int u = 0; u < 4; ++u) {
+            const int p = p0 + u * PL;
+            if (p < HW) {
+                rd_ldv<T, V>(f + (long long)p * cs + c, v[u]);
+                rd_ldv<T, V>(g + (long long)p * cs + C + c, d[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = p0 + u * PL;
+            if (p >= HW) break;
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                if (v[u][e] > m[e]) { m[e] = v[u][e]; mi[e] = p; }
+                s[e] += d[u][e];
+            }
         }
     }
 #pragma unroll
@@ -287,12 +303,19 @@ __global__ __launch_bounds__(256) void global_max_concat_bwd_kernel(const T* __r
 #pragma unroll
     for (int e = 0; e < V; ++e) { tot[e] = s_tot[q * V + e]; bi[e] = s_best[q * V + e]; }
     T* o = dl3 + (long long)b * HW * C;
-    for (int p = pl; p < HW; p += PL) {
-        float d[V];
-        rd_ldv<T, V>(g + (long long)p * cs + c, d);
+    for (int p0 = pl; p0 < HW; p0 += 8 * PL) {
+        float d[8][V];
 #pragma unroll
-        for (int e = 0; e < V; ++e) d[e] += p == bi[e] ? tot[e] : 0.f;
-        rd_stv<T, V>(o + (long long)p * C + c, d);
+        for (int u = 0; u < 8; ++u)
+            if (p0 + u * PL < HW) rd_ldv<T, V>(g + (long long)(p0 + u * PL) * cs + c, d[u]);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int p = p0 + u * PL;
+            if (p >= HW) break;
+#pragma unroll
+            for (int e = 0; e < V; ++e) d[u][e] += p == bi[e] ? tot[e] : 0.f;
+            rd_stv<T, V>(o + (long long)p * C + c, d[u]);
+        }
     }
 }
 
@@ -358,16 +381,36 @@ __global__ __launch_bounds__(256) void dense_loss_kernel(const float* __restrict
                                                          float region_lw, float* __restrict__ dhead,
                                                          double* __restrict__ partial, int mask_type)
 {
+    // the head rows of the workgroup's 256 pixels go through LDS (coalesced copy, eight loads in flight per thread; a thread then walks
+    // its own row, odd stride = no bank conflicts) and the gradient rows go back the same way: a thread reading / writing its own
+    // 160-byte row in memory is 37 + 40 instructions of 64 different cache lines each (55 us for 21 MB at B = 32, round 5)
+    extern __shared__ float s_rows[];
     __shared__ double s_red[4][6];
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int sh = head_cs | 1;
+    const long long i0 = (long long)blockIdx.x * 256, i = i0 + threadIdx.x;
     const long long n = (long long)B * HW;
+    const int nrow = (int)(n - i0 < 256 ? n - i0 : 256) * head_cs;
+    for (int j0 = threadIdx.x; j0 < nrow; j0 += 8 * 256) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = j0 + u * 256;
+            v[u] = j < nrow ? head[i0 * head_cs + j] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = j0 + u * 256;
+            if (j < nrow) s_rows[(j / head_cs) * sh + j % head_cs] = v[u];
+        }
+    }
+    __syncthreads();
     double acc[6] = {0, 0, 0, 0, 0, 0};
     if (i < n) {
         const int b = (int)(i / HW), p = (int)(i - (long long)b * HW);
         const float denom = fmaxf((float)sums[0], 1.0f);
         const float inv_d = 1.0f / denom, inv_n = 1.0f / (float)n;
-        const float* h = head + i * head_cs;
-        float* dh = dhead + i * head_cs;
+        float* h = s_rows + threadIdx.x * sh;
+        float* dh = h;  // in place: every column is read before it is written (z[] holds the region logits)
         const float mv = m_visib[i], mt = m_trunc[i];
         // xyz L1 on the visible mask
 #pragma unroll
@@ -420,6 +463,8 @@ __global__ __launch_bounds__(256) void dense_loss_kernel(const float* __restrict
             }
         for (int c = MC + 4 + K; c < head_cs; ++c) dh[c] = 0.f;
     }
+    __syncthreads();
+    for (int j = threadIdx.x; j < nrow; j += 256) dhead[i0 * head_cs + j] = s_rows[(j / head_cs) * sh + j % head_cs];
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
 #pragma unroll
@@ -474,10 +519,14 @@ extern "C" int rdpn6d_dense_losses_mt_f32(const float* head, int head_cs, const 
     const int nblk = (int)((n + 255) / 256);
     hipLaunchKernelGGL(mask_sum_kernel, dim3(1), dim3(1024), 0, s, mask_visib, n, scratch);
     RD_LAUNCH_CHECK();
-#define RD_DL(KM, MCV) hipLaunchKernelGGL((dense_loss_kernel<KM, MCV>), dim3(nblk), dim3(256), 0, s, head, head_cs, gt_xyz, mask_visib, \
+    RD_REQUIRE(head_cs <= 128, "head row stride (LDS staging: 256 rows of head_cs | 1 floats)");
+    const size_t lds = (size_t)256 * (head_cs | 1) * sizeof(float);
+#define RD_DL(KM, MCV)                                                                                                                  \
+    if (lds > 64 * 1024) RD_LDS_OPT_IN((dense_loss_kernel<KM, MCV>), 132 * 1024);                                                       \
+    hipLaunchKernelGGL((dense_loss_kernel<KM, MCV>), dim3(nblk), dim3(256), lds, s, head, head_cs, gt_xyz, mask_visib, \
                                           mask_trunc, gt_region, B, HW, K, scratch, xyz_lw, mask_lw, region_lw, dhead, scratch + 8, mask_type)
-    if (K <= 32) { if (mc == 1) RD_DL(32, 1); else RD_DL(32, 2); }
-    else { if (mc == 1) RD_DL(64, 1); else RD_DL(64, 2); }
+    if (K <= 32) { if (mc == 1) { RD_DL(32, 1); } else { RD_DL(32, 2); } }
+    else { if (mc == 1) { RD_DL(64, 1); } else { RD_DL(64, 2); } }
 #undef RD_DL
     RD_LAUNCH_CHECK();
     hipLaunchKernelGGL(dense_loss_finalize_kernel, dim3(1), dim3(384), 0, s, scratch + 8, nblk, scratch, n, xyz_lw, mask_lw, region_lw, losses);
