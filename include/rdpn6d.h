@@ -120,6 +120,16 @@ int rdpn6d_conv2d_bf16_bnbwd(const rdpn6d_conv_desc* d, const void* bn_x, int bn
 int rdpn6d_bn_relu_backward_apply_bf16(const void* x, int xcs, int xco, const void* dy, int dcs, int dco, const float* mean,
                                        const float* invstd, const float* gamma, const float* beta, float* dgamma, float* dbeta, void* dx,
                                        int xgcs, int xgco, long long M, int C, const double* partial, int S, void* stream);
+/* The same pair for the LAST BatchNorm of a residual block, y = relu(bn(x) + identity) (torchvision BasicBlock / Bottleneck: out += identity;
+ * relu): the input-gradient convolution that writes the gradient w.r.t. the block output (its own residual input added in the epilogue)
+ * also writes that BatchNorm's backward sums with the mask y > 0 read from the STORED block output bn_y, and the apply step finishes as
+ * rdpn6d_bn_backward_bf16(relu = 1) would (dres = the masked gradient).  *rows == 0: the launch took a kernel without this epilogue. */
+int rdpn6d_conv2d_bf16_bnbwd_y(const rdpn6d_conv_desc* d, const void* bn_x, int bn_cs, int bn_co, const void* bn_y, int y_cs, int y_co,
+                               const float* mean, const float* invstd, double* partial, int* rows, void* stream);
+int rdpn6d_bn_backward_apply_bf16(const void* x, int xcs, int xco, const void* dy, int dcs, int dco, const void* y, int ycs, int yco,
+                                  const float* mean, const float* invstd, const float* gamma, float* dgamma, float* dbeta, void* dx,
+                                  int xgcs, int xgco, void* dres, int rcs, int rco, long long M, int C, const double* partial, int S,
+                                  void* stream);
 void rdpn6d_conv_bf16_force_tile(int bm, int bn);
 /* profiling: LDS stages of the 4-wave tiles (0 = the heuristic: 3 for 64x64 tiles with >= 64 K-chunks, else 2) */
 void rdpn6d_conv_bf16_force_stages(int nst);
@@ -614,6 +624,12 @@ int rdpn6d_conv2d_fp16_bnbwd(const rdpn6d_conv_desc* d, const void* bn_x, int bn
 int rdpn6d_bn_relu_backward_apply_fp16(const void* x, int xcs, int xco, const void* dy, int dcs, int dco, const float* mean,
                                        const float* invstd, const float* gamma, const float* beta, float* dgamma, float* dbeta, void* dx,
                                        int xgcs, int xgco, long long M, int C, const double* partial, int S, void* stream);
+int rdpn6d_conv2d_fp16_bnbwd_y(const rdpn6d_conv_desc* d, const void* bn_x, int bn_cs, int bn_co, const void* bn_y, int y_cs, int y_co,
+                               const float* mean, const float* invstd, double* partial, int* rows, void* stream);
+int rdpn6d_bn_backward_apply_fp16(const void* x, int xcs, int xco, const void* dy, int dcs, int dco, const void* y, int ycs, int yco,
+                                  const float* mean, const float* invstd, const float* gamma, float* dgamma, float* dbeta, void* dx,
+                                  int xgcs, int xgco, void* dres, int rcs, int rco, long long M, int C, const double* partial, int S,
+                                  void* stream);
 int rdpn6d_conv2d_fp16_bnstats(const rdpn6d_conv_desc* d, double* stats, int stats_row0, int* stats_rows, void* stream);
 void rdpn6d_conv_fp16_force_tile(int bm, int bn);
 void rdpn6d_conv_fp16_force_stages(int nst);

@@ -51,6 +51,9 @@ SIGNATURES = {
     "rdpn6d_conv2d_bf16_bnstats": (_i, [ctypes.POINTER(ConvDesc), _vp, _i, _vp, _vp]),
     "rdpn6d_conv2d_bf16_bnbwd": (_i, [ctypes.POINTER(ConvDesc), _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rdpn6d_bn_relu_backward_apply_bf16": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _ll, _i, _vp, _i, _vp]),
+    "rdpn6d_conv2d_bf16_bnbwd_y": (_i, [ctypes.POINTER(ConvDesc), _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "rdpn6d_bn_backward_apply_bf16": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _i, _ll, _i,
+                                           _vp, _i, _vp]),
     "rdpn6d_bn_stats_finalize": (_i, [_vp, _i, _i, _ll, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "rdpn6d_conv_bf16_tile_for": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp]),
     "rdpn6d_split_bf16x3": (_i, [_vp, _ll, _vp, _ll, _vp]),

@@ -31,6 +31,10 @@ struct ConvBArgs {
     const void* bnb_x = nullptr;
     int bnb_cs = 0, bnb_co = 0;
     const float *bnb_mean = nullptr, *bnb_invstd = nullptr, *bnb_gamma = nullptr, *bnb_beta = nullptr;
+    // ... or of a residual block's last BatchNorm (rdpn6d_conv2d_bf16_bnbwd_y): dy is the gradient w.r.t. the block OUTPUT
+    // y = relu(bn(x) + identity), so the mask is the stored y > 0 (the STATS == 2 instantiation reads bnb_y next to bnb_x; beta unused)
+    const void* bnb_y = nullptr;
+    int bnb_ycs = 0, bnb_yco = 0;
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -59,7 +63,7 @@ __device__ __forceinline__ void conv_bf16_act(float (&v)[N], const int act, cons
 // STATS: the instantiation that also writes the BatchNorm partial sums (ConvBArgs::stats / bnb_x) - a template flag, not a run-time
 // branch, because its registers (parameters and pre-loaded rows of 8 channels) would otherwise raise the VGPR count of EVERY kernel that
 // shares this epilogue: the 64x128 inference tile went from 124 to 134 VGPRs = from four to three wavefronts per SIMD (-2.4 % crops/s).
-template <int BM, int BN, int WM, int WN, int TM, int TN, bool MASK_ROWS, bool STATS = false>
+template <int BM, int BN, int WM, int WN, int TM, int TN, bool MASK_ROWS, int STATS = 0>
 __device__ __forceinline__ void conv_bf16_epilogue_vec(const ConvBArgs& a, f32x16 (&acc)[TM][TN], unsigned char* smem,
                                                        const long long m0, const int n0, const int wave, const int lane,
                                                        const int wm, const int wn)
@@ -100,14 +104,17 @@ __device__ __forceinline__ void conv_bf16_epilogue_vec(const ConvBArgs& a, f32x1
         constexpr int NRB = 32 / (64 / (WC / 8));  // row groups per 32-row accumulator tile in the 16-bit walk
         rd_u32x4 bxq[TM][NRB];                     // ... and the BatchNorm-input rows of this lane's outputs, ALL requested up front (one
                                                    // dependent load per row group cost the 256x256 kernel 34 us per head layer)
+        rd_u32x4 byq[STATS == 2 ? TM : 1][STATS == 2 ? NRB : 1];  // STATS == 2: the stored block-output rows (the ReLU mask) as well
         if (STATS && a.stats && a.bnb_x && !a.out_f32) {
             const int c = nb + (lane % (WC / 8)) * 8;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 bmu[q] = a.bnb_mean[c + q];
                 bis[q] = a.bnb_invstd[c + q];
-                bga[q] = a.bnb_gamma[c + q];
-                bbe[q] = a.bnb_beta[c + q];
+                if constexpr (STATS != 2) {
+                    bga[q] = a.bnb_gamma[c + q];
+                    bbe[q] = a.bnb_beta[c + q];
+                }
             }
             constexpr int LPRB = WC / 8, RPIB = 64 / LPRB;
 #pragma unroll
@@ -117,6 +124,8 @@ __device__ __forceinline__ void conv_bf16_epilogue_vec(const ConvBArgs& a, f32x1
                     const long long mrow = m0 + wm * (BM / WM) + i * 32 + rr * RPIB + lane / LPRB;
                     const long long mr = mrow < a.M ? mrow : 0;  // (linear geometry: pixel = row; rows past M are skipped below)
                     bxq[i][rr] = *reinterpret_cast<const rd_u32x4*>(reinterpret_cast<const bf16_t*>(a.bnb_x) + mr * a.bnb_cs + a.bnb_co + c);
+                    if constexpr (STATS == 2)
+                        byq[i][rr] = *reinterpret_cast<const rd_u32x4*>(reinterpret_cast<const bf16_t*>(a.bnb_y) + mr * a.bnb_ycs + a.bnb_yco + c);
                 }
         }
 #pragma unroll
@@ -174,11 +183,22 @@ __device__ __forceinline__ void conv_bf16_epilogue_vec(const ConvBArgs& a, f32x1
                         if (a.bnb_x) {  // backward sums of the BatchNorm + ReLU this gradient flows into (linear geometry: pix = row)
                             float xr[8];
                             rd_unpack8(bxq[i][rr], xr);
+                            if constexpr (STATS == 2) {  // residual block: the mask is the stored block output (chan_partial_kernel's relu == 1)
+                                float yr[8];
+                                rd_unpack8(byq[i][rr], yr);
 #pragma unroll
-                            for (int q = 0; q < 8; ++q) {
-                                const float g = bn_stored_positive<bf16_t>(bn_fwd_value(xr[q], bmu[q], bis[q], bga[q], bbe[q])) ? r[q] : 0.f;
-                                st1[q] += g;
-                                st2[q] += g * ((xr[q] - bmu[q]) * bis[q]);
+                                for (int q = 0; q < 8; ++q) {
+                                    const float g = yr[q] > 0.f ? r[q] : 0.f;
+                                    st1[q] += g;
+                                    st2[q] += g * ((xr[q] - bmu[q]) * bis[q]);
+                                }
+                            } else {
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) {
+                                    const float g = bn_stored_positive<bf16_t>(bn_fwd_value(xr[q], bmu[q], bis[q], bga[q], bbe[q])) ? r[q] : 0.f;
+                                    st1[q] += g;
+                                    st2[q] += g * ((xr[q] - bmu[q]) * bis[q]);
+                                }
                             }
                         } else {
 #pragma unroll
@@ -217,7 +237,7 @@ __device__ __forceinline__ void conv_bf16_epilogue_vec(const ConvBArgs& a, f32x1
 
 // acc: the wave's (BM/WM) x (BN/WN) tile as TM x TN 32x32 MFMA accumulators; smem: the workgroup's dynamic LDS (idle
 // once the K loop is done); wm / wn: the wave's position in the WM x WN grid.
-template <int BM, int BN, int WM, int WN, int TM, int TN, bool STATS = false>
+template <int BM, int BN, int WM, int WN, int TM, int TN, int STATS = 0>
 __device__ __forceinline__ void conv_bf16_epilogue(const ConvBArgs& a, f32x16 (&acc)[TM][TN], unsigned char* smem, const long long m0,
                                                    const int n0, const int wave, const int lane, const int wm, const int wn)
 {

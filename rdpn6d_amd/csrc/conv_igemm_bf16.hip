@@ -22,7 +22,7 @@
 
 #include <cstdlib>
 
-template <int BM, int BN, int RB, int WM, int WN, int NST, bool STATS = false>
+template <int BM, int BN, int RB, int WM, int WN, int NST, int STATS = 0>
 __global__ __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) void conv_igemm_bf16_kernel(const ConvBArgs a)
 {
     constexpr int NW = WM * WN;      // wavefronts per workgroup
@@ -323,7 +323,15 @@ static int conv_bf16_launch_one(const ConvBArgs& a, int nsplit, hipStream_t s)
     constexpr int lds = lds_stage > lds_epi ? lds_stage : lds_epi;
     if (a.stats) {  // training: the instantiation whose epilogue writes BatchNorm partial sums (RB = 128 only: the trunk / head layers)
         if constexpr (RB == 128 && WM * WN == 4) {
-            auto kern = conv_igemm_bf16_kernel<BM, BN, RB, WM, WN, NST, true>;
+            if (a.bnb_y) {  // ... of a residual block's last BatchNorm: mask from the stored block output
+                auto kern = conv_igemm_bf16_kernel<BM, BN, RB, WM, WN, NST, 2>;
+                if (lds > 64 * 1024) {
+                    RD_LDS_OPT_IN(kern, lds);
+                }
+                hipLaunchKernelGGL(kern, dim3((unsigned)(a.mtiles * a.ntiles), (unsigned)nsplit), dim3(64 * WM * WN), lds, s, a);
+                return RDPN6D_OK;
+            }
+            auto kern = conv_igemm_bf16_kernel<BM, BN, RB, WM, WN, NST, 1>;
             if (lds > 64 * 1024) {
                 RD_LDS_OPT_IN(kern, lds);
             }
@@ -367,10 +375,12 @@ static int conv_bf16_launch(const ConvBArgs& a, int bm, int bn, int nsplit, hipS
     return conv_bf16_launch_one<64, 64, RB, 2, 2, 2>(a, nsplit, s);
 }
 
-struct ConvBnBwd {  // see ConvBArgs::bnb_x
+struct ConvBnBwd {  // see ConvBArgs::bnb_x / bnb_y
     const void* x;
     int cs, co;
     const float *mean, *invstd, *gamma, *beta;
+    const void* y = nullptr;
+    int ycs = 0, yco = 0;
 };
 static int conv2d_bf16_impl(const rdpn6d_conv_desc* d, int out_f32, int ksplit, float* workspace, void* stream, double* stats = nullptr,
                             int stats_row0 = 0, int* stats_rows = nullptr, const ConvBnBwd* bnb = nullptr);
@@ -409,6 +419,24 @@ extern "C" int rdpn6d_conv2d_bf16_bnbwd(const rdpn6d_conv_desc* d, const void* b
     RD_REQUIRE(bn_cs % 8 == 0 && bn_co % 8 == 0 && d && bn_co + d->N <= bn_cs, "BatchNorm input slice: 16-byte aligned, N channels");
     RD_REQUIRE(d->osy == 1 && d->osx == 1 && d->ooy == 0 && d->oox == 0 && d->OH == d->Ho && d->OW == d->Wo, "linear output geometry");
     const ConvBnBwd b = {bn_x, bn_cs, bn_co, mean, invstd, gamma, beta};
+    return conv2d_bf16_impl(d, 0, 1, nullptr, stream, partial, 0, rows, &b);
+}
+
+// The same for the LAST BatchNorm of a residual block, y = relu(bn(x) + identity): this launch is the input-gradient convolution that
+// writes the gradient w.r.t. the block output y (its own residual input - the next block's identity gradient - added in the epilogue),
+// and the ReLU mask is the STORED y > 0 (chan_partial_kernel's relu == 1).  rdpn6d_bn_backward_apply_bf16 finishes.  *rows == 0 (and a
+// normal convolution) when the launch falls to a kernel without this epilogue (the 256x256 one) or the geometry does not allow it.
+extern "C" int rdpn6d_conv2d_bf16_bnbwd_y(const rdpn6d_conv_desc* d, const void* bn_x, int bn_cs, int bn_co, const void* bn_y, int y_cs,
+                                          int y_co, const float* mean, const float* invstd, double* partial, int* rows, void* stream)
+{
+    RD_REQUIRE(bn_x && bn_y && mean && invstd && partial && rows, "null pointer");
+    RD_REQUIRE(bn_cs % 8 == 0 && bn_co % 8 == 0 && d && bn_co + d->N <= bn_cs, "BatchNorm input slice: 16-byte aligned, N channels");
+    RD_REQUIRE(y_cs % 8 == 0 && y_co % 8 == 0 && y_co + d->N <= y_cs, "block output slice: 16-byte aligned, N channels");
+    RD_REQUIRE(d->osy == 1 && d->osx == 1 && d->ooy == 0 && d->oox == 0 && d->OH == d->Ho && d->OW == d->Wo, "linear output geometry");
+    ConvBnBwd b = {bn_x, bn_cs, bn_co, mean, invstd, nullptr, nullptr};
+    b.y = bn_y;
+    b.ycs = y_cs;
+    b.yco = y_co;
     return conv2d_bf16_impl(d, 0, 1, nullptr, stream, partial, 0, rows, &b);
 }
 
@@ -465,13 +493,14 @@ static int conv2d_bf16_impl(const rdpn6d_conv_desc* d, int out_f32, int ksplit, 
     }
     if (stats_rows) *stats_rows = 0;
     if (stats && !out_f32 && a.vec_out && d->N == d->Npad && ksplit <= 1 && rb == 128 && !(bm == 256 && bn == 128) &&
-        ((bm == 256 && bn == 256) || a.M % bm == 0)) {
+        ((bm == 256 && bn == 256 && !(bnb && bnb->y)) || (a.M % bm == 0 && !(bm == 256 && bn == 256)))) {
         // every tile takes the coalesced epilogue (full column tiles: bn divides Npad = N; full row tiles, or the 8-phase kernel's masked rows)
         a.stats = stats;
         a.stats_row0 = stats_row0;
         if (bnb) {
             a.bnb_x = bnb->x; a.bnb_cs = bnb->cs; a.bnb_co = bnb->co;
             a.bnb_mean = bnb->mean; a.bnb_invstd = bnb->invstd; a.bnb_gamma = bnb->gamma; a.bnb_beta = bnb->beta;
+            a.bnb_y = bnb->y; a.bnb_ycs = bnb->ycs; a.bnb_yco = bnb->yco;
         }
         *stats_rows = a.mtiles * 2;  // wave rows per tile: WM of the launch below
     }

@@ -15,7 +15,7 @@ using ic = std::integral_constant<int, V>;
 
 namespace {
 
-template <int BM, int BN, int WM, int WN, int NST, int PM, bool STATS = false>
+template <int BM, int BN, int WM, int WN, int NST, int PM, int STATS = 0>
 __global__ __launch_bounds__(512) void conv_lp_pp_kernel(const ConvBArgs a)
 {
     constexpr int RB = 128, RPP = 8, NW = 8;
@@ -227,8 +227,14 @@ static int launch_lp_pp(const ConvBArgs& a, hipStream_t s)
     constexpr int lds_epi = 8 * 32 * (BN / WN + 8) * 4;
     constexpr int lds = lds_stage > lds_epi ? lds_stage : lds_epi;
     static_assert(lds <= 160 * 1024, "LDS");
+    if (a.stats && a.bnb_y) {  // ... of a residual block's last BatchNorm (mask from the stored block output)
+        auto kern = conv_lp_pp_kernel<BM, BN, WM, WN, NST, PM, 2>;
+        RD_LDS_OPT_IN(kern, lds);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(a.mtiles * a.ntiles)), dim3(512), lds, s, a);
+        return RDPN6D_OK;
+    }
     if (a.stats) {  // training: the instantiation whose epilogue writes BatchNorm partial sums
-        auto kern = conv_lp_pp_kernel<BM, BN, WM, WN, NST, PM, true>;
+        auto kern = conv_lp_pp_kernel<BM, BN, WM, WN, NST, PM, 1>;
         RD_LDS_OPT_IN(kern, lds);
         hipLaunchKernelGGL(kern, dim3((unsigned)(a.mtiles * a.ntiles)), dim3(512), lds, s, a);
         return RDPN6D_OK;

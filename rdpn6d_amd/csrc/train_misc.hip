@@ -355,9 +355,15 @@ __global__ __launch_bounds__(1024) void mask_sum_kernel(const float* __restrict_
     __shared__ double s[16];
     double a = 0.0;
     const long long n4 = ((reinterpret_cast<size_t>(m) & 15) == 0) ? n / 4 : 0;
-    for (long long i = threadIdx.x; i < n4; i += 1024) {
-        const f32x4 v = reinterpret_cast<const f32x4*>(m)[i];
-        a += ((double)v[0] + (double)v[1]) + ((double)v[2] + (double)v[3]);
+    // (eight loads in flight, added in the loop's own order: one per iteration was 32 dependent round trips at B = 32 - 19 us)
+    for (long long i0 = threadIdx.x; i0 < n4; i0 += 8 * 1024) {
+        f32x4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + u * 1024 < n4) v[u] = reinterpret_cast<const f32x4*>(m)[i0 + u * 1024];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + u * 1024 < n4) a += ((double)v[u][0] + (double)v[u][1]) + ((double)v[u][2] + (double)v[u][3]);
     }
     for (long long i = n4 * 4 + threadIdx.x; i < n; i += 1024) a += (double)m[i];
 #pragma unroll

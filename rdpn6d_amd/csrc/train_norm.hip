@@ -595,6 +595,30 @@ extern "C" int rdpn6d_bn_relu_backward_apply_bf16(const void* x, int xcs, int xc
                                                   dgamma, dbeta, (rd_bf16_t*)dx, xgcs, xgco, M, C, partial, S, stream);
 }
 
+// ... and of rdpn6d_bn_backward_bf16(relu = 1) - the last BatchNorm of a residual block: mask from the stored block output y, dres = the
+// masked gradient (the identity branch's) - after rdpn6d_conv2d_bf16_bnbwd_y wrote the S rows of partial sums.
+extern "C" int rdpn6d_bn_backward_apply_bf16(const void* x, int xcs, int xco, const void* dy, int dcs, int dco, const void* y, int ycs,
+                                             int yco, const float* mean, const float* invstd, const float* gamma, float* dgamma,
+                                             float* dbeta, void* dx, int xgcs, int xgco, void* dres, int rcs, int rco, long long M, int C,
+                                             const double* partial, int S, void* stream)
+{
+    typedef rd_bf16_t T;
+    RD_REQUIRE(x && dy && y && mean && invstd && gamma && dgamma && dbeta && dx && partial && S > 0, "null pointer");
+    RD_REQUIRE(M > 0 && C > 0 && C % 8 == 0, "shape");
+    RD_REQUIRE(xcs % 8 == 0 && xco % 8 == 0 && dcs % 8 == 0 && dco % 8 == 0 && xgcs % 8 == 0 && xgco % 8 == 0 && ycs % 8 == 0 && yco % 8 == 0 &&
+                   (!dres || (rcs % 8 == 0 && rco % 8 == 0)),
+               "16-byte aligned channel slices");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(chan_sum_finalize_rows_kernel, dim3((C + 7) / 8), dim3(256), 0, s, partial, S, C, dbeta, dgamma);
+    RD_LAUNCH_CHECK();
+    const long long total8 = M * (C / 8);
+    const int blocks8 = (int)((total8 + 255) / 256 < 16384 ? (total8 + 255) / 256 : 16384);
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 8>), dim3(blocks8), dim3(256), 0, s, (const T*)x, xcs, xco, (const T*)dy, dcs, dco, (const T*)y, ycs,
+                       yco, mean, invstd, gamma, (const float*)nullptr, dgamma, dbeta, (T*)dx, xgcs, xgco, (T*)dres, rcs, rco, M, C, 1);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}
+
 // (NT threads per crop: 1024 for maps of >= 256 pixels - one workgroup per crop is all the parallelism there is, B = 32 workgroups on
 //  256 CUs, and with 256 threads each of them walked 128 pixels three times: 75 us forward / 110 us backward for ConvPnPNet's first map)
 template <int NT>

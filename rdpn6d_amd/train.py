@@ -68,6 +68,8 @@ class TrainEngine:
         self._bn_by_dy, self._scratch_bnb_need = {}, 0
         # transposing weight packs through LDS tiles (repack_kernel); RDPN6D_REPACK_TILES=0: the pair form for every entry (A/B, tests)
         self.repack_tiles = os.environ.get("RDPN6D_REPACK_TILES", "1") != "0"
+        # ... and the LAST BatchNorm of a residual block from the next block's first input-gradient convolution (rdpn6d_conv2d_bf16_bnbwd_y)
+        self.bn_fuse_bwd_res = bool(model.cfg.get("SOLVER", {}).get("BN_FUSE_BWD_RES", os.environ.get("RDPN6D_BN_FUSE_BWD_RES", "1") != "0"))
         self.bn_remask = bool(model.cfg.get("SOLVER", {}).get("BN_REMASK", os.environ.get("RDPN6D_BN_REMASK", "1") != "0"))
         self.x3_launches = 0
         cfg = model.cfg
@@ -268,9 +270,14 @@ class TrainEngine:
                         run.stats_rows = rows.value
                     elif run.bn_bwd is not None:  # an input-gradient convolution whose output is the gradient of a BatchNorm + ReLU:
                         r = run.bn_bwd            # that BatchNorm's backward sums come out of this launch's epilogue (conv_unit)
-                        _lib.check(self.lpf("rdpn6d_conv2d_bf16_bnbwd")(ctypes.byref(d), _ptr(r["x_raw"]), r["cs"], r["co"], _ptr(r["mean"]),
-                                                                        _ptr(r["invstd"]), _ptr(r["ga"]), _ptr(r["be"]), _ptr(self._scratch_bnb),
-                                                                        ctypes.byref(rows), self.st()), name)
+                        if r["y"] is not None:    # (the last BatchNorm of a residual block: mask from the stored block output)
+                            _lib.check(self.lpf("rdpn6d_conv2d_bf16_bnbwd_y")(ctypes.byref(d), _ptr(r["x_raw"]), r["cs"], r["co"], _ptr(r["y"]),
+                                                                              r["ycs"], r["yco"], _ptr(r["mean"]), _ptr(r["invstd"]),
+                                                                              _ptr(self._scratch_bnb), ctypes.byref(rows), self.st()), name)
+                        else:
+                            _lib.check(self.lpf("rdpn6d_conv2d_bf16_bnbwd")(ctypes.byref(d), _ptr(r["x_raw"]), r["cs"], r["co"], _ptr(r["mean"]),
+                                                                            _ptr(r["invstd"]), _ptr(r["ga"]), _ptr(r["be"]),
+                                                                            _ptr(self._scratch_bnb), ctypes.byref(rows), self.st()), name)
                         run.stats_rows = rows.value
                         self._bnb_owner = r  # the ONE shared sums buffer now holds this BatchNorm's partial sums (checked by its bwd)
                     else:
@@ -369,7 +376,7 @@ class TrainEngine:
 
     # ------------------------------------------------------------------ layer builders
     def conv_unit(self, name, P, x, xhw, in_cs, in_co, cin_real, y, yhw, out_cs, out_co, *, stride=1, perm=None, bias=None,
-                  dx=None, dx_cs=None, dx_res=None, act_out=None, slope=0.0, first=False):
+                  dx=None, dx_cs=None, dx_res=None, act_out=None, slope=0.0, first=False, dx_final=False):
         """One convolution: forward launch now, backward launches pushed on self.bwd (executed in reverse).
         x: input activation tensor; y: raw output tensor; dx: gradient buffer for the input (None = not needed).
         The gradient w.r.t. y is expected in self.bufs['d:'+name] when the backward runs."""
@@ -532,7 +539,10 @@ class TrainEngine:
                 else:
                     drun = dlaunch("dgrad " + name, dd, wd)
                     rec = self._bn_by_dy.get(dx.data_ptr())
-                    if (rec is not None and rec["producer"] is None and getattr(drun, "bn_capable", False) and dx_res is None
+                    # (a residual block's last BatchNorm - rec["y"] - takes the gradient w.r.t. the block output: only the launch that
+                    #  completes it, residual added, may carry its sums)
+                    if (rec is not None and rec["producer"] is None and getattr(drun, "bn_capable", False)
+                            and (dx_res is None if rec["y"] is None else dx_final)
                             and rec["dy_cs"] == dx_cs and rec["dy_co"] == in_co and rec["C"] == cin_real
                             and rec["M"] == B * xhw[0] * xhw[1]):
                         drun.bn_bwd, rec["producer"] = rec, drun
@@ -663,10 +673,12 @@ class TrainEngine:
         f_bwd_remask = getattr(lib, f"rdpn6d_bn_relu_backward_{t}")
         # the convolution that CONSUMES y registers after this unit: if its input-gradient launch can also produce this BatchNorm's
         # backward sums (conv_unit), the reduction pass over dy and x_raw is skipped here
-        rec = dict(x_raw=x_raw, cs=cs, co=co, C=C, M=M, mean=mean, invstd=invstd, ga=ga, be=be, dy_cs=dy_cs, dy_co=dy_co, producer=None)
+        res_form = relu and res is not None and dres is not None  # y = relu(bn(x) + identity): the mask is the stored y
+        rec = dict(x_raw=x_raw, cs=cs, co=co, C=C, M=M, mean=mean, invstd=invstd, ga=ga, be=be, dy_cs=dy_cs, dy_co=dy_co, producer=None,
+                   y=y if res_form else None, ycs=ycs, yco=yco)
         self.records.append(dict(kind="bn", name=name, bn=bn, x_raw=x_raw, cs=cs, co=co, C=C, M=M, y=y, ycs=ycs, yco=yco, relu=relu, res=res,
                                  res_cs=res_cs, dx=dx, dres=dres, dy=dy, dy_cs=dy_cs, dy_co=dy_co))
-        if remask and t != "f32" and self.bn_fuse_bwd:
+        if (remask or (res_form and self.bn_fuse_bwd_res)) and t != "f32" and self.bn_fuse_bwd:
             self._bn_by_dy[dy.data_ptr()] = rec
 
         def bwd():
@@ -678,6 +690,12 @@ class TrainEngine:
                     # (true for the chained ResNet / head topologies; a re-ordered _build would otherwise read another layer's sums)
                     raise RuntimeError(f"fused BatchNorm backward of {name}: the shared partial-sum buffer was overwritten by another "
                                        "layer's input-gradient convolution before this BatchNorm consumed it (set SOLVER.BN_FUSE_BWD=False)")
+                if rec["y"] is not None:
+                    _lib.check(self.lpf("rdpn6d_bn_backward_apply_bf16")(
+                        _ptr(x_raw), cs, co, _ptr(dy), dy_cs, dy_co, _ptr(y), ycs, yco, _ptr(mean), _ptr(invstd), _ptr(ga),
+                        _ptr(self._grad(bn.weight)), _ptr(self._grad(bn.bias)), _ptr(dx), cs, co, _ptr(dres), dres.shape[-1], 0, M, C,
+                        _ptr(self._scratch_bnb), prod.stats_rows, self.st()), "bn bwd (apply) " + name)
+                    return
                 _lib.check(self.lpf("rdpn6d_bn_relu_backward_apply_bf16")(
                     _ptr(x_raw), cs, co, _ptr(dy), dy_cs, dy_co, _ptr(mean), _ptr(invstd), _ptr(ga), _ptr(be), _ptr(self._grad(bn.weight)),
                     _ptr(self._grad(bn.bias)), _ptr(dx), cs, co, M, C, _ptr(self._scratch_bnb), prod.stats_rows, self.st()),
@@ -774,7 +792,7 @@ class TrainEngine:
                                               stride=s, dx=d_cur, dx_res=d_cur if s == 1 else None)
                         res_t = ad
                     d_r1 = self.conv_unit(f"{nm}.conv1", blk.conv1, cur, (hw, hw), c, 0, c, r1, (hw, hw), width, 0, dx=d_cur,
-                                          dx_res=None if has_ds else dres)
+                                          dx_res=None if has_ds else dres, dx_final=not has_ds)
                     if has_ds:
                         self.bn_unit(f"{nm}.downsample.1", blk.downsample[1], rd, cout, 0, cout, M, ad, cout, 0, False, dx=d_rd,
                                      dy=dres, dy_cs=cout)
@@ -804,7 +822,7 @@ class TrainEngine:
                                           stride=s, dx=d_cur)
                     res_t = ad
                 d_r1 = self.conv_unit(f"{nm}.conv1", blk.conv1, cur, (hw, hw), c, 0, c, r1, (ohw, ohw), cout, 0, stride=s,
-                                      dx=d_cur, dx_res=None if has_ds else dres)
+                                      dx=d_cur, dx_res=None if has_ds else dres, dx_final=not has_ds)
                 if has_ds:
                     self.bn_unit(f"{nm}.downsample.1", blk.downsample[1], rd, cout, 0, cout, M, ad, cout, 0, False, dx=d_rd,
                                  dy=dres, dy_cs=cout)
@@ -1049,13 +1067,16 @@ class TrainEngine:
             g = wg_out[:nout, 0]
             if g_view:
                 g = g_view(g)
-            _lib.check(lib.rdpn6d_channel_sum_f32(_ptr(d_y), B, ca, out_cs, 0, _ptr(bg), 0, _ptr(self._scratch_d), self.st()), "bias " + name)
+            gb = self._grad(bs[0]) if len(bs) == 1 and ca == nout else None  # one bias of ca entries: summed in place as well
+            _lib.check(lib.rdpn6d_channel_sum_f32(_ptr(d_y), B, ca, out_cs, 0, _ptr(bg if gb is None else gb), 0, _ptr(self._scratch_d),
+                                                  self.st()), "bias " + name)
             o = 0
             for wp, bp in zip(ws, bs):
                 n = wp.shape[0]
                 if not direct:
                     self._grad(wp).copy_(g[o:o + n])
-                self._grad(bp).copy_(bg[o:o + n])
+                if gb is None:
+                    self._grad(bp).copy_(bg[o:o + n])
                 o += n
 
         self.bwd.append([bwd, self._launch_conv("dgrad " + name, dd, wd, ksplit=True)])

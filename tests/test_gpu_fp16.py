@@ -124,7 +124,12 @@ def test_fp16_training_through_the_reference_loop_with_gradscaler():
     exact semantics step by step instead of "no overflow after N steps":
       * a step whose parameter gradients contain a non-finite value is SKIPPED (weights bit-identical, same loss next step) and the scale
         halves; a step with finite gradients is TAKEN (weights move) and the scale stays (growth interval 2000);
-      * the only parameter gradient that is ever non-finite is backbone.conv1.weight (the weight gradient computed from d:stem);
+      * a non-finite parameter gradient always traces back to an fp16 OVERFLOW of a stored activation gradient - a handful of elements of a
+        "d:" buffer whose finite maximum sits at the fp16 limit (d:stem at 65536 / 32768: backbone.conv1.weight; everything below an
+        overflowed map is NaN through its BatchNorm).  Round 4 asserted "only backbone.conv1.weight, ever": true of THAT trajectory -
+        with the residual blocks' BatchNorm sums taken from the convolution epilogue (round 5: 1e-7 apart per step, checked step by
+        step against the separate pass, tools/debug history in profiles/r5_experiments.md) the run is another sample of the same
+        chaotic fp16 trajectory and tipped ONE element of d:layer1.2.out (layer2 maxima at 0.93-0.98 of the limit) over at step 9;
       * the scale never falls below 4096, at most four steps are skipped in twelve, the loss falls over the steps taken;
       * started AT 8192 (the settled scale) the same loop skips nothing in six steps."""
     from rdpn6d_amd import synth
@@ -143,7 +148,7 @@ def test_fp16_training_through_the_reference_loop_with_gradscaler():
         sd = synth.make_trained_like_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=1234)
         model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
         scaler = torch.amp.GradScaler("cuda", init_scale=init_scale)
-        hist, scales, skipped, bad_names = [], [], [], set()
+        hist, scales, skipped, bad_names, overflow_sites = [], [], [], set(), set()
         for it in range(steps):
             _, ld = model(b["roi_img"], gt_xyz=b["roi_xyz"], gt_mask_trunc=b["roi_mask_trunc"], gt_mask_visib=b["roi_mask_visib"],
                           gt_mask_obj=b["roi_mask_obj"], gt_region=b["roi_region"], gt_ego_rot=b["ego_rot"], gt_points=b["roi_points"],
@@ -156,6 +161,18 @@ def test_fp16_training_through_the_reference_loop_with_gradscaler():
             scaler.scale(losses).backward()
             bad = [n for n, p in model.named_parameters() if not torch.isfinite(p.grad).all()]
             bad_names.update(bad)
+            if bad:  # every non-finite parameter gradient comes from an fp16 OVERFLOW of a stored activation gradient: a handful of
+                # elements of a buffer whose finite maximum sits at the fp16 limit (everything downstream of it is then NaN by BatchNorm)
+                eng_ = model.train_engine(4, dev)
+                sites = []
+                for k_, v_ in eng_.bufs.items():
+                    if k_.startswith("d:") and v_.dtype == torch.float16:
+                        f_ = v_.float()
+                        nf_ = int((~torch.isfinite(f_)).sum().item())
+                        if 0 < nf_ < 1e-3 * f_.numel() and f_[torch.isfinite(f_)].abs().max().item() > 0.5 * 65504:
+                            sites.append(k_)
+                assert sites, (it, bad[:4])
+                overflow_sites.update(sites)
             before = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).clone()
             scaler.step(opt)
             scaler.update()
@@ -169,16 +186,16 @@ def test_fp16_training_through_the_reference_loop_with_gradscaler():
         assert eng.amp and eng.lp == "fp16" and eng.bufs["act:head3"].dtype == torch.float16
         n16 = sum(v.dtype == torch.float16 for k, v in eng.bufs.items() if k.startswith("d:"))
         assert n16 > 40 and not any(v.dtype == torch.bfloat16 for v in eng.bufs.values())  # activation gradients stored in fp16
-        return hist, scales, skipped, bad_names
+        return hist, scales, skipped, bad_names, overflow_sites
 
-    hist, scales, skipped, bad_names = loop(65536.0, 12)
+    hist, scales, skipped, bad_names, sites = loop(65536.0, 12)
     print("fp16 AMP + GradScaler from 65536: total loss", [round(h, 4) for h in hist], "scale", scales, "skipped", [int(s) for s in skipped],
-          "non-finite gradients only in", sorted(bad_names))
-    assert np.isfinite(hist).all() and bad_names <= {"backbone.conv1.weight"}
+          "overflowing activation-gradient buffers", sorted(sites), "-", len(bad_names), "parameter gradients non-finite at some step")
+    assert np.isfinite(hist).all() and "backbone.conv1.weight" in bad_names and "d:stem" in sites
     assert min(scales) >= 4096.0 and sum(skipped) <= 4 and skipped[:2] == [True, True]  # 65536 and 32768 always overflow d:stem
     taken = [h for h, s in zip(hist, skipped) if not s]
     assert len(taken) >= 8 and min(taken[-3:]) < taken[0]
-    hist2, scales2, skipped2, _ = loop(8192.0, 6)
+    hist2, scales2, skipped2, _, _ = loop(8192.0, 6)
     print("fp16 AMP + GradScaler from 8192: total loss", [round(h, 4) for h in hist2], "skipped", [int(s) for s in skipped2])
     assert not any(skipped2) and set(scales2) == {8192.0} and min(hist2[-3:]) < hist2[0]
 

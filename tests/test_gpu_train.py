@@ -496,6 +496,94 @@ def test_conv_epilogue_writes_the_batchnorm_backward_sums(t, case):
     assert outs[1][2].float().abs().max().item() > 1e-3
 
 
+@pytest.mark.parametrize("t", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", [
+    (8, 64, 64, 64, 3),      # 128 x 64 (layer1: the next block's conv1)
+    (16, 32, 128, 128, 3),   # layer2
+    (64, 16, 256, 256, 3),   # the ping-pong kernel
+    (8, 16, 256, 256, 1),    # 1x1 (a Bottleneck's conv1)
+    (16, 64, 256, 256, 3),   # 256 x 256 eight-phase kernel: no such epilogue, rows == 0 and a normal convolution
+    (3, 9, 64, 64, 3),       # ragged tiles: rows == 0
+])
+def test_conv_epilogue_writes_a_residual_blocks_batchnorm_backward_sums(t, case):
+    """rdpn6d_conv2d_*_bnbwd_y + rdpn6d_bn_backward_apply_*: the input-gradient convolution of the NEXT block's first layer writes the
+    gradient w.r.t. a residual block's output (its own residual input added in the epilogue) - bit for bit what the plain launch stores -
+    and the backward sums of that block's last BatchNorm with the mask read from the stored block output; dgamma / dbeta / dx / dres
+    then equal rdpn6d_bn_backward_*(relu = 1)'s (summation order differs: 2e-6 of the largest sum; dx one rounding apart at most, dres
+    bit-identical)."""
+    import ctypes
+    from rdpn6d_amd import _lib
+    from rdpn6d_amd.gdrn import _pad_to, _ptr, pack_conv_weight
+
+    lib, dev = _lib.load(), torch.device("cuda:0")
+    dt = torch.bfloat16 if t == "bf16" else torch.float16
+    B, H, Cin, Cout, k = case
+    g = torch.Generator().manual_seed(sum(case) + 23)
+    gin = (torch.randn(B, H, H, Cin, generator=g) / 8).to(dev).to(dt)
+    w = (torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).to(dev)
+    wp = pack_conv_weight(w, cin_pad=_pad_to(Cin, 32)).to(dt)
+    pad = k // 2
+    M = B * H * H
+    xbn = torch.randn(M, Cout, generator=g).to(dev).to(dt)       # the BatchNorm's input
+    ident = torch.randn(M, Cout, generator=g).to(dev).to(dt)     # the block's identity branch
+    res_g = (torch.randn(M, Cout, generator=g) / 4).to(dev).to(dt)  # the residual input of the convolution (the next block's identity gradient)
+    gamma = (torch.rand(Cout, generator=g) + 0.5).to(dev)
+    gamma[::5] *= -1.0
+    beta = (0.3 * torch.randn(Cout, generator=g)).to(dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    mean, istd, rm, rv = (torch.zeros(Cout, device=dev) for _ in range(4))
+    scr = torch.empty(512 * 1024 * 2 + 4096, dtype=torch.float64, device=dev)
+    _lib.check(getattr(lib, f"rdpn6d_bn_train_stats_{t}")(_ptr(xbn), M, Cout, Cout, 0, 1e-5, 0.1, _ptr(mean), _ptr(istd), _ptr(rm), _ptr(rv), _ptr(scr), st))
+    yblk = torch.empty_like(xbn)                                  # y = relu(bn(x) + identity), as stored
+    _lib.check(getattr(lib, f"rdpn6d_bn_apply_{t}")(_ptr(xbn), Cout, 0, _ptr(mean), _ptr(istd), _ptr(gamma), _ptr(beta), _ptr(ident), Cout, 0,
+                                                    _ptr(yblk), Cout, 0, M, Cout, 1, st))
+    d = _lib.ConvDesc()
+    d.B, d.H, d.W, d.Cin, d.in_cs, d.in_co = B, H, H, Cin, Cin, 0
+    d.Ho, d.Wo, d.stride = H, H, 1
+    taps = [(ky - pad, kx - pad) for ky in range(k) for kx in range(k)]
+    d.ntaps = len(taps)
+    for i, (dy_, dx_) in enumerate(taps):
+        d.dy[i], d.dx[i] = dy_, dx_
+    d.N, d.Npad, d.OH, d.OW = Cout, wp.shape[0], H, H
+    d.osy = d.osx = 1
+    d.out_cs = Cout
+    d.res, d.res_cs, d.res_co = _ptr(res_g), Cout, 0
+    y0, y1 = torch.empty(M, Cout, device=dev, dtype=dt), torch.empty(M, Cout, device=dev, dtype=dt)
+    d.x, d.w, d.y = _ptr(gin), _ptr(wp), _ptr(y0)
+    _lib.check(getattr(lib, f"rdpn6d_conv2d_{t}")(ctypes.byref(d), 0, st))
+    d.y = _ptr(y1)
+    part = torch.full((((M + 63) // 64) * 2 * Cout * 2 + 8,), float("nan"), dtype=torch.float64, device=dev)
+    rows = ctypes.c_int(-1)
+    _lib.check(getattr(lib, f"rdpn6d_conv2d_{t}_bnbwd_y")(ctypes.byref(d), _ptr(xbn), Cout, 0, _ptr(yblk), Cout, 0, _ptr(mean), _ptr(istd),
+                                                         _ptr(part), ctypes.byref(rows), st))
+    torch.cuda.synchronize()
+    assert torch.equal(y0, y1) and (y0.float() - res_g.float()).abs().max().item() > 1e-3
+    if M % 64 or case[:2] == (16, 64):
+        assert rows.value == 0
+        return
+    assert 0 < rows.value <= ((M + 63) // 64) * 2
+    assert torch.isfinite(part[: rows.value * Cout * 2]).all() and torch.isnan(part[rows.value * Cout * 2:]).all()
+    outs = []
+    for fused in (True, False):
+        dg, db = torch.full((Cout,), 3.0, device=dev), torch.full((Cout,), 3.0, device=dev)
+        dx, dres = torch.empty_like(xbn), torch.empty_like(xbn)
+        if fused:
+            _lib.check(getattr(lib, f"rdpn6d_bn_backward_apply_{t}")(_ptr(xbn), Cout, 0, _ptr(y0), Cout, 0, _ptr(yblk), Cout, 0, _ptr(mean), _ptr(istd),
+                                                                     _ptr(gamma), _ptr(dg), _ptr(db), _ptr(dx), Cout, 0, _ptr(dres), Cout, 0, M, Cout,
+                                                                     _ptr(part), rows.value, st))
+        else:
+            _lib.check(getattr(lib, f"rdpn6d_bn_backward_{t}")(_ptr(xbn), Cout, 0, _ptr(y0), Cout, 0, _ptr(yblk), Cout, 0, _ptr(mean), _ptr(istd),
+                                                               _ptr(gamma), _ptr(dg), _ptr(db), _ptr(dx), Cout, 0, _ptr(dres), Cout, 0, M, Cout, 1,
+                                                               _ptr(scr), st))
+        torch.cuda.synchronize()
+        outs.append((dg.clone(), db.clone(), dx.clone(), dres.clone()))
+    for a, b, n in zip(outs[0], outs[1], ("dgamma", "dbeta")):
+        assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item(), (n, (a - b).abs().max().item(), b.abs().max().item())
+    ulp = 2.0 ** -8 if t == "bf16" else 2.0 ** -11
+    assert (outs[0][2].float() - outs[1][2].float()).abs().max().item() <= ulp * outs[1][2].float().abs().max().item()
+    assert torch.equal(outs[0][3], outs[1][3]) and (outs[0][3] == 0).float().mean().item() > 0.2 and outs[1][2].float().abs().max().item() > 1e-3
+
+
 @pytest.mark.parametrize("case", [
     # Bn, Ha, Hb, stride, Ca, Cb, k
     (2, 16, 16, 1, 128, 128, 3),
