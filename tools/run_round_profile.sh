@@ -24,7 +24,8 @@ cd $R; f=$(ls $O/prof/*/*kernel_stats.csv | head -1); cp $f $O/kernel_stats.csv;
 python3 tools/conv_stack_fraction.py $O/kernel_stats.csv > $O/conv_stack_fraction.txt; tail -1 $O/conv_stack_fraction.txt
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/proft -- python3 $R/bench.py --train --dtype bf16 --no-cpu-baseline --steps 10 --warmup 2 > /dev/null 2>&1
-cd $R; f=$(ls $O/proft/*/*kernel_stats.csv | head -1); cp $f $O/train_bf16_kernel_stats.csv; rm -rf $O/proft
+cd $R; f=$(ls $O/proft/*/*kernel_stats.csv | head -1); cp $f $O/train_bf16_kernel_stats.csv
+f=$(ls $O/proft/*/*kernel_trace.csv | head -1); python3 tools/train_trace_summary.py $f 1 120 > $O/train_bf16_per_launch.txt; rm -rf $O/proft
 bash tools/pmc_bench.sh $TAG > $O/pmc.log 2>&1; cp gpurun_out/pmc_$TAG/summary.json $O/pmc_summary.json; cp gpurun_out/pmc_$TAG/summary.md $O/pmc_summary.md; rm -rf gpurun_out/pmc_$TAG/raw_*
 for f in bench_mul bench_c4_ycbv_mul bench_x3 bench_fp32mfma bench_bf16 bench_fp16 bench_train_bf16 bench_train_fp16 bench_train_f32 bench_train_c5_fp16 bench_sustained; do python3 -c "
 import json; d=json.load(open('$O/$f.json')); print('$f', d['value'], d['ms_per_step'], d.get('ms_per_step_trace', {}).get('drift_last_vs_first'))"; done
