@@ -484,7 +484,8 @@ int rdpn6d_pose_train_sym_f32(const float* rt, int rt_stride, const float* roi_c
 int rdpn6d_train_vis_scalars_f32(const float* rot, const float* trans, const float* gt_rot, const float* gt_trans, const float* rt,
                                  int rt_stride, const float* gt_trans_ratio, int B, float* out17, void* stream);
 /* Fused multi-tensor Ranger step over flat buffers (replaces lib/torch_utils/solver/ranger.py:100-200).
- * work = array of {int64 off; int32 len; int32 row} runs (row = index of the centralisation mean, -1 = none);
+ * work = array of {int64 off; int32 len; int32 row} runs (row = index of the centralisation mean, -1 = none; row >= 0x40000000: the run IS
+ * a whole centralisation row and the update kernel takes its mean itself - no entry in row_off / row_len for it);
  * row_off/row_len describe the rows whose gradient mean is subtracted (gradient centralisation);
  * neg_step_lr = -step_size*lr and rectified = (N_sma > threshold) are computed on the host from the step count. */
 int rdpn6d_ranger_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* slow, const void* work,

@@ -174,6 +174,13 @@ template <typename T, int V> __device__ __forceinline__ void rd_ldv(const T* p, 
     }
 }
 
+// streaming form of rd_ldv<T, 8>: the line is not kept in the caches (an operand that is not read again before it has left them anyway)
+template <typename T> __device__ __forceinline__ void rd_ldv8_nt(const T* p, float (&v)[8])
+{
+    static_assert(sizeof(T) == 2, "16-bit tensors");
+    rd_unpack8(__builtin_nontemporal_load(reinterpret_cast<const rd_u32x4*>(p)), v);
+}
+
 template <typename T, int V> __device__ __forceinline__ void rd_stv(T* p, const float (&v)[V])
 {
     if constexpr (V == 4) rd_st4<T>(p, f32x4{v[0], v[1], v[2], v[3]});

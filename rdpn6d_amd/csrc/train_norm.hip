@@ -10,6 +10,9 @@
 #include "common.h"
 #include <float.h>
 #include <cstdlib>
+// BatchNorm backward-apply reads x and dy for the last time in the step: streaming (non-temporal) loads, -0.03 ms per bf16 step at B = 32
+// (round 5; RDPN6D_BN_NT=0: plain loads)
+static bool bn_nt_loads() { static const int v = getenv("RDPN6D_BN_NT") ? atoi(getenv("RDPN6D_BN_NT")) : 1; return v != 0; }
 
 #define NS_MAX 512  // row splits of the partial reductions (the scratch contract: 512 * C * 2 doubles).  128 left a 131 072 x 256 tensor on 256
                     // workgroups of 4 waves, sixteen dependent load rounds each: latency-bound at a third of the HBM rate
@@ -448,7 +451,7 @@ extern "C" int rdpn6d_bn_apply_bf16(const void* x, int xcs, int xco, const float
 // tensor read less in the reduction pass and in the apply pass (the head's seven 67-MB activations and the stem's, at B = 32).
 //   dgamma = sum g*xhat, dbeta = sum g
 //   dx = gamma*invstd * (g - dbeta/M - xhat*dgamma/M);   dres (optional) = g  (identity branch of a residual block)
-template <typename T, int V>
+template <typename T, int V, bool NT = false>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ x, int xcs, int xco, const T* __restrict__ dy, int dcs, int dco,
                                     const T* __restrict__ y, int ycs, int yco, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
@@ -463,8 +466,13 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ x, int xcs, int xco, c
         const int c = (int)(i % CV) * V;
         const long long m = i / CV;
         float xv[V], g[V], o[V];
-        rd_ldv<T, V>(x + m * xcs + xco + c, xv);
-        rd_ldv<T, V>(dy + m * dcs + dco + c, g);
+        if constexpr (NT) {
+            rd_ldv8_nt<T>(x + m * xcs + xco + c, xv);
+            rd_ldv8_nt<T>(dy + m * dcs + dco + c, g);
+        } else {
+            rd_ldv<T, V>(x + m * xcs + xco + c, xv);
+            rd_ldv<T, V>(dy + m * dcs + dco + c, g);
+        }
         if (relu == 1) {
             float yv[V];
             rd_ldv<T, V>(y + m * ycs + yco + c, yv);
@@ -508,6 +516,10 @@ static int bn_backward_impl(const T* x, int xcs, int xco, const T* dy, int dcs, 
             (relu != 1 || (ycs % 8 == 0 && yco % 8 == 0)) && (!dres || (rcs % 8 == 0 && rco % 8 == 0))) {
             const long long total8 = M * (C / 8);
             const int blocks8 = (int)((total8 + 255) / 256 < 16384 ? (total8 + 255) / 256 : 16384);
+            if (bn_nt_loads())
+                hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 8, true>), dim3(blocks8), dim3(256), 0, s, x, xcs, xco, dy, dcs, dco, y, ycs, yco, mean,
+                                   invstd, gamma, beta, dgamma, dbeta, dx, xgcs, xgco, dres, rcs, rco, M, C, relu);
+            else
             hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 8>), dim3(blocks8), dim3(256), 0, s, x, xcs, xco, dy, dcs, dco, y, ycs, yco, mean,
                                invstd, gamma, beta, dgamma, dbeta, dx, xgcs, xgco, dres, rcs, rco, M, C, relu);
             RD_LAUNCH_CHECK();
@@ -573,6 +585,10 @@ static int bn_relu_backward_apply_impl(const T* x, int xcs, int xco, const T* dy
         if (C % 8 == 0 && xcs % 8 == 0 && xco % 8 == 0 && dcs % 8 == 0 && dco % 8 == 0 && xgcs % 8 == 0 && xgco % 8 == 0) {
             const long long total8 = M * (C / 8);
             const int blocks8 = (int)((total8 + 255) / 256 < 16384 ? (total8 + 255) / 256 : 16384);
+            if (bn_nt_loads())
+                hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 8, true>), dim3(blocks8), dim3(256), 0, s, x, xcs, xco, dy, dcs, dco, (const T*)nullptr, 0, 0,
+                                   mean, invstd, gamma, beta, dgamma, dbeta, dx, xgcs, xgco, (T*)nullptr, 0, 0, M, C, 2);
+            else
             hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 8>), dim3(blocks8), dim3(256), 0, s, x, xcs, xco, dy, dcs, dco, (const T*)nullptr, 0, 0,
                                mean, invstd, gamma, beta, dgamma, dbeta, dx, xgcs, xgco, (T*)nullptr, 0, 0, M, C, 2);
             RD_LAUNCH_CHECK();
@@ -613,6 +629,10 @@ extern "C" int rdpn6d_bn_backward_apply_bf16(const void* x, int xcs, int xco, co
     RD_LAUNCH_CHECK();
     const long long total8 = M * (C / 8);
     const int blocks8 = (int)((total8 + 255) / 256 < 16384 ? (total8 + 255) / 256 : 16384);
+    if (bn_nt_loads())
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 8, true>), dim3(blocks8), dim3(256), 0, s, (const T*)x, xcs, xco, (const T*)dy, dcs, dco, (const T*)y,
+                           ycs, yco, mean, invstd, gamma, (const float*)nullptr, dgamma, dbeta, (T*)dx, xgcs, xgco, (T*)dres, rcs, rco, M, C, 1);
+    else
     hipLaunchKernelGGL((bn_bwd_apply_kernel<T, 8>), dim3(blocks8), dim3(256), 0, s, (const T*)x, xcs, xco, (const T*)dy, dcs, dco, (const T*)y, ycs,
                        yco, mean, invstd, gamma, (const float*)nullptr, dgamma, dbeta, (T*)dx, xgcs, xgco, (T*)dres, rcs, rco, M, C, 1);
     RD_LAUNCH_CHECK();

@@ -21,6 +21,7 @@ from torch.optim.optimizer import Optimizer
 from . import _lib
 
 _CHUNK = 4096  # elements per work item (one 256-thread workgroup)
+_ROW_HERE = 0x40000000  # RangerWork.row: the item is a whole gradient-centralisation row (csrc/ranger.hip)
 
 
 class Ranger(Optimizer):
@@ -115,6 +116,9 @@ class Ranger(Optimizer):
                 if self.use_gc and p.dim() > self.gc_min_dim:
                     rl = k // p.shape[0]
                     for r in range(p.shape[0]):
+                        if rl <= 2 * _CHUNK:  # the whole row is one work item: the update kernel takes the row mean itself
+                            work.append((o + r * rl, rl, _ROW_HERE))
+                            continue
                         ridx = len(row_off)
                         row_off.append(o + r * rl)
                         row_len.append(rl)

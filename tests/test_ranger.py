@@ -127,3 +127,20 @@ def test_hip_ranger_step_under_a_loss_scale(gold):
         for a, p in zip(plain[step], ps):
             assert np.array_equal(a, p.detach().cpu().numpy()), step
     _check([[p.detach().cpu().numpy() for p in ps]], {f"s0_p{i}": gold[f"s13_p{i}"] for i in range(len(ps))}, 3e-6)
+
+
+@pytest.mark.gpu
+def test_hip_ranger_row_means_inside_the_update_kernel(monkeypatch):
+    """Gradient centralisation (ranger.py:146-148): a work item that IS a whole row takes the row mean inside the update kernel, with
+    gc_row_mean_kernel's own summation; longer rows keep the separate pass.  Same bits either way: the trajectory with every row split
+    (work items of 1 024 elements, so the 5 000-element rows go through the separate kernel) equals the default's."""
+    import rdpn6d_amd.ranger as rg
+
+    traj, opt, _ = _run(rg.Ranger, "cuda:0")
+    assert opt._nrows == 0  # every centralised row of the fixture is one work item
+    monkeypatch.setattr(rg, "_CHUNK", 1024)
+    traj2, opt2, _ = _run(rg.Ranger, "cuda:0")
+    assert opt2._nrows == 9  # the (9, 5000) tensor's rows
+    for a, b in zip(traj, traj2):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
