@@ -593,6 +593,8 @@ def test_conv_epilogue_writes_a_residual_blocks_batchnorm_backward_sums(t, case)
     (5, 7, 7, 1, 36, 68, 3),       # ragged everything (channels multiples of 4 only)
     (8, 64, 64, 1, 256, 96, 3),    # >= 32 768 pixels, 256 gradient channels: the 256 x 128 tile (ragged Cb)
     (8, 64, 128, 2, 512, 128, 1),  # the same tile, two A tiles, stride 2
+    (8, 64, 64, 1, 256, 256, 3),   # a head layer's shape (256 x 128 tile, two B tiles per tap)
+    (9, 64, 64, 1, 256, 512, 1),   # four B tiles, a pixel count that is no multiple of the split
 ])
 def test_wgrad_bf16_vs_fp32_kernel(case):
     """bf16 weight-gradient kernel (transpose LDS reads) vs the fp32 kernel on the same bf16-valued operands: products are exact
