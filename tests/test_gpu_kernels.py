@@ -1208,3 +1208,37 @@ def test_conv_bf16x3_error_bound_under_cancellation(dev):
     print(f"cancellation test: |err| / (2^-24 sum|a||b|): bf16x3 {r3:.3f}  fp32-MFMA {r1:.3f};  |y|max {y64.abs().max().item():.3e} vs sum|a||b| max {bound.max().item() * 2 ** 24:.3e}")
     assert r3 <= 1.25 * r1 and r3 <= 48.0 and r1 <= 48.0
     assert y64.abs().max().item() < 1e-2 * bound.max().item() * 2 ** 24  # the case really cancels (>= 100x)
+
+
+def test_transpose_and_gradient_finite_check(dev):
+    """Two small round-5 entry points on their own.  rdpn6d_transpose_rc_f32: y[b][c][r] = x[b][r][c] for sizes that are and are not
+    multiples of the 32 x 32 tile (the training step uses it for the ConvPnPNet map in fc1's NCHW-flatten order, conv_pnp_net.py:151).
+    rdpn6d_grad_nonfinite_f32: flag = 1 exactly when one element - at EVERY position of a 16-byte vector, and in the scalar tail - is
+    +Inf, -Inf or NaN; large finite values and denormals leave it 0; a set flag is cleared by the next clean call."""
+    from rdpn6d_amd import _lib
+    from rdpn6d_amd.gdrn import _ptr
+
+    lib = _lib.load()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator().manual_seed(17)
+    for B, R, C in ((32, 64, 128), (3, 33, 70), (1, 1, 5), (2, 100, 1)):
+        x = torch.randn(B, R, C, generator=g).to(dev)
+        y = torch.full((B, C, R), 7.0, device=dev)
+        _lib.check(lib.rdpn6d_transpose_rc_f32(_ptr(x), B, R, C, _ptr(y), st))
+        assert torch.equal(y, x.transpose(1, 2).contiguous()), (B, R, C)
+    flag = torch.full((1,), 5, dtype=torch.int32, device=dev)
+    for n in (4096, 4099, 7, 1 << 20):
+        base = torch.randn(n, generator=g).to(dev)
+        base[0], base[n // 2] = 3.0e38, 1e-42  # finite extremes
+        _lib.check(lib.rdpn6d_grad_nonfinite_f32(_ptr(base), n, _ptr(flag), st))
+        assert int(flag.item()) == 0, n
+        for pos in sorted({0, 1, 2, 3, n // 2 + 1, n - 1, n - 2, n - 3}):
+            if not 0 <= pos < n:
+                continue
+            for bad in (float("inf"), float("-inf"), float("nan")):
+                t = base.clone()
+                t[pos] = bad
+                _lib.check(lib.rdpn6d_grad_nonfinite_f32(_ptr(t), n, _ptr(flag), st))
+                assert int(flag.item()) == 1, (n, pos, bad)
+        _lib.check(lib.rdpn6d_grad_nonfinite_f32(_ptr(base), n, _ptr(flag), st))
+        assert int(flag.item()) == 0, n
