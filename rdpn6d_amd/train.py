@@ -540,9 +540,11 @@ class TrainEngine:
                     drun = dlaunch("dgrad " + name, dd, wd)
                     rec = self._bn_by_dy.get(dx.data_ptr())
                     # (a residual block's last BatchNorm - rec["y"] - takes the gradient w.r.t. the block output: only the launch that
-                    #  completes it, residual added, may carry its sums)
+                    #  completes it, residual added, may carry its sums - and only a launch with work to hide the two extra tensor reads
+                    #  behind: a Bottleneck's 1x1 conv1 is HBM-bound, its fused epilogue cost 117 us against 57 + the separate pass's 47,
+                    #  C5 shape, round 5)
                     if (rec is not None and rec["producer"] is None and getattr(drun, "bn_capable", False)
-                            and (dx_res is None if rec["y"] is None else dx_final)
+                            and (dx_res is None if rec["y"] is None else (dx_final and n_red * kk2 >= 576))
                             and rec["dy_cs"] == dx_cs and rec["dy_co"] == in_co and rec["C"] == cin_real
                             and rec["M"] == B * xhw[0] * xhw[1]):
                         drun.bn_bwd, rec["producer"] = rec, drun
