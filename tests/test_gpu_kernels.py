@@ -1242,3 +1242,27 @@ def test_transpose_and_gradient_finite_check(dev):
                 assert int(flag.item()) == 1, (n, pos, bad)
         _lib.check(lib.rdpn6d_grad_nonfinite_f32(_ptr(base), n, _ptr(flag), st))
         assert int(flag.item()) == 0, n
+
+
+@pytest.mark.parametrize("t", ["f32", "bf16", "fp16"])
+@pytest.mark.parametrize("case", [(2, 8, 512, 4), (3, 5, 64, 2), (1, 10, 2048, 4), (2, 4, 36, 4)])
+def test_upsample_bilinear_backward_vs_autograd(dev, t, case):
+    """rdpn6d_upsample_bilinear_backward_*: the gradient of nn.UpsamplingBilinear2d(scale_factor) (align_corners=True,
+    resnet_backbone.py:280) against autograd on the same stored gradient - the vector form (channel counts that are a multiple of 4 / 8)
+    and the scalar one (36 channels in 16 bits)."""
+    from rdpn6d_amd import _lib
+    from rdpn6d_amd.gdrn import _ptr
+
+    lib = _lib.load()
+    B, H, C, f = case
+    dt = {"f32": torch.float32, "bf16": torch.bfloat16, "fp16": torch.float16}[t]
+    g = torch.Generator().manual_seed(sum(case))
+    dy = torch.randn(B, H * f, H * f, C, generator=g).to(dev).to(dt)
+    dx = torch.full((B, H, H, C), 9.0, device=dev, dtype=dt)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(getattr(lib, f"rdpn6d_upsample_bilinear_backward_{t}")(_ptr(dy), B, H, H, C, f, _ptr(dx), st))
+    x = torch.zeros(B, C, H, H, dtype=torch.float64, requires_grad=True)
+    F.interpolate(x, scale_factor=f, mode="bilinear", align_corners=True).backward(dy.double().cpu().permute(0, 3, 1, 2))
+    ref = x.grad.permute(0, 2, 3, 1)
+    err = (dx.double().cpu() - ref).abs().max().item() / ref.abs().max().item()
+    assert err <= (2e-6 if t == "f32" else 2.0 ** -8 if t == "bf16" else 2.0 ** -10), err
