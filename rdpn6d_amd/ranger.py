@@ -218,6 +218,8 @@ class Ranger(Optimizer):
     def found_inf(self):
         """True when the last step(skip_if_nonfinite=True) found a NaN / Inf gradient and left parameters and state untouched (one host
         read; the step counter has advanced all the same - rewound here, as a skipped GradScaler step does not count)."""
+        if getattr(self, "_found_inf", None) is None:  # no step(skip_if_nonfinite=True) yet
+            return False
         bad = bool(int(self._found_inf.item()))
         if bad:
             self._step -= 1
