@@ -187,6 +187,7 @@ class Ranger(Optimizer):
             if getattr(self, "_found_inf", None) is None:
                 self._found_inf = torch.zeros(1, dtype=torch.int32, device=F["g"].device)
             _lib.check(lib.rdpn6d_grad_nonfinite_f32(P(F["g"]), F["g"].numel(), P(self._found_inf), st), "grad_nonfinite")
+            self._found_inf_pending, self._found_inf_last = True, False
         for gi, g in enumerate(self.param_groups):
             if self._nwork[gi] == 0:
                 continue
@@ -220,11 +221,14 @@ class Ranger(Optimizer):
         read; the step counter has advanced all the same - rewound here, as a skipped GradScaler step does not count)."""
         if getattr(self, "_found_inf", None) is None:  # no step(skip_if_nonfinite=True) yet
             return False
+        if not getattr(self, "_found_inf_pending", False):  # asked again about the same step: the answer it gave (no second rewind)
+            return self._found_inf_last
         bad = bool(int(self._found_inf.item()))
         if bad:
             self._step -= 1
             for p in self._params:
                 self.state[p]["step"] = self._step
+        self._found_inf_pending, self._found_inf_last = False, bad
         return bad
 
     def load_state_dict(self, state_dict):
