@@ -12,10 +12,13 @@ point-wise depth fusion -> dense mask/residual/region head -> glue -> ConvPnPNet
 runs its own batch ("weak" scaling); value = all ranks' crops / max-over-ranks time.
 
 Prints ONE JSON line (rank 0) with the driver's contract plus
-  "roofline"     - the dominant kernel (the conv kernel instance that carries most of the step's FLOPs: the fp32-accurate
-                   bf16x3 kernel by default, conv_igemm_f32_kernel<128,128> with --no-x3, the 8-phase bf16 kernel with
+  "roofline"     - the dominant kernel (the conv kernel instance that carries most of the step's FLOPs: by default the fp32-accurate
+                   h2 eight-phase kernel conv_h2_8ph_kernel_t<false> - two fp16 planes per operand, three partial products; the
+                   bf16x3 kernel with --fast x3, conv_igemm_f32_kernel<128,128> with --fast none, the 8-phase 16-bit kernel with
                    --dtype bf16) timed live with events on the launch stream: algorithmic FLOPs of its launches / their
-                   total duration vs its MFMA ceiling (416.7 = 2500/6, 157.3, 2500 TFLOP/s; MI355X_MICROARCH.md);
+                   total duration vs its MFMA ceiling (833.3 = 2500/3, 416.7 = 2500/6, 157.3, 2500 TFLOP/s; MI355X_MICROARCH.md);
+  "train"        - (default run only) a short bf16 B=32 training leg after the timed region: ms_per_step, crops_per_s, tflops,
+                   frac_of_2500, the dominant kernel, and where each gradient bucket's all-reduce was issued (--train-leg 0 = off);
   "cpu_baseline" - the torch-CPU oracle (a port of the reference path, pinned to it by golden vectors)
                    timed on this box's host cores on a bounded sample of the same workload.
 """
@@ -301,26 +304,29 @@ def train_roofline(eng, one_step, reps=3):
             "share_of_step_flops": round(sum(flops) / reps / (132.3e9 * eng.B), 3)}
 
 
-def train_bench(args, rank, world, device, dist):
-    """Training throughput (SURVEY.md C3 shape in fp32: 32 crops per GPU, data parallel, gradient all-reduce over RCCL).
-    Not the headline metric; printed as its own JSON line."""
+def train_leg(rank, world, device, dist, dtype="bf16", B=32, backbone=34, res=256, steps=100, warmup=3, preheat=3.0, buckets="stages",
+              comm_dtype=None):
+    """The training step (fwd + nine losses + bwd + per-stage gradient all-reduce + fused Ranger + weight re-pack) timed like the
+    headline: W warm-up steps, `preheat` seconds of un-timed steps, barrier, EXACTLY `steps` steps, barrier, max over ranks.  Every rank
+    runs the same number of steps (the steps carry the all-reduces).  Returns the figures as a dict (rank 0's view); `--train` prints
+    them as its own line, the default run attaches them to the headline line as "train"."""
     from rdpn6d_amd import synth
-    from rdpn6d_amd.parallel import GradBuckets
+    from rdpn6d_amd.parallel import GROUPS, STAGES, GradBuckets, stage_params
     from rdpn6d_amd.ranger import Ranger
 
-    B = args.batch if args.batch != 64 else 32
-    model, _ = build_model(device, "mul", backbone=args.backbone, res=args.res)
+    model, _ = build_model(device, "mul", backbone=backbone, res=res)
     model.cfg.TEST.USE_PNP = False
-    amp = args.dtype in ("bf16", "fp16")
+    amp = dtype in ("bf16", "fp16")
     model.cfg.SOLVER.AMP.ENABLED = amp  # --dtype bf16 | fp16: mixed precision (16-bit fwd/dgrad/wgrad convolutions, fp32 everything else)
-    model.cfg.SOLVER.AMP.DTYPE = args.dtype if amp else "bf16"
+    model.cfg.SOLVER.AMP.DTYPE = dtype if amp else "bf16"
     eng = model.train_engine(B, device)
-    if args.dtype == "fp16":
+    if dtype == "fp16":
         eng.loss_scale = 4096.0  # static loss scale (the reference: GradScaler, engine.py:302-309)
-    buckets = GradBuckets(model, always_reduce=bool(os.environ.get("RDPN6D_BENCH_FORCE_DIST")))
-    order = [p for g in ("pnp_net", "rot_head_net", "backbone") for p in getattr(model, g).parameters()]
-    opt = Ranger(order, lr=1e-4, flat_grad=buckets.flat)  # fused HIP step over the same flat gradient buffer
-    inp = synth.make_inputs(B, seed=200 + rank, res=args.res)
+    gb = GradBuckets(model, groups=STAGES if buckets == "stages" else GROUPS, always_reduce=bool(os.environ.get("RDPN6D_BENCH_FORCE_DIST")),
+                     comm_dtype={None: None, "f32": None, "bf16": torch.bfloat16}[comm_dtype], timing=True)
+    order = [p for g in STAGES for p in stage_params(model, g)]
+    opt = Ranger(order, lr=1e-4, flat_grad=gb.flat)  # fused HIP step over the same flat gradient buffer
+    inp = synth.make_inputs(B, seed=200 + rank, res=res)
     batch = {k: torch.from_numpy(v).to(device) for k, v in {**inp, **synth.make_train_gt(B, inp)}.items()}
 
     skipped = [0]
@@ -329,13 +335,14 @@ def train_bench(args, rank, world, device, dist):
         losses = eng.forward_losses(batch)
         if eng.loss_scale != 1.0:
             eng.seed_backward({n: eng.loss_scale for n in eng.LOSS_NAMES})
-        eng.backward(on_group_done=buckets.reduce)
-        buckets.finish()
-        if eng.loss_scale != 1.0:
+        eng.backward(on_group_done=gb.reduce)
+        gb.finish()
+        if dtype == "fp16":
             # fp16: GradScaler's rule (engine.py:302-309) - a step whose reduced gradients are not finite is SKIPPED and the scale halved
             # (one host read per step, as scaler.step() has); un-skipped, one overflow of an fp16 activation gradient poisons the weights.
             # The un-scaling and the finite check ride in the optimizer's own launches (Ranger.step): one 144-MB read instead of
-            # torch's isfinite().all() + mul_() (nine launches, 227 us of a 10.6-ms step)
+            # torch's isfinite().all() + mul_() (nine launches, 227 us of a 10.6-ms step).  Keyed on the dtype, not on the scale: a
+            # scale that has halved its way down to 1 still needs the guard
             opt.step(grad_scale=eng.loss_scale, skip_if_nonfinite=True)
             if opt.found_inf():
                 skipped[0] += 1
@@ -351,7 +358,7 @@ def train_bench(args, rank, world, device, dist):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         one_step()
     torch.cuda.synchronize()
     # pre-heat: every step carries the gradient all-reduces, so all ranks must run the SAME number of steps - rank 0's clock decides
@@ -360,7 +367,7 @@ def train_bench(args, rank, world, device, dist):
     tp = time.perf_counter()
     go = torch.ones(1, dtype=torch.int32, device=device if dist is None or dist.get_backend() == "nccl" else "cpu")
     while True:
-        go[0] = int(time.perf_counter() - tp < args.preheat)
+        go[0] = int(time.perf_counter() - tp < preheat)
         if dist is not None:
             dist.broadcast(go, src=0)
         if not int(go.item()):
@@ -370,7 +377,7 @@ def train_bench(args, rank, world, device, dist):
         torch.cuda.synchronize()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         losses = one_step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
@@ -379,32 +386,52 @@ def train_bench(args, rank, world, device, dist):
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
+    sync = gb.report()  # (events of the LAST timed step: where each stage's all-reduce was issued relative to the backward's end)
     # the event-timed steps carry the gradient all-reduces too: EVERY rank runs them (rank 0 alone would leave the others' collective
-    # sequence three all-reduces short - a hang); only rank 0's figures are reported
+    # sequence short - a hang); only rank 0's figures are reported
     roof = train_roofline(eng, one_step) if amp else None
     if dist is not None:
         dist.barrier()
+    value = world * B * steps / elapsed
+    std = (backbone, res) == (34, 256)
+    out = {
+        "ms_per_step": round(elapsed / steps * 1e3, 3), "crops_per_s": round(value, 1), "steps": steps, "warmup": warmup, "preheat_s": preheat,
+        "batch_per_gpu": B, "global_batch": B * world, "n_gpus": world,
+        "dtype": f"{dtype} convolutions (fwd + dgrad + wgrad) and stored activations, fp32 BN math / losses / pose branch / optimizer" if amp else "f32",
+        "workload": ("LM-O style" if std else "MP6D style (BASELINE C5 shape)")
+                    + f" training step, MASK_ATTENTION=mul, K=32, ResNet-{backbone}, {res}x{res} crops, per-GPU BatchNorm, "
+                    + ("SOLVER.AMP.ENABLED" if amp else "fp32"),
+        "parallelism": f"dp{world}: flat gradient buffer, {len(gb.groups)} RCCL all-reduces (one per stage of the backward, issued as the "
+                       f"stage's gradients complete), fused HIP Ranger",
+        "gflop_per_crop": {"fwd+dgrad+wgrad": 132.3} if std else None,
+        "tflops": round(132.3e9 * value / 1e12, 2) if std else None,
+        "frac_of_2500": round(132.3e9 * value / world / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4) if (amp and std) else None,
+        "dominant_kernel": roof, "gradient_sync": sync,
+        "allreduce_exposed_ms": None if sync is None else sync["allreduce_exposed_ms"],
+        "loss_scale_final": eng.loss_scale if dtype == "fp16" else None, "steps_skipped_for_overflow": skipped[0] if dtype == "fp16" else None,
+        "loss_total": round(float(sum(v.item() for v in losses.values())), 4)}
+    return out
+
+
+def train_bench(args, rank, world, device, dist):
+    """`--train`: the training step as its own JSON line (SURVEY.md C3 shape: 32 crops per GPU, data parallel, gradient all-reduce over
+    RCCL).  Not the headline metric."""
+    B = args.batch if args.batch != 64 else 32
+    t = train_leg(rank, world, device, dist, dtype=args.dtype, B=B, backbone=args.backbone, res=args.res, steps=args.steps, warmup=args.warmup,
+                  preheat=args.preheat, buckets=args.buckets, comm_dtype=args.allreduce_dtype)
     if rank == 0:
-        value = world * B * args.steps / elapsed
         print(json.dumps({
-            "metric": f"RGB-D crops/sec, TRAINING step (fwd+losses+bwd+allreduce+Ranger) at {args.res}x{args.res}", "value": round(value, 1),
+            "metric": f"RGB-D crops/sec, TRAINING step (fwd+losses+bwd+allreduce+Ranger) at {args.res}x{args.res}", "value": t["crops_per_s"],
             "unit": "crops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": t["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "world": world, "backend": dist.get_backend() if dist is not None else None, "device_count": torch.cuda.device_count(),
-            "dtype": f"{args.dtype} convolutions (fwd + dgrad + wgrad) and stored activations, fp32 BN math / losses / pose branch / optimizer" if amp else "f32",
-            "data": "synthetic",
-            "config": {"workload": ("LM-O style" if (args.backbone, args.res) == (34, 256) else "MP6D style (BASELINE C5 shape)")
-                                   + f" training step, MASK_ATTENTION=mul, K=32, ResNet-{args.backbone}, {args.res}x{args.res} crops, per-GPU BatchNorm, "
-                                   + ("SOLVER.AMP.ENABLED" if amp else "fp32"),
-                       "batch_per_gpu": B, "global_batch": B * world,
-                       "parallelism": f"dp{world}: flat gradient buffer, 3 bucketed RCCL all-reduces overlapped with backward, fused HIP Ranger"},
-            "achieved_tflops_whole_step": round(132.3e9 * value / 1e12, 2) if (args.backbone, args.res) == (34, 256) else None,
-            "whole_step_frac_of_16bit_mfma_peak": (round(132.3e9 * value / world / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4)
-                                                   if (amp and (args.backbone, args.res) == (34, 256)) else None),
-            "gflop_per_crop": {"fwd+dgrad+wgrad": 132.3} if (args.backbone, args.res) == (34, 256) else None,
-            "preheat_s": args.preheat, "roofline": roof,
-            "loss_scale_final": eng.loss_scale if args.dtype == "fp16" else None, "steps_skipped_for_overflow": skipped[0] if args.dtype == "fp16" else None,
-            "loss_total": round(float(sum(v.item() for v in losses.values())), 4)}))
+            "dtype": t["dtype"], "data": "synthetic",
+            "config": {"workload": t["workload"], "batch_per_gpu": B, "global_batch": B * world, "parallelism": t["parallelism"]},
+            "achieved_tflops_whole_step": t["tflops"], "whole_step_frac_of_16bit_mfma_peak": t["frac_of_2500"],
+            "gflop_per_crop": t["gflop_per_crop"], "preheat_s": args.preheat, "roofline": t["dominant_kernel"],
+            "gradient_sync": t["gradient_sync"], "allreduce_exposed_ms": t["allreduce_exposed_ms"],
+            "loss_scale_final": t["loss_scale_final"], "steps_skipped_for_overflow": t["steps_skipped_for_overflow"],
+            "loss_total": t["loss_total"]}))
     if dist is not None:
         dist.destroy_process_group()
 
@@ -445,6 +472,14 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "fp16"],
                     help="f32 (default, the parity-bearing headline) | bf16: secondary line, cfg.TEST.AMP_TEST mode "
                          "(trunk + fusion + head on the bf16 matrix pipe, fp32 head output / ConvPnPNet / pose / RANSAC)")
+    ap.add_argument("--train-leg", type=float, default=1.5, metavar="SECONDS",
+                    help="default (inference) run: after the timed region, a short bf16 B=32 training leg - SECONDS of pre-heat + 60 timed "
+                         "steps - reported under \"train\" in the same JSON line (not part of `value`); 0 = off")
+    ap.add_argument("--buckets", default="stages", choices=["stages", "coarse"],
+                    help="training: gradient all-reduce buckets - one per stage of the backward (pnp_net, rot_head_net, layer4, layer3, rest: "
+                         "default) | coarse = the three sub-modules (round 5's form: the backbone's 86 MB go out after the backward has ended)")
+    ap.add_argument("--allreduce-dtype", default="f32", choices=["f32", "bf16"],
+                    help="training: transport dtype of the gradient all-reduce (cfg.SOLVER.ALLREDUCE_DTYPE; bf16 = 72.8 instead of 145.6 MB)")
     ap.add_argument("--train", action="store_true",
                     help="secondary line: training step (fwd + losses + bwd + bucketed RCCL all-reduce + Ranger), B=32/GPU; "
                          "fp32, or mixed precision (cfg.SOLVER.AMP.ENABLED) with --dtype bf16")
@@ -559,8 +594,15 @@ def main():
     if rank == 0:
         with torch.no_grad():
             roof = roofline(model, t, B, device)
-        if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(sd)
+    if dist is not None:
+        dist.barrier()
+    train = None
+    if args.train_leg > 0 and args.dtype == "f32" and B == 64 and not args.graph:
+        # the driver's one command also puts the TRAINING step on record: BASELINE C3's per-GPU shape - bf16 AMP,
+        # 32 crops per GPU, fwd + losses + bwd + per-stage all-reduce + Ranger - after the headline's timed region, never part of `value`
+        train = train_leg(rank, world, device, dist, dtype="bf16", B=32, steps=60, warmup=3, preheat=args.train_leg)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(sd)
     if dist is not None:
         dist.barrier()
     if rank == 0:
@@ -603,6 +645,8 @@ def main():
                                          "drift_last_vs_first": round(blk[-1] / blk[0], 4), "timed_seconds": round(elapsed, 2)}
         if dtype_note:
             line["dtype_note"] = dtype_note
+        if train is not None:
+            line["train"] = train
         if cpu is not None:
             line["cpu_baseline"] = cpu
         print(json.dumps(line))

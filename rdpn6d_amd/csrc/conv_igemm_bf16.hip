@@ -432,7 +432,12 @@ extern "C" int rdpn6d_conv2d_bf16_bnbwd_y(const rdpn6d_conv_desc* d, const void*
     RD_REQUIRE(bn_x && bn_y && mean && invstd && partial && rows, "null pointer");
     RD_REQUIRE(bn_cs % 8 == 0 && bn_co % 8 == 0 && d && bn_co + d->N <= bn_cs, "BatchNorm input slice: 16-byte aligned, N channels");
     RD_REQUIRE(y_cs % 8 == 0 && y_co % 8 == 0 && y_co + d->N <= y_cs, "block output slice: 16-byte aligned, N channels");
-    RD_REQUIRE(d->osy == 1 && d->osx == 1 && d->ooy == 0 && d->oox == 0 && d->OH == d->Ho && d->OW == d->Wo, "linear output geometry");
+    if (!(d->osy == 1 && d->osx == 1 && d->ooy == 0 && d->oox == 0 && d->OH == d->Ho && d->OW == d->Wo)) {
+        // strided / phased output (an input-gradient phase of a stride-2 convolution): the epilogue's row bookkeeping does not apply -
+        // as promised above, the plain convolution runs and *rows == 0 tells the caller to take the sums in a separate pass
+        *rows = 0;
+        return conv2d_bf16_impl(d, 0, 1, nullptr, stream, nullptr, 0, nullptr, nullptr);
+    }
     ConvBnBwd b = {bn_x, bn_cs, bn_co, mean, invstd, nullptr, nullptr};
     b.y = bn_y;
     b.ycs = y_cs;

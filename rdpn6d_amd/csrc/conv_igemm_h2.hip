@@ -1174,6 +1174,11 @@ extern "C" int rdpn6d_conv2d_h2_colmax(const rdpn6d_conv_desc* d, unsigned long 
     RD_REQUIRE(d && keys, "null pointer");
     RD_REQUIRE(rdpn6d_conv_h2_colmax_ok(d, rows_per_group), "column-max form: 256x256 kernel, rows_per_group % 256 == 0, linear output, no activation / residual");
     RD_REQUIRE(d->y == nullptr, "the column-max form does not write the activation (desc.y must be null)");
+    // atomicMax never decreases: the table must be zero when the launch starts.  The decode kernel re-zeroes it, but a forward that
+    // stopped between the two launches (an error, a partially replayed launch list) would leave stale maxima for the next one - so the
+    // table is cleared HERE, on the launch stream, whatever happened before (B * Npad * 8 bytes: 256 KiB at B = 64)
+    const long long groups = (long long)d->B * d->Ho * d->Wo / rows_per_group;
+    RD_CHECK_HIP(hipMemsetAsync(keys, 0, (size_t)groups * d->Npad * sizeof(unsigned long long), (hipStream_t)stream));
     const H2Fuse f = {nullptr, nullptr, nullptr, reinterpret_cast<float*>(keys), rows_per_group, 0};
     return conv2d_h2_impl(d, nullptr, nullptr, overflow_flag, nullptr, nullptr, 0, &f, stream);
 }

@@ -1685,11 +1685,11 @@ class GDRN(_TreeWatch, nn.Module):
 
 
 class _HipBackward(torch.autograd.Function):
-    """Glue between ``losses.backward()`` (engine.py:308) and the HIP backward pass.  One node per parameter group, chained in the
-    order the backward completes them (parallel.GROUPS: pnp_net -> rot_head_net -> backbone):
+    """Glue between ``losses.backward()`` (engine.py:308) and the HIP backward pass.  One node per gradient stage, chained in the
+    order the backward completes them (parallel.STAGES: pnp_net -> rot_head_net -> backbone.layer4 -> backbone.layer3 -> backbone.rest):
 
-        token_bb = stage(backbone params)            token_hd = stage(token_bb, rot_head params)
-        nine losses = stage(token_hd, losses, pnp_net params)
+        token_rest = stage(backbone.rest params)     token_l3 = stage(token_rest, layer3 params)     token_l4 = stage(token_l3, layer4 params)
+        token_hd = stage(token_l4, rot_head params)  nine losses = stage(token_hd, losses, pnp_net params)
 
     The group's trainable PARAMETERS are inputs of its node and the node's backward returns their gradients, so every parameter's
     AccumulateGrad runs - which is what torch DDP (and Lightning-Lite's ``_LiteModule`` around it: main_gdrn.py:113, engine.py:308)
@@ -1738,11 +1738,11 @@ class _HipBackward(torch.autograd.Function):
 
 
 def _attach_hip_backward(model, eng, losses):
-    """the nine loss tensors, hanging off the chained _HipBackward nodes (one per parameter group with trainable parameters)"""
-    from .parallel import GROUPS
+    """the nine loss tensors, hanging off the chained _HipBackward nodes (one per gradient stage with trainable parameters)"""
+    from .parallel import STAGES, stage_params
 
     names = list(losses)
-    groups = [(g, [p for p in getattr(model, g).parameters() if p.requires_grad]) for g in GROUPS]
+    groups = [(g, stage_params(model, g)) for g in STAGES]
     groups = [(g, ps) for g, ps in groups if ps]
     if not groups:
         raise RuntimeError("rdpn6d_amd.GDRN: do_loss=True with every parameter frozen - nothing to differentiate")

@@ -284,9 +284,10 @@ def groupnorm_relu_(x, groups, gamma, beta):
     return x
 
 
-def farthest_point_sampling(pts, sn, init_center=False, start=None):
-    """Host-array face of the fps ABI (mirrors core/csrc/fps/fps_utils.py:6-21): returns pts[idxs] (sn,3) f32.
-    ``start`` pins the random variant's start index (extra to the reference)."""
+def farthest_point_sampling(pts, sn, init_center=False, start=None, return_index=False):
+    """Host-array face of the fps ABI (core/csrc/fps/fps_utils.py:6-21): returns pts[idxs] (sn,3) f32, exactly what the reference's
+    function returns (get_fps_and_center, core/utils/data_utils.py:217-226, concatenates it with the centroid row).  Extras, both off by
+    default: ``start`` pins the random variant's start index, ``return_index=True`` returns (pts[idxs], idxs) for the parity tests."""
     pts = np.ascontiguousarray(pts, np.float32)
     pn, three = pts.shape
     assert three == 3
@@ -301,7 +302,7 @@ def farthest_point_sampling(pts, sn, init_center=False, start=None):
         lib.farthest_point_sampling(pts.ctypes.data_as(P), idxs.ctypes.data_as(P), pn, sn)
         if (idxs < 0).any():
             raise RuntimeError("farthest_point_sampling failed: " + lib.rdpn6d_last_error().decode())
-    return pts[idxs], idxs
+    return (pts[idxs], idxs) if return_index else pts[idxs]
 
 
 def ransac_kabsch(out_nchw, coord2d, fps, extents, resize_ratios, region_argmax, mask_thr=0.5, inlier_thr=0.01,

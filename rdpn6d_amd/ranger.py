@@ -162,7 +162,8 @@ class Ranger(Optimizer):
         """grad_scale / skip_if_nonfinite (round 5): the step under a loss scale as the reference runs it (GradScaler.unscale_ +
         GradScaler.step, engine.py:302-309) without the separate passes - every gradient is read as grad / grad_scale (the buffer
         keeps the scaled values), and with skip_if_nonfinite one pass sets a device flag for NaN / Inf anywhere in the flat gradient
-        and the update kernels skip the whole step on it; found_inf() reads the flag (the one host read GradScaler.step has)."""
+        and the update kernels skip the whole step on it; found_inf() reads the flag (the one host read GradScaler.step has).  A guarded
+        step whose flag nobody read is resolved at the start of the next step(), whatever its kind: a skipped step never counts."""
         if self._flat is None:
             self._build()
         F = self._flat
@@ -173,6 +174,8 @@ class Ranger(Optimizer):
             if p.grad.data_ptr() != F["g"].data_ptr() + o:
                 F["g"][o // 4:o // 4 + p.numel()].copy_(p.grad.reshape(-1))
                 p.grad = F["g"][o // 4:o // 4 + p.numel()].view_as(p)
+        if getattr(self, "_found_inf_pending", False):
+            self.found_inf()  # the previous guarded step was never asked about: resolve it now, so a skipped step is rewound exactly once
         self._step += 1
         step = self._step
         from .gdrn import bump_weights_epoch

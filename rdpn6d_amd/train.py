@@ -119,7 +119,9 @@ class TrainEngine:
         # only make the big kernels share the chip.  Kept as a switch; RDPN6D_WGRAD_SIDE=1 forces it on for profiling runs.
         self.wgrad_side = (bool(model.cfg.get("SOLVER", {}).get("WGRAD_SIDE_STREAM", False)) or os.environ.get("RDPN6D_WGRAD_SIDE", "0") == "1")
         self._side, self._side_join, self._side_dirty, self._wg_partial_side = None, None, False, None
+        self._bwd_writes, self._side_reads = {}, []  # (build-time bookkeeping of _check_side_operands)
         self._build()
+        self._check_side_operands()
         for grp in self._wgrad_group_list:
             _, _, _, ca, _, _, _, cb, _, yhw, _, _, k, _, _ = grp["geom"]
             if len(grp["members"]) > 1:
@@ -383,6 +385,7 @@ class TrainEngine:
         w = P.weight
         cout, _, k, _ = w.shape
         pad = k // 2
+        self._note_bwd_write(dx)
         lowp = self.amp and not name.startswith("pnp_net")  # ConvPnPNet stays fp32 (pose regression)
         x3_fwd, xp3, g3 = False, None, None  # bf16x3 forward taken; planes of x / of the output gradient
         cin_pad = _pad_to(cin_real, 32 if lowp else 16)
@@ -500,13 +503,14 @@ class TrainEngine:
             if grp is None or len(grp["members"]) >= 16:
                 grp = self._wgrad_groups[geom] = dict(members=[], geom=geom, tdy=tdy, tdx=tdx)
                 self._wgrad_group_list.append(grp)  # (a stage with more than 16 same-shaped convolutions - ResNet-101 / 152 - has several)
-                launches.append(self._side_launch(lambda grp=grp: self._run_wgrad_group(grp), lambda grp=grp: [t[3] for t in grp["members"]]))
+                launches.append(self._side_launch(lambda grp=grp: self._run_wgrad_group(grp), lambda grp=grp: [t[3] for t in grp["members"]],
+                                                  reads=lambda grp=grp: [t for m_ in grp["members"] for t in m_[1:3]]))
             grp["members"].append((name, dyb, xb, w))
             grouped = True
         if not grouped:
             # (operands read in place from this layer's own buffers, gradient scattered straight into the parameter's: safe on the side stream)
             side_ok = lowp and inv_perm is None and bias is None and dyb is dy and xb is x
-            launches.append(self._side_launch(wgrad, [w]) if side_ok else wgrad)
+            launches.append(self._side_launch(wgrad, [w], reads=[dy, x]) if side_ok else wgrad)
         if dx is not None:
             n_red = _pad_to(cout, 32 if lowp else 16)  # reduction channels of the dgrad = output channels of the forward
             cdx = _pad_to(cin_real, 64)
@@ -573,13 +577,32 @@ class TrainEngine:
         self.bwd.append(launches)
         return dy
 
-    def _side_launch(self, fn, params):
+    def _note_bwd_write(self, *tensors):
+        """(build time) the backward launches of the unit being registered - list index len(self.bwd) - write these buffers"""
+        for t in tensors:
+            if t is not None:
+                self._bwd_writes.setdefault(t.data_ptr(), []).append(len(self.bwd))
+
+    def _check_side_operands(self):
+        """cfg.SOLVER.WGRAD_SIDE_STREAM: a side-stream weight gradient reads its layer's output gradient and input activation while the
+        main stream goes on with the backward - safe only if no LATER backward launch (= a unit registered EARLIER: lower list index)
+        writes those buffers.  Checked here for every side launch against every buffer a unit declared as its dx / dres, instead of
+        trusting the buffer naming; a violation is a build error, not a timing-dependent wrong gradient."""
+        for idx, reads in self._side_reads:
+            for t in (reads() if callable(reads) else reads):
+                later = [j for j in self._bwd_writes.get(t.data_ptr(), []) if j < idx]
+                if later:
+                    raise RuntimeError(f"WGRAD_SIDE_STREAM: an operand of the side-stream weight gradient at backward list {idx} is written "
+                                       f"again by list(s) {later}, which run after it on the main stream")
+
+    def _side_launch(self, fn, params, reads=()):
         """`fn` (a weight-gradient launch closure writing the gradients of `params`) on the engine's side stream: the side stream waits for an event recorded on the
         current stream at the closure's place in the launch list (its operands - this layer's output gradient and input activation -
         are complete there and are not written again before the step ends), uses its own split-K scratch, and is joined by
         _join_side() before a parameter group's gradients are handed on."""
         if not self.wgrad_side:
             return fn
+        self._side_reads.append((len(self.bwd), reads))
         ev = [None]
 
         def run():
@@ -633,6 +656,7 @@ class TrainEngine:
         unless given) and writes dx (same layout as x_raw) and optionally dres (the ReLU-masked gradient, which is
         the gradient of the residual branch)."""
         lib = self.lib
+        self._note_bwd_write(dx, dres)
         mean, invstd = self.buf("mean:" + name, _pad_to(C, 4)), self.buf("istd:" + name, _pad_to(C, 4))
         ga, be = bn.weight, bn.bias  # read in place (C % 4 == 0); pointers are taken at launch time
 
@@ -773,7 +797,9 @@ class TrainEngine:
         self.bwd.append([lambda: _lib.check(f_pool_b(_ptr(a0), _ptr(d_p0), B, R2, R2, 64, _ptr(d_a0), self.st()), "maxpool bwd")])
         # ---- residual trunk
         cur, d_cur, hw, c = p0, d_p0, R4, 64
+        stage_first = {}  # first launch list of a ResNet stage = the LAST one its backward runs (the stage's grouped weight gradient included)
         for li in range(4):
+            stage_first[li + 1] = len(self.bwd)
             for bi, blk in enumerate(getattr(bb, f"layer{li + 1}")):
                 nm = f"layer{li + 1}.{bi}"
                 if hasattr(blk, "conv3"):  # Bottleneck: 1x1 - 3x3(s) - 1x1(x4)
@@ -871,7 +897,10 @@ class TrainEngine:
         self.fwd.append(lambda: _lib.check(f_gm(_ptr(feat), B, R8 * R8, 512, 1024, self.st()), "gmax"))
         self.bwd.append([lambda: _lib.check(f_gm_b(_ptr(feat), _ptr(d_feat), B, R8 * R8, 512, 1024, _ptr(d_l3), self.st()), "gmax bwd")])
         # ---- dense head: ConvTranspose as 4 phase convs (forward), stride-2 conv (dgrad), gathered wgrad
-        self._group_marks = {0: "backbone", len(self.bwd): "rot_head_net"}  # bwd index where a group's gradients are complete
+        # bwd index after which a stage's parameter gradients are complete (parallel.STAGES, the order the backward finishes them):
+        # layer4 / layer3 as soon as their own launches are through - their all-reduces then overlap the rest of the trunk's backward
+        self._group_marks = {0: "backbone.rest", stage_first[3]: "backbone.layer3", stage_first[4]: "backbone.layer4",
+                             len(self.bwd): "rot_head_net"}
         F = head.features[0].weight.shape[1]
         Mh = B * R4 * R4
         rt0, at0 = self.buf("raw:head0", B, R4, R4, F), self.buf("act:head0", B, R4, R4, F)
@@ -953,6 +982,11 @@ class TrainEngine:
             a_prev = a_i
         last = head.features[nfeat - 1]
         nout = last.weight.shape[0]
+        MC = 2 if self.mask_type == 2 else 1
+        if nout != MC + 4 + K:  # (head_cs is padded: the C-side width check would pass a head one mask channel off, and the glue / loss /
+            #                      backward kernels would then read xyz and region one channel plane off, silently - same rule as InferencePlan)
+            raise ValueError(f"the head's output convolution has {nout} channels; ROT_HEAD.MASK_LOSS_TYPE={self.model.cfg.MODEL.CDPN.ROT_HEAD.MASK_LOSS_TYPE!r} "
+                             f"with NUM_REGIONS={K} needs {MC} + 3 + {K + 1} (GDRN.py:637-659): build the model with the config it is run with")
         self.head_cs = _pad_to(nout, 16)
         ho = self.buf("act:head_out", B, R4 * R4, self.head_cs, zero=True)
         self.head_out = ho
@@ -1197,9 +1231,10 @@ class TrainEngine:
         return flat_grad_storage(grads), grads
 
     def backward_stages(self, unscale=1.0):
-        """The backward of sum(seed_i * loss_i) into param.grad as a GENERATOR: yields 'pnp_net', 'rot_head_net', 'backbone' - each
-        right after the launches that complete that group's parameter gradients (the order the backward finishes them).  backward()
-        drives it for the bucket hooks of parallel.GradBuckets; gdrn._HipBackward drives it from three chained autograd nodes, so
+        """The backward of sum(seed_i * loss_i) into param.grad as a GENERATOR: yields the names of parallel.STAGES ('pnp_net',
+        'rot_head_net', 'backbone.layer4', 'backbone.layer3', 'backbone.rest') - each right after the launches that complete that
+        stage's parameter gradients (the order the backward finishes them).  backward()
+        drives it for the bucket hooks of parallel.GradBuckets; gdrn._HipBackward drives it from five chained autograd nodes, so
         that under torch DDP the AccumulateGrad hooks of a group - and with them DDP's bucket all-reduces - fire while the rest
         of the backward is still being issued.  Must be run to exhaustion."""
         if self._consumed:
@@ -1247,8 +1282,8 @@ class TrainEngine:
                         torch._foreach_add_([p.grad for p in ps], [prev[id(p)] for p in ps])
 
     def backward(self, on_group_done=None, unscale=1.0):
-        """Backward of sum(seed_i * loss_i) into param.grad.  on_group_done(name) is called after the gradients of
-        'pnp_net', 'rot_head_net' and 'backbone' are complete (gradient-bucket all-reduce hook).
+        """Backward of sum(seed_i * loss_i) into param.grad.  on_group_done(name) is called after the gradients of each stage of
+        parallel.STAGES are complete (gradient-bucket all-reduce hook: parallel.GradBuckets.reduce).
         The kernels WRITE param.grad (split-K reduces, BatchNorm / bias sums store, they do not add): that equals autograd's
         accumulate after the zero_grad the reference loop issues before every backward (engine.py:304-308).  For gradient
         accumulation over micro-batches - not part of the reference loop - set `accumulate_grad = True`: the gradients already

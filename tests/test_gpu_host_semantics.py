@@ -86,6 +86,41 @@ def test_eval_after_training_steps_uses_the_new_weights():
     assert abs((o4["region"] - o2["region"]).mean().item() - 1.0) < 1e-4
 
 
+@pytest.mark.parametrize("amp", [False, "bf16"])
+def test_backward_stages_yield_final_gradients_in_completion_order(amp):
+    """the backbone's gradient bucket is split per ResNet stage.  TrainEngine.backward_stages() must yield
+    parallel.STAGES in order - pnp_net -> rot_head_net -> backbone.layer4 -> backbone.layer3 -> backbone.rest - and at each yield the
+    stage's parameter gradients must be FINAL: a snapshot taken there (what an all-reduce issued there would read) equals the
+    gradient after the whole backward, bit for bit.  Under AMP the stage's grouped weight gradient (rdpn6d_wgrad_bf16_group) is one
+    of the launches that must have run by then."""
+    from rdpn6d_amd.parallel import STAGES, stage_params
+
+    dev = torch.device("cuda:0")
+    model, _ = _model()
+    if amp:
+        model.cfg.SOLVER.AMP.ENABLED, model.cfg.SOLVER.AMP.DTYPE = True, amp
+    eng = model.train_engine(2, dev)
+    b = _batch(2, 4, dev)
+    for p in model.parameters():
+        p.grad = torch.full_like(p, float("nan"))  # the backward WRITES every gradient: nothing of this may survive
+    eng.forward_losses(b)
+    eng.seed_backward({n: 1.0 for n in eng.LOSS_NAMES})
+    seen, snaps = [], {}
+    for st in eng.backward_stages():
+        torch.cuda.synchronize()
+        seen.append(st)
+        snaps[st] = [p.grad.clone() for p in stage_params(model, st)]
+    torch.cuda.synchronize()
+    assert seen == list(STAGES)
+    for st in STAGES:
+        ps = stage_params(model, st)
+        assert len(ps) == len(snaps[st]) > 0
+        for p, g in zip(ps, snaps[st]):
+            assert torch.isfinite(g).all(), st
+            assert torch.equal(p.grad, g), f"a gradient of stage {st} was still written after the stage was handed on"
+    assert sum(len(v) for v in snaps.values()) == len(list(model.parameters()))
+
+
 def test_ranger_and_gradbuckets_share_one_buffer_in_any_order():
     """the factory's optimizer orders its groups backbone | rot_head | pnp_net, GradBuckets lays the gradients out
     pnp_net | rot_head_net | backbone; zero_grad(set_to_none=True) runs before the first step as in engine.py:304.  The
@@ -124,8 +159,11 @@ def test_ranger_and_gradbuckets_share_one_buffer_in_any_order():
     opt.step()
     buckets = GradBuckets(model, optimizer=opt)
     assert buckets.flat.data_ptr() == opt._flat["g"].data_ptr()
-    for g, (lo, hi) in buckets.slices.items():
-        assert hi - lo == sum(p.numel() for p in getattr(model, g).parameters())
+    from rdpn6d_amd.parallel import STAGES, stage_params
+
+    assert tuple(buckets.slices) == STAGES
+    for g, (lo, hi) in buckets.slices.items():  # every stage is one contiguous slice of the buffer the optimizer laid out
+        assert hi - lo == sum(p.numel() for p in stage_params(model, g))
     # a caller that drops the gradients (nn.Module.zero_grad defaults to set_to_none=True) is re-homed before the reduce
     ld = _train_losses(model, b)
     model.zero_grad(set_to_none=True)
@@ -289,7 +327,7 @@ def _dp_worker(rank, world, port, q, backend="gloo"):
                 torch.cuda.synchronize()
                 got = torch.cat([p.grad.detach().reshape(-1).cpu() for p in model.parameters()])
                 err = ((got - mean).abs().max() / mean.abs().max()).item()
-                if fired != ["pnp_net", "rot_head_net", "backbone"]:
+                if fired != ["pnp_net", "rot_head_net", "backbone.layer4", "backbone.layer3", "backbone.rest"] or buckets.last_issue_order != fired:
                     ok, msg = False, f"bucket order {fired}"
                 if err > 1e-6:
                     ok, msg = False, f"reduced gradient differs from the rank mean: {err:.2e}"
@@ -386,8 +424,10 @@ def _ddp_worker(rank, world, port, q, backend="gloo", bucket_view=False):
         # (2) the wrapped run
         model, opt = _model()
         fired = []
-        for g in ("pnp_net", "rot_head_net", "backbone"):
-            next(getattr(model, g).parameters()).register_post_accumulate_grad_hook(lambda p, g=g: fired.append(g))
+        from rdpn6d_amd.parallel import STAGES, stage_params
+
+        for g in STAGES:
+            stage_params(model, g)[0].register_post_accumulate_grad_hook(lambda p, g=g: fired.append(g))
         ddp = DDP(model, device_ids=[0], gradient_as_bucket_view=bucket_view)
         ok, msg = True, ""
         for it in range(3):
@@ -406,7 +446,7 @@ def _ddp_worker(rank, world, port, q, backend="gloo", bucket_view=False):
                 err = ((got - mean).abs().max() / mean.abs().max()).item()
                 if err > 1e-6:
                     ok, msg = False, f"DDP-reduced gradient differs from the rank mean: {err:.2e}"
-                if fired != ["pnp_net", "rot_head_net", "backbone"]:
+                if fired != list(STAGES):
                     ok, msg = False, f"AccumulateGrad hooks fired in the order {fired}"
                 if not bucket_view:  # the gradients never left Ranger's-to-be flat layout: still one tensor per parameter, written once
                     if any(p.grad is None for p in model.parameters()):

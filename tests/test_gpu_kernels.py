@@ -154,9 +154,9 @@ def test_fps_bit_exact(dev, oracle_lib, golden_dir):
     for name, kind, n, sn, seed, mode in fps_cases():
         pts = make_cloud(kind, n, seed)
         if mode == "center":
-            _, idx = ops.farthest_point_sampling(pts, sn, init_center=True)
+            _, idx = ops.farthest_point_sampling(pts, sn, init_center=True, return_index=True)
         else:
-            _, idx = ops.farthest_point_sampling(pts, sn, start=int(mode))
+            _, idx = ops.farthest_point_sampling(pts, sn, start=int(mode), return_index=True)
         assert np.array_equal(idx, gold[name]), f"{name}: {idx[:8]} vs {gold[name][:8]}"
 
 
@@ -222,6 +222,21 @@ def test_fps_reference_symbols(dev, oracle_lib):
     lib.farthest_point_sampling(pts.ctypes.data_as(P), idx.ctypes.data_as(P), 3000, 16)  # random start
     oracle_lib.oracle_fps_from_start(pts.ctypes.data_as(P), want.ctypes.data_as(P), 3000, 16, int(idx[0]))
     assert np.array_equal(idx, want)
+
+
+def test_get_fps_and_center_body_on_the_hip_face(dev, oracle_lib):
+    """the body of get_fps_and_center (core/utils/data_utils.py:217-226) on ops.farthest_point_sampling: the face returns pts[idxs]
+    alone, like core/csrc/fps/fps_utils.py:21."""
+    from rdpn6d_amd import ops
+    from tests.fps_cases import make_cloud
+
+    pts = make_cloud("gauss", 3000, 21).astype(np.float64)
+    fps_pts = ops.farthest_point_sampling(pts, 8, init_center=True)
+    res_pts = np.concatenate([fps_pts, np.array([[np.average(pts[:, 0]), np.average(pts[:, 1]), np.average(pts[:, 2])]])], axis=0)
+    p32 = np.ascontiguousarray(pts, np.float32)
+    want = np.zeros(8, dtype=np.int32)
+    oracle_lib.oracle_fps_init_center(p32.ctypes.data_as(ctypes.c_void_p), want.ctypes.data_as(ctypes.c_void_p), 3000, 8)
+    assert res_pts.shape == (9, 3) and np.array_equal(res_pts[:8].astype(np.float32), p32[want])
 
 
 # ----------------------------------------------------------------------------- whole path vs golden

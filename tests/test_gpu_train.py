@@ -1220,7 +1220,7 @@ def test_training_step_is_deterministic(B, amp):
 
 @pytest.mark.parametrize("B,amp", [(32, "bf16"), (8, "fp16")])
 def test_weight_gradients_on_the_side_stream_change_nothing(B, amp):
-    """cfg.SOLVER.WGRAD_SIDE_STREAM (round 5, default on): the weight-gradient launches whose operands are read in place run on a second
+    """cfg.SOLVER.WGRAD_SIDE_STREAM (round 5, default OFF - measured no faster): the weight-gradient launches whose operands are read in place run on a second
     HIP stream, ordered by events (their operands complete before, the parameter group's gradients joined before they are handed on).
     Same kernels, same reductions: losses and all 164 gradients are BIT-IDENTICAL to the one-stream step, over three steps with the
     optimizer in between (a missed dependency would show as a stale or torn gradient) - and the side stream is really used."""

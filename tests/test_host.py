@@ -329,3 +329,41 @@ def test_bench_gpus_flag_is_checked_before_anything_touches_a_gpu():
         env.pop("WORLD_SIZE")
         r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"], env=env, cwd=root, capture_output=True, text=True, timeout=300)
         assert r.returncode != 0 and "no CPU fallback" in r.stderr
+
+
+def test_fps_python_face_returns_what_the_reference_returns(oracle_lib, monkeypatch):
+    """`ops.farthest_point_sampling` is the body of core/csrc/fps/fps_utils.py:6-21: it returns pts[idxs] ALONE, so that the body of
+    get_fps_and_center (core/utils/data_utils.py:217-226: concatenate with the centroid row) runs on it unchanged.  On this GPU-less
+    box the C ABI behind the face is stood in for by the C oracle (the checker; the product library needs a GPU and is exercised by
+    tests/test_gpu_kernels.py::test_get_fps_and_center_body_on_the_hip_face)."""
+    import ctypes
+    from types import SimpleNamespace
+
+    import numpy as np
+
+    from rdpn6d_amd import _lib, ops
+    from tests.fps_cases import make_cloud
+
+    def fps_host(pts, idx, pn, sn, start):
+        if start < 0:
+            oracle_lib.oracle_fps_init_center(pts, idx, pn, sn)
+        else:
+            oracle_lib.oracle_fps_from_start(pts, idx, pn, sn, start)
+        return 0
+
+    monkeypatch.setattr(_lib, "load", lambda: SimpleNamespace(rdpn6d_fps_host=fps_host, rdpn6d_last_error=lambda: b""))
+    pts = make_cloud("gauss", 3000, 21).astype(np.float64)  # the loaders hand float64 model points over
+    num_fps = 8
+    # -- body of get_fps_and_center, with the package's function where the reference imports its own
+    avgx, avgy, avgz = np.average(pts[:, 0]), np.average(pts[:, 1]), np.average(pts[:, 2])
+    fps_pts = ops.farthest_point_sampling(pts, num_fps, init_center=True)
+    res_pts = np.concatenate([fps_pts, np.array([[avgx, avgy, avgz]])], axis=0)
+    # --
+    assert isinstance(fps_pts, np.ndarray) and fps_pts.shape == (num_fps, 3) and fps_pts.dtype == np.float32
+    assert res_pts.shape == (num_fps + 1, 3)
+    want = np.zeros(num_fps, np.int32)
+    p32 = np.ascontiguousarray(pts, np.float32)
+    oracle_lib.oracle_fps_init_center(p32.ctypes.data_as(ctypes.c_void_p), want.ctypes.data_as(ctypes.c_void_p), 3000, num_fps)
+    assert np.array_equal(fps_pts, p32[want])
+    both = ops.farthest_point_sampling(pts, num_fps, init_center=True, return_index=True)
+    assert isinstance(both, tuple) and np.array_equal(both[1], want) and np.array_equal(both[0], fps_pts)

@@ -22,32 +22,106 @@ def test_shard_range_matches_inference_sampler():
                 assert all(e - b <= shard for b, e in got)
 
 
+class _ToyTrunk(nn.Module):
+    """the sub-module names (and registration order) of gdrn's backbone holder: spatial_net first, then the stem, then the stages"""
+
+    def __init__(self):
+        super().__init__()
+        self.spatial_net = nn.Linear(3, 2)
+        self.conv1 = nn.Linear(5, 7)
+        self.bn1 = nn.BatchNorm1d(7)
+        self.layer1 = nn.Linear(2, 2, bias=False)
+        self.layer2 = nn.Linear(4, 3)
+        self.layer3 = nn.Linear(3, 6)
+        self.layer4 = nn.Linear(6, 9)
+
+
 class _Toy(nn.Module):
     def __init__(self):
         super().__init__()
-        self.backbone = nn.Linear(5, 7)
+        self.backbone = _ToyTrunk()
         self.rot_head_net = nn.Conv2d(2, 3, 3)
         self.pnp_net = nn.Linear(4, 2, bias=False)
 
 
+def _fill(m, stage, rank, salt=0.0):
+    from rdpn6d_amd.parallel import stage_params
+
+    for i, p in enumerate(stage_params(m, stage)):
+        p.grad.copy_(torch.arange(p.numel(), dtype=torch.float32).view_as(p) * (0.37 + rank) + (i + 1) * 1.1 ** rank + salt)
+
+
 def _worker(rank, world, port, q):
+    from rdpn6d_amd.parallel import GROUPS, STAGES
+
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.manual_seed(0)
     m = _Toy()
-    gb = GradBuckets(m)
+    gb = GradBuckets(m)  # one bucket per stage
     assert gb.flat.numel() == sum(p.numel() for p in m.parameters())
-    order = []
-    for g in ("pnp_net", "rot_head_net", "backbone"):  # the backward completes groups in this order
-        for p in getattr(m, g).parameters():
+    assert gb.groups == STAGES == ("pnp_net", "rot_head_net", "backbone.layer4", "backbone.layer3", "backbone.rest")
+    for g in STAGES:  # the backward completes the stages in this order
+        for p in stage_params_of(m, g):
             p.grad.fill_(float(rank + 1))
             p.grad.view(-1)[0] = 10.0 * (rank + 1)
         gb.reduce(g)
-        order.append(g)
+    ok = gb._issued == list(STAGES)
     gb.finish()
-    ok = all(torch.allclose(p.grad.view(-1)[1:], torch.full((p.numel() - 1,), 1.5)) and abs(p.grad.view(-1)[0].item() - 15.0) < 1e-6
-             for p in m.parameters())
+    ok = ok and gb.last_issue_order == list(STAGES)
+    ok = ok and all(torch.allclose(p.grad.view(-1)[1:], torch.full((p.numel() - 1,), 1.5)) and abs(p.grad.view(-1)[0].item() - 15.0) < 1e-6
+                    for p in m.parameters())
     ok = ok and all(p.grad.data_ptr() >= gb.flat.data_ptr() for p in m.parameters())  # views into the flat buffer
+    # every stage is one contiguous slice, laid out in completion order
+    ends = [gb.slices[g] for g in STAGES]
+    ok = ok and ends[0][0] == 0 and all(ends[i][1] == ends[i + 1][0] for i in range(4)) and ends[-1][1] == gb.flat.numel()
+    # --- five buckets == three buckets, bit for bit (round 6: the backbone's bucket split per ResNet stage)
+    means = {}
+    for form, groups in (("stages", STAGES), ("coarse", GROUPS)):
+        m2 = _Toy()
+        g2 = GradBuckets(m2, groups=groups)
+        issued_at = []
+        for st in STAGES:
+            _fill(m2, st, rank)
+            g2.reduce(st)
+            issued_at.append(list(g2._issued))
+        if form == "coarse":  # the coarse backbone bucket waits for its LAST stage
+            ok = ok and issued_at == [["pnp_net"], ["pnp_net", "rot_head_net"], ["pnp_net", "rot_head_net"], ["pnp_net", "rot_head_net"],
+                                      list(GROUPS)]
+        g2.finish()
+        means[form] = {n: p.grad.clone() for n, p in m2.named_parameters()}
+    ok = ok and all(torch.equal(means["stages"][n], means["coarse"][n]) for n in means["stages"])
+    # ... and both are the rank mean of what the two ranks wrote
+    m3 = _Toy()
+    g3 = GradBuckets(m3)
+    want = {}
+    for r in range(world):
+        for st in STAGES:
+            _fill(m3, st, r)
+        for n, p in m3.named_parameters():
+            want[n] = want.get(n, 0) + p.grad.clone()
+    ok = ok and all(torch.equal(means["stages"][n], want[n] / world) for n in want)
+    # --- bf16 transport (cfg.SOLVER.ALLREDUCE_DTYPE): the mean of the bf16-rounded gradients, inside one bf16 rounding of the fp32 mean
+    m4 = _Toy()
+    g4 = GradBuckets(m4, comm_dtype=torch.bfloat16)
+    for st in STAGES:
+        _fill(m4, st, rank)
+        g4.reduce(st)
+    g4.finish()
+    for n, p in m4.named_parameters():
+        ref = want[n] / world
+        ok = ok and p.grad.dtype == torch.float32 and bool(((p.grad - ref).abs() <= 2.0 ** -7 * ref.abs() + 1e-6).all())
+    # --- a bucket nobody reduced is an error, not a silent divergence of the ranks
+    m5 = _Toy()
+    g5 = GradBuckets(m5)
+    g5.reduce("pnp_net")
+    try:
+        g5.finish()
+        ok = False
+    except RuntimeError as e:
+        ok = ok and "never reduced" in str(e)
+    g5.reduce("pnp_net"), g5.reduce("rot_head_net"), g5.reduce("backbone")  # (a coarse name = all of its stages; same collectives on both ranks)
+    g5.finish()
     poses = gather_poses(torch.full((3, 3, 3), float(rank)), torch.full((3, 3), float(rank)))
     ok = ok and poses.shape == (6, 12) and poses[:3].eq(0).all().item() and poses[3:].eq(1).all().item()
     red = reduce_loss_dict({"loss_a": torch.tensor(float(rank)), "loss_b": torch.tensor(2.0 + rank)})
@@ -56,6 +130,12 @@ def _worker(rank, world, port, q):
     ok = ok and (b, e) == ((0, 5) if rank == 0 else (5, 9))
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
+
+
+def stage_params_of(m, g):
+    from rdpn6d_amd.parallel import stage_params
+
+    return stage_params(m, g)
 
 
 def test_bucketed_allreduce_two_ranks_gloo():
@@ -79,6 +159,35 @@ def test_single_process_is_a_no_op():
     gb.reduce("backbone")
     gb.finish()
     assert all((p.grad == 2).all() for p in m.parameters())
+    assert gb.last_issue_order == ["backbone.layer4", "backbone.layer3", "backbone.rest"]
+
+
+def test_stage_layout_and_order():
+    """parallel.STAGES = the order the backward completes parameter gradients in: pnp -> head -> layer4 -> layer3 ->
+    rest; each stage is one contiguous slice of the buffer GradBuckets builds AND of a buffer in module.parameters() order (what an
+    optimizer that built first hands over); spatial_net (done early, tiny) rides with the tail."""
+    from rdpn6d_amd.parallel import GROUPS, STAGES, stage_params, stages_of
+
+    assert STAGES == ("pnp_net", "rot_head_net", "backbone.layer4", "backbone.layer3", "backbone.rest")
+    assert stages_of("backbone") == STAGES[2:] and stages_of("pnp_net") == ("pnp_net",)
+    with pytest.raises(KeyError):
+        stages_of("neck")
+    m = _Toy()
+    rest = stage_params(m, "backbone.rest")
+    names = {id(p): n for n, p in m.named_parameters()}
+    assert [names[id(p)].split(".")[1] for p in rest] == ["spatial_net", "spatial_net", "conv1", "conv1", "bn1", "bn1", "layer1", "layer2", "layer2"]
+    assert sum(p.numel() for g in STAGES for p in stage_params(m, g)) == sum(p.numel() for p in m.parameters())
+    assert [id(p) for p in stage_params(m, "backbone")] == [id(p) for st in STAGES[2:] for p in stage_params(m, st)]
+    # parameters() order: [spatial_net conv1 bn1 layer1 layer2 | layer3 | layer4] - every stage contiguous there too
+    order = [id(p) for p in m.backbone.parameters()]
+    for st in STAGES[2:]:
+        idx = sorted(order.index(id(p)) for p in stage_params(m, st))
+        assert idx == list(range(idx[0], idx[0] + len(idx))), st
+    with pytest.raises(ValueError):
+        GradBuckets(m, groups=("pnp_net", "backbone"))  # rot_head_net missing
+    m.backbone.layer3.weight.requires_grad_(False)  # frozen parameters are left out of the buckets
+    gb = GradBuckets(m, groups=GROUPS)
+    assert gb.flat.numel() == sum(p.numel() for p in m.parameters() if p.requires_grad)
     pose = gather_poses(torch.zeros(2, 3, 3), torch.ones(2, 3))
     assert pose.shape == (2, 12)
 
@@ -97,11 +206,11 @@ class _FakeEngine:
         self.seed = w
 
     def backward_stages(self):
-        from rdpn6d_amd.parallel import GROUPS
+        from rdpn6d_amd.parallel import STAGES, stage_params
 
-        for g in GROUPS:
+        for g in STAGES:
             self.log.append("stage:" + g)
-            for p in getattr(self.model, g).parameters():
+            for p in stage_params(self.model, g):
                 if p.grad is None:
                     p.grad = torch.zeros_like(p)
                 p.grad.copy_(torch.full_like(p, (self.rank + 1.0) * self.seed["loss_mask"]))  # WRITES, like the kernels
@@ -123,8 +232,11 @@ def _ddp_worker(rank, world, port, q):
         torch.manual_seed(0)
         m = _ToyLoss()
         m.eng = eng = _FakeEngine(m, rank)
+        from rdpn6d_amd.parallel import STAGES, stage_params
+
+        stage_of = {id(p): st for st in STAGES for p in stage_params(m, st)}
         for name, p in m.named_parameters():
-            p.register_post_accumulate_grad_hook(lambda p, name=name: eng.log.append("hook:" + name.split(".")[0]))
+            p.register_post_accumulate_grad_hook(lambda p: eng.log.append("hook:" + stage_of[id(p)]))
         ddp = torch.nn.parallel.DistributedDataParallel(m)
         opt = torch.optim.SGD(m.parameters(), lr=0.1)
         ok, msg = True, ""
@@ -141,11 +253,11 @@ def _ddp_worker(rank, world, port, q):
             kinds = [e for e in eng.log]
             # every group's hooks fire right after ITS stage and before the next stage starts
             pos = {e: i for i, e in enumerate(kinds) if e.startswith("stage:")}
-            for g, nxt in (("pnp_net", "rot_head_net"), ("rot_head_net", "backbone")):
+            for g, nxt in zip(STAGES[:-1], STAGES[1:]):
                 hooks = [i for i, e in enumerate(kinds) if e == "hook:" + g]
                 if not hooks or not (pos["stage:" + g] < min(hooks) and max(hooks) < pos["stage:" + nxt]):
                     ok, msg = False, f"it {it}: hooks of {g} did not fire between its stage and the next: {kinds}"
-            if sum(e.startswith("hook:") for e in kinds) != 5:
+            if sum(e.startswith("hook:") for e in kinds) != len(list(m.parameters())):
                 ok, msg = False, f"it {it}: {kinds}"
             opt.step()
         w = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
