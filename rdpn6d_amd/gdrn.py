@@ -403,12 +403,45 @@ class InferencePlan:
         # set by a kernel that had to clamp to the fp16 range.  ONE flag per (model, device), shared by every plan of the model and
         # never reset by a plan: it survives plan rebuilds (new weights, another batch size) - GDRN.forward reads it (below)
         self.h2_flag = model.h2_range_flag(device)
+        # Per-tensor exponents of the h2 format (round 6).  A tensor is stored as a * 2^e; e = 4 (a * 16) unless the model's table
+        # (GDRN.h2_exponents: filled by calibrate_h2() or by an overflow of that very tensor) says otherwise.  Everything is folded on
+        # the HOST into the fp32 epilogue scale / shift vectors of the producing launch and the scale of the consuming one - powers of
+        # two, exact; the kernels keep their constant 16 - so a plan with every exponent at 4 is bit for bit the plan of round 5.
+        # `_slots[i]` = the exponent variable behind flag slot i (every launch that can clamp gets its own slot of the model's flag
+        # array, so an overflow names its tensor); None = a launch without a variable (glue row, GroupNorm, xyz sub-sampling)
+        self._exp_table = dict(model.h2_exponents(device))
+        self._slots, self._texp, self._tvar = [], {}, {}
+        self._h2_out, self._probe = {}, None  # launch -> (h2 output tensor, variable): what GDRN.calibrate_h2 measures, launch by launch
         # rows from which a layer takes the fast path's tile kernel: bf16x3 pays from 8192 (two crops' head); with h2 the WHOLE network
         # stays in the h2 format from one crop on (B = 1 1.48 -> 1.24 ms, B = 4 1.83 -> 1.71, B = 7 2.40 -> 2.05: no fp32 <-> plane
         # conversions, the rewrites of DESIGN.md section 4 apply at every batch size).  RDPN6D_TILE_MIN_ROWS overrides (profiling)
         self._tile_min_rows = int(os.environ.get("RDPN6D_TILE_MIN_ROWS", 1024 if self.fast == "h2" else 8192))
         self._side_stream = None  # second HIP stream for work that only depends on the glue kernel (plain RANSAC), created on first use
         self._build(model)
+
+    # ---- h2 exponents / range-flag slots
+    def exp(self, var):
+        """exponent e of the h2 tensor(s) behind variable `var` (stored as a * 2^e); 4 unless the model's table says otherwise"""
+        return int(self._exp_table.get(var, 4)) if var is not None else 4
+
+    def flag_ptr(self, var):
+        """this launch's own slot of the model's range-flag array (GDRN.NFLAG ints), tagged with the exponent variable of the tensor the
+        launch writes; past the last slot every launch shares it, tagged None (an overflow there falls back to the whole-model switch)"""
+        n = self.h2_flag.numel()
+        if len(self._slots) >= n - 1:
+            if len(self._slots) == n - 1:
+                self._slots.append(None)
+            return ctypes.c_void_p(self.h2_flag.data_ptr() + 4 * (n - 1))
+        self._slots.append(var)
+        return ctypes.c_void_p(self.h2_flag.data_ptr() + 4 * (len(self._slots) - 1))
+
+    def tag(self, t, e, var):
+        """remember the exponent (and its variable) of the h2 tensor `t` for the launches that read it"""
+        if t is not None:
+            self._texp[t.data_ptr()], self._tvar[t.data_ptr()] = int(e), var
+
+    def exp_of(self, t):
+        return self._texp.get(t.data_ptr(), 4) if t is not None else 4
 
     # ---- buffers
     def buf(self, name, *shape, dtype=torch.float32, zero=False):
@@ -506,7 +539,7 @@ class InferencePlan:
         """launch: fp32 NHWC tensor -> its plane form (h2 tensor | three bf16 planes [3, plane_elems])"""
         if self.fast == "h2":
             C = x.shape[-1]
-            self.launches.append(_Launch(name, self.lib.rdpn6d_split_h2, (_ptr(x), C, 0, C, _ptr(planes), x.numel() // C, _ptr(self.h2_flag))))
+            self.launches.append(_Launch(name, self.lib.rdpn6d_split_h2, (_ptr(x), C, 0, C, _ptr(planes), x.numel() // C, self.flag_ptr(None))))
             return
         self.launches.append(_Launch(name, self.lib.rdpn6d_split_bf16x3, (_ptr(x), x.numel(), _ptr(planes), planes.shape[1])))
 
@@ -529,12 +562,34 @@ class InferencePlan:
         return cur
 
     def conv_x3(self, name, xp, xshape, w32, scale, shift, y, yp, yshape, *, cin, in_cs, k=1, stride=1, pad=0, N, out_cs, act=0,
-                slope=0.0, taps=None, phase=None, res_planes=None, res_cs=0, crop_bias=None, fuse=None):
+                slope=0.0, taps=None, phase=None, res_planes=None, res_cs=0, crop_bias=None, fuse=None, evar=None):
         """bf16x3 convolution: xp = input planes [3, >= B*H*W*in_cs]; y fp32 output or None; yp output planes or None;
-        res_planes = the residual as planes (output geometry, res_cs channels per pixel)."""
+        res_planes = the residual as planes (output geometry, res_cs channels per pixel).
+        evar (h2): the exponent variable of the OUTPUT h2 tensor (or of the fused launch's in-LDS tile); a launch with a residual
+        inherits the residual's variable - a residual chain shares one exponent, the kernel adds the two records as stored."""
+        fptr = None
         if self.fast == "h2":
             wp, inv = pack_h2_weight(w32.contiguous())
-            scale = inv if scale is None else (scale * inv).contiguous()  # 2^-(sw+4): exact
+            e_in = self.exp_of(xp)
+            if yp is None and fuse is None:
+                evar, e_out = None, 4  # fp32 output: the true value
+                if res_planes is not None and self.exp_of(res_planes) != 4:
+                    raise NotImplementedError(f"{name}: fp32 output with a residual stored at 2^{self.exp_of(res_planes)} (h2 exponents other "
+                                              "than 4 need the all-h2 plan)")
+            elif res_planes is not None:
+                evar, e_out = self._tvar.get(res_planes.data_ptr()), self.exp_of(res_planes)
+            else:
+                e_out = self.exp(evar)
+            scale = inv if scale is None else scale * inv  # 2^-(sw+4): exact
+            # input stored at 2^e_in instead of 2^4, output wanted at 2^e_out instead of 2^4: both folded here (powers of two: exact)
+            scale = (scale * 2.0 ** (e_out - e_in)).contiguous()
+            if shift is not None and e_out != 4:
+                shift = (shift * 2.0 ** (e_out - 4)).contiguous()
+            if fuse is not None and e_out != 4:  # the 1x1 output convolution reads the in-LDS tile at 2^e_out: undo it in ITS scale
+                fuse = (fuse[0], (fuse[1] * 2.0 ** (4 - e_out)).contiguous()) + tuple(fuse[2:])
+            self.tag(yp, e_out, evar)
+            fptr = self.flag_ptr(evar)
+            n_before = len(self.launches)
         else:
             wp = self.weight_planes(w32)
         d = _lib.ConvDesc()
@@ -563,37 +618,43 @@ class InferencePlan:
             w1, s1, b1, out, ocs, nout = fuse
             assert y is None and yp is None and self.lib.rdpn6d_conv_h2_fuse1x1_ok(ctypes.byref(d)), name
             self.keep += [w1, s1, b1]
-            self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_h2_fuse1x1, (ctypes.byref(d), _ptr(res_planes), _ptr(self.h2_flag), _ptr(crop_bias),
+            self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_h2_fuse1x1, (ctypes.byref(d), _ptr(res_planes), fptr, _ptr(crop_bias),
                                                                                     _ptr(w1), _ptr(s1), _ptr(b1), _ptr(out), ocs, nout), keep=(d,)))
-            return
+            return self._note_h2_out(n_before, yp, evar, phase)
         if self.fast == "h2":
             assert self.lib.rdpn6d_conv_h2_kernel_for(ctypes.byref(d)), name
             ws_bytes = int(self.lib.rdpn6d_conv_h2_workspace_bytes(ctypes.byref(d)))
             if ws_bytes:  # a launch too small to fill the chip: split-K through the plan's shared workspace (launches are stream-ordered)
                 ws = self.h2_workspace(ws_bytes)
-                self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_h2_ws, (ctypes.byref(d), _ptr(yp), _ptr(res_planes), _ptr(self.h2_flag),
+                self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_h2_ws, (ctypes.byref(d), _ptr(yp), _ptr(res_planes), fptr,
                                                                                    _ptr(crop_bias), _ptr(ws), ws.numel()), keep=(d, crop_bias)))
-                return
+                return self._note_h2_out(n_before, yp, evar, phase)
             if crop_bias is not None:  # per-crop bias rows [B][4][Npad] (the folded global-max half of the ConvTranspose input)
-                self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_h2_cb, (ctypes.byref(d), _ptr(yp), _ptr(res_planes), _ptr(self.h2_flag),
+                self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_h2_cb, (ctypes.byref(d), _ptr(yp), _ptr(res_planes), fptr,
                                                                                    _ptr(crop_bias)), keep=(d, crop_bias)))
-                return
+                return self._note_h2_out(n_before, yp, evar, phase)
             if self.h2_wfrag and self.lib.rdpn6d_conv_h2_wfrag_wanted(ctypes.byref(d)):
                 # this layer's kernel can take its weight fragments straight from L2 (fragment-major copy of the weights, same bytes):
                 # a third of the K loop's LDS traffic gone (csrc/conv_igemm_h2_pp.hip, BFG); bit-identical results
                 wf = torch.empty_like(wp)
                 _lib.check(self.lib.rdpn6d_h2_weight_frag(_ptr(wp), wp.shape[0], d.ntaps, cin // 32, _ptr(wf), None), "h2_weight_frag")
                 self.keep.append(wf)
-                self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_h2_wf, (ctypes.byref(d), _ptr(yp), _ptr(res_planes), _ptr(self.h2_flag), _ptr(wf)),
+                self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_h2_wf, (ctypes.byref(d), _ptr(yp), _ptr(res_planes), fptr, _ptr(wf)),
                                              keep=(d,)))
-                return
-            self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_h2, (ctypes.byref(d), _ptr(yp), _ptr(res_planes), _ptr(self.h2_flag)), keep=(d,)))
-            return
+                return self._note_h2_out(n_before, yp, evar, phase)
+            self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_h2, (ctypes.byref(d), _ptr(yp), _ptr(res_planes), fptr), keep=(d,)))
+            return self._note_h2_out(n_before, yp, evar, phase)
         assert self.lib.rdpn6d_conv_bf16x3_eligible(ctypes.byref(d)), name
         self.launches.append(_Launch(name, self.lib.rdpn6d_conv2d_bf16x3_ex,
                                      (ctypes.byref(d), xp.shape[1], wp.shape[1], _ptr(yp), yp.shape[1] if yp is not None else 0,
                                       _ptr(res_planes), res_planes.shape[1] if res_planes is not None else 0),
                                      keep=(d,)))
+
+    def _note_h2_out(self, n_before, yp, evar, phase):
+        """(calibration bookkeeping) the launch just appended writes the h2 tensor `yp` of variable `evar`; of the four sub-pixel phase
+        launches that fill one tensor only the last is probed"""
+        if yp is not None and len(self.launches) == n_before + 1 and (phase is None or tuple(phase[4:6]) == (1, 1)):
+            self._h2_out[id(self.launches[-1])] = (yp, evar)
 
     def call(self, name, fn, *args):
         self.launches.append(_Launch(name, fn, args))
@@ -642,12 +703,15 @@ class InferencePlan:
         if self.fused_front:
             # conv1 + BN + ReLU + max-pool in ONE kernel on the fp16 matrix pipe, pooled activation written as an h2 tensor
             wh, inv = pack_stem_h2_weight(bb.conv1.weight)
-            scf = (sc[:64] * inv).contiguous()
+            e_st = self.exp("stem")  # (ReLU and max-pool commute with the positive factor 2^(e - 4))
+            scf = (sc[:64] * inv * 2.0 ** (e_st - 4)).contiguous()
+            sh = (sh * 2.0 ** (e_st - 4)).contiguous()
             pcur = self.planes_buf("pool_planes", B * R4 * R4 * 64, 1)
             p0 = None
             self.keep += [wh, scf, sh]
             self.stem_fn = lib.rdpn6d_stem_pool_h2
-            self.stem_args = (B, 6, R, _ptr(wh), _ptr(scf), _ptr(sh), _ptr(pcur), _ptr(self.h2_flag))
+            self.stem_args = (B, 6, R, _ptr(wh), _ptr(scf), _ptr(sh), _ptr(pcur), self.flag_ptr("stem"))
+            self.tag(pcur, e_st, "stem")
         elif self.bf16 and R % 4 == 0 and model.cfg.get("TEST", {}).get("FUSED_FRONT_LP", True):
             # 16-bit mode: the same fused kernel (fp32-accurate h2 arithmetic on the fp16 matrix pipe), the pooled activation rounded once
             # into the mode's NHWC bf16 / fp16 tensor - instead of the VALU stem + max-pool pair and the [B,128,128,64] tensor between them
@@ -687,7 +751,7 @@ class InferencePlan:
                         wd = pack_conv_weight(blk.downsample[0].weight.detach().float())
                         scd, shd = fold_bn(blk.downsample[1], npad=wd.shape[0])
                         self.conv_x3(f"{nm}.downsample", pcur, (cur_hw, cur_hw), wd, scd, shd, None, pds, (ohw, ohw), cin=cur_c,
-                                     in_cs=cur_c, k=1, stride=s, pad=0, N=cout, out_cs=cout, act=0)
+                                     in_cs=cur_c, k=1, stride=s, pad=0, N=cout, out_cs=cout, act=0, evar=f"layer{li + 1}")  # (the stage's residual chain)
                         res_p = pds
                     o = self.buf(f"l{li}_o{bi % 2}", B, ohw, ohw, cout) if last else None
                     po = None if last else self.planes_buf(f"l{li}_o{bi % 2}_planes", npl, 1)
@@ -700,9 +764,9 @@ class InferencePlan:
                         pt1 = self.planes_buf(f"l{li}_ta{bi % 2}_planes", B * cur_hw * cur_hw * width, 1)
                         pt2 = self.planes_buf(f"l{li}_tb{bi % 2}_planes", B * ohw * ohw * width, 1)
                         self.conv_x3(f"{nm}.conv1", pcur, (cur_hw, cur_hw), w1, sc1, sh1, None, pt1, (cur_hw, cur_hw), cin=cur_c,
-                                     in_cs=cur_c, k=1, N=width, out_cs=width, act=1)
+                                     in_cs=cur_c, k=1, N=width, out_cs=width, act=1, evar=f"{nm}.conv1")
                         self.conv_x3(f"{nm}.conv2", pt1, (cur_hw, cur_hw), w2, sc2, sh2, None, pt2, (ohw, ohw), cin=width, in_cs=width,
-                                     k=3, stride=s, pad=1, N=width, out_cs=width, act=1)
+                                     k=3, stride=s, pad=1, N=width, out_cs=width, act=1, evar=f"{nm}.conv2")
                         w3 = pack_conv_weight(blk.conv3.weight.detach().float())
                         sc3, sh3 = fold_bn(blk.bn3, npad=w3.shape[0])
                         self.conv_x3(f"{nm}.conv3", pt2, (ohw, ohw), w3, sc3, sh3, o, po, (ohw, ohw), cin=width, in_cs=width, k=1,
@@ -710,7 +774,7 @@ class InferencePlan:
                     else:
                         pt = self.planes_buf(f"l{li}_t{bi % 2}_planes", npl, 1)
                         self.conv_x3(f"{nm}.conv1", pcur, (cur_hw, cur_hw), w1, sc1, sh1, None, pt, (ohw, ohw), cin=cur_c, in_cs=cur_c,
-                                     k=3, stride=s, pad=1, N=cout, out_cs=cout, act=1)
+                                     k=3, stride=s, pad=1, N=cout, out_cs=cout, act=1, evar=f"{nm}.conv1")
                         self.conv_x3(f"{nm}.conv2", pt, (ohw, ohw), w2, sc2, sh2, o, po, (ohw, ohw), cin=cout, in_cs=cout, k=3,
                                      stride=1, pad=1, N=cout, out_cs=cout, act=1, res_planes=res_p, res_cs=cout)
                     cur, pcur, cur_hw, cur_c = o, po, ohw, cout
@@ -761,7 +825,8 @@ class InferencePlan:
             pcs = 96  # [emb(64) | xyz(3) + 0-pad: one 32-channel group]
             pin = self.planes_buf("pn_in_planes", npx * pcs, 1)
             self.xyz_fn = lib.rdpn6d_xyz_subsample_h2
-            self.xyz_args = (B, 6, R, 8, _ptr(pin), pcs, 64, _ptr(self.h2_flag))
+            self.xyz_args = (B, 6, R, 8, _ptr(pin), pcs, 64, self.flag_ptr(None))  # (metres: no range issue, fixed 2^4)
+            e_emb = self.exp("spatial_net.emb")
             we = pack_conv_weight(sn.xyz_emb.weight.detach().float())
             sce, she = fold_bn(sn.xb, sn.xyz_emb.bias, npad=we.shape[0])
             self.conv_first = bool(model.cfg.get("TEST", {}).get("CONV_BEFORE_UPSAMPLE", True))
@@ -770,21 +835,31 @@ class InferencePlan:
                 # (weights sum to 1) - evaluate it on layer4's 8x8 map and up-sample its 64 channels instead of all 512 (ReLU after)
                 emb = self.planes_buf("emb_lowres_planes", B * cur_hw * cur_hw * 64, 1)
                 self.conv_x3("spatial_net.xyz_emb", pcur, (cur_hw, cur_hw), we, sce, she, None, emb, (cur_hw, cur_hw), cin=C4, in_cs=C4,
-                             N=64, out_cs=64, act=0)
+                             N=64, out_cs=64, act=0, evar="spatial_net.emb")
                 self.call("upsample", lib.rdpn6d_upsample_bilinear_h2_ex, _ptr(emb), B, cur_hw, cur_hw, 64, R8 // cur_hw, _ptr(pin), pcs, 0, 1,
-                          _ptr(self.h2_flag))
+                          self.flag_ptr("spatial_net.emb"))  # (interpolation + ReLU: the records pass through at their exponent)
             else:
                 up = self.planes_buf("up_planes", npx * C4, 1)
-                self.call("upsample", lib.rdpn6d_upsample_bilinear_h2, _ptr(pcur), B, cur_hw, cur_hw, C4, R8 // cur_hw, _ptr(up), _ptr(self.h2_flag))
-                self.conv_x3("spatial_net.xyz_emb", up, (R8, R8), we, sce, she, None, pin, (R8, R8), cin=C4, in_cs=C4, N=64, out_cs=pcs, act=1)
+                self.call("upsample", lib.rdpn6d_upsample_bilinear_h2, _ptr(pcur), B, cur_hw, cur_hw, C4, R8 // cur_hw, _ptr(up),
+                          self.flag_ptr(self._tvar.get(pcur.data_ptr())))
+                self.tag(up, self.exp_of(pcur), self._tvar.get(pcur.data_ptr()))
+                self.conv_x3("spatial_net.xyz_emb", up, (R8, R8), we, sce, she, None, pin, (R8, R8), cin=C4, in_cs=C4, N=64, out_cs=pcs, act=1,
+                             evar="spatial_net.emb")
             wc1 = pack_conv_weight(sn.conv1.weight.detach().float(), cin_pad=pcs, perm=perm)
+            # pn_in holds [emb at 2^e_emb | xyz at 2^4]: one tensor, two exponents - conv1 reads it as a 2^4 tensor and the difference
+            # sits in the emb COLUMNS of its weights (a power of two per input channel: exact)
+            self.tag(pin, 4, None)
+            if e_emb != 4:
+                wc1[:, :, :64] *= 2.0 ** (4 - e_emb)
             s1, h1 = fold_bn(sn.b1, sn.conv1.bias, npad=wc1.shape[0])
             l1 = self.planes_buf("pn_l1_planes", npx * 128, 1)
-            self.conv_x3("spatial_net.conv1", pin, (R8, R8), wc1, s1, h1, None, l1, (R8, R8), cin=pcs, in_cs=pcs, N=128, out_cs=128, act=1)
+            self.conv_x3("spatial_net.conv1", pin, (R8, R8), wc1, s1, h1, None, l1, (R8, R8), cin=pcs, in_cs=pcs, N=128, out_cs=128, act=1,
+                         evar="spatial_net.l1")
             wc2 = pack_conv_weight(sn.conv2.weight.detach().float())
             s2, h2 = fold_bn(sn.b2, sn.conv2.bias, npad=wc2.shape[0])
             l2 = self.planes_buf("pn_l2_planes", npx * 256, 1)
-            self.conv_x3("spatial_net.conv2", l1, (R8, R8), wc2, s2, h2, None, l2, (R8, R8), cin=128, in_cs=128, N=256, out_cs=256, act=1)
+            self.conv_x3("spatial_net.conv2", l1, (R8, R8), wc2, s2, h2, None, l2, (R8, R8), cin=128, in_cs=128, N=256, out_cs=256, act=1,
+                         evar="spatial_net.l2")
             wc3 = pack_conv_weight(sn.conv3.weight.detach().float())
             s3, h3 = fold_bn(sn.b3, sn.conv3.bias, npad=wc3.shape[0])
             # cfg.TEST.FOLD_GLOBAL_MAX: the broadcast half of [l3 | max(l3)] is spatially constant, so its share of the ConvTranspose
@@ -793,10 +868,12 @@ class InferencePlan:
             fcs = 512 if self.fold_gmax else 1024
             feat = self.planes_buf("feat_planes", npx * fcs, 1)
             i_conv3 = len(self.launches)
-            self.conv_x3("spatial_net.conv3", l2, (R8, R8), wc3, s3, h3, None, feat, (R8, R8), cin=256, in_cs=256, N=512, out_cs=fcs, act=0)
+            self.conv_x3("spatial_net.conv3", l2, (R8, R8), wc3, s3, h3, None, feat, (R8, R8), cin=256, in_cs=256, N=512, out_cs=fcs, act=0,
+                         evar="spatial_net.l3")
             if self.fold_gmax:
                 gmax = self.planes_buf("gmax_planes", B * 512, 1)
                 self.call("global_max", lib.rdpn6d_global_max_h2, _ptr(feat), B, R8 * R8, 512, 512, _ptr(gmax))
+                self.tag(gmax, self.exp_of(feat), "spatial_net.l3")  # (the per-crop max of the records: same exponent)
             else:
                 self.call("global_max_concat", lib.rdpn6d_global_max_concat_h2, _ptr(feat), B, R8 * R8, 512, 1024)
         else:
@@ -875,7 +952,7 @@ class InferencePlan:
                         and lib.rdpn6d_conv_h2_colmax_ok(ctypes.byref(d3), R8 * R8)):
                     keys = self.buf("gmax_keys", B, d3.Npad, dtype=torch.int64, zero=True)
                     self.launches[i_conv3] = _Launch("spatial_net.conv3+max", lib.rdpn6d_conv2d_h2_colmax,
-                                                     (ctypes.byref(d3), _ptr(keys), R8 * R8, _ptr(self.h2_flag)), keep=(d3,))
+                                                     (ctypes.byref(d3), _ptr(keys), R8 * R8, L3.args[3]), keep=(d3,))  # (conv3's own flag slot)
                     self.launches[i_conv3 + 1] = _Launch("global_max.decode", lib.rdpn6d_h2_colmax_decode, (_ptr(keys), B, 512, d3.Npad, _ptr(gmax)))
                     self.fused_gmax = True
                     self.bufs.pop("feat_planes", None)  # (never written now)
@@ -884,8 +961,10 @@ class InferencePlan:
             self.conv_x3("rot_head.convT.const", gmax, (1, 1), wconst, None, vconst, V, None, (1, 1), cin=512, in_cs=512, N=9 * F,
                          out_cs=9 * F, act=0)
             cbias = self.buf("convT_crop_bias", 4, B, 4, Fp)
-            self.call("convT_const_bias", lib.rdpn6d_convt3x3s2_const_bias_f32, _ptr(V), _ptr(sct), B, F, _ptr(cbias))
-            self.keep += [sct]
+            # (the bias rows are added next to `shift` in the phase convolutions' epilogues: same factor 2^(e - 4) as theirs)
+            sct_b = sct if self.exp("rot_head.convT") == 4 else (sct * 2.0 ** (self.exp("rot_head.convT") - 4)).contiguous()
+            self.call("convT_const_bias", lib.rdpn6d_convt3x3s2_const_bias_f32, _ptr(V), _ptr(sct_b), B, F, _ptr(cbias))
+            self.keep += [sct, sct_b]
         for py in (0, 1):
             for px in (0, 1):
                 ys = [(1, 0)] if py == 0 else [(0, 1), (2, 0)]  # (kernel index, input offset)
@@ -900,7 +979,7 @@ class InferencePlan:
                 if x3_ct:  # planes in, planes out (the fp32 tensor is never materialised)
                     self.conv_x3(f"rot_head.convT.phase{py}{px}", pF, (R8, R8), wp[:, :, :ct_cin].contiguous(), sct, sht, None, pA, (R4, R4),
                                  cin=ct_cin, in_cs=ct_cin, N=F, out_cs=F, act=1, taps=taps, phase=(R8, R8, 2, 2, py, px),
-                                 crop_bias=cbias[py * 2 + px] if fold else None)
+                                 crop_bias=cbias[py * 2 + px] if fold else None, evar="rot_head.convT")  # (four phases, ONE tensor)
                 else:
                     self.conv(f"rot_head.convT.phase{py}{px}", feat, (R8, R8), wp.contiguous().to(adt), sct, sht, hA, (R4, R4),
                               cin=1024, in_cs=1024, N=F, out_cs=F, act=1, taps=taps, phase=(R8, R8, 2, 2, py, px), lowp=lp)
@@ -935,12 +1014,12 @@ class InferencePlan:
                     w1h, inv1 = pack_h2_weight(w1)
                     b1 = _pad_vec(last.bias.detach().float(), 64, 0.0)
                     self.conv_x3(f"rot_head.features.{i}+out", pa, (R4, R4), w32, sch, shh, None, None, (R4, R4), cin=F, in_cs=F, k=3, pad=1,
-                                 N=F, out_cs=F, act=1, fuse=(w1h, inv1.contiguous(), b1, ho, self.head_cs, nout))
+                                 N=F, out_cs=F, act=1, fuse=(w1h, inv1.contiguous(), b1, ho, self.head_cs, nout), evar=f"rot_head.features.{i}")
                     self.fused_out = True
                     pa, pb = pb, pa
                     continue
                 self.conv_x3(f"rot_head.features.{i}", pa, (R4, R4), w32, sch, shh, b if is_last else None,
-                             None if is_last else pb, (R4, R4), cin=F, in_cs=F, k=3, pad=1, N=F, out_cs=F, act=1)
+                             None if is_last else pb, (R4, R4), cin=F, in_cs=F, k=3, pad=1, N=F, out_cs=F, act=1, evar=f"rot_head.features.{i}")
                 pa, pb = pb, pa
             else:
                 wh = pw(head.features[i].weight.detach().float())
@@ -979,7 +1058,7 @@ class InferencePlan:
         self.glue_args = lambda coord2d, fps: (_ptr(ho), self.head_cs, _ptr(coord2d), _ptr(fps), B, HW, K,
                                                1 if self.mask_attention == "mul" else 0, self.mask_type, _ptr(minmax),
                                                _ptr(self.out_nchw), _ptr(pnp_in), self.pnp_cs, _ptr(self.argmax)) + (
-                                                   (_ptr(self.h2_flag),) if self.pnp_h2 else ())
+                                                   (self.flag_ptr(None),) if self.pnp_h2 else ())
         self.post = []  # launches after the glue
         main, self.launches = self.launches, self.post
         self._main_launches = main
@@ -998,7 +1077,7 @@ class InferencePlan:
                              stride=2, pad=1, N=fd, out_cs=fd, act=0)
                 yh = self.planes_buf(f"pnp_c{i}_planes", B * (hw // 2) ** 2 * fd, 1)
                 self.call(f"pnp_net.features.{i + 1}", lib.rdpn6d_groupnorm_relu_h2, _ptr(y), B, (hw // 2) ** 2, fd, gn.groups, _ptr(g),
-                          _ptr(bta), _ptr(yh), _ptr(self.h2_flag))
+                          _ptr(bta), _ptr(yh), self.flag_ptr(None))
                 x, hw, cin = yh, hw // 2, fd
                 continue
             self.conv(f"pnp_net.features.{i}", x, (hw, hw), wpn, None, None, y, (hw // 2, hw // 2), cin=cin, in_cs=cin,
@@ -1129,8 +1208,13 @@ class InferencePlan:
         B = self.B
         _lib.check(self.stem_fn(_ptr(x), self.stem_args[0], x.shape[1], *self.stem_args[2:], st), "stem")
         _lib.check(self.xyz_fn(_ptr(x), self.xyz_args[0], x.shape[1], *self.xyz_args[2:], st), "xyz")
+        probe = self._probe
+        if probe is not None:
+            probe(("stem", self.stem_args))
         for L in self.launches:
             _lib.check(L.fn(*L.args, st), L.name)
+            if probe is not None:
+                probe(L)
         self.flag_read_queued = False
         if not self.pnp_h2 and after_h2 is not None and not torch.cuda.is_current_stream_capturing():
             after_h2()
@@ -1165,7 +1249,7 @@ class InferencePlan:
             return False
         if wait:
             torch.cuda.current_stream().synchronize()
-        return bool(int(self.h2_flag.item()) != 0)
+        return bool(int(self.h2_flag.ne(0).any().item()))
 
     def run_graphed(self, key, launch):
         """Replay `launch()` (a closure issuing the whole step on the current stream) as one hipGraph.  The graph is
@@ -1262,7 +1346,10 @@ class GDRN(_TreeWatch, nn.Module):
         self._stamp_tensors = None  # cached [parameters + buffers] of the stamp (rebuilt when the module tree changes: _TreeWatch)
         self._stamp_tree_epoch = -1
         _MODELS.add(self)
-        self._h2_flags = {}  # device -> (device int32 flag written by the h2 kernels, pinned host copy, [event of the last copy])
+        self._h2_flags = {}  # device -> (device int32 flag ARRAY written by the h2 kernels, pinned host copy, [event of the last copy])
+        self._h2_exp = {}    # device -> {exponent variable: e}: h2 tensors stored as a * 2^e instead of a * 2^4 (h2_exponents)
+
+    NFLAG = 512  # range-flag slots per (model, device): one per launch that can clamp (ResNet-152: ~190), the last one shared by the rest
 
     # ---- range guard of the two-plane fp16 ("h2") format, DESIGN.md section 2
     @staticmethod
@@ -1277,8 +1364,92 @@ class GDRN(_TreeWatch, nn.Module):
         """the device flag every h2 kernel of this model's plans on `device` sets when it had to clamp an activation"""
         key = self._dev_key(device)
         if key not in self._h2_flags:
-            self._h2_flags[key] = [torch.zeros(1, dtype=torch.int32, device=device), torch.zeros(1, dtype=torch.int32).pin_memory(), None]
+            self._h2_flags[key] = [torch.zeros(self.NFLAG, dtype=torch.int32, device=device), torch.zeros(self.NFLAG, dtype=torch.int32).pin_memory(), None]
         return self._h2_flags[key][0]
+
+    def h2_exponents(self, device):
+        """{exponent variable: e} of this model's h2 plans on `device`: the h2 tensor(s) behind a variable - one activation, or a
+        residual chain - hold a * 2^e instead of the default a * 2^4 (|a| < 4094).  Filled by calibrate_h2() and, one tensor at a
+        time, when a forward overflowed that tensor (GDRN.forward, cfg.TEST.H2_RANGE_CHECK); cleared by load_state_dict."""
+        return self._h2_exp.setdefault(self._dev_key(device), {})
+
+    def _lower_h2_exponents(self, plan, device, binades=2, floor=-12):
+        """An h2 kernel of `plan` clamped: lower the exponent of exactly the tensors whose launches raised their flag slot by `binades`
+        (two per retry: an activation 2^16 over the range is back inside after eight), clear the flags and drop the stale plans.
+        False when a flagged launch has no exponent variable (glue row, GroupNorm, xyz sub-sampling: values bounded by construction or
+        caller data), the plan is not the all-h2 one, or a variable would pass the floor - the caller then leaves h2 as before."""
+        ent = self._h2_flags.get(self._dev_key(device))
+        if ent is None or ent[2] is None:
+            return False
+        ent[2].synchronize()
+        hit = torch.nonzero(ent[1]).reshape(-1).tolist()
+        slots = getattr(plan, "_slots", [])
+        names = {slots[i] if i < len(slots) else None for i in hit}
+        if not hit or None in names or not getattr(plan, "h2_pointwise", False):
+            return False
+        tab = self.h2_exponents(device)
+        if any(tab.get(v, 4) - binades < floor for v in names):
+            return False
+        for v in names:
+            tab[v] = tab.get(v, 4) - binades
+        ent[0].zero_()
+        ent[1].zero_()
+        ent[2] = None
+        return True
+
+    @torch.no_grad()
+    def calibrate_h2(self, *args, headroom=1, raise_small=False, **kwargs):
+        """Plan-time choice of the h2 exponents from a calibration batch: runs `forward(*args, **kwargs)` launch by
+        launch, reads the largest |hi| record every h2-producing launch wrote, and sets each exponent variable so that the largest
+        value seen sits `headroom` binades under the format's end: 2^e * max|a| <= 65504 / 2^headroom.  Exponents only go DOWN from
+        the default 4 unless raise_small (a tensor whose values are all tiny keeps more of its lo term with a larger e).  A tensor that
+        overflows during calibration is lowered and the pass repeated.  Returns the table {variable: e} (also kept on the model)."""
+        import math
+
+        x = args[0] if args else kwargs["x"]
+        dev = x.device
+        self.eval()
+        for _ in range(12):
+            tab = self.h2_exponents(dev)
+            plan = self.plan(x.shape[0], dev)
+            if plan.fast != "h2" or not getattr(plan, "h2_pointwise", False):
+                raise RuntimeError("calibrate_h2: the plan for this batch / config is not the all-h2 plan")
+            seen = {}
+
+            def probe(L, plan=plan, seen=seen):
+                if isinstance(L, tuple):  # the fused stem: its pooled h2 output
+                    out = (plan.bufs.get("pool_planes"), "stem") if getattr(plan, "fused_front", False) else None
+                else:
+                    out = plan._h2_out.get(id(L))
+                if out is None or out[0] is None:
+                    return
+                t, var = out
+                hi = t.reshape(-1).view(-1, 2, 32)[:, 0]  # [records][hi x 32 | lo x 32]
+                seen[var] = max(seen.get(var, 0.0), float(hi.float().abs().amax()))
+
+            plan._probe = probe
+            before = dict(tab)
+            try:
+                self.forward(*args, **kwargs)
+            finally:
+                plan._probe = None
+            torch.cuda.synchronize()
+            if dict(self.h2_exponents(dev)) != before or self.plan(x.shape[0], dev) is not plan:
+                continue  # (a tensor overflowed: forward lowered it and re-ran on a new plan - measure again on that one)
+            changed = False
+            for var, m in seen.items():
+                if var is None or m <= 0.0:
+                    continue
+                e_now = tab.get(var, 4)
+                a_max = m / 2.0 ** e_now
+                e_fit = math.floor(math.log2(65504.0 / 2.0 ** headroom / a_max))
+                e_new = e_fit if raise_small else min(e_fit, 4)
+                e_new = max(min(e_new, 14), -12)
+                if e_new != e_now and (e_new < e_now or raise_small):
+                    tab[var], changed = e_new, True
+            if not changed:
+                return dict(tab)
+        raise RuntimeError("calibrate_h2 did not settle in 12 passes")
 
     def _range_flag_fetch(self, device):
         """queue flag -> pinned host memory behind the forward just issued (outside any hipGraph: a replayed graph is followed by
@@ -1299,7 +1470,7 @@ class GDRN(_TreeWatch, nn.Module):
                 continue
             if wait:
                 ent[2].synchronize()
-            hit |= bool(ent[2].query() and int(ent[1][0]) != 0)
+            hit |= bool(ent[2].query() and bool(ent[1].ne(0).any()))
         return hit
 
     def _leave_h2(self, device, when):
@@ -1312,6 +1483,7 @@ class GDRN(_TreeWatch, nn.Module):
             self.cfg["TEST"] = {}
         self.cfg.TEST.FP16X2 = False
         self.invalidate_plans()
+        self._last_h2_plan = {}
         for ent in self._h2_flags.values():  # (no h2 kernel runs from here on; a model switched back by hand starts clean)
             ent[0].zero_()
             ent[1].zero_()
@@ -1325,6 +1497,7 @@ class GDRN(_TreeWatch, nn.Module):
     def load_state_dict(self, *a, **k):
         r = super().load_state_dict(*a, **k)
         self.invalidate_plans()
+        self._h2_exp = {}  # (calibrated for the old weights)
         return r
 
     def _apply(self, fn, *a, **k):
@@ -1366,6 +1539,8 @@ class GDRN(_TreeWatch, nn.Module):
         hold device buffers, ctypes argument blocks and the ORIGINAL's tensors"""
         d = self.__dict__.copy()
         d["_plans"], d["_h2_flags"], d["_stamp_tensors"] = {}, {}, None
+        d.pop("_last_h2_plan", None)
+        d["_h2_exp"] = {k: dict(v) for k, v in d.get("_h2_exp", {}).items()}  # (plain ints: the copy keeps the calibration)
         # ... nor with the `vis/*` state: device table, pinned host rows, a pending event (not picklable, and the copy's rows are its own)
         d.pop("_vis", None)
         d.pop("vis_sink", None)
@@ -1500,9 +1675,9 @@ class GDRN(_TreeWatch, nn.Module):
                bool(tc.get("CONV_BEFORE_UPSAMPLE", True)), bool(tc.get("COMPOSE_CONV3_CONVT", True)), bool(tc.get("PNP_H2", True)), bool(tc.get("FUSE_HEAD_OUT", True)))
         stamp = self._weights_stamp()
         plan = self._plans.get(key)
-        if plan is not None and plan.weights_stamp != stamp:
-            del self._plans[key], plan  # weights moved under the packed copies (optimizer step, BN statistics, in-place edit)
-            plan = None
+        if plan is not None and (plan.weights_stamp != stamp or plan._exp_table != self.h2_exponents(device)):
+            del self._plans[key], plan  # weights moved under the packed copies (optimizer step, BN statistics, in-place edit), or an h2
+            plan = None                 # exponent was lowered / calibrated since the plan folded the old one into its scale vectors
         if plan is None:
             plan = self._plans[key] = InferencePlan(self, B, device, bf16=bf16)
             plan.weights_stamp = stamp
@@ -1545,7 +1720,14 @@ class GDRN(_TreeWatch, nn.Module):
         if range_check not in ("sync", "deferred"):
             raise ValueError(f"TEST.H2_RANGE_CHECK={range_check!r}: sync | deferred")
         if range_check == "deferred" and self.h2_range_exceeded(x.device, wait=False):
-            self._leave_h2(x.device, "an earlier forward, whose outputs were computed with that value clamped")
+            import warnings
+
+            last = getattr(self, "_last_h2_plan", {}).get(self._dev_key(x.device))
+            if last is not None and self._lower_h2_exponents(last, x.device):
+                warnings.warn("rdpn6d_amd: an activation left the range of its h2 tensor in an EARLIER forward (H2_RANGE_CHECK='deferred': its "
+                              "outputs were computed with that value clamped); that tensor's exponent has been lowered", RuntimeWarning, stacklevel=2)
+            else:
+                self._leave_h2(x.device, "an earlier forward, whose outputs were computed with that value clamped")
         if pcfg.TRANS_TYPE != "centroid_z" or pcfg.Z_TYPE != "REL":
             raise ValueError("only TRANS_TYPE='centroid_z' with Z_TYPE='REL' is implemented")
         use_pnp = bool(tcfg.get("USE_PNP", False))
@@ -1637,11 +1819,23 @@ class GDRN(_TreeWatch, nn.Module):
 
         plan, out = infer()
         if plan.fast == "h2":
+            if not hasattr(self, "_last_h2_plan"):
+                self._last_h2_plan = {}
+            self._last_h2_plan[self._dev_key(x.device)] = plan
             # the flag read answers for THIS forward: queued by run() behind the last h2 kernel (eager launches), or here - behind the
             # replayed graph, or the first, eager run of a graph key, whose run() is not told to queue it
             if not (getattr(plan, "flag_read_queued", False) and not tcfg.get("HIP_GRAPH", False)):
                 self._range_flag_fetch(x.device)
-            if range_check == "sync" and self.h2_range_exceeded(x.device, wait=True):
+            tries = 0
+            while range_check == "sync" and plan.fast == "h2" and self.h2_range_exceeded(x.device, wait=True):
+                # (round 6) the overflow names its tensor (one flag slot per launch): that tensor's exponent goes down two binades, the
+                # plan is re-built with the new scale vectors and the batch re-run - the other layers, and the model, stay on h2
+                if tries < 10 and self._lower_h2_exponents(plan, x.device):
+                    tries += 1
+                    plan, out = infer()
+                    if not (getattr(plan, "flag_read_queued", False) and not tcfg.get("HIP_GRAPH", False)):
+                        self._range_flag_fetch(x.device)
+                    continue
                 self._leave_h2(x.device, "this forward; the batch is re-run on the bf16x3 kernels")
                 plan, out = infer()
         return out

@@ -64,16 +64,23 @@ def test_conv_fp16_layer_vs_fp32_kernel_on_fp16_operands(case):
     assert err <= 2.0 ** -10 * scale  # one fp16 rounding of the output (2^-11 relative) + summation order
 
 
-def test_fp16_inference_mode_vs_autocast_fp16_yardstick():
-    """cfg.TEST.AMP_TEST with cfg.TEST.AMP_DTYPE = "fp16": the HIP fp16 maps are at least as close to the fp64 answer as the
+def test_fp16_inference_mode_vs_autocast_fp16_yardstick(golden_dir):
+    """cfg.TEST.AMP_TEST with cfg.TEST.AMP_DTYPE = "fp16": the HIP fp16 maps are at least as close to the exact answer as the
     torch-CPU oracle under torch.autocast(float16) - what the reference's own AMP_TEST path computes - and, with 11 instead of
-    8 significand bits, several times closer than the bf16 mode."""
+    8 significand bits, several times closer than the bf16 mode.
+    The yardstick - the autocast oracle's distance from its own float64 evaluation, per map - is a pure function of the oracle and the
+    seeds and is read from tests/golden/fp16_yardstick.npz (tools/oracle/gen_fp16_yardstick.py; evaluating it here took 90 s of host
+    time per run); the "exact" answer the HIP maps are held against is the fp32 oracle (its own distance from float64, recorded in the
+    same file, is three orders below the fp16 errors being compared)."""
+    import os
+
     from oracle import model_oracle
     from rdpn6d_amd import synth
     from rdpn6d_amd.config import gdrn_base_cfg
     from rdpn6d_amd.gdrn import build_model_optimizer
 
     dev = torch.device("cuda:0")
+    yard = np.load(os.path.join(golden_dir, "fp16_yardstick.npz"))
     orc = model_oracle.GDRNOracle(32, "none")
     sd = synth.make_trained_like_state_dict({k: tuple(v.shape) for k, v in orc.state_dict().items()}, seed=1234)
     orc.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
@@ -86,9 +93,7 @@ def test_fp16_inference_mode_vs_autocast_fp16_yardstick():
     model.eval()
     args = lambda d: (d["roi_img"], d["roi_coord_2d"], d["fps"], d["roi_cam"], d["roi_center"], d["roi_wh"], d["resize_ratio"])  # noqa: E731
     with torch.no_grad():
-        with torch.autocast("cpu", dtype=torch.float16):
-            oac = orc(*args(tc))
-        o64 = orc.double()(*args({k: (v.double() if v.dtype.is_floating_point else v) for k, v in tc.items()}))
+        o32 = orc(*args(tc))
     t = {k: v.to(dev) for k, v in tc.items()}
     outs = {}
     try:
@@ -99,11 +104,14 @@ def test_fp16_inference_mode_vs_autocast_fp16_yardstick():
             assert plan.lp == dt and plan.bufs["head_a"].dtype == (torch.float16 if dt == "fp16" else torch.bfloat16)
     finally:
         model.cfg.TEST.AMP_TEST, model.cfg.TEST.AMP_DTYPE = False, "bf16"
-    for k in ("mask", "coor_x", "coor_y", "coor_z", "region"):
-        exact = o64[k]
+    assert [str(k) for k in yard["inf_maps"]] == ["mask", "coor_x", "coor_y", "coor_z", "region"]
+    for i, k in enumerate(("mask", "coor_x", "coor_y", "coor_z", "region")):
+        exact = o32[k].double()
         f = {dt: (torch.linalg.norm(outs[dt][k].cpu().double() - exact) / torch.linalg.norm(exact)).item() for dt in outs}
-        fac = (torch.linalg.norm(oac[k].double() - exact) / torch.linalg.norm(exact)).item()
-        print(f"{k}: rel-Frobenius vs fp64: HIP-fp16 {f['fp16']:.3e} | autocast(fp16) oracle {fac:.3e} | HIP-bf16 {f['bf16']:.3e}")
+        fac, f32 = float(yard["inf_autocast_vs_f64"][i]), float(yard["inf_fp32_vs_f64"][i])
+        print(f"{k}: rel-Frobenius vs the fp32 oracle: HIP-fp16 {f['fp16']:.3e} | HIP-bf16 {f['bf16']:.3e}; autocast(fp16) oracle vs float64 "
+              f"{fac:.3e} (fixture; fp32 oracle vs float64 {f32:.1e})")
+        assert f32 < 1e-2 * fac  # the stand-in for "exact" is two orders finer than what is being compared
         assert f["fp16"] <= 1.1 * fac and f["fp16"] <= 0.5 * f["bf16"], k
     assert torch.isfinite(outs["fp16"]["rot"]).all() and torch.isfinite(outs["fp16"]["trans"]).all()
 
@@ -228,35 +236,39 @@ def test_fp16_step_vs_autocast_fp16_yardstick_and_c5_resnet50_320():
     torch.cuda.synchronize()
     t = {k: torch.from_numpy(v) for k, v in {**inp, **gt}.items()}
 
-    def run_oracle(dtype, autocast):
-        o = model_oracle.GDRNOracle(32, "mul")
-        o.load_state_dict(sd, strict=True)
-        o = o.to(dtype).train()
-        tt = {k: (v.to(dtype) if v.dtype.is_floating_point else v) for k, v in t.items()}
-        with torch.autocast("cpu", dtype=torch.float16, enabled=autocast):
-            out = o(tt["roi_img"], tt["roi_coord_2d"], tt["fps"], tt["roi_cam"], tt["roi_center"], tt["roi_wh"], tt["resize_ratio"], train_pose=True)
-            L = model_oracle.gdrn_losses({k: (v.float() if autocast and torch.is_tensor(v) and v.is_floating_point() else v) for k, v in out.items()},
-                                         tt, tt["roi_extent"])
-        (sum(L.values()) * (4096.0 if autocast else 1.0)).backward()
-        return o, L
+    # the float64 and autocast(fp16) evaluations of the oracle (2 minutes of host time per run) are in tests/golden/fp16_yardstick.npz
+    # (tools/oracle/gen_fp16_yardstick.py): per parameter the autocast oracle's relative gradient error vs float64, the total-loss
+    # errors.  "Exact" here = the fp32 oracle's gradients (3 s; 1e-6 from float64 per the same file, the errors compared are 1e-3)
+    import os
 
-    o64, L64 = run_oracle(torch.float64, False)
-    oac, Lac = run_oracle(torch.float32, True)
-    tot64 = sum(v.item() for v in L64.values())
-    e_hip, e_ac = abs(sum(v.item() for v in losses.values()) - tot64), abs(sum(v.item() for v in Lac.values()) - tot64)
-    r64, rac = dict(o64.named_parameters()), dict(oac.named_parameters())
+    yard = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fp16_yardstick.npz"))
+    o = model_oracle.GDRNOracle(32, "mul")
+    o.load_state_dict(sd, strict=True)
+    o.train()
+    out = o(t["roi_img"], t["roi_coord_2d"], t["fps"], t["roi_cam"], t["roi_center"], t["roi_wh"], t["resize_ratio"], train_pose=True)
+    L32 = model_oracle.gdrn_losses(out, t, t["roi_extent"])
+    sum(L32.values()).backward()
+    tot = float(yard["train_total_f64"])
+    assert abs(sum(v.item() for v in L32.values()) - tot) <= 1e-4 * tot  # same fixture as the generator's
+    e_hip, e_ac = abs(sum(v.item() for v in losses.values()) - tot), float(yard["train_total_autocast_err"])
+    r32 = dict(o.named_parameters())
+    ya = {str(n): (float(a), float(b), float(c)) for n, a, b, c in zip(yard["train_param_names"], yard["train_grad_autocast_vs_f64"],
+                                                                       yard["train_grad_fp32_vs_f64"], yard["train_grad_norm_f64"])}
     eh, ea = [], []
     for name, p in model.named_parameters():
-        g64 = r64[name].grad
-        n = g64.norm().item()
-        if n < 1e-4:
+        g = r32[name].grad.double()
+        n = g.norm().item()
+        if ya[name][2] < 1e-4:
             continue
         assert torch.isfinite(p.grad).all(), name
-        eh.append((p.grad.cpu().double() - g64).norm().item() / n)
-        ea.append((rac[name].grad.double() / 4096.0 - g64).norm().item() / n)
-    print(f"fp16 step: total loss off by HIP {e_hip:.2e} | autocast(fp16) oracle {e_ac:.2e} (fp64 total {tot64:.4f}); median relative gradient "
-          f"error vs fp64: HIP {np.median(eh):.3e} | autocast oracle {np.median(ea):.3e}; worst {max(eh):.3e} | {max(ea):.3e}")
-    assert np.median(eh) <= 1.1 * np.median(ea) and max(eh) <= 1.5 * max(ea) and e_hip <= 1e-2 * tot64
+        # an UPPER bound of the HIP gradient's distance from float64 (triangle inequality through the fp32 oracle, whose own distance -
+        # un-forced ReLU decisions, ~1e-2 - is in the fixture): the claim below is therefore no weaker than round 5's direct comparison
+        eh.append((p.grad.cpu().double() - g).norm().item() / n * (n / ya[name][2]) + ya[name][1])
+        ea.append(ya[name][0])
+        assert ya[name][1] < 0.1 * ya[name][0], name
+    print(f"fp16 step: total loss off by HIP {e_hip:.2e} | autocast(fp16) oracle {e_ac:.2e} (float64 total {tot:.4f}); median relative gradient "
+          f"error vs float64: HIP <= {np.median(eh):.3e} | autocast oracle {np.median(ea):.3e}; worst <= {max(eh):.3e} | {max(ea):.3e}")
+    assert np.median(eh) <= 1.1 * np.median(ea) and max(eh) <= 1.5 * max(ea) and e_hip <= 1e-2 * tot
     del eng, model
     torch.cuda.empty_cache()
 
