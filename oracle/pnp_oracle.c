@@ -13,8 +13,10 @@
  * least-squares solve (SOLVEPNP_ITERATIVE), the network pose is kept below 4 correspondences and its translation is kept
  * when the solved one moved more than 1 m (gdrn_evaluator.py:293-296).
  *
- * Minimal solver: P3P on three correspondences, disambiguated by the reprojection error of a fourth (what OpenCV's P3P /
- * AP3P RANSAC models do).  The P3P is the Lambda-Twist formulation (Persson & Nordberg, ECCV 2018), written from its
+ * Minimal solver, two of them (oracle_ransac_pnp_ex's `minimal`; cfg.TEST.PNP_MINIMAL): 1 = EPnP on sets of FIVE with an EPnP refit on
+ * the inliers - what the reference's call names (flags=cv2.SOLVEPNP_EPNP), restated from the EPnP paper further down; 0 = P3P on
+ * three correspondences, disambiguated by the reprojection error of a fourth (what OpenCV's P3P / AP3P RANSAC models do), with a
+ * Gauss-Newton refit - the default, and what a crop with exactly four correspondences takes in either mode.  The P3P is the Lambda-Twist formulation (Persson & Nordberg, ECCV 2018), written from its
  * derivation: depths L = (l1, l2, l3) along the unit bearings y_i satisfy  l_i^2 + l_j^2 + b_ij l_i l_j = a_ij
  * (a_ij = |x_i - x_j|^2, b_ij = -2 y_i.y_j), i.e. three quadrics L^T M_ij L = a_ij.  D1 = a23 M12 - a12 M23 and
  * D2 = a23 M13 - a13 M23 are homogeneous; for a root g of det(D1 + g D2) = 0 the form D0 = D1 + g D2 is a pair of planes
@@ -365,16 +367,383 @@ static void pnp_refit(int n, const float* ip, const float* mp, const unsigned ch
     }
 }
 
+
+/* =====================================================================================================================
+ * EPnP (Lepetit, Moreno-Noguer, Fua: "EPnP: An Accurate O(n) Solution to the PnP Problem", IJCV 2009) - the solver the reference's
+ * call names: cv2.solvePnPRansac(..., flags=cv2.SOLVEPNP_EPNP) (lib/pysixd/misc.py:170-179): RANSAC over MINIMAL SETS OF FIVE
+ * correspondences, each solved by EPnP, and a final EPnP over the inliers of the best model (no iterative refinement).  Restated
+ * from the paper (OpenCV's epnp.cpp follows it step for step; its source is third-party and absent here: PARITY UNPINNED):
+ *   1. four control points: the centroid c0 and c0 + sqrt(lambda_i / n) u_i along the principal directions u_i of the point set;
+ *   2. every model point as an affine combination sum_j alpha_j c_j (barycentric coordinates; with the control points on the
+ *      principal axes the inverse of [c1-c0 c2-c0 c3-c0] is diag(1/k) U^T);
+ *   3. two rows of M (2n x 12) per correspondence: sum_j alpha_j (fu X_j + (uc - u) Z_j) = 0, sum_j alpha_j (fv Y_j + (vc - v) Z_j) = 0
+ *      in the unknown camera-frame control points (X_j Y_j Z_j);
+ *   4. the four eigenvectors v_0..v_3 of M^T M (12 x 12, cyclic Jacobi) with the smallest eigenvalues span the solution:
+ *      x = sum_k beta_k v_k; the betas follow from the six control-point distances (L b = rho, the paper's linearisations for
+ *      N = 4, 2, 3 unknown betas) and five Gauss-Newton steps on the distance constraints;
+ *   5. each of the three beta candidates gives camera-frame control points, hence camera-frame model points, hence (R, t) by
+ *      Horn's absolute orientation; the candidate with the smallest mean reprojection error wins.
+ * Arithmetic: IEEE double, + - * / sqrt only, operation order fixed (the HIP kernel mirrors it: csrc/pnp.hip).
+ */
+#define EP_SWEEPS 30
+
+/* cyclic Jacobi eigen-decomposition of the symmetric n x n matrix A (row-major, both triangles kept): on return diag(A) holds the
+ * eigenvalues and the COLUMNS of V the eigenvectors.  A rotation (p, q) touches row / column k of A and row k of V independently
+ * for every k - the HIP kernel gives those to lanes 0..n-1 and computes exactly these expressions. */
+static void ep_jacobi(int n, double* A, double* V)
+{
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) V[i * n + j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < EP_SWEEPS; sweep++) {
+        double off = 0.0, dg = 0.0;
+        for (int p = 0; p < n; p++) {
+            dg += A[p * n + p] * A[p * n + p];
+            for (int q = p + 1; q < n; q++) off += A[p * n + q] * A[p * n + q];
+        }
+        if (!(off > 1e-30 * dg)) break;
+        for (int p = 0; p < n - 1; p++)
+            for (int q = p + 1; q < n; q++) {
+                const double apq = A[p * n + q];
+                if (apq == 0.0) continue;
+                const double app = A[p * n + p], aqq = A[q * n + q];
+                const double theta = (aqq - app) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < n; k++) {
+                    if (k != p && k != q) {
+                        const double akp = A[k * n + p], akq = A[k * n + q];
+                        const double nkp = c * akp - sn * akq, nkq = sn * akp + c * akq;
+                        A[k * n + p] = nkp; A[p * n + k] = nkp;
+                        A[k * n + q] = nkq; A[q * n + k] = nkq;
+                    }
+                    const double vkp = V[k * n + p], vkq = V[k * n + q];
+                    V[k * n + p] = c * vkp - sn * vkq;
+                    V[k * n + q] = sn * vkp + c * vkq;
+                }
+                A[p * n + p] = app - t * apq;
+                A[q * n + q] = aqq + t * apq;
+                A[p * n + q] = 0.0;
+                A[q * n + p] = 0.0;
+            }
+    }
+}
+
+/* least squares min |A x - b| for an m x n system (n <= 5) through the normal equations (a 1e-13 trace ridge keeps a rank-deficient
+ * linearisation solvable; Gaussian elimination with partial pivoting); 0 if a pivot vanishes */
+static int ep_lsq(int m, int n, const double* A, const double* b, double* x)
+{
+    double N[5][6];
+    for (int i = 0; i < n; i++) {
+        for (int j = 0; j < n; j++) {
+            double s = 0.0;
+            for (int r = 0; r < m; r++) s += A[r * n + i] * A[r * n + j];
+            N[i][j] = s;
+        }
+        double s = 0.0;
+        for (int r = 0; r < m; r++) s += A[r * n + i] * b[r];
+        N[i][n] = s;
+    }
+    double tr = 0.0;
+    for (int i = 0; i < n; i++) tr += N[i][i];
+    for (int i = 0; i < n; i++) N[i][i] += 1e-13 * tr;
+    for (int c = 0; c < n; c++) {
+        int p = c;
+        for (int r = c + 1; r < n; r++)
+            if (fabs(N[r][c]) > fabs(N[p][c])) p = r;
+        if (N[p][c] == 0.0) return 0;
+        if (p != c)
+            for (int k = 0; k <= n; k++) { const double tmp = N[c][k]; N[c][k] = N[p][k]; N[p][k] = tmp; }
+        for (int r = c + 1; r < n; r++) {
+            const double f = N[r][c] / N[c][c];
+            for (int k = c; k <= n; k++) N[r][k] -= f * N[c][k];
+        }
+    }
+    for (int c = n - 1; c >= 0; c--) {
+        double s = N[c][n];
+        for (int k = c + 1; k < n; k++) s -= N[c][k] * x[k];
+        x[c] = s / N[c][c];
+    }
+    return 1;
+}
+
+/* Horn's absolute orientation, S[r][c] = sum (w_r - wbar_r)(c_c - cbar_c): the rotation taking model to camera coordinates */
+static void ep_horn(const double S[9], double R[9])
+{
+    const double Sxx = S[0], Sxy = S[1], Sxz = S[2], Syx = S[3], Syy = S[4], Syz = S[5], Szx = S[6], Szy = S[7], Szz = S[8];
+    double A[16] = {Sxx + Syy + Szz, Syz - Szy, Szx - Sxz, Sxy - Syx,
+                    Syz - Szy, Sxx - Syy - Szz, Sxy + Syx, Szx + Sxz,
+                    Szx - Sxz, Sxy + Syx, -Sxx + Syy - Szz, Syz + Szy,
+                    Sxy - Syx, Szx + Sxz, Syz + Szy, -Sxx - Syy + Szz};
+    double V[16];
+    ep_jacobi(4, A, V);
+    int best = 0;
+    for (int i = 1; i < 4; i++)
+        if (A[i * 4 + i] > A[best * 4 + best]) best = i;
+    double w = V[0 * 4 + best], x = V[1 * 4 + best], y = V[2 * 4 + best], z = V[3 * 4 + best];
+    const double nq = sqrt(w * w + x * x + y * y + z * z);
+    w = w / nq; x = x / nq; y = y / nq; z = z / nq;
+    R[0] = 1.0 - 2.0 * (y * y + z * z); R[1] = 2.0 * (x * y - w * z);       R[2] = 2.0 * (x * z + w * y);
+    R[3] = 2.0 * (x * y + w * z);       R[4] = 1.0 - 2.0 * (x * x + z * z); R[5] = 2.0 * (y * z - w * x);
+    R[6] = 2.0 * (x * z - w * y);       R[7] = 2.0 * (y * z + w * x);       R[8] = 1.0 - 2.0 * (x * x + y * y);
+}
+
+typedef struct {
+    double c0[3];     /* centroid = control point 0 */
+    double U[9];      /* principal directions in the columns */
+    double ik[3];     /* 1 / k_i, k_i = sqrt(lambda_i / n): control point i = c0 + k_i U[:, i-1] */
+    double cws[4][3];
+} ep_frame;
+
+/* barycentric coordinates of model point p */
+static void ep_alphas(const ep_frame* f, const float* p, double a[4])
+{
+    const double d0 = (double)p[0] - f->c0[0], d1 = (double)p[1] - f->c0[1], d2 = (double)p[2] - f->c0[2];
+    a[1] = (f->U[0] * d0 + f->U[3] * d1 + f->U[6] * d2) * f->ik[0];
+    a[2] = (f->U[1] * d0 + f->U[4] * d1 + f->U[7] * d2) * f->ik[1];
+    a[3] = (f->U[2] * d0 + f->U[5] * d1 + f->U[8] * d2) * f->ik[2];
+    a[0] = 1.0 - a[1] - a[2] - a[3];
+}
+
+/* control points from the first and second moments of the point set (sum p, sum p p^T over cnt points); 0 for a (near-)planar set */
+static int ep_frame_from_moments(int cnt, const double sp[3], const double spp[6] /* xx xy xz yy yz zz */, ep_frame* f)
+{
+    const double inv = 1.0 / (double)cnt;
+    for (int c = 0; c < 3; c++) f->c0[c] = sp[c] * inv;
+    double C[9];
+    C[0] = spp[0] - sp[0] * f->c0[0]; C[1] = spp[1] - sp[0] * f->c0[1]; C[2] = spp[2] - sp[0] * f->c0[2];
+    C[4] = spp[3] - sp[1] * f->c0[1]; C[5] = spp[4] - sp[1] * f->c0[2]; C[8] = spp[5] - sp[2] * f->c0[2];
+    C[3] = C[1]; C[6] = C[2]; C[7] = C[5];
+    ep_jacobi(3, C, f->U);
+    double lmax = C[0] > C[4] ? C[0] : C[4];
+    if (C[8] > lmax) lmax = C[8];
+    if (!(lmax > 0.0)) return 0;
+    for (int i = 0; i < 3; i++) {
+        const double lam = C[i * 3 + i];
+        if (!(lam > 1e-12 * lmax)) return 0;  /* planar / collinear set: the barycentric frame is singular */
+        const double k = sqrt(lam * inv);
+        f->ik[i] = 1.0 / k;
+        for (int c = 0; c < 3; c++) f->cws[i + 1][c] = f->c0[c] + k * f->U[c * 3 + i];
+    }
+    for (int c = 0; c < 3; c++) f->cws[0][c] = f->c0[c];
+    return 1;
+}
+
+/* the two rows of M for one correspondence, accumulated into the upper triangle of M^T M (78 entries, row-major over i <= j) */
+static void ep_accumulate_mtm(const double a[4], double u, double v, const double* K4, double* mtm /* [78] */)
+{
+    double r1[12], r2[12];
+    for (int j = 0; j < 4; j++) {
+        r1[3 * j] = a[j] * K4[0]; r1[3 * j + 1] = 0.0;          r1[3 * j + 2] = a[j] * (K4[2] - u);
+        r2[3 * j] = 0.0;          r2[3 * j + 1] = a[j] * K4[1]; r2[3 * j + 2] = a[j] * (K4[3] - v);
+    }
+    int e = 0;
+    for (int i = 0; i < 12; i++)
+        for (int j = i; j < 12; j++, e++) mtm[e] += r1[i] * r1[j] + r2[i] * r2[j];
+}
+
+/* steps 4 - 5 without the pose: from M^T M (upper triangle) to the three beta candidates and the null-space vectors */
+static int ep_betas(const double* mtm, const ep_frame* f, double v[4][12], double betas[3][4])
+{
+    double A[144], V[144];
+    int e = 0;
+    for (int i = 0; i < 12; i++)
+        for (int j = i; j < 12; j++, e++) { A[i * 12 + j] = mtm[e]; A[j * 12 + i] = mtm[e]; }
+    ep_jacobi(12, A, V);
+    /* the four smallest eigenvalues, ascending (ties: lower index first) */
+    int used[12] = {0};
+    for (int k = 0; k < 4; k++) {
+        int best = -1;
+        for (int i = 0; i < 12; i++)
+            if (!used[i] && (best < 0 || A[i * 12 + i] < A[best * 12 + best])) best = i;
+        used[best] = 1;
+        for (int r = 0; r < 12; r++) v[k][r] = V[r * 12 + best];
+    }
+    /* differences of the control-point triples of every null vector over the six pairs, L (6 x 10), rho */
+    static const int pa[6] = {0, 0, 0, 1, 1, 2}, pb[6] = {1, 2, 3, 2, 3, 3};
+    double dv[4][6][3], L[6][10], rho[6];
+    for (int k = 0; k < 4; k++)
+        for (int j = 0; j < 6; j++)
+            for (int c = 0; c < 3; c++) dv[k][j][c] = v[k][3 * pa[j] + c] - v[k][3 * pb[j] + c];
+    for (int j = 0; j < 6; j++) {
+        L[j][0] = dot3(dv[0][j], dv[0][j]);
+        L[j][1] = 2.0 * dot3(dv[0][j], dv[1][j]);
+        L[j][2] = dot3(dv[1][j], dv[1][j]);
+        L[j][3] = 2.0 * dot3(dv[0][j], dv[2][j]);
+        L[j][4] = 2.0 * dot3(dv[1][j], dv[2][j]);
+        L[j][5] = dot3(dv[2][j], dv[2][j]);
+        L[j][6] = 2.0 * dot3(dv[0][j], dv[3][j]);
+        L[j][7] = 2.0 * dot3(dv[1][j], dv[3][j]);
+        L[j][8] = 2.0 * dot3(dv[2][j], dv[3][j]);
+        L[j][9] = dot3(dv[3][j], dv[3][j]);
+        double d[3];
+        for (int c = 0; c < 3; c++) d[c] = f->cws[pa[j]][c] - f->cws[pb[j]][c];
+        rho[j] = dot3(d, d);
+    }
+    double Lsub[30], b5[5];
+    /* N = 4: unknowns b11 b12 b13 b14 (columns 0 1 3 6) */
+    static const int c4[4] = {0, 1, 3, 6};
+    for (int j = 0; j < 6; j++)
+        for (int k = 0; k < 4; k++) Lsub[j * 4 + k] = L[j][c4[k]];
+    for (int k = 0; k < 4; k++) betas[0][k] = 0.0;
+    if (ep_lsq(6, 4, Lsub, rho, b5)) {
+        if (b5[0] < 0.0) { betas[0][0] = sqrt(-b5[0]); betas[0][1] = -b5[1] / betas[0][0]; betas[0][2] = -b5[2] / betas[0][0]; betas[0][3] = -b5[3] / betas[0][0]; }
+        else { betas[0][0] = sqrt(b5[0]); betas[0][1] = b5[1] / betas[0][0]; betas[0][2] = b5[2] / betas[0][0]; betas[0][3] = b5[3] / betas[0][0]; }
+    }
+    /* N = 2: b11 b12 b22 (columns 0 1 2) */
+    for (int j = 0; j < 6; j++)
+        for (int k = 0; k < 3; k++) Lsub[j * 3 + k] = L[j][k];
+    for (int k = 0; k < 4; k++) betas[1][k] = 0.0;
+    if (ep_lsq(6, 3, Lsub, rho, b5)) {
+        if (b5[0] < 0.0) { betas[1][0] = sqrt(-b5[0]); betas[1][1] = b5[2] < 0.0 ? sqrt(-b5[2]) : 0.0; }
+        else { betas[1][0] = sqrt(b5[0]); betas[1][1] = b5[2] > 0.0 ? sqrt(b5[2]) : 0.0; }
+        if (b5[1] < 0.0) betas[1][0] = -betas[1][0];
+    }
+    /* N = 3: b11 b12 b22 b13 b23 (columns 0 1 2 3 4) */
+    for (int j = 0; j < 6; j++)
+        for (int k = 0; k < 5; k++) Lsub[j * 5 + k] = L[j][k];
+    for (int k = 0; k < 4; k++) betas[2][k] = 0.0;
+    if (ep_lsq(6, 5, Lsub, rho, b5)) {
+        if (b5[0] < 0.0) { betas[2][0] = sqrt(-b5[0]); betas[2][1] = b5[2] < 0.0 ? sqrt(-b5[2]) : 0.0; }
+        else { betas[2][0] = sqrt(b5[0]); betas[2][1] = b5[2] > 0.0 ? sqrt(b5[2]) : 0.0; }
+        if (b5[1] < 0.0) betas[2][0] = -betas[2][0];
+        betas[2][2] = betas[2][0] != 0.0 ? b5[3] / betas[2][0] : 0.0;
+    }
+    /* five Gauss-Newton steps on  sum_j (rho_j - beta^T L_j beta)^2  for each candidate */
+    for (int cnd = 0; cnd < 3; cnd++) {
+        double* b = betas[cnd];
+        for (int it = 0; it < 5; it++) {
+            double J[24], r[6], dx[4];
+            for (int j = 0; j < 6; j++) {
+                const double* l = L[j];
+                J[j * 4 + 0] = 2.0 * l[0] * b[0] + l[1] * b[1] + l[3] * b[2] + l[6] * b[3];
+                J[j * 4 + 1] = l[1] * b[0] + 2.0 * l[2] * b[1] + l[4] * b[2] + l[7] * b[3];
+                J[j * 4 + 2] = l[3] * b[0] + l[4] * b[1] + 2.0 * l[5] * b[2] + l[8] * b[3];
+                J[j * 4 + 3] = l[6] * b[0] + l[7] * b[1] + l[8] * b[2] + 2.0 * l[9] * b[3];
+                r[j] = rho[j] - (l[0] * b[0] * b[0] + l[1] * b[0] * b[1] + l[2] * b[1] * b[1] + l[3] * b[0] * b[2] + l[4] * b[1] * b[2]
+                                 + l[5] * b[2] * b[2] + l[6] * b[0] * b[3] + l[7] * b[1] * b[3] + l[8] * b[2] * b[3] + l[9] * b[3] * b[3]);
+            }
+            if (!ep_lsq(6, 4, J, r, dx)) break;
+            for (int k = 0; k < 4; k++) b[k] += dx[k];
+        }
+    }
+    return 1;
+}
+
+/* camera-frame control points of a beta candidate */
+static void ep_ccs(const double v[4][12], const double* b, double ccs[4][3])
+{
+    for (int j = 0; j < 4; j++)
+        for (int c = 0; c < 3; c++)
+            ccs[j][c] = b[0] * v[0][3 * j + c] + b[1] * v[1][3 * j + c] + b[2] * v[2][3 * j + c] + b[3] * v[3][3 * j + c];
+}
+
+/* EPnP over the correspondences listed in idx[0..cnt) (idx == NULL: all i < cnt with use[i] != 0, or all when use == NULL).
+ * Returns 0 when the set is degenerate. */
+static int epnp_solve(int cnt_or_n, const int* idx, const unsigned char* use, const float* ip, const float* mp, const double* K4, double* R, double* t)
+{
+    /* pass 1: moments */
+    double sp[3] = {0, 0, 0}, spp[6] = {0, 0, 0, 0, 0, 0};
+    int cnt = 0, first = -1;
+    for (int q = 0; q < cnt_or_n; q++) {
+        const int i = idx ? idx[q] : q;
+        if (!idx && use && !use[i]) continue;
+        const double x = mp[3 * i], y = mp[3 * i + 1], z = mp[3 * i + 2];
+        sp[0] += x; sp[1] += y; sp[2] += z;
+        spp[0] += x * x; spp[1] += x * y; spp[2] += x * z; spp[3] += y * y; spp[4] += y * z; spp[5] += z * z;
+        if (first < 0) first = i;
+        cnt++;
+    }
+    if (cnt < 4) return 0;
+    ep_frame f;
+    if (!ep_frame_from_moments(cnt, sp, spp, &f)) return 0;
+    /* pass 2: M^T M */
+    double mtm[78];
+    for (int e = 0; e < 78; e++) mtm[e] = 0.0;
+    for (int q = 0; q < cnt_or_n; q++) {
+        const int i = idx ? idx[q] : q;
+        if (!idx && use && !use[i]) continue;
+        double a[4];
+        ep_alphas(&f, mp + 3 * i, a);
+        ep_accumulate_mtm(a, (double)ip[2 * i], (double)ip[2 * i + 1], K4, mtm);
+    }
+    double v[4][12], betas[3][4];
+    if (!ep_betas(mtm, &f, v, betas)) return 0;
+    /* pass 3: per candidate the camera-frame points' moments against the model points', Horn, mean reprojection error */
+    double a1[4];
+    ep_alphas(&f, mp + 3 * first, a1);
+    int bestc = -1;
+    double beste = HUGE_VAL;
+    for (int cnd = 0; cnd < 3; cnd++) {
+        double ccs[4][3];
+        ep_ccs(v, betas[cnd], ccs);
+        /* the eigenvectors' sign is arbitrary: the first point must lie in front of the camera */
+        const double z1 = a1[0] * ccs[0][2] + a1[1] * ccs[1][2] + a1[2] * ccs[2][2] + a1[3] * ccs[3][2];
+        if (z1 < 0.0)
+            for (int j = 0; j < 4; j++)
+                for (int c = 0; c < 3; c++) ccs[j][c] = -ccs[j][c];
+        double sc[3] = {0, 0, 0}, swc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int q = 0; q < cnt_or_n; q++) {
+            const int i = idx ? idx[q] : q;
+            if (!idx && use && !use[i]) continue;
+            double a[4], pc[3];
+            ep_alphas(&f, mp + 3 * i, a);
+            for (int c = 0; c < 3; c++) pc[c] = a[0] * ccs[0][c] + a[1] * ccs[1][c] + a[2] * ccs[2][c] + a[3] * ccs[3][c];
+            for (int c = 0; c < 3; c++) sc[c] += pc[c];
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 3; c++) swc[r * 3 + c] += (double)mp[3 * i + r] * pc[c];
+        }
+        const double inv = 1.0 / (double)cnt;
+        double S[9], Rc[9], tc[3], cbar[3];
+        for (int c = 0; c < 3; c++) cbar[c] = sc[c] * inv;
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) S[r * 3 + c] = swc[r * 3 + c] - sp[r] * cbar[c];  /* sum (w - wbar)(c - cbar)^T */
+        ep_horn(S, Rc);
+        for (int r = 0; r < 3; r++) tc[r] = cbar[r] - (Rc[r * 3] * f.c0[0] + Rc[r * 3 + 1] * f.c0[1] + Rc[r * 3 + 2] * f.c0[2]);
+        double err = 0.0;
+        for (int q = 0; q < cnt_or_n; q++) {
+            const int i = idx ? idx[q] : q;
+            if (!idx && use && !use[i]) continue;
+            const double e2 = reproj_err2(Rc, tc, K4, mp + 3 * i, ip + 2 * i);
+            err += e2 < HUGE_VAL ? sqrt(e2) : 1e12;
+        }
+        if (err < beste) {
+            beste = err;
+            bestc = cnd;
+            memcpy(R, Rc, sizeof(Rc));
+            memcpy(t, tc, sizeof(tc));
+        }
+    }
+    return bestc >= 0 && beste < HUGE_VAL;
+}
+
+/* hypothesis h of crop b with the EPnP minimal solver: five distinct correspondences (n >= 5) */
+static int epnp_hypothesis(unsigned seed, unsigned b, unsigned h, int n, const float* ip, const float* mp, const double* K4, double* R, double* t)
+{
+    for (unsigned tr = 0; tr < 8; tr++) {
+        int idx[5], dup = 0;
+        for (int j = 0; j < 5; j++) idx[j] = (int)(pnp_hash(seed, b, h, tr, (unsigned)j) % (unsigned)n);
+        for (int i = 0; i < 5; i++)
+            for (int j = i + 1; j < 5; j++) dup |= idx[i] == idx[j];
+        if (dup) continue;
+        if (epnp_solve(5, idx, NULL, ip, mp, K4, R, t)) return 1;
+    }
+    return 0;
+}
+
 /*
  * image_points [B][HW][2], model_points [B][HW][3] (first counts[b] rows valid: the output of the correspondence selection),
  * cams [B][9] (K row-major), net_pose [B][12] or NULL.  mode 0: plain RANSAC; 1: network pose = hypothesis 0; 2: no RANSAC,
  * Gauss-Newton from the network pose over all correspondences.
  * pose_out [B][12] (R row-major | t), n_inliers [B], inlier_mask [B][HW] (indexed like the correspondence lists), best_hyp [B].
  */
-void oracle_ransac_pnp(const float* image_points, const float* model_points, const int* counts, const float* cams, const float* net_pose,
-                       int B, int HW, float reproj_thr, int iters, float confidence, unsigned seed, int mode, float max_t_diff,
-                       float* pose_out, int* n_inliers, unsigned char* inlier_mask, int* best_hyp)
+/* minimal: 0 = P3P + 1 (sets of 4, Gauss-Newton refit: the round-2 solver), 1 = EPnP (sets of 5, EPnP refit on the inliers: the
+ * solver the reference's call names, cfg.TEST.PNP_MINIMAL = "epnp") */
+void oracle_ransac_pnp_ex(const float* image_points, const float* model_points, const int* counts, const float* cams, const float* net_pose,
+                          int B, int HW, float reproj_thr, int iters, float confidence, unsigned seed, int mode, float max_t_diff, int minimal,
+                          float* pose_out, int* n_inliers, unsigned char* inlier_mask, int* best_hyp)
 {
+    /* (exactly four correspondences: EPnP's null space is then four-dimensional and its linearisations are not a solver - measured 21
+     *  degrees off on exact data; such a crop takes the P3P + 1 path, which is exact on four points) */
     if (iters > PNP_MAX_ITERS) iters = PNP_MAX_ITERS;
     const double thr2 = (double)reproj_thr * (double)reproj_thr;
     for (int b = 0; b < B; b++) {
@@ -383,6 +752,7 @@ void oracle_ransac_pnp(const float* image_points, const float* model_points, con
         unsigned char* msk = inlier_mask + (size_t)b * HW;
         float* po = pose_out + b * 12;
         const int n = counts[b];
+        const int epnp = minimal == 1 && n >= 5, msize = epnp ? 5 : 4;
         const double K4[4] = {cams[b * 9 + 0], cams[b * 9 + 4], cams[b * 9 + 2], cams[b * 9 + 5]};
         memset(msk, 0, (size_t)HW);
         n_inliers[b] = 0;
@@ -412,7 +782,8 @@ void oracle_ransac_pnp(const float* image_points, const float* model_points, con
                     for (int i = 0; i < 3; i++) th[0][i] = net_pose[b * 12 + 9 + i];
                     ok = 1;
                 } else {
-                    ok = pnp_hypothesis(seed, (unsigned)b, (unsigned)h, n, ip, mp, K4, Rh[h], th[h]);
+                    ok = epnp ? epnp_hypothesis(seed, (unsigned)b, (unsigned)h, n, ip, mp, K4, Rh[h], th[h])
+                                      : pnp_hypothesis(seed, (unsigned)b, (unsigned)h, n, ip, mp, K4, Rh[h], th[h]);
                 }
                 if (!ok) continue;
                 int cnt = 0;
@@ -422,11 +793,11 @@ void oracle_ransac_pnp(const float* image_points, const float* model_points, con
             int best = -1, best_cnt = 0, niters = iters;
             for (int h = 0; h < iters && h < niters; h++) {
                 const int cnt = cnts[h];
-                if (cnt > best_cnt && cnt >= 4) {
+                if (cnt > best_cnt && cnt >= msize) {
                     best = h;
                     best_cnt = cnt;
                     const double w = (double)cnt / (double)n;
-                    const double miss = 1.0 - w * w * w * w, target = 1.0 - (double)confidence;
+                    const double miss = 1.0 - (msize == 5 ? w * w * w * w * w : w * w * w * w), target = 1.0 - (double)confidence;
                     double prod = 1.0;
                     int k = 0;
                     while (prod > target && k < iters) { prod *= miss; k++; }
@@ -442,7 +813,12 @@ void oracle_ransac_pnp(const float* image_points, const float* model_points, con
             memcpy(R, Rh[best], sizeof(R));
             memcpy(t, th[best], sizeof(t));
             for (int i = 0; i < n; i++) msk[i] = reproj_err2(R, t, K4, mp + 3 * i, ip + 2 * i) < thr2 ? 1 : 0;
-            pnp_refit(n, ip, mp, msk, K4, R, t);
+            if (epnp) {  /* solvePnP(inliers, SOLVEPNP_EPNP); a degenerate inlier set keeps the minimal model */
+                double Rr[9], tr3[3];
+                if (epnp_solve(n, NULL, msk, ip, mp, K4, Rr, tr3)) { memcpy(R, Rr, sizeof(R)); memcpy(t, tr3, sizeof(t)); }
+            } else {
+                pnp_refit(n, ip, mp, msk, K4, R, t);
+            }
         }
         for (int i = 0; i < 9; i++) po[i] = (float)R[i];
         for (int i = 0; i < 3; i++) po[9 + i] = (float)t[i];
@@ -453,4 +829,19 @@ void oracle_ransac_pnp(const float* image_points, const float* model_points, con
                 for (int i = 0; i < 3; i++) po[9 + i] = net_pose[b * 12 + 9 + i];
         }
     }
+}
+
+void oracle_ransac_pnp(const float* image_points, const float* model_points, const int* counts, const float* cams, const float* net_pose,
+                       int B, int HW, float reproj_thr, int iters, float confidence, unsigned seed, int mode, float max_t_diff,
+                       float* pose_out, int* n_inliers, unsigned char* inlier_mask, int* best_hyp)
+{
+    oracle_ransac_pnp_ex(image_points, model_points, counts, cams, net_pose, B, HW, reproj_thr, iters, confidence, seed, mode, max_t_diff, 0,
+                         pose_out, n_inliers, inlier_mask, best_hyp);
+}
+
+/* EPnP on its own over the first n correspondences (tests: noise-free data must give back the pose) */
+int oracle_epnp(const float* image_points, const float* model_points, int n, const float* cam9, double* R, double* t)
+{
+    const double K4[4] = {cam9[0], cam9[4], cam9[2], cam9[5]};
+    return epnp_solve(n, NULL, NULL, image_points, model_points, K4, R, t);
 }

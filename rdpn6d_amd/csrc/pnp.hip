@@ -417,6 +417,393 @@ __device__ static int solve6(double H[6][6], double g[6])
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------------
+// EPnP minimal solver (cfg.TEST.PNP_MINIMAL = "epnp"; rdpn6d_ransac_pnp_ex minimal = 1): what the reference's call names -
+// cv2.solvePnPRansac(..., flags=cv2.SOLVEPNP_EPNP), lib/pysixd/misc.py:170-179: minimal sets of FIVE, EPnP refit on the inliers.
+// The executable specification is oracle/pnp_oracle.c (ep_* functions, restated from the EPnP paper); every function here is that
+// code operation by operation.  One hypothesis per wavefront as before: the small linear algebra (3x3 / 4x4 Jacobi, 6x{3,4,5} least
+// squares, Gauss-Newton on the betas, Horn) runs redundantly on all 64 lanes (uniform data); the 12x12 part does not fit registers
+// and goes through a per-wavefront LDS scratch: M^T M one entry per lane, the cyclic Jacobi with row / column k of a rotation on
+// lane k (k < 12) - the oracle's per-k expressions, so eigenvalues and eigenvectors come out bit for bit.
+#define EP_SWEEPS 30
+
+template <int N>
+__device__ static void ep_jacobi_small(double* A, double* V)
+{
+    for (int i = 0; i < N; i++)
+        for (int j = 0; j < N; j++) V[i * N + j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < EP_SWEEPS; sweep++) {
+        double off = 0.0, dg = 0.0;
+        for (int p = 0; p < N; p++) {
+            dg += A[p * N + p] * A[p * N + p];
+            for (int q = p + 1; q < N; q++) off += A[p * N + q] * A[p * N + q];
+        }
+        if (!(off > 1e-30 * dg)) break;
+        for (int p = 0; p < N - 1; p++)
+            for (int q = p + 1; q < N; q++) {
+                const double apq = A[p * N + q];
+                if (apq == 0.0) continue;
+                const double app = A[p * N + p], aqq = A[q * N + q];
+                const double theta = (aqq - app) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < N; k++) {
+                    if (k != p && k != q) {
+                        const double akp = A[k * N + p], akq = A[k * N + q];
+                        const double nkp = c * akp - sn * akq, nkq = sn * akp + c * akq;
+                        A[k * N + p] = nkp; A[p * N + k] = nkp;
+                        A[k * N + q] = nkq; A[q * N + k] = nkq;
+                    }
+                    const double vkp = V[k * N + p], vkq = V[k * N + q];
+                    V[k * N + p] = c * vkp - sn * vkq;
+                    V[k * N + q] = sn * vkp + c * vkq;
+                }
+                A[p * N + p] = app - t * apq;
+                A[q * N + q] = aqq + t * apq;
+                A[p * N + q] = 0.0;
+                A[q * N + p] = 0.0;
+            }
+    }
+}
+
+// the 12 x 12 form on one wavefront: A, V [144] in LDS, lane k < 12 owns row / column k of every rotation; all lanes hold the
+// (uniform) rotation parameters.  LDS operations of one wavefront execute in program order; the wave barriers keep the compiler
+// from moving an access across a step another lane depends on.
+__device__ static void ep_jacobi12_wave(double* A, double* V, int lane)
+{
+    for (int e = lane; e < 144; e += 64) V[e] = (e / 12) == (e % 12) ? 1.0 : 0.0;
+    __builtin_amdgcn_wave_barrier();
+    for (int sweep = 0; sweep < EP_SWEEPS; sweep++) {
+        double off = 0.0, dg = 0.0;
+        for (int p = 0; p < 12; p++) {
+            dg += A[p * 12 + p] * A[p * 12 + p];
+            for (int q = p + 1; q < 12; q++) off += A[p * 12 + q] * A[p * 12 + q];
+        }
+        if (!(off > 1e-30 * dg)) break;
+        for (int p = 0; p < 11; p++)
+            for (int q = p + 1; q < 12; q++) {
+                const double apq = A[p * 12 + q];
+                if (apq == 0.0) continue;  // uniform
+                const double app = A[p * 12 + p], aqq = A[q * 12 + q];
+                const double theta = (aqq - app) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                __builtin_amdgcn_wave_barrier();
+                const int k = lane;
+                if (k < 12) {
+                    if (k != p && k != q) {
+                        const double akp = A[k * 12 + p], akq = A[k * 12 + q];
+                        const double nkp = c * akp - sn * akq, nkq = sn * akp + c * akq;
+                        A[k * 12 + p] = nkp; A[p * 12 + k] = nkp;
+                        A[k * 12 + q] = nkq; A[q * 12 + k] = nkq;
+                    }
+                    const double vkp = V[k * 12 + p], vkq = V[k * 12 + q];
+                    V[k * 12 + p] = c * vkp - sn * vkq;
+                    V[k * 12 + q] = sn * vkp + c * vkq;
+                }
+                if (lane == 0) {
+                    A[p * 12 + p] = app - t * apq;
+                    A[q * 12 + q] = aqq + t * apq;
+                    A[p * 12 + q] = 0.0;
+                    A[q * 12 + p] = 0.0;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+    }
+}
+
+__device__ static int ep_lsq(int m, int n, const double* A, const double* b, double* x)
+{
+    double N[5][6];
+    for (int i = 0; i < n; i++) {
+        for (int j = 0; j < n; j++) {
+            double s = 0.0;
+            for (int r = 0; r < m; r++) s += A[r * n + i] * A[r * n + j];
+            N[i][j] = s;
+        }
+        double s = 0.0;
+        for (int r = 0; r < m; r++) s += A[r * n + i] * b[r];
+        N[i][n] = s;
+    }
+    double tr = 0.0;
+    for (int i = 0; i < n; i++) tr += N[i][i];
+    for (int i = 0; i < n; i++) N[i][i] += 1e-13 * tr;
+    for (int c = 0; c < n; c++) {
+        int p = c;
+        for (int r = c + 1; r < n; r++)
+            if (fabs(N[r][c]) > fabs(N[p][c])) p = r;
+        if (N[p][c] == 0.0) return 0;
+        if (p != c)
+            for (int k = 0; k <= n; k++) { const double tmp = N[c][k]; N[c][k] = N[p][k]; N[p][k] = tmp; }
+        for (int r = c + 1; r < n; r++) {
+            const double f = N[r][c] / N[c][c];
+            for (int k = c; k <= n; k++) N[r][k] -= f * N[c][k];
+        }
+    }
+    for (int c = n - 1; c >= 0; c--) {
+        double s = N[c][n];
+        for (int k = c + 1; k < n; k++) s -= N[c][k] * x[k];
+        x[c] = s / N[c][c];
+    }
+    return 1;
+}
+
+__device__ static void ep_horn(const double* S, double* R)
+{
+    const double Sxx = S[0], Sxy = S[1], Sxz = S[2], Syx = S[3], Syy = S[4], Syz = S[5], Szx = S[6], Szy = S[7], Szz = S[8];
+    double A[16] = {Sxx + Syy + Szz, Syz - Szy, Szx - Sxz, Sxy - Syx,
+                    Syz - Szy, Sxx - Syy - Szz, Sxy + Syx, Szx + Sxz,
+                    Szx - Sxz, Sxy + Syx, -Sxx + Syy - Szz, Syz + Szy,
+                    Sxy - Syx, Szx + Sxz, Syz + Szy, -Sxx - Syy + Szz};
+    double V[16];
+    ep_jacobi_small<4>(A, V);
+    int best = 0;
+    for (int i = 1; i < 4; i++)
+        if (A[i * 4 + i] > A[best * 4 + best]) best = i;
+    double w = V[0 * 4 + best], x = V[1 * 4 + best], y = V[2 * 4 + best], z = V[3 * 4 + best];
+    const double nq = sqrt(w * w + x * x + y * y + z * z);
+    w = w / nq; x = x / nq; y = y / nq; z = z / nq;
+    R[0] = 1.0 - 2.0 * (y * y + z * z); R[1] = 2.0 * (x * y - w * z);       R[2] = 2.0 * (x * z + w * y);
+    R[3] = 2.0 * (x * y + w * z);       R[4] = 1.0 - 2.0 * (x * x + z * z); R[5] = 2.0 * (y * z - w * x);
+    R[6] = 2.0 * (x * z - w * y);       R[7] = 2.0 * (y * z + w * x);       R[8] = 1.0 - 2.0 * (x * x + y * y);
+}
+
+struct ep_frame {
+    double c0[3], U[9], ik[3], cws[4][3];
+};
+
+__device__ static void ep_alphas(const ep_frame& f, const float* p, double* a)
+{
+    const double d0 = (double)p[0] - f.c0[0], d1 = (double)p[1] - f.c0[1], d2 = (double)p[2] - f.c0[2];
+    a[1] = (f.U[0] * d0 + f.U[3] * d1 + f.U[6] * d2) * f.ik[0];
+    a[2] = (f.U[1] * d0 + f.U[4] * d1 + f.U[7] * d2) * f.ik[1];
+    a[3] = (f.U[2] * d0 + f.U[5] * d1 + f.U[8] * d2) * f.ik[2];
+    a[0] = 1.0 - a[1] - a[2] - a[3];
+}
+
+__device__ static int ep_frame_from_moments(int cnt, const double* sp, const double* spp, ep_frame& f)
+{
+    const double inv = 1.0 / (double)cnt;
+    for (int c = 0; c < 3; c++) f.c0[c] = sp[c] * inv;
+    double C[9];
+    C[0] = spp[0] - sp[0] * f.c0[0]; C[1] = spp[1] - sp[0] * f.c0[1]; C[2] = spp[2] - sp[0] * f.c0[2];
+    C[4] = spp[3] - sp[1] * f.c0[1]; C[5] = spp[4] - sp[1] * f.c0[2]; C[8] = spp[5] - sp[2] * f.c0[2];
+    C[3] = C[1]; C[6] = C[2]; C[7] = C[5];
+    ep_jacobi_small<3>(C, f.U);
+    double lmax = C[0] > C[4] ? C[0] : C[4];
+    if (C[8] > lmax) lmax = C[8];
+    if (!(lmax > 0.0)) return 0;
+    for (int i = 0; i < 3; i++) {
+        const double lam = C[i * 3 + i];
+        if (!(lam > 1e-12 * lmax)) return 0;
+        const double k = sqrt(lam * inv);
+        f.ik[i] = 1.0 / k;
+        for (int c = 0; c < 3; c++) f.cws[i + 1][c] = f.c0[c] + k * f.U[c * 3 + i];
+    }
+    for (int c = 0; c < 3; c++) f.cws[0][c] = f.c0[c];
+    return 1;
+}
+
+// element `col` of the two rows of M of one correspondence (oracle ep_accumulate_mtm's r1 / r2)
+__device__ __forceinline__ void ep_row_elem(const double* a, double u, double v, const double* K4, int col, double& r1, double& r2)
+{
+    const int j = col / 3, c = col - 3 * j;
+    const double aj = a[j];
+    r1 = c == 0 ? aj * K4[0] : (c == 1 ? 0.0 : aj * (K4[2] - u));
+    r2 = c == 0 ? 0.0 : (c == 1 ? aj * K4[1] : aj * (K4[3] - v));
+}
+
+// from the null-space vectors vv[4][12] (LDS or registers) to the three beta candidates (oracle ep_betas after the Jacobi step)
+__device__ static void ep_betas_from_null(const double* vv /* [4][12] */, const ep_frame& f, double betas[3][4])
+{
+    const int pa[6] = {0, 0, 0, 1, 1, 2}, pb[6] = {1, 2, 3, 2, 3, 3};
+    double L[6][10], rho[6];
+    for (int j = 0; j < 6; j++) {
+        double dv[4][3];
+        for (int k = 0; k < 4; k++)
+            for (int c = 0; c < 3; c++) dv[k][c] = vv[k * 12 + 3 * pa[j] + c] - vv[k * 12 + 3 * pb[j] + c];
+        L[j][0] = dot3(dv[0], dv[0]);
+        L[j][1] = 2.0 * dot3(dv[0], dv[1]);
+        L[j][2] = dot3(dv[1], dv[1]);
+        L[j][3] = 2.0 * dot3(dv[0], dv[2]);
+        L[j][4] = 2.0 * dot3(dv[1], dv[2]);
+        L[j][5] = dot3(dv[2], dv[2]);
+        L[j][6] = 2.0 * dot3(dv[0], dv[3]);
+        L[j][7] = 2.0 * dot3(dv[1], dv[3]);
+        L[j][8] = 2.0 * dot3(dv[2], dv[3]);
+        L[j][9] = dot3(dv[3], dv[3]);
+        double d[3];
+        for (int c = 0; c < 3; c++) d[c] = f.cws[pa[j]][c] - f.cws[pb[j]][c];
+        rho[j] = dot3(d, d);
+    }
+    double Lsub[30], b5[5];
+    const int c4[4] = {0, 1, 3, 6};
+    for (int j = 0; j < 6; j++)
+        for (int k = 0; k < 4; k++) Lsub[j * 4 + k] = L[j][c4[k]];
+    for (int k = 0; k < 4; k++) betas[0][k] = 0.0;
+    if (ep_lsq(6, 4, Lsub, rho, b5)) {
+        if (b5[0] < 0.0) { betas[0][0] = sqrt(-b5[0]); betas[0][1] = -b5[1] / betas[0][0]; betas[0][2] = -b5[2] / betas[0][0]; betas[0][3] = -b5[3] / betas[0][0]; }
+        else { betas[0][0] = sqrt(b5[0]); betas[0][1] = b5[1] / betas[0][0]; betas[0][2] = b5[2] / betas[0][0]; betas[0][3] = b5[3] / betas[0][0]; }
+    }
+    for (int j = 0; j < 6; j++)
+        for (int k = 0; k < 3; k++) Lsub[j * 3 + k] = L[j][k];
+    for (int k = 0; k < 4; k++) betas[1][k] = 0.0;
+    if (ep_lsq(6, 3, Lsub, rho, b5)) {
+        if (b5[0] < 0.0) { betas[1][0] = sqrt(-b5[0]); betas[1][1] = b5[2] < 0.0 ? sqrt(-b5[2]) : 0.0; }
+        else { betas[1][0] = sqrt(b5[0]); betas[1][1] = b5[2] > 0.0 ? sqrt(b5[2]) : 0.0; }
+        if (b5[1] < 0.0) betas[1][0] = -betas[1][0];
+    }
+    for (int j = 0; j < 6; j++)
+        for (int k = 0; k < 5; k++) Lsub[j * 5 + k] = L[j][k];
+    for (int k = 0; k < 4; k++) betas[2][k] = 0.0;
+    if (ep_lsq(6, 5, Lsub, rho, b5)) {
+        if (b5[0] < 0.0) { betas[2][0] = sqrt(-b5[0]); betas[2][1] = b5[2] < 0.0 ? sqrt(-b5[2]) : 0.0; }
+        else { betas[2][0] = sqrt(b5[0]); betas[2][1] = b5[2] > 0.0 ? sqrt(b5[2]) : 0.0; }
+        if (b5[1] < 0.0) betas[2][0] = -betas[2][0];
+        betas[2][2] = betas[2][0] != 0.0 ? b5[3] / betas[2][0] : 0.0;
+    }
+    for (int cnd = 0; cnd < 3; cnd++) {
+        double* b = betas[cnd];
+        for (int it = 0; it < 5; it++) {
+            double J[24], r[6], dx[4];
+            for (int j = 0; j < 6; j++) {
+                const double* l = L[j];
+                J[j * 4 + 0] = 2.0 * l[0] * b[0] + l[1] * b[1] + l[3] * b[2] + l[6] * b[3];
+                J[j * 4 + 1] = l[1] * b[0] + 2.0 * l[2] * b[1] + l[4] * b[2] + l[7] * b[3];
+                J[j * 4 + 2] = l[3] * b[0] + l[4] * b[1] + 2.0 * l[5] * b[2] + l[8] * b[3];
+                J[j * 4 + 3] = l[6] * b[0] + l[7] * b[1] + l[8] * b[2] + 2.0 * l[9] * b[3];
+                r[j] = rho[j] - (l[0] * b[0] * b[0] + l[1] * b[0] * b[1] + l[2] * b[1] * b[1] + l[3] * b[0] * b[2] + l[4] * b[1] * b[2]
+                                 + l[5] * b[2] * b[2] + l[6] * b[0] * b[3] + l[7] * b[1] * b[3] + l[8] * b[2] * b[3] + l[9] * b[3] * b[3]);
+            }
+            if (!ep_lsq(6, 4, J, r, dx)) break;
+            for (int k = 0; k < 4; k++) b[k] += dx[k];
+        }
+    }
+}
+
+// after the Jacobi step on the wavefront's scratch: the four smallest eigenvalues' vectors go to rows 0..3 of A (= vv[4][12])
+__device__ static void ep_pick_null_vectors(double* A, const double* V, int lane)
+{
+    int sel[4];
+    bool used[12];
+    for (int i = 0; i < 12; i++) used[i] = false;
+    for (int k = 0; k < 4; k++) {
+        int best = -1;
+        for (int i = 0; i < 12; i++)
+            if (!used[i] && (best < 0 || A[i * 12 + i] < A[best * 12 + best])) best = i;
+        used[best] = true;
+        sel[k] = best;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 48) {
+        const int k = lane / 12, r = lane - 12 * k;
+        A[k * 12 + r] = V[r * 12 + sel[k]];
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ static void ep_ccs(const double* vv, const double* b, double ccs[4][3])
+{
+    for (int j = 0; j < 4; j++)
+        for (int c = 0; c < 3; c++)
+            ccs[j][c] = b[0] * vv[3 * j + c] + b[1] * vv[12 + 3 * j + c] + b[2] * vv[24 + 3 * j + c] + b[3] * vv[36 + 3 * j + c];
+}
+
+/* EPnP over the cnt (= 5) correspondences idx[]: one wavefront, uniform data, scratch = this wavefront's A | V [288] in LDS */
+__device__ static int epnp_solve_minimal(int cnt, const int* idx, const float* ip, const float* mp, const double* K4, double* scratch, int lane,
+                                         double* R, double* t)
+{
+    double sp[3] = {0, 0, 0}, spp[6] = {0, 0, 0, 0, 0, 0};
+    for (int q = 0; q < cnt; q++) {
+        const int i = idx[q];
+        const double x = mp[3 * i], y = mp[3 * i + 1], z = mp[3 * i + 2];
+        sp[0] += x; sp[1] += y; sp[2] += z;
+        spp[0] += x * x; spp[1] += x * y; spp[2] += x * z; spp[3] += y * y; spp[4] += y * z; spp[5] += z * z;
+    }
+    ep_frame f;
+    if (!ep_frame_from_moments(cnt, sp, spp, f)) return 0;  // uniform
+    double* A = scratch;
+    double* V = scratch + 144;
+    // M^T M: upper-triangle entry e on lane e (and e + 64), the correspondences in order
+    for (int e = lane; e < 78; e += 64) {
+        int i = 0, rem = e;
+        while (rem >= 12 - i) { rem -= 12 - i; i++; }
+        const int j = i + rem;
+        double acc = 0.0;
+        for (int q = 0; q < cnt; q++) {
+            double a[4], r1i, r2i, r1j, r2j;
+            ep_alphas(f, mp + 3 * idx[q], a);
+            const double u = (double)ip[2 * idx[q]], v = (double)ip[2 * idx[q] + 1];
+            ep_row_elem(a, u, v, K4, i, r1i, r2i);
+            ep_row_elem(a, u, v, K4, j, r1j, r2j);
+            acc += r1i * r1j + r2i * r2j;
+        }
+        A[i * 12 + j] = acc;
+        A[j * 12 + i] = acc;
+    }
+    __builtin_amdgcn_wave_barrier();
+    ep_jacobi12_wave(A, V, lane);
+    ep_pick_null_vectors(A, V, lane);
+    double betas[3][4];
+    ep_betas_from_null(A, f, betas);
+    double a1[4];
+    ep_alphas(f, mp + 3 * idx[0], a1);
+    int bestc = -1;
+    double beste = PNP_HUGE;
+    for (int cnd = 0; cnd < 3; cnd++) {
+        double ccs[4][3];
+        ep_ccs(A, betas[cnd], ccs);
+        const double z1 = a1[0] * ccs[0][2] + a1[1] * ccs[1][2] + a1[2] * ccs[2][2] + a1[3] * ccs[3][2];
+        if (z1 < 0.0)
+            for (int j = 0; j < 4; j++)
+                for (int c = 0; c < 3; c++) ccs[j][c] = -ccs[j][c];
+        double sc[3] = {0, 0, 0}, swc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int q = 0; q < cnt; q++) {
+            const int i = idx[q];
+            double a[4], pc[3];
+            ep_alphas(f, mp + 3 * i, a);
+            for (int c = 0; c < 3; c++) pc[c] = a[0] * ccs[0][c] + a[1] * ccs[1][c] + a[2] * ccs[2][c] + a[3] * ccs[3][c];
+            for (int c = 0; c < 3; c++) sc[c] += pc[c];
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 3; c++) swc[r * 3 + c] += (double)mp[3 * i + r] * pc[c];
+        }
+        const double inv = 1.0 / (double)cnt;
+        double S[9], Rc[9], tc[3], cbar[3];
+        for (int c = 0; c < 3; c++) cbar[c] = sc[c] * inv;
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) S[r * 3 + c] = swc[r * 3 + c] - sp[r] * cbar[c];
+        ep_horn(S, Rc);
+        for (int r = 0; r < 3; r++) tc[r] = cbar[r] - (Rc[r * 3] * f.c0[0] + Rc[r * 3 + 1] * f.c0[1] + Rc[r * 3 + 2] * f.c0[2]);
+        double err = 0.0;
+        for (int q = 0; q < cnt; q++) {
+            const double e2 = reproj_err2(Rc, tc, K4, mp + 3 * idx[q], ip + 2 * idx[q]);
+            err += e2 < PNP_HUGE ? sqrt(e2) : 1e12;
+        }
+        if (err < beste) {
+            beste = err;
+            bestc = cnd;
+            for (int i = 0; i < 9; i++) R[i] = Rc[i];
+            for (int i = 0; i < 3; i++) t[i] = tc[i];
+        }
+    }
+    return bestc >= 0 && beste < PNP_HUGE;
+}
+
+/* hypothesis h of crop b, EPnP minimal solver: five distinct correspondences (n >= 5) */
+__device__ static int epnp_hypothesis(unsigned seed, unsigned b, unsigned h, int n, const float* ip, const float* mp, const double* K4, double* scratch,
+                                      int lane, double* R, double* t)
+{
+    for (unsigned tr = 0; tr < 8; tr++) {
+        int idx[5], dup = 0;
+        for (int j = 0; j < 5; j++) idx[j] = (int)(pnp_hash(seed, b, h, tr, (unsigned)j) % (unsigned)n);
+        for (int i = 0; i < 5; i++)
+            for (int j = i + 1; j < 5; j++) dup |= idx[i] == idx[j];
+        if (dup) continue;
+        if (epnp_solve_minimal(5, idx, ip, mp, K4, scratch, lane, R, t)) return 1;
+    }
+    return 0;
+}
+
 // deterministic block-wide sum of NV doubles (fixed butterfly + fixed wave order); result to all threads
 template <int NV>
 __device__ __forceinline__ void pnp_block_sum(double* v, double* s_buf /* [PNP_WAVES * NV] */)
@@ -466,6 +853,148 @@ __device__ static int pnp_solve6(double (&H)[6][6], double (&g)[6])
     return 1;
 }
 
+// EPnP over the winner's inliers (this thread's points i = tid + k * PNP_THREADS flagged in use_bits), the whole workgroup: moments,
+// M^T M and the per-candidate sums are block reductions (fixed tree: deterministic, but not the oracle's serial order - the refit
+// agrees with it to ~1e-9 like the Gauss-Newton one), the 12 x 12 Jacobi runs on wavefront 0's scratch, everything else redundantly
+// on every thread.  Writes s_cur (R | t) and returns 1 (uniform) when the inlier set was solvable.
+template <int CH>
+__device__ __forceinline__ void ep_mtm_chunk(const double* r1, const double* r2, double* acc /* [26] */)
+{
+    int e = 0;
+#pragma unroll
+    for (int i = 0; i < 12; i++)
+#pragma unroll
+        for (int j = i; j < 12; j++, e++)
+            if (e >= CH * 26 && e < CH * 26 + 26) acc[e - CH * 26] += r1[i] * r1[j] + r2[i] * r2[j];
+}
+template <int CH>
+__device__ static void ep_mtm_pass(int n, const unsigned* use_bits, const ep_frame& f, const float* s_ip, const float* s_mp, const double* K4,
+                                   double* s_red, double* A)
+{
+    double acc[26];
+#pragma unroll
+    for (int q = 0; q < 26; q++) acc[q] = 0.0;
+    int k = 0;
+    for (int i = threadIdx.x; i < n; i += PNP_THREADS, k++) {
+        if (!((use_bits[k >> 5] >> (k & 31)) & 1u)) continue;
+        double a[4], r1[12], r2[12];
+        ep_alphas(f, s_mp + 3 * i, a);
+        const double u = (double)s_ip[2 * i], v = (double)s_ip[2 * i + 1];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            r1[3 * j] = a[j] * K4[0]; r1[3 * j + 1] = 0.0;          r1[3 * j + 2] = a[j] * (K4[2] - u);
+            r2[3 * j] = 0.0;          r2[3 * j + 1] = a[j] * K4[1]; r2[3 * j + 2] = a[j] * (K4[3] - v);
+        }
+        ep_mtm_chunk<CH>(r1, r2, acc);
+    }
+    pnp_block_sum<26>(acc, s_red);
+    if (threadIdx.x == 0) {
+        int e = 0;
+        for (int i = 0; i < 12; i++)
+            for (int j = i; j < 12; j++, e++)
+                if (e >= CH * 26 && e < CH * 26 + 26) { A[i * 12 + j] = acc[e - CH * 26]; A[j * 12 + i] = acc[e - CH * 26]; }
+    }
+}
+
+__device__ static int epnp_refit_block(int n, const unsigned* use_bits, const float* s_ip, const float* s_mp, const double* K4, double* s_red,
+                                       double* scratch, double* s_cur)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double m[10];
+#pragma unroll
+    for (int q = 0; q < 10; q++) m[q] = 0.0;
+    int first = 0x7fffffff, k = 0;
+    for (int i = tid; i < n; i += PNP_THREADS, k++) {
+        if (!((use_bits[k >> 5] >> (k & 31)) & 1u)) continue;
+        const double x = s_mp[3 * i], y = s_mp[3 * i + 1], z = s_mp[3 * i + 2];
+        m[0] += x; m[1] += y; m[2] += z;
+        m[3] += x * x; m[4] += x * y; m[5] += x * z; m[6] += y * y; m[7] += y * z; m[8] += z * z;
+        m[9] += 1.0;
+        if (i < first) first = i;
+    }
+    pnp_block_sum<10>(m, s_red);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(first, o); first = other < first ? other : first; }
+    __syncthreads();
+    if (lane == 0) s_red[wave] = (double)first;
+    __syncthreads();
+    for (int wv = 0; wv < PNP_WAVES; wv++) { const int fw = (int)s_red[wv]; first = fw < first ? fw : first; }
+    __syncthreads();
+    const int cnt = (int)m[9];
+    if (cnt < 5) return 0;
+    ep_frame f;
+    if (!ep_frame_from_moments(cnt, m, m + 3, f)) return 0;
+    double* A = scratch;
+    double* V = scratch + 144;
+    ep_mtm_pass<0>(n, use_bits, f, s_ip, s_mp, K4, s_red, A);
+    ep_mtm_pass<1>(n, use_bits, f, s_ip, s_mp, K4, s_red, A);
+    ep_mtm_pass<2>(n, use_bits, f, s_ip, s_mp, K4, s_red, A);
+    __syncthreads();
+    if (wave == 0) {
+        ep_jacobi12_wave(A, V, lane);
+        ep_pick_null_vectors(A, V, lane);
+    }
+    __syncthreads();
+    double betas[3][4];
+    ep_betas_from_null(A, f, betas);
+    double a1[4];
+    ep_alphas(f, s_mp + 3 * first, a1);
+    int bestc = -1;
+    double beste = PNP_HUGE, Rb[9], tb[3];
+    for (int cnd = 0; cnd < 3; cnd++) {
+        double ccs[4][3];
+        ep_ccs(A, betas[cnd], ccs);
+        const double z1 = a1[0] * ccs[0][2] + a1[1] * ccs[1][2] + a1[2] * ccs[2][2] + a1[3] * ccs[3][2];
+        if (z1 < 0.0)
+            for (int j = 0; j < 4; j++)
+                for (int c = 0; c < 3; c++) ccs[j][c] = -ccs[j][c];
+        double acc[12];
+#pragma unroll
+        for (int q = 0; q < 12; q++) acc[q] = 0.0;
+        k = 0;
+        for (int i = tid; i < n; i += PNP_THREADS, k++) {
+            if (!((use_bits[k >> 5] >> (k & 31)) & 1u)) continue;
+            double a[4], pc[3];
+            ep_alphas(f, s_mp + 3 * i, a);
+            for (int c = 0; c < 3; c++) pc[c] = a[0] * ccs[0][c] + a[1] * ccs[1][c] + a[2] * ccs[2][c] + a[3] * ccs[3][c];
+            for (int c = 0; c < 3; c++) acc[c] += pc[c];
+            for (int r = 0; r < 3; r++)
+                for (int c = 0; c < 3; c++) acc[3 + r * 3 + c] += (double)s_mp[3 * i + r] * pc[c];
+        }
+        pnp_block_sum<12>(acc, s_red);
+        const double inv = 1.0 / (double)cnt;
+        double S[9], Rc[9], tc[3], cbar[3];
+        for (int c = 0; c < 3; c++) cbar[c] = acc[c] * inv;
+        for (int r = 0; r < 3; r++)
+            for (int c = 0; c < 3; c++) S[r * 3 + c] = acc[3 + r * 3 + c] - m[r] * cbar[c];
+        ep_horn(S, Rc);
+        for (int r = 0; r < 3; r++) tc[r] = cbar[r] - (Rc[r * 3] * f.c0[0] + Rc[r * 3 + 1] * f.c0[1] + Rc[r * 3 + 2] * f.c0[2]);
+        double err[1] = {0.0};
+        k = 0;
+        for (int i = tid; i < n; i += PNP_THREADS, k++) {
+            if (!((use_bits[k >> 5] >> (k & 31)) & 1u)) continue;
+            const double e2 = reproj_err2(Rc, tc, K4, s_mp + 3 * i, s_ip + 2 * i);
+            err[0] += e2 < PNP_HUGE ? sqrt(e2) : 1e12;
+        }
+        pnp_block_sum<1>(err, s_red);
+        if (err[0] < beste) {
+            beste = err[0];
+            bestc = cnd;
+            for (int i = 0; i < 9; i++) Rb[i] = Rc[i];
+            for (int i = 0; i < 3; i++) tb[i] = tc[i];
+        }
+    }
+    const int ok = bestc >= 0 && beste < PNP_HUGE;
+    __syncthreads();
+    if (ok && tid == 0) {
+        for (int i = 0; i < 9; i++) s_cur[i] = Rb[i];
+        for (int i = 0; i < 3; i++) s_cur[9 + i] = tb[i];
+    }
+    __syncthreads();
+    return ok;
+}
+
+template <bool EPNP>
 __global__ __launch_bounds__(PNP_THREADS) void ransac_pnp_kernel(
     const float* __restrict__ image_points, const float* __restrict__ model_points, const int* __restrict__ counts,
     const float* __restrict__ cams, const float* __restrict__ net_pose, int HW, float reproj_thr, int iters, float confidence,
@@ -476,13 +1005,17 @@ __global__ __launch_bounds__(PNP_THREADS) void ransac_pnp_kernel(
     double* s_red = reinterpret_cast<double*>(pnp_smem);               // PNP_WAVES * 27
     double* s_pose = s_red + PNP_WAVES * 27;                           // 12 * PNP_MAX_ITERS (R | t per hypothesis)
     double* s_cur = s_pose + 12 * PNP_MAX_ITERS;                       // 12: the pose being refined
-    int* s_cnt = reinterpret_cast<int*>(s_cur + 12);                   // PNP_MAX_ITERS
+    double* s_ep = s_cur + 12;                                         // EPNP: PNP_WAVES * 288 (a wavefront's 12 x 12 A | V)
+    int* s_cnt = reinterpret_cast<int*>(s_ep + (EPNP ? PNP_WAVES * 288 : 0));  // PNP_MAX_ITERS
     int* s_misc = s_cnt + PNP_MAX_ITERS;                               // 4
     float* s_ip = reinterpret_cast<float*>(s_misc + 4);                // 2 * HW
     float* s_mp = s_ip + 2 * (size_t)HW;                               // 3 * HW
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = counts[b];
+    // (exactly four correspondences: EPnP's null space is four-dimensional there - such a crop takes the P3P + 1 path in either mode)
+    const bool epnp = EPNP && n >= 5;
+    const int msize = epnp ? 5 : 4;
     const double K4[4] = {(double)cams[b * 9 + 0], (double)cams[b * 9 + 4], (double)cams[b * 9 + 2], (double)cams[b * 9 + 5]};
     const double thr2 = (double)reproj_thr * (double)reproj_thr;
     float* po = pose_out + b * 12;
@@ -516,7 +1049,8 @@ __global__ __launch_bounds__(PNP_THREADS) void ransac_pnp_kernel(
                 for (int i = 0; i < 3; i++) t[i] = (double)net_pose[b * 12 + 9 + i];
                 ok = 1;
             } else {
-                ok = pnp_hypothesis(seed, (unsigned)b, (unsigned)h, n, s_ip, s_mp, K4, R, t);
+                ok = epnp ? epnp_hypothesis(seed, (unsigned)b, (unsigned)h, n, s_ip, s_mp, K4, s_ep + wave * 288, lane, R, t)
+                          : pnp_hypothesis(seed, (unsigned)b, (unsigned)h, n, s_ip, s_mp, K4, R, t);
             }
             if (!ok) continue;  // wave-uniform
             int cnt = 0;
@@ -537,11 +1071,11 @@ __global__ __launch_bounds__(PNP_THREADS) void ransac_pnp_kernel(
             int niters = iters;
             for (int h = 0; h < iters && h < niters; h++) {
                 const int cnt = s_cnt[h];
-                if (cnt > best_cnt && cnt >= 4) {
+                if (cnt > best_cnt && cnt >= msize) {
                     best = h;
                     best_cnt = cnt;
                     const double w = (double)cnt / (double)n;
-                    const double miss = 1.0 - w * w * w * w, target = 1.0 - (double)confidence;
+                    const double miss = 1.0 - (msize == 5 ? w * w * w * w * w : w * w * w * w), target = 1.0 - (double)confidence;
                     double prod = 1.0;
                     int k = 0;
                     while (prod > target && k < iters) { prod *= miss; k++; }
@@ -582,7 +1116,11 @@ __global__ __launch_bounds__(PNP_THREADS) void ransac_pnp_kernel(
             if (mode != 2 && in) msk[i] = 1;
         }
     }
-    for (int it = 0; it < PNP_REFIT_ITERS; it++) {
+    if (epnp && mode != 2) {
+        // solvePnP(inliers, SOLVEPNP_EPNP): the final model of the reference's call; a degenerate inlier set keeps the minimal model
+        epnp_refit_block(n, use_bits, s_ip, s_mp, K4, s_red, s_ep, s_cur);
+    }
+    for (int it = 0; it < ((epnp && mode != 2) ? 0 : PNP_REFIT_ITERS); it++) {
         double R[9], t[3];
 #pragma unroll
         for (int i = 0; i < 9; i++) R[i] = s_cur[i];
@@ -669,9 +1207,10 @@ __global__ __launch_bounds__(PNP_THREADS) void ransac_pnp_kernel(
     }
 }
 
-size_t pnp_smem_bytes(int HW)
+size_t pnp_smem_bytes(int HW, bool epnp)
 {
-    size_t s = sizeof(double) * (PNP_WAVES * 27 + 12 * PNP_MAX_ITERS + 12) + sizeof(int) * (PNP_MAX_ITERS + 4) + sizeof(float) * 5 * (size_t)HW;
+    size_t s = sizeof(double) * (PNP_WAVES * 27 + 12 * PNP_MAX_ITERS + 12 + (epnp ? PNP_WAVES * 288 : 0)) + sizeof(int) * (PNP_MAX_ITERS + 4)
+               + sizeof(float) * 5 * (size_t)HW;
     return (s + 15) & ~(size_t)15;
 }
 
@@ -681,22 +1220,40 @@ size_t pnp_smem_bytes(int HW)
 // net_pose [B,12] or NULL.  mode 0: RANSAC (TEST.PNP_TYPE = "ransac_pnp"); 1: the network pose is hypothesis 0
 // ("net_ransac_pnp", 20 iterations in the reference); 2: Gauss-Newton from the network pose over all correspondences
 // ("net_iter_pnp").  inlier_mask [B,HW] is indexed like the correspondence lists.
+// minimal: 0 = P3P + 1 (sets of 4, Gauss-Newton refit), 1 = EPnP (sets of 5, EPnP refit on the inliers: cv2.SOLVEPNP_EPNP's structure,
+// lib/pysixd/misc.py:170-179; cfg.TEST.PNP_MINIMAL = "epnp")
+extern "C" int rdpn6d_ransac_pnp_ex(const float* image_points, const float* model_points, const int* counts, const float* cams,
+                                    const float* net_pose, int B, int HW, float reproj_thr, int iters, float confidence, unsigned seed,
+                                    int mode, float max_t_diff, int minimal, float* pose_out, int* n_inliers, unsigned char* inlier_mask,
+                                    int* best_hyp, void* stream)
+{
+    RD_REQUIRE(image_points && model_points && counts && cams && pose_out && n_inliers && inlier_mask && best_hyp, "null pointer");
+    RD_REQUIRE(B > 0 && HW > 0 && HW <= 6400, "HW must be in 1..6400 (LDS-resident correspondences)");
+    RD_REQUIRE(mode >= 0 && mode <= 2 && (mode == 0 || net_pose), "mode 0 | 1 | 2 (1 and 2 need the network pose)");
+    RD_REQUIRE(minimal == 0 || minimal == 1, "minimal solver: 0 P3P + 1 | 1 EPnP");
+    RD_REQUIRE(iters >= 1 && iters <= PNP_MAX_ITERS && reproj_thr > 0.f && confidence > 0.f && confidence < 1.f, "iterations / thresholds");
+    RD_REQUIRE(mode == 0 || max_t_diff > 0.f, "max_t_diff");
+    RD_REQUIRE(pose_out != net_pose, "pose_out must not alias net_pose");
+    const size_t smem = pnp_smem_bytes(HW, minimal == 1);
+    RD_REQUIRE(smem <= 160 * 1024, "correspondences do not fit the 160 KiB LDS");
+    if (minimal == 1) {
+        RD_LDS_OPT_IN(ransac_pnp_kernel<true>, 160 * 1024);
+        hipLaunchKernelGGL(ransac_pnp_kernel<true>, dim3(B), dim3(PNP_THREADS), smem, (hipStream_t)stream, image_points, model_points, counts, cams,
+                           net_pose, HW, reproj_thr, iters, confidence, seed, mode, max_t_diff, pose_out, n_inliers, inlier_mask, best_hyp);
+    } else {
+        RD_LDS_OPT_IN(ransac_pnp_kernel<false>, 160 * 1024);
+        hipLaunchKernelGGL(ransac_pnp_kernel<false>, dim3(B), dim3(PNP_THREADS), smem, (hipStream_t)stream, image_points, model_points, counts, cams,
+                           net_pose, HW, reproj_thr, iters, confidence, seed, mode, max_t_diff, pose_out, n_inliers, inlier_mask, best_hyp);
+    }
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}
+
 extern "C" int rdpn6d_ransac_pnp_f32(const float* image_points, const float* model_points, const int* counts, const float* cams,
                                      const float* net_pose, int B, int HW, float reproj_thr, int iters, float confidence, unsigned seed,
                                      int mode, float max_t_diff, float* pose_out, int* n_inliers, unsigned char* inlier_mask,
                                      int* best_hyp, void* stream)
 {
-    RD_REQUIRE(image_points && model_points && counts && cams && pose_out && n_inliers && inlier_mask && best_hyp, "null pointer");
-    RD_REQUIRE(B > 0 && HW > 0 && HW <= 6400, "HW must be in 1..6400 (LDS-resident correspondences)");
-    RD_REQUIRE(mode >= 0 && mode <= 2 && (mode == 0 || net_pose), "mode 0 | 1 | 2 (1 and 2 need the network pose)");
-    RD_REQUIRE(iters >= 1 && iters <= PNP_MAX_ITERS && reproj_thr > 0.f && confidence > 0.f && confidence < 1.f, "iterations / thresholds");
-    RD_REQUIRE(mode == 0 || max_t_diff > 0.f, "max_t_diff");
-    RD_REQUIRE(pose_out != net_pose, "pose_out must not alias net_pose");
-    const size_t smem = pnp_smem_bytes(HW);
-    RD_REQUIRE(smem <= 160 * 1024, "correspondences do not fit the 160 KiB LDS");
-    RD_LDS_OPT_IN(ransac_pnp_kernel, 160 * 1024);
-    hipLaunchKernelGGL(ransac_pnp_kernel, dim3(B), dim3(PNP_THREADS), smem, (hipStream_t)stream, image_points, model_points, counts, cams,
-                       net_pose, HW, reproj_thr, iters, confidence, seed, mode, max_t_diff, pose_out, n_inliers, inlier_mask, best_hyp);
-    RD_LAUNCH_CHECK();
-    return RDPN6D_OK;
+    return rdpn6d_ransac_pnp_ex(image_points, model_points, counts, cams, net_pose, B, HW, reproj_thr, iters, confidence, seed, mode, max_t_diff, 0,
+                                pose_out, n_inliers, inlier_mask, best_hyp, stream);
 }

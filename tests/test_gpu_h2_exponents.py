@@ -157,14 +157,18 @@ def test_calibrate_h2_sets_the_exponents_before_any_overflow(golden_dir):
     assert err < 1e-4
 
 
-def test_lowered_exponents_do_not_change_a_network_that_never_needed_them(golden_dir):
-    """the exponent is pure bookkeeping: with EVERY variable two binades down on the ordinary fixture (activations O(1): nothing near
-    either end of the format) the maps move by round-off of the lo terms only (<= 2e-6), the plan is still h2, nothing is flagged"""
+def test_lowered_exponents_cost_round_off_only(golden_dir):
+    """the exponent is bookkeeping, not arithmetic: with EVERY variable two binades down on the ordinary fixture (activations O(1))
+    the plan is still h2, nothing is flagged, and the maps stay inside the bare 1e-4 of the float64 evaluation.  They are NOT
+    bit-identical: an h2 record's lo term is an fp16 subnormal below |a| * 2^e = 2^-3, so small activations keep a few bits less at a
+    smaller exponent (absolute error 2^-25 / 2^e) - fp32-ulp-sized differences, which this fixture amplifies ~1e3-fold like any other
+    round-off (measured: 2.9e-5 between e = 4 and e = 2).  That is why the default stays at 4 and tensors are lowered one at a time."""
     from rdpn6d_amd import synth
 
     dev = torch.device("cuda:0")
     sd = _weights(golden_dir)
     inp = synth.make_inputs(4, seed=5)
+    want = _oracle64(sd, inp)
     t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in inp.items()}
     model = _model(sd)
     base = _fwd(model, t)
@@ -175,6 +179,7 @@ def test_lowered_exponents_do_not_change_a_network_that_never_needed_them(golden
     low = _fwd(model, t)
     assert model.plan(4, dev) is not plan and model.plan(4, dev).fast == "h2" and not model.h2_range_exceeded(dev)
     d = max((low[k] - base[k]).abs().max().item() for k in MAPS)
-    same = sum(int(torch.equal(low[k], base[k])) for k in MAPS)
-    print(f"all {len(names)} exponents 4 -> 2: maps max-abs difference {d:.1e} ({same} of 5 maps bit-identical)")
-    assert d <= 2e-6
+    e_base = max((base[k].cpu().double() - want[k]).abs().max().item() for k in MAPS)
+    e_low = max((low[k].cpu().double() - want[k]).abs().max().item() for k in MAPS)
+    print(f"all {len(names)} exponents 4 -> 2: maps move by {d:.1e}; max-abs vs float64 {e_base:.1e} (default) -> {e_low:.1e}")
+    assert e_base < 1e-4 and e_low < 1e-4 and d < 1e-4

@@ -12,18 +12,19 @@ from tests.ransac_cases import pose_errors
 P = ctypes.c_void_p
 
 
-def run_pnp_oracle(lib, c, net_pose=None, reproj_thr=3.0, iters=100, conf=0.99, seed=7, mode=0, max_t_diff=1.0):
+def run_pnp_oracle(lib, c, net_pose=None, reproj_thr=3.0, iters=100, conf=0.99, seed=7, mode=0, max_t_diff=1.0, minimal="p3p"):
+    """minimal: "p3p" (sets of 4, Gauss-Newton refit) | "epnp" (sets of 5, EPnP refit: cv2.SOLVEPNP_EPNP's structure)"""
     B, HW = c["B"], c["HW"]
     pose, nin = np.zeros((B, 12), np.float32), np.zeros(B, np.int32)
     msk, best = np.zeros((B, HW), np.uint8), np.zeros(B, np.int32)
-    f = lib.oracle_ransac_pnp
+    f = lib.oracle_ransac_pnp_ex
     f.argtypes = [P, P, P, P, P, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_float, ctypes.c_uint, ctypes.c_int,
-                  ctypes.c_float, P, P, P, P]
+                  ctypes.c_float, ctypes.c_int, P, P, P, P]
     f.restype = None
     keep = [np.ascontiguousarray(c[k]) for k in ("image_points", "model_points", "counts", "cams")]
     npz = np.ascontiguousarray(net_pose, dtype=np.float32) if net_pose is not None else None
     f(*[k.ctypes.data_as(P) for k in keep], npz.ctypes.data_as(P) if npz is not None else None, B, HW, reproj_thr, iters, conf, seed, mode,
-      max_t_diff, pose.ctypes.data_as(P), nin.ctypes.data_as(P), msk.ctypes.data_as(P), best.ctypes.data_as(P))
+      max_t_diff, {"p3p": 0, "epnp": 1}[minimal], pose.ctypes.data_as(P), nin.ctypes.data_as(P), msk.ctypes.data_as(P), best.ctypes.data_as(P))
     return pose, nin, msk, best
 
 
@@ -89,3 +90,59 @@ def test_pnp_deterministic_and_seed_dependent(oracle_lib):
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
     assert not np.array_equal(a[3], d[3]) or not np.array_equal(a[2], d[2])
     assert (a[3] >= 0).all() and (a[3] < 100).all()
+
+
+# ----------------------------------------------------------------------------------------------------------------- EPnP minimal solver
+def test_epnp_alone_is_exact_on_exact_data(oracle_lib):
+    """the EPnP restatement (control points, barycentric coordinates, null space of M^T M, betas, Horn) on noise-free correspondences:
+    five points - the RANSAC's minimal set - and two hundred give the pose back to fp32 pixel precision"""
+    c = make_pnp_case(B=3, n=[5, 6, 200], noise_px=0.0, outliers=0.0, seed=4)
+    oracle_lib.oracle_epnp.restype = ctypes.c_int
+    for b in range(3):
+        R, t = np.zeros(9), np.zeros(3)
+        ip, mp, cam = (np.ascontiguousarray(c[k][b]) for k in ("image_points", "model_points", "cams"))
+        ok = oracle_lib.oracle_epnp(ip.ctypes.data_as(P), mp.ctypes.data_as(P), int(c["counts"][b]), cam.ctypes.data_as(P), R.ctypes.data_as(P),
+                                    t.ctypes.data_as(P))
+        re, te = pose_errors(np.concatenate([R, t]).astype(np.float32), c["R"][b], c["t"][b])
+        assert ok == 1 and re < 0.05 and te < 1e-5 and abs(np.linalg.det(R.reshape(3, 3)) - 1.0) < 1e-12, (b, ok, re, te)
+    # a planar point set has no barycentric frame: refused, not a wrong pose
+    flat = np.ascontiguousarray(c["model_points"][2]).copy()
+    flat[:, 2] = 0.0
+    assert oracle_lib.oracle_epnp(ip.ctypes.data_as(P), flat.ctypes.data_as(P), 200, cam.ctypes.data_as(P), R.ctypes.data_as(P), t.ctypes.data_as(P)) == 0
+
+
+@pytest.mark.parametrize("outliers", [0.0, 0.3, 0.5])
+def test_epnp_ransac_recovers_known_pose_like_p3p(oracle_lib, outliers):
+    """cfg.TEST.PNP_MINIMAL = "epnp" - five-point minimal sets, the call site's 100 iterations / 3 px / 0.99, EPnP refit
+    on the inliers (lib/pysixd/misc.py:170-179) - recovers the analytic pose at 0 - 50 % outliers, with an inlier set comparable to the
+    P3P + 1 solver's on the same data (both are consensus sets of ONE minimal model under 1 px noise)."""
+    c = make_pnp_case(B=4, outliers=outliers, seed=int(outliers * 10))
+    pe, ne, me, be = run_pnp_oracle(oracle_lib, c, minimal="epnp")
+    pp, np_, mp_, bp = run_pnp_oracle(oracle_lib, c, minimal="p3p")
+    for b in range(c["B"]):
+        n = int(c["counts"][b])
+        clean = c["clean"][b, :n]
+        for nm, pose, msk, nin, best in (("epnp", pe, me, ne, be), ("p3p", pp, mp_, np_, bp)):
+            re, te = pose_errors(pose[b], c["R"][b], c["t"][b])
+            assert best[b] >= 0 and re < 1.0 and te < 0.02, (nm, b, re, te)
+            assert msk[b, :n][clean].mean() > 0.6 and (not (~clean).any() or msk[b, :n][~clean].mean() < 0.02), (nm, b)
+            assert nin[b] == msk[b].sum() and msk[b, n:].sum() == 0
+        both = (me[b, :n] & mp_[b, :n]).sum() / max(1, (me[b, :n] | mp_[b, :n]).sum())
+        assert both > 0.6, (b, both)  # the two consensus sets overlap (intersection over union)
+
+
+def test_epnp_minimal_counts_and_determinism(oracle_lib):
+    """n = 4: EPnP's null space is four-dimensional there - the crop takes the P3P + 1 path (exact); n = 5: the one minimal set;
+    below 4 the sentinel; same seed same answer, another seed another winner"""
+    c = make_pnp_case(B=3, n=[4, 5, 200], noise_px=0.0, outliers=0.0, seed=4)
+    pose, nin, msk, best = run_pnp_oracle(oracle_lib, c, minimal="epnp")
+    for b in range(3):
+        re, te = pose_errors(pose[b], c["R"][b], c["t"][b])
+        assert re < 0.05 and te < 1e-5 and nin[b] == c["counts"][b], (b, re, te, nin[b])
+    c = make_pnp_case(B=2, n=[3, 0], seed=5)
+    pose, nin, msk, best = run_pnp_oracle(oracle_lib, c, minimal="epnp")
+    assert (pose == -100).all() and (nin == 0).all() and (best == -1).all()
+    c = make_pnp_case(B=2, outliers=0.4, seed=11)
+    a, b, d = (run_pnp_oracle(oracle_lib, c, seed=s_, minimal="epnp") for s_ in (1, 1, 2))
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    assert not np.array_equal(a[3], d[3]) or not np.array_equal(a[2], d[2])
