@@ -603,6 +603,17 @@ int rdpn6d_select_correspondences_mt_f32(const float* out_nchw, int C, const flo
 int rdpn6d_ransac_pnp_f32(const float* image_points, const float* model_points, const int* counts, const float* cams,
                           const float* net_pose, int B, int HW, float reproj_thr, int iters, float confidence, unsigned seed, int mode,
                           float max_t_diff, float* pose_out, int* n_inliers, unsigned char* inlier_mask, int* best_hyp, void* stream);
+/* ... with the minimal solver as an argument (cfg.TEST.PNP_MINIMAL): minimal 0 = the entry above (P3P + 1 on sets of 4, Gauss-Newton
+ * refit); minimal 1 = EPnP - what the reference's call names: cv2.solvePnPRansac(..., flags=cv2.SOLVEPNP_EPNP), lib/pysixd/misc.py:170-179
+ * (called from gdrn_evaluator.py:261-292 / :386-389): minimal sets of FIVE, each solved by EPnP (control points, barycentric
+ * coordinates, null space of M^T M by a 12 x 12 Jacobi on the wavefront's LDS scratch, betas + Gauss-Newton, Horn), confidence stop
+ * on w^5, and a final EPnP over the inliers of the best model (no iterative refinement).  A crop with exactly four correspondences
+ * takes the P3P + 1 path in either mode (EPnP's null space is four-dimensional there).  Masks / counts / winner bit-exact vs
+ * oracle_ransac_pnp_ex (oracle/pnp_oracle.c, restated from the EPnP paper; cv2 absent: PARITY UNPINNED), the refit pose to ~1e-9. */
+int rdpn6d_ransac_pnp_ex(const float* image_points, const float* model_points, const int* counts, const float* cams,
+                         const float* net_pose, int B, int HW, float reproj_thr, int iters, float confidence, unsigned seed,
+                         int mode, float max_t_diff, int minimal, float* pose_out, int* n_inliers, unsigned char* inlier_mask,
+                         int* best_hyp, void* stream);
 /* rank 1: GPU crop builder (core/gdrn_modeling/data_loader.py:523-627, core/utils/data_utils.py:81-152; cv2.warpAffine
  * bilinear arithmetic restated, parity with cv2 unpinned).  images [N,H,W,3] u8, depths [N,H,W] f32; per ROI: image index,
  * inverse affine maps for the R and R/4 crops (6 doubles each), fx fy cx cy of (A @ K), resize_ratio ->

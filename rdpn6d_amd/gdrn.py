@@ -1273,7 +1273,7 @@ class InferencePlan:
         g.replay()
 
     def run_pnp2d(self, roi_coord_2d, roi_extents, roi_cams, im_hw, uv_channels, mask_thr=0.5, reproj_thr=3.0, iters=100, confidence=0.99,
-                  seed=0, net_mode=0, max_t_diff=1.0):
+                  seed=0, net_mode=0, max_t_diff=1.0, minimal=0):
         """the reference's classical solve on the maps the last run() left in out_nchw: correspondence selection exactly as
         get_img_model_points_with_coords2d (row A8, bit-exact) + per-crop 2D-3D RANSAC-PnP (rows A9 / A10).
         im_hw: (B, 2) int32 device tensor, [H, W] of the image each crop comes from."""
@@ -1292,9 +1292,9 @@ class InferencePlan:
             netp[:, :9].copy_(self.rot.view(B, 9))
             netp[:, 9:].copy_(self.trans)
         cams = roi_cams.reshape(B, 9)
-        _lib.check(self.lib.rdpn6d_ransac_pnp_f32(_ptr(ip), _ptr(mp), _ptr(cnt), _ptr(cams), _ptr(netp), B, HW, reproj_thr, iters, confidence,
-                                                  seed, net_mode, max_t_diff, _ptr(self.pnp_pose), _ptr(self.pnp_ninl), _ptr(self.pnp_mask),
-                                                  _ptr(self.pnp_best), st), "ransac_pnp")
+        _lib.check(self.lib.rdpn6d_ransac_pnp_ex(_ptr(ip), _ptr(mp), _ptr(cnt), _ptr(cams), _ptr(netp), B, HW, reproj_thr, iters, confidence,
+                                                 seed, net_mode, max_t_diff, int(minimal), _ptr(self.pnp_pose), _ptr(self.pnp_ninl),
+                                                 _ptr(self.pnp_mask), _ptr(self.pnp_best), st), "ransac_pnp")
         self.pnp_counts = cnt
 
     def run_ransac(self, roi_coord_2d, fps, roi_extents, resize_ratios, mask_thr=0.5, inlier_thr=0.01, iters=100,
@@ -1741,6 +1741,12 @@ class GDRN(_TreeWatch, nn.Module):
             if pnp_type not in modes:
                 raise NotImplementedError(f"TEST.PNP_TYPE={pnp_type!r}: one of {sorted(modes)}")
             net_mode, kabsch = modes[pnp_type], pnp_type.endswith("kabsch")
+            # cfg.TEST.PNP_MINIMAL (2D-3D types): "p3p" (default: P3P + 1 on sets of four, Gauss-Newton refit) | "epnp" - the solver the
+            # reference's own call names, cv2.SOLVEPNP_EPNP (lib/pysixd/misc.py:170-179): sets of five, EPnP refit on the inliers
+            pm = str(tcfg.get("PNP_MINIMAL", "p3p")).lower()
+            if pm not in ("p3p", "epnp"):
+                raise ValueError(f"TEST.PNP_MINIMAL={pm!r}: p3p | epnp")
+            pnp_minimal = 1 if pm == "epnp" else 0
             # both solves read the mask like get_out_mask (engine_utils.py:118-136): L1 per-crop min-max, BCE sigmoid, CE arg-max
             # (the plan's mask_type, handed to the selection / RANSAC kernels)
             assert roi_extents is not None, "USE_PNP needs roi_extents"
@@ -1784,7 +1790,7 @@ class GDRN(_TreeWatch, nn.Module):
                                    mask_thr=float(self.cfg.MODEL.CDPN.ROT_HEAD.MASK_THR_TEST),
                                    reproj_thr=float(tcfg.get("PNP_REPROJ_THR", 3.0)), iters=int(tcfg.get("PNP_ITERS", 20 if net_mode == 1 else 100)),
                                    confidence=float(tcfg.get("PNP_CONFIDENCE", 0.99)), seed=int(tcfg.get("PNP_SEED", 0)), net_mode=net_mode,
-                                   max_t_diff=float(tcfg.get("PNP_MAX_T_DIFF", 1.0)))
+                                   max_t_diff=float(tcfg.get("PNP_MAX_T_DIFF", 1.0)), minimal=pnp_minimal)
                 elif use_pnp:
                     kabsch_solve()
 

@@ -333,12 +333,14 @@ def ransac_kabsch(out_nchw, coord2d, fps, extents, resize_ratios, region_argmax,
 
 
 def ransac_pnp(image_points, model_points, counts, cams, reproj_thr=3.0, iters=100, confidence=0.99, seed=0, net_pose=None,
-               net_mode="ransac", max_t_diff=1.0):
+               net_mode="ransac", max_t_diff=1.0, minimal="p3p"):
     """2D-3D RANSAC-PnP per crop (rdpn6d_ransac_pnp_f32; the role of misc.pnp_v2 -> cv2.solvePnPRansac(EPnP, 3 px, 100 iterations) at
     gdrn_evaluator.py:316-435).  image_points [B,HW,2] px, model_points [B,HW,3] m, counts [B] int32 from
     select_correspondences; cams [B,3,3].  With net_pose [B,12]: net_mode "ransac" = the learned pose is hypothesis 0, "iter" =
     Gauss-Newton from it over all correspondences (process_net_and_pnp).  Returns pose [B,12] (R row-major | t; -100 when fewer
-    than 4 correspondences), n_inliers [B], inlier_mask [B,HW] (indexed like the lists), best_hyp [B]."""
+    than 4 correspondences), n_inliers [B], inlier_mask [B,HW] (indexed like the lists), best_hyp [B].
+    minimal (cfg.TEST.PNP_MINIMAL): "p3p" = P3P + 1 on sets of four with a Gauss-Newton refit (default) | "epnp" = the solver the
+    reference's call names (flags=cv2.SOLVEPNP_EPNP): EPnP on sets of five, EPnP refit on the inliers."""
     _need_gpu(image_points, model_points, counts, cams)
     B, HW = image_points.shape[0], image_points.shape[1]
     dev = image_points.device
@@ -350,9 +352,9 @@ def ransac_pnp(image_points, model_points, counts, cams, reproj_thr=3.0, iters=1
     assert args[2].dtype == torch.int32
     npz = net_pose.float().contiguous() if net_pose is not None else None
     mode = 0 if net_pose is None else {"ransac": 1, "iter": 2}[net_mode]
-    _lib.check(_lib.load().rdpn6d_ransac_pnp_f32(*[_ptr(t) for t in args], _ptr(npz), B, HW, float(reproj_thr), int(iters), float(confidence),
-                                                 int(seed), mode, float(max_t_diff), _ptr(pose), _ptr(nin), _ptr(mask), _ptr(best), _stream()),
-               "ransac_pnp")
+    _lib.check(_lib.load().rdpn6d_ransac_pnp_ex(*[_ptr(t) for t in args], _ptr(npz), B, HW, float(reproj_thr), int(iters), float(confidence),
+                                                int(seed), mode, float(max_t_diff), {"p3p": 0, "epnp": 1}[str(minimal).lower()], _ptr(pose),
+                                                _ptr(nin), _ptr(mask), _ptr(best), _stream()), "ransac_pnp")
     return pose, nin, mask, best
 
 
