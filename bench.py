@@ -105,6 +105,12 @@ def roofline(model, t, B, device, reps=3):
     flops = sum(conv_flops(L.keep[0]) for L in sel)
     total_ms, n = 0.0, 0
     step(model, t)
+    # the clock the (power-limited) eight-phase kernel runs at: its workgroup 0 leaves shader-clock ticks and the constant 100 MHz
+    # counter at its start and end (rdpn6d_conv_h2_set_clock_probe) - boxes of the pool differ by 7 % on exactly this number
+    clk = torch.zeros(4, dtype=torch.int64, device=device) if tile == "h2" else None
+    ghz = []
+    if clk is not None:
+        lib.rdpn6d_conv_h2_set_clock_probe(ctypes.c_void_p(clk.data_ptr()))
     for _ in range(reps):
         # replay the plan with events around the selected launches (same stream the kernels run on)
         x = t["roi_img"]
@@ -123,6 +129,12 @@ def roofline(model, t, B, device, reps=3):
         torch.cuda.synchronize()
         total_ms += sum(a.elapsed_time(b) for a, b in evs)
         n += len(evs)
+        if clk is not None:  # (the last eight-phase launch of the pass: the head's final layer)
+            c = clk.tolist()
+            if c[3] > c[1]:
+                ghz.append((c[2] - c[0]) / ((c[3] - c[1]) * 10.0))
+    if clk is not None:
+        lib.rdpn6d_conv_h2_set_clock_probe(None)
     avg_ms = total_ms / max(n, 1)
     achieved = flops / len(sel) / (avg_ms * 1e-3) / 1e12 if sel else 0.0
     extra = {}
@@ -130,7 +142,10 @@ def roofline(model, t, B, device, reps=3):
         # fp32-accurate products as three fp16 partial products: the ceiling for ALGORITHMIC flops is the fp16 pipe / 3
         kname, peak = ("conv_h2_8ph_kernel_t<false>" if tile == "h2" else "conv_h2_tile_kernel"), round(BF16_MFMA_PEAK_TFLOPS / 3.0, 1)
         extra = {"peak_note": "2500 TFLOP/s dense fp16 MFMA / 3 partial products per fp32 product (157.3 on the fp32 MFMA pipe)",
-                 "mfma_tflops_issued": round(3.0 * achieved, 1)}
+                 "mfma_tflops_issued": round(3.0 * achieved, 1),
+                 # shader clock of the dominant kernel while it runs (s_memtime ticks per 100 MHz s_memrealtime tick, workgroup 0 of the
+                 # head's last eight-phase launch, mean of the event-timed passes): the part's peak is quoted at 2.4 GHz
+                 "clock_ghz": round(sum(ghz) / len(ghz), 3) if ghz else None}
     elif tile in ("x3", "x3tile"):
         # fp32-accurate products as six bf16 partial products: the ceiling for ALGORITHMIC flops is the bf16 pipe / 6
         kname, peak = ("conv_igemm_bf16x3_kernel" if tile == "x3" else "conv_x3_tile_kernel"), round(BF16_MFMA_PEAK_TFLOPS / 6.0, 1)

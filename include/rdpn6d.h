@@ -184,6 +184,10 @@ long long rdpn6d_conv_h2_workspace_bytes(const rdpn6d_conv_desc* d);
  * tensor [Npad][ntaps][cchunks][hi x 32 | lo x 32] into [Npad/32][ntaps][cchunks][slot 0..7][row 0..31][8 halfs] (same bytes);
  * rdpn6d_conv_h2_wfrag_wanted says whether a layer's kernel has that form; rdpn6d_conv2d_h2_wf = rdpn6d_conv2d_h2 + the re-ordered
  * weights (null or an unwanted w_frag: the ordinary kernel).  Results are bit-identical with and without. */
+/* measurement only: while `buf` (device memory, 4 x uint64) is set, workgroup 0 of every 256x256 eight-phase h2 launch leaves
+ * {s_memtime, s_memrealtime} at its start and end there: ticks of the shader clock against the constant 100 MHz counter = the clock the
+ * power-limited dominant kernel ran at (bench.py roofline.clock_ghz); NULL switches it off */
+void rdpn6d_conv_h2_set_clock_probe(unsigned long long* buf);
 void rdpn6d_conv_h2_set_wfrag(int mode); /* 0 (default): no layer wants them - measured slower, kept for the record; 1: 128x128; 2: + 256x128 */
 /* Column-max form: for a layer whose output only a per-group channel max reads (resnet_backbone.py:51-52: the point-wise branch's
  * adaptive max over a crop's pixels, when nothing else needs the layer's output).  keys [groups][Npad] uint64 (zero before the call)

@@ -166,6 +166,7 @@ SIGNATURES = {
     "rdpn6d_conv2d_h2_colmax": (_i, [ctypes.POINTER(ConvDesc), _vp, _i, _vp, _vp]),
     "rdpn6d_h2_colmax_decode": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "rdpn6d_conv_h2_set_wfrag": (None, [_i]),
+    "rdpn6d_conv_h2_set_clock_probe": (None, [_vp]),
     "rdpn6d_conv_h2_wfrag_wanted": (_i, [ctypes.POINTER(ConvDesc)]),
     "rdpn6d_h2_weight_frag": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "rdpn6d_conv2d_h2_wf": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),

@@ -30,6 +30,10 @@ struct ConvH2Args {
     // the weights once more, FRAGMENT-MAJOR ([Npad/32][ntaps][Cin/32][slot 0..7][row 0..31][8 halfs]: rdpn6d_h2_weight_frag), for the kernels
     // that load their weight fragments straight from L2 instead of staging the weight tile through LDS (conv_igemm_h2_pp.hip, BFG); null = none
     const void* w_frag;
+    // measurement only (rdpn6d_conv_h2_set_clock_probe; null = off): workgroup 0 of the 256x256 eight-phase kernel leaves
+    // {s_memtime, s_memrealtime} at its start and its end here - shader-clock ticks against the constant 100 MHz counter = the clock the
+    // power-limited kernel actually ran at (bench.py: roofline.clock_ghz; boxes of the pool differ by 7 % on exactly this)
+    unsigned long long* clk_probe;
 };
 
 

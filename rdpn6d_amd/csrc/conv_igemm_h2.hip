@@ -517,7 +517,14 @@ __device__ __forceinline__ void conv_h2_8ph_body(const ConvH2Args& ax)
 template <bool FUSE>
 __global__ __launch_bounds__(512) void conv_h2_8ph_kernel_t(const ConvH2Args ax)
 {
+    const bool probe = ax.clk_probe != nullptr && blockIdx.x == 0 && blockIdx.y == 0;  // uniform
+    unsigned long long t0 = 0, r0 = 0;
+    if (probe) { t0 = __builtin_readcyclecounter(); r0 = __builtin_amdgcn_s_memrealtime(); }
     conv_h2_8ph_body<FUSE, false>(ax);
+    if (probe && threadIdx.x == 0) {
+        ax.clk_probe[0] = t0; ax.clk_probe[1] = r0;
+        ax.clk_probe[2] = __builtin_readcyclecounter(); ax.clk_probe[3] = __builtin_amdgcn_s_memrealtime();
+    }
 }
 __global__ __launch_bounds__(512) void conv_h2_8ph_colmax_kernel(const ConvH2Args ax) { conv_h2_8ph_body<false, true>(ax); }
 
@@ -1038,6 +1045,10 @@ static int h2_tile_ksplit(const rdpn6d_conv_desc* d, long long M, int bm, int bn
 // (rdpn6d_conv_h2_set_wfrag, or RDPN6D_H2_BFG in the environment for profiling runs)
 static int g_h2_wfrag_mode = getenv("RDPN6D_H2_BFG") ? atoi(getenv("RDPN6D_H2_BFG")) : 0;
 extern "C" void rdpn6d_conv_h2_set_wfrag(int mode) { g_h2_wfrag_mode = mode; }
+// measurement: while set, every launch of the 256x256 eight-phase kernel (plain and fused-output instances) has its workgroup 0 write
+// {s_memtime, s_memrealtime} x {start, end} to buf[0..3] (device memory, 32 bytes); null switches it off again
+static unsigned long long* g_h2_clk_probe = nullptr;
+extern "C" void rdpn6d_conv_h2_set_clock_probe(unsigned long long* buf) { g_h2_clk_probe = buf; }
 static bool h2_wfrag_shape_ok(int shape)
 {
     const int mode = g_h2_wfrag_mode;
@@ -1246,6 +1257,7 @@ static int conv2d_h2_impl(const rdpn6d_conv_desc* d, void* y_h2, const void* res
     ax.fuse_cs = fuse ? fuse->cs : 0;
     ax.fuse_n = fuse ? fuse->n : 0;
     ax.w_frag = nullptr;
+    ax.clk_probe = g_h2_clk_probe;
     ax.nsplit = 1;
     ax.mpad = 0;
     a.dy_pack = a.dx_pack = 0;
