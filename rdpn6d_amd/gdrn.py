@@ -1409,6 +1409,19 @@ class GDRN(_TreeWatch, nn.Module):
         x = args[0] if args else kwargs["x"]
         dev = x.device
         self.eval()
+        tcfg = self.cfg.get("TEST", {})
+        graph_was = bool(tcfg.get("HIP_GRAPH", False))
+        if graph_was:  # (the probe reads tensors back after every launch: not inside a graph capture)
+            self.cfg.TEST.HIP_GRAPH = False
+        try:
+            return self._calibrate_h2(x, dev, args, kwargs, headroom, raise_small)
+        finally:
+            if graph_was:
+                self.cfg.TEST.HIP_GRAPH = True
+
+    def _calibrate_h2(self, x, dev, args, kwargs, headroom, raise_small):
+        import math
+
         for _ in range(12):
             tab = self.h2_exponents(dev)
             plan = self.plan(x.shape[0], dev)

@@ -38,6 +38,72 @@ def test_every_declared_symbol_is_exported(lib):
     assert set(_lib.SIGNATURES) == set(names)
 
 
+def _header_prototypes():
+    """(name, return type, [parameter types]) of every prototype in include/rdpn6d.h, comments stripped"""
+    src = open(os.path.join(ROOT, "include", "rdpn6d.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
+    out = []
+    for m in re.finditer(r"([A-Za-z_][A-Za-z_0-9 \*]*?)\b([a-z_0-9]+)\s*\(([^;{}]*)\)\s*;", src):
+        ret, name, params = m.group(1).strip(), m.group(2), m.group(3).strip()
+        if ret.startswith(("typedef", "#")) or not ret:
+            continue
+        plist = [] if params in ("", "void") else [p.strip() for p in params.split(",")]
+        out.append((name, ret, plist))
+    return out
+
+
+def _ctype_of(decl, is_return=False):
+    """the ctypes type a C parameter declaration binds to in rdpn6d_amd/_lib.py (pointers are untyped there, by design)"""
+    from rdpn6d_amd import _lib
+
+    d = re.sub(r"\bconst\b|\b__restrict__\b", " ", decl).strip()
+    if "rdpn6d_conv_desc" in d and "*" in d:
+        return ctypes.POINTER(_lib.ConvDesc)
+    if "*" in d or "[" in d:
+        if is_return and re.match(r"char\s*\*", d):
+            return ctypes.c_char_p
+        return ctypes.c_void_p
+    base = re.sub(r"\b[A-Za-z_][A-Za-z_0-9]*$", "", d).strip() if not is_return else d  # drop the parameter name
+    base = " ".join(base.split())
+    table = {"int": ctypes.c_int, "float": ctypes.c_float, "unsigned": ctypes.c_uint, "unsigned int": ctypes.c_uint,
+             "long long": ctypes.c_longlong, "unsigned long long": ctypes.c_ulonglong, "double": ctypes.c_double, "void": None,
+             "size_t": ctypes.c_size_t}
+    if base not in table:
+        raise AssertionError(f"unmapped C type {decl!r} -> {base!r}")
+    return table[base]
+
+
+def test_ctypes_signatures_match_the_header_prototypes():
+    """rdpn6d_amd/_lib.py mirrors include/rdpn6d.h by hand (~170 prototypes).  Symbol presence says nothing about
+    an argument that was added to one side only - a shifted int / float argument is a silently wrong call on this ABI (ints and floats
+    travel in different registers).  Parse every prototype and hold the ctypes table to it: return type, parameter COUNT, and the
+    class of every parameter (pointer | int | unsigned | float | long long | double | the descriptor pointer)."""
+    from rdpn6d_amd import _lib
+
+    protos = _header_prototypes()
+    assert len(protos) == len(_declared_symbols()) == len(_lib.SIGNATURES)
+
+    def same(a, b):  # (c_int / c_uint are different classes, c_longlong / c_ulonglong too; a descriptor pointer bound as void* is a pointer)
+        ptr = (ctypes.c_void_p, ctypes.POINTER(_lib.ConvDesc))
+        return a is b or (a in ptr and b in ptr)
+
+    bad = []
+    for name, ret, params in protos:
+        rt, at = _lib.SIGNATURES[name]
+        want_r = _ctype_of(ret, is_return=True)
+        if not same(rt, want_r):
+            bad.append(f"{name}: returns {ret!r} -> {want_r}, ctypes has {rt}")
+        want = [_ctype_of(p) for p in params]
+        if len(want) != len(at):
+            bad.append(f"{name}: {len(want)} parameters in the header, {len(at)} in _lib.SIGNATURES")
+            continue
+        for i, (w, g, p) in enumerate(zip(want, at, params)):
+            if not same(w, g):
+                bad.append(f"{name}: parameter {i} {p!r} -> {w}, ctypes has {g}")
+    assert not bad, "\n".join(bad)
+
+
 def test_conv_desc_layout_matches_header():
     from rdpn6d_amd._lib import ConvDesc
 

@@ -844,6 +844,19 @@ def test_other_resnet_trunks_vs_oracle(dev, layers, R, B):
     et = _rel(o["trans"].cpu().numpy().astype(np.float64), o64["trans"].numpy())
     print(f"resnet{layers} R={R} B={B}: arg-max flips vs fp64 {flips}, pose rel err R {er:.2e} t {et:.2e}")
     assert flips <= 4 * B and er < (2e-3 if flips == 0 else 2e-2) and et < (2e-3 if flips == 0 else 2e-2)
+    if B == 2 and R == 256 and plan.fast == "h2" and plan.h2_pointwise:
+        # (round 6) the per-tensor h2 exponents on THIS trunk's plan - Bottleneck: conv1 / conv2 variables, the residual chain through
+        # conv3 and the down-sampling branch: every variable one binade down is the same network up to round-off
+        names = sorted({v for v in plan._slots if v is not None})
+        assert any(v.endswith(".conv1") for v in names) and {"layer2", "layer3", "layer4"} <= set(names)
+        assert (layers < 50) or any(v.endswith(".conv2") for v in names)
+        model.h2_exponents(dev).update({v: 3 for v in names})
+        o3 = _run(model, {k: v.to(dev) for k, v in tc.items()})
+        assert model.plan(B, dev) is not plan and not model.h2_range_exceeded(dev)
+        for k in ("mask", "coor_x", "coor_y", "coor_z", "region"):
+            self_err = (o32[k].double() - o64[k]).abs().max().item()
+            err = (o3[k].cpu().double() - o64[k]).abs().max().item()
+            assert err <= 3.0 * self_err + 1e-6, (k, err, self_err)
 
 
 @pytest.mark.parametrize("case", [(2, 8, 512, 512, 3, True, 6), (1, 16, 256, 256, 3, False, 4), (3, 8, 96, 128, 1, False, 2)])
