@@ -313,3 +313,19 @@ def test_gradients_handed_to_autograd_stay_in_the_flat_buffer():
         for p in m.parameters():
             p.requires_grad_(False)
         m(torch.zeros(1))
+
+
+def test_gradbuckets_from_cfg_reads_the_solver_keys():
+    """cfg.SOLVER.ALLREDUCE_DTYPE (f32 | bf16) and cfg.SOLVER.GRAD_BUCKETS (stages | coarse): the two switches of the gradient exchange"""
+    from rdpn6d_amd.config import gdrn_base_cfg
+    from rdpn6d_amd.parallel import GROUPS, STAGES
+
+    cfg = gdrn_base_cfg(device="cpu")
+    gb = GradBuckets.from_cfg(_Toy(), cfg)
+    assert gb.groups == STAGES and gb.comm_dtype is None
+    cfg.SOLVER.ALLREDUCE_DTYPE, cfg.SOLVER.GRAD_BUCKETS = "bf16", "coarse"
+    gb = GradBuckets.from_cfg(_Toy(), cfg)
+    assert gb.groups == GROUPS and gb.comm_dtype is torch.bfloat16
+    cfg.SOLVER.ALLREDUCE_DTYPE = "fp8"
+    with pytest.raises(ValueError, match="ALLREDUCE_DTYPE"):
+        GradBuckets.from_cfg(_Toy(), cfg)
