@@ -183,3 +183,36 @@ def test_lowered_exponents_cost_round_off_only(golden_dir):
     e_low = max((low[k].cpu().double() - want[k]).abs().max().item() for k in MAPS)
     print(f"all {len(names)} exponents 4 -> 2: maps move by {d:.1e}; max-abs vs float64 {e_base:.1e} (default) -> {e_low:.1e}")
     assert e_base < 1e-4 and e_low < 1e-4 and d < 1e-4
+
+
+def test_deferred_range_check_adapts_the_exponents_at_the_next_forward(golden_dir):
+    """cfg.TEST.H2_RANGE_CHECK = "deferred" (pipelined serving, no host wait per forward): the forward that overflowed returns clamped
+    values; the NEXT forward finds the flag slots, lowers those tensors' exponents (a warning says that an earlier forward's outputs
+    were computed with clamped values) and stays on h2; after at most a few such forwards the outputs are the adapted plan's."""
+    from rdpn6d_amd import synth
+
+    dev = torch.device("cuda:0")
+    sd = _heavy_tailed(_weights(golden_dir))
+    inp = synth.make_inputs(4, seed=5)
+    want = _oracle64(sd, inp)
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in inp.items()}
+    model = _model(sd)
+    model.cfg.TEST.H2_RANGE_CHECK = "deferred"
+    with _no_warnings():
+        _fwd(model, t)  # clamped, nobody waited
+    assert model.h2_range_exceeded(dev, wait=True) and dict(model.h2_exponents(dev)) == {}
+    warned = 0
+    for _ in range(6):
+        import warnings
+
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            o = _fwd(model, t)
+        warned += sum("EARLIER forward" in str(x.message) for x in w)
+        torch.cuda.synchronize()
+        if not model.h2_range_exceeded(dev, wait=True):
+            break
+    tab = dict(model.h2_exponents(dev))
+    assert warned >= 1 and model.cfg.TEST.FP16X2 is True and model.plan(4, dev).fast == "h2"
+    assert set(tab) == {"layer2.0.conv1", "layer3", "rot_head.features.3"} and all(e < 4 for e in tab.values()), tab
+    assert max((o[k].cpu().double() - want[k]).abs().max().item() for k in MAPS) < 1e-4
