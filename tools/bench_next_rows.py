@@ -173,3 +173,11 @@ if os.path.exists(so):
     cpu = cpu_time(lambda: run_pnp_oracle(ol, cp4), 3.0)
 row("2D-3D RANSAC-PnP (100 P3P hypotheses per crop in fp64, 3 px reprojection scoring from LDS, Gauss-Newton refit)", 64, "crops", sec,
     64 * 1600 * 20, cpu, 4, "latency / fp64-ALU bound; bytes: 20 B per correspondence once")
+
+# ---- A9 with the reference call's own minimal solver: EPnP on sets of five + EPnP refit (cfg.TEST.PNP_MINIMAL = "epnp", round 6)
+sec = gpu_time(lambda: ops.ransac_pnp(tp["image_points"], tp["model_points"], tp["counts"], tp["cams"].reshape(64, 3, 3), minimal="epnp"))
+cpu = None
+if os.path.exists(so):
+    cpu = cpu_time(lambda: run_pnp_oracle(ol, cp4, minimal="epnp"), 3.0)
+row("2D-3D RANSAC-PnP, EPnP minimal solver (100 five-point EPnP hypotheses per crop in fp64: 12x12 Jacobi on an LDS scratch per wavefront; EPnP refit "
+    "on the inliers)", 64, "crops", sec, 64 * 1600 * 20, cpu, 4, "latency / fp64-ALU bound; bytes: 20 B per correspondence once")
