@@ -999,8 +999,13 @@ __global__ __launch_bounds__(PNP_THREADS) void ransac_pnp_kernel(
     const float* __restrict__ image_points, const float* __restrict__ model_points, const int* __restrict__ counts,
     const float* __restrict__ cams, const float* __restrict__ net_pose, int HW, float reproj_thr, int iters, float confidence,
     unsigned seed, int mode, float max_t_diff, float* __restrict__ pose_out, int* __restrict__ n_inliers,
-    unsigned char* __restrict__ inlier_mask, int* __restrict__ best_hyp)
+    unsigned char* __restrict__ inlier_mask, int* __restrict__ best_hyp, int part, int* __restrict__ g_cnt, double* __restrict__ g_pose)
 {
+    // part 0: the whole solve in one workgroup per crop.  With fewer crops than compute units a crop's hypotheses are spread over
+    // gridDim.y workgroups (part 1: phases 1 - 2 only, counts and poses to the GLOBAL scoreboard g_cnt / g_pose [B][PNP_MAX_ITERS]) and a
+    // second launch (part 2: one workgroup per crop reads the scoreboard, phases 3 - 4) finishes - the same per-hypothesis arithmetic and the
+    // same scan order, hence bit-identical results (tests/test_gpu_pnp.py); at B = 64 the EPnP form runs 13 rounds of hypotheses on 64
+    // of 256 compute units otherwise (6.5 ms), a per-image batch on a handful
     extern __shared__ __attribute__((aligned(16))) unsigned char pnp_smem[];
     double* s_red = reinterpret_cast<double*>(pnp_smem);               // PNP_WAVES * 27
     double* s_pose = s_red + PNP_WAVES * 27;                           // 12 * PNP_MAX_ITERS (R | t per hypothesis)
@@ -1020,10 +1025,13 @@ __global__ __launch_bounds__(PNP_THREADS) void ransac_pnp_kernel(
     const double thr2 = (double)reproj_thr * (double)reproj_thr;
     float* po = pose_out + b * 12;
     unsigned char* msk = inlier_mask + (size_t)b * HW;
-    for (int p = tid; p < HW; p += PNP_THREADS) msk[p] = 0;
+    if (part != 1)
+        for (int p = tid; p < HW; p += PNP_THREADS) msk[p] = 0;
     if (n < 4) {  // gdrn_evaluator.py:391-392 (sentinel) / :297-300 (keep the network pose)
-        if (tid < 12) po[tid] = net_pose ? net_pose[b * 12 + tid] : -100.f;
-        if (tid == 0) { n_inliers[b] = 0; best_hyp[b] = -1; }
+        if (part != 1) {
+            if (tid < 12) po[tid] = net_pose ? net_pose[b * 12 + tid] : -100.f;
+            if (tid == 0) { n_inliers[b] = 0; best_hyp[b] = -1; }
+        }
         return;
     }
     // ---- phase 1
@@ -1033,13 +1041,16 @@ __global__ __launch_bounds__(PNP_THREADS) void ransac_pnp_kernel(
         for (int i = tid; i < 2 * n; i += PNP_THREADS) s_ip[i] = gi[i];
         for (int i = tid; i < 3 * n; i += PNP_THREADS) s_mp[i] = gm[i];
     }
-    for (int h = tid; h < iters; h += PNP_THREADS) s_cnt[h] = -1;
+    for (int h = tid; h < iters; h += PNP_THREADS) s_cnt[h] = part == 2 ? g_cnt[(size_t)b * PNP_MAX_ITERS + h] : -1;
+    if (part == 2)
+        for (int i = tid; i < 12 * iters; i += PNP_THREADS) s_pose[i] = g_pose[(size_t)b * 12 * PNP_MAX_ITERS + i];
     __syncthreads();
 
     int best = -1, best_cnt = 0;
     if (mode != 2) {
-        // ---- phase 2: one hypothesis per wavefront
-        for (int h = wave; h < iters; h += PNP_WAVES) {
+        // ---- phase 2: one hypothesis per wavefront (part 1: this workgroup's share, results to the global scoreboard)
+        const int h_step = PNP_WAVES * (part == 1 ? (int)gridDim.y : 1);
+        for (int h = wave + PNP_WAVES * (part == 1 ? (int)blockIdx.y : 0); part != 2 && h < iters; h += h_step) {
             double R[9], t[3];
             int ok = 0;
             if (mode == 1 && h == 0) {
@@ -1052,19 +1063,25 @@ __global__ __launch_bounds__(PNP_THREADS) void ransac_pnp_kernel(
                 ok = epnp ? epnp_hypothesis(seed, (unsigned)b, (unsigned)h, n, s_ip, s_mp, K4, s_ep + wave * 288, lane, R, t)
                           : pnp_hypothesis(seed, (unsigned)b, (unsigned)h, n, s_ip, s_mp, K4, R, t);
             }
-            if (!ok) continue;  // wave-uniform
+            if (!ok) {  // wave-uniform
+                if (part == 1 && lane == 0) g_cnt[(size_t)b * PNP_MAX_ITERS + h] = -1;
+                continue;
+            }
             int cnt = 0;
             for (int i = lane; i < n; i += 64) cnt += reproj_err2(R, t, K4, s_mp + 3 * i, s_ip + 2 * i) < thr2 ? 1 : 0;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
             if (lane == 0) {
-                s_cnt[h] = cnt;  // the LDS inlier scoreboard
+                int* cdst = part == 1 ? g_cnt + (size_t)b * PNP_MAX_ITERS : s_cnt;       // the inlier scoreboard: LDS, or global in the
+                double* pdst = part == 1 ? g_pose + (size_t)b * 12 * PNP_MAX_ITERS : s_pose;  // split form
+                cdst[h] = cnt;
 #pragma unroll
-                for (int i = 0; i < 9; i++) s_pose[12 * h + i] = R[i];
+                for (int i = 0; i < 9; i++) pdst[12 * h + i] = R[i];
 #pragma unroll
-                for (int i = 0; i < 3; i++) s_pose[12 * h + 9 + i] = t[i];
+                for (int i = 0; i < 3; i++) pdst[12 * h + 9 + i] = t[i];
             }
         }
+        if (part == 1) return;
         __syncthreads();
         // ---- phase 3: scoreboard scan with the confidence-driven stop
         if (tid == 0) {
@@ -1220,12 +1237,51 @@ size_t pnp_smem_bytes(int HW, bool epnp)
 // net_pose [B,12] or NULL.  mode 0: RANSAC (TEST.PNP_TYPE = "ransac_pnp"); 1: the network pose is hypothesis 0
 // ("net_ransac_pnp", 20 iterations in the reference); 2: Gauss-Newton from the network pose over all correspondences
 // ("net_iter_pnp").  inlier_mask [B,HW] is indexed like the correspondence lists.
+// workspace of the split form: the global scoreboard [B][PNP_MAX_ITERS] of (count, pose)
+extern "C" long long rdpn6d_ransac_pnp_workspace_bytes(int B) { return B > 0 ? (long long)B * PNP_MAX_ITERS * (4 + 12 * 8) : 0; }
+
+template <bool EPNP>
+static int pnp_launch(const float* image_points, const float* model_points, const int* counts, const float* cams, const float* net_pose, int B,
+                      int HW, float reproj_thr, int iters, float confidence, unsigned seed, int mode, float max_t_diff, float* pose_out,
+                      int* n_inliers, unsigned char* inlier_mask, int* best_hyp, void* workspace, long long workspace_bytes, hipStream_t s)
+{
+    const size_t smem = pnp_smem_bytes(HW, EPNP);
+    RD_REQUIRE(smem <= 160 * 1024, "correspondences do not fit the 160 KiB LDS");
+    RD_LDS_OPT_IN(ransac_pnp_kernel<EPNP>, 160 * 1024);
+    // fewer crops than compute units: spread a crop's hypotheses over `parts` workgroups (at most one round of hypotheses each)
+    int parts = 1;
+    if (mode != 2 && workspace && workspace_bytes >= rdpn6d_ransac_pnp_workspace_bytes(B)) {
+        static const int cus = [] { int d = 0, n = 256; hipDeviceProp_t pr; if (hipGetDevice(&d) == hipSuccess && hipGetDeviceProperties(&pr, d) == hipSuccess) n = pr.multiProcessorCount; return n; }();
+        const int rounds = (iters + PNP_WAVES - 1) / PNP_WAVES;
+        parts = cus / B;
+        if (parts > rounds) parts = rounds;
+        if (const char* e = getenv("RDPN6D_PNP_PARTS")) parts = atoi(e);  // (A/B runs)
+        if (parts < 1) parts = 1;
+    }
+    if (parts >= 2) {
+        int* g_cnt = reinterpret_cast<int*>(workspace);
+        double* g_pose = reinterpret_cast<double*>(g_cnt + (size_t)B * PNP_MAX_ITERS);
+        hipLaunchKernelGGL(ransac_pnp_kernel<EPNP>, dim3(B, parts), dim3(PNP_THREADS), smem, s, image_points, model_points, counts, cams, net_pose,
+                           HW, reproj_thr, iters, confidence, seed, mode, max_t_diff, pose_out, n_inliers, inlier_mask, best_hyp, 1, g_cnt, g_pose);
+        RD_LAUNCH_CHECK();
+        hipLaunchKernelGGL(ransac_pnp_kernel<EPNP>, dim3(B), dim3(PNP_THREADS), smem, s, image_points, model_points, counts, cams, net_pose,
+                           HW, reproj_thr, iters, confidence, seed, mode, max_t_diff, pose_out, n_inliers, inlier_mask, best_hyp, 2, g_cnt, g_pose);
+        RD_LAUNCH_CHECK();
+        return RDPN6D_OK;
+    }
+    hipLaunchKernelGGL(ransac_pnp_kernel<EPNP>, dim3(B), dim3(PNP_THREADS), smem, s, image_points, model_points, counts, cams, net_pose, HW,
+                       reproj_thr, iters, confidence, seed, mode, max_t_diff, pose_out, n_inliers, inlier_mask, best_hyp, 0, nullptr, nullptr);
+    RD_LAUNCH_CHECK();
+    return RDPN6D_OK;
+}
+
 // minimal: 0 = P3P + 1 (sets of 4, Gauss-Newton refit), 1 = EPnP (sets of 5, EPnP refit on the inliers: cv2.SOLVEPNP_EPNP's structure,
-// lib/pysixd/misc.py:170-179; cfg.TEST.PNP_MINIMAL = "epnp")
-extern "C" int rdpn6d_ransac_pnp_ex(const float* image_points, const float* model_points, const int* counts, const float* cams,
+// lib/pysixd/misc.py:170-179; cfg.TEST.PNP_MINIMAL = "epnp").  workspace (rdpn6d_ransac_pnp_workspace_bytes(B) bytes, or NULL): lets a
+// batch of fewer crops than compute units spread each crop's hypotheses over several workgroups (two launches; same results bit for bit)
+extern "C" int rdpn6d_ransac_pnp_ws(const float* image_points, const float* model_points, const int* counts, const float* cams,
                                     const float* net_pose, int B, int HW, float reproj_thr, int iters, float confidence, unsigned seed,
                                     int mode, float max_t_diff, int minimal, float* pose_out, int* n_inliers, unsigned char* inlier_mask,
-                                    int* best_hyp, void* stream)
+                                    int* best_hyp, void* workspace, long long workspace_bytes, void* stream)
 {
     RD_REQUIRE(image_points && model_points && counts && cams && pose_out && n_inliers && inlier_mask && best_hyp, "null pointer");
     RD_REQUIRE(B > 0 && HW > 0 && HW <= 6400, "HW must be in 1..6400 (LDS-resident correspondences)");
@@ -1234,19 +1290,20 @@ extern "C" int rdpn6d_ransac_pnp_ex(const float* image_points, const float* mode
     RD_REQUIRE(iters >= 1 && iters <= PNP_MAX_ITERS && reproj_thr > 0.f && confidence > 0.f && confidence < 1.f, "iterations / thresholds");
     RD_REQUIRE(mode == 0 || max_t_diff > 0.f, "max_t_diff");
     RD_REQUIRE(pose_out != net_pose, "pose_out must not alias net_pose");
-    const size_t smem = pnp_smem_bytes(HW, minimal == 1);
-    RD_REQUIRE(smem <= 160 * 1024, "correspondences do not fit the 160 KiB LDS");
-    if (minimal == 1) {
-        RD_LDS_OPT_IN(ransac_pnp_kernel<true>, 160 * 1024);
-        hipLaunchKernelGGL(ransac_pnp_kernel<true>, dim3(B), dim3(PNP_THREADS), smem, (hipStream_t)stream, image_points, model_points, counts, cams,
-                           net_pose, HW, reproj_thr, iters, confidence, seed, mode, max_t_diff, pose_out, n_inliers, inlier_mask, best_hyp);
-    } else {
-        RD_LDS_OPT_IN(ransac_pnp_kernel<false>, 160 * 1024);
-        hipLaunchKernelGGL(ransac_pnp_kernel<false>, dim3(B), dim3(PNP_THREADS), smem, (hipStream_t)stream, image_points, model_points, counts, cams,
-                           net_pose, HW, reproj_thr, iters, confidence, seed, mode, max_t_diff, pose_out, n_inliers, inlier_mask, best_hyp);
-    }
-    RD_LAUNCH_CHECK();
-    return RDPN6D_OK;
+    if (minimal == 1)
+        return pnp_launch<true>(image_points, model_points, counts, cams, net_pose, B, HW, reproj_thr, iters, confidence, seed, mode, max_t_diff,
+                                pose_out, n_inliers, inlier_mask, best_hyp, workspace, workspace_bytes, (hipStream_t)stream);
+    return pnp_launch<false>(image_points, model_points, counts, cams, net_pose, B, HW, reproj_thr, iters, confidence, seed, mode, max_t_diff,
+                             pose_out, n_inliers, inlier_mask, best_hyp, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" int rdpn6d_ransac_pnp_ex(const float* image_points, const float* model_points, const int* counts, const float* cams,
+                                    const float* net_pose, int B, int HW, float reproj_thr, int iters, float confidence, unsigned seed,
+                                    int mode, float max_t_diff, int minimal, float* pose_out, int* n_inliers, unsigned char* inlier_mask,
+                                    int* best_hyp, void* stream)
+{
+    return rdpn6d_ransac_pnp_ws(image_points, model_points, counts, cams, net_pose, B, HW, reproj_thr, iters, confidence, seed, mode, max_t_diff,
+                                minimal, pose_out, n_inliers, inlier_mask, best_hyp, nullptr, 0, stream);
 }
 
 extern "C" int rdpn6d_ransac_pnp_f32(const float* image_points, const float* model_points, const int* counts, const float* cams,
