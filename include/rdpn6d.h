@@ -618,6 +618,15 @@ int rdpn6d_ransac_pnp_ex(const float* image_points, const float* model_points, c
                          const float* net_pose, int B, int HW, float reproj_thr, int iters, float confidence, unsigned seed,
                          int mode, float max_t_diff, int minimal, float* pose_out, int* n_inliers, unsigned char* inlier_mask,
                          int* best_hyp, void* stream);
+/* ... and with a caller-provided workspace (rdpn6d_ransac_pnp_workspace_bytes(B) bytes of device memory, or NULL = the entry above):
+ * with fewer crops than compute units each crop's hypotheses are spread over up to ceil(iters / 8) workgroups (a global scoreboard, a
+ * second launch for scan + refit) - the reference's test loop feeds the 1 - 15 crops of one image per call; results bit-identical to
+ * the one-launch form. */
+long long rdpn6d_ransac_pnp_workspace_bytes(int B);
+int rdpn6d_ransac_pnp_ws(const float* image_points, const float* model_points, const int* counts, const float* cams,
+                         const float* net_pose, int B, int HW, float reproj_thr, int iters, float confidence, unsigned seed,
+                         int mode, float max_t_diff, int minimal, float* pose_out, int* n_inliers, unsigned char* inlier_mask,
+                         int* best_hyp, void* workspace, long long workspace_bytes, void* stream);
 /* rank 1: GPU crop builder (core/gdrn_modeling/data_loader.py:523-627, core/utils/data_utils.py:81-152; cv2.warpAffine
  * bilinear arithmetic restated, parity with cv2 unpinned).  images [N,H,W,3] u8, depths [N,H,W] f32; per ROI: image index,
  * inverse affine maps for the R and R/4 crops (6 doubles each), fx fy cx cy of (A @ K), resize_ratio ->

@@ -172,6 +172,8 @@ SIGNATURES = {
     "rdpn6d_conv2d_h2_wf": (_i, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
     "rdpn6d_ransac_pnp_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _f, ctypes.c_uint, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "rdpn6d_ransac_pnp_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _f, ctypes.c_uint, _i, _f, _i, _vp, _vp, _vp, _vp, _vp]),
+    "rdpn6d_ransac_pnp_workspace_bytes": (_ll, [_i]),
+    "rdpn6d_ransac_pnp_ws": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _f, ctypes.c_uint, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _ll, _vp]),
     "rdpn6d_select_correspondences_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rdpn6d_select_correspondences_mt_f32": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
 }

@@ -1292,9 +1292,10 @@ class InferencePlan:
             netp[:, :9].copy_(self.rot.view(B, 9))
             netp[:, 9:].copy_(self.trans)
         cams = roi_cams.reshape(B, 9)
-        _lib.check(self.lib.rdpn6d_ransac_pnp_ex(_ptr(ip), _ptr(mp), _ptr(cnt), _ptr(cams), _ptr(netp), B, HW, reproj_thr, iters, confidence,
+        ws = self.buf("pnp2d_ws", int(self.lib.rdpn6d_ransac_pnp_workspace_bytes(B)), dtype=torch.uint8)  # (split form at small batches)
+        _lib.check(self.lib.rdpn6d_ransac_pnp_ws(_ptr(ip), _ptr(mp), _ptr(cnt), _ptr(cams), _ptr(netp), B, HW, reproj_thr, iters, confidence,
                                                  seed, net_mode, max_t_diff, int(minimal), _ptr(self.pnp_pose), _ptr(self.pnp_ninl),
-                                                 _ptr(self.pnp_mask), _ptr(self.pnp_best), st), "ransac_pnp")
+                                                 _ptr(self.pnp_mask), _ptr(self.pnp_best), _ptr(ws), ws.numel(), st), "ransac_pnp")
         self.pnp_counts = cnt
 
     def run_ransac(self, roi_coord_2d, fps, roi_extents, resize_ratios, mask_thr=0.5, inlier_thr=0.01, iters=100,

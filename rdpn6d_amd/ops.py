@@ -333,7 +333,7 @@ def ransac_kabsch(out_nchw, coord2d, fps, extents, resize_ratios, region_argmax,
 
 
 def ransac_pnp(image_points, model_points, counts, cams, reproj_thr=3.0, iters=100, confidence=0.99, seed=0, net_pose=None,
-               net_mode="ransac", max_t_diff=1.0, minimal="p3p"):
+               net_mode="ransac", max_t_diff=1.0, minimal="p3p", split=True):
     """2D-3D RANSAC-PnP per crop (rdpn6d_ransac_pnp_f32; the role of misc.pnp_v2 -> cv2.solvePnPRansac(EPnP, 3 px, 100 iterations) at
     gdrn_evaluator.py:316-435).  image_points [B,HW,2] px, model_points [B,HW,3] m, counts [B] int32 from
     select_correspondences; cams [B,3,3].  With net_pose [B,12]: net_mode "ransac" = the learned pose is hypothesis 0, "iter" =
@@ -352,9 +352,13 @@ def ransac_pnp(image_points, model_points, counts, cams, reproj_thr=3.0, iters=1
     assert args[2].dtype == torch.int32
     npz = net_pose.float().contiguous() if net_pose is not None else None
     mode = 0 if net_pose is None else {"ransac": 1, "iter": 2}[net_mode]
-    _lib.check(_lib.load().rdpn6d_ransac_pnp_ex(*[_ptr(t) for t in args], _ptr(npz), B, HW, float(reproj_thr), int(iters), float(confidence),
-                                                int(seed), mode, float(max_t_diff), {"p3p": 0, "epnp": 1}[str(minimal).lower()], _ptr(pose),
-                                                _ptr(nin), _ptr(mask), _ptr(best), _stream()), "ransac_pnp")
+    lib = _lib.load()
+    # (workspace of the split form: with fewer crops than CUs a crop's hypotheses are spread over several workgroups - same results)
+    ws = torch.empty(int(lib.rdpn6d_ransac_pnp_workspace_bytes(B)) if split else 1, dtype=torch.uint8, device=dev)
+    _lib.check(lib.rdpn6d_ransac_pnp_ws(*[_ptr(t) for t in args], _ptr(npz), B, HW, float(reproj_thr), int(iters), float(confidence),
+                                        int(seed), mode, float(max_t_diff), {"p3p": 0, "epnp": 1}[str(minimal).lower()], _ptr(pose),
+                                        _ptr(nin), _ptr(mask), _ptr(best), _ptr(ws) if split else None, ws.numel() if split else 0, _stream()),
+               "ransac_pnp")
     return pose, nin, mask, best
 
 

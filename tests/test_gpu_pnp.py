@@ -303,3 +303,25 @@ def test_model_pnp_minimal_epnp_inside_forward(oracle_lib, golden_dir):
     model.cfg.TEST.PNP_MINIMAL = "dlt"
     with torch.no_grad(), pytest.raises(ValueError, match="PNP_MINIMAL"):
         model(t["roi_img"], **kw)
+
+
+@pytest.mark.parametrize("minimal", ["p3p", "epnp"])
+@pytest.mark.parametrize("B", [3, 64])
+def test_pnp_split_over_workgroups_is_bit_identical(minimal, B):
+    """with fewer crops than compute units a crop's hypotheses are spread over several workgroups (global scoreboard, second launch for
+    scan + refit): poses, masks, counts and winners equal the one-launch form's bit for bit, both minimal solvers, per-image and full
+    batches, with and without the network pose as hypothesis 0"""
+    from rdpn6d_amd import ops
+    from tests.pnp_cases import make_pnp_case
+
+    c = make_pnp_case(B=B, n=[3, 4, 900] if B == 3 else 1200, outliers=0.3, seed=B)
+    net = np.zeros((B, 12), np.float32)
+    for b in range(B):
+        net[b, :9], net[b, 9:] = c["R"][b].reshape(-1), c["t"][b] + 0.01
+    g, nd = _dev(c, net)
+    for kw in (dict(), dict(net_pose=nd, net_mode="ransac", iters=20)):
+        a = ops.ransac_pnp(g["image_points"], g["model_points"], g["counts"], g["cams"].reshape(B, 3, 3), seed=5, minimal=minimal, split=True, **kw)
+        u = ops.ransac_pnp(g["image_points"], g["model_points"], g["counts"], g["cams"].reshape(B, 3, 3), seed=5, minimal=minimal, split=False, **kw)
+        torch.cuda.synchronize()
+        for x, y in zip(a, u):
+            assert torch.equal(x, y)
