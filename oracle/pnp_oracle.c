@@ -387,9 +387,39 @@ static void pnp_refit(int n, const float* ip, const float* mp, const unsigned ch
  */
 #define EP_SWEEPS 30
 
-/* cyclic Jacobi eigen-decomposition of the symmetric n x n matrix A (row-major, both triangles kept): on return diag(A) holds the
- * eigenvalues and the COLUMNS of V the eigenvectors.  A rotation (p, q) touches row / column k of A and row k of V independently
- * for every k - the HIP kernel gives those to lanes 0..n-1 and computes exactly these expressions. */
+/* one Jacobi rotation (p, q) of the symmetric n x n matrix A (both triangles kept) and the eigenvector matrix V (columns): a rotation
+ * touches row / column k of A and row k of V independently for every k - the HIP kernel gives those to lanes 0..n-1 */
+static void ep_rotate(int n, double* A, double* V, int p, int q)
+{
+    const double apq = A[p * n + q];
+    if (apq == 0.0) return;
+    const double app = A[p * n + p], aqq = A[q * n + q];
+    const double theta = (aqq - app) / (2.0 * apq);
+    const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+    const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+    for (int k = 0; k < n; k++) {
+        if (k != p && k != q) {
+            const double akp = A[k * n + p], akq = A[k * n + q];
+            const double nkp = c * akp - sn * akq, nkq = sn * akp + c * akq;
+            A[k * n + p] = nkp; A[p * n + k] = nkp;
+            A[k * n + q] = nkq; A[q * n + k] = nkq;
+        }
+        const double vkp = V[k * n + p], vkq = V[k * n + q];
+        V[k * n + p] = c * vkp - sn * vkq;
+        V[k * n + q] = sn * vkp + c * vkq;
+    }
+    A[p * n + p] = app - t * apq;
+    A[q * n + q] = aqq + t * apq;
+    A[p * n + q] = 0.0;
+    A[q * n + p] = 0.0;
+}
+
+/* Jacobi eigen-decomposition of the symmetric n x n matrix A (row-major): on return diag(A) holds the eigenvalues and the COLUMNS of V
+ * the eigenvectors.  Sweeps until the off-diagonal mass is below 1e-30 of the diagonal's.  Pair order: cyclic by rows for the small
+ * matrices (n = 3, 4); for n = 12 the ROUND-ROBIN (tournament) order - 11 steps of 6 DISJOINT pairs: (11, s) and (s + i, s - i) mod 11,
+ * i = 1..5.  The rotations of a step do not touch each other's three defining entries, so computing a pair's angle when its turn comes
+ * (here) or all six angles from the matrix at the start of the step (the GPU: one pair per lane - the fp64 divide / square-root chain
+ * is the cost of a rotation) gives the same numbers bit for bit; the rotations are applied in the order below in both. */
 static void ep_jacobi(int n, double* A, double* V)
 {
     for (int i = 0; i < n; i++)
@@ -401,30 +431,16 @@ static void ep_jacobi(int n, double* A, double* V)
             for (int q = p + 1; q < n; q++) off += A[p * n + q] * A[p * n + q];
         }
         if (!(off > 1e-30 * dg)) break;
-        for (int p = 0; p < n - 1; p++)
-            for (int q = p + 1; q < n; q++) {
-                const double apq = A[p * n + q];
-                if (apq == 0.0) continue;
-                const double app = A[p * n + p], aqq = A[q * n + q];
-                const double theta = (aqq - app) / (2.0 * apq);
-                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
-                for (int k = 0; k < n; k++) {
-                    if (k != p && k != q) {
-                        const double akp = A[k * n + p], akq = A[k * n + q];
-                        const double nkp = c * akp - sn * akq, nkq = sn * akp + c * akq;
-                        A[k * n + p] = nkp; A[p * n + k] = nkp;
-                        A[k * n + q] = nkq; A[q * n + k] = nkq;
-                    }
-                    const double vkp = V[k * n + p], vkq = V[k * n + q];
-                    V[k * n + p] = c * vkp - sn * vkq;
-                    V[k * n + q] = sn * vkp + c * vkq;
+        if (n == 12) {
+            for (int s = 0; s < 11; s++)
+                for (int i = 0; i < 6; i++) {
+                    const int a = i == 0 ? 11 : (s + i) % 11, b = i == 0 ? s : (s + 11 - i) % 11;
+                    ep_rotate(n, A, V, a < b ? a : b, a < b ? b : a);
                 }
-                A[p * n + p] = app - t * apq;
-                A[q * n + q] = aqq + t * apq;
-                A[p * n + q] = 0.0;
-                A[q * n + p] = 0.0;
-            }
+        } else {
+            for (int p = 0; p < n - 1; p++)
+                for (int q = p + 1; q < n; q++) ep_rotate(n, A, V, p, q);
+        }
     }
 }
 

@@ -466,9 +466,12 @@ __device__ static void ep_jacobi_small(double* A, double* V)
     }
 }
 
-// the 12 x 12 form on one wavefront: A, V [144] in LDS, lane k < 12 owns row / column k of every rotation; all lanes hold the
-// (uniform) rotation parameters.  LDS operations of one wavefront execute in program order; the wave barriers keep the compiler
-// from moving an access across a step another lane depends on.
+// the 12 x 12 form on one wavefront: A, V [144] in LDS.  ROUND-ROBIN pair order (oracle ep_jacobi, n == 12): a step has six disjoint
+// pairs, whose rotation parameters - one fp64 divide / square-root chain of ~1 000 cycles each, the cost of a rotation - are computed
+// by lanes 0..5 AT ONCE from the matrix at the start of the step (no rotation of the step touches another pair's three entries: the
+// same numbers as computing each when its turn comes); the six rotations are then applied in the oracle's order, row / column k of a
+// rotation on lane k (k < 12) with exactly its per-k expressions.  LDS operations of one wavefront execute in program order; the wave
+// barriers keep the compiler from moving an access across a step another lane depends on.
 __device__ static void ep_jacobi12_wave(double* A, double* V, int lane)
 {
     for (int e = lane; e < 144; e += 64) V[e] = (e / 12) == (e % 12) ? 1.0 : 0.0;
@@ -480,15 +483,26 @@ __device__ static void ep_jacobi12_wave(double* A, double* V, int lane)
             for (int q = p + 1; q < 12; q++) off += A[p * 12 + q] * A[p * 12 + q];
         }
         if (!(off > 1e-30 * dg)) break;
-        for (int p = 0; p < 11; p++)
-            for (int q = p + 1; q < 12; q++) {
-                const double apq = A[p * 12 + q];
+        for (int st = 0; st < 11; st++) {
+            // this lane's pair (lanes >= 6 repeat pair lane % 6: harmless, their results are not read)
+            const int i6 = lane % 6;
+            const int ra = i6 == 0 ? 11 : (st + i6) % 11, rb = i6 == 0 ? st : (st + 11 - i6) % 11;
+            const int mp = ra < rb ? ra : rb, mq = ra < rb ? rb : ra;
+            const double mapq = A[mp * 12 + mq], mapp = A[mp * 12 + mp], maqq = A[mq * 12 + mq];
+            double mt = 0.0, mc = 1.0, msn = 0.0;
+            if (mapq != 0.0) {
+                const double theta = (maqq - mapp) / (2.0 * mapq);
+                mt = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                mc = 1.0 / sqrt(mt * mt + 1.0);
+                msn = mt * mc;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                const int p = __shfl(mp, j), q = __shfl(mq, j);
+                const double apq = __shfl(mapq, j);
                 if (apq == 0.0) continue;  // uniform
-                const double app = A[p * 12 + p], aqq = A[q * 12 + q];
-                const double theta = (aqq - app) / (2.0 * apq);
-                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
-                __builtin_amdgcn_wave_barrier();
+                const double app = __shfl(mapp, j), aqq = __shfl(maqq, j), t = __shfl(mt, j), c = __shfl(mc, j), sn = __shfl(msn, j);
                 const int k = lane;
                 if (k < 12) {
                     if (k != p && k != q) {
@@ -509,6 +523,7 @@ __device__ static void ep_jacobi12_wave(double* A, double* V, int lane)
                 }
                 __builtin_amdgcn_wave_barrier();
             }
+        }
     }
 }
 
@@ -662,8 +677,12 @@ __device__ static void ep_betas_from_null(const double* vv /* [4][12] */, const 
         if (b5[1] < 0.0) betas[2][0] = -betas[2][0];
         betas[2][2] = betas[2][0] != 0.0 ? b5[3] / betas[2][0] : 0.0;
     }
-    for (int cnd = 0; cnd < 3; cnd++) {
-        double* b = betas[cnd];
+    // five Gauss-Newton steps per candidate: the three candidates are independent and run the same code - lane l refines candidate l % 3
+    // (the oracle's loop body on that candidate's numbers), then every lane collects all three from lanes 0, 1, 2
+    {
+        const int cnd = (int)(threadIdx.x & 63) % 3;
+        double b[4];
+        for (int k = 0; k < 4; k++) b[k] = cnd == 0 ? betas[0][k] : (cnd == 1 ? betas[1][k] : betas[2][k]);
         for (int it = 0; it < 5; it++) {
             double J[24], r[6], dx[4];
             for (int j = 0; j < 6; j++) {
@@ -678,6 +697,8 @@ __device__ static void ep_betas_from_null(const double* vv /* [4][12] */, const 
             if (!ep_lsq(6, 4, J, r, dx)) break;
             for (int k = 0; k < 4; k++) b[k] += dx[k];
         }
+        for (int c3 = 0; c3 < 3; c3++)
+            for (int k = 0; k < 4; k++) betas[c3][k] = __shfl(b[k], c3);
     }
 }
 
@@ -748,11 +769,15 @@ __device__ static int epnp_solve_minimal(int cnt, const int* idx, const float* i
     ep_betas_from_null(A, f, betas);
     double a1[4];
     ep_alphas(f, mp + 3 * idx[0], a1);
-    int bestc = -1;
-    double beste = PNP_HUGE;
-    for (int cnd = 0; cnd < 3; cnd++) {
+    // the three candidates are independent and run the same code: lane l evaluates candidate l % 3 (the oracle's loop body on that
+    // candidate's numbers), then the oracle's strict "<" comparison runs over lanes 0, 1, 2 in order and the winner's pose is fetched
+    double err, Rc[9], tc[3];
+    {
+        const int cnd = lane % 3;
+        double bsel[4];
+        for (int k = 0; k < 4; k++) bsel[k] = cnd == 0 ? betas[0][k] : (cnd == 1 ? betas[1][k] : betas[2][k]);
         double ccs[4][3];
-        ep_ccs(A, betas[cnd], ccs);
+        ep_ccs(A, bsel, ccs);
         const double z1 = a1[0] * ccs[0][2] + a1[1] * ccs[1][2] + a1[2] * ccs[2][2] + a1[3] * ccs[3][2];
         if (z1 < 0.0)
             for (int j = 0; j < 4; j++)
@@ -768,24 +793,27 @@ __device__ static int epnp_solve_minimal(int cnt, const int* idx, const float* i
                 for (int c = 0; c < 3; c++) swc[r * 3 + c] += (double)mp[3 * i + r] * pc[c];
         }
         const double inv = 1.0 / (double)cnt;
-        double S[9], Rc[9], tc[3], cbar[3];
+        double S[9], cbar[3];
         for (int c = 0; c < 3; c++) cbar[c] = sc[c] * inv;
         for (int r = 0; r < 3; r++)
             for (int c = 0; c < 3; c++) S[r * 3 + c] = swc[r * 3 + c] - sp[r] * cbar[c];
         ep_horn(S, Rc);
         for (int r = 0; r < 3; r++) tc[r] = cbar[r] - (Rc[r * 3] * f.c0[0] + Rc[r * 3 + 1] * f.c0[1] + Rc[r * 3 + 2] * f.c0[2]);
-        double err = 0.0;
+        err = 0.0;
         for (int q = 0; q < cnt; q++) {
             const double e2 = reproj_err2(Rc, tc, K4, mp + 3 * idx[q], ip + 2 * idx[q]);
             err += e2 < PNP_HUGE ? sqrt(e2) : 1e12;
         }
-        if (err < beste) {
-            beste = err;
-            bestc = cnd;
-            for (int i = 0; i < 9; i++) R[i] = Rc[i];
-            for (int i = 0; i < 3; i++) t[i] = tc[i];
-        }
     }
+    int bestc = -1;
+    double beste = PNP_HUGE;
+    for (int c3 = 0; c3 < 3; c3++) {
+        const double e = __shfl(err, c3);
+        if (e < beste) { beste = e; bestc = c3; }
+    }
+    const int src = bestc < 0 ? 0 : bestc;
+    for (int i = 0; i < 9; i++) R[i] = __shfl(Rc[i], src);
+    for (int i = 0; i < 3; i++) t[i] = __shfl(tc[i], src);
     return bestc >= 0 && beste < PNP_HUGE;
 }
 
