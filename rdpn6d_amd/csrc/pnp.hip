@@ -423,8 +423,9 @@ __device__ static int solve6(double H[6][6], double g[6])
 // The executable specification is oracle/pnp_oracle.c (ep_* functions, restated from the EPnP paper); every function here is that
 // code operation by operation.  One hypothesis per wavefront as before: the small linear algebra (3x3 / 4x4 Jacobi, 6x{3,4,5} least
 // squares, Gauss-Newton on the betas, Horn) runs redundantly on all 64 lanes (uniform data); the 12x12 part does not fit registers
-// and goes through a per-wavefront LDS scratch: M^T M one entry per lane, the cyclic Jacobi with row / column k of a rotation on
-// lane k (k < 12) - the oracle's per-k expressions, so eigenvalues and eigenvectors come out bit for bit.
+// and goes through a per-wavefront LDS scratch: M^T M one entry per lane, the round-robin Jacobi with the six rotation parameters of
+// a step on six lanes and row / column k of a rotation on lane k (k < 12) - the oracle's per-k expressions, so eigenvalues and
+// eigenvectors come out bit for bit; the three beta candidates (refinement, Horn, reprojection error) run one per lane.
 #define EP_SWEEPS 30
 
 template <int N>
