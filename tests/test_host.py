@@ -367,3 +367,53 @@ def test_fps_python_face_returns_what_the_reference_returns(oracle_lib, monkeypa
     assert np.array_equal(fps_pts, p32[want])
     both = ops.farthest_point_sampling(pts, num_fps, init_center=True, return_index=True)
     assert isinstance(both, tuple) and np.array_equal(both[1], want) and np.array_equal(both[0], fps_pts)
+
+
+def test_h2_overflow_lowers_only_the_flagged_tensors(monkeypatch):
+    """GDRN._lower_h2_exponents (round 6): the range-flag array has one slot per launch; the slots that were raised name exponent
+    variables through the plan's table - those go down two binades, nothing else moves; a raised slot WITHOUT a variable (glue row,
+    depth-xyz), a plan that is not the all-h2 one, or a variable at the floor make it decline (the caller then leaves h2 as before).
+    Host logic only: the flag tensors are stood in for by CPU tensors and a recorded event."""
+    from types import SimpleNamespace
+
+    import torch
+
+    from rdpn6d_amd.config import gdrn_base_cfg
+    from rdpn6d_amd.gdrn import build_model_optimizer
+
+    model, _ = build_model_optimizer(gdrn_base_cfg(device="cpu"))
+    dev = torch.device("cpu")
+    key = model._dev_key(dev)
+    ev = SimpleNamespace(synchronize=lambda: None, query=lambda: True)
+
+    def arm(slots):
+        host = torch.zeros(model.NFLAG, dtype=torch.int32)
+        host[list(slots)] = 1
+        model._h2_flags[key] = [torch.zeros(model.NFLAG, dtype=torch.int32), host, ev]
+
+    plan = SimpleNamespace(_slots=["stem", "layer2", None, "rot_head.convT", "layer2"], h2_pointwise=True)
+    arm([1, 4])  # two launches of one residual chain
+    assert model._lower_h2_exponents(plan, dev) and model.h2_exponents(dev) == {"layer2": 2}
+    assert int(model._h2_flags[key][1].abs().sum()) == 0 and model._h2_flags[key][2] is None  # flags cleared for the re-run
+    arm([1, 3])
+    assert model._lower_h2_exponents(plan, dev) and model.h2_exponents(dev) == {"layer2": 0, "rot_head.convT": 2}
+    arm([2])  # a launch without a variable
+    before = dict(model.h2_exponents(dev))
+    assert not model._lower_h2_exponents(plan, dev) and model.h2_exponents(dev) == before
+    arm([0, 2])  # ... even next to one with a variable: nothing is lowered
+    assert not model._lower_h2_exponents(plan, dev) and model.h2_exponents(dev) == before
+    arm([400])  # past the plan's slots (the shared last slot)
+    assert not model._lower_h2_exponents(plan, dev)
+    arm([0])
+    assert not model._lower_h2_exponents(SimpleNamespace(_slots=plan._slots, h2_pointwise=False), dev)
+    model.h2_exponents(dev)["stem"] = -12  # at the floor
+    assert not model._lower_h2_exponents(plan, dev) and model.h2_exponents(dev)["stem"] == -12
+    arm([])  # nothing raised
+    assert not model._lower_h2_exponents(plan, dev)
+    # load_state_dict forgets a calibration made for other weights; a deep copy keeps it
+    import copy
+
+    twin = copy.deepcopy(model)
+    assert twin.h2_exponents(dev) == model.h2_exponents(dev) and twin.h2_exponents(dev) is not model.h2_exponents(dev)
+    model.load_state_dict(model.state_dict())
+    assert model.h2_exponents(dev) == {}
