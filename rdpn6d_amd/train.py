@@ -118,6 +118,10 @@ class TrainEngine:
         # (profiles/r5_experiments.md) - the step's kernels already run back to back (sum of kernel durations = step time), two streams
         # only make the big kernels share the chip.  Kept as a switch; RDPN6D_WGRAD_SIDE=1 forces it on for profiling runs.
         self.wgrad_side = (bool(model.cfg.get("SOLVER", {}).get("WGRAD_SIDE_STREAM", False)) or os.environ.get("RDPN6D_WGRAD_SIDE", "0") == "1")
+        # cfg.SOLVER.AMP.PNP_NET (default False; RDPN6D_PNP_LOWP=1 for A/B runs): ConvPnPNet's convolutions on the 16-bit pipe too, as torch
+        # autocast runs them in the reference's AMP step (engine.py:279-309) - see conv_unit
+        self.pnp_lowp = bool(self.amp) and (bool(model.cfg.get("SOLVER", {}).get("AMP", {}).get("PNP_NET", False))
+                                            or os.environ.get("RDPN6D_PNP_LOWP", "0") == "1")
         self._side, self._side_join, self._side_dirty, self._wg_partial_side = None, None, False, None
         self._bwd_writes, self._side_reads = {}, []  # (build-time bookkeeping of _check_side_operands)
         self._build()
@@ -386,7 +390,10 @@ class TrainEngine:
         cout, _, k, _ = w.shape
         pad = k // 2
         self._note_bwd_write(dx)
-        lowp = self.amp and not name.startswith("pnp_net")  # ConvPnPNet stays fp32 (pose regression)
+        # ConvPnPNet stays fp32 under AMP (pose regression) unless cfg.SOLVER.AMP.PNP_NET says otherwise (round 6): its three stride-2
+        # convolutions then run like the reference's autocast runs them - 16-bit operands (one compact copy of the fp32 input / output
+        # gradient each), fp32 accumulation and fp32 outputs; GroupNorm, the FC stack and the pose decode stay fp32
+        lowp = self.amp and (self.pnp_lowp or not name.startswith("pnp_net"))
         x3_fwd, xp3, g3 = False, None, None  # bf16x3 forward taken; planes of x / of the output gradient
         cin_pad = _pad_to(cin_real, 32 if lowp else 16)
         npad = _pad_to(cout, 64)

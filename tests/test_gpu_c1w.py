@@ -391,6 +391,8 @@ def test_amp_step_every_layer_gradient_recomputed_from_the_stored_operands(c1w, 
                 DY = _nchw(r["dy"], r["out_co"], r["cout"])
                 if r["lowp"] and r["dy"].dtype == torch.float32:  # (the head output's fp32 gradient: wgrad / dgrad read a compact 16-bit copy)
                     DY = DY.to(dt).double()
+                if r["lowp"] and r["x"].dtype == torch.float32:   # (cfg.SOLVER.AMP.PNP_NET: ConvPnPNet's fp32 inputs are read through a 16-bit copy too)
+                    X = X.to(dt).double()
                 fwd = lambda X, w, r=r: F.conv2d(X, w, None, r["stride"], r["k"] // 2)  # noqa: E731
             wl = w.to(fdt).requires_grad_(True)
             gw, = torch.autograd.grad(fwd(X.to(fdt), wl), wl, DY.to(fdt))
