@@ -118,10 +118,16 @@ class TrainEngine:
         # (profiles/r5_experiments.md) - the step's kernels already run back to back (sum of kernel durations = step time), two streams
         # only make the big kernels share the chip.  Kept as a switch; RDPN6D_WGRAD_SIDE=1 forces it on for profiling runs.
         self.wgrad_side = (bool(model.cfg.get("SOLVER", {}).get("WGRAD_SIDE_STREAM", False)) or os.environ.get("RDPN6D_WGRAD_SIDE", "0") == "1")
-        # cfg.SOLVER.AMP.PNP_NET (default False; RDPN6D_PNP_LOWP=1 for A/B runs): ConvPnPNet's convolutions on the 16-bit pipe too, as torch
-        # autocast runs them in the reference's AMP step (engine.py:279-309) - see conv_unit
-        self.pnp_lowp = bool(self.amp) and (bool(model.cfg.get("SOLVER", {}).get("AMP", {}).get("PNP_NET", False))
-                                            or os.environ.get("RDPN6D_PNP_LOWP", "0") == "1")
+        # cfg.SOLVER.AMP.PNP_NET: ConvPnPNet's three convolutions on the 16-bit pipe too, as torch autocast runs them in the reference's AMP
+        # step (engine.py:279-309) - see conv_unit.  Default: ON with DTYPE "fp16" (the reference's AMP dtype: the pose branch then sees
+        # what it sees there), OFF with "bf16": ConvPnPNet reads the caller's depth-xyz and 2D coordinates directly, and an 8-bit
+        # significand puts metres on a 4 - 8 mm grid (fp16: 1 mm).  Measured (B = 32, one MI355X): -0.18 ms per step (9.38 -> 9.20 ms bf16).
+        # RDPN6D_PNP_LOWP=0|1 overrides for A/B runs.
+        pn = model.cfg.get("SOLVER", {}).get("AMP", {}).get("PNP_NET", None)
+        pn = (self.lp == "fp16") if pn is None else bool(pn)
+        if os.environ.get("RDPN6D_PNP_LOWP") in ("0", "1"):
+            pn = os.environ["RDPN6D_PNP_LOWP"] == "1"
+        self.pnp_lowp = bool(self.amp) and pn
         self._side, self._side_join, self._side_dirty, self._wg_partial_side = None, None, False, None
         self._bwd_writes, self._side_reads = {}, []  # (build-time bookkeeping of _check_side_operands)
         self._build()
