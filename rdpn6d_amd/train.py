@@ -119,15 +119,17 @@ class TrainEngine:
         # only make the big kernels share the chip.  Kept as a switch; RDPN6D_WGRAD_SIDE=1 forces it on for profiling runs.
         self.wgrad_side = (bool(model.cfg.get("SOLVER", {}).get("WGRAD_SIDE_STREAM", False)) or os.environ.get("RDPN6D_WGRAD_SIDE", "0") == "1")
         # cfg.SOLVER.AMP.PNP_NET: ConvPnPNet's three convolutions on the 16-bit pipe too, as torch autocast runs them in the reference's AMP
-        # step (engine.py:279-309) - see conv_unit.  Default: ON with DTYPE "fp16" (the reference's AMP dtype: the pose branch then sees
-        # what it sees there), OFF with "bf16": ConvPnPNet reads the caller's depth-xyz and 2D coordinates directly, and an 8-bit
-        # significand puts metres on a 4 - 8 mm grid (fp16: 1 mm).  Measured (B = 32, one MI355X): -0.18 ms per step (9.38 -> 9.20 ms bf16).
-        # RDPN6D_PNP_LOWP=0|1 overrides for A/B runs.
+        # step (engine.py:279-309) - see conv_unit.  "all" | "inner" (the second and third only) | "none"; True / False = all / none.
+        # Default: "all" with DTYPE "fp16" (the reference's AMP dtype: the pose branch then sees what it sees there), "inner" with "bf16":
+        # the FIRST convolution reads the caller's depth-xyz and 2D coordinates directly, and an 8-bit significand puts metres on a
+        # 4 - 8 mm grid (fp16: 1 mm) - it stays fp32; the other two read GroupNorm outputs like any 16-bit layer of the trunk.
+        # Measured (B = 32, one MI355X): all three -0.18 ms per step bf16 (9.38 -> 9.20), -0.23 ms fp16.  RDPN6D_PNP_LOWP=0|1|inner: A/B runs.
         pn = model.cfg.get("SOLVER", {}).get("AMP", {}).get("PNP_NET", None)
-        pn = (self.lp == "fp16") if pn is None else bool(pn)
-        if os.environ.get("RDPN6D_PNP_LOWP") in ("0", "1"):
-            pn = os.environ["RDPN6D_PNP_LOWP"] == "1"
-        self.pnp_lowp = bool(self.amp) and pn
+        pn = ("all" if self.lp == "fp16" else "inner") if pn is None else ({True: "all", False: "none"}.get(pn, str(pn).lower()))
+        pn = {"0": "none", "1": "all", "inner": "inner"}.get(os.environ.get("RDPN6D_PNP_LOWP", ""), pn)
+        if pn not in ("all", "inner", "none"):
+            raise ValueError(f"SOLVER.AMP.PNP_NET={pn!r}: all | inner | none")
+        self.pnp_lowp = pn if self.amp else "none"
         self._side, self._side_join, self._side_dirty, self._wg_partial_side = None, None, False, None
         self._bwd_writes, self._side_reads = {}, []  # (build-time bookkeeping of _check_side_operands)
         self._build()
@@ -399,7 +401,7 @@ class TrainEngine:
         # ConvPnPNet stays fp32 under AMP (pose regression) unless cfg.SOLVER.AMP.PNP_NET says otherwise (round 6): its three stride-2
         # convolutions then run like the reference's autocast runs them - 16-bit operands (one compact copy of the fp32 input / output
         # gradient each), fp32 accumulation and fp32 outputs; GroupNorm, the FC stack and the pose decode stay fp32
-        lowp = self.amp and (self.pnp_lowp or not name.startswith("pnp_net"))
+        lowp = self.amp and (not name.startswith("pnp_net") or self.pnp_lowp == "all" or (self.pnp_lowp == "inner" and not name.endswith(".0")))
         x3_fwd, xp3, g3 = False, None, None  # bf16x3 forward taken; planes of x / of the output gradient
         cin_pad = _pad_to(cin_real, 32 if lowp else 16)
         npad = _pad_to(cout, 64)
