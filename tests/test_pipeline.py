@@ -187,3 +187,37 @@ def test_bench_secondary_lines(extra, check):
     assert out["value"] > 0 and check in out["config"]["workload"]
     if "--train" not in extra:
         assert "flops_note" in out and "does not execute" not in out["flops_note"]  # the rewrites were switched off
+
+
+def test_bench_default_line_carries_the_training_leg():
+    """the driver's ONE command (`python bench.py`, batch 64, fp32-accurate inference) also records the training
+    step: after the headline's timed region a short bf16 AMP B = 32 leg runs and lands under "train" - never in `value`.  (Short
+    windows here; the contract keys are what is checked: the headline's metric / roofline / the train leg's step time, FLOP
+    accounting, dominant kernel and the per-bucket issue times in the backward's completion order.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--preheat", "0.3", "--train-leg", "0.3",
+                        "--no-cpu-baseline"], cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1  # ONE JSON line
+    out = json.loads(lines[0])
+    assert out["metric"].startswith("RGB-D crops/sec (fwd+PnP)") and out["n_gpus"] == 1 and out["config"]["batch_per_gpu"] == 64
+    assert out["roofline"]["kernel"].startswith("conv_h2_8ph_kernel_t") and 1.0 < out["roofline"]["clock_ghz"] < 2.6
+    t = out["train"]
+    assert t["batch_per_gpu"] == 32 and t["steps"] == 60 and t["ms_per_step"] > 0 and t["dtype"].startswith("bf16")
+    assert abs(t["crops_per_s"] - 32 * 1e3 / t["ms_per_step"]) < 0.01 * t["crops_per_s"]
+    assert abs(t["tflops"] - 132.3e-3 * t["crops_per_s"]) < 0.5 and abs(t["frac_of_2500"] - t["tflops"] / 2500.0) < 1e-3
+    assert t["dominant_kernel"]["kernel"].startswith("conv_igemm_bf16_8ph_kernel")
+    names = [b["name"] for b in t["gradient_sync"]["buckets"]]
+    assert names == ["pnp_net", "rot_head_net", "backbone.layer4", "backbone.layer3", "backbone.rest"]
+    ahead = [b["issued_ms_before_backward_end"] for b in t["gradient_sync"]["buckets"]]
+    assert all(x >= y for x, y in zip(ahead, ahead[1:])) and ahead[2] > 0.5 and ahead[-1] < 0.1  # layer4 well before the end, the tail at it
+    # --train-leg 0 switches it off
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--preheat", "0", "--train-leg", "0",
+                        "--no-cpu-baseline"], cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "train" not in json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
