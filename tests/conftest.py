@@ -11,6 +11,18 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The torch-CPU oracles (test infrastructure) are what the GPU suite waits for.  A GPU box has 256 logical CPUs and torch then
+    # starts as many intra-op threads: on the oracles' small convolutions that is SLOWER than a few dozen (bench.py's cpu_baseline
+    # sweep finds its best rate at 16 - 32 threads on every box of the pool).  RDPN6D_TEST_THREADS overrides; boxes with fewer cores keep
+    # their own default.
+    try:
+        import torch
+
+        want = int(os.environ.get("RDPN6D_TEST_THREADS", "32"))
+        if want > 0 and torch.get_num_threads() > want:
+            torch.set_num_threads(want)
+    except Exception:  # noqa: BLE001  (a box without torch still collects the pure-C oracle tests)
+        pass
 
 
 @pytest.fixture(scope="session")
