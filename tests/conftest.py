@@ -11,18 +11,25 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    # The torch-CPU oracles (test infrastructure) are what the GPU suite waits for.  A GPU box has 256 logical CPUs and torch then
-    # starts as many intra-op threads: on the oracles' small convolutions that is SLOWER than a few dozen (bench.py's cpu_baseline
-    # sweep finds its best rate at 16 - 32 threads on every box of the pool).  RDPN6D_TEST_THREADS overrides; boxes with fewer cores keep
-    # their own default.
-    try:
-        import torch
 
-        want = int(os.environ.get("RDPN6D_TEST_THREADS", "32"))
-        if want > 0 and torch.get_num_threads() > want:
-            torch.set_num_threads(want)
-    except Exception:  # noqa: BLE001  (a box without torch still collects the pure-C oracle tests)
-        pass
+
+@pytest.fixture
+def few_threads():
+    """The torch-CPU oracles are what the GPU suite waits for.  A GPU box has 128 - 256 CPUs and torch starts as many intra-op threads:
+    on the oracles' small convolutions that is 2 - 2.5x SLOWER than 32 (bench.py's cpu_baseline sweep finds its best rate at 16 - 32 on
+    every box; the whole suite: 232 s with 32 threads against 422 - 535 s).  Not applied globally: fp32 summation order in the CPU
+    convolutions follows the thread count, and the tests that compare against an UN-forced fp32 oracle run (ReLU decisions of its
+    own) or sit within 10 % of a stated bound were established at the boxes' default - two of them move past their bounds at 32
+    (`profiles/r6_notes.md`).  Used by the heavy tests whose assertions are float64-yardstick-relative and do not care."""
+    import torch
+
+    before = torch.get_num_threads()
+    if before > 32:
+        torch.set_num_threads(32)
+    try:
+        yield
+    finally:
+        torch.set_num_threads(before)
 
 
 @pytest.fixture(scope="session")

@@ -248,7 +248,7 @@ def test_c1w_gradients_vs_reference_golden_within_the_references_own_reproducibi
 
 
 @pytest.mark.parametrize("B,lp", [(4, "bf16"), (4, "fp16")])
-def test_amp_step_end_to_end_vs_the_16bit_operand_oracle_lands_on_the_formats_reproducibility(c1w, B, lp):
+def test_amp_step_end_to_end_vs_the_16bit_operand_oracle_lands_on_the_formats_reproducibility(c1w, few_threads, B, lp):
     """END-TO-END yardstick of the mixed-precision step (the sharp test is the LOCAL one below).  The reference-pinned oracle is
     evaluated on 16-BIT-ROUNDED OPERANDS with fp32 accumulation (oracle.lowp_storage: a rounding - value and gradient - at every point
     where rdpn6d_amd/train.py stores 16 bits), takes its 48 ReLU / LeakyReLU decisions and its region arg-max from the HIP forward
@@ -324,7 +324,7 @@ def _nchw(t, co, c):
 
 
 @pytest.mark.parametrize("B,lp", [(4, "bf16"), (4, "fp16"), (32, "bf16")])
-def test_amp_step_every_layer_gradient_recomputed_from_the_stored_operands(c1w, B, lp):
+def test_amp_step_every_layer_gradient_recomputed_from_the_stored_operands(c1w, few_threads, B, lp):
     """THE sharp parity test of the mixed-precision training step, LOCAL instead of end-to-end.
 
     Why local: 16-bit rounding is a discontinuity at every stored element, so two correct implementations of the SAME 16-bit

@@ -64,7 +64,7 @@ def test_conv_fp16_layer_vs_fp32_kernel_on_fp16_operands(case):
     assert err <= 2.0 ** -10 * scale  # one fp16 rounding of the output (2^-11 relative) + summation order
 
 
-def test_fp16_inference_mode_vs_autocast_fp16_yardstick(golden_dir):
+def test_fp16_inference_mode_vs_autocast_fp16_yardstick(golden_dir, few_threads):
     """cfg.TEST.AMP_TEST with cfg.TEST.AMP_DTYPE = "fp16": the HIP fp16 maps are at least as close to the exact answer as the
     torch-CPU oracle under torch.autocast(float16) - what the reference's own AMP_TEST path computes - and, with 11 instead of
     8 significand bits, several times closer than the bf16 mode.
@@ -210,7 +210,7 @@ def test_fp16_training_through_the_reference_loop_with_gradscaler():
     assert not any(skipped2) and set(scales2) == {8192.0} and min(hist2[-3:]) < hist2[0]
 
 
-def test_fp16_step_vs_autocast_fp16_yardstick_and_c5_resnet50_320():
+def test_fp16_step_vs_autocast_fp16_yardstick_and_c5_resnet50_320(few_threads):
     """(a) one fp16 training step against fp64 with the torch.autocast(float16) oracle as yardstick (static loss scale 4096 on both
     sides' terms: the HIP engine's `loss_scale`); (b) BASELINE configuration C5's shape - ResNet-50 trunk, 320x320 crops - at
     B = 16 in fp16: finite losses / gradients and a Ranger step that lowers the loss."""

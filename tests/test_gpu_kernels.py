@@ -511,7 +511,7 @@ def test_pose_teacher_forced_on_reference_maps(golden_setup, dev, att):
 
 
 @pytest.mark.parametrize("K,R,cam", [(64, 256, "lm"), (32, 320, "ycbv"), (8, 128, "lm")])
-def test_generalised_geometry_vs_oracle(dev, K, R, cam):
+def test_generalised_geometry_vs_oracle(dev, few_threads, K, R, cam):
     """NUM_REGIONS != 32 and INPUT_RES != 256 (10 LM-O configs use K=64; C5 uses 320x320): the reference hard-codes nIn=43 and
     the 64x64 / 8x8 geometry and cannot build these; the HIP path is checked against the (generalised) torch-CPU oracle with the
     same fp64 yardstick as C1."""
@@ -799,7 +799,7 @@ def test_model_pnp_type_net_variants(golden_setup, dev, oracle_lib, pnp_type):
 
 
 @pytest.mark.parametrize("layers,R,B", [(50, 256, 2), (50, 320, 2), (18, 256, 2), (18, 256, 16), (50, 256, 16)])
-def test_other_resnet_trunks_vs_oracle(dev, layers, R, B):
+def test_other_resnet_trunks_vs_oracle(dev, few_threads, layers, R, B):
     """resnet_backbone.py:15-21 offers 18 / 34 (BasicBlock) and 50 / 101 / 152 (Bottleneck).  The reference cannot RUN the
     Bottleneck trunks (md_pointnet(512, ...) is hard-coded while layer4 then has 2048 channels) - BASELINE config 5 asks for
     ResNet-50 at 320x320 - so parity is against the generalised torch-CPU oracle, with the usual fp64 yardstick.

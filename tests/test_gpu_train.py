@@ -191,7 +191,7 @@ def test_reference_api_do_loss_backward_and_optimizer_step(train_setup):
     assert max(hist[1:4]) < hist[0] and min(hist) < hist[0] - 1.0 and all(h == h for h in hist)
 
 
-def test_amp_training_step_vs_autocast_yardstick(golden_dir):
+def test_amp_training_step_vs_autocast_yardstick(golden_dir, few_threads):
     """cfg.SOLVER.AMP.ENABLED (the reference's autocast switch, engine.py:279-309): bf16 forward / input-gradient convolutions,
     fp32 everything else.  Yardstick as for the bf16 inference mode: the torch-CPU oracle under torch.autocast(bfloat16), both
     measured against the fp64 evaluation, on the network with damped residual branches (the undamped random-weight network
@@ -837,7 +837,7 @@ def test_maxpool_backward_first_max_rule_and_stem_im2col():
 
 
 @pytest.mark.parametrize("amp", [False, True])
-def test_resnet50_training_step(amp):
+def test_resnet50_training_step(few_threads, amp):
     """Bottleneck trunk (BASELINE config 5: ResNet-50, 320x320, reduced precision): the whole training step against the
     generalised oracle's autograd, fp64 graph as the yardstick (fp32), plus a loss-goes-down run in mixed precision."""
     from oracle import model_oracle
@@ -912,7 +912,7 @@ def test_resnet50_training_step(amp):
 
 
 @pytest.mark.parametrize("K,R,amp", [(64, 128, False), (64, 128, True), (8, 256, False)])
-def test_training_step_generalised_geometry(K, R, amp):
+def test_training_step_generalised_geometry(few_threads, K, R, amp):
     """NUM_REGIONS = 64 (ten LM-O configs; the reference's nIn = 43 cannot build it) and 128x128 crops through the whole
     training step, against the generalised oracle's autograd (fp64 yardstick); under AMP only finiteness + loss agreement."""
     from oracle import model_oracle
