@@ -19,8 +19,8 @@ def few_threads():
     on the oracles' small convolutions that is 2 - 2.5x SLOWER than 32 (bench.py's cpu_baseline sweep finds its best rate at 16 - 32 on
     every box; the whole suite: 232 s with 32 threads against 422 - 535 s).  Not applied globally: fp32 summation order in the CPU
     convolutions follows the thread count, and the tests that compare against an UN-forced fp32 oracle run (ReLU decisions of its
-    own) or sit within 10 % of a stated bound were established at the boxes' default - two of them move past their bounds at 32
-    (`profiles/r6_notes.md`).  Used by the heavy tests whose assertions are float64-yardstick-relative and do not care."""
+    own: which side of a near-zero unit it lands on) or sit within 10 % of a stated bound were established at the boxes' default -
+    two of them move past their bounds at 32 (`profiles/r6_notes.md`).  Used by the heavy tests whose assertions are float64-yardstick-relative and do not care."""
     import torch
 
     before = torch.get_num_threads()
