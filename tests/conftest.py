@@ -13,6 +13,26 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+class capped_threads:
+    """context manager form of the `few_threads` fixture below: at most `n` torch intra-op threads inside (float64 oracle evaluations
+    inside module fixtures: their results do not depend on the thread count at any tolerance the suite states)"""
+
+    def __init__(self, n=32):
+        self.n = n
+
+    def __enter__(self):
+        import torch
+
+        self.before = torch.get_num_threads()
+        if self.before > self.n:
+            torch.set_num_threads(self.n)
+
+    def __exit__(self, *a):
+        import torch
+
+        torch.set_num_threads(self.before)
+
+
 @pytest.fixture
 def few_threads():
     """The torch-CPU oracles are what the GPU suite waits for.  A GPU box has 128 - 256 CPUs and torch starts as many intra-op threads:

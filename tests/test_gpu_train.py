@@ -44,13 +44,16 @@ def train_setup(golden_dir):
         L = model_oracle.gdrn_losses(o, t, t["roi_extent"])
         sum(L.values()).backward()
         # fp64 evaluation of the same graph = the exact gradients (the yardstick for fp32 round-off)
+        from tests.conftest import capped_threads
+
         o64 = model_oracle.GDRNOracle(32, att)
         o64.load_state_dict(sd, strict=True)
         o64.double().train()
         t64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in t.items()}
-        oo = o64(t64["roi_img"], t64["roi_coord_2d"], t64["fps"], t64["roi_cam"], t64["roi_center"], t64["roi_wh"], t64["resize_ratio"],
-                 train_pose=True)
-        sum(model_oracle.gdrn_losses(oo, t64, t64["roi_extent"]).values()).backward()
+        with capped_threads():  # (float64: the thread count changes nothing the tests can see, and 32 threads are 2x faster than 128)
+            oo = o64(t64["roi_img"], t64["roi_coord_2d"], t64["fps"], t64["roi_cam"], t64["roi_center"], t64["roi_wh"], t64["resize_ratio"],
+                     train_pose=True)
+            sum(model_oracle.gdrn_losses(oo, t64, t64["roi_extent"]).values()).backward()
         out[att] = (model, eng, losses, orc, L, o64)
     return out, gold
 
